@@ -1,0 +1,268 @@
+#!/usr/bin/env python
+"""bench.py - PDE samples/s of one DPOT auto-regressive training step (128^2 x 10 -> 1), DPOT-Tiny, on N MI355X.
+
+    python bench.py --gpus 1 --steps 20 --warmup 5
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+           bench.py --gpus N --steps K --warmup W
+
+A step = forward + masked relative-L2 loss + backward (+ RCCL gradient all-reduce) + global-norm clip + fused Adam,
+T_ar = 1, on BASELINE.json configs[1]: DPOT-Tiny (embed 512, depth 4, 4 blocks, modes 32, patch 8), per-GPU batch 32,
+fp32, synthetic N(0,1) fields already resident in HBM.  Weak scaling: every rank processes its own batch of 32.
+Rank 0 prints ONE JSON line (metric/value/unit + `roofline` for the AFNO mixer kernel + `cpu_baseline`).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import torch
+import torch.distributed as dist
+
+TINY = dict(img_size=128, patch_size=8, in_channels=4, out_channels=4, in_timesteps=10, out_timesteps=1, n_blocks=4,
+            embed_dim=512, out_layer_dim=32, depth=4, modes=32, mlp_ratio=1, n_cls=12)
+FP32_MFMA_PEAK_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
+HBM_PEAK_GBS = 8000.0              # MI355X_MICROARCH.md: HBM3E spec
+
+
+def log(*a):
+    print(*a, file=sys.stderr, flush=True)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=32, help="per-GPU batch (BASELINE configs[1]: 32)")
+    ap.add_argument("--no-graph", action="store_true", help="eager launches instead of hipGraph replay")
+    ap.add_argument("--overlap", action="store_true",
+                    help="N>1: eager step with bucketed all-reduce overlapped with backward (default: graph replay of "
+                         "fwd+bwd, then bucketed all-reduce, then fused Adam)")
+    ap.add_argument("--noise-scale", type=float, default=0.0)
+    ap.add_argument("--skip-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=15.0)
+    return ap.parse_args()
+
+
+# ------------------------------------------------------------------------------------------------------
+def mixer_roofline(model, B: int):
+    """Time the AFNO mixer kernel (one MLP layer of the block-diagonal complex MLP = one launch of the tagged MFMA
+    GEMM instantiation) with HIP events on the launch stream, on the real layer-0 weights and a real-sized spectrum."""
+    from dpot_amd import ops
+    E, nb, h = model.embed_dim, model.n_blocks, model.latent_size[0]
+    bs = E // nb
+    mx, my = min(model.modes, h), min(model.modes, h // 2 + 1)
+    Mm = B * mx * my
+    f = model.blocks[0].filter
+    with torch.no_grad():
+        S = torch.randn(Mm, 2 * E, device="cuda")
+        wb1, bb1 = ops.afno_pack(f.w1.detach(), f.b1.detach())
+        wb1.normal_(0, 0.05)                                   # random data, not the near-zero init (DVFS-honest)
+        O1, O1pre = torch.empty_like(S), torch.empty_like(S)
+        kw = dict(lda=2 * E, ldb=2 * bs, ldc=2 * E, batch=nb, strideA=2 * bs, strideB=4 * bs * bs, strideC=2 * bs,
+                  strideBias=2 * bs, bias=bb1, act=1, mode=ops.EPI_ACT, preact=O1pre, ldpre=2 * E, stridePre=2 * bs,
+                  tag=1)
+        for _ in range(5):
+            ops.gemm(S, wb1, O1, Mm, 2 * bs, 2 * bs, **kw)
+        reps = 50
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            ops.gemm(S, wb1, O1, Mm, 2 * bs, 2 * bs, **kw)
+        e1.record()
+        e1.synchronize()
+        t = e0.elapsed_time(e1) * 1e-3 / reps
+    flops = 2.0 * Mm * (2 * bs) * (2 * bs) * nb                # = 75.5 MFLOP/sample: half of SURVEY 8(d)'s 151.0 (2 layers)
+    # algorithmic bytes of one layer launch: spectrum in + spectrum out + the block weights once
+    bytes_alg = 2.0 * Mm * 2 * E * 4 + nb * (2 * bs) * (2 * bs) * 4
+    achieved = flops / t / 1e12
+    return {
+        "kernel": "gemm_f32_kernel<128,128,NN,tag=afno> (AFNO mixer, one complex MLP layer, bias+GELU fused)",
+        "bound": "mfma", "achieved": round(achieved, 2), "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+        "frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": None,
+        "us_per_launch": round(t * 1e6, 2), "flops_per_launch": flops, "algorithmic_bytes_per_launch": bytes_alg,
+        "hbm_frac": round(bytes_alg / t / 1e9 / HBM_PEAK_GBS, 4),
+        "note": "FLOP-bound (128 FLOP/B >> 20 FLOP/B ridge): hbm_frac is reported because north_star asks for it",
+    }
+
+
+def cpu_baseline(seconds: float):
+    """the CPU oracle (a port of the reference's PyTorch-CPU path; parity-pinned in tests/) timed on this box's host
+    cores on a bounded sample of the same workload: DPOT-Tiny train steps at B=4 (BASELINE configs[0])."""
+    from oracle import dpot_ref as R
+    cores = os.cpu_count() or 1
+    threads = max(1, min(cores, 64))
+    torch.set_num_threads(threads)
+    cfg = R.DPOTConfig(**R.TINY)
+    g = torch.Generator().manual_seed(1234)
+    B = 4
+    st = R.TrainState(params={k: v.clone() for k, v in R.recipe_state_dict(cfg, salt=1).items()})
+    xx = torch.randn(B, 128, 128, 10, 4, generator=g)
+    yy = torch.randn(B, 128, 128, 1, 4, generator=g)
+    msk = torch.ones(B, 128, 128, 1, 4)
+    R.train_step(st, xx, yy, msk, cfg, lr=1e-3)                # warm-up
+    n, t0 = 0, time.perf_counter()
+    while True:
+        R.train_step(st, xx, yy, msk, cfg, lr=1e-3)
+        n += 1
+        el = time.perf_counter() - t0
+        if el >= seconds or n >= 200:
+            break
+    return {"value": round(B * n / el, 2), "unit": "samples/s", "cores": threads, "kind": "port",
+            "sample": f"DPOT-Tiny train step (fwd+loss+bwd+clip+Adam), B={B}, {n} steps in {el:.1f} s, "
+                      f"torch {torch.__version__} CPU, {threads} threads of {cores} logical cores"}
+
+
+# ------------------------------------------------------------------------------------------------------
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", 0))
+    local_rank = int(os.environ.get("LOCAL_RANK", 0))
+    world = int(os.environ.get("WORLD_SIZE", 1))
+    if args.gpus != world:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run with --nproc-per-node {args.gpus}")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    from dpot_amd import DPOTNet, _lib
+    from dpot_amd.dp import BucketedGradReducer
+    from dpot_amd.train import FlatParams, FusedAdam, GraphedTrainStep, one_cycle_lr, train_step
+    _lib.load()
+
+    torch.manual_seed(0)                                       # identical random-init weights on every rank
+    model = DPOTNet(**TINY).cuda()
+    fp = FlatParams(model)
+    # DDP semantics for N>1: cls_head takes part (zero gradients -> weight decay only), grads averaged over ranks
+    opt = FusedAdam(fp, lr=1e-3, betas=(0.9, 0.9), weight_decay=1e-6, max_norm=10000.0, update_tail=world > 1)
+    reducer = BucketedGradReducer(fp, n_buckets=4, overlap=True) if world > 1 else None
+    if reducer is not None:
+        reducer.broadcast_parameters(0)
+    grad_scale = 1.0 / world
+
+    B = args.batch
+    g = torch.Generator().manual_seed(1234 + rank)
+    xx = torch.randn(B, 128, 128, 10, 4, generator=g).cuda()
+    yy = torch.randn(B, 128, 128, 1, 4, generator=g).cuda()
+    msk = torch.ones(B, 128, 128, 1, 4, device="cuda")
+    total_steps = args.warmup + args.steps + 8
+    lr_at = lambda s: one_cycle_lr(s, max(total_steps, 10), 1e-3, pct_start=0.2)
+
+    mode = "eager"
+    graphed = None
+    if not args.no_graph and not (world > 1 and args.overlap):
+        try:
+            # N>1: the graph holds fwd+bwd only; the all-reduce and the optimiser run after the replay
+            if world > 1:
+                graphed = _GraphedFwdBwd(model, opt, xx, yy, msk, args.noise_scale)
+            else:
+                graphed = GraphedTrainStep(model, opt, xx, yy, msk, noise_scale=args.noise_scale, warmup=2)
+            mode = "hipgraph"
+        except Exception as e:                                 # pragma: no cover - depends on the box
+            log(f"[bench] hipGraph capture failed ({type(e).__name__}: {e}); falling back to eager launches")
+            graphed = None
+
+    step_idx = [0]
+
+    def one_step():
+        lr = lr_at(step_idx[0])
+        step_idx[0] += 1
+        if graphed is None:
+            return train_step(model, opt, xx, yy, msk, noise_scale=args.noise_scale, lr=lr, reducer=reducer,
+                              grad_scale=grad_scale)[0]
+        if world > 1:
+            graphed.replay()
+            reducer.begin_step()
+            reducer.finish()                                   # bucketed RCCL all-reduce (SUM) of the flat gradient
+            opt.step(lr, grad_scale)
+            return graphed.loss
+        return graphed.replay(lr)
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        one_step()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = one_step()
+    fence()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], device="cuda", dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = t.item()
+    final_loss = float(loss.item())
+
+    if rank == 0:
+        ms = elapsed / args.steps * 1e3
+        value = world * B * args.steps / elapsed
+        out = {
+            "metric": "PDE samples/sec (128^2 x10 -> 1 rollout step), DPOT-Tiny train step",
+            "value": round(value, 2), "unit": "samples/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(ms, 4), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "DPOT-Tiny (embed 512, depth 4, n_blocks 4, modes 32, patch 8) on synthetic "
+                                   "ns2d-shaped 128x128x10x4 fields, T_ar=1: fwd + rel-L2 loss + bwd + clip + Adam",
+                       "per_gpu_batch": B, "global_batch": B * world, "parallelism": f"dp{world}",
+                       "launch": mode, "noise_scale": args.noise_scale, "final_loss": round(final_loss, 5)},
+        }
+        # fraction of the fp32 MFMA roof for the whole step: 3 x 3.79 GFLOP per sample
+        out["model_flops_frac"] = round(3 * 3.79e9 * value / world / (FP32_MFMA_PEAK_TFLOPS * 1e12), 4)
+        try:
+            out["roofline"] = mixer_roofline(model, B)
+        except Exception as e:                                 # pragma: no cover
+            log(f"[bench] roofline probe failed: {e}")
+            out["roofline"] = None
+        if world == 1 and not args.skip_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(args.cpu_seconds)
+            out["speedup_vs_cpu_baseline"] = round(value / out["cpu_baseline"]["value"], 1)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+class _GraphedFwdBwd:
+    """hipGraph of zero_grad + rollout + loss + backward for a fixed batch (the N>1 path: collectives stay eager)."""
+
+    def __init__(self, model, opt, xx, yy, msk, noise_scale):
+        from dpot_amd.train import rollout
+        self.opt = opt
+
+        def body():
+            opt.zero_grad()
+            loss, _ = rollout(model, xx, yy, msk, 1, noise_scale)
+            loss.backward()
+            return loss.detach()
+
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(2):
+                body()
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph):
+            self.loss = body()
+
+    def replay(self):
+        self.graph.replay()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,112 @@
+"""ctypes binding of libdpot_hip.so (include/dpot_hip.h).
+
+The product path has NO fallback: if the HIP library is missing or a call fails, an exception is raised.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import threading
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "lib", "libdpot_hip.so")
+
+c_fp = C.c_void_p       # device pointer (float*)
+c_i = C.c_int
+c_i64 = C.c_int64
+c_f = C.c_float
+
+
+class GemmDesc(C.Structure):
+    """mirror of struct dpot_gemm_desc"""
+    _fields_ = [
+        ("A", c_fp), ("B", c_fp), ("C", c_fp),
+        ("M", C.c_int32), ("N", C.c_int32), ("K", C.c_int32),
+        ("batch", C.c_int32),
+        ("transA", C.c_int32), ("transB", C.c_int32),
+        ("lda", C.c_int32), ("ldb", C.c_int32), ("ldc", C.c_int32),
+        ("strideA", c_i64), ("strideB", c_i64), ("strideC", c_i64),
+        ("bias", c_fp), ("strideBias", c_i64),
+        ("act", C.c_int32), ("epi_mode", C.c_int32),
+        ("aux", c_fp), ("ldaux", C.c_int32), ("strideAux", c_i64),
+        ("preact", c_fp), ("ldpre", C.c_int32), ("stridePre", c_i64),
+        ("res", c_fp), ("ldres", C.c_int32), ("res_div", C.c_int32), ("res_mod", C.c_int32),
+        ("strideRes", c_i64),
+        ("accumulate", C.c_int32), ("splitk", C.c_int32),
+        ("workspace", c_fp),
+        ("tile", C.c_int32),
+        ("tag", C.c_int32),
+    ]
+
+
+# name -> (restype, argtypes); every symbol include/dpot_hip.h declares
+SIGNATURES = {
+    "dpot_version": (c_i, []),
+    "dpot_last_error": (C.c_char_p, []),
+    "dpot_gemm_f32": (c_i, [C.POINTER(GemmDesc), c_fp]),
+    "dpot_gemm_workspace_bytes": (c_i64, [C.POINTER(GemmDesc)]),
+    "dpot_gemm_auto_splitk": (c_i, [c_i, c_i, c_i, c_i]),
+    "dpot_rfft2": (c_i, [c_fp, c_fp] + [c_i] * 8 + [c_fp]),
+    "dpot_irfft2": (c_i, [c_fp, c_fp, c_fp] + [c_i] * 8 + [c_fp]),
+    "dpot_afno_pack": (c_i, [c_fp] * 4 + [c_i, c_i, c_fp]),
+    "dpot_afno_unpack_grad": (c_i, [c_fp] * 4 + [c_i, c_i, c_fp]),
+    "dpot_groupnorm_fwd": (c_i, [c_fp] * 6 + [c_i] * 4 + [c_f, c_fp]),
+    "dpot_groupnorm_bwd": (c_i, [c_fp] * 10 + [c_i] * 4 + [c_fp]),
+    "dpot_patchify": (c_i, [c_fp] * 5 + [c_i] * 6 + [c_fp]),
+    "dpot_unpatchify": (c_i, [c_fp] * 2 + [c_i] * 6 + [c_fp]),
+    "dpot_pixel_shuffle": (c_i, [c_fp] * 2 + [c_i] * 6 + [c_fp]),
+    "dpot_copy2d_pad": (c_i, [c_fp, c_i, c_i, c_fp, c_i, c_i, c_fp]),
+    "dpot_transpose2d": (c_i, [c_fp, c_fp, c_i, c_i, c_i, c_fp]),
+    "dpot_colsum_parts": (c_i, [c_i]),
+    "dpot_colsum": (c_i, [c_fp, c_i, c_i, c_i, c_fp, c_fp, c_fp]),
+    "dpot_group_rowsum": (c_i, [c_fp, c_fp] + [c_i] * 4 + [c_fp]),
+    "dpot_token_mean": (c_i, [c_fp, c_fp] + [c_i] * 3 + [c_fp]),
+    "dpot_token_mean_bwd": (c_i, [c_fp] * 3 + [c_i] * 3 + [c_fp]),
+    "dpot_add": (c_i, [c_fp] * 3 + [c_i64, c_fp]),
+    "dpot_scale_shift": (c_i, [c_fp] * 4 + [c_i] * 3 + [c_fp]),
+    "dpot_timeagg_scale_w": (c_i, [c_fp] * 4 + [c_i, c_i, c_fp]),
+    "dpot_timeagg_scale_w_bwd": (c_i, [c_fp] * 6 + [c_i, c_i, c_fp]),
+    "dpot_rel_l2_fwd": (c_i, [c_fp] * 5 + [c_i] * 4 + [c_fp]),
+    "dpot_rel_l2_bwd": (c_i, [c_fp] * 6 + [c_i] * 4 + [c_fp]),
+    "dpot_sumsq": (c_i, [c_fp, c_i64, c_fp, c_fp, c_i, c_fp]),
+    "dpot_adam_step": (c_i, [c_fp] * 4 + [c_i64, c_fp, c_fp, c_f, c_fp]),
+    "dpot_noise_inject": (c_i, [c_fp] * 4 + [c_f] + [c_i] * 3 + [c_fp]),
+}
+
+_lib = None
+_lock = threading.Lock()
+
+
+class DpotHipError(RuntimeError):
+    pass
+
+
+def lib_path() -> str:
+    return LIB_PATH
+
+
+def load():
+    """dlopen libdpot_hip.so and bind every symbol.  Raises if the library has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    with _lock:
+        if _lib is not None:
+            return _lib
+        if not os.path.exists(LIB_PATH):
+            raise DpotHipError(
+                f"{LIB_PATH} is missing - build it first (python -m dpot_amd.build, or __graft_entry__.build()). "
+                "dpot_amd has no CPU / eager fallback by design.")
+        lib = C.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(lib, name)          # AttributeError if the .so does not export it
+            fn.restype = res
+            fn.argtypes = args
+        _lib = lib
+    return _lib
+
+
+def check(rc: int, what: str = "") -> None:
+    if rc != 0:
+        msg = load().dpot_last_error()
+        raise DpotHipError(f"libdpot_hip {what} failed (rc={rc}): {msg.decode() if msg else '?'}")

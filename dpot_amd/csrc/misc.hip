@@ -1,0 +1,343 @@
+// misc.hip - data movement and small reductions around the GEMMs (all HBM-bound):
+//   patchify / unpatchify (strided 8x8 conv <-> GEMM rows), pixel shuffle (ConvTranspose k=s=P), padded copies,
+//   transposes, column sums (bias gradients), pos_embed gradient, token mean (cls head), TimeAggregator scaling.
+#include "common.h"
+
+namespace dpot {
+
+// ---------------------------------------------------------------------------------------------------------
+// patchify: one workgroup per patch site (b,px,py).  The P input rows of a site are P contiguous runs of
+// P*T*C floats -> staged through LDS with coalesced reads, then written as T consecutive GEMM rows of
+// K0 = (C+3)*P*P floats (coalesced).  Columns C..C+2 are the unit grid (x, y, t).
+// ---------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void patchify_kernel(const float* __restrict__ x, const float* __restrict__ gx,
+                                                       const float* __restrict__ gy, const float* __restrict__ gt,
+                                                       float* __restrict__ A, int X, int Y, int T, int C, int P) {
+  extern __shared__ float sm[];  // [P][P*T*C]
+  const int w = Y / P, h = X / P;
+  const int site = blockIdx.x;
+  const int py = site % w, px = (site / w) % h, b = site / (w * h);
+  const int run = P * T * C;
+  for (int idx = threadIdx.x; idx < P * run; idx += 256) {
+    const int i = idx / run, r = idx % run;
+    sm[idx] = x[(((long long)b * X + px * P + i) * Y + py * P) * T * C + r];
+  }
+  __syncthreads();
+  const int PP = P * P, K0 = (C + 3) * PP;
+  float* out = A + (long long)site * T * K0;
+  for (int idx = threadIdx.x; idx < T * K0; idx += 256) {
+    const int t = idx / K0, k = idx % K0;
+    const int c = k / PP, i = (k % PP) / P, j = k % P;
+    float v;
+    if (c < C) v = sm[i * run + (j * T + t) * C + c];
+    else if (c == C) v = gx[px * P + i];
+    else if (c == C + 1) v = gy[py * P + j];
+    else v = gt[t];
+    out[idx] = v;
+  }
+}
+
+__global__ __launch_bounds__(256) void unpatchify_kernel(const float* __restrict__ dA, float* __restrict__ dx, int X,
+                                                         int Y, int T, int C, int P) {
+  extern __shared__ float sm[];  // [P][P*T*C]
+  const int w = Y / P, h = X / P;
+  const int site = blockIdx.x;
+  const int py = site % w, px = (site / w) % h, b = site / (w * h);
+  const int run = P * T * C;
+  const int PP = P * P, K0 = (C + 3) * PP, KC = C * PP;
+  const float* in = dA + (long long)site * T * K0;
+  for (int idx = threadIdx.x; idx < T * KC; idx += 256) {
+    const int t = idx / KC, k = idx % KC;
+    const int c = k / PP, i = (k % PP) / P, j = k % P;
+    sm[i * run + (j * T + t) * C + c] = in[(long long)t * K0 + k];
+  }
+  __syncthreads();
+  for (int idx = threadIdx.x; idx < P * run; idx += 256) {
+    const int i = idx / run, r = idx % run;
+    dx[(((long long)b * X + px * P + i) * Y + py * P) * T * C + r] = sm[idx];
+  }
+}
+
+// z[(b,px,py,i,j), Cc] <-> out[b, px*P+i, py*P+j, Cc]
+__global__ void pixel_shuffle_kernel(const float* __restrict__ src, float* __restrict__ dst, int h, int w, int P,
+                                     int Cc, int inverse, long long total) {
+  for (long long idx = blockIdx.x * 256ll + threadIdx.x; idx < total; idx += (long long)gridDim.x * 256) {
+    // idx enumerates the image layout [b, X, Y, Cc]
+    const int c = (int)(idx % Cc);
+    long long r = idx / Cc;
+    const int Yy = (int)(r % (w * P));
+    r /= (w * P);
+    const int Xx = (int)(r % (h * P));
+    const long long b = r / (h * P);
+    const int px = Xx / P, i = Xx % P, py = Yy / P, j = Yy % P;
+    const long long zi = (((((b * h + px) * w + py) * P + i) * P + j)) * Cc + c;
+    if (inverse) dst[zi] = src[idx];
+    else dst[idx] = src[zi];
+  }
+}
+
+__global__ void copy2d_pad_kernel(const float* __restrict__ src, int sR, int sC, float* __restrict__ dst, int dR,
+                                  int dC) {
+  const long long total = (long long)dR * dC;
+  for (long long idx = blockIdx.x * 256ll + threadIdx.x; idx < total; idx += (long long)gridDim.x * 256) {
+    const int r = (int)(idx / dC), c = (int)(idx % dC);
+    dst[idx] = (r < sR && c < sC) ? src[(long long)r * sC + c] : 0.f;
+  }
+}
+
+// dst[C,R] = src[R,C]^T per batch; 32x32 tiles through LDS (+1 padding: conflict-free)
+__global__ __launch_bounds__(256) void transpose2d_kernel(const float* __restrict__ src, float* __restrict__ dst, int R,
+                                                          int C) {
+  __shared__ float tile[32][33];
+  const long long boff = (long long)blockIdx.z * R * C;
+  const int c0 = blockIdx.x * 32, r0 = blockIdx.y * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
+  for (int k = ty; k < 32; k += 8) {
+    const int r = r0 + k, c = c0 + tx;
+    if (r < R && c < C) tile[k][tx] = src[boff + (long long)r * C + c];
+  }
+  __syncthreads();
+  for (int k = ty; k < 32; k += 8) {
+    const int c = c0 + k, r = r0 + tx;
+    if (r < R && c < C) dst[boff + (long long)c * R + r] = tile[tx][k];
+  }
+}
+
+// column sums, stage 1: grid (cdiv(N,64), parts); block = 64 columns x 4 row lanes
+__global__ __launch_bounds__(256) void colsum_part_kernel(const float* __restrict__ X, int M, int N, int ld,
+                                                          float* __restrict__ part, int rows_per_part) {
+  __shared__ float red[4][64];
+  const int tc = threadIdx.x & 63, tr = threadIdx.x >> 6;
+  const int n = blockIdx.x * 64 + tc;
+  const int m0 = blockIdx.y * rows_per_part;
+  int m1 = m0 + rows_per_part;
+  if (m1 > M) m1 = M;
+  float s = 0.f;
+  if (n < N)
+    for (int m = m0 + tr; m < m1; m += 4) s += X[(long long)m * ld + n];
+  red[tr][tc] = s;
+  __syncthreads();
+  if (tr == 0 && n < N) part[(long long)blockIdx.y * N + n] = (red[0][tc] + red[1][tc]) + (red[2][tc] + red[3][tc]);
+}
+__global__ void colsum_final_kernel(const float* __restrict__ part, int parts, int N, float* __restrict__ out) {
+  const int n = blockIdx.x * 256 + threadIdx.x;
+  if (n >= N) return;
+  float s = 0.f;
+  for (int p = 0; p < parts; ++p) s += part[(long long)p * N + n];
+  out[n] = s;
+}
+
+// out[r, n] = sum_{b,t} X[((b*R + r)*T + t)*N + n]
+__global__ void group_rowsum_kernel(const float* __restrict__ X, float* __restrict__ out, int B, int R, int T, int N) {
+  const int n = blockIdx.x * 256 + threadIdx.x;
+  const int r = blockIdx.y;
+  if (n >= N) return;
+  float s = 0.f;
+  for (int b = 0; b < B; ++b) {
+    const float* p = X + (((long long)b * R + r) * T) * N + n;
+    for (int t = 0; t < T; ++t) s += p[(long long)t * N];
+  }
+  out[(long long)r * N + n] = s;
+}
+
+__global__ void token_mean_kernel(const float* __restrict__ x, float* __restrict__ y, int T, int E) {
+  const int e = blockIdx.x * 256 + threadIdx.x;
+  const int b = blockIdx.y;
+  if (e >= E) return;
+  const float* p = x + (long long)b * T * E + e;
+  float s = 0.f;
+  for (int t = 0; t < T; ++t) s += p[(long long)t * E];
+  y[(long long)b * E + e] = s / (float)T;
+}
+__global__ void token_mean_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ add,
+                                      float* __restrict__ dx, int T, int E, long long total) {
+  const float inv = 1.0f / (float)T;
+  for (long long idx = blockIdx.x * 256ll + threadIdx.x; idx < total; idx += (long long)gridDim.x * 256) {
+    const int e = (int)(idx % E);
+    const long long b = idx / ((long long)T * E);
+    float v = dy[b * E + e] * inv;
+    if (add) v += add[idx];
+    dx[idx] = v;
+  }
+}
+
+__global__ void add_kernel(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ y,
+                           long long n) {
+  for (long long i = blockIdx.x * 256ll + threadIdx.x; i < n; i += (long long)gridDim.x * 256) y[i] = a[i] + b[i];
+}
+
+__global__ void scale_shift_kernel(const float* __restrict__ x, const float* __restrict__ scale,
+                                   const float* __restrict__ shift, float* __restrict__ y, int T, int E,
+                                   long long total) {
+  for (long long idx = blockIdx.x * 256ll + threadIdx.x; idx < total; idx += (long long)gridDim.x * 256) {
+    const int e = (int)(idx % E);
+    const long long b = idx / ((long long)T * E);
+    y[idx] = fmaf(x[idx], scale[b * E + e], shift[b * E + e]);
+  }
+}
+
+// TimeAggregator exp_mlp: one block per (t, i) row of w[T,E,E]
+__global__ __launch_bounds__(256) void timeagg_scale_w_kernel(const float* __restrict__ w, const float* __restrict__ gamma,
+                                                              const float* __restrict__ tt, float* __restrict__ ws,
+                                                              int E) {
+  const int i = blockIdx.x, t = blockIdx.y;
+  const float cs = cosf(tt[t] * gamma[i]);
+  const long long off = ((long long)t * E + i) * E;
+  for (int j = threadIdx.x; j < E; j += 256) ws[off + j] = w[off + j] * cs;
+}
+// one block per i: dw rows for every t, and dgamma[i]
+__global__ __launch_bounds__(256) void timeagg_scale_w_bwd_kernel(const float* __restrict__ dws, const float* __restrict__ w,
+                                                                  const float* __restrict__ gamma,
+                                                                  const float* __restrict__ tt, float* __restrict__ dw,
+                                                                  float* __restrict__ dgamma, int T, int E) {
+  __shared__ float sh[16];
+  const int i = blockIdx.x;
+  const float ga = gamma[i];
+  float dg = 0.f;
+  for (int t = 0; t < T; ++t) {
+    const float tv = tt[t];
+    const float arg = tv * ga;
+    const float cs = cosf(arg), sn = sinf(arg);
+    const long long off = ((long long)t * E + i) * E;
+    float s = 0.f;
+    for (int j = threadIdx.x; j < E; j += 256) {
+      const float d = dws[off + j];
+      dw[off + j] = d * cs;
+      s = fmaf(d, w[off + j], s);
+    }
+    s = block_sum(s, sh);
+    dg += s * (-sn) * tv;
+  }
+  if (dgamma && threadIdx.x == 0) dgamma[i] = dg;
+}
+
+static inline unsigned grid_for(long long n, int cap = 8192) {
+  long long g = (n + 255) / 256;
+  if (g > cap) g = cap;
+  if (g < 1) g = 1;
+  return (unsigned)g;
+}
+
+}  // namespace dpot
+
+using namespace dpot;
+
+extern "C" int dpot_patchify(const float* x, const float* gx, const float* gy, const float* gt, float* A, int B,
+                             int X, int Y, int T, int C, int P, dpot_stream_t stream) {
+  DPOT_REQUIRE(x && gx && gy && gt && A, "patchify: null pointer");
+  DPOT_REQUIRE(B > 0 && P > 0 && X % P == 0 && Y % P == 0 && T > 0 && C > 0, "patchify: bad shape");
+  const size_t lds = sizeof(float) * (size_t)P * P * T * C;
+  DPOT_REQUIRE(lds <= 64 * 1024, "patchify: patch slab of %zu bytes exceeds 64 KiB", lds);
+  const long long sites = (long long)B * (X / P) * (Y / P);
+  DPOT_REQUIRE(sites < (1ll << 31), "patchify: too many sites");
+  hipLaunchKernelGGL(patchify_kernel, dim3((unsigned)sites), dim3(256), lds, as_stream(stream), x, gx, gy, gt, A, X, Y,
+                     T, C, P);
+  return check_launch("patchify_kernel");
+}
+
+extern "C" int dpot_unpatchify(const float* dA, float* dx, int B, int X, int Y, int T, int C, int P,
+                               dpot_stream_t stream) {
+  DPOT_REQUIRE(dA && dx, "unpatchify: null pointer");
+  DPOT_REQUIRE(B > 0 && P > 0 && X % P == 0 && Y % P == 0 && T > 0 && C > 0, "unpatchify: bad shape");
+  const size_t lds = sizeof(float) * (size_t)P * P * T * C;
+  DPOT_REQUIRE(lds <= 64 * 1024, "unpatchify: patch slab of %zu bytes exceeds 64 KiB", lds);
+  const long long sites = (long long)B * (X / P) * (Y / P);
+  hipLaunchKernelGGL(unpatchify_kernel, dim3((unsigned)sites), dim3(256), lds, as_stream(stream), dA, dx, X, Y, T, C,
+                     P);
+  return check_launch("unpatchify_kernel");
+}
+
+extern "C" int dpot_pixel_shuffle(const float* z, float* out, int B, int h, int w, int P, int Cc, int inverse,
+                                  dpot_stream_t stream) {
+  DPOT_REQUIRE(z && out && B > 0 && h > 0 && w > 0 && P > 0 && Cc > 0, "pixel_shuffle: bad argument");
+  const long long total = (long long)B * h * P * w * P * Cc;
+  hipLaunchKernelGGL(pixel_shuffle_kernel, dim3(grid_for(total)), dim3(256), 0, as_stream(stream), z, out, h, w, P, Cc,
+                     inverse, total);
+  return check_launch("pixel_shuffle_kernel");
+}
+
+extern "C" int dpot_copy2d_pad(const float* src, int sR, int sC, float* dst, int dR, int dC, dpot_stream_t stream) {
+  DPOT_REQUIRE(src && dst && sR > 0 && sC > 0 && dR > 0 && dC > 0, "copy2d_pad: bad argument");
+  hipLaunchKernelGGL(copy2d_pad_kernel, dim3(grid_for((long long)dR * dC)), dim3(256), 0, as_stream(stream), src, sR,
+                     sC, dst, dR, dC);
+  return check_launch("copy2d_pad_kernel");
+}
+
+extern "C" int dpot_transpose2d(const float* src, float* dst, int nbatch, int R, int C, dpot_stream_t stream) {
+  DPOT_REQUIRE(src && dst && nbatch > 0 && R > 0 && C > 0 && nbatch <= 65535 && cdiv(R, 32) <= 65535,
+               "transpose2d: bad argument");
+  hipLaunchKernelGGL(transpose2d_kernel, dim3(cdiv(C, 32), cdiv(R, 32), nbatch), dim3(256), 0, as_stream(stream), src,
+                     dst, R, C);
+  return check_launch("transpose2d_kernel");
+}
+
+extern "C" int dpot_colsum_parts(int M) {
+  int parts = cdiv(M, 128);
+  if (parts > 64) parts = 64;
+  if (parts < 1) parts = 1;
+  return parts;
+}
+
+extern "C" int dpot_colsum(const float* X, int M, int N, int ld, float* out, float* part, dpot_stream_t stream) {
+  DPOT_REQUIRE(X && out && part && M > 0 && N > 0 && ld >= N, "colsum: bad argument");
+  const int parts = dpot_colsum_parts(M);
+  const int rpp = cdiv(M, parts);
+  hipLaunchKernelGGL(colsum_part_kernel, dim3(cdiv(N, 64), parts), dim3(256), 0, as_stream(stream), X, M, N, ld, part,
+                     rpp);
+  int rc = check_launch("colsum_part_kernel");
+  if (rc) return rc;
+  hipLaunchKernelGGL(colsum_final_kernel, dim3(cdiv(N, 256)), dim3(256), 0, as_stream(stream), (const float*)part,
+                     parts, N, out);
+  return check_launch("colsum_final_kernel");
+}
+
+extern "C" int dpot_group_rowsum(const float* X, float* out, int B, int R, int T, int N, dpot_stream_t stream) {
+  DPOT_REQUIRE(X && out && B > 0 && R > 0 && T > 0 && N > 0 && R <= 65535, "group_rowsum: bad argument");
+  hipLaunchKernelGGL(group_rowsum_kernel, dim3(cdiv(N, 256), R), dim3(256), 0, as_stream(stream), X, out, B, R, T, N);
+  return check_launch("group_rowsum_kernel");
+}
+
+extern "C" int dpot_token_mean(const float* x, float* y, int B, int T, int E, dpot_stream_t stream) {
+  DPOT_REQUIRE(x && y && B > 0 && T > 0 && E > 0 && B <= 65535, "token_mean: bad argument");
+  hipLaunchKernelGGL(token_mean_kernel, dim3(cdiv(E, 256), B), dim3(256), 0, as_stream(stream), x, y, T, E);
+  return check_launch("token_mean_kernel");
+}
+
+extern "C" int dpot_token_mean_bwd(const float* dy, const float* add, float* dx, int B, int T, int E,
+                                   dpot_stream_t stream) {
+  DPOT_REQUIRE(dy && dx && B > 0 && T > 0 && E > 0, "token_mean_bwd: bad argument");
+  const long long total = (long long)B * T * E;
+  hipLaunchKernelGGL(token_mean_bwd_kernel, dim3(grid_for(total)), dim3(256), 0, as_stream(stream), dy, add, dx, T, E,
+                     total);
+  return check_launch("token_mean_bwd_kernel");
+}
+
+extern "C" int dpot_add(const float* a, const float* b, float* y, int64_t n, dpot_stream_t stream) {
+  DPOT_REQUIRE(a && b && y && n > 0, "add: bad argument");
+  hipLaunchKernelGGL(add_kernel, dim3(grid_for(n)), dim3(256), 0, as_stream(stream), a, b, y, (long long)n);
+  return check_launch("add_kernel");
+}
+
+extern "C" int dpot_scale_shift(const float* x, const float* scale, const float* shift, float* y, int B, int T, int E,
+                                dpot_stream_t stream) {
+  DPOT_REQUIRE(x && scale && shift && y && B > 0 && T > 0 && E > 0, "scale_shift: bad argument");
+  const long long total = (long long)B * T * E;
+  hipLaunchKernelGGL(scale_shift_kernel, dim3(grid_for(total)), dim3(256), 0, as_stream(stream), x, scale, shift, y, T,
+                     E, total);
+  return check_launch("scale_shift_kernel");
+}
+
+extern "C" int dpot_timeagg_scale_w(const float* w, const float* gamma, const float* tt, float* ws, int T, int E,
+                                    dpot_stream_t stream) {
+  DPOT_REQUIRE(w && gamma && tt && ws && T > 0 && E > 0 && T <= 65535, "timeagg_scale_w: bad argument");
+  hipLaunchKernelGGL(timeagg_scale_w_kernel, dim3(E, T), dim3(256), 0, as_stream(stream), w, gamma, tt, ws, E);
+  return check_launch("timeagg_scale_w_kernel");
+}
+
+extern "C" int dpot_timeagg_scale_w_bwd(const float* dws, const float* w, const float* gamma, const float* tt,
+                                        float* dw, float* dgamma, int T, int E, dpot_stream_t stream) {
+  DPOT_REQUIRE(dws && w && gamma && tt && dw && T > 0 && E > 0, "timeagg_scale_w_bwd: bad argument");
+  hipLaunchKernelGGL(timeagg_scale_w_bwd_kernel, dim3(E), dim3(256), 0, as_stream(stream), dws, w, gamma, tt, dw,
+                     dgamma, T, E);
+  return check_launch("timeagg_scale_w_bwd_kernel");
+}

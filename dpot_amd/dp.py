@@ -1,0 +1,135 @@
+"""Data parallelism for the DPOT step: one process per GPU, RCCL all-reduce of the flat gradient buffer over xGMI,
+overlapped with backward.  Replaces what the reference gets from HF-accelerate -> torch DDP -> NCCL
+(train_temporal_parallel.py:102,185,243-244).
+
+Semantics kept from the reference:
+  * every rank holds a full replica; parameters are broadcast from rank 0 once at start-up;
+  * the loss is a per-rank batch SUM and DDP AVERAGES gradients over ranks -> here: all-reduce(SUM) of the flat
+    buffer and a 1/world_size ``grad_scale`` folded into the fused clip+Adam kernel (no extra pass over memory);
+  * clip + Adam run redundantly on every rank after the reduction (replicated optimiser, no ZeRO);
+  * per-rank batch = configured batch size (Accelerator(split_batches=False)): ``shard_indices`` hands rank r the
+    batches r, r+W, ... of the shuffled batch list.
+
+MI355X-specific choices: xGMI is point-to-point (7 links x ~153 GB/s per GPU), ring collectives are per-link
+bound and latency matters for the 30 MB Tiny gradient, so the buffer is cut into FEW LARGE contiguous buckets
+(default 4) in reverse execution order; each bucket is reduced on a side HIP stream as soon as autograd has
+produced its last gradient, and the compute stream only waits for the side stream right before the optimiser.
+"""
+from __future__ import annotations
+
+from typing import List, Optional, Sequence
+
+import torch
+import torch.distributed as dist
+
+from .train import FlatParams
+
+
+class BucketedGradReducer:
+    def __init__(self, flat: FlatParams, process_group=None, n_buckets: int = 4, overlap: bool = True):
+        self.fp = flat
+        self.pg = process_group
+        self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
+        self.grad_scale = 1.0 / self.world
+        self.is_cuda = flat.grad.is_cuda
+        self.overlap = overlap and self.is_cuda
+        self.stream = torch.cuda.Stream() if self.overlap else None
+        # contiguous buckets over the flat buffer, cut at parameter boundaries, roughly equal bytes
+        n_params = len(flat.params)
+        ends = [flat.offsets[i + 1] if i + 1 < n_params else flat.total for i in range(n_params)]
+        target = flat.total / max(1, n_buckets)
+        self.bucket_of: List[int] = [0] * n_params
+        self.ranges: List[List[int]] = []
+        start, b = 0, 0
+        for i in range(n_params):
+            self.bucket_of[i] = b
+            # the cls_head tail (no gradient in single-loss training) always gets a bucket of its own
+            if ends[i] - start >= target or i == n_params - 1 or ends[i] == flat.n_head:
+                self.ranges.append([start, ends[i]])
+                start = ends[i]
+                b += 1
+        self.n_buckets = len(self.ranges)
+        self.members = [[i for i in range(n_params) if self.bucket_of[i] == k] for k in range(self.n_buckets)]
+        self._pending = [0] * self.n_buckets
+        self._seen: List[bool] = [False] * n_params
+        self._work = []
+        self._launched = [False] * self.n_buckets
+        self._hooks = []
+        for i, p in enumerate(flat.params):
+            self._hooks.append(p.register_post_accumulate_grad_hook(self._make_hook(i)))
+
+    # -- set-up ------------------------------------------------------------------------------------------
+    def broadcast_parameters(self, src: int = 0) -> None:
+        """rank 0 -> all, one collective over the flat fp32 parameter buffer (DDP's initial broadcast)."""
+        if self.world > 1:
+            dist.broadcast(self.fp.flat, src=src, group=self.pg)
+
+    # -- per step ----------------------------------------------------------------------------------------
+    def begin_step(self) -> None:
+        self._pending = [len(m) for m in self.members]
+        self._seen = [False] * len(self.fp.params)
+        self._launched = [False] * self.n_buckets
+        self._work = []
+
+    def _make_hook(self, i: int):
+        def hook(_param):
+            if self._seen[i]:
+                return
+            self._seen[i] = True
+            k = self.bucket_of[i]
+            self._pending[k] -= 1
+            if self._pending[k] == 0:
+                self._launch(k)
+        return hook
+
+    def _launch(self, k: int) -> None:
+        if self._launched[k] or self.world == 1:
+            self._launched[k] = True
+            return
+        self._launched[k] = True
+        lo, hi = self.ranges[k]
+        buf = self.fp.grad[lo:hi]
+        if self.overlap:
+            self.stream.wait_stream(torch.cuda.current_stream())     # gradients of this bucket are complete
+            with torch.cuda.stream(self.stream):
+                dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.pg)
+        else:
+            self._work.append(dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.pg, async_op=True))
+
+    def finish(self) -> None:
+        """reduce whatever has not been reduced yet (parameters that received no gradient this step still take
+        part: their slice is zero, as with DDP + `0.0 * cls_loss`), then make the compute stream wait."""
+        for k in range(self.n_buckets):
+            if not self._launched[k]:
+                self._launch(k)
+        if self.overlap:
+            torch.cuda.current_stream().wait_stream(self.stream)
+        for w in self._work:
+            w.wait()
+        self._work = []
+
+    def remove_hooks(self) -> None:
+        for h in self._hooks:
+            h.remove()
+        self._hooks = []
+
+
+def shard_indices(n_samples: int, batch_size: int, rank: int, world: int, epoch: int, seed: int = 0,
+                  shuffle: bool = True) -> List[List[int]]:
+    """accelerate's BatchSamplerShard(split_batches=False) contract: all ranks build the same shuffled batch list
+    (common seed) and rank r takes batches r, r+W, ...; the ragged tail is dropped so every rank runs the same
+    number of steps."""
+    g = torch.Generator()
+    g.manual_seed(seed + epoch)
+    order = torch.randperm(n_samples, generator=g).tolist() if shuffle else list(range(n_samples))
+    batches = [order[i:i + batch_size] for i in range(0, n_samples - batch_size + 1, batch_size)]
+    usable = len(batches) // world * world
+    return [batches[i] for i in range(rank, usable, world)]
+
+
+def all_reduce_scalar(value: torch.Tensor, process_group=None) -> torch.Tensor:
+    """sum of a per-rank scalar (eval metrics; train_temporal_parallel.py:294-297 gathers them)."""
+    if dist.is_initialized() and dist.get_world_size(process_group) > 1:
+        value = value.clone()
+        dist.all_reduce(value, op=dist.ReduceOp.SUM, group=process_group)
+    return value

@@ -1,0 +1,283 @@
+"""Autograd functions of the DPOT step, one per stage, each with a hand-written backward that calls the HIP
+kernels directly (no autograd tracing inside a stage, no eager-PyTorch math):
+
+  EmbedFn   patch embed (8x8/8 conv as GEMM + act + 1x1 conv + pos) -> TimeAggregator   models/dpot.py:373-384
+  BlockFn   GroupNorm -> AFNO mixer -> GroupNorm -> channel MLP -> +residual             models/dpot.py:165-180
+  HeadFn    out_layer (ConvTranspose as GEMM + pixel tail) and cls_head                  models/dpot.py:394-398
+  RelL2Fn   masked relative L2 loss                                                      utils/criterion.py:38-59
+
+Internal activation layout: channels-last tokens [B, h*w, E] (row-major [B*h*w, E]).
+"""
+from __future__ import annotations
+
+from typing import Optional
+
+import torch
+
+from . import ops
+from .ops import EPI_ACT, EPI_DACT, EPI_LINEAR
+
+Tensor = torch.Tensor
+
+
+def _pad4(n: int) -> int:
+    return (n + 3) // 4 * 4
+
+
+# ======================================================================================================
+class EmbedFn(torch.autograd.Function):
+    """x[B,X,Y,T,C] -> latent [B, h*w, E]"""
+
+    @staticmethod
+    def forward(ctx, x, pos, w0, b0, w2, b2, taw, tagamma, gx, gy, gt, tt, P: int, act: int):
+        x = x.contiguous()
+        B, X, Y, T, Cc = x.shape
+        h, w = X // P, Y // P
+        tok = h * w
+        hid, E = w0.shape[0], w2.shape[0]
+        K0 = (Cc + 3) * P * P
+        hidp = _pad4(hid)
+        M0 = B * tok * T
+
+        A0 = ops.patchify(x, gx, gy, gt, P)                                    # [M0, K0], rows (b,px,py,t)
+        w0p = ops.copy2d_pad(w0, hid, K0, hidp, K0)                            # zero rows hid..hidp
+        b0p = ops.copy2d_pad(b0, 1, hid, 1, hidp).view(hidp)
+        w2p = ops.copy2d_pad(w2, E, hid, E, hidp)                              # zero cols hid..hidp
+        Hh, Hpre = ops.linear_fwd(A0, w0p, b0p, act=act, save_pre=True)        # [M0, hidp]
+        posT = ops.transpose2d(pos, 1, E, tok).view(tok, E)                    # [tok, E]
+        Zt, _ = ops.linear_fwd(Hh, w2p, b2, res=posT, res_div=T, res_mod=tok)  # [M0, E] == [B*tok, T*E]
+        ws = ops.timeagg_scale_w(taw, tagamma, tt) if tagamma is not None else taw
+        Yl = torch.empty(B * tok, E, dtype=torch.float32, device=x.device)
+        ops.gemm(Zt, ws, Yl, B * tok, E, T * E, lda=T * E, ldb=E, ldc=E)       # sum_{t,i} Zt[m,(t,i)] ws[(t,i),j]
+        ctx.save_for_backward(A0, Hpre, Hh, Zt, w0p, w2p, ws, taw, tagamma, tt)
+        ctx.dims = (B, X, Y, T, Cc, P, h, w, hid, hidp, E, K0, act)
+        ctx.x_needs_grad = x.requires_grad
+        return Yl.view(B, tok, E)
+
+    @staticmethod
+    def backward(ctx, dY):
+        A0, Hpre, Hh, Zt, w0p, w2p, ws, taw, tagamma, tt = ctx.saved_tensors
+        B, X, Y, T, Cc, P, h, w, hid, hidp, E, K0, act = ctx.dims
+        tok = h * w
+        M0 = B * tok * T
+        dY = dY.contiguous().view(B * tok, E)
+        # TimeAggregator
+        dZt = torch.empty(B * tok, T * E, dtype=torch.float32, device=dY.device)
+        ops.gemm(dY, ws, dZt, B * tok, T * E, E, transB=True, lda=E, ldb=E, ldc=T * E)
+        dws = torch.empty(T * E, E, dtype=torch.float32, device=dY.device)
+        ops.gemm(Zt, dY, dws, T * E, E, B * tok, transA=True, lda=T * E, ldb=E, ldc=E,
+                 splitk=ops.auto_splitk(T * E, E, B * tok))
+        if tagamma is not None:
+            dtaw, dgamma = ops.timeagg_scale_w_bwd(dws.view(T, E, E), taw, tagamma, tt)
+        else:
+            dtaw, dgamma = dws.view(T, E, E), None
+        # pos_embed + second (1x1) conv
+        dZ2 = dZt.view(M0, E)
+        dposT = ops.group_rowsum(dZ2, B, tok, T, E)                            # [tok, E]
+        dpos = ops.transpose2d(dposT, 1, tok, E).view(1, E, h, w)
+        db2 = ops.colsum(dZ2, M0, E)
+        dw2p = ops.linear_bwd_weight(dZ2, Hh)                                  # [E, hidp]
+        dw2 = ops.copy2d_pad(dw2p, E, hidp, E, hid).view(E, hid, 1, 1)
+        dHpre = ops.linear_bwd_data(dZ2, w2p, act=act, aux=Hpre)               # [M0, hidp]
+        # first (PxP / stride P) conv
+        db0 = ops.colsum(dHpre, M0, hidp)[:hid].contiguous()
+        dw0p = ops.linear_bwd_weight(dHpre, A0)                                # [hidp, K0]
+        dw0 = dw0p[:hid].contiguous().view(hid, Cc + 3, P, P)
+        dx = None
+        if ctx.x_needs_grad:
+            dA0 = ops.linear_bwd_data(dHpre, w0p)                              # [M0, K0]
+            dx = ops.unpatchify(dA0, B, X, Y, T, Cc, P)
+        return dx, dpos, dw0, db0, dw2, db2, dtaw, dgamma, None, None, None, None, None, None
+
+
+# ======================================================================================================
+class BlockFn(torch.autograd.Function):
+    """x[B,tok,E] -> x + MLP(GN2(GN1(x) + irfft2(Mix(rfft2(GN1(x))))))"""
+
+    @staticmethod
+    def forward(ctx, x, n1w, n1b, w1, b1, w2, b2, n2w, n2b, f1w, f1b, f2w, f2b, h: int, w: int, nb: int, modes: int,
+                act: int):
+        x = x.contiguous()
+        B, tok, E = x.shape
+        bs = E // nb
+        mx, my = min(modes, h), min(modes, w // 2 + 1)
+        Mm = B * mx * my
+        mh = f1w.shape[0]
+        M = B * tok
+        dev = x.device
+
+        xn1, mean1, rstd1 = ops.groupnorm_fwd(x, n1w, n1b)
+        S = ops.rfft2(xn1, h, w, nb, mx, my, 0)                                # [Mm, 2E]
+        wb1, bb1 = ops.afno_pack(w1, b1)
+        wb2, bb2 = ops.afno_pack(w2, b2)
+        O1 = torch.empty(Mm, 2 * E, dtype=torch.float32, device=dev)
+        O1pre = torch.empty_like(O1)
+        kw = dict(lda=2 * E, ldb=2 * bs, ldc=2 * E, batch=nb, strideA=2 * bs, strideB=4 * bs * bs, strideC=2 * bs,
+                  strideBias=2 * bs, tag=1)
+        ops.gemm(S, wb1, O1, Mm, 2 * bs, 2 * bs, bias=bb1, act=act, mode=EPI_ACT, preact=O1pre, ldpre=2 * E,
+                 stridePre=2 * bs, **kw)
+        O2 = torch.empty_like(O1)
+        ops.gemm(O1, wb2, O2, Mm, 2 * bs, 2 * bs, bias=bb2, **kw)
+        y1 = ops.irfft2(O2, B, h, w, E, nb, mx, my, 1, res=xn1)                # + x_orig (the normalised input)
+        xn2, mean2, rstd2 = ops.groupnorm_fwd(y1, n2w, n2b)
+        Hh, Hpre = ops.linear_fwd(xn2.view(M, E), f1w, f1b, act=act, save_pre=True)
+        out, _ = ops.linear_fwd(Hh, f2w, f2b, res=x.view(M, E))
+        ctx.save_for_backward(x, mean1, rstd1, S, O1pre, O1, y1, mean2, rstd2, xn2, Hpre, Hh, wb1, wb2, n1w, n2w, f1w,
+                              f2w)
+        ctx.dims = (B, tok, E, h, w, nb, bs, mx, my, mh, act)
+        return out.view(B, tok, E)
+
+    @staticmethod
+    def backward(ctx, dout):
+        (x, mean1, rstd1, S, O1pre, O1, y1, mean2, rstd2, xn2, Hpre, Hh, wb1, wb2, n1w, n2w, f1w,
+         f2w) = ctx.saved_tensors
+        B, tok, E, h, w, nb, bs, mx, my, mh, act = ctx.dims
+        M, Mm = B * tok, B * mx * my
+        dev = dout.device
+        dout = dout.contiguous()
+        do2 = dout.view(M, E)
+        # channel MLP
+        dHpre = ops.linear_bwd_data(do2, f2w, act=act, aux=Hpre)               # [M, mh]
+        df2w = ops.linear_bwd_weight(do2, Hh)
+        df2b = ops.colsum(do2, M, E)
+        dxn2 = ops.linear_bwd_data(dHpre, f1w)                                 # [M, E]
+        df1w = ops.linear_bwd_weight(dHpre, xn2.view(M, E))
+        df1b = ops.colsum(dHpre, M, mh)
+        dy1, dn2w, dn2b = ops.groupnorm_bwd(dxn2.view(B, tok, E), y1, mean2, rstd2, n2w)
+        # AFNO mixer
+        dO2 = ops.rfft2(dy1, h, w, nb, mx, my, 1)                              # adjoint of irfft2
+        kw = dict(lda=2 * E, ldb=2 * bs, ldc=2 * E, batch=nb, strideA=2 * bs, strideB=4 * bs * bs, strideC=2 * bs)
+        dO1pre = torch.empty(Mm, 2 * E, dtype=torch.float32, device=dev)
+        ops.gemm(dO2, wb2, dO1pre, Mm, 2 * bs, 2 * bs, transB=True, act=act, mode=EPI_DACT, aux=O1pre, ldaux=2 * E,
+                 strideAux=2 * bs, **kw)
+        sk = ops.auto_splitk(2 * bs, 2 * bs, Mm, nb)
+        wkw = dict(transA=True, lda=2 * E, ldb=2 * E, ldc=2 * bs, batch=nb, strideA=2 * bs, strideB=2 * bs,
+                   strideC=4 * bs * bs, splitk=sk)
+        dwb2 = torch.empty(nb, 2 * bs, 2 * bs, dtype=torch.float32, device=dev)
+        ops.gemm(O1, dO2, dwb2, 2 * bs, 2 * bs, Mm, **wkw)
+        dbb2 = ops.colsum(dO2, Mm, 2 * E)
+        dS = torch.empty(Mm, 2 * E, dtype=torch.float32, device=dev)
+        ops.gemm(dO1pre, wb1, dS, Mm, 2 * bs, 2 * bs, transB=True, **kw)
+        dwb1 = torch.empty(nb, 2 * bs, 2 * bs, dtype=torch.float32, device=dev)
+        ops.gemm(S, dO1pre, dwb1, 2 * bs, 2 * bs, Mm, **wkw)
+        dbb1 = ops.colsum(dO1pre, Mm, 2 * E)
+        dw1, db1 = ops.afno_unpack_grad(dwb1, dbb1, nb, bs)
+        dw2, db2 = ops.afno_unpack_grad(dwb2, dbb2, nb, bs)
+        dxn1 = ops.irfft2(dS, B, h, w, E, nb, mx, my, 0, res=dy1)              # adjoint of rfft2, + skip path
+        dx, dn1w, dn1b = ops.groupnorm_bwd(dxn1, x, mean1, rstd1, n1w, add=dout)
+        return (dx, dn1w, dn1b, dw1, db1, dw2, db2, dn2w, dn2b, df1w.view(mh, E, 1, 1), df1b, df2w.view(E, mh, 1, 1),
+                df2b, None, None, None, None, None)
+
+
+# ======================================================================================================
+class HeadFn(torch.autograd.Function):
+    """x[B,tok,E] -> (pred [B,X,Y,T_out*C_out], cls_pred [B,n_cls])"""
+
+    @staticmethod
+    def forward(ctx, x, o0w, o0b, o2w, o2b, o4w, o4b, c0w, c0b, c2w, c2b, c4w, c4b, h: int, w: int, P: int, act: int):
+        ctx.set_materialize_grads(False)      # an unused output (cls_pred in train_temporal.py:226) costs nothing
+        x = x.contiguous()
+        B, tok, E = x.shape
+        old, co = o0w.shape[1], o4w.shape[0]
+        PP = P * P
+        M, Mp = B * tok, B * tok * PP
+        dev = x.device
+        # ConvTranspose2d(k=s=P) as GEMM with columns ordered (i, j, o): the result IS the pixel-major [Mp, old] matrix
+        wt = ops.transpose2d(o0w, E, old, PP).view(E, PP * old)
+        bexp = o0b.repeat(PP)
+        U = torch.empty(M, PP * old, dtype=torch.float32, device=dev)
+        Upre = torch.empty_like(U)
+        ops.gemm(x, wt, U, M, PP * old, E, lda=E, ldb=PP * old, ldc=PP * old, bias=bexp, act=act, mode=EPI_ACT,
+                 preact=Upre, ldpre=PP * old)
+        V, Vpre = ops.linear_fwd(U.view(Mp, old), o2w, o2b, act=act, save_pre=True)
+        Z, _ = ops.linear_fwd(V, o4w, o4b)                                     # [Mp, co]
+        pred = ops.pixel_shuffle(Z, B, h, w, P, co)                            # [B, X, Y, co]
+        # classification head
+        cm = ops.token_mean(x)
+        c1, c1pre = ops.linear_fwd(cm, c0w, c0b, act=act, save_pre=True)
+        c2, c2pre = ops.linear_fwd(c1, c2w, c2b, act=act, save_pre=True)
+        cls, _ = ops.linear_fwd(c2, c4w, c4b)
+        ctx.save_for_backward(x, wt, U, Upre, V, Vpre, o2w, o4w, cm, c1, c1pre, c2, c2pre, c0w, c2w, c4w)
+        ctx.dims = (B, tok, E, h, w, P, old, co, act)
+        return pred, cls
+
+    @staticmethod
+    def backward(ctx, dpred, dcls):
+        x, wt, U, Upre, V, Vpre, o2w, o4w, cm, c1, c1pre, c2, c2pre, c0w, c2w, c4w = ctx.saved_tensors
+        B, tok, E, h, w, P, old, co, act = ctx.dims
+        PP = P * P
+        M, Mp = B * tok, B * tok * PP
+        dev = x.device
+        o2w2, o4w2 = o2w.view(old, old), o4w.view(co, old)
+        do0w = do0b = do2w = do2b = do4w = do4b = dx_out = None
+        dc0w = dc0b = dc2w = dc2b = dc4w = dc4b = None
+        if dpred is not None:
+            # ---- out layer
+            dZ = ops.pixel_shuffle(dpred.contiguous(), B, h, w, P, co, inverse=True)      # [Mp, co]
+            dVpre = ops.linear_bwd_data(dZ, o4w2, act=act, aux=Vpre)                      # [Mp, old]
+            do4w = ops.linear_bwd_weight(dZ, V).view(co, old, 1, 1)
+            do4b = ops.colsum(dZ, Mp, co)
+            dUpre = ops.linear_bwd_data(dVpre, o2w2, act=act, aux=Upre.view(Mp, old))     # [Mp, old]
+            do2w = ops.linear_bwd_weight(dVpre, U.view(Mp, old)).view(old, old, 1, 1)
+            do2b = ops.colsum(dVpre, Mp, old)
+            do0b = ops.colsum(dUpre, Mp, old)
+            dU2 = dUpre.view(M, PP * old)
+            dx_out = torch.empty(M, E, dtype=torch.float32, device=dev)
+            ops.gemm(dU2, wt, dx_out, M, E, PP * old, transB=True, lda=PP * old, ldb=PP * old, ldc=E)
+            dwt = torch.empty(E, PP * old, dtype=torch.float32, device=dev)
+            ops.gemm(x, dU2, dwt, E, PP * old, M, transA=True, lda=E, ldb=PP * old, ldc=PP * old,
+                     splitk=ops.auto_splitk(E, PP * old, M))
+            do0w = ops.transpose2d(dwt, E, PP, old).view(E, old, P, P)
+            dx_out = dx_out.view(B, tok, E)
+        dx = dx_out
+        if dcls is not None:
+            # ---- cls head
+            dcls = dcls.contiguous()
+            dc2pre = ops.linear_bwd_data(dcls, c4w, act=act, aux=c2pre)
+            dc4w = ops.linear_bwd_weight(dcls, c2)
+            dc4b = ops.colsum(dcls, B, dcls.shape[1])
+            dc1pre = ops.linear_bwd_data(dc2pre, c2w, act=act, aux=c1pre)
+            dc2w = ops.linear_bwd_weight(dc2pre, c1)
+            dc2b = ops.colsum(dc2pre, B, E)
+            dcm = ops.linear_bwd_data(dc1pre, c0w)
+            dc0w = ops.linear_bwd_weight(dc1pre, cm)
+            dc0b = ops.colsum(dc1pre, B, E)
+            dx = ops.token_mean_bwd(dcm, tok, add=dx_out)
+        return (dx, do0w, do0b, do2w, do2b, do4w, do4b, dc0w, dc0b, dc2w, dc2b, dc4w, dc4b, None, None, None, None)
+
+
+# ======================================================================================================
+class RelL2Fn(torch.autograd.Function):
+    """sum_b sum_c ||(x-y) m||_2 / (||y m||_2 + 1e-8) / n_channels_b   (SimpleLpLoss(size_average=False))"""
+
+    @staticmethod
+    def forward(ctx, x, y, mask: Optional[Tensor]):
+        x, y = ops._req(x.contiguous(), "pred"), ops._req(y.contiguous(), "target")
+        B, Cc = x.shape[0], x.shape[-1]
+        Tt = x.shape[-2] if x.dim() >= 3 else 1
+        S = x.numel() // (B * Cc)
+        if mask is not None:
+            mask = mask.contiguous()
+            if mask.numel() == x.numel():
+                Tt_m = 1
+            elif mask.numel() * Tt == x.numel():
+                Tt_m = Tt
+            else:
+                raise ValueError(f"mask shape {tuple(mask.shape)} does not broadcast over {tuple(x.shape)}")
+        else:
+            Tt_m = 1
+        loss, stats = ops.rel_l2_fwd(x, y, mask, B, S, Cc, Tt_m)
+        ctx.save_for_backward(x, y, mask if mask is not None else x.new_empty(0), stats)
+        ctx.meta = (B, S, Cc, Tt_m, mask is not None)
+        return loss.view(())
+
+    @staticmethod
+    def backward(ctx, g):
+        x, y, mask, stats = ctx.saved_tensors
+        B, S, Cc, Tt_m, has_mask = ctx.meta
+        dx = ops.rel_l2_bwd(x, y, mask if has_mask else None, stats, g.contiguous().view(1), B, S, Cc, Tt_m)
+        return dx, None, None
+
+
+def rel_l2_loss(x: Tensor, y: Tensor, mask: Optional[Tensor] = None) -> Tensor:
+    return RelL2Fn.apply(x, y, mask)

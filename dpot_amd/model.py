@@ -1,0 +1,159 @@
+"""DPOTNet for MI355X.
+
+Drop-in for the reference model class (models/dpot.py:245-403): identical constructor signature, identical
+``state_dict`` keys / shapes / ordering (so pretrained ``.pth`` files load unchanged, also through
+utils/utilities.py:99-166 style per-component loading) and the same call contract
+
+    pred, cls_pred = model(x)          # x: [B, X, Y, T_in, C_in]  ->  [B, X, Y, T_out, C_out], [B, n_cls]
+
+but the compute is the hand-written HIP path in libdpot_hip.so (functional.py / ops.py).  The torch modules
+below (Conv2d, GroupNorm, Linear, ...) are used purely as *parameter containers* - they own the weights with the
+reference's names and default initialisation; their own forward() is never called.
+
+The model only runs on a CUDA (ROCm) device; calling it with CPU tensors raises - there is no fallback path.
+"""
+from __future__ import annotations
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from . import _lib, ops
+from .functional import BlockFn, EmbedFn, HeadFn
+
+ACTIVATIONS = ("gelu", "tanh", "sigmoid", "relu", "leaky_relu", "softplus", "ELU", "silu")
+
+
+class _AFNOParams(nn.Module):
+    """weights of the block-diagonal complex MLP shared by all Fourier modes (models/dpot.py:41-48)"""
+
+    def __init__(self, width: int, num_blocks: int):
+        super().__init__()
+        assert width % num_blocks == 0, f"hidden_size {width} should be divisble by num_blocks {num_blocks}"
+        bs = width // num_blocks
+        scale = 1.0 / (bs * bs)
+        self.w1 = nn.Parameter(scale * torch.rand(2, num_blocks, bs, bs))
+        self.b1 = nn.Parameter(scale * torch.rand(2, num_blocks, bs))
+        self.w2 = nn.Parameter(scale * torch.rand(2, num_blocks, bs, bs))
+        self.b2 = nn.Parameter(scale * torch.rand(2, num_blocks, bs))
+
+
+class _BlockParams(nn.Module):
+    def __init__(self, width: int, n_blocks: int, mlp_ratio: float):
+        super().__init__()
+        self.norm1 = nn.GroupNorm(8, width)
+        self.filter = _AFNOParams(width, n_blocks)
+        self.norm2 = nn.GroupNorm(8, width)
+        hidden = int(width * mlp_ratio)
+        self.mlp = nn.Sequential(nn.Conv2d(width, hidden, 1), nn.Identity(), nn.Conv2d(hidden, width, 1))
+
+
+class _PatchEmbedParams(nn.Module):
+    def __init__(self, img_size: int, patch_size: int, in_chans: int, hidden: int, out_dim: int):
+        super().__init__()
+        self.img_size = (img_size, img_size)
+        self.patch_size = (patch_size, patch_size)
+        self.out_size = (img_size // patch_size, img_size // patch_size)
+        self.num_patches = self.out_size[0] * self.out_size[1]
+        self.proj = nn.Sequential(nn.Conv2d(in_chans, hidden, patch_size, patch_size), nn.Identity(),
+                                  nn.Conv2d(hidden, out_dim, 1))
+
+
+class _TimeAggParams(nn.Module):
+    def __init__(self, n_timesteps: int, width: int, kind: str):
+        super().__init__()
+        self.type = kind
+        self.w = nn.Parameter(1.0 / (n_timesteps * width ** 0.5) * torch.randn(n_timesteps, width, width))
+        if kind == "exp_mlp":
+            self.gamma = nn.Parameter(2 ** torch.linspace(-10, 10, width).unsqueeze(0))
+        elif kind != "mlp":
+            raise ValueError(f"unknown time_agg {kind!r}")
+
+
+class DPOTNet(nn.Module):
+    def __init__(self, img_size=224, patch_size=16, mixing_type='afno', in_channels=1, out_channels=4, in_timesteps=1,
+                 out_timesteps=1, n_blocks=4, embed_dim=768, out_layer_dim=32, depth=12, modes=32, mlp_ratio=1.,
+                 n_cls=12, normalize=False, act='gelu', time_agg='exp_mlp'):
+        super().__init__()
+        if act not in ACTIVATIONS:
+            raise KeyError(act)
+        if mixing_type != 'afno':
+            raise ValueError("only mixing_type='afno' exists in the reference")
+        self.in_channels, self.out_channels = in_channels, out_channels
+        self.in_timesteps, self.out_timesteps = in_timesteps, out_timesteps
+        self.n_blocks, self.modes = n_blocks, modes
+        self.num_features = self.embed_dim = embed_dim
+        self.mlp_ratio = mlp_ratio
+        self.normalize, self.time_agg, self.n_cls = normalize, time_agg, n_cls
+        self.mixing_type = mixing_type
+        self.img_size, self.patch_size = img_size, patch_size
+        self.act_name, self._act = act, ops.ACT_IDS[act]
+
+        self.patch_embed = _PatchEmbedParams(img_size, patch_size, in_channels + 3, out_channels * patch_size + 3,
+                                             embed_dim)
+        self.latent_size = self.patch_embed.out_size
+        h = self.latent_size[0]
+        self.pos_embed = nn.Parameter(torch.zeros(1, embed_dim, h, h))
+        self.blocks = nn.ModuleList([_BlockParams(embed_dim, n_blocks, mlp_ratio) for _ in range(depth)])
+        if normalize:
+            self.scale_feats_mu = nn.Linear(2 * in_channels, embed_dim)
+            self.scale_feats_sigma = nn.Linear(2 * in_channels, embed_dim)
+        self.cls_head = nn.Sequential(nn.Linear(embed_dim, embed_dim), nn.Identity(), nn.Linear(embed_dim, embed_dim),
+                                      nn.Identity(), nn.Linear(embed_dim, n_cls))
+        self.time_agg_layer = _TimeAggParams(in_timesteps, embed_dim, time_agg)
+        self.out_layer = nn.Sequential(
+            nn.ConvTranspose2d(embed_dim, out_layer_dim, patch_size, patch_size), nn.Identity(),
+            nn.Conv2d(out_layer_dim, out_layer_dim, 1), nn.Identity(),
+            nn.Conv2d(out_layer_dim, out_channels * out_timesteps, 1))
+        torch.nn.init.trunc_normal_(self.pos_embed, std=.02)
+
+        # coordinate tables of models/dpot.py:350-360 (np.linspace in float64, then cast) - not part of state_dict
+        for name, n in (("_gx", img_size), ("_gy", img_size), ("_gt", in_timesteps)):
+            self.register_buffer(name, torch.tensor(np.linspace(0, 1, n), dtype=torch.float32), persistent=False)
+        self.register_buffer("_tt", torch.linspace(0, 1, in_timesteps), persistent=False)
+
+    # ------------------------------------------------------------------------------------------------
+    def forward(self, x):
+        if not x.is_cuda:
+            raise _lib.DpotHipError("DPOTNet (dpot_amd) runs on MI355X only: move the model and the input to 'cuda'. "
+                                    "There is no CPU fallback.")
+        B, X, Y, T, Cin = x.shape
+        assert X == self.img_size and Y == self.img_size, \
+            f"Input image size ({X}*{Y}) doesn't match model ({self.img_size}*{self.img_size})."
+        assert T == self.in_timesteps and Cin == self.in_channels, "input timesteps / channels mismatch"
+        x = x.float()
+        if self.normalize:
+            # models/dpot.py:366-370 - per-sample statistics + two tiny Linear(2C -> E): O(B*C) host-side glue
+            mu = x.mean(dim=(1, 2, 3), keepdim=True)
+            sigma = x.std(dim=(1, 2, 3), keepdim=True) + 1e-6
+            x = (x - mu) / sigma
+            stat = torch.cat([mu, sigma], dim=-1)[:, 0, 0, 0, :]
+            s_mu = self.scale_feats_mu(stat)
+            s_sigma = self.scale_feats_sigma(stat)
+
+        pe, ta = self.patch_embed.proj, self.time_agg_layer
+        P = self.patch_size
+        h = self.latent_size[0]
+        lat = EmbedFn.apply(x, self.pos_embed, pe[0].weight, pe[0].bias, pe[2].weight, pe[2].bias, ta.w,
+                            ta.gamma if self.time_agg == "exp_mlp" else None, self._gx, self._gy, self._gt, self._tt,
+                            P, self._act)
+        if self.normalize:
+            lat = s_sigma[:, None, :] * lat + s_mu[:, None, :]          # AdaIN (models/dpot.py:386-387)
+        for blk in self.blocks:
+            f = blk.filter
+            lat = BlockFn.apply(lat, blk.norm1.weight, blk.norm1.bias, f.w1, f.b1, f.w2, f.b2, blk.norm2.weight,
+                                blk.norm2.bias, blk.mlp[0].weight, blk.mlp[0].bias, blk.mlp[2].weight,
+                                blk.mlp[2].bias, h, h, self.n_blocks, self.modes, self._act)
+        ol, ch = self.out_layer, self.cls_head
+        pred, cls_pred = HeadFn.apply(lat, ol[0].weight, ol[0].bias, ol[2].weight, ol[2].bias, ol[4].weight,
+                                      ol[4].bias, ch[0].weight, ch[0].bias, ch[2].weight, ch[2].bias, ch[4].weight,
+                                      ch[4].bias, h, h, P, self._act)
+        pred = pred.view(B, X, Y, self.out_timesteps, self.out_channels)
+        if self.normalize:
+            pred = pred * sigma + mu
+        return pred, cls_pred
+
+    def extra_repr(self) -> str:
+        return (f"img_size={self.img_size}, patch_size={self.patch_size}, embed_dim={self.embed_dim}, "
+                f"depth={len(self.blocks)}, n_blocks={self.n_blocks}, modes={self.modes}, act={self.act_name}, "
+                f"backend=libdpot_hip(gfx950)")

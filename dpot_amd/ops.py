@@ -1,0 +1,321 @@
+"""Tensor-level wrappers over the C ABI (include/dpot_hip.h).
+
+PyTorch is used here only as the owner of device memory and of the HIP stream: every function takes
+contiguous fp32 CUDA tensors, passes ``data_ptr()`` / sizes / the current stream to libdpot_hip.so and returns
+tensors.  There is deliberately no CPU or eager-PyTorch fallback.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional, Tuple
+
+import torch
+
+from . import _lib
+from ._lib import GemmDesc, check
+
+Tensor = torch.Tensor
+
+ACT_IDS = {None: 0, "none": 0, "gelu": 1, "tanh": 2, "sigmoid": 3, "relu": 4, "leaky_relu": 5, "softplus": 6,
+           "ELU": 7, "silu": 8}
+EPI_LINEAR, EPI_ACT, EPI_DACT = 0, 1, 2
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _req(t: Tensor, name: str = "tensor") -> Tensor:
+    if not t.is_cuda:
+        raise _lib.DpotHipError(f"{name} must live on the MI355X (got a {t.device} tensor): dpot_amd has no CPU path")
+    if t.dtype != torch.float32:
+        raise _lib.DpotHipError(f"{name} must be float32, got {t.dtype}")
+    if not t.is_contiguous():
+        raise _lib.DpotHipError(f"{name} must be contiguous")
+    return t
+
+
+def _p(t: Optional[Tensor]) -> Optional[int]:
+    return None if t is None else t.data_ptr()
+
+
+# ------------------------------------------------------------------------------------------------------
+# GEMM
+# ------------------------------------------------------------------------------------------------------
+def auto_splitk(M: int, N: int, K: int, batch: int = 1) -> int:
+    return _lib.load().dpot_gemm_auto_splitk(M, N, K, batch)
+
+
+def gemm(A: Tensor, B: Tensor, C_: Tensor, M: int, N: int, K: int, *, transA: bool = False, transB: bool = False,
+         lda: int, ldb: int, ldc: int, batch: int = 1, strideA: int = 0, strideB: int = 0, strideC: int = 0,
+         bias: Optional[Tensor] = None, strideBias: int = 0, act: int = 0, mode: int = EPI_LINEAR,
+         aux: Optional[Tensor] = None, ldaux: int = 0, strideAux: int = 0,
+         preact: Optional[Tensor] = None, ldpre: int = 0, stridePre: int = 0,
+         res: Optional[Tensor] = None, ldres: int = 0, res_div: int = 0, res_mod: int = 0, strideRes: int = 0,
+         accumulate: bool = False, splitk: int = 1, tile: int = 0, tag: int = 0) -> Tensor:
+    """C = epilogue(A @ B) on the matrix cores; see include/dpot_hip.h for the exact semantics."""
+    lib = _lib.load()
+    d = GemmDesc()
+    d.A, d.B, d.C = A.data_ptr(), B.data_ptr(), C_.data_ptr()
+    d.M, d.N, d.K, d.batch = M, N, K, batch
+    d.transA, d.transB = int(transA), int(transB)
+    d.lda, d.ldb, d.ldc = lda, ldb, ldc
+    d.strideA, d.strideB, d.strideC = strideA, strideB, strideC
+    d.bias, d.strideBias = _p(bias), strideBias
+    d.act, d.epi_mode = act, mode
+    d.aux, d.ldaux, d.strideAux = _p(aux), ldaux, strideAux
+    d.preact, d.ldpre, d.stridePre = _p(preact), ldpre, stridePre
+    d.res, d.ldres, d.res_div, d.res_mod, d.strideRes = _p(res), ldres, res_div, res_mod, strideRes
+    d.accumulate = int(accumulate)
+    d.tile = tile
+    d.tag = tag
+    ws = None
+    if splitk > 1:
+        ws = torch.empty(splitk * batch * M * N, dtype=torch.float32, device=A.device)
+        d.splitk, d.workspace = splitk, ws.data_ptr()
+    else:
+        d.splitk, d.workspace = 1, None
+    check(lib.dpot_gemm_f32(C.byref(d), _stream()), "gemm_f32")
+    return C_
+
+
+def linear_fwd(x: Tensor, W: Tensor, bias: Optional[Tensor], act: int = 0, save_pre: bool = False,
+               res: Optional[Tensor] = None, res_div: int = 0, res_mod: int = 0,
+               ldw: Optional[int] = None) -> Tuple[Tensor, Optional[Tensor]]:
+    """y[M,N] = act(x[M,K] @ W[N,K]^T + bias) (+ res)   -  nn.Linear / 1x1-conv semantics."""
+    M, K = x.shape
+    N = W.shape[0]
+    y = torch.empty(M, N, dtype=torch.float32, device=x.device)
+    pre = torch.empty_like(y) if save_pre else None
+    gemm(x, W, y, M, N, K, transB=True, lda=x.stride(0), ldb=ldw or W.stride(0), ldc=N, bias=bias, act=act,
+         mode=EPI_ACT if act else EPI_LINEAR, preact=pre, ldpre=N, res=res, ldres=N, res_div=res_div,
+         res_mod=res_mod)
+    return y, pre
+
+
+def linear_bwd_data(dy: Tensor, W: Tensor, act: int = 0, aux: Optional[Tensor] = None) -> Tensor:
+    """dx[M,K] = dy[M,N] @ W[N,K]  (optionally times act'(aux[M,K]))."""
+    M, N = dy.shape
+    K = W.shape[1]
+    dx = torch.empty(M, K, dtype=torch.float32, device=dy.device)
+    gemm(dy, W, dx, M, K, N, transB=False, lda=dy.stride(0), ldb=W.stride(0), ldc=K, act=act,
+         mode=EPI_DACT if aux is not None else EPI_LINEAR, aux=aux, ldaux=K)
+    return dx
+
+
+def linear_bwd_weight(dy: Tensor, x: Tensor) -> Tensor:
+    """dW[N,K] = dy[M,N]^T @ x[M,K]   (split-K over the token dimension)."""
+    M, N = dy.shape
+    K = x.shape[1]
+    dW = torch.empty(N, K, dtype=torch.float32, device=dy.device)
+    gemm(dy, x, dW, N, K, M, transA=True, transB=False, lda=dy.stride(0), ldb=x.stride(0), ldc=K,
+         splitk=auto_splitk(N, K, M))
+    return dW
+
+
+# ------------------------------------------------------------------------------------------------------
+# spectral ops
+# ------------------------------------------------------------------------------------------------------
+def rfft2(x: Tensor, h: int, w: int, nb: int, mx: int, my: int, col_weights: int = 0) -> Tensor:
+    """x[B,h*w,E] -> spec[B*mx*my, 2E] (planar per channel block)."""
+    B, E = x.shape[0], x.shape[-1]
+    spec = torch.empty(B * mx * my, 2 * E, dtype=torch.float32, device=x.device)
+    check(_lib.load().dpot_rfft2(x.data_ptr(), spec.data_ptr(), B, h, w, E, nb, mx, my, col_weights, _stream()),
+          "rfft2")
+    return spec
+
+
+def irfft2(spec: Tensor, B: int, h: int, w: int, E: int, nb: int, mx: int, my: int, col_weights: int = 1,
+           res: Optional[Tensor] = None) -> Tensor:
+    y = torch.empty(B, h * w, E, dtype=torch.float32, device=spec.device)
+    check(_lib.load().dpot_irfft2(spec.data_ptr(), _p(res), y.data_ptr(), B, h, w, E, nb, mx, my, col_weights,
+                                  _stream()), "irfft2")
+    return y
+
+
+def afno_pack(w: Tensor, b: Tensor) -> Tuple[Tensor, Tensor]:
+    _, nb, bs, _ = w.shape
+    wbig = torch.empty(nb, 2 * bs, 2 * bs, dtype=torch.float32, device=w.device)
+    bbig = torch.empty(nb, 2 * bs, dtype=torch.float32, device=w.device)
+    check(_lib.load().dpot_afno_pack(w.data_ptr(), b.data_ptr(), wbig.data_ptr(), bbig.data_ptr(), nb, bs,
+                                     _stream()), "afno_pack")
+    return wbig, bbig
+
+
+def afno_unpack_grad(dwbig: Tensor, dbbig: Tensor, nb: int, bs: int) -> Tuple[Tensor, Tensor]:
+    dw = torch.empty(2, nb, bs, bs, dtype=torch.float32, device=dwbig.device)
+    db = torch.empty(2, nb, bs, dtype=torch.float32, device=dwbig.device)
+    check(_lib.load().dpot_afno_unpack_grad(dwbig.data_ptr(), dbbig.data_ptr(), dw.data_ptr(), db.data_ptr(), nb, bs,
+                                            _stream()), "afno_unpack_grad")
+    return dw, db
+
+
+# ------------------------------------------------------------------------------------------------------
+# GroupNorm
+# ------------------------------------------------------------------------------------------------------
+def groupnorm_fwd(x: Tensor, gamma: Tensor, beta: Tensor, G: int = 8, eps: float = 1e-5):
+    B, T, E = x.shape
+    y = torch.empty_like(x)
+    mean = torch.empty(B, G, dtype=torch.float32, device=x.device)
+    rstd = torch.empty(B, G, dtype=torch.float32, device=x.device)
+    check(_lib.load().dpot_groupnorm_fwd(x.data_ptr(), gamma.data_ptr(), beta.data_ptr(), y.data_ptr(),
+                                         mean.data_ptr(), rstd.data_ptr(), B, T, E, G, eps, _stream()), "groupnorm_fwd")
+    return y, mean, rstd
+
+
+def groupnorm_bwd(dy: Tensor, x: Tensor, mean: Tensor, rstd: Tensor, gamma: Tensor, G: int = 8,
+                  add: Optional[Tensor] = None):
+    B, T, E = x.shape
+    dx = torch.empty_like(x)
+    dgamma = torch.empty(E, dtype=torch.float32, device=x.device)
+    dbeta = torch.empty(E, dtype=torch.float32, device=x.device)
+    part = torch.empty(2, B, E, dtype=torch.float32, device=x.device)
+    check(_lib.load().dpot_groupnorm_bwd(dy.data_ptr(), x.data_ptr(), mean.data_ptr(), rstd.data_ptr(),
+                                         gamma.data_ptr(), _p(add), dx.data_ptr(), dgamma.data_ptr(),
+                                         dbeta.data_ptr(), part.data_ptr(), B, T, E, G, _stream()), "groupnorm_bwd")
+    return dx, dgamma, dbeta
+
+
+# ------------------------------------------------------------------------------------------------------
+# data movement / small ops
+# ------------------------------------------------------------------------------------------------------
+def patchify(x: Tensor, gx: Tensor, gy: Tensor, gt: Tensor, P: int) -> Tensor:
+    B, X, Y, T, Cc = x.shape
+    K0 = (Cc + 3) * P * P
+    A = torch.empty(B * (X // P) * (Y // P) * T, K0, dtype=torch.float32, device=x.device)
+    check(_lib.load().dpot_patchify(x.data_ptr(), gx.data_ptr(), gy.data_ptr(), gt.data_ptr(), A.data_ptr(), B, X, Y,
+                                    T, Cc, P, _stream()), "patchify")
+    return A
+
+
+def unpatchify(dA: Tensor, B: int, X: int, Y: int, T: int, Cc: int, P: int) -> Tensor:
+    dx = torch.empty(B, X, Y, T, Cc, dtype=torch.float32, device=dA.device)
+    check(_lib.load().dpot_unpatchify(dA.data_ptr(), dx.data_ptr(), B, X, Y, T, Cc, P, _stream()), "unpatchify")
+    return dx
+
+
+def pixel_shuffle(z: Tensor, B: int, h: int, w: int, P: int, Cc: int, inverse: bool = False) -> Tensor:
+    """inverse=False: z[(b,px,py,i,j),Cc] -> out[b,px*P+i,py*P+j,Cc];  inverse=True: the other way."""
+    out = torch.empty(B * h * w * P * P, Cc, dtype=torch.float32, device=z.device)
+    if not inverse:
+        out = out.view(B, h * P, w * P, Cc)
+        check(_lib.load().dpot_pixel_shuffle(z.data_ptr(), out.data_ptr(), B, h, w, P, Cc, 0, _stream()),
+              "pixel_shuffle")
+    else:
+        check(_lib.load().dpot_pixel_shuffle(z.data_ptr(), out.data_ptr(), B, h, w, P, Cc, 1, _stream()),
+              "pixel_shuffle")
+    return out
+
+
+def copy2d_pad(src: Tensor, sR: int, sC: int, dR: int, dC: int) -> Tensor:
+    dst = torch.empty(dR, dC, dtype=torch.float32, device=src.device)
+    check(_lib.load().dpot_copy2d_pad(src.data_ptr(), sR, sC, dst.data_ptr(), dR, dC, _stream()), "copy2d_pad")
+    return dst
+
+
+def transpose2d(src: Tensor, nbatch: int, R: int, Cn: int) -> Tensor:
+    dst = torch.empty(nbatch, Cn, R, dtype=torch.float32, device=src.device)
+    check(_lib.load().dpot_transpose2d(src.data_ptr(), dst.data_ptr(), nbatch, R, Cn, _stream()), "transpose2d")
+    return dst
+
+
+def colsum(X: Tensor, M: int, N: int, ld: Optional[int] = None) -> Tensor:
+    lib = _lib.load()
+    out = torch.empty(N, dtype=torch.float32, device=X.device)
+    part = torch.empty(lib.dpot_colsum_parts(M), N, dtype=torch.float32, device=X.device)
+    check(lib.dpot_colsum(X.data_ptr(), M, N, ld or N, out.data_ptr(), part.data_ptr(), _stream()), "colsum")
+    return out
+
+
+def group_rowsum(X: Tensor, B: int, R: int, T: int, N: int) -> Tensor:
+    out = torch.empty(R, N, dtype=torch.float32, device=X.device)
+    check(_lib.load().dpot_group_rowsum(X.data_ptr(), out.data_ptr(), B, R, T, N, _stream()), "group_rowsum")
+    return out
+
+
+def token_mean(x: Tensor) -> Tensor:
+    B, T, E = x.shape
+    y = torch.empty(B, E, dtype=torch.float32, device=x.device)
+    check(_lib.load().dpot_token_mean(x.data_ptr(), y.data_ptr(), B, T, E, _stream()), "token_mean")
+    return y
+
+
+def token_mean_bwd(dy: Tensor, T: int, add: Optional[Tensor] = None) -> Tensor:
+    B, E = dy.shape
+    dx = torch.empty(B, T, E, dtype=torch.float32, device=dy.device)
+    check(_lib.load().dpot_token_mean_bwd(dy.data_ptr(), _p(add), dx.data_ptr(), B, T, E, _stream()),
+          "token_mean_bwd")
+    return dx
+
+
+def add(a: Tensor, b: Tensor) -> Tensor:
+    y = torch.empty_like(a)
+    check(_lib.load().dpot_add(a.data_ptr(), b.data_ptr(), y.data_ptr(), a.numel(), _stream()), "add")
+    return y
+
+
+def scale_shift(x: Tensor, scale: Tensor, shift: Tensor) -> Tensor:
+    B, T, E = x.shape
+    y = torch.empty_like(x)
+    check(_lib.load().dpot_scale_shift(x.data_ptr(), scale.data_ptr(), shift.data_ptr(), y.data_ptr(), B, T, E,
+                                       _stream()), "scale_shift")
+    return y
+
+
+def timeagg_scale_w(w: Tensor, gamma: Tensor, tt: Tensor) -> Tensor:
+    T, E, _ = w.shape
+    ws = torch.empty_like(w)
+    check(_lib.load().dpot_timeagg_scale_w(w.data_ptr(), gamma.data_ptr(), tt.data_ptr(), ws.data_ptr(), T, E,
+                                           _stream()), "timeagg_scale_w")
+    return ws
+
+
+def timeagg_scale_w_bwd(dws: Tensor, w: Tensor, gamma: Tensor, tt: Tensor) -> Tuple[Tensor, Tensor]:
+    T, E, _ = w.shape
+    dw = torch.empty_like(w)
+    dgamma = torch.empty(1, E, dtype=torch.float32, device=w.device)
+    check(_lib.load().dpot_timeagg_scale_w_bwd(dws.data_ptr(), w.data_ptr(), gamma.data_ptr(), tt.data_ptr(),
+                                               dw.data_ptr(), dgamma.data_ptr(), T, E, _stream()),
+          "timeagg_scale_w_bwd")
+    return dw, dgamma
+
+
+# ------------------------------------------------------------------------------------------------------
+# loss / optimiser
+# ------------------------------------------------------------------------------------------------------
+def rel_l2_fwd(x: Tensor, y: Tensor, mask: Optional[Tensor], B: int, S: int, Cc: int, Tt: int):
+    stats = torch.empty(B, Cc, 4, dtype=torch.float32, device=x.device)
+    loss = torch.empty(1, dtype=torch.float32, device=x.device)
+    check(_lib.load().dpot_rel_l2_fwd(x.data_ptr(), y.data_ptr(), _p(mask), stats.data_ptr(), loss.data_ptr(), B, S,
+                                      Cc, Tt, _stream()), "rel_l2_fwd")
+    return loss, stats
+
+
+def rel_l2_bwd(x: Tensor, y: Tensor, mask: Optional[Tensor], stats: Tensor, gloss: Tensor, B: int, S: int, Cc: int,
+               Tt: int) -> Tensor:
+    dx = torch.empty_like(x)
+    check(_lib.load().dpot_rel_l2_bwd(x.data_ptr(), y.data_ptr(), _p(mask), stats.data_ptr(), gloss.data_ptr(),
+                                      dx.data_ptr(), B, S, Cc, Tt, _stream()), "rel_l2_bwd")
+    return dx
+
+
+def sumsq(g: Tensor, out: Tensor, part: Tensor, accumulate: bool = False) -> Tensor:
+    check(_lib.load().dpot_sumsq(g.data_ptr(), g.numel(), out.data_ptr(), part.data_ptr(), int(accumulate),
+                                 _stream()), "sumsq")
+    return out
+
+
+def adam_step(p: Tensor, g: Tensor, m: Tensor, v: Tensor, hyper: Tensor, sumsq_: Optional[Tensor],
+              grad_scale: float = 1.0) -> None:
+    check(_lib.load().dpot_adam_step(p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), p.numel(),
+                                     hyper.data_ptr(), _p(sumsq_), grad_scale, _stream()), "adam_step")
+
+
+def noise_inject(xx: Tensor, eps: Tensor, noise_scale: float) -> Tensor:
+    B, Cc = xx.shape[0], xx.shape[-1]
+    S = xx.numel() // (B * Cc)
+    out = torch.empty_like(xx)
+    norms = torch.empty(B, Cc, dtype=torch.float32, device=xx.device)
+    check(_lib.load().dpot_noise_inject(xx.data_ptr(), eps.data_ptr(), out.data_ptr(), norms.data_ptr(), noise_scale,
+                                        B, S, Cc, _stream()), "noise_inject")
+    return out

@@ -1,0 +1,234 @@
+/*
+ * dpot_hip.h - C ABI of libdpot_hip.so: the MI355X (gfx950 / CDNA4) kernels behind the DPOT
+ * auto-regressive forward/backward step.
+ *
+ * The reference (HaoZhongkai/DPOT) has no FFI/plugin layer: its hot path is Python on top of PyTorch
+ * ATen.  This header is therefore the "inner face" of the drop-in boundary: the
+ * entry points a maintainer binds (ctypes - see INTEGRATION.md) to replace the ATen calls made by
+ *   models/dpot.py:51-110   AFNO2D.forward      -> dpot_rfft2 / dpot_gemm_f32 / dpot_irfft2
+ *   models/dpot.py:142,152  GroupNorm(8, width) -> dpot_groupnorm_fwd / _bwd
+ *   models/dpot.py:157-161  Block.mlp (1x1 conv)-> dpot_gemm_f32 (bias + activation epilogues)
+ *   models/dpot.py:198-202  PatchEmbed          -> dpot_patchify + dpot_gemm_f32
+ *   models/dpot.py:226-234  TimeAggregator      -> dpot_timeagg_scale_w + dpot_gemm_f32
+ *   models/dpot.py:315-321  out_layer           -> dpot_gemm_f32 + dpot_pixel_shuffle
+ *   utils/criterion.py:38-59 SimpleLpLoss       -> dpot_rel_l2_fwd / _bwd
+ *   utils/optimizer.py:9-52 adam()              -> dpot_sumsq + dpot_adam_step
+ *
+ * Conventions
+ *   - plain pointers and sizes only; every pointer is a DEVICE pointer unless stated otherwise
+ *   - all tensors are fp32; activations are channels-last: [B, h, w, E] == row-major [B*h*w, E]
+ *   - the caller owns every buffer (including workspaces); the library never allocates or frees
+ *   - kernels are enqueued on `stream` (a hipStream_t passed as void*) and never synchronise, so every
+ *     call is legal inside HIP stream capture (hipGraph)
+ *   - return value: 0 on success, negative DPOT_E* on error; dpot_last_error() gives the message
+ *   - re-entrant and stateless (no global state besides the thread-local error string)
+ */
+#ifndef DPOT_HIP_H
+#define DPOT_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DPOT_OK 0
+#define DPOT_EINVAL (-1)   /* bad shape / argument            */
+#define DPOT_EUNSUP (-2)   /* unsupported size                */
+#define DPOT_EHIP (-3)     /* HIP runtime error on launch     */
+
+typedef void* dpot_stream_t; /* hipStream_t */
+
+/* activation ids (models/dpot.py:19 ACTIVATION table) */
+enum {
+  DPOT_ACT_NONE = 0,
+  DPOT_ACT_GELU = 1,      /* exact erf GELU (nn.GELU() default) */
+  DPOT_ACT_TANH = 2,
+  DPOT_ACT_SIGMOID = 3,
+  DPOT_ACT_RELU = 4,
+  DPOT_ACT_LEAKY_RELU = 5, /* slope 0.1 */
+  DPOT_ACT_SOFTPLUS = 6,
+  DPOT_ACT_ELU = 7,
+  DPOT_ACT_SILU = 8
+};
+
+/* epilogue modes of dpot_gemm_f32 */
+enum {
+  DPOT_EPI_LINEAR = 0, /* v                                  */
+  DPOT_EPI_ACT = 1,    /* act(v)                             */
+  DPOT_EPI_DACT = 2    /* v * act'(aux[m,n])  (backward)     */
+};
+
+int dpot_version(void);
+const char* dpot_last_error(void);
+
+/* ------------------------------------------------------------------------------------------------
+ * fp32 GEMM on the CDNA4 matrix cores (v_mfma_f32_32x32x2_f32: exact fp32, k-ordered fma chain).
+ *
+ *   for b in [0,batch):   C_b[m,n] = epilogue( sum_k A_b[m,k] * B_b[k,n] )
+ *
+ *   transA = 0: A_b is [M,K] row-major (lda = row stride)   transA = 1: A_b is [K,M] row-major
+ *   transB = 0: B_b is [K,N] row-major (ldb = row stride)   transB = 1: B_b is [N,K] row-major
+ *   X_b = X + b * strideX  (in floats)
+ *
+ *   epilogue, in this order:
+ *       v  = acc
+ *       v += bias[b*strideBias + n]                               (bias != NULL)
+ *       preact[b*stridePre + m*ldpre + n] = v                      (preact != NULL)
+ *       v  = act(v)               (epi_mode == DPOT_EPI_ACT)
+ *       v  = v * act'(aux[m,n])   (epi_mode == DPOT_EPI_DACT; aux = saved pre-activation)
+ *       v += res[b*strideRes + ((m / res_div) % res_mod) * ldres + n]   (res != NULL)
+ *       v += C_b[m,n]             (accumulate != 0)
+ *       C_b[m*ldc + n] = v
+ *
+ *   splitk > 1 partitions K over `splitk` workgroups per tile; partial sums go to `workspace`
+ *   (splitk * batch * M * N floats) and a second kernel reduces them in a fixed order (deterministic)
+ *   and applies the epilogue.
+ * ------------------------------------------------------------------------------------------------ */
+typedef struct dpot_gemm_desc {
+  const float* A;
+  const float* B;
+  float* C;
+  int32_t M, N, K;
+  int32_t batch;
+  int32_t transA, transB;
+  int32_t lda, ldb, ldc;
+  int64_t strideA, strideB, strideC;
+  const float* bias;
+  int64_t strideBias;
+  int32_t act;      /* DPOT_ACT_*  */
+  int32_t epi_mode; /* DPOT_EPI_*  */
+  const float* aux;
+  int32_t ldaux;
+  int64_t strideAux;
+  float* preact;
+  int32_t ldpre;
+  int64_t stridePre;
+  const float* res;
+  int32_t ldres;
+  int32_t res_div, res_mod; /* 0 -> plain residual (res_div = 1, res_mod = infinity) */
+  int64_t strideRes;
+  int32_t accumulate;
+  int32_t splitk;
+  float* workspace;
+  int32_t tile; /* 0 = auto, 64 or 128 = force BMxBN tile */
+  int32_t tag;  /* 1 = launch the separately-named AFNO-mixer instantiation (profiling identity only) */
+} dpot_gemm_desc;
+
+int dpot_gemm_f32(const dpot_gemm_desc* d, dpot_stream_t stream);
+/* bytes of workspace dpot_gemm_f32 needs for this descriptor (0 when splitk <= 1) */
+int64_t dpot_gemm_workspace_bytes(const dpot_gemm_desc* d);
+/* the split-K factor the library would pick for this shape (>= 1) */
+int dpot_gemm_auto_splitk(int M, int N, int K, int batch);
+
+/* ------------------------------------------------------------------------------------------------
+ * rfft2 / irfft2, norm="ortho", over the two spatial axes of a channels-last field, done as two in-LDS
+ * direct DFT passes (latent grids are 16x16 / 32x32: a dense DFT is cheaper than a strided FFT plan).
+ *
+ * spectrum layout ("planar per channel block"): spec[B, mx, my, nb, 2, bs]  (2 = re, im; bs = E/nb)
+ *   -> row (b,kx,ky) of the [B*mx*my, 2E] matrix holds, per channel block, [re(bs) | im(bs)], which is
+ *      exactly the A operand of the block-diagonal complex MLP written as a real GEMM with
+ *      Wbig = [[Wr, Wi], [-Wi, Wr]].
+ * Only modes kx < mx, ky < my are produced / consumed (models/dpot.py:70-94 keeps [:modes,:modes] of the
+ * half spectrum; everything else is zero).
+ *
+ * col_weights: 0 -> every ky column weight 1            (true rfft2 / adjoint of rfft2)
+ *              1 -> interior ky columns weight 2         (true irfft2 / adjoint of irfft2)
+ *   dpot_rfft2 (x, w=0) = rfft2(x)           dpot_rfft2 (g, w=1) = d irfft2 / d spectrum  applied to g
+ *   dpot_irfft2(S, w=1) = irfft2(S, s=(h,w))  dpot_irfft2(G, w=0) = d rfft2 / d x applied to G
+ * dpot_irfft2 optionally adds `res` ([B,h,w,E]) - the "+ x_orig" of models/dpot.py:106.
+ * ------------------------------------------------------------------------------------------------ */
+int dpot_rfft2(const float* x, float* spec, int B, int h, int w, int E, int nb, int mx, int my,
+               int col_weights, dpot_stream_t stream);
+int dpot_irfft2(const float* spec, const float* res, float* y, int B, int h, int w, int E, int nb, int mx,
+                int my, int col_weights, dpot_stream_t stream);
+
+/* AFNO weight packing: w[2,nb,bs,bs], b[2,nb,bs] -> Wbig[nb,2bs,2bs] = [[Wr,Wi],[-Wi,Wr]], bbig[nb,2,bs]
+ * and the adjoint (gradients back to the reference layout).  models/dpot.py:45-48,72-94 */
+int dpot_afno_pack(const float* w, const float* b, float* wbig, float* bbig, int nb, int bs,
+                   dpot_stream_t stream);
+int dpot_afno_unpack_grad(const float* dwbig, const float* dbbig, float* dw, float* db, int nb, int bs,
+                          dpot_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * GroupNorm(G, E) on channels-last x[B, T, E] (T = h*w tokens), eps inside rsqrt.  models/dpot.py:142,152
+ * fwd: y = (x - mean[b,g]) * rstd[b,g] * gamma[c] + beta[c]; mean/rstd [B,G] are saved for backward.
+ * bwd: dx = rstd * (gamma*dy - mean_g(gamma*dy) - xhat * mean_g(gamma*dy*xhat)) (+ add), and
+ *      dgamma/dbeta via per-sample partials part[2,B,E] that are then reduced over B in a fixed order.
+ * ------------------------------------------------------------------------------------------------ */
+int dpot_groupnorm_fwd(const float* x, const float* gamma, const float* beta, float* y, float* mean,
+                       float* rstd, int B, int T, int E, int G, float eps, dpot_stream_t stream);
+int dpot_groupnorm_bwd(const float* dy, const float* x, const float* mean, const float* rstd,
+                       const float* gamma, const float* add, float* dx, float* dgamma, float* dbeta,
+                       float* part /* [2,B,E] */, int B, int T, int E, int G, dpot_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * data movement / small ops
+ * ------------------------------------------------------------------------------------------------ */
+/* x[B,X,Y,T,C] -> A[(b,px,py,t), (c,i,j)], c in [0,C+3): channels C..C+2 are the (x,y,t) unit grid
+ * (models/dpot.py:350-360,374-375); gx/gy/gt are the grid coordinate tables (X, Y, T floats). */
+int dpot_patchify(const float* x, const float* gx, const float* gy, const float* gt, float* A, int B, int X,
+                  int Y, int T, int C, int P, dpot_stream_t stream);
+/* adjoint w.r.t. x: dA[(b,px,py,t), (c,i,j)] -> dx[B,X,Y,T,C]  (grid columns ignored) */
+int dpot_unpatchify(const float* dA, float* dx, int B, int X, int Y, int T, int C, int P,
+                    dpot_stream_t stream);
+/* z[(b,px,py,i,j), Cc] <-> out[b, px*P+i, py*P+j, Cc]   (ConvTranspose2d k=s=P pixel order) */
+int dpot_pixel_shuffle(const float* z, float* out, int B, int h, int w, int P, int Cc, int inverse,
+                       dpot_stream_t stream);
+/* dst[dR,dC] = src[0:dR,0:dC] zero-filled outside src[sR,sC]  (pad or crop a dense 2-D matrix) */
+int dpot_copy2d_pad(const float* src, int sR, int sC, float* dst, int dR, int dC, dpot_stream_t stream);
+/* dst[C,R] = src[R,C]^T   (batched: nbatch consecutive matrices) */
+int dpot_transpose2d(const float* src, float* dst, int nbatch, int R, int C, dpot_stream_t stream);
+/* out[n] = sum_m X[m*ld + n], m in [0,M): two-stage deterministic column sum; part = [parts, N] scratch
+ * with parts = dpot_colsum_parts(M) */
+int dpot_colsum_parts(int M);
+int dpot_colsum(const float* X, int M, int N, int ld, float* out, float* part, dpot_stream_t stream);
+/* out[r, n] = sum_{b,t} X[((b*R + r)*T + t)*N + n]   (pos_embed gradient: sum over batch and time) */
+int dpot_group_rowsum(const float* X, float* out, int B, int R, int T, int N, dpot_stream_t stream);
+/* y[b,e] = mean_t x[b,t,e]  and its adjoint dx[b,t,e] = dy[b,e]/T (+ add[b,t,e]) */
+int dpot_token_mean(const float* x, float* y, int B, int T, int E, dpot_stream_t stream);
+int dpot_token_mean_bwd(const float* dy, const float* add, float* dx, int B, int T, int E,
+                        dpot_stream_t stream);
+/* y = a + b (n floats) */
+int dpot_add(const float* a, const float* b, float* y, int64_t n, dpot_stream_t stream);
+/* y[b,t,e] = x[b,t,e] * scale[b,e] + shift[b,e]  (AdaIN, models/dpot.py:386-387) */
+int dpot_scale_shift(const float* x, const float* scale, const float* shift, float* y, int B, int T, int E,
+                     dpot_stream_t stream);
+
+/* TimeAggregator 'exp_mlp' (models/dpot.py:229-232): ws[t,i,j] = w[t,i,j] * cos(tt[t] * gamma[i]) and the
+ * adjoint: dw = dws * cos(.), dgamma[i] = sum_{t,j} dws[t,i,j] * w[t,i,j] * (-sin(tt[t]*gamma[i])) * tt[t] */
+int dpot_timeagg_scale_w(const float* w, const float* gamma, const float* tt, float* ws, int T, int E,
+                         dpot_stream_t stream);
+int dpot_timeagg_scale_w_bwd(const float* dws, const float* w, const float* gamma, const float* tt, float* dw,
+                             float* dgamma, int T, int E, dpot_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * loss / optimiser
+ * ------------------------------------------------------------------------------------------------ */
+/* masked relative L2 summed over the batch (SimpleLpLoss(size_average=False), utils/criterion.py:38-59).
+ * x,y: [B, S, C] (S = X*Y*T), mask: [B, Sm, C] with S % Sm == 0 broadcast over the time axis (or NULL).
+ * stats[B, C, 4] = {sum d^2, sum y^2, sum mask, unused}; loss: 1 float.  bwd: dx = gloss[0] * dloss/dx. */
+int dpot_rel_l2_fwd(const float* x, const float* y, const float* mask, float* stats, float* loss, int B,
+                    int S, int C, int Tt, dpot_stream_t stream);
+int dpot_rel_l2_bwd(const float* x, const float* y, const float* mask, const float* stats,
+                    const float* gloss, float* dx, int B, int S, int C, int Tt, dpot_stream_t stream);
+
+/* out[0] (+)= sum g[i]^2 over n floats (fixed-order two-stage reduction; part = 1024 floats scratch) */
+int dpot_sumsq(const float* g, int64_t n, float* out, float* part, int accumulate, dpot_stream_t stream);
+/* One Adam step over a flat fp32 buffer (utils/optimizer.py:26-52) with the clip of
+ * train_temporal.py:228 folded in:  g' = g * grad_scale * min(1, max_norm / (sqrt(sumsq[0])*grad_scale + 1e-6));
+ * g' += wd*p; m = b1*m + (1-b1)*g'; v = b2*v + (1-b2)*g'^2; p -= lr/bc1 * m / (sqrt(v)/sqrt(bc2) + eps).
+ * hyper (DEVICE, 8 floats) = {lr, beta1, beta2, eps, weight_decay, bias_corr1, bias_corr2, max_norm};
+ * sumsq may be NULL (no clipping). */
+int dpot_adam_step(float* p, const float* g, float* m, float* v, int64_t n, const float* hyper,
+                   const float* sumsq, float grad_scale, dpot_stream_t stream);
+
+/* xx_out = xx + noise_scale * ||xx||_2(over X,Y,T per (b,c)) * eps   (train_temporal.py:205)
+ * xx, eps: [B, S, C]; norms: [B, C] scratch */
+int dpot_noise_inject(const float* xx, const float* eps, float* out, float* norms, float noise_scale, int B,
+                      int S, int C, dpot_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DPOT_HIP_H */

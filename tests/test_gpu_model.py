@@ -1,0 +1,308 @@
+"""GPU parity tests, stage and model level: the HIP path against (a) the committed golden vectors generated from
+the reference (oracle/make_golden.py) and (b) the CPU oracle on the same seeded inputs; plus size-independent
+properties at the full BASELINE size (DPOT-Tiny, B=32)."""
+from collections import OrderedDict
+
+import numpy as np
+import pytest
+import torch
+
+from helpers import assert_close, assert_sub, load
+from oracle import dpot_ref as R
+
+pytestmark = pytest.mark.gpu
+
+
+def build(kw, salt):
+    from dpot_amd import DPOTNet
+    cfg = R.DPOTConfig(**kw)
+    m = DPOTNet(**kw)
+    m.load_state_dict(R.recipe_state_dict(cfg, salt=salt))
+    return m.cuda(), cfg
+
+
+def grads_of(m):
+    return {k: p.grad for k, p in m.named_parameters()}
+
+
+# ------------------------------------------------------------------------------------------------------
+def _block_fn(m, x, h):
+    from dpot_amd.functional import BlockFn
+    blk = m.blocks[0]
+    f = blk.filter
+    return BlockFn.apply(x, blk.norm1.weight, blk.norm1.bias, f.w1, f.b1, f.w2, f.b2, blk.norm2.weight,
+                         blk.norm2.bias, blk.mlp[0].weight, blk.mlp[0].bias, blk.mlp[2].weight, blk.mlp[2].bias, h, h,
+                         m.n_blocks, m.modes, m._act)
+
+
+@pytest.mark.parametrize("name", ["g1_afno_trunc", "g1_afno_tiny"])
+def test_afno_mixer_golden(name):
+    """AFNO2D alone (golden g1): drive the BlockFn pieces = rfft2 -> 2 GEMMs -> irfft2 + residual, fwd and bwd"""
+    from dpot_amd import ops
+    fx = load(name)
+    B, h, E, nb, modes = (int(fx[k]) for k in ("B", "h", "E", "nb", "modes"))
+    cfg = R.DPOTConfig(img_size=h * 8, patch_size=8, embed_dim=E, n_blocks=nb, modes=modes, depth=1)
+    pre = "blocks.0.filter."
+    sd = {k[len(pre):]: v.cuda().requires_grad_(True) for k, v in R.recipe_state_dict(cfg, salt=3).items()
+          if k.startswith(pre)}
+    x = R.recipe_input((B, h, h, E), salt=11)
+    up = (R.recipe_input((B, h, h, E), salt=12) * 0.3)
+
+    class MixFn(torch.autograd.Function):                      # the mixer slice of BlockFn, same kernel sequence
+        @staticmethod
+        def forward(ctx, xx, w1, b1, w2, b2):
+            bs = E // nb
+            mx, my = min(modes, h), min(modes, h // 2 + 1)
+            Mm = B * mx * my
+            S = ops.rfft2(xx, h, h, nb, mx, my, 0)
+            wb1, bb1 = ops.afno_pack(w1, b1)
+            wb2, bb2 = ops.afno_pack(w2, b2)
+            kw = dict(lda=2 * E, ldb=2 * bs, ldc=2 * E, batch=nb, strideA=2 * bs, strideB=4 * bs * bs,
+                      strideC=2 * bs)
+            O1, O1pre = torch.empty(Mm, 2 * E, device="cuda"), torch.empty(Mm, 2 * E, device="cuda")
+            ops.gemm(S, wb1, O1, Mm, 2 * bs, 2 * bs, bias=bb1, strideBias=2 * bs, act=1, mode=ops.EPI_ACT,
+                     preact=O1pre, ldpre=2 * E, stridePre=2 * bs, **kw)
+            O2 = torch.empty_like(O1)
+            ops.gemm(O1, wb2, O2, Mm, 2 * bs, 2 * bs, bias=bb2, strideBias=2 * bs, **kw)
+            ctx.save_for_backward(S, O1pre, O1, wb1, wb2)
+            ctx.c = (bs, mx, my, Mm, kw)
+            return ops.irfft2(O2, B, h, h, E, nb, mx, my, 1, res=xx)
+
+        @staticmethod
+        def backward(ctx, dy):
+            S, O1pre, O1, wb1, wb2 = ctx.saved_tensors
+            bs, mx, my, Mm, kw = ctx.c
+            dy = dy.contiguous()
+            dO2 = ops.rfft2(dy, h, h, nb, mx, my, 1)
+            dO1pre = torch.empty(Mm, 2 * E, device="cuda")
+            ops.gemm(dO2, wb2, dO1pre, Mm, 2 * bs, 2 * bs, transB=True, act=1, mode=ops.EPI_DACT, aux=O1pre,
+                     ldaux=2 * E, strideAux=2 * bs, **kw)
+            wkw = dict(transA=True, lda=2 * E, ldb=2 * E, ldc=2 * bs, batch=nb, strideA=2 * bs, strideB=2 * bs,
+                       strideC=4 * bs * bs, splitk=ops.auto_splitk(2 * bs, 2 * bs, Mm, nb))
+            dwb2 = torch.empty(nb, 2 * bs, 2 * bs, device="cuda")
+            ops.gemm(O1, dO2, dwb2, 2 * bs, 2 * bs, Mm, **wkw)
+            dS = torch.empty(Mm, 2 * E, device="cuda")
+            ops.gemm(dO1pre, wb1, dS, Mm, 2 * bs, 2 * bs, transB=True, **kw)
+            dwb1 = torch.empty(nb, 2 * bs, 2 * bs, device="cuda")
+            ops.gemm(S, dO1pre, dwb1, 2 * bs, 2 * bs, Mm, **wkw)
+            dw1, db1 = ops.afno_unpack_grad(dwb1, ops.colsum(dO1pre, Mm, 2 * E), nb, bs)
+            dw2, db2 = ops.afno_unpack_grad(dwb2, ops.colsum(dO2, Mm, 2 * E), nb, bs)
+            return ops.irfft2(dS, B, h, h, E, nb, mx, my, 0, res=dy), dw1, db1, dw2, db2
+
+    xg = x.cuda().view(B, h * h, E).requires_grad_(True)
+    y = MixFn.apply(xg, sd["w1"], sd["b1"], sd["w2"], sd["b2"])
+    (y * up.cuda().view(B, h * h, E)).sum().backward()
+    full = name == "g1_afno_trunc"
+    cmp = (lambda t, k: assert_close(t.reshape(fx[k].shape), fx[k], k)) if full else \
+        (lambda t, k: assert_sub(t, fx, k, k))
+    cmp(y.view(B, h, h, E), "y")
+    cmp(xg.grad.view(B, h, h, E), "dx")
+    for k in ("w1", "b1", "w2", "b2"):
+        cmp(sd[k].grad, "d" + k)
+
+
+def test_block_golden():
+    fx = load("g2_block")
+    B, h, E, nb = (int(fx[k]) for k in ("B", "h", "E", "nb"))
+    kw = dict(img_size=h * 8, patch_size=8, embed_dim=E, n_blocks=nb, modes=32, depth=1, mlp_ratio=2)
+    m, cfg = build(kw, salt=5)
+    from dpot_amd import ops
+    x = R.recipe_input((B, h, h, E), salt=21).cuda().view(B, h * h, E).requires_grad_(True)
+    up = (R.recipe_input((B, h, h, E), salt=22) * 0.3).cuda().view(B, h * h, E)
+    gn, _, _ = ops.groupnorm_fwd(x.detach(), m.blocks[0].norm1.weight.detach(), m.blocks[0].norm1.bias.detach())
+    assert_close(gn.view(B, h, h, E), fx["gn"], "groupnorm")
+    y = _block_fn(m, x, h)
+    (y * up).sum().backward()
+    assert_close(y.view(B, h, h, E), fx["y"], "block.y")
+    assert_close(x.grad.view(B, h, h, E), fx["dx"], "block.dx")
+    g = grads_of(m)
+    for k in fx.files:
+        if k.startswith("d."):
+            assert_close(g["blocks.0." + k[2:]], fx[k], k)
+
+
+def test_embed_and_head_golden():
+    from dpot_amd.functional import EmbedFn, HeadFn
+    kw = dict(R.MINI, depth=1)
+    m, cfg = build(kw, salt=7)
+    B = 2
+    fx = load("g3_embed")
+    x = R.recipe_input((B, cfg.img_size, cfg.img_size, cfg.in_timesteps, cfg.in_channels), salt=31).cuda()
+    x.requires_grad_(True)
+    pe, ta = m.patch_embed.proj, m.time_agg_layer
+    lat = EmbedFn.apply(x, m.pos_embed, pe[0].weight, pe[0].bias, pe[2].weight, pe[2].bias, ta.w, ta.gamma, m._gx,
+                        m._gy, m._gt, m._tt, m.patch_size, m._act)
+    h = cfg.latent
+    up = (R.recipe_input((B, h, h, cfg.embed_dim), salt=32) * 0.3).cuda().view(B, h * h, -1)
+    (lat * up).sum().backward()
+    assert_close(lat.view(B, h, h, -1), fx["agg"], "embed.agg")
+    assert_close(x.grad, fx["dx"], "embed.dx")
+    g = grads_of(m)
+    for k in fx.files:
+        if k.startswith("d."):
+            assert_close(g[k[2:]], fx[k], "embed." + k)
+    # out layer + cls head
+    fx = load("g3_out")
+    m.zero_grad()
+    latin = R.recipe_input((B, h, h, cfg.embed_dim), salt=33).cuda().view(B, h * h, -1).requires_grad_(True)
+    ol, ch = m.out_layer, m.cls_head
+    pred, cls = HeadFn.apply(latin, ol[0].weight, ol[0].bias, ol[2].weight, ol[2].bias, ol[4].weight, ol[4].bias,
+                             ch[0].weight, ch[0].bias, ch[2].weight, ch[2].bias, ch[4].weight, ch[4].bias, h, h,
+                             m.patch_size, m._act)
+    pred = pred.view(B, cfg.img_size, cfg.img_size, cfg.out_timesteps, cfg.out_channels)
+    up_o = (R.recipe_input(tuple(pred.shape), salt=34) * 0.3).cuda()
+    up_c = (R.recipe_input(tuple(cls.shape), salt=35) * 0.3).cuda()
+    ((pred * up_o).sum() + (cls * up_c).sum()).backward()
+    assert_close(pred, fx["y"], "out.y")
+    assert_close(cls, fx["cls"], "out.cls")
+    assert_close(latin.grad.view(B, h, h, -1), fx["dlat"], "out.dlat")
+    g = grads_of(m)
+    for k in fx.files:
+        if k.startswith("d."):
+            assert_close(g[k[2:]], fx[k], "out." + k)
+
+
+@pytest.mark.parametrize("name,normalize", [("g4_mini", False), ("g4_mini_norm", True)])
+def test_full_mini_model_golden(name, normalize):
+    fx = load(name)
+    m, cfg = build(dict(R.MINI, normalize=normalize), salt=9)
+    x = R.recipe_input((2, cfg.img_size, cfg.img_size, cfg.in_timesteps, cfg.in_channels), salt=41)
+    if normalize:
+        x = x * 2.0 + 0.7
+    x = x.cuda().requires_grad_(True)
+    y, c = m(x)
+    assert y.is_contiguous() and tuple(y.shape) == (2, cfg.img_size, cfg.img_size, 1, cfg.out_channels)
+    up_y = (R.recipe_input(tuple(y.shape), salt=42) * 0.3).cuda()
+    up_c = (R.recipe_input(tuple(c.shape), salt=43) * 0.3).cuda()
+    ((y * up_y).sum() + (c * up_c).sum()).backward()
+    assert_close(y, fx["pred"], "pred")
+    assert_close(c, fx["cls"], "cls")
+    assert_close(x.grad, fx["dx"], "dx")
+    g = grads_of(m)
+    for k in fx.files:
+        if k.startswith("d."):
+            assert_close(g[k[2:]], fx[k], k)
+
+
+def test_reference_main_config_golden():
+    fx = load("g9_refmain")
+    kw = dict(img_size=20, patch_size=5, in_channels=3, out_channels=3, in_timesteps=6, out_timesteps=1, embed_dim=32,
+              normalize=True)
+    m, cfg = build(kw, salt=19)
+    with torch.no_grad():
+        y, c = m(R.recipe_input((4, 20, 20, 6, 3), salt=91).cuda())
+    assert tuple(y.shape) == (4, 20, 20, 1, 3)
+    assert_close(y, fx["pred"], "pred")
+    assert_close(c, fx["cls"], "cls")
+
+
+def test_tiny_forward_golden():
+    fx = load("g5_tiny")
+    m, cfg = build(R.TINY, salt=1)
+    with torch.no_grad():
+        y, c = m(R.recipe_input((2, 128, 128, 10, 4), salt=51).cuda())
+    assert_sub(y, fx, "pred", "tiny.pred")
+    assert_close(c, fx["cls"], "tiny.cls")
+
+
+def test_rollout_train_step_golden():
+    """3-step AR rollout + backward + clip + Adam (golden g6 from the reference's own Adam/SimpleLpLoss)"""
+    from dpot_amd.train import FlatParams, FusedAdam, train_step
+    fx = load("g6_rollout")
+    m, cfg = build(R.MINI, salt=13)
+    B, T_ar, lr = int(fx["B"]), int(fx["T_ar"]), float(fx["lr"])
+    xx = R.recipe_input((B, cfg.img_size, cfg.img_size, cfg.in_timesteps, cfg.in_channels), salt=61).cuda()
+    yy = R.recipe_input((B, cfg.img_size, cfg.img_size, T_ar, cfg.out_channels), salt=62).cuda()
+    msk = torch.ones(B, cfg.img_size, cfg.img_size, 1, cfg.out_channels, device="cuda")
+    fp = FlatParams(m)
+    opt = FusedAdam(fp, lr=lr, betas=(0.9, 0.9), weight_decay=1e-6, max_norm=10000.0)
+    cls_before = m.cls_head[0].weight.detach().clone()
+    loss, pred = train_step(m, opt, xx, yy, msk)
+    assert abs(loss.item() - float(fx["loss"])) <= 1e-4 * float(fx["loss"])
+    assert abs(opt.grad_norm().item() - float(fx["grad_norm"])) <= 1e-4 * float(fx["grad_norm"])
+    assert_sub(pred, fx, "pred", "rollout.pred")
+    g = grads_of(m)
+    for n, gn in zip(fx["names"], fx["grad_norms"]):
+        assert abs(g[str(n)].norm().item() - gn) <= 1e-4 * gn + 1e-7, n
+    sd = m.state_dict()
+    for n in fx["names"]:
+        n = str(n)
+        stride = int(fx[f"p.{n}.stride"])
+        got = sd[n].detach().cpu().reshape(-1)[::stride]
+        assert (got - torch.from_numpy(fx[f"p.{n}.sub"])).abs().max().item() <= 0.05 * lr, n
+    assert torch.equal(m.cls_head[0].weight.detach(), cls_before)      # no gradient -> skipped, as the reference
+
+
+def test_train_step_vs_oracle_two_steps_and_graph():
+    """eager step == oracle step, and the hipGraph-captured step reproduces the eager one bit-for-bit"""
+    from dpot_amd.train import FlatParams, FusedAdam, GraphedTrainStep, train_step
+    kw = R.MINI
+    B = 4
+    xx = R.recipe_input((B, 32, 32, 4, 3), salt=1).cuda()
+    yy = R.recipe_input((B, 32, 32, 1, 3), salt=2).cuda()
+    msk = torch.ones(B, 32, 32, 1, 3, device="cuda")
+    lr = 1e-3
+    # oracle
+    cfg = R.DPOTConfig(**kw)
+    st = R.TrainState(params=OrderedDict((k, v.clone()) for k, v in R.recipe_state_dict(cfg, salt=23).items()))
+    ref_losses = [R.train_step(st, xx.cpu(), yy.cpu(), msk.cpu(), cfg, lr=lr)["loss"].item() for _ in range(2)]
+    # eager
+    m, _ = build(kw, salt=23)
+    opt = FusedAdam(FlatParams(m), lr=lr, betas=(0.9, 0.9), weight_decay=1e-6, max_norm=10000.0)
+    losses = [train_step(m, opt, xx, yy, msk)[0].item() for _ in range(2)]
+    for a, b in zip(losses, ref_losses):
+        assert abs(a - b) <= 2e-4 * abs(b), (losses, ref_losses)
+    eager_params = {k: v.detach().clone() for k, v in m.state_dict().items()}
+    # graphed: warm-up steps are real steps -> 0 warm-up iterations beyond capture is not possible; use a fresh model
+    m2, _ = build(kw, salt=23)
+    opt2 = FusedAdam(FlatParams(m2), lr=lr, betas=(0.9, 0.9), weight_decay=1e-6, max_norm=10000.0)
+    gs = GraphedTrainStep(m2, opt2, xx, yy, msk, warmup=1)            # 1 eager step (= step 1) ...
+    l2 = gs.replay(lr).item()                                          # ... + 1 replayed step (= step 2)
+    assert abs(l2 - losses[1]) <= 1e-6 * abs(losses[1])
+    for k, v in m2.state_dict().items():
+        assert (v - eager_params[k]).abs().max().item() <= 1e-6, k
+
+
+# ------------------------------------------------------------------------------------------------------
+# full-size properties (DPOT-Tiny, B=32: the BASELINE configs[1] workload)
+# ------------------------------------------------------------------------------------------------------
+def test_tiny_b32_properties():
+    from dpot_amd import ops
+    m, cfg = build(R.TINY, salt=1)
+    B = 32
+    g = torch.Generator().manual_seed(1234)
+    x = torch.randn(B, 128, 128, 10, 4, generator=g).cuda()
+    with torch.no_grad():
+        y, c = m(x)
+        y2, _ = m(x)
+        assert torch.isfinite(y).all() and torch.isfinite(c).all()
+        assert torch.equal(y, y2), "forward must be deterministic"
+        # batch independence: sample 5 alone == sample 5 inside the batch
+        y5, _ = m(x[5:6].contiguous())
+        assert_close(y5, y[5:6], "batch independence")
+        # rfft2 -> irfft2 round trip at full size (all modes kept) is the identity
+        lat = torch.randn(B, 256, 512, generator=g).cuda()
+        S = ops.rfft2(lat, 16, 16, 4, 16, 9, 0)
+        back = ops.irfft2(S, B, 16, 16, 512, 4, 16, 9, 1)
+        assert_close(back, lat, "rfft2/irfft2 round trip")
+        # Parseval with the Hermitian column weights: ||x||^2 == sum_k w_k |X_k|^2
+        Sw = S.view(B, 16, 9, 4, 2, 128)
+        wts = torch.tensor([1.0] + [2.0] * 7 + [1.0], device="cuda").view(1, 1, 9, 1, 1, 1)
+        assert abs((Sw ** 2 * wts).sum().item() / (lat ** 2).sum().item() - 1.0) < 1e-5
+    # one AR train step runs at full size and produces finite gradients for every trained tensor
+    from dpot_amd.train import FlatParams, FusedAdam, train_step
+    opt = FusedAdam(FlatParams(m), lr=1e-3, betas=(0.9, 0.9), weight_decay=1e-6, max_norm=10000.0)
+    yy = torch.randn(B, 128, 128, 1, 4, generator=g).cuda()
+    msk = torch.ones(B, 128, 128, 1, 4, device="cuda")
+    loss, _ = train_step(m, opt, x, yy, msk)
+    assert torch.isfinite(loss) and torch.isfinite(opt.fp.grad).all() and torch.isfinite(opt.fp.flat).all()
+    # oracle comparison of the loss on a 2-sample slice of the same weights (CPU oracle runs in ~1 s)
+    m2, _ = build(R.TINY, salt=1)
+    with torch.no_grad():
+        from dpot_amd.functional import rel_l2_loss
+        p2, _ = m2(x[:2].contiguous())
+        l_gpu = rel_l2_loss(p2, yy[:2].contiguous(), msk[:2].contiguous()).item()
+        po, _ = R.dpot_forward(R.recipe_state_dict(cfg, salt=1), x[:2].cpu(), cfg)
+        l_ref = R.rel_l2_loss(po, yy[:2].cpu(), msk[:2].cpu()).item()
+    assert_close(p2, po, "tiny pred vs oracle")
+    assert abs(l_gpu - l_ref) <= 1e-4 * abs(l_ref)

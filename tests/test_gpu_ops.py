@@ -1,0 +1,300 @@
+"""GPU parity tests, kernel level: every C-ABI entry point against the CPU oracle / fp64 torch on the same
+seeded inputs.  Tolerance: rtol 1e-4 (north_star, fp32) with an absolute term of 1e-4 * max|ref|."""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+from helpers import assert_close
+from oracle import dpot_ref as R
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ops():
+    from dpot_amd import ops as _ops
+    from dpot_amd import _lib
+    _lib.load()
+    assert torch.cuda.is_available()
+    return _ops
+
+
+def rnd(*shape, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.randn(*shape, generator=g) * scale).float()
+
+
+ACTS = {"gelu": torch.nn.functional.gelu, "tanh": torch.tanh, "sigmoid": torch.sigmoid, "relu": torch.relu,
+        "leaky_relu": lambda v: torch.nn.functional.leaky_relu(v, 0.1), "softplus": torch.nn.functional.softplus,
+        "ELU": torch.nn.functional.elu, "silu": torch.nn.functional.silu}
+
+
+# ------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("transA,transB", [(False, True), (False, False), (True, False), (True, True)])
+@pytest.mark.parametrize("M,N,K,tile", [(256, 256, 128, 0), (100, 35, 77, 0), (130, 260, 36, 128), (8192, 512, 512, 0),
+                                        (33, 12, 512, 0)])
+def test_gemm_layouts(ops, transA, transB, M, N, K, tile):
+    A = rnd(K, M, seed=1) if transA else rnd(M, K, seed=1)
+    B = rnd(N, K, seed=2) if transB else rnd(K, N, seed=2)
+    ref = (A.t() if transA else A).double() @ (B.t() if transB else B).double()
+    Ad, Bd = A.cuda(), B.cuda()
+    C = torch.full((M, N), float("nan"), device="cuda")
+    ops.gemm(Ad, Bd, C, M, N, K, transA=transA, transB=transB, lda=A.shape[1], ldb=B.shape[1], ldc=N, tile=tile)
+    assert_close(C, ref, f"gemm {M}x{N}x{K} tA={transA} tB={transB}")
+
+
+@pytest.mark.parametrize("act", list(ACTS))
+def test_gemm_epilogue_activations(ops, act):
+    M, N, K = 200, 96, 64
+    A, W, b = rnd(M, K, seed=3), rnd(N, K, seed=4, scale=0.3), rnd(N, seed=5)
+    res = rnd(M, N, seed=6)
+    a_id = ops.ACT_IDS[act]
+    y, pre = ops.linear_fwd(A.cuda(), W.cuda(), b.cuda(), act=a_id, save_pre=True, res=res.cuda())
+    pre_ref = A.double() @ W.double().t() + b.double()
+    assert_close(pre, pre_ref, "preact")
+    assert_close(y, ACTS[act](pre_ref) + res.double(), f"act {act}")
+    # DACT epilogue: dx = (dy @ W2) * act'(aux)
+    dy = rnd(M, N, seed=7)
+    W2 = rnd(N, K, seed=8, scale=0.3)
+    aux = rnd(M, K, seed=9)
+    dx = ops.linear_bwd_data(dy.cuda(), W2.cuda(), act=a_id, aux=aux.cuda())
+    a = aux.double().requires_grad_(True)
+    ACTS[act](a).sum().backward()
+    assert_close(dx, (dy.double() @ W2.double()) * a.grad, f"dact {act}")
+
+
+def test_gemm_residual_row_map_and_accumulate(ops):
+    M, N, K, T, tok = 240, 64, 36, 4, 12                    # rows are (b, tok, t): res row = (m / T) % tok
+    A, W, b = rnd(M, K, seed=1), rnd(N, K, seed=2), rnd(N, seed=3)
+    pos = rnd(tok, N, seed=4)
+    y, _ = ops.linear_fwd(A.cuda(), W.cuda(), b.cuda(), res=pos.cuda(), res_div=T, res_mod=tok)
+    idx = (torch.arange(M) // T) % tok
+    assert_close(y, A.double() @ W.double().t() + b.double() + pos.double()[idx], "row-mapped residual")
+    C = rnd(M, N, seed=5).cuda()
+    C0 = C.clone()
+    ops.gemm(A.cuda(), W.cuda(), C, M, N, K, transB=True, lda=K, ldb=K, ldc=N, accumulate=True)
+    assert_close(C, C0.cpu().double() + A.double() @ W.double().t(), "accumulate")
+
+
+def test_gemm_batched_strided_and_splitk(ops):
+    nb, bs, Mm = 4, 24, 300                                  # the AFNO mixer call pattern, bs not a multiple of 32
+    E2 = 2 * bs * nb
+    S, Wb, bb = rnd(Mm, E2, seed=1), rnd(nb, 2 * bs, 2 * bs, seed=2, scale=0.2), rnd(nb, 2 * bs, seed=3)
+    O = torch.full((Mm, E2), float("nan"), device="cuda")
+    Opre = torch.empty_like(O)
+    kw = dict(lda=E2, ldb=2 * bs, ldc=E2, batch=nb, strideA=2 * bs, strideB=4 * bs * bs, strideC=2 * bs)
+    ops.gemm(S.cuda(), Wb.cuda(), O, Mm, 2 * bs, 2 * bs, bias=bb.cuda(), strideBias=2 * bs, act=1, mode=ops.EPI_ACT,
+             preact=Opre, ldpre=E2, stridePre=2 * bs, **kw)
+    ref = torch.einsum("mki,kio->mko", S.double().view(Mm, nb, 2 * bs), Wb.double()) + bb.double()
+    assert_close(Opre, ref.reshape(Mm, E2), "batched preact")
+    assert_close(O, torch.nn.functional.gelu(ref).reshape(Mm, E2), "batched gelu")
+    # wgrad pattern: dW_k = S_k^T dO_k with split-K, deterministic
+    dO = rnd(Mm, E2, seed=4)
+    outs = []
+    for _ in range(2):
+        dW = torch.empty(nb, 2 * bs, 2 * bs, device="cuda")
+        ops.gemm(S.cuda(), dO.cuda(), dW, 2 * bs, 2 * bs, Mm, transA=True, lda=E2, ldb=E2, ldc=2 * bs, batch=nb,
+                 strideA=2 * bs, strideB=2 * bs, strideC=4 * bs * bs, splitk=5)
+        outs.append(dW)
+    refw = torch.einsum("mki,mko->kio", S.double().view(Mm, nb, 2 * bs), dO.double().view(Mm, nb, 2 * bs))
+    assert_close(outs[0], refw, "split-K wgrad")
+    assert torch.equal(outs[0], outs[1]), "split-K reduction must be deterministic"
+
+
+def test_linear_bwd_weight_auto_splitk_large_k(ops):
+    M, N, K = 65536, 32, 32                                  # out-layer tail wgrad: tiny output, huge contraction
+    dy, x = rnd(M, N, seed=1), rnd(M, K, seed=2)
+    dW = ops.linear_bwd_weight(dy.cuda(), x.cuda())
+    assert_close(dW, dy.double().t() @ x.double(), "wgrad")
+
+
+# ------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("B,h,w,E,nb,modes", [(2, 16, 16, 64, 4, 32), (3, 16, 16, 512, 4, 32), (2, 16, 16, 64, 4, 5),
+                                              (2, 32, 32, 96, 2, 64), (2, 4, 4, 32, 4, 32), (1, 14, 14, 24, 3, 6),
+                                              (2, 5, 7, 8, 1, 32)])
+def test_rfft2_irfft2_vs_torch(ops, B, h, w, E, nb, modes):
+    bs = E // nb
+    mx, my = min(modes, h), min(modes, w // 2 + 1)
+    x = rnd(B, h, w, E, seed=1)
+    spec = ops.rfft2(x.cuda().view(B, h * w, E), h, w, nb, mx, my, 0)            # [B*mx*my, 2E]
+    ref = torch.fft.rfft2(x.double(), dim=(1, 2), norm="ortho")[:, :mx, :my]     # [B,mx,my,E]
+    got = spec.cpu().view(B, mx, my, nb, 2, bs)
+    assert_close(got[..., 0, :].reshape(B, mx, my, E), ref.real, "rfft2.re")
+    assert_close(got[..., 1, :].reshape(B, mx, my, E), ref.imag, "rfft2.im")
+    # inverse on an arbitrary (non-Hermitian) spectrum, with residual
+    sre, sim = rnd(B, mx, my, E, seed=2), rnd(B, mx, my, E, seed=3)
+    res = rnd(B, h, w, E, seed=4)
+    full = torch.zeros(B, h, w // 2 + 1, E, dtype=torch.complex128)
+    full[:, :mx, :my] = torch.complex(sre.double(), sim.double())
+    yref = torch.fft.irfft2(full, s=(h, w), dim=(1, 2), norm="ortho") + res.double()
+    planar = torch.stack([sre.view(B, mx, my, nb, bs), sim.view(B, mx, my, nb, bs)], dim=-2).reshape(B * mx * my, 2 * E)
+    y = ops.irfft2(planar.cuda(), B, h, w, E, nb, mx, my, 1, res=res.cuda().view(B, h * w, E))
+    assert_close(y.view(B, h, w, E), yref, "irfft2")
+
+
+def test_dft_adjoints_match_autograd(ops):
+    """col_weights variants are the exact adjoints torch.autograd uses for irfft2 / rfft2"""
+    B, h, w, E, nb = 2, 16, 16, 32, 4
+    bs, mx, my = E // nb, 7, 6
+    x = rnd(B, h, w, E, seed=1).double().requires_grad_(True)
+    G = torch.complex(rnd(B, mx, my, E, seed=2).double(), rnd(B, mx, my, E, seed=3).double())
+    s = torch.fft.rfft2(x, dim=(1, 2), norm="ortho")[:, :mx, :my]
+    (s.real * G.real + s.imag * G.imag).sum().backward()
+    planar = torch.stack([G.real.view(B, mx, my, nb, bs), G.imag.view(B, mx, my, nb, bs)], dim=-2)
+    gx = ops.irfft2(planar.reshape(B * mx * my, 2 * E).float().cuda(), B, h, w, E, nb, mx, my, 0)
+    assert_close(gx.view(B, h, w, E), x.grad, "adjoint of rfft2")
+    Sr = rnd(B, mx, my, E, seed=4).double().requires_grad_(True)
+    Si = rnd(B, mx, my, E, seed=5).double().requires_grad_(True)
+    full = torch.zeros(B, h, w // 2 + 1, E, dtype=torch.complex128)
+    full[:, :mx, :my] = torch.complex(Sr, Si)
+    g = rnd(B, h, w, E, seed=6)
+    (torch.fft.irfft2(full, s=(h, w), dim=(1, 2), norm="ortho") * g.double()).sum().backward()
+    gs = ops.rfft2(g.cuda().view(B, h * w, E), h, w, nb, mx, my, 1).cpu().view(B, mx, my, nb, 2, bs)
+    assert_close(gs[..., 0, :].reshape(B, mx, my, E), Sr.grad, "adjoint of irfft2 (re)")
+    assert_close(gs[..., 1, :].reshape(B, mx, my, E), Si.grad, "adjoint of irfft2 (im)")
+
+
+def test_afno_pack_unpack(ops):
+    nb, bs = 3, 8
+    w, b = rnd(2, nb, bs, bs, seed=1), rnd(2, nb, bs, seed=2)
+    wb, bb = ops.afno_pack(w.cuda(), b.cuda())
+    ref = torch.cat([torch.cat([w[0], w[1]], dim=2), torch.cat([-w[1], w[0]], dim=2)], dim=1)
+    assert torch.equal(wb.cpu(), ref)
+    assert torch.equal(bb.cpu(), b.permute(1, 0, 2).reshape(nb, 2 * bs))
+    dwb, dbb = rnd(nb, 2 * bs, 2 * bs, seed=3), rnd(nb, 2 * bs, seed=4)
+    dw, db = ops.afno_unpack_grad(dwb.cuda(), dbb.cuda(), nb, bs)
+    assert_close(dw[0], dwb[:, :bs, :bs] + dwb[:, bs:, bs:], "dWr")
+    assert_close(dw[1], dwb[:, :bs, bs:] - dwb[:, bs:, :bs], "dWi")
+    assert torch.equal(db.cpu(), dbb.view(nb, 2, bs).permute(1, 0, 2).contiguous())
+
+
+# ------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("B,T,E", [(2, 64, 64), (3, 256, 512), (2, 16, 96), (2, 1024, 1536), (1, 9, 8)])
+def test_groupnorm(ops, B, T, E):
+    x = (rnd(B, T, E, seed=1) * 2.0 + 0.5)
+    gamma, beta = rnd(E, seed=2) * 0.3 + 1.0, rnd(E, seed=3) * 0.2
+    dy, add = rnd(B, T, E, seed=4), rnd(B, T, E, seed=5)
+    xd = x.double().requires_grad_(True)
+    gd, bd = gamma.double().requires_grad_(True), beta.double().requires_grad_(True)
+    yref = torch.nn.functional.group_norm(xd.permute(0, 2, 1), 8, gd, bd, 1e-5).permute(0, 2, 1)
+    (yref * dy.double()).sum().backward()
+    y, mean, rstd = ops.groupnorm_fwd(x.cuda(), gamma.cuda(), beta.cuda())
+    assert_close(y, yref, "gn fwd")
+    dx, dg, db = ops.groupnorm_bwd(dy.cuda(), x.cuda(), mean, rstd, gamma.cuda(), add=add.cuda())
+    assert_close(dx, xd.grad + add.double(), "gn dx")
+    assert_close(dg, gd.grad, "gn dgamma")
+    assert_close(db, bd.grad, "gn dbeta")
+
+
+# ------------------------------------------------------------------------------------------------------
+def test_patchify_unpatchify(ops):
+    B, X, T, Cc, P = 2, 24, 3, 2, 4
+    x = rnd(B, X, X, T, Cc, seed=1)
+    gx, gt = R.unit_grid(X), R.unit_grid(T)
+    A = ops.patchify(x.cuda(), gx.cuda(), gx.cuda(), gt.cuda(), P)
+    ref = R.patchify(R.append_grid(x), P).reshape(-1, (Cc + 3) * P * P)
+    assert torch.equal(A.cpu(), ref)
+    dA = rnd(*A.shape, seed=2)
+    dx = ops.unpatchify(dA.cuda(), B, X, X, T, Cc, P)
+    xr = x.clone().requires_grad_(True)
+    (R.patchify(R.append_grid(xr), P).reshape(-1, (Cc + 3) * P * P) * dA).sum().backward()
+    assert torch.equal(dx.cpu(), xr.grad)
+
+
+def test_small_data_movement_ops(ops):
+    B, h, w, P, Cc = 2, 3, 5, 4, 3
+    z = rnd(B * h * w * P * P, Cc, seed=1)
+    out = ops.pixel_shuffle(z.cuda(), B, h, w, P, Cc)
+    ref = z.view(B, h, w, P, P, Cc).permute(0, 1, 3, 2, 4, 5).reshape(B, h * P, w * P, Cc)
+    assert torch.equal(out.cpu(), ref)
+    back = ops.pixel_shuffle(out, B, h, w, P, Cc, inverse=True)
+    assert torch.equal(back.cpu(), z)
+    src = rnd(35, 448, seed=2)
+    assert torch.equal(ops.copy2d_pad(src.cuda(), 35, 448, 36, 448).cpu(), torch.cat([src, torch.zeros(1, 448)]))
+    assert torch.equal(ops.copy2d_pad(src.cuda(), 35, 448, 30, 440).cpu(), src[:30, :440])
+    t = rnd(5, 70, 33, seed=3)
+    assert torch.equal(ops.transpose2d(t.cuda(), 5, 70, 33).cpu(), t.transpose(1, 2).contiguous())
+    Xm = rnd(5000, 77, seed=4)
+    assert_close(ops.colsum(Xm.cuda(), 5000, 77), Xm.double().sum(0), "colsum")
+    assert_close(ops.colsum(Xm.cuda(), 5000, 40, ld=77), Xm[:, :40].double().sum(0), "colsum ld")
+    Bq, Rr, T, N = 3, 6, 4, 40
+    Xg = rnd(Bq * Rr * T, N, seed=5)
+    assert_close(ops.group_rowsum(Xg.cuda(), Bq, Rr, T, N), Xg.double().view(Bq, Rr, T, N).sum((0, 2)), "group_rowsum")
+    xt = rnd(3, 50, 64, seed=6)
+    assert_close(ops.token_mean(xt.cuda()), xt.double().mean(1), "token_mean")
+    dy, addt = rnd(3, 64, seed=7), rnd(3, 50, 64, seed=8)
+    assert_close(ops.token_mean_bwd(dy.cuda(), 50, add=addt.cuda()), dy.double()[:, None, :] / 50 + addt.double(),
+                 "token_mean_bwd")
+    assert_close(ops.add(xt.cuda(), addt.cuda()), xt.double() + addt.double(), "add")
+    sc, sh = rnd(3, 64, seed=9), rnd(3, 64, seed=10)
+    assert_close(ops.scale_shift(xt.cuda(), sc.cuda(), sh.cuda()), xt.double() * sc.double()[:, None] + sh.double()[:, None],
+                 "scale_shift")
+
+
+def test_timeagg_scale(ops):
+    T, E = 10, 64
+    w = rnd(T, E, E, seed=1)
+    gamma = (2 ** torch.linspace(-10, 10, E)).unsqueeze(0) * (0.9 + 0.2 * torch.rand(1, E, generator=torch.Generator().manual_seed(2)))
+    tt = torch.linspace(0, 1, T)
+    ws = ops.timeagg_scale_w(w.cuda(), gamma.cuda(), tt.cuda())
+    temb = torch.cos(tt.unsqueeze(-1) @ gamma)                                   # fp32 arguments, as the reference
+    assert_close(ws, w.double() * temb.double()[:, :, None], "timeagg scale")
+    dws = rnd(T, E, E, seed=3)
+    wd, gd = w.double().requires_grad_(True), gamma.double().requires_grad_(True)
+    ((wd * torch.cos(tt.double().unsqueeze(-1) @ gd)[:, :, None]) * dws.double()).sum().backward()
+    dw, dg = ops.timeagg_scale_w_bwd(dws.cuda(), w.cuda(), gamma.cuda(), tt.cuda())
+    assert_close(dw, wd.grad, "timeagg dw", rtol=2e-4, atol_scale=2e-4)       # cos of fp32-rounded t*gamma (~1e3 rad)
+    assert_close(dg, gd.grad, "timeagg dgamma", rtol=2e-4, atol_scale=2e-4)
+
+
+# ------------------------------------------------------------------------------------------------------
+def test_rel_l2_loss_and_grad(ops):
+    from dpot_amd.functional import rel_l2_loss
+    B, X, T, Cc = 3, 16, 2, 4
+    x, y = rnd(B, X, X, T, Cc, seed=1), rnd(B, X, X, T, Cc, seed=2)
+    msk = torch.ones(B, X, X, 1, Cc)
+    msk[0, :, :, :, 2:] = 0.0
+    msk[1, :, :, :, 3] = 0.0
+    for m in (msk, None):
+        xr = x.clone().requires_grad_(True)
+        lref = R.rel_l2_loss(xr, y, m)
+        lref.backward()
+        xg = x.cuda().requires_grad_(True)
+        l = rel_l2_loss(xg, y.cuda(), m.cuda() if m is not None else None)
+        (l * 1.7).backward()
+        assert abs(l.item() - lref.item()) <= 1e-5 * abs(lref.item())
+        assert_close(xg.grad, 1.7 * xr.grad, "loss grad")
+
+
+def test_sumsq_adam_noise(ops):
+    n = 1_000_003
+    g = rnd(n + 1, seed=1)[:n].contiguous()
+    gd = torch.zeros(n + 5, device="cuda")[:n]
+    gd.copy_(g)
+    out, part = torch.zeros(1, device="cuda"), torch.zeros(1024, device="cuda")
+    ops.sumsq(gd, out, part)
+    assert abs(out.item() - (g.double() ** 2).sum().item()) <= 1e-6 * (g.double() ** 2).sum().item()
+    # Adam vs the oracle's update rule, 3 steps, with clipping active (max_norm below the gradient norm)
+    p0, m0, v0 = rnd(n, seed=2), torch.zeros(n), torch.zeros(n)
+    p, m, v = p0.clone().cuda(), m0.clone().cuda(), v0.clone().cuda()
+    pr, mr, vr = p0.clone(), m0.clone(), v0.clone()
+    lr, b1, b2, eps, wd, max_norm, gscale = 1e-3, 0.9, 0.9, 1e-8, 1e-6, 50.0, 0.5
+    hyper = torch.zeros(8, device="cuda")
+    for step in range(1, 4):
+        gk = rnd(n, seed=10 + step)
+        ops.sumsq(gk.cuda(), out, part)
+        hyper.copy_(torch.tensor([lr, b1, b2, eps, wd, 1 - b1 ** step, 1 - b2 ** step, max_norm]))
+        ops.adam_step(p, gk.cuda(), m, v, hyper, out, gscale)
+        gs = gk * gscale
+        coef = R.clip_coef(R.grad_global_norm([gs]), max_norm)
+        assert coef.item() < 1.0
+        R.adam_update(pr, gs * coef, mr, vr, step, lr, b1, b2, eps, wd)
+    assert (p.cpu() - pr).abs().max().item() <= 2e-3 * lr * 3
+    assert_close(m, mr, "exp_avg")
+    assert_close(v, vr, "exp_avg_sq")
+    xx, epsn = rnd(2, 8, 8, 3, 4, seed=5), rnd(2, 8, 8, 3, 4, seed=6)
+    got = ops.noise_inject(xx.cuda(), epsn.cuda(), 0.05)
+    ref = xx + 0.05 * torch.sum(xx ** 2, dim=(1, 2, 3), keepdim=True) ** 0.5 * epsn
+    assert_close(got, ref, "noise inject")
