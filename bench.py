@@ -84,7 +84,8 @@ def mixer_roofline(model, B: int):
     bytes_alg = 2.0 * Mm * 2 * E * 4 + nb * (2 * bs) * (2 * bs) * 4
     achieved = flops / t / 1e12
     return {
-        "kernel": "gemm_f32_kernel<128,128,NN,tag=afno> (AFNO mixer, one complex MLP layer, bias+GELU fused)",
+        "kernel": "dpot::gemm_f32_kernel<64,64,NN,vec,TAG=1> (AFNO mixer: one layer of the block-diagonal complex MLP "
+                  "as a real MFMA GEMM, bias+GELU fused)",
         "bound": "mfma", "achieved": round(achieved, 2), "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
         "frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": None,
         "us_per_launch": round(t * 1e6, 2), "flops_per_launch": flops, "algorithmic_bytes_per_launch": bytes_alg,
@@ -98,8 +99,6 @@ def cpu_baseline(seconds: float):
     cores on a bounded sample of the same workload: DPOT-Tiny train steps at B=4 (BASELINE configs[0])."""
     from oracle import dpot_ref as R
     cores = os.cpu_count() or 1
-    threads = max(1, min(cores, 64))
-    torch.set_num_threads(threads)
     cfg = R.DPOTConfig(**R.TINY)
     g = torch.Generator().manual_seed(1234)
     B = 4
@@ -107,6 +106,19 @@ def cpu_baseline(seconds: float):
     xx = torch.randn(B, 128, 128, 10, 4, generator=g)
     yy = torch.randn(B, 128, 128, 1, 4, generator=g)
     msk = torch.ones(B, 128, 128, 1, 4)
+    # the reference hard-codes OMP_NUM_THREADS=16 (train_temporal.py:4); give the CPU its best shot: calibrate the
+    # thread count on 2 steps each, then time the bounded sample with the fastest setting
+    best, threads = None, 1
+    for cand in [c for c in (8, 16, 32, 64, 128) if c <= cores] or [cores]:
+        torch.set_num_threads(cand)
+        R.train_step(st, xx, yy, msk, cfg, lr=1e-3)            # warm-up at this thread count
+        t0 = time.perf_counter()
+        for _ in range(2):
+            R.train_step(st, xx, yy, msk, cfg, lr=1e-3)
+        dt = time.perf_counter() - t0
+        if best is None or dt < best:
+            best, threads = dt, cand
+    torch.set_num_threads(threads)
     R.train_step(st, xx, yy, msk, cfg, lr=1e-3)                # warm-up
     n, t0 = 0, time.perf_counter()
     while True:

@@ -9,6 +9,7 @@
 //
 // Works for any h, w (no power-of-two requirement: img_size/patch_size is arbitrary in the reference).
 #include "common.h"
+#include "dft_fast.h"
 
 namespace dpot {
 
@@ -233,6 +234,12 @@ extern "C" int dpot_rfft2(const float* x, float* spec, int B, int h, int w, int 
   int rc = check_dft_args("rfft2", B, h, w, E, nb, mx, my);
   if (rc) return rc;
   DPOT_REQUIRE(x && spec, "rfft2: null pointer");
+  {
+    int frc = 0;
+    if (try_rfft2_fast(x, spec, B, h, w, E, nb, mx, my, col_weights, (float)(1.0 / sqrt((double)h * (double)w)),
+                       as_stream(stream), &frc))
+      return frc;
+  }
   const int tw = ((2 * w + 2 * h + 3) & ~3);
   const int CC = pick_cc(E, (long long)h * w + (long long)h * my * 2, tw);
   if (CC == 0) {
@@ -253,6 +260,12 @@ extern "C" int dpot_irfft2(const float* spec, const float* res, float* y, int B,
   int rc = check_dft_args("irfft2", B, h, w, E, nb, mx, my);
   if (rc) return rc;
   DPOT_REQUIRE(spec && y, "irfft2: null pointer");
+  {
+    int frc = 0;
+    if (try_irfft2_fast(spec, res, y, B, h, w, E, nb, mx, my, col_weights,
+                        (float)(1.0 / sqrt((double)h * (double)w)), as_stream(stream), &frc))
+      return frc;
+  }
   const int tw = ((2 * w + 2 * h + 3) & ~3);
   const int CC = pick_cc(E, (long long)mx * my * 2 + (long long)h * my * 2, tw);
   if (CC == 0) {

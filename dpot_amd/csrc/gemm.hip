@@ -8,11 +8,15 @@
 //   * 256 threads = 4 waves in a 2x2 grid; each wave owns a (BM/2)x(BN/2) sub-tile = (BM/64)x(BN/64)
 //     accumulators of 32x32 (16 VGPRs each)
 //   * BK = 32 K-slab staged through LDS; global loads for slab t+1 are issued before the MFMAs of slab t
-//     (register double buffering) - a slab is ~1.7 us of MFMA per wave, far more than the HBM latency
+//     (register double buffering).  Loads are UNCONDITIONAL from clamped addresses + a select: a predicated
+//     load makes hipcc branch around it and wait vmcnt(0) per load, which serialises the whole prefetch
 //   * K-contiguous operands sit in LDS as [row][BK+4] (ds_read_b128 per lane = 4 k-steps, conflict free);
 //     row-contiguous operands (transposed views) sit as [BK][rows] and are read with ds_read_b32
+//   * epilogue works on whole 16-element accumulator fragments: all aux/residual loads of a fragment are issued
+//     together (clamped addresses), only the stores are predicated
 //   * blockIdx -> tile mapping is XCD aware: the 8 XCDs get contiguous chunks of tile space so that
 //     workgroups sharing an A row-panel / the whole weight matrix hit the same 4 MiB L2
+//   * tile size is picked to minimise wave quantisation over the 256 CUs (128x128 unless 64x64 balances better)
 //   * split-K (wgrad: K = tokens*batch is huge, M x N small) writes partials to a workspace that a second
 //     kernel reduces in fixed order - deterministic, no atomics
 #include "common.h"
@@ -51,12 +55,19 @@ struct GemmArgs {
   int lda, ldb;
   long long sA, sB;
   int batch, splits, ktiles_per_split;
-  int vecA, vecB;
   int tilesM, tilesN;
+  int evec;  // epilogue may use 16-byte accesses
   float* ws;  // split-K partials [split][batch][M][N]
   EpiArgs e;
 };
 
+__device__ __forceinline__ int res_row(const EpiArgs& e, int m) {
+  if (e.res_div > 1) m = m / e.res_div;
+  if (e.res_mod > 0) m = m % e.res_mod;
+  return m;
+}
+
+// scalar epilogue (split-K reduction kernel)
 __device__ __forceinline__ void epi_store(const EpiArgs& e, int b, int m, int n, float v) {
   if (e.bias) v += e.bias[b * e.sBias + n];
   if (e.pre) e.pre[b * e.sPre + (long long)m * e.ldpre + n] = v;
@@ -65,63 +76,153 @@ __device__ __forceinline__ void epi_store(const EpiArgs& e, int b, int m, int n,
   } else if (e.mode == DPOT_EPI_DACT) {
     v *= act_bwd(e.act, e.aux[b * e.sAux + (long long)m * e.ldaux + n]);
   }
-  if (e.res) {
-    int rm = m;
-    if (e.res_div > 1) rm = rm / e.res_div;
-    if (e.res_mod > 0) rm = rm % e.res_mod;
-    v += e.res[b * e.sRes + (long long)rm * e.ldres + n];
-  }
+  if (e.res) v += e.res[b * e.sRes + (long long)res_row(e, m) * e.ldres + n];
   float* c = e.C + b * e.sC + (long long)m * e.ldc + n;
   if (e.accumulate) v += *c;
   *c = v;
 }
 
-// ---- global -> register tile loaders --------------------------------------------------------------
+// ---- tile epilogue --------------------------------------------------------------------------------
+// The 32x32 accumulator fragment of a wave (C/D layout: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)) is
+// bounced through a per-wave LDS slab so that (a) the epilogue is a compact 4-trip loop instead of 64 inlined
+// copies of the activation code and (b) each lane owns 4 consecutive columns: bias / aux / residual loads and the
+// C store are 16-byte accesses, 128 B contiguous per row.
+constexpr int EPI_LD = 36;  // floats per staged row (16-B aligned rows, conflict-free b128 reads)
+
+struct Vec4 {
+  float v[4];
+};
+__device__ __forceinline__ Vec4 ld4(const float* p, bool vec) {
+  Vec4 r;
+  if (vec) {
+    const float4 t = *reinterpret_cast<const float4*>(p);
+    r.v[0] = t.x; r.v[1] = t.y; r.v[2] = t.z; r.v[3] = t.w;
+  } else {
+    r.v[0] = p[0]; r.v[1] = p[1]; r.v[2] = p[2]; r.v[3] = p[3];
+  }
+  return r;
+}
+
+__device__ __forceinline__ void epi_fragment(const EpiArgs& e, int evec, int b, int m0f, int n0f, const f32x16& acc,
+                                             float* stage, int lane) {
+  const int li = lane & 31, kh = lane >> 5;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) stage[((r & 3) + 8 * (r >> 2) + 4 * kh) * EPI_LD + li] = acc[r];
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  const int c4 = (lane & 7) * 4;
+  const int n = n0f + c4;
+#pragma unroll 1
+  for (int it = 0; it < 4; ++it) {
+    const int row = it * 8 + (lane >> 3);
+    const int m = m0f + row;
+    const float4 t = *reinterpret_cast<const float4*>(&stage[row * EPI_LD + c4]);
+    float v[4] = {t.x, t.y, t.z, t.w};
+    if (evec) {
+      // N % 4 == 0: the 4 columns are all valid or all invalid; loads come from clamped addresses
+      const bool ok = (m < e.M) && (n < e.N);
+      const int mc = m < e.M ? m : e.M - 1;
+      const int nc = n < e.N ? n : e.N - 4;
+      if (e.bias) {
+        const Vec4 q = ld4(e.bias + b * e.sBias + nc, true);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) v[k] += q.v[k];
+      }
+      if (e.pre && ok)
+        *reinterpret_cast<float4*>(e.pre + b * e.sPre + (long long)mc * e.ldpre + nc) =
+            make_float4(v[0], v[1], v[2], v[3]);
+      if (e.mode == DPOT_EPI_ACT) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) v[k] = act_fwd(e.act, v[k]);
+      } else if (e.mode == DPOT_EPI_DACT) {
+        const Vec4 q = ld4(e.aux + b * e.sAux + (long long)mc * e.ldaux + nc, true);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) v[k] *= act_bwd(e.act, q.v[k]);
+      }
+      if (e.res) {
+        const Vec4 q = ld4(e.res + b * e.sRes + (long long)res_row(e, mc) * e.ldres + nc, true);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) v[k] += q.v[k];
+      }
+      float* c = e.C + b * e.sC + (long long)mc * e.ldc + nc;
+      if (e.accumulate) {
+        const Vec4 q = ld4(c, true);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) v[k] += q.v[k];
+      }
+      if (ok) *reinterpret_cast<float4*>(c) = make_float4(v[0], v[1], v[2], v[3]);
+    } else {
+      // odd shapes (N or a leading dimension not a multiple of 4): scalar, element-wise predicated
+      if (m < e.M) {
+        for (int k = 0; k < 4; ++k)
+          if (n + k < e.N) epi_store(e, b, m, n + k, v[k]);
+      }
+    }
+  }
+  __builtin_amdgcn_wave_barrier();
+}
+
+// ---- global -> register tile loaders ------------------------------------------------------------------
+// FULL = the whole K-slab is inside [k0, kmax): loads are unconditional.  Rows beyond rmax are CLAMPED to a valid
+// row instead of being zeroed: they only feed accumulator rows/columns that the epilogue never stores.  (A load
+// followed by a select is turned by hipcc into a branch around the load + s_waitcnt vmcnt(0), which serialises the
+// prefetch - so the steady-state path must not contain any per-lane condition on a load.)
+// FULL = false (the last, partial slab when K % 32 != 0): elements with k >= kmax are zeroed.
 // K-contiguous source: element (r, k) at base[r*ld + k]; tile [R][BK]
-template <int R>
+template <int R, bool VEC, bool FULL>
 __device__ __forceinline__ void load_kcontig(float4 (&reg)[R / 32], const float* __restrict__ base, int ld,
-                                             int r0, int rmax, int k0, int kmax, bool vec, int tid) {
+                                             int r0, int rmax, int k0, int kmax, int tid) {
 #pragma unroll
   for (int i = 0; i < R / 32; ++i) {
     const int f = tid + 256 * i;
     const int r = r0 + (f >> 3);
     const int k = k0 + ((f & 7) << 2);
-    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (r < rmax) {
-      const float* p = base + (long long)r * ld + k;
-      if (vec) {
-        if (k < kmax) v = *reinterpret_cast<const float4*>(p);
+    const float* row = base + (long long)(r < rmax ? r : rmax - 1) * ld;
+    float4 v;
+    if constexpr (FULL) {
+      if constexpr (VEC) {
+        v = *reinterpret_cast<const float4*>(row + k);
       } else {
-        if (k + 0 < kmax) v.x = p[0];
-        if (k + 1 < kmax) v.y = p[1];
-        if (k + 2 < kmax) v.z = p[2];
-        if (k + 3 < kmax) v.w = p[3];
+        v.x = row[k + 0]; v.y = row[k + 1]; v.z = row[k + 2]; v.w = row[k + 3];
       }
+    } else {
+      const int kl = kmax - 1;
+      v.x = row[k + 0 < kmax ? k + 0 : kl];
+      v.y = row[k + 1 < kmax ? k + 1 : kl];
+      v.z = row[k + 2 < kmax ? k + 2 : kl];
+      v.w = row[k + 3 < kmax ? k + 3 : kl];
+      if (!(k + 0 < kmax)) v.x = 0.f;
+      if (!(k + 1 < kmax)) v.y = 0.f;
+      if (!(k + 2 < kmax)) v.z = 0.f;
+      if (!(k + 3 < kmax)) v.w = 0.f;
     }
     reg[i] = v;
   }
 }
 // row-contiguous source: element (r, k) at base[k*ld + r]; tile [BK][R]
-template <int R>
+template <int R, bool VEC, bool FULL>
 __device__ __forceinline__ void load_rcontig(float4 (&reg)[R / 32], const float* __restrict__ base, int ld,
-                                             int r0, int rmax, int k0, int kmax, bool vec, int tid) {
+                                             int r0, int rmax, int k0, int kmax, int tid) {
   constexpr int F4_PER_ROW = R / 4;
 #pragma unroll
   for (int i = 0; i < R / 32; ++i) {
     const int f = tid + 256 * i;
     const int k = k0 + f / F4_PER_ROW;
     const int r = r0 + ((f % F4_PER_ROW) << 2);
-    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (k < kmax) {
-      const float* p = base + (long long)k * ld + r;
-      if (vec) {
-        if (r < rmax) v = *reinterpret_cast<const float4*>(p);
-      } else {
-        if (r + 0 < rmax) v.x = p[0];
-        if (r + 1 < rmax) v.y = p[1];
-        if (r + 2 < rmax) v.z = p[2];
-        if (r + 3 < rmax) v.w = p[3];
-      }
+    const float* row = base + (long long)(FULL ? k : (k < kmax ? k : kmax - 1)) * ld;
+    float4 v;
+    if constexpr (VEC) {
+      v = *reinterpret_cast<const float4*>(row + (r < rmax ? r : rmax - 4));
+    } else {
+      const int rl = rmax - 1;
+      v.x = row[r + 0 < rmax ? r + 0 : rl];
+      v.y = row[r + 1 < rmax ? r + 1 : rl];
+      v.z = row[r + 2 < rmax ? r + 2 : rl];
+      v.w = row[r + 3 < rmax ? r + 3 : rl];
+    }
+    if constexpr (!FULL) {
+      if (!(k < kmax)) v = make_float4(0.f, 0.f, 0.f, 0.f);
     }
     reg[i] = v;
   }
@@ -161,14 +262,17 @@ __device__ __forceinline__ float4 frag(const float* lds, int row, int kk, int kh
 }
 
 // TA: A stored [K,M] (row-contiguous tile);  TB: B stored [N,K] (K-contiguous tile)
+// VEC: 16-byte global loads (alignment / divisibility checked on the host)
 // TAG only changes the kernel's name (so rocprof reports the AFNO mixer launches on their own line)
-template <int BM, int BN, bool TA, bool TB, int TAG>
+template <int BM, int BN, bool TA, bool TB, bool VEC, int TAG>
 __global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmArgs p) {
   constexpr bool A_KC = !TA;
   constexpr bool B_KC = TB;
   constexpr int TM = BM / 64, TN = BN / 64;
   constexpr int WM = BM / 2, WN = BN / 2;
-  __shared__ __attribute__((aligned(16))) float smem[TileLds<BM, A_KC>::floats + TileLds<BN, B_KC>::floats];
+  constexpr int OPER_FLOATS = TileLds<BM, A_KC>::floats + TileLds<BN, B_KC>::floats;
+  constexpr int STAGE_FLOATS = 4 * 32 * EPI_LD;
+  __shared__ __attribute__((aligned(16))) float smem[OPER_FLOATS > STAGE_FLOATS ? OPER_FLOATS : STAGE_FLOATS];
   float* As = smem;
   float* Bs = smem + TileLds<BM, A_KC>::floats;
 
@@ -208,10 +312,17 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmArgs p) {
 
   float4 ra[BM / 32], rb[BN / 32];
   auto gload = [&](int k0) {
-    if constexpr (A_KC) load_kcontig<BM>(ra, A, p.lda, m0, p.M, k0, kend, p.vecA, tid);
-    else load_rcontig<BM>(ra, A, p.lda, m0, p.M, k0, kend, p.vecA, tid);
-    if constexpr (B_KC) load_kcontig<BN>(rb, B, p.ldb, n0, p.N, k0, kend, p.vecB, tid);
-    else load_rcontig<BN>(rb, B, p.ldb, n0, p.N, k0, kend, p.vecB, tid);
+    if (k0 + BK <= kend) {   // uniform: whole slab in range -> branch-free loads
+      if constexpr (A_KC) load_kcontig<BM, VEC, true>(ra, A, p.lda, m0, p.M, k0, kend, tid);
+      else load_rcontig<BM, VEC, true>(ra, A, p.lda, m0, p.M, k0, kend, tid);
+      if constexpr (B_KC) load_kcontig<BN, VEC, true>(rb, B, p.ldb, n0, p.N, k0, kend, tid);
+      else load_rcontig<BN, VEC, true>(rb, B, p.ldb, n0, p.N, k0, kend, tid);
+    } else {
+      if constexpr (A_KC) load_kcontig<BM, VEC, false>(ra, A, p.lda, m0, p.M, k0, kend, tid);
+      else load_rcontig<BM, VEC, false>(ra, A, p.lda, m0, p.M, k0, kend, tid);
+      if constexpr (B_KC) load_kcontig<BN, VEC, false>(rb, B, p.ldb, n0, p.N, k0, kend, tid);
+      else load_rcontig<BN, VEC, false>(rb, B, p.ldb, n0, p.N, k0, kend, tid);
+    }
   };
   auto sstore = [&]() {
     if constexpr (A_KC) store_kcontig<BM>(As, ra, tid); else store_rcontig<BM>(As, ra, tid);
@@ -249,24 +360,33 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmArgs p) {
     }
   }
 
-  // ---- epilogue: C/D layout of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
-#pragma unroll
-  for (int i = 0; i < TM; ++i)
-#pragma unroll
-    for (int j = 0; j < TN; ++j) {
-      const int n = n0 + wn * WN + j * 32 + li;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int m = m0 + wm * WM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
-        if (m < p.M && n < p.N) {
-          if (p.splits > 1) {
-            p.ws[(((long long)zs * p.batch + zb) * p.M + m) * p.N + n] = acc[i][j][r];
-          } else {
-            epi_store(p.e, zb, m, n, acc[i][j][r]);
-          }
-        }
-      }
-    }
+  // ---- epilogue (the operand slabs in LDS are dead: reuse them as per-wave staging)
+  __syncthreads();
+  float* stage = smem + wave * (32 * EPI_LD);
+  // explicit (i, j) instances: a `#pragma unroll` over loops that contain the non-unrolled epilogue loop is
+  // declined by the compiler and would turn acc[i][j] into a scratch array
+#define DPOT_EPI_FRAG(I, J)                                                                    \
+  do {                                                                                         \
+    const int n0f = n0 + wn * WN + (J) * 32;                                                   \
+    const int m0f = m0 + wm * WM + (I) * 32;                                                   \
+    if (p.splits > 1) {                                                                        \
+      float* ws = p.ws + ((long long)zs * p.batch + zb) * p.M * p.N;                           \
+      const int n = n0f + li;                                                                  \
+      _Pragma("unroll") for (int r = 0; r < 16; ++r) {                                         \
+        const int m = m0f + 4 * kh + (r & 3) + 8 * (r >> 2);                                   \
+        if (m < p.M && n < p.N) ws[(long long)m * p.N + n] = acc[I][J][r];                     \
+      }                                                                                        \
+    } else {                                                                                   \
+      epi_fragment(p.e, p.evec, zb, m0f, n0f, acc[I][J], stage, lane);                         \
+    }                                                                                          \
+  } while (0)
+  DPOT_EPI_FRAG(0, 0);
+  if constexpr (TN > 1) DPOT_EPI_FRAG(0, 1);
+  if constexpr (TM > 1) {
+    DPOT_EPI_FRAG(1, 0);
+    if constexpr (TN > 1) DPOT_EPI_FRAG(1, 1);
+  }
+#undef DPOT_EPI_FRAG
 }
 
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ ws, int splits, int batch,
@@ -275,18 +395,30 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
   const long long total = MN * batch;
   for (long long idx = blockIdx.x * 256ll + threadIdx.x; idx < total; idx += (long long)gridDim.x * 256) {
     float v = 0.f;
-    for (int s = 0; s < splits; ++s) v += ws[(long long)s * total + idx];
+    int s = 0;
+    for (; s + 4 <= splits; s += 4) {  // 4 independent loads in flight, summed in a fixed order
+      const float a0 = ws[(long long)(s + 0) * total + idx], a1 = ws[(long long)(s + 1) * total + idx];
+      const float a2 = ws[(long long)(s + 2) * total + idx], a3 = ws[(long long)(s + 3) * total + idx];
+      v += (a0 + a1) + (a2 + a3);
+    }
+    for (; s < splits; ++s) v += ws[(long long)s * total + idx];
     const int b = (int)(idx / MN);
     const long long rem = idx - (long long)b * MN;
     epi_store(e, b, (int)(rem / e.N), (int)(rem % e.N), v);
   }
 }
 
+constexpr int NUM_CU = 256;
+
 static int pick_tile(int M, int N, int batch, int forced) {
   if (forced == 64 || forced == 128) return forced;
   if (M <= 64 || N <= 64) return 64;
   const long long t128 = (long long)cdiv(M, 128) * cdiv(N, 128) * batch;
-  return t128 >= 192 ? 128 : 64;
+  const long long t64 = (long long)cdiv(M, 64) * cdiv(N, 64) * batch;
+  // CU load balance: tiles are dealt round-robin to 256 CUs; time ~ the busiest CU
+  const double eff128 = (double)t128 / (double)(NUM_CU * cdiv64(t128, NUM_CU));
+  const double eff64 = (double)t64 / (double)(NUM_CU * cdiv64(t64, NUM_CU));
+  return eff128 >= 0.92 * eff64 ? 128 : 64;
 }
 
 }  // namespace dpot
@@ -308,6 +440,21 @@ extern "C" int dpot_gemm_auto_splitk(int M, int N, int K, int batch) {
 extern "C" int64_t dpot_gemm_workspace_bytes(const dpot_gemm_desc* d) {
   if (!d || d->splitk <= 1) return 0;
   return (int64_t)d->splitk * d->batch * d->M * d->N * (int64_t)sizeof(float);
+}
+
+template <int BMN, bool VEC>
+static void launch_gemm(const dpot_gemm_desc* d, const GemmArgs& p, dim3 grid, hipStream_t s) {
+  const int key = (d->transA ? 2 : 0) | (d->transB ? 1 : 0);
+  if (d->tag == 1 && key == 0) {
+    hipLaunchKernelGGL((gemm_f32_kernel<BMN, BMN, false, false, VEC, 1>), grid, dim3(256), 0, s, p);
+    return;
+  }
+  switch (key) {
+    case 0: hipLaunchKernelGGL((gemm_f32_kernel<BMN, BMN, false, false, VEC, 0>), grid, dim3(256), 0, s, p); break;
+    case 1: hipLaunchKernelGGL((gemm_f32_kernel<BMN, BMN, false, true, VEC, 0>), grid, dim3(256), 0, s, p); break;
+    case 2: hipLaunchKernelGGL((gemm_f32_kernel<BMN, BMN, true, false, VEC, 0>), grid, dim3(256), 0, s, p); break;
+    default: hipLaunchKernelGGL((gemm_f32_kernel<BMN, BMN, true, true, VEC, 0>), grid, dim3(256), 0, s, p); break;
+  }
 }
 
 extern "C" int dpot_gemm_f32(const dpot_gemm_desc* d, dpot_stream_t stream) {
@@ -333,8 +480,9 @@ extern "C" int dpot_gemm_f32(const dpot_gemm_desc* d, dpot_stream_t stream) {
   // vector (16 B) loads need: 16-B aligned base + batch stride, ld % 4 == 0 and the contiguous extent % 4 == 0
   const int contA = d->transA ? d->M : d->K;
   const int contB = d->transB ? d->K : d->N;
-  p.vecA = aligned16(d->A) && (d->lda % 4 == 0) && (contA % 4 == 0) && (d->strideA % 4 == 0);
-  p.vecB = aligned16(d->B) && (d->ldb % 4 == 0) && (contB % 4 == 0) && (d->strideB % 4 == 0);
+  const bool vecA = aligned16(d->A) && (d->lda % 4 == 0) && (contA % 4 == 0) && (d->strideA % 4 == 0);
+  const bool vecB = aligned16(d->B) && (d->ldb % 4 == 0) && (contB % 4 == 0) && (d->strideB % 4 == 0);
+  const bool vec = vecA && vecB;
   p.ws = d->workspace;
   EpiArgs& e = p.e;
   e.C = d->C; e.ldc = d->ldc; e.sC = d->strideC;
@@ -345,31 +493,23 @@ extern "C" int dpot_gemm_f32(const dpot_gemm_desc* d, dpot_stream_t stream) {
   e.act = d->act; e.mode = d->epi_mode; e.accumulate = d->accumulate;
   e.M = d->M; e.N = d->N;
 
+  auto vec_ok = [](const void* ptr, int ld, long long stride) {
+    return ptr == nullptr || (aligned16(ptr) && ld % 4 == 0 && stride % 4 == 0);
+  };
+  p.evec = (d->N % 4 == 0) && vec_ok(d->C, d->ldc, d->strideC) && vec_ok(d->bias, 4, d->strideBias) &&
+           vec_ok(d->aux, d->ldaux, d->strideAux) && vec_ok(d->preact, d->ldpre, d->stridePre) &&
+           vec_ok(d->res, d->ldres, d->strideRes);
   const int t = pick_tile(d->M, d->N, d->batch, d->tile);
   p.tilesM = cdiv(d->M, t); p.tilesN = cdiv(d->N, t);
   const long long ntiles = (long long)p.tilesM * p.tilesN;
   DPOT_REQUIRE(ntiles < (1ll << 31) && (long long)d->batch * splits <= 65535, "gemm: grid too large");
   dim3 grid((unsigned)ntiles, 1, (unsigned)(d->batch * splits));
   hipStream_t s = as_stream(stream);
-#define LAUNCH(BMN, TA_, TB_) \
-  hipLaunchKernelGGL((gemm_f32_kernel<BMN, BMN, TA_, TB_, 0>), grid, dim3(256), 0, s, p)
-  const int key = (t == 128 ? 4 : 0) | (d->transA ? 2 : 0) | (d->transB ? 1 : 0);
-  if (d->tag == 1 && key == 0) {
-    hipLaunchKernelGGL((gemm_f32_kernel<64, 64, false, false, 1>), grid, dim3(256), 0, s, p);
-  } else if (d->tag == 1 && key == 4) {
-    hipLaunchKernelGGL((gemm_f32_kernel<128, 128, false, false, 1>), grid, dim3(256), 0, s, p);
-  } else
-  switch (key) {
-    case 0: LAUNCH(64, false, false); break;
-    case 1: LAUNCH(64, false, true); break;
-    case 2: LAUNCH(64, true, false); break;
-    case 3: LAUNCH(64, true, true); break;
-    case 4: LAUNCH(128, false, false); break;
-    case 5: LAUNCH(128, false, true); break;
-    case 6: LAUNCH(128, true, false); break;
-    default: LAUNCH(128, true, true); break;
+  if (t == 128) {
+    if (vec) launch_gemm<128, true>(d, p, grid, s); else launch_gemm<128, false>(d, p, grid, s);
+  } else {
+    if (vec) launch_gemm<64, true>(d, p, grid, s); else launch_gemm<64, false>(d, p, grid, s);
   }
-#undef LAUNCH
   int rc = check_launch("gemm_f32_kernel");
   if (rc != DPOT_OK) return rc;
   if (splits > 1) {

@@ -103,51 +103,85 @@ __global__ __launch_bounds__(256) void transpose2d_kernel(const float* __restric
   }
 }
 
-// column sums, stage 1: grid (cdiv(N,64), parts); block = 64 columns x 4 row lanes
-__global__ __launch_bounds__(256) void colsum_part_kernel(const float* __restrict__ X, int M, int N, int ld,
-                                                          float* __restrict__ part, int rows_per_part) {
-  __shared__ float red[4][64];
-  const int tc = threadIdx.x & 63, tr = threadIdx.x >> 6;
-  const int n = blockIdx.x * 64 + tc;
+// column sums: grid (cdiv(N,CW), parts); block = CW column lanes x (256/CW) row lanes, rows strided by the lanes,
+// 4 independent accumulators per thread (memory-level parallelism), fixed-order combine -> deterministic.
+// Stage 2 runs the same kernel over the [parts, N] partials with parts = 1.
+template <int CW>
+__global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ X, int M, int N, int ld,
+                                                     float* __restrict__ out, int rows_per_part) {
+  constexpr int RL = 256 / CW;
+  __shared__ float red[RL][CW];
+  const int tc = threadIdx.x % CW, tr = threadIdx.x / CW;
+  const int n = blockIdx.x * CW + tc;
   const int m0 = blockIdx.y * rows_per_part;
   int m1 = m0 + rows_per_part;
   if (m1 > M) m1 = M;
-  float s = 0.f;
-  if (n < N)
-    for (int m = m0 + tr; m < m1; m += 4) s += X[(long long)m * ld + n];
-  red[tr][tc] = s;
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  if (n < N) {
+    const float* p = X + n;
+    int m = m0 + tr;
+    for (; m + 3 * RL < m1; m += 4 * RL) {
+      s0 += p[(long long)m * ld];
+      s1 += p[(long long)(m + RL) * ld];
+      s2 += p[(long long)(m + 2 * RL) * ld];
+      s3 += p[(long long)(m + 3 * RL) * ld];
+    }
+    for (; m < m1; m += RL) s0 += p[(long long)m * ld];
+  }
+  red[tr][tc] = (s0 + s1) + (s2 + s3);
   __syncthreads();
-  if (tr == 0 && n < N) part[(long long)blockIdx.y * N + n] = (red[0][tc] + red[1][tc]) + (red[2][tc] + red[3][tc]);
-}
-__global__ void colsum_final_kernel(const float* __restrict__ part, int parts, int N, float* __restrict__ out) {
-  const int n = blockIdx.x * 256 + threadIdx.x;
-  if (n >= N) return;
-  float s = 0.f;
-  for (int p = 0; p < parts; ++p) s += part[(long long)p * N + n];
-  out[n] = s;
+  if (tr == 0 && n < N) {
+    float s = 0.f;
+#pragma unroll
+    for (int r = 0; r < RL; ++r) s += red[r][tc];
+    out[(long long)blockIdx.y * N + n] = s;
+  }
 }
 
 // out[r, n] = sum_{b,t} X[((b*R + r)*T + t)*N + n]
-__global__ void group_rowsum_kernel(const float* __restrict__ X, float* __restrict__ out, int B, int R, int T, int N) {
-  const int n = blockIdx.x * 256 + threadIdx.x;
+// block = 64 column lanes x 4 lanes over the (b, t) pairs; fixed-order combine
+__global__ __launch_bounds__(256) void group_rowsum_kernel(const float* __restrict__ X, float* __restrict__ out, int B,
+                                                           int R, int T, int N) {
+  __shared__ float red[4][64];
+  const int tc = threadIdx.x & 63, tr = threadIdx.x >> 6;
+  const int n = blockIdx.x * 64 + tc;
   const int r = blockIdx.y;
-  if (n >= N) return;
-  float s = 0.f;
-  for (int b = 0; b < B; ++b) {
-    const float* p = X + (((long long)b * R + r) * T) * N + n;
-    for (int t = 0; t < T; ++t) s += p[(long long)t * N];
+  float s0 = 0.f, s1 = 0.f;
+  if (n < N) {
+    const int BT = B * T;
+    int q = tr;
+    for (; q + 4 < BT; q += 8) {
+      const int b0 = q / T, t0 = q % T, b1 = (q + 4) / T, t1 = (q + 4) % T;
+      s0 += X[(((long long)b0 * R + r) * T + t0) * N + n];
+      s1 += X[(((long long)b1 * R + r) * T + t1) * N + n];
+    }
+    for (; q < BT; q += 4) s0 += X[(((long long)(q / T) * R + r) * T + (q % T)) * N + n];
   }
-  out[(long long)r * N + n] = s;
+  red[tr][tc] = s0 + s1;
+  __syncthreads();
+  if (tr == 0 && n < N) out[(long long)r * N + n] = (red[0][tc] + red[1][tc]) + (red[2][tc] + red[3][tc]);
 }
 
-__global__ void token_mean_kernel(const float* __restrict__ x, float* __restrict__ y, int T, int E) {
-  const int e = blockIdx.x * 256 + threadIdx.x;
+__global__ __launch_bounds__(256) void token_mean_kernel(const float* __restrict__ x, float* __restrict__ y, int T,
+                                                         int E) {
+  __shared__ float red[4][64];
+  const int tc = threadIdx.x & 63, tr = threadIdx.x >> 6;
+  const int e = blockIdx.x * 64 + tc;
   const int b = blockIdx.y;
-  if (e >= E) return;
-  const float* p = x + (long long)b * T * E + e;
-  float s = 0.f;
-  for (int t = 0; t < T; ++t) s += p[(long long)t * E];
-  y[(long long)b * E + e] = s / (float)T;
+  float s0 = 0.f, s1 = 0.f;
+  if (e < E) {
+    const float* p = x + (long long)b * T * E + e;
+    int t = tr;
+    for (; t + 4 < T; t += 8) {
+      s0 += p[(long long)t * E];
+      s1 += p[(long long)(t + 4) * E];
+    }
+    for (; t < T; t += 4) s0 += p[(long long)t * E];
+  }
+  red[tr][tc] = s0 + s1;
+  __syncthreads();
+  if (tr == 0 && e < E)
+    y[(long long)b * E + e] = ((red[0][tc] + red[1][tc]) + (red[2][tc] + red[3][tc])) / (float)T;
 }
 __global__ void token_mean_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ add,
                                       float* __restrict__ dx, int T, int E, long long total) {
@@ -272,34 +306,50 @@ extern "C" int dpot_transpose2d(const float* src, float* dst, int nbatch, int R,
 }
 
 extern "C" int dpot_colsum_parts(int M) {
-  int parts = cdiv(M, 128);
-  if (parts > 64) parts = 64;
+  int parts = cdiv(M, 256);
+  if (parts > 1024) parts = 1024;
   if (parts < 1) parts = 1;
   return parts;
 }
 
+static void launch_colsum(const float* X, int M, int N, int ld, float* out, int parts, hipStream_t s) {
+  const int rpp = cdiv(M, parts);
+  if (N <= 16) {
+    hipLaunchKernelGGL(colsum_kernel<16>, dim3(cdiv(N, 16), parts), dim3(256), 0, s, X, M, N, ld, out, rpp);
+  } else if (N <= 32) {
+    hipLaunchKernelGGL(colsum_kernel<32>, dim3(cdiv(N, 32), parts), dim3(256), 0, s, X, M, N, ld, out, rpp);
+  } else {
+    hipLaunchKernelGGL(colsum_kernel<64>, dim3(cdiv(N, 64), parts), dim3(256), 0, s, X, M, N, ld, out, rpp);
+  }
+}
+
 extern "C" int dpot_colsum(const float* X, int M, int N, int ld, float* out, float* part, dpot_stream_t stream) {
   DPOT_REQUIRE(X && out && part && M > 0 && N > 0 && ld >= N, "colsum: bad argument");
-  const int parts = dpot_colsum_parts(M);
-  const int rpp = cdiv(M, parts);
-  hipLaunchKernelGGL(colsum_part_kernel, dim3(cdiv(N, 64), parts), dim3(256), 0, as_stream(stream), X, M, N, ld, part,
-                     rpp);
-  int rc = check_launch("colsum_part_kernel");
+  // aim for ~1024 workgroups in stage 1 whatever the aspect ratio
+  int parts = dpot_colsum_parts(M);
+  const int colblocks = cdiv(N, N <= 16 ? 16 : N <= 32 ? 32 : 64);
+  const int want = cdiv(1024, colblocks);
+  if (parts > want) parts = want;
+  if (parts <= 1) {
+    launch_colsum(X, M, N, ld, out, 1, as_stream(stream));
+    return check_launch("colsum_kernel");
+  }
+  launch_colsum(X, M, N, ld, part, parts, as_stream(stream));
+  int rc = check_launch("colsum_kernel");
   if (rc) return rc;
-  hipLaunchKernelGGL(colsum_final_kernel, dim3(cdiv(N, 256)), dim3(256), 0, as_stream(stream), (const float*)part,
-                     parts, N, out);
-  return check_launch("colsum_final_kernel");
+  launch_colsum(part, parts, N, N, out, 1, as_stream(stream));
+  return check_launch("colsum_kernel(stage 2)");
 }
 
 extern "C" int dpot_group_rowsum(const float* X, float* out, int B, int R, int T, int N, dpot_stream_t stream) {
   DPOT_REQUIRE(X && out && B > 0 && R > 0 && T > 0 && N > 0 && R <= 65535, "group_rowsum: bad argument");
-  hipLaunchKernelGGL(group_rowsum_kernel, dim3(cdiv(N, 256), R), dim3(256), 0, as_stream(stream), X, out, B, R, T, N);
+  hipLaunchKernelGGL(group_rowsum_kernel, dim3(cdiv(N, 64), R), dim3(256), 0, as_stream(stream), X, out, B, R, T, N);
   return check_launch("group_rowsum_kernel");
 }
 
 extern "C" int dpot_token_mean(const float* x, float* y, int B, int T, int E, dpot_stream_t stream) {
   DPOT_REQUIRE(x && y && B > 0 && T > 0 && E > 0 && B <= 65535, "token_mean: bad argument");
-  hipLaunchKernelGGL(token_mean_kernel, dim3(cdiv(E, 256), B), dim3(256), 0, as_stream(stream), x, y, T, E);
+  hipLaunchKernelGGL(token_mean_kernel, dim3(cdiv(E, 64), B), dim3(256), 0, as_stream(stream), x, y, T, E);
   return check_launch("token_mean_kernel");
 }
 
