@@ -164,13 +164,12 @@ __device__ __forceinline__ void epi_fragment(const EpiArgs& e, int evec, int b, 
 }
 
 // ---- global -> register tile loaders ------------------------------------------------------------------
-// FULL = the whole K-slab is inside [k0, kmax): loads are unconditional.  Rows beyond rmax are CLAMPED to a valid
-// row instead of being zeroed: they only feed accumulator rows/columns that the epilogue never stores.  (A load
-// followed by a select is turned by hipcc into a branch around the load + s_waitcnt vmcnt(0), which serialises the
-// prefetch - so the steady-state path must not contain any per-lane condition on a load.)
-// FULL = false (the last, partial slab when K % 32 != 0): elements with k >= kmax are zeroed.
+// Loads are UNCONDITIONAL: out-of-range rows / k are CLAMPED to a valid address instead of being predicated.
+// (A load followed by a select is turned by hipcc into a branch around the load + s_waitcnt vmcnt(0), which
+// serialises the whole prefetch.)  Clamped rows only feed accumulator rows/columns the epilogue never stores;
+// the k >= kmax part of the last, partial K-slab is zeroed in LDS after the store (zero_tail_*).
 // K-contiguous source: element (r, k) at base[r*ld + k]; tile [R][BK]
-template <int R, bool VEC, bool FULL>
+template <int R, bool VEC>
 __device__ __forceinline__ void load_kcontig(float4 (&reg)[R / 32], const float* __restrict__ base, int ld,
                                              int r0, int rmax, int k0, int kmax, int tid) {
 #pragma unroll
@@ -178,30 +177,19 @@ __device__ __forceinline__ void load_kcontig(float4 (&reg)[R / 32], const float*
     const int f = tid + 256 * i;
     const int r = r0 + (f >> 3);
     const int k = k0 + ((f & 7) << 2);
-    const float* row = base + (long long)(r < rmax ? r : rmax - 1) * ld;
+    const float* row = base + (long long)min(r, rmax - 1) * ld;
     float4 v;
-    if constexpr (FULL) {
-      if constexpr (VEC) {
-        v = *reinterpret_cast<const float4*>(row + k);
-      } else {
-        v.x = row[k + 0]; v.y = row[k + 1]; v.z = row[k + 2]; v.w = row[k + 3];
-      }
+    if constexpr (VEC) {
+      v = *reinterpret_cast<const float4*>(row + min(k, kmax - 4));
     } else {
       const int kl = kmax - 1;
-      v.x = row[k + 0 < kmax ? k + 0 : kl];
-      v.y = row[k + 1 < kmax ? k + 1 : kl];
-      v.z = row[k + 2 < kmax ? k + 2 : kl];
-      v.w = row[k + 3 < kmax ? k + 3 : kl];
-      if (!(k + 0 < kmax)) v.x = 0.f;
-      if (!(k + 1 < kmax)) v.y = 0.f;
-      if (!(k + 2 < kmax)) v.z = 0.f;
-      if (!(k + 3 < kmax)) v.w = 0.f;
+      v.x = row[min(k + 0, kl)]; v.y = row[min(k + 1, kl)]; v.z = row[min(k + 2, kl)]; v.w = row[min(k + 3, kl)];
     }
     reg[i] = v;
   }
 }
 // row-contiguous source: element (r, k) at base[k*ld + r]; tile [BK][R]
-template <int R, bool VEC, bool FULL>
+template <int R, bool VEC>
 __device__ __forceinline__ void load_rcontig(float4 (&reg)[R / 32], const float* __restrict__ base, int ld,
                                              int r0, int rmax, int k0, int kmax, int tid) {
   constexpr int F4_PER_ROW = R / 4;
@@ -210,22 +198,28 @@ __device__ __forceinline__ void load_rcontig(float4 (&reg)[R / 32], const float*
     const int f = tid + 256 * i;
     const int k = k0 + f / F4_PER_ROW;
     const int r = r0 + ((f % F4_PER_ROW) << 2);
-    const float* row = base + (long long)(FULL ? k : (k < kmax ? k : kmax - 1)) * ld;
+    const float* row = base + (long long)min(k, kmax - 1) * ld;
     float4 v;
     if constexpr (VEC) {
-      v = *reinterpret_cast<const float4*>(row + (r < rmax ? r : rmax - 4));
+      v = *reinterpret_cast<const float4*>(row + min(r, rmax - 4));
     } else {
       const int rl = rmax - 1;
-      v.x = row[r + 0 < rmax ? r + 0 : rl];
-      v.y = row[r + 1 < rmax ? r + 1 : rl];
-      v.z = row[r + 2 < rmax ? r + 2 : rl];
-      v.w = row[r + 3 < rmax ? r + 3 : rl];
-    }
-    if constexpr (!FULL) {
-      if (!(k < kmax)) v = make_float4(0.f, 0.f, 0.f, 0.f);
+      v.x = row[min(r + 0, rl)]; v.y = row[min(r + 1, rl)]; v.z = row[min(r + 2, rl)]; v.w = row[min(r + 3, rl)];
     }
     reg[i] = v;
   }
+}
+// zero the k >= krem part of a staged slab (last, partial K-slab only)
+template <int R>
+__device__ __forceinline__ void zero_tail_kcontig(float* lds, int krem, int tid) {
+  for (int idx = tid; idx < R * BK; idx += 256) {
+    const int r = idx / BK, k = idx % BK;
+    if (k >= krem) lds[r * (BK + KPAD) + k] = 0.f;
+  }
+}
+template <int R>
+__device__ __forceinline__ void zero_tail_rcontig(float* lds, int krem, int tid) {
+  for (int idx = tid + krem * R; idx < BK * R; idx += 256) lds[idx] = 0.f;
 }
 template <int R>
 __device__ __forceinline__ void store_kcontig(float* lds, const float4 (&reg)[R / 32], int tid) {
@@ -312,26 +306,25 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmArgs p) {
 
   float4 ra[BM / 32], rb[BN / 32];
   auto gload = [&](int k0) {
-    if (k0 + BK <= kend) {   // uniform: whole slab in range -> branch-free loads
-      if constexpr (A_KC) load_kcontig<BM, VEC, true>(ra, A, p.lda, m0, p.M, k0, kend, tid);
-      else load_rcontig<BM, VEC, true>(ra, A, p.lda, m0, p.M, k0, kend, tid);
-      if constexpr (B_KC) load_kcontig<BN, VEC, true>(rb, B, p.ldb, n0, p.N, k0, kend, tid);
-      else load_rcontig<BN, VEC, true>(rb, B, p.ldb, n0, p.N, k0, kend, tid);
-    } else {
-      if constexpr (A_KC) load_kcontig<BM, VEC, false>(ra, A, p.lda, m0, p.M, k0, kend, tid);
-      else load_rcontig<BM, VEC, false>(ra, A, p.lda, m0, p.M, k0, kend, tid);
-      if constexpr (B_KC) load_kcontig<BN, VEC, false>(rb, B, p.ldb, n0, p.N, k0, kend, tid);
-      else load_rcontig<BN, VEC, false>(rb, B, p.ldb, n0, p.N, k0, kend, tid);
-    }
+    if constexpr (A_KC) load_kcontig<BM, VEC>(ra, A, p.lda, m0, p.M, k0, kend, tid);
+    else load_rcontig<BM, VEC>(ra, A, p.lda, m0, p.M, k0, kend, tid);
+    if constexpr (B_KC) load_kcontig<BN, VEC>(rb, B, p.ldb, n0, p.N, k0, kend, tid);
+    else load_rcontig<BN, VEC>(rb, B, p.ldb, n0, p.N, k0, kend, tid);
   };
-  auto sstore = [&]() {
+  auto sstore = [&](int k0) {
     if constexpr (A_KC) store_kcontig<BM>(As, ra, tid); else store_rcontig<BM>(As, ra, tid);
     if constexpr (B_KC) store_kcontig<BN>(Bs, rb, tid); else store_rcontig<BN>(Bs, rb, tid);
+    if (k0 + BK > kend) {  // uniform: only the last slab of a K that is not a multiple of 32
+      __syncthreads();
+      const int krem = kend - k0;
+      if constexpr (A_KC) zero_tail_kcontig<BM>(As, krem, tid); else zero_tail_rcontig<BM>(As, krem, tid);
+      if constexpr (B_KC) zero_tail_kcontig<BN>(Bs, krem, tid); else zero_tail_rcontig<BN>(Bs, krem, tid);
+    }
   };
 
   if (nk > 0) {
     gload(kbeg);
-    sstore();
+    sstore(kbeg);
     __syncthreads();
     for (int kt = 0; kt < nk; ++kt) {
       if (kt + 1 < nk) gload(kbeg + (kt + 1) * BK);
@@ -354,7 +347,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmArgs p) {
       }
       __syncthreads();
       if (kt + 1 < nk) {
-        sstore();
+        sstore(kbeg + (kt + 1) * BK);
         __syncthreads();
       }
     }
@@ -413,12 +406,10 @@ constexpr int NUM_CU = 256;
 static int pick_tile(int M, int N, int batch, int forced) {
   if (forced == 64 || forced == 128) return forced;
   if (M <= 64 || N <= 64) return 64;
+  // measured (scripts/gemm_bench.py): a 128x128 tile only pays once every CU holds >= 2 workgroups (their barrier
+  // and prologue bubbles overlap); below that the 64x64 tile (4+ co-resident workgroups per CU) is faster
   const long long t128 = (long long)cdiv(M, 128) * cdiv(N, 128) * batch;
-  const long long t64 = (long long)cdiv(M, 64) * cdiv(N, 64) * batch;
-  // CU load balance: tiles are dealt round-robin to 256 CUs; time ~ the busiest CU
-  const double eff128 = (double)t128 / (double)(NUM_CU * cdiv64(t128, NUM_CU));
-  const double eff64 = (double)t64 / (double)(NUM_CU * cdiv64(t64, NUM_CU));
-  return eff128 >= 0.92 * eff64 ? 128 : 64;
+  return t128 >= 2 * NUM_CU ? 128 : 64;
 }
 
 }  // namespace dpot
@@ -429,9 +420,9 @@ extern "C" int dpot_gemm_auto_splitk(int M, int N, int K, int batch) {
   const int t = pick_tile(M, N, batch, 0);
   const long long tiles = (long long)cdiv(M, t) * cdiv(N, t) * batch;
   const int ktiles = cdiv(K, BK);
-  if (tiles >= 128 || ktiles < 8) return 1;
-  long long s = (512 + tiles - 1) / tiles;
-  const long long smax = ktiles / 4;
+  if (tiles >= 4 * NUM_CU || ktiles < 8) return 1;
+  long long s = (4 * NUM_CU + tiles - 1) / tiles;   // aim at ~1024 workgroups (4 per CU)
+  const long long smax = ktiles / 4;                // keep >= 4 K-slabs per split
   if (s > smax) s = smax;
   if (s > 512) s = 512;
   return s < 1 ? 1 : (int)s;

@@ -29,7 +29,7 @@ def test_library_exports_every_declared_symbol(built_lib):
     lib = _lib.load()                       # binds every symbol or raises AttributeError
     assert lib.dpot_version() >= 100
     assert lib.dpot_colsum_parts(8192) == 32
-    assert lib.dpot_gemm_auto_splitk(8192, 512, 512, 1) == 1
+    assert lib.dpot_gemm_auto_splitk(81920, 512, 512, 1) == 1
     assert lib.dpot_gemm_auto_splitk(512, 512, 8192, 1) > 1
 
 
