@@ -63,6 +63,7 @@ SIGNATURES = {
     "dpot_token_mean": (c_i, [c_fp, c_fp] + [c_i] * 3 + [c_fp]),
     "dpot_token_mean_bwd": (c_i, [c_fp] * 3 + [c_i] * 3 + [c_fp]),
     "dpot_add": (c_i, [c_fp] * 3 + [c_i64, c_fp]),
+    "dpot_bias_add": (c_i, [c_fp] * 3 + [c_i, c_i, c_fp]),
     "dpot_scale_shift": (c_i, [c_fp] * 4 + [c_i] * 3 + [c_fp]),
     "dpot_timeagg_scale_w": (c_i, [c_fp] * 4 + [c_i, c_i, c_fp]),
     "dpot_timeagg_scale_w_bwd": (c_i, [c_fp] * 6 + [c_i, c_i, c_fp]),

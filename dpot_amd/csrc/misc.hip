@@ -200,6 +200,12 @@ __global__ void add_kernel(const float* __restrict__ a, const float* __restrict_
   for (long long i = blockIdx.x * 256ll + threadIdx.x; i < n; i += (long long)gridDim.x * 256) y[i] = a[i] + b[i];
 }
 
+__global__ void bias_add_kernel(const float* __restrict__ x, const float* __restrict__ v, float* __restrict__ y, int N,
+                                long long total) {
+  for (long long i = blockIdx.x * 256ll + threadIdx.x; i < total; i += (long long)gridDim.x * 256)
+    y[i] = x[i] + v[i % N];
+}
+
 __global__ void scale_shift_kernel(const float* __restrict__ x, const float* __restrict__ scale,
                                    const float* __restrict__ shift, float* __restrict__ y, int T, int E,
                                    long long total) {
@@ -366,6 +372,13 @@ extern "C" int dpot_add(const float* a, const float* b, float* y, int64_t n, dpo
   DPOT_REQUIRE(a && b && y && n > 0, "add: bad argument");
   hipLaunchKernelGGL(add_kernel, dim3(grid_for(n)), dim3(256), 0, as_stream(stream), a, b, y, (long long)n);
   return check_launch("add_kernel");
+}
+
+extern "C" int dpot_bias_add(const float* x, const float* v, float* y, int R, int N, dpot_stream_t stream) {
+  DPOT_REQUIRE(x && v && y && R > 0 && N > 0, "bias_add: bad argument");
+  const long long total = (long long)R * N;
+  hipLaunchKernelGGL(bias_add_kernel, dim3(grid_for(total)), dim3(256), 0, as_stream(stream), x, v, y, N, total);
+  return check_launch("bias_add_kernel");
 }
 
 extern "C" int dpot_scale_shift(const float* x, const float* scale, const float* shift, float* y, int B, int T, int E,

@@ -44,41 +44,67 @@ class EmbedFn(torch.autograd.Function):
         b0p = ops.copy2d_pad(b0, 1, hid, 1, hidp).view(hidp)
         w2p = ops.copy2d_pad(w2, E, hid, E, hidp)                              # zero cols hid..hidp
         Hh, Hpre = ops.linear_fwd(A0, w0p, b0p, act=act, save_pre=True)        # [M0, hidp]
+        # Everything after the activation is LINEAR (1x1 conv hid->E, + pos_embed, TimeAggregator), and the hidden
+        # width is only hid = out_channels*P+3 (35).  Instead of materialising z[M0, E] (168 MB at B=32) and
+        # contracting it with ws[T*E, E] (K = 5120), the 1x1 conv is folded INTO the aggregation weights every step:
+        #     V[t,h,j]  = sum_i w2[i,h] * ws[t,i,j]                         (T small GEMMs, 0.2 GFLOP)
+        #     c[tok,j]  = sum_i (pos[tok,i] + b2[i]) * sum_t ws[t,i,j]       (token-dependent constant)
+        #     y[m,j]    = sum_{t,h} H[m,(t,h)] * V[(t,h),j] + c[tok(m),j]    (K = T*hidp = 360 instead of 5120)
+        # Same result up to fp32 re-association; 15x fewer FLOPs for this stage, and its backward.
+        dev = x.device
+        M = B * tok
         posT = ops.transpose2d(pos, 1, E, tok).view(tok, E)                    # [tok, E]
-        Zt, _ = ops.linear_fwd(Hh, w2p, b2, res=posT, res_div=T, res_mod=tok)  # [M0, E] == [B*tok, T*E]
+        posb = ops.bias_add(posT, b2)                                          # pos + conv bias
         ws = ops.timeagg_scale_w(taw, tagamma, tt) if tagamma is not None else taw
-        Yl = torch.empty(B * tok, E, dtype=torch.float32, device=x.device)
-        ops.gemm(Zt, ws, Yl, B * tok, E, T * E, lda=T * E, ldb=E, ldc=E)       # sum_{t,i} Zt[m,(t,i)] ws[(t,i),j]
-        ctx.save_for_backward(A0, Hpre, Hh, Zt, w0p, w2p, ws, taw, tagamma, tt)
+        V = torch.empty(T * hidp, E, dtype=torch.float32, device=dev)
+        ops.gemm(w2p, ws, V, hidp, E, E, transA=True, lda=hidp, ldb=E, ldc=E, batch=T, strideA=0, strideB=E * E,
+                 strideC=hidp * E)
+        wsum = ops.colsum(ws, T, E * E).view(E, E)
+        cc = torch.empty(tok, E, dtype=torch.float32, device=dev)
+        ops.gemm(posb, wsum, cc, tok, E, E, lda=E, ldb=E, ldc=E)
+        Yl = torch.empty(M, E, dtype=torch.float32, device=dev)
+        ops.gemm(Hh, V, Yl, M, E, T * hidp, lda=T * hidp, ldb=E, ldc=E, res=cc, ldres=E, res_mod=tok)
+        ctx.save_for_backward(A0, Hpre, Hh, w0p, w2p, ws, V, wsum, posb, taw, tagamma, tt)
         ctx.dims = (B, X, Y, T, Cc, P, h, w, hid, hidp, E, K0, act)
         ctx.x_needs_grad = x.requires_grad
         return Yl.view(B, tok, E)
 
     @staticmethod
     def backward(ctx, dY):
-        A0, Hpre, Hh, Zt, w0p, w2p, ws, taw, tagamma, tt = ctx.saved_tensors
+        A0, Hpre, Hh, w0p, w2p, ws, V, wsum, posb, taw, tagamma, tt = ctx.saved_tensors
         B, X, Y, T, Cc, P, h, w, hid, hidp, E, K0, act = ctx.dims
         tok = h * w
-        M0 = B * tok * T
-        dY = dY.contiguous().view(B * tok, E)
-        # TimeAggregator
-        dZt = torch.empty(B * tok, T * E, dtype=torch.float32, device=dY.device)
-        ops.gemm(dY, ws, dZt, B * tok, T * E, E, transB=True, lda=E, ldb=E, ldc=T * E)
-        dws = torch.empty(T * E, E, dtype=torch.float32, device=dY.device)
-        ops.gemm(Zt, dY, dws, T * E, E, B * tok, transA=True, lda=T * E, ldb=E, ldc=E,
-                 splitk=ops.auto_splitk(T * E, E, B * tok))
-        if tagamma is not None:
-            dtaw, dgamma = ops.timeagg_scale_w_bwd(dws.view(T, E, E), taw, tagamma, tt)
-        else:
-            dtaw, dgamma = dws.view(T, E, E), None
-        # pos_embed + second (1x1) conv
-        dZ2 = dZt.view(M0, E)
-        dposT = ops.group_rowsum(dZ2, B, tok, T, E)                            # [tok, E]
-        dpos = ops.transpose2d(dposT, 1, tok, E).view(1, E, h, w)
-        db2 = ops.colsum(dZ2, M0, E)
-        dw2p = ops.linear_bwd_weight(dZ2, Hh)                                  # [E, hidp]
+        M, M0 = B * tok, B * tok * T
+        dev = dY.device
+        dY = dY.contiguous().view(M, E)
+        # y = H V + c  ->  dH = dY V^T (times act'), dV = H^T dY, dc = sum_b dY
+        dHpre = torch.empty(M0, hidp, dtype=torch.float32, device=dev)         # viewed [M, T*hidp]
+        ops.gemm(dY, V, dHpre, M, T * hidp, E, transB=True, lda=E, ldb=E, ldc=T * hidp, act=act, mode=EPI_DACT,
+                 aux=Hpre, ldaux=T * hidp)
+        dV = torch.empty(T * hidp, E, dtype=torch.float32, device=dev)
+        ops.gemm(Hh, dY, dV, T * hidp, E, M, transA=True, lda=T * hidp, ldb=E, ldc=E,
+                 splitk=ops.auto_splitk(T * hidp, E, M))
+        dc = ops.group_rowsum(dY, B, tok, 1, E)                                # [tok, E]
+        # c = posb wsum  ->  dwsum = posb^T dc, dposb = dc wsum^T
+        dwsum = torch.empty(E, E, dtype=torch.float32, device=dev)
+        ops.gemm(posb, dc, dwsum, E, E, tok, transA=True, lda=E, ldb=E, ldc=E, splitk=ops.auto_splitk(E, E, tok))
+        dposb = torch.empty(tok, E, dtype=torch.float32, device=dev)
+        ops.gemm(dc, wsum, dposb, tok, E, E, transB=True, lda=E, ldb=E, ldc=E)
+        dpos = ops.transpose2d(dposb, 1, tok, E).view(1, E, h, w)
+        db2 = ops.colsum(dposb, tok, E)
+        # V_t = w2^T ws_t  ->  dw2 = sum_t ws_t dV_t^T,  dws_t = w2 dV_t (+ dwsum for every t)
+        dw2_t = torch.empty(T, E, hidp, dtype=torch.float32, device=dev)
+        ops.gemm(ws, dV, dw2_t, E, hidp, E, transB=True, lda=E, ldb=E, ldc=hidp, batch=T, strideA=E * E,
+                 strideB=hidp * E, strideC=E * hidp)
+        dw2p = ops.colsum(dw2_t, T, E * hidp).view(E, hidp)
         dw2 = ops.copy2d_pad(dw2p, E, hidp, E, hid).view(E, hid, 1, 1)
-        dHpre = ops.linear_bwd_data(dZ2, w2p, act=act, aux=Hpre)               # [M0, hidp]
+        dws = torch.empty(T, E, E, dtype=torch.float32, device=dev)
+        ops.gemm(w2p, dV, dws, E, E, hidp, lda=hidp, ldb=E, ldc=E, batch=T, strideA=0, strideB=hidp * E,
+                 strideC=E * E, res=dwsum, ldres=E, strideRes=0)
+        if tagamma is not None:
+            dtaw, dgamma = ops.timeagg_scale_w_bwd(dws, taw, tagamma, tt)
+        else:
+            dtaw, dgamma = dws, None
         # first (PxP / stride P) conv
         db0 = ops.colsum(dHpre, M0, hidp)[:hid].contiguous()
         dw0p = ops.linear_bwd_weight(dHpre, A0)                                # [hidp, K0]

@@ -254,6 +254,14 @@ def add(a: Tensor, b: Tensor) -> Tensor:
     return y
 
 
+def bias_add(x: Tensor, v: Tensor) -> Tensor:
+    """y[r, n] = x[r, n] + v[n]"""
+    R, N = x.shape
+    y = torch.empty_like(x)
+    check(_lib.load().dpot_bias_add(x.data_ptr(), v.data_ptr(), y.data_ptr(), R, N, _stream()), "bias_add")
+    return y
+
+
 def scale_shift(x: Tensor, scale: Tensor, shift: Tensor) -> Tensor:
     B, T, E = x.shape
     y = torch.empty_like(x)

@@ -191,6 +191,8 @@ int dpot_token_mean_bwd(const float* dy, const float* add, float* dx, int B, int
                         dpot_stream_t stream);
 /* y = a + b (n floats) */
 int dpot_add(const float* a, const float* b, float* y, int64_t n, dpot_stream_t stream);
+/* y[r, n] = x[r, n] + v[n]   (row-broadcast add; pos_embed + conv bias folded ahead of the TimeAggregator) */
+int dpot_bias_add(const float* x, const float* v, float* y, int R, int N, dpot_stream_t stream);
 /* y[b,t,e] = x[b,t,e] * scale[b,e] + shift[b,e]  (AdaIN, models/dpot.py:386-387) */
 int dpot_scale_shift(const float* x, const float* scale, const float* shift, float* y, int B, int T, int E,
                      dpot_stream_t stream);
