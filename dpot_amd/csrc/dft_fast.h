@@ -250,7 +250,8 @@ static int launch_irfft2_fast(const float* spec, const float* res, float* y, int
 static inline int try_rfft2_fast(const float* x, float* spec, int B, int h, int w, int E, int nb, int mx, int my,
                                  int colw, float scale, hipStream_t s, int* rc) {
   if (h == 16 && w == 16) {
-    if (E % 64 == 0) { *rc = launch_rfft2_fast<16, 16, 64>(x, spec, B, E, nb, mx, my, colw, scale, s); return 1; }
+    // 64-channel slabs only when that still gives every CU >= 2 workgroups (latency hiding); else 32-channel slabs
+    if (E % 64 == 0 && (long long)B * (E / 64) >= 512) { *rc = launch_rfft2_fast<16, 16, 64>(x, spec, B, E, nb, mx, my, colw, scale, s); return 1; }
     if (E % 32 == 0) { *rc = launch_rfft2_fast<16, 16, 32>(x, spec, B, E, nb, mx, my, colw, scale, s); return 1; }
   } else if (h == 32 && w == 32) {
     if (E % 16 == 0) { *rc = launch_rfft2_fast<32, 32, 16>(x, spec, B, E, nb, mx, my, colw, scale, s); return 1; }
@@ -260,7 +261,7 @@ static inline int try_rfft2_fast(const float* x, float* spec, int B, int h, int 
 static inline int try_irfft2_fast(const float* spec, const float* res, float* y, int B, int h, int w, int E, int nb,
                                   int mx, int my, int colw, float scale, hipStream_t s, int* rc) {
   if (h == 16 && w == 16) {
-    if (E % 64 == 0) { *rc = launch_irfft2_fast<16, 16, 64>(spec, res, y, B, E, nb, mx, my, colw, scale, s); return 1; }
+    if (E % 64 == 0 && (long long)B * (E / 64) >= 512) { *rc = launch_irfft2_fast<16, 16, 64>(spec, res, y, B, E, nb, mx, my, colw, scale, s); return 1; }
     if (E % 32 == 0) { *rc = launch_irfft2_fast<16, 16, 32>(spec, res, y, B, E, nb, mx, my, colw, scale, s); return 1; }
   } else if (h == 32 && w == 32) {
     if (E % 16 == 0) { *rc = launch_irfft2_fast<32, 32, 16>(spec, res, y, B, E, nb, mx, my, colw, scale, s); return 1; }

@@ -19,12 +19,17 @@ __device__ __forceinline__ ChanLayout chan_layout(int C, int nthreads) {
   return l;
 }
 
-// one block (1024 threads) per sample: stats[b, c, 0..2] = {sum ((x-y)m)^2, sum (y m)^2, sum m}
+// grid (B, NCH): one 1024-thread block per (sample, chunk of the S axis):
+// part[b, chunk, c, 0..2] = partial {sum ((x-y)m)^2, sum (y m)^2, sum m}; combined in fixed order by the final kernel
 __global__ __launch_bounds__(1024) void rel_l2_stats_kernel(const float* __restrict__ x, const float* __restrict__ y,
-                                                            const float* __restrict__ mask, float* __restrict__ stats,
+                                                            const float* __restrict__ mask, float* __restrict__ part,
                                                             int S, int C, int Tt) {
   __shared__ double red[3][1024];
   const int b = blockIdx.x;
+  const int nch = gridDim.y, chunk = blockIdx.y;
+  const int rows = (S + nch - 1) / nch;
+  const int s_beg = chunk * rows;
+  const int s_end = min(S, s_beg + rows);
   const ChanLayout L = chan_layout(C, 1024);
   const int tc = threadIdx.x % L.CP, ts = threadIdx.x / L.CP;
   double d2 = 0.0, y2 = 0.0, ms = 0.0;
@@ -32,7 +37,7 @@ __global__ __launch_bounds__(1024) void rel_l2_stats_kernel(const float* __restr
     const float* xb = x + (long long)b * S * C;
     const float* yb = y + (long long)b * S * C;
     const float* mb = mask ? mask + (long long)b * (S / Tt) * C : nullptr;
-    for (int s = ts; s < S; s += L.TS) {
+    for (int s = s_beg + ts; s < s_end; s += L.TS) {
       const float m = mb ? mb[(long long)(s / Tt) * C + tc] : 1.f;
       const float yv = yb[(long long)s * C + tc] * m;
       const float d = xb[(long long)s * C + tc] * m - yv;
@@ -52,7 +57,7 @@ __global__ __launch_bounds__(1024) void rel_l2_stats_kernel(const float* __restr
       bq += red[1][r * L.CP + tc];
       cq += red[2][r * L.CP + tc];
     }
-    float* st = stats + ((long long)b * C + tc) * 4;
+    float* st = part + (((long long)b * nch + chunk) * C + tc) * 4;
     st[0] = (float)a;
     st[1] = (float)bq;
     st[2] = (float)cq;
@@ -60,15 +65,26 @@ __global__ __launch_bounds__(1024) void rel_l2_stats_kernel(const float* __restr
   }
 }
 
-__global__ void rel_l2_final_kernel(const float* __restrict__ stats, float* __restrict__ loss, int B, int C,
-                                    int has_mask) {
+__global__ void rel_l2_final_kernel(float* __restrict__ stats, const float* __restrict__ part, int nchunk,
+                                    float* __restrict__ loss, int B, int C, int has_mask) {
   __shared__ double shd[16];
   double acc = 0.0;
   for (int b = threadIdx.x; b < B; b += blockDim.x) {
     double s = 0.0;
     int nch = 0;
     for (int c = 0; c < C; ++c) {
-      const float* st = stats + ((long long)b * C + c) * 4;
+      float* st = stats + ((long long)b * C + c) * 4;
+      double a0 = 0.0, a1 = 0.0, a2 = 0.0;
+      for (int k = 0; k < nchunk; ++k) {
+        const float* pp = part + (((long long)b * nchunk + k) * C + c) * 4;
+        a0 += (double)pp[0];
+        a1 += (double)pp[1];
+        a2 += (double)pp[2];
+      }
+      st[0] = (float)a0;
+      st[1] = (float)a1;
+      st[2] = (float)a2;
+      st[3] = 0.f;
       s += (double)(sqrtf(st[0]) / (sqrtf(st[1]) + 1e-8f));
       if (st[2] != 0.f) ++nch;
     }
@@ -202,15 +218,24 @@ static inline unsigned grid_for(long long n, int cap = 4096) {
 
 using namespace dpot;
 
+extern "C" int dpot_rel_l2_chunks(int S, int C) {
+  long long n = ((long long)S * C + 16383) / 16384;
+  if (n > 32) n = 32;
+  if (n < 1) n = 1;
+  return (int)n;
+}
+
 extern "C" int dpot_rel_l2_fwd(const float* x, const float* y, const float* mask, float* stats, float* loss, int B,
                                int S, int C, int Tt, dpot_stream_t stream) {
   DPOT_REQUIRE(x && y && stats && loss, "rel_l2_fwd: null pointer");
   DPOT_REQUIRE(B > 0 && S > 0 && C > 0 && C <= 1024 && Tt > 0 && S % Tt == 0, "rel_l2_fwd: bad shape");
-  hipLaunchKernelGGL(rel_l2_stats_kernel, dim3(B), dim3(1024), 0, as_stream(stream), x, y, mask, stats, S, C, Tt);
+  const int nch = dpot_rel_l2_chunks(S, C);
+  float* part = stats + (size_t)B * C * 4;
+  hipLaunchKernelGGL(rel_l2_stats_kernel, dim3(B, nch), dim3(1024), 0, as_stream(stream), x, y, mask, part, S, C, Tt);
   int rc = check_launch("rel_l2_stats_kernel");
   if (rc) return rc;
-  hipLaunchKernelGGL(rel_l2_final_kernel, dim3(1), dim3(256), 0, as_stream(stream), (const float*)stats, loss, B, C,
-                     mask ? 1 : 0);
+  hipLaunchKernelGGL(rel_l2_final_kernel, dim3(1), dim3(256), 0, as_stream(stream), stats, (const float*)part, nch,
+                     loss, B, C, mask ? 1 : 0);
   return check_launch("rel_l2_final_kernel");
 }
 

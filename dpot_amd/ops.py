@@ -292,7 +292,8 @@ def timeagg_scale_w_bwd(dws: Tensor, w: Tensor, gamma: Tensor, tt: Tensor) -> Tu
 # loss / optimiser
 # ------------------------------------------------------------------------------------------------------
 def rel_l2_fwd(x: Tensor, y: Tensor, mask: Optional[Tensor], B: int, S: int, Cc: int, Tt: int):
-    stats = torch.empty(B, Cc, 4, dtype=torch.float32, device=x.device)
+    nch = _lib.load().dpot_rel_l2_chunks(S, Cc)
+    stats = torch.empty(1 + nch, B, Cc, 4, dtype=torch.float32, device=x.device)
     loss = torch.empty(1, dtype=torch.float32, device=x.device)
     check(_lib.load().dpot_rel_l2_fwd(x.data_ptr(), y.data_ptr(), _p(mask), stats.data_ptr(), loss.data_ptr(), B, S,
                                       Cc, Tt, _stream()), "rel_l2_fwd")

@@ -209,7 +209,9 @@ int dpot_timeagg_scale_w_bwd(const float* dws, const float* w, const float* gamm
  * ------------------------------------------------------------------------------------------------ */
 /* masked relative L2 summed over the batch (SimpleLpLoss(size_average=False), utils/criterion.py:38-59).
  * x,y: [B, S, C] (S = X*Y*T), mask: [B, Sm, C] with S % Sm == 0 broadcast over the time axis (or NULL).
- * stats[B, C, 4] = {sum d^2, sum y^2, sum mask, unused}; loss: 1 float.  bwd: dx = gloss[0] * dloss/dx. */
+ * stats: (1 + dpot_rel_l2_chunks(S, C)) * B * C * 4 floats; the first [B, C, 4] block holds the final
+ * {sum d^2, sum y^2, sum mask, unused}, the rest is per-chunk scratch.  loss: 1 float.  bwd: dx = gloss[0] * dloss/dx. */
+int dpot_rel_l2_chunks(int S, int C);
 int dpot_rel_l2_fwd(const float* x, const float* y, const float* mask, float* stats, float* loss, int B,
                     int S, int C, int Tt, dpot_stream_t stream);
 int dpot_rel_l2_bwd(const float* x, const float* y, const float* mask, const float* stats,
