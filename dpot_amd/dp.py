@@ -55,6 +55,9 @@ class BucketedGradReducer:
         self._work = []
         self._launched = [False] * self.n_buckets
         self._hooks = []
+        # two notification sources: (a) the HIP stage backwards write gradients straight into the flat buffer and
+        # call FlatParams.fire(i); (b) ordinary autograd accumulation (foreign graphs) -> post-accumulate hooks
+        flat.callbacks.append(self._on_ready)
         for i, p in enumerate(flat.params):
             self._hooks.append(p.register_post_accumulate_grad_hook(self._make_hook(i)))
 
@@ -71,15 +74,18 @@ class BucketedGradReducer:
         self._launched = [False] * self.n_buckets
         self._work = []
 
+    def _on_ready(self, i: int) -> None:
+        if self._seen[i]:
+            return
+        self._seen[i] = True
+        k = self.bucket_of[i]
+        self._pending[k] -= 1
+        if self._pending[k] == 0:
+            self._launch(k)
+
     def _make_hook(self, i: int):
         def hook(_param):
-            if self._seen[i]:
-                return
-            self._seen[i] = True
-            k = self.bucket_of[i]
-            self._pending[k] -= 1
-            if self._pending[k] == 0:
-                self._launch(k)
+            self._on_ready(i)
         return hook
 
     def _launch(self, k: int) -> None:

@@ -1,12 +1,16 @@
 """Autograd functions of the DPOT step, one per stage, each with a hand-written backward that calls the HIP
 kernels directly (no autograd tracing inside a stage, no eager-PyTorch math):
 
-  EmbedFn   patch embed (8x8/8 conv as GEMM + act + 1x1 conv + pos) -> TimeAggregator   models/dpot.py:373-384
-  BlockFn   GroupNorm -> AFNO mixer -> GroupNorm -> channel MLP -> +residual             models/dpot.py:165-180
-  HeadFn    out_layer (ConvTranspose as GEMM + pixel tail) and cls_head                  models/dpot.py:394-398
-  RelL2Fn   masked relative L2 loss                                                      utils/criterion.py:38-59
+  EmbedFn   patch embed (8x8/8 conv as GEMM + act) -> folded [1x1 conv + pos + TimeAggregator] GEMM  models/dpot.py:373-384
+  BlockFn   GroupNorm -> AFNO mixer -> GroupNorm -> channel MLP -> +residual                        models/dpot.py:165-180
+  HeadFn    out_layer (ConvTranspose as GEMM + pixel tail) and cls_head                             models/dpot.py:394-398
+  RelL2Fn   masked relative L2 loss                                                                 utils/criterion.py:38-59
 
 Internal activation layout: channels-last tokens [B, h*w, E] (row-major [B*h*w, E]).
+
+Parameter gradients: when the parameters live in a train.FlatParams buffer, the backward kernels write them straight
+into their slot of the flat gradient buffer (see _Sink) and autograd receives None - no per-parameter accumulate
+kernels, and the data-parallel reducer is notified the moment a parameter's gradient is final.
 """
 from __future__ import annotations
 
@@ -15,13 +19,53 @@ from typing import Optional
 import torch
 
 from . import ops
-from .ops import EPI_ACT, EPI_DACT, EPI_LINEAR
+from .ops import EPI_ACT, EPI_DACT
 
 Tensor = torch.Tensor
 
 
 def _pad4(n: int) -> int:
     return (n + 3) // 4 * 4
+
+
+class _Sink:
+    """Where the gradient of one parameter goes.
+
+    forward:  ``_Sink(param, needed)`` registers one pending use if ``param`` is bound to a FlatParams slot.
+    backward: ``out()`` is the buffer the producing kernel should write (the slot itself for the first contribution of
+              a step, None = "allocate a temporary" otherwise); ``done(t)`` finalises: returns ``t`` for plain
+              autograd, or adds/marks the slot, notifies the owner when the last pending use has delivered, and
+              returns None (autograd then has nothing to accumulate)."""
+    __slots__ = ("fp", "i")
+
+    def __init__(self, param: Optional[Tensor], needed: bool):
+        s = getattr(param, "_dpot_grad_slot", None) if (needed and param is not None) else None
+        self.fp, self.i = s if s is not None else (None, -1)
+        if self.fp is not None:
+            self.fp.pending[self.i] += 1
+
+    def out(self) -> Optional[Tensor]:
+        if self.fp is None or self.fp.filled[self.i]:
+            return None
+        return self.fp.grad_views[self.i]
+
+    def done(self, t: Optional[Tensor]) -> Optional[Tensor]:
+        if self.fp is None or t is None:
+            return t
+        fp, i = self.fp, self.i
+        view = fp.grad_views[i]
+        if t.data_ptr() == view.data_ptr():
+            fp.filled[i] = True
+        else:
+            view.add_(t.reshape(view.shape))          # a further use of the same parameter in this step
+        fp.pending[i] -= 1
+        if fp.pending[i] == 0:
+            fp.fire(i)
+        return None
+
+
+def _sinks(ctx, params, first_index: int):
+    return [_Sink(p, ctx.needs_input_grad[first_index + k]) for k, p in enumerate(params)]
 
 
 # ======================================================================================================
@@ -37,7 +81,8 @@ class EmbedFn(torch.autograd.Function):
         hid, E = w0.shape[0], w2.shape[0]
         K0 = (Cc + 3) * P * P
         hidp = _pad4(hid)
-        M0 = B * tok * T
+        dev = x.device
+        M = B * tok
 
         A0 = ops.patchify(x, gx, gy, gt, P)                                    # [M0, K0], rows (b,px,py,t)
         w0p = ops.copy2d_pad(w0, hid, K0, hidp, K0)                            # zero rows hid..hidp
@@ -51,8 +96,6 @@ class EmbedFn(torch.autograd.Function):
         #     c[tok,j]  = sum_i (pos[tok,i] + b2[i]) * sum_t ws[t,i,j]       (token-dependent constant)
         #     y[m,j]    = sum_{t,h} H[m,(t,h)] * V[(t,h),j] + c[tok(m),j]    (K = T*hidp = 360 instead of 5120)
         # Same result up to fp32 re-association; 15x fewer FLOPs for this stage, and its backward.
-        dev = x.device
-        M = B * tok
         posT = ops.transpose2d(pos, 1, E, tok).view(tok, E)                    # [tok, E]
         posb = ops.bias_add(posT, b2)                                          # pos + conv bias
         ws = ops.timeagg_scale_w(taw, tagamma, tt) if tagamma is not None else taw
@@ -66,13 +109,14 @@ class EmbedFn(torch.autograd.Function):
         ops.gemm(Hh, V, Yl, M, E, T * hidp, lda=T * hidp, ldb=E, ldc=E, res=cc, ldres=E, res_mod=tok)
         ctx.save_for_backward(A0, Hpre, Hh, w0p, w2p, ws, V, wsum, posb, taw, tagamma, tt)
         ctx.dims = (B, X, Y, T, Cc, P, h, w, hid, hidp, E, K0, act)
-        ctx.x_needs_grad = x.requires_grad
+        ctx.sinks = _sinks(ctx, (pos, w0, b0, w2, b2, taw, tagamma), 1)
         return Yl.view(B, tok, E)
 
     @staticmethod
     def backward(ctx, dY):
         A0, Hpre, Hh, w0p, w2p, ws, V, wsum, posb, taw, tagamma, tt = ctx.saved_tensors
         B, X, Y, T, Cc, P, h, w, hid, hidp, E, K0, act = ctx.dims
+        s_pos, s_w0, s_b0, s_w2, s_b2, s_taw, s_gamma = ctx.sinks
         tok = h * w
         M, M0 = B * tok, B * tok * T
         dev = dY.device
@@ -90,27 +134,30 @@ class EmbedFn(torch.autograd.Function):
         ops.gemm(posb, dc, dwsum, E, E, tok, transA=True, lda=E, ldb=E, ldc=E, splitk=ops.auto_splitk(E, E, tok))
         dposb = torch.empty(tok, E, dtype=torch.float32, device=dev)
         ops.gemm(dc, wsum, dposb, tok, E, E, transB=True, lda=E, ldb=E, ldc=E)
-        dpos = ops.transpose2d(dposb, 1, tok, E).view(1, E, h, w)
-        db2 = ops.colsum(dposb, tok, E)
+        dpos = s_pos.done(ops.transpose2d(dposb, 1, tok, E, out=s_pos.out()).view(1, E, h, w))
+        db2 = s_b2.done(ops.colsum(dposb, tok, E, out=s_b2.out()))
         # V_t = w2^T ws_t  ->  dw2 = sum_t ws_t dV_t^T,  dws_t = w2 dV_t (+ dwsum for every t)
         dw2_t = torch.empty(T, E, hidp, dtype=torch.float32, device=dev)
         ops.gemm(ws, dV, dw2_t, E, hidp, E, transB=True, lda=E, ldb=E, ldc=hidp, batch=T, strideA=E * E,
                  strideB=hidp * E, strideC=E * hidp)
         dw2p = ops.colsum(dw2_t, T, E * hidp).view(E, hidp)
-        dw2 = ops.copy2d_pad(dw2p, E, hidp, E, hid).view(E, hid, 1, 1)
-        dws = torch.empty(T, E, E, dtype=torch.float32, device=dev)
+        dw2 = s_w2.done(ops.copy2d_pad(dw2p, E, hidp, E, hid, out=s_w2.out()).view(E, hid, 1, 1))
+        dws = s_taw.out() if tagamma is None else None
+        dws = ops._out(dws, (T, E, E), dev)
         ops.gemm(w2p, dV, dws, E, E, hidp, lda=hidp, ldb=E, ldc=E, batch=T, strideA=0, strideB=hidp * E,
                  strideC=E * E, res=dwsum, ldres=E, strideRes=0)
         if tagamma is not None:
-            dtaw, dgamma = ops.timeagg_scale_w_bwd(dws, taw, tagamma, tt)
+            dtaw, dgamma = ops.timeagg_scale_w_bwd(dws, taw, tagamma, tt, out_dw=s_taw.out(),
+                                                   out_dgamma=s_gamma.out())
+            dtaw, dgamma = s_taw.done(dtaw), s_gamma.done(dgamma)
         else:
-            dtaw, dgamma = dws, None
+            dtaw, dgamma = s_taw.done(dws), None
         # first (PxP / stride P) conv
-        db0 = ops.colsum(dHpre, M0, hidp)[:hid].contiguous()
-        dw0p = ops.linear_bwd_weight(dHpre, A0)                                # [hidp, K0]
-        dw0 = dw0p[:hid].contiguous().view(hid, Cc + 3, P, P)
+        db0 = s_b0.done(ops.colsum(dHpre, M0, hid, ld=hidp, out=s_b0.out()))
+        dw0p = ops.linear_bwd_weight(dHpre, A0)                                # [hidp, K0] (padded: 16-byte loads)
+        dw0 = s_w0.done(ops.copy2d_pad(dw0p, hidp, K0, hid, K0, out=s_w0.out()).view(hid, Cc + 3, P, P))
         dx = None
-        if ctx.x_needs_grad:
+        if ctx.needs_input_grad[0]:
             dA0 = ops.linear_bwd_data(dHpre, w0p)                              # [M0, K0]
             dx = ops.unpatchify(dA0, B, X, Y, T, Cc, P)
         return dx, dpos, dw0, db0, dw2, db2, dtaw, dgamma, None, None, None, None, None, None
@@ -151,6 +198,7 @@ class BlockFn(torch.autograd.Function):
         ctx.save_for_backward(x, mean1, rstd1, S, O1pre, O1, y1, mean2, rstd2, xn2, Hpre, Hh, wb1, wb2, n1w, n2w, f1w,
                               f2w)
         ctx.dims = (B, tok, E, h, w, nb, bs, mx, my, mh, act)
+        ctx.sinks = _sinks(ctx, (n1w, n1b, w1, b1, w2, b2, n2w, n2b, f1w, f1b, f2w, f2b), 1)
         return out.view(B, tok, E)
 
     @staticmethod
@@ -158,18 +206,21 @@ class BlockFn(torch.autograd.Function):
         (x, mean1, rstd1, S, O1pre, O1, y1, mean2, rstd2, xn2, Hpre, Hh, wb1, wb2, n1w, n2w, f1w,
          f2w) = ctx.saved_tensors
         B, tok, E, h, w, nb, bs, mx, my, mh, act = ctx.dims
+        s_n1w, s_n1b, s_w1, s_b1, s_w2, s_b2, s_n2w, s_n2b, s_f1w, s_f1b, s_f2w, s_f2b = ctx.sinks
         M, Mm = B * tok, B * mx * my
         dev = dout.device
         dout = dout.contiguous()
         do2 = dout.view(M, E)
         # channel MLP
         dHpre = ops.linear_bwd_data(do2, f2w, act=act, aux=Hpre)               # [M, mh]
-        df2w = ops.linear_bwd_weight(do2, Hh)
-        df2b = ops.colsum(do2, M, E)
+        df2w = s_f2w.done(ops.linear_bwd_weight(do2, Hh, out=s_f2w.out()).view(E, mh, 1, 1))
+        df2b = s_f2b.done(ops.colsum(do2, M, E, out=s_f2b.out()))
         dxn2 = ops.linear_bwd_data(dHpre, f1w)                                 # [M, E]
-        df1w = ops.linear_bwd_weight(dHpre, xn2.view(M, E))
-        df1b = ops.colsum(dHpre, M, mh)
-        dy1, dn2w, dn2b = ops.groupnorm_bwd(dxn2.view(B, tok, E), y1, mean2, rstd2, n2w)
+        df1w = s_f1w.done(ops.linear_bwd_weight(dHpre, xn2.view(M, E), out=s_f1w.out()).view(mh, E, 1, 1))
+        df1b = s_f1b.done(ops.colsum(dHpre, M, mh, out=s_f1b.out()))
+        dy1, dn2w, dn2b = ops.groupnorm_bwd(dxn2.view(B, tok, E), y1, mean2, rstd2, n2w, out_dgamma=s_n2w.out(),
+                                            out_dbeta=s_n2b.out())
+        dn2w, dn2b = s_n2w.done(dn2w), s_n2b.done(dn2b)
         # AFNO mixer
         dO2 = ops.rfft2(dy1, h, w, nb, mx, my, 1)                              # adjoint of irfft2
         kw = dict(lda=2 * E, ldb=2 * bs, ldc=2 * E, batch=nb, strideA=2 * bs, strideB=4 * bs * bs, strideC=2 * bs)
@@ -187,12 +238,14 @@ class BlockFn(torch.autograd.Function):
         dwb1 = torch.empty(nb, 2 * bs, 2 * bs, dtype=torch.float32, device=dev)
         ops.gemm(S, dO1pre, dwb1, 2 * bs, 2 * bs, Mm, **wkw)
         dbb1 = ops.colsum(dO1pre, Mm, 2 * E)
-        dw1, db1 = ops.afno_unpack_grad(dwb1, dbb1, nb, bs)
-        dw2, db2 = ops.afno_unpack_grad(dwb2, dbb2, nb, bs)
+        dw1, db1 = ops.afno_unpack_grad(dwb1, dbb1, nb, bs, out_dw=s_w1.out(), out_db=s_b1.out())
+        dw2, db2 = ops.afno_unpack_grad(dwb2, dbb2, nb, bs, out_dw=s_w2.out(), out_db=s_b2.out())
+        dw1, db1, dw2, db2 = s_w1.done(dw1), s_b1.done(db1), s_w2.done(dw2), s_b2.done(db2)
         dxn1 = ops.irfft2(dS, B, h, w, E, nb, mx, my, 0, res=dy1)              # adjoint of rfft2, + skip path
-        dx, dn1w, dn1b = ops.groupnorm_bwd(dxn1, x, mean1, rstd1, n1w, add=dout)
-        return (dx, dn1w, dn1b, dw1, db1, dw2, db2, dn2w, dn2b, df1w.view(mh, E, 1, 1), df1b, df2w.view(E, mh, 1, 1),
-                df2b, None, None, None, None, None)
+        dx, dn1w, dn1b = ops.groupnorm_bwd(dxn1, x, mean1, rstd1, n1w, add=dout, out_dgamma=s_n1w.out(),
+                                           out_dbeta=s_n1b.out())
+        dn1w, dn1b = s_n1w.done(dn1w), s_n1b.done(dn1b)
+        return (dx, dn1w, dn1b, dw1, db1, dw2, db2, dn2w, dn2b, df1w, df1b, df2w, df2b, None, None, None, None, None)
 
 
 # ======================================================================================================
@@ -225,12 +278,17 @@ class HeadFn(torch.autograd.Function):
         cls, _ = ops.linear_fwd(c2, c4w, c4b)
         ctx.save_for_backward(x, wt, U, Upre, V, Vpre, o2w, o4w, cm, c1, c1pre, c2, c2pre, c0w, c2w, c4w)
         ctx.dims = (B, tok, E, h, w, P, old, co, act)
+        # the cls_head sinks are registered lazily in backward: whether that branch runs is only known there
+        ctx.sinks = _sinks(ctx, (o0w, o0b, o2w, o2b, o4w, o4b), 1)
+        ctx.cls_params = (c0w, c0b, c2w, c2b, c4w, c4b)
+        ctx.cls_needed = tuple(ctx.needs_input_grad[7:13])
         return pred, cls
 
     @staticmethod
     def backward(ctx, dpred, dcls):
         x, wt, U, Upre, V, Vpre, o2w, o4w, cm, c1, c1pre, c2, c2pre, c0w, c2w, c4w = ctx.saved_tensors
         B, tok, E, h, w, P, old, co, act = ctx.dims
+        s_o0w, s_o0b, s_o2w, s_o2b, s_o4w, s_o4b = ctx.sinks
         PP = P * P
         M, Mp = B * tok, B * tok * PP
         dev = x.device
@@ -241,33 +299,34 @@ class HeadFn(torch.autograd.Function):
             # ---- out layer
             dZ = ops.pixel_shuffle(dpred.contiguous(), B, h, w, P, co, inverse=True)      # [Mp, co]
             dVpre = ops.linear_bwd_data(dZ, o4w2, act=act, aux=Vpre)                      # [Mp, old]
-            do4w = ops.linear_bwd_weight(dZ, V).view(co, old, 1, 1)
-            do4b = ops.colsum(dZ, Mp, co)
+            do4w = s_o4w.done(ops.linear_bwd_weight(dZ, V, out=s_o4w.out()).view(co, old, 1, 1))
+            do4b = s_o4b.done(ops.colsum(dZ, Mp, co, out=s_o4b.out()))
             dUpre = ops.linear_bwd_data(dVpre, o2w2, act=act, aux=Upre.view(Mp, old))     # [Mp, old]
-            do2w = ops.linear_bwd_weight(dVpre, U.view(Mp, old)).view(old, old, 1, 1)
-            do2b = ops.colsum(dVpre, Mp, old)
-            do0b = ops.colsum(dUpre, Mp, old)
+            do2w = s_o2w.done(ops.linear_bwd_weight(dVpre, U.view(Mp, old), out=s_o2w.out()).view(old, old, 1, 1))
+            do2b = s_o2b.done(ops.colsum(dVpre, Mp, old, out=s_o2b.out()))
+            do0b = s_o0b.done(ops.colsum(dUpre, Mp, old, out=s_o0b.out()))
             dU2 = dUpre.view(M, PP * old)
             dx_out = torch.empty(M, E, dtype=torch.float32, device=dev)
             ops.gemm(dU2, wt, dx_out, M, E, PP * old, transB=True, lda=PP * old, ldb=PP * old, ldc=E)
             dwt = torch.empty(E, PP * old, dtype=torch.float32, device=dev)
             ops.gemm(x, dU2, dwt, E, PP * old, M, transA=True, lda=E, ldb=PP * old, ldc=PP * old,
                      splitk=ops.auto_splitk(E, PP * old, M))
-            do0w = ops.transpose2d(dwt, E, PP, old).view(E, old, P, P)
+            do0w = s_o0w.done(ops.transpose2d(dwt, E, PP, old, out=s_o0w.out()).view(E, old, P, P))
             dx_out = dx_out.view(B, tok, E)
         dx = dx_out
         if dcls is not None:
             # ---- cls head
+            s_c0w, s_c0b, s_c2w, s_c2b, s_c4w, s_c4b = [_Sink(p, n) for p, n in zip(ctx.cls_params, ctx.cls_needed)]
             dcls = dcls.contiguous()
             dc2pre = ops.linear_bwd_data(dcls, c4w, act=act, aux=c2pre)
-            dc4w = ops.linear_bwd_weight(dcls, c2)
-            dc4b = ops.colsum(dcls, B, dcls.shape[1])
+            dc4w = s_c4w.done(ops.linear_bwd_weight(dcls, c2, out=s_c4w.out()))
+            dc4b = s_c4b.done(ops.colsum(dcls, B, dcls.shape[1], out=s_c4b.out()))
             dc1pre = ops.linear_bwd_data(dc2pre, c2w, act=act, aux=c1pre)
-            dc2w = ops.linear_bwd_weight(dc2pre, c1)
-            dc2b = ops.colsum(dc2pre, B, E)
+            dc2w = s_c2w.done(ops.linear_bwd_weight(dc2pre, c1, out=s_c2w.out()))
+            dc2b = s_c2b.done(ops.colsum(dc2pre, B, E, out=s_c2b.out()))
             dcm = ops.linear_bwd_data(dc1pre, c0w)
-            dc0w = ops.linear_bwd_weight(dc1pre, cm)
-            dc0b = ops.colsum(dc1pre, B, E)
+            dc0w = s_c0w.done(ops.linear_bwd_weight(dc1pre, cm, out=s_c0w.out()))
+            dc0b = s_c0b.done(ops.colsum(dc1pre, B, E, out=s_c0b.out()))
             dx = ops.token_mean_bwd(dcm, tok, add=dx_out)
         return (dx, do0w, do0b, do2w, do2b, do4w, do4b, dc0w, dc0b, dc2w, dc2b, dc4w, dc4b, None, None, None, None)
 

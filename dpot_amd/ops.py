@@ -103,11 +103,19 @@ def linear_bwd_data(dy: Tensor, W: Tensor, act: int = 0, aux: Optional[Tensor] =
     return dx
 
 
-def linear_bwd_weight(dy: Tensor, x: Tensor) -> Tensor:
-    """dW[N,K] = dy[M,N]^T @ x[M,K]   (split-K over the token dimension)."""
+def _out(out: Optional[Tensor], shape, device) -> Tensor:
+    """`out` (a gradient slot inside the flat gradient buffer, see train.FlatParams) or a fresh tensor"""
+    if out is None:
+        return torch.empty(shape, dtype=torch.float32, device=device)
+    return out.view(shape)
+
+
+def linear_bwd_weight(dy: Tensor, x: Tensor, out: Optional[Tensor] = None, n_rows: Optional[int] = None) -> Tensor:
+    """dW[N,K] = dy[M,N]^T @ x[M,K]   (split-K over the token dimension); n_rows < N computes only dW[:n_rows]."""
     M, N = dy.shape
+    N = n_rows or N
     K = x.shape[1]
-    dW = torch.empty(N, K, dtype=torch.float32, device=dy.device)
+    dW = _out(out, (N, K), dy.device)
     gemm(dy, x, dW, N, K, M, transA=True, transB=False, lda=dy.stride(0), ldb=x.stride(0), ldc=K,
          splitk=auto_splitk(N, K, M))
     return dW
@@ -142,9 +150,10 @@ def afno_pack(w: Tensor, b: Tensor) -> Tuple[Tensor, Tensor]:
     return wbig, bbig
 
 
-def afno_unpack_grad(dwbig: Tensor, dbbig: Tensor, nb: int, bs: int) -> Tuple[Tensor, Tensor]:
-    dw = torch.empty(2, nb, bs, bs, dtype=torch.float32, device=dwbig.device)
-    db = torch.empty(2, nb, bs, dtype=torch.float32, device=dwbig.device)
+def afno_unpack_grad(dwbig: Tensor, dbbig: Tensor, nb: int, bs: int, out_dw: Optional[Tensor] = None,
+                     out_db: Optional[Tensor] = None) -> Tuple[Tensor, Tensor]:
+    dw = _out(out_dw, (2, nb, bs, bs), dwbig.device)
+    db = _out(out_db, (2, nb, bs), dwbig.device)
     check(_lib.load().dpot_afno_unpack_grad(dwbig.data_ptr(), dbbig.data_ptr(), dw.data_ptr(), db.data_ptr(), nb, bs,
                                             _stream()), "afno_unpack_grad")
     return dw, db
@@ -164,11 +173,12 @@ def groupnorm_fwd(x: Tensor, gamma: Tensor, beta: Tensor, G: int = 8, eps: float
 
 
 def groupnorm_bwd(dy: Tensor, x: Tensor, mean: Tensor, rstd: Tensor, gamma: Tensor, G: int = 8,
-                  add: Optional[Tensor] = None):
+                  add: Optional[Tensor] = None, out_dgamma: Optional[Tensor] = None,
+                  out_dbeta: Optional[Tensor] = None):
     B, T, E = x.shape
     dx = torch.empty_like(x)
-    dgamma = torch.empty(E, dtype=torch.float32, device=x.device)
-    dbeta = torch.empty(E, dtype=torch.float32, device=x.device)
+    dgamma = _out(out_dgamma, (E,), x.device)
+    dbeta = _out(out_dbeta, (E,), x.device)
     part = torch.empty(2, B, E, dtype=torch.float32, device=x.device)
     check(_lib.load().dpot_groupnorm_bwd(dy.data_ptr(), x.data_ptr(), mean.data_ptr(), rstd.data_ptr(),
                                          gamma.data_ptr(), _p(add), dx.data_ptr(), dgamma.data_ptr(),
@@ -207,21 +217,21 @@ def pixel_shuffle(z: Tensor, B: int, h: int, w: int, P: int, Cc: int, inverse: b
     return out
 
 
-def copy2d_pad(src: Tensor, sR: int, sC: int, dR: int, dC: int) -> Tensor:
-    dst = torch.empty(dR, dC, dtype=torch.float32, device=src.device)
+def copy2d_pad(src: Tensor, sR: int, sC: int, dR: int, dC: int, out: Optional[Tensor] = None) -> Tensor:
+    dst = _out(out, (dR, dC), src.device)
     check(_lib.load().dpot_copy2d_pad(src.data_ptr(), sR, sC, dst.data_ptr(), dR, dC, _stream()), "copy2d_pad")
     return dst
 
 
-def transpose2d(src: Tensor, nbatch: int, R: int, Cn: int) -> Tensor:
-    dst = torch.empty(nbatch, Cn, R, dtype=torch.float32, device=src.device)
+def transpose2d(src: Tensor, nbatch: int, R: int, Cn: int, out: Optional[Tensor] = None) -> Tensor:
+    dst = _out(out, (nbatch, Cn, R), src.device)
     check(_lib.load().dpot_transpose2d(src.data_ptr(), dst.data_ptr(), nbatch, R, Cn, _stream()), "transpose2d")
     return dst
 
 
-def colsum(X: Tensor, M: int, N: int, ld: Optional[int] = None) -> Tensor:
+def colsum(X: Tensor, M: int, N: int, ld: Optional[int] = None, out: Optional[Tensor] = None) -> Tensor:
     lib = _lib.load()
-    out = torch.empty(N, dtype=torch.float32, device=X.device)
+    out = _out(out, (N,), X.device)
     part = torch.empty(lib.dpot_colsum_parts(M), N, dtype=torch.float32, device=X.device)
     check(lib.dpot_colsum(X.data_ptr(), M, N, ld or N, out.data_ptr(), part.data_ptr(), _stream()), "colsum")
     return out
@@ -278,10 +288,11 @@ def timeagg_scale_w(w: Tensor, gamma: Tensor, tt: Tensor) -> Tensor:
     return ws
 
 
-def timeagg_scale_w_bwd(dws: Tensor, w: Tensor, gamma: Tensor, tt: Tensor) -> Tuple[Tensor, Tensor]:
+def timeagg_scale_w_bwd(dws: Tensor, w: Tensor, gamma: Tensor, tt: Tensor, out_dw: Optional[Tensor] = None,
+                        out_dgamma: Optional[Tensor] = None) -> Tuple[Tensor, Tensor]:
     T, E, _ = w.shape
-    dw = torch.empty_like(w)
-    dgamma = torch.empty(1, E, dtype=torch.float32, device=w.device)
+    dw = _out(out_dw, (T, E, E), w.device)
+    dgamma = _out(out_dgamma, (1, E), w.device)
     check(_lib.load().dpot_timeagg_scale_w_bwd(dws.data_ptr(), w.data_ptr(), gamma.data_ptr(), tt.data_ptr(),
                                                dw.data_ptr(), dgamma.data_ptr(), T, E, _stream()),
           "timeagg_scale_w_bwd")

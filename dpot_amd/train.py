@@ -46,18 +46,36 @@ class FlatParams:
         self.n_head = self.offsets[len(head)] if tail else off
         self.flat = torch.zeros(self.total, dtype=dt, device=dev)
         self.grad = torch.zeros(self.total, dtype=dt, device=dev)
+        self.grad_views: List[Tensor] = []
+        n_p = len(self.params)
+        self.filled: List[bool] = [False] * n_p      # slot already holds a gradient contribution this step
+        self.pending: List[int] = [0] * n_p          # forward uses whose backward has not delivered yet
+        self.callbacks: List[Callable[[int], None]] = []   # fired with the parameter index when its grad is final
         with torch.no_grad():
-            for p, o in zip(self.params, self.offsets):
+            for i, (p, o) in enumerate(zip(self.params, self.offsets)):
                 n = p.numel()
                 self.flat[o:o + n].copy_(p.detach().reshape(-1))
                 p.data = self.flat[o:o + n].view(p.shape)
-                p.grad = self.grad[o:o + n].view(p.shape)
+                self.grad_views.append(self.grad[o:o + n].view(p.shape))
+                p.grad = self.grad_views[i]
+                # The stage backwards (functional._Sink) write parameter gradients STRAIGHT into these slots (first
+                # contribution of a step: the kernel's output buffer is the slot; later ones - AR rollout, the model
+                # runs T_ar times - are added in place) and return None to autograd, so there is no per-parameter
+                # accumulate kernel.  p.grad stays bound to the slot, so foreign autograd graphs still accumulate
+                # into the flat buffer the ordinary way.
+                p._dpot_grad_slot = (self, i)
 
     def zero_grad(self) -> None:
         self.grad.zero_()
-        for p, o in zip(self.params, self.offsets):      # keep .grad pointing into the flat buffer
-            if p.grad is None or p.grad.data_ptr() != self.grad.data_ptr() + 4 * o:
-                p.grad = self.grad[o:o + p.numel()].view(p.shape)
+        for i, p in enumerate(self.params):
+            self.filled[i] = False
+            self.pending[i] = 0
+            if p.grad is None or p.grad.data_ptr() != self.grad_views[i].data_ptr():
+                p.grad = self.grad_views[i]
+
+    def fire(self, i: int) -> None:
+        for cb in self.callbacks:
+            cb(i)
 
 
 class FusedAdam:
