@@ -67,6 +67,10 @@ SIGNATURES = {
     "dpot_scale_shift": (c_i, [c_fp] * 4 + [c_i] * 3 + [c_fp]),
     "dpot_timeagg_scale_w": (c_i, [c_fp] * 4 + [c_i, c_i, c_fp]),
     "dpot_timeagg_scale_w_bwd": (c_i, [c_fp] * 6 + [c_i, c_i, c_fp]),
+    "dpot_out_tail_partial_rows": (c_i, [c_i] * 4),
+    "dpot_out_tail_partial_cols": (c_i, []),
+    "dpot_out_tail_fwd": (c_i, [c_fp] * 6 + [c_i] * 6 + [c_fp]),
+    "dpot_out_tail_bwd": (c_i, [c_fp] * 7 + [c_i] * 6 + [c_fp]),
     "dpot_rel_l2_chunks": (c_i, [c_i, c_i]),
     "dpot_rel_l2_fwd": (c_i, [c_fp] * 5 + [c_i] * 4 + [c_fp]),
     "dpot_rel_l2_bwd": (c_i, [c_fp] * 6 + [c_i] * 4 + [c_fp]),

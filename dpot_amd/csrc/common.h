@@ -27,9 +27,39 @@ static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 static inline int64_t cdiv64(int64_t a, int64_t b) { return (a + b - 1) / b; }
 
 // ---- activations (models/dpot.py:19) ---------------------------------------------------------------
+// Exact-erf GELU is the DPOT default and sits in every GEMM epilogue and in the fused tail; libm's erff costs ~150
+// VALU instructions per element (two divergent branches), which made GELU ~8% of the whole training step.
+// Phi(x) = 0.5 (1 + erf(x/sqrt2)) is evaluated branch-free from Abramowitz-Stegun 7.1.26,
+//   1 - erf(z) = t (a1 + t (a2 + t (a3 + t (a4 + t a5)))) exp(-z^2),  t = 1/(1 + p z),  |err| <= 1.5e-7,
+// on |x| with the reflection Phi(-x) = 1 - Phi(x) (no cancellation in the left tail); measured in fp32 against
+// float64 erf over [-12, 12]: |Phi err| <= 3.0e-7, |gelu err| <= 6.5e-7 (1.6e-7 relative), |gelu' err| <= 3.3e-7 -
+// two orders below the 1e-4 parity tolerance.  exp(-z^2) = exp(-x^2/2) is also the Gaussian of the derivative.
+__device__ __forceinline__ void gelu_parts(float x, float& cdf, float& gauss) {
+  const float z = fabsf(x) * 0.70710678118654752440f;
+  const float t = __frcp_rn(fmaf(0.3275911f, z, 1.0f));
+  float poly = fmaf(t, 1.061405429f, -1.453152027f);
+  poly = fmaf(t, poly, 1.421413741f);
+  poly = fmaf(t, poly, -0.284496736f);
+  poly = fmaf(t, poly, 0.254829592f);
+  poly *= t;
+  gauss = __expf(-z * z);
+  const float half = 0.5f * poly * gauss;
+  cdf = x >= 0.f ? 1.0f - half : half;
+}
+__device__ __forceinline__ float gelu_fwd(float x) {
+  float cdf, g;
+  gelu_parts(x, cdf, g);
+  return x * cdf;
+}
+__device__ __forceinline__ float gelu_bwd(float x) {
+  float cdf, g;
+  gelu_parts(x, cdf, g);
+  return fmaf(x * 0.39894228040143267794f, g, cdf);
+}
+
 __device__ __forceinline__ float act_fwd(int act, float x) {
   switch (act) {
-    case DPOT_ACT_GELU: return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f));
+    case DPOT_ACT_GELU: return gelu_fwd(x);
     case DPOT_ACT_TANH: return tanhf(x);
     case DPOT_ACT_SIGMOID: return 1.0f / (1.0f + expf(-x));
     case DPOT_ACT_RELU: return x > 0.f ? x : 0.f;
@@ -44,11 +74,7 @@ __device__ __forceinline__ float act_fwd(int act, float x) {
 // derivative of the activation as a function of the PRE-activation x
 __device__ __forceinline__ float act_bwd(int act, float x) {
   switch (act) {
-    case DPOT_ACT_GELU: {
-      const float cdf = 0.5f * (1.0f + erff(x * 0.70710678118654752440f));
-      const float pdf = 0.39894228040143267794f * expf(-0.5f * x * x);
-      return cdf + x * pdf;
-    }
+    case DPOT_ACT_GELU: return gelu_bwd(x);
     case DPOT_ACT_TANH: {
       const float t = tanhf(x);
       return 1.0f - t * t;

@@ -54,10 +54,9 @@ class _Sink:
             return t
         fp, i = self.fp, self.i
         view = fp.grad_views[i]
-        if t.data_ptr() == view.data_ptr():
-            fp.filled[i] = True
-        else:
-            view.add_(t.reshape(view.shape))          # a further use of the same parameter in this step
+        if t.data_ptr() != view.data_ptr():
+            view.add_(t.reshape(view.shape))          # produced elsewhere (or a further use in this step): accumulate
+        fp.filled[i] = True
         fp.pending[i] -= 1
         if fp.pending[i] == 0:
             fp.fire(i)
@@ -264,20 +263,32 @@ class HeadFn(torch.autograd.Function):
         # ConvTranspose2d(k=s=P) as GEMM with columns ordered (i, j, o): the result IS the pixel-major [Mp, old] matrix
         wt = ops.transpose2d(o0w, E, old, PP).view(E, PP * old)
         bexp = o0b.repeat(PP)
-        U = torch.empty(M, PP * old, dtype=torch.float32, device=dev)
-        Upre = torch.empty_like(U)
-        ops.gemm(x, wt, U, M, PP * old, E, lda=E, ldb=PP * old, ldc=PP * old, bias=bexp, act=act, mode=EPI_ACT,
-                 preact=Upre, ldpre=PP * old)
-        V, Vpre = ops.linear_fwd(U.view(Mp, old), o2w, o2b, act=act, save_pre=True)
-        Z, _ = ops.linear_fwd(V, o4w, o4b)                                     # [Mp, co]
-        pred = ops.pixel_shuffle(Z, B, h, w, P, co)                            # [B, X, Y, co]
+        fused = ops.out_tail_supported(old, co, Mp)
+        if fused:
+            # GEMM writes only the pre-activation; the whole per-pixel tail (act, 1x1, act, 1x1, pixel shuffle) is one
+            # kernel that reads it once (csrc/tail.hip)
+            U = V = Vpre = None
+            Upre = torch.empty(M, PP * old, dtype=torch.float32, device=dev)
+            ops.gemm(x, wt, Upre, M, PP * old, E, lda=E, ldb=PP * old, ldc=PP * old, bias=bexp)
+            w4p, b4p = ops.out_tail_pad(o4w, o4b, co)
+            pred = ops.out_tail_fwd(Upre, o2w, o2b, w4p, b4p, B, h, w, P, co, act)  # [B, X, Y, co]
+            V = w4p                                                            # (saved slot reused: padded W4)
+        else:
+            U = torch.empty(M, PP * old, dtype=torch.float32, device=dev)
+            Upre = torch.empty_like(U)
+            ops.gemm(x, wt, U, M, PP * old, E, lda=E, ldb=PP * old, ldc=PP * old, bias=bexp, act=act, mode=EPI_ACT,
+                     preact=Upre, ldpre=PP * old)
+            V, Vpre = ops.linear_fwd(U.view(Mp, old), o2w, o2b, act=act, save_pre=True)
+            Z, _ = ops.linear_fwd(V, o4w, o4b)                                 # [Mp, co]
+            pred = ops.pixel_shuffle(Z, B, h, w, P, co)                        # [B, X, Y, co]
         # classification head
         cm = ops.token_mean(x)
         c1, c1pre = ops.linear_fwd(cm, c0w, c0b, act=act, save_pre=True)
         c2, c2pre = ops.linear_fwd(c1, c2w, c2b, act=act, save_pre=True)
         cls, _ = ops.linear_fwd(c2, c4w, c4b)
-        ctx.save_for_backward(x, wt, U, Upre, V, Vpre, o2w, o4w, cm, c1, c1pre, c2, c2pre, c0w, c2w, c4w)
+        ctx.save_for_backward(x, wt, U, Upre, V, Vpre, o2w, o2b, o4w, cm, c1, c1pre, c2, c2pre, c0w, c2w, c4w)
         ctx.dims = (B, tok, E, h, w, P, old, co, act)
+        ctx.fused = fused
         # the cls_head sinks are registered lazily in backward: whether that branch runs is only known there
         ctx.sinks = _sinks(ctx, (o0w, o0b, o2w, o2b, o4w, o4b), 1)
         ctx.cls_params = (c0w, c0b, c2w, c2b, c4w, c4b)
@@ -286,7 +297,7 @@ class HeadFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dpred, dcls):
-        x, wt, U, Upre, V, Vpre, o2w, o4w, cm, c1, c1pre, c2, c2pre, c0w, c2w, c4w = ctx.saved_tensors
+        x, wt, U, Upre, V, Vpre, o2w, o2b, o4w, cm, c1, c1pre, c2, c2pre, c0w, c2w, c4w = ctx.saved_tensors
         B, tok, E, h, w, P, old, co, act = ctx.dims
         s_o0w, s_o0b, s_o2w, s_o2b, s_o4w, s_o4b = ctx.sinks
         PP = P * P
@@ -297,14 +308,22 @@ class HeadFn(torch.autograd.Function):
         dc0w = dc0b = dc2w = dc2b = dc4w = dc4b = None
         if dpred is not None:
             # ---- out layer
-            dZ = ops.pixel_shuffle(dpred.contiguous(), B, h, w, P, co, inverse=True)      # [Mp, co]
-            dVpre = ops.linear_bwd_data(dZ, o4w2, act=act, aux=Vpre)                      # [Mp, old]
-            do4w = s_o4w.done(ops.linear_bwd_weight(dZ, V, out=s_o4w.out()).view(co, old, 1, 1))
-            do4b = s_o4b.done(ops.colsum(dZ, Mp, co, out=s_o4b.out()))
-            dUpre = ops.linear_bwd_data(dVpre, o2w2, act=act, aux=Upre.view(Mp, old))     # [Mp, old]
-            do2w = s_o2w.done(ops.linear_bwd_weight(dVpre, U.view(Mp, old), out=s_o2w.out()).view(old, old, 1, 1))
-            do2b = s_o2b.done(ops.colsum(dVpre, Mp, old, out=s_o2b.out()))
-            do0b = s_o0b.done(ops.colsum(dUpre, Mp, old, out=s_o0b.out()))
+            if ctx.fused:
+                dUpre, pv = ops.out_tail_bwd(Upre, dpred.contiguous(), o2w, o2b, V, B, h, w, P, co, act)
+                do2w = s_o2w.done(pv[0:1024].view(old, old, 1, 1))
+                do4w = s_o4w.done(pv[1024:1024 + co * old].view(co, old, 1, 1))
+                do2b = s_o2b.done(pv[2048:2048 + old])
+                do0b = s_o0b.done(pv[2080:2080 + old])
+                do4b = s_o4b.done(pv[2112:2112 + co])
+            else:
+                dZ = ops.pixel_shuffle(dpred.contiguous(), B, h, w, P, co, inverse=True)  # [Mp, co]
+                dVpre = ops.linear_bwd_data(dZ, o4w2, act=act, aux=Vpre)                  # [Mp, old]
+                do4w = s_o4w.done(ops.linear_bwd_weight(dZ, V, out=s_o4w.out()).view(co, old, 1, 1))
+                do4b = s_o4b.done(ops.colsum(dZ, Mp, co, out=s_o4b.out()))
+                dUpre = ops.linear_bwd_data(dVpre, o2w2, act=act, aux=Upre.view(Mp, old))  # [Mp, old]
+                do2w = s_o2w.done(ops.linear_bwd_weight(dVpre, U.view(Mp, old), out=s_o2w.out()).view(old, old, 1, 1))
+                do2b = s_o2b.done(ops.colsum(dVpre, Mp, old, out=s_o2b.out()))
+                do0b = s_o0b.done(ops.colsum(dUpre, Mp, old, out=s_o0b.out()))
             dU2 = dUpre.view(M, PP * old)
             dx_out = torch.empty(M, E, dtype=torch.float32, device=dev)
             ops.gemm(dU2, wt, dx_out, M, E, PP * old, transB=True, lda=PP * old, ldb=PP * old, ldc=E)

@@ -299,6 +299,35 @@ def timeagg_scale_w_bwd(dws: Tensor, w: Tensor, gamma: Tensor, tt: Tensor, out_d
     return dw, dgamma
 
 
+def out_tail_supported(old: int, co: int, n_pixels: int) -> bool:
+    return old == 32 and 0 < co <= 32 and n_pixels % 32 == 0
+
+
+def out_tail_pad(w4: Tensor, b4: Tensor, co: int) -> Tuple[Tensor, Tensor]:
+    """W4 [co,32] -> [32,32], b4 [co] -> [32], zero padded (the tail kernels load them unconditionally)"""
+    return copy2d_pad(w4, co, 32, 32, 32), copy2d_pad(b4, 1, co, 1, 32).view(32)
+
+
+def out_tail_fwd(upre: Tensor, w2: Tensor, b2: Tensor, w4p: Tensor, b4p: Tensor, B: int, h: int, w: int, P: int,
+                 co: int, act: int) -> Tensor:
+    out = torch.empty(B, h * P, w * P, co, dtype=torch.float32, device=upre.device)
+    check(_lib.load().dpot_out_tail_fwd(upre.data_ptr(), w2.data_ptr(), b2.data_ptr(), w4p.data_ptr(),
+                                        b4p.data_ptr(), out.data_ptr(), B, h, w, P, co, act, _stream()), "out_tail_fwd")
+    return out
+
+
+def out_tail_bwd(upre: Tensor, dout: Tensor, w2: Tensor, b2: Tensor, w4p: Tensor, B: int, h: int, w: int, P: int,
+                 co: int, act: int) -> Tuple[Tensor, Tensor]:
+    """returns (dupre [pixels,32], reduced partial vector [2144] = dW2 | dW4 | db2 | colsum(dupre) | db4)"""
+    lib = _lib.load()
+    rows, cols = lib.dpot_out_tail_partial_rows(B, h, w, P), lib.dpot_out_tail_partial_cols()
+    dupre = torch.empty_like(upre)
+    part = torch.empty(rows, cols, dtype=torch.float32, device=upre.device)
+    check(lib.dpot_out_tail_bwd(upre.data_ptr(), dout.data_ptr(), w2.data_ptr(), b2.data_ptr(), w4p.data_ptr(),
+                                dupre.data_ptr(), part.data_ptr(), B, h, w, P, co, act, _stream()), "out_tail_bwd")
+    return dupre, colsum(part, rows, cols)
+
+
 # ------------------------------------------------------------------------------------------------------
 # loss / optimiser
 # ------------------------------------------------------------------------------------------------------

@@ -205,6 +205,23 @@ int dpot_timeagg_scale_w_bwd(const float* dws, const float* w, const float* gamm
                              float* dgamma, int T, int E, dpot_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * fused per-pixel tail of the out layer (models/dpot.py:316-321 after the ConvTranspose), out_layer_dim == 32:
+ *   out[b, px*P+i, py*P+j, :] = W4 act(W2 act(upre[p, :]) + b2) + b4,   p = ((b*h+px)*w+py)*P*P + i*P + j
+ *   upre: [B*h*w*P*P, 32] pixel-major ConvTranspose output (bias included, pre-activation); co <= 32;
+ *   w4 / b4 must be ZERO-PADDED to [32,32] / [32] by the caller (dpot_copy2d_pad): weight loads are unconditional
+ * bwd: dupre = d loss / d upre; partials[rows, cols] (rows = dpot_out_tail_partial_rows, cols =
+ *   dpot_out_tail_partial_cols = 2144) holds one row per wave: dW2[32*32] | dW4[32*32, rows >= co zero] | db2[32] |
+ *   colsum(dupre)[32] | db4[32]; the caller reduces it over rows with dpot_colsum.
+ * ------------------------------------------------------------------------------------------------ */
+int dpot_out_tail_partial_rows(int B, int h, int w, int P);
+int dpot_out_tail_partial_cols(void);
+int dpot_out_tail_fwd(const float* upre, const float* w2, const float* b2, const float* w4, const float* b4,
+                      float* out, int B, int h, int w, int P, int co, int act, dpot_stream_t stream);
+int dpot_out_tail_bwd(const float* upre, const float* dout, const float* w2, const float* b2, const float* w4,
+                      float* dupre, float* partials, int B, int h, int w, int P, int co, int act,
+                      dpot_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
  * loss / optimiser
  * ------------------------------------------------------------------------------------------------ */
 /* masked relative L2 summed over the batch (SimpleLpLoss(size_average=False), utils/criterion.py:38-59).

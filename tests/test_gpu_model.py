@@ -263,6 +263,34 @@ def test_train_step_vs_oracle_two_steps_and_graph():
         assert (v - eager_params[k]).abs().max().item() <= 1e-6, k
 
 
+@pytest.mark.parametrize("out_channels,act", [(4, "gelu"), (3, "gelu"), (4, "silu"), (9, "tanh")])
+def test_head_fused_tail_vs_oracle(out_channels, act):
+    """out_layer_dim == 32 takes the fused per-pixel tail kernels (csrc/tail.hip): forward + every gradient vs oracle"""
+    from dpot_amd.functional import HeadFn
+    kw = dict(R.MINI, depth=1, out_layer_dim=32, out_channels=out_channels, act=act)
+    m, cfg = build(kw, salt=29)
+    B, h = 3, cfg.latent
+    lat = R.recipe_input((B, h, h, cfg.embed_dim), salt=33)
+    sd = OrderedDict((k, v.clone().requires_grad_(True)) for k, v in R.recipe_state_dict(cfg, salt=29).items())
+    lo = lat.clone().requires_grad_(True)
+    o_ref, c_ref = R.out_layer(sd, lo, cfg), R.cls_head(sd, lo, cfg)
+    up_o = R.recipe_input(tuple(o_ref.shape), salt=34) * 0.3
+    up_c = R.recipe_input(tuple(c_ref.shape), salt=35) * 0.3
+    ((o_ref * up_o).sum() + (c_ref * up_c).sum()).backward()
+    latin = lat.cuda().view(B, h * h, -1).requires_grad_(True)
+    ol, ch = m.out_layer, m.cls_head
+    pred, cls = HeadFn.apply(latin, ol[0].weight, ol[0].bias, ol[2].weight, ol[2].bias, ol[4].weight, ol[4].bias,
+                             ch[0].weight, ch[0].bias, ch[2].weight, ch[2].bias, ch[4].weight, ch[4].bias, h, h,
+                             m.patch_size, m._act)
+    pred = pred.view(B, cfg.img_size, cfg.img_size, cfg.out_timesteps, cfg.out_channels)
+    ((pred * up_o.cuda()).sum() + (cls * up_c.cuda()).sum()).backward()
+    assert_close(pred, o_ref, "fused tail fwd")
+    assert_close(latin.grad.view(B, h, h, -1), lo.grad, "fused tail dlat")
+    for k, p in m.named_parameters():
+        if k.startswith("out_layer.") or k.startswith("cls_head."):
+            assert_close(p.grad, sd[k].grad, "fused tail d" + k)
+
+
 # ------------------------------------------------------------------------------------------------------
 # full-size properties (DPOT-Tiny, B=32: the BASELINE configs[1] workload)
 # ------------------------------------------------------------------------------------------------------
