@@ -141,11 +141,19 @@ def main():
     if args.gpus != world:
         if world == 1 and args.gpus > 1:
             raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run with --nproc-per-node {args.gpus}")
+    # DPOT_BENCH_DEBUG_GLOO=1: functional dry-run of the N>1 code path on a 1-GPU box (all ranks share cuda:0, gloo
+    # collectives) - for testing only, never a performance number
+    debug_gloo = os.environ.get("DPOT_BENCH_DEBUG_GLOO") == "1"
+    if debug_gloo:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if debug_gloo:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     from dpot_amd import DPOTNet, _lib
     from dpot_amd.dp import BucketedGradReducer
