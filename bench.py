@@ -83,11 +83,23 @@ def mixer_roofline(model, B: int):
     # algorithmic bytes of one layer launch: spectrum in + spectrum out + the block weights once
     bytes_alg = 2.0 * Mm * 2 * E * 4 + nb * (2 * bs) * (2 * bs) * 4
     achieved = flops / t / 1e12
+    # HBM traffic per launch from the L2 memory-side counters: collected in separate rocprofv3 --pmc passes
+    # (scripts/gpu_pmc.sh -> profiles/r01_pmc_mixer.json; bench.py itself cannot run the profiler).  Units and the
+    # gfx950 correction follow MI355X_MICROARCH.md section HBM: bytes = (2 * FETCH_SIZE + WRITE_SIZE) * 1024
+    traffic = None
+    try:
+        pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_mixer.json")))
+        traffic = (2.0 * pmc["FETCH_SIZE"]["mean"] + pmc["WRITE_SIZE"]["max"]) * 1024.0
+    except Exception:
+        pass
     return {
         "kernel": "dpot::gemm_f32_kernel<64,64,NN,vec,TAG=1> (AFNO mixer: one layer of the block-diagonal complex MLP "
                   "as a real MFMA GEMM, bias+GELU fused)",
         "bound": "mfma", "achieved": round(achieved, 2), "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-        "frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": None,
+        "frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": traffic,
+        "traffic_note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), (2*FETCH+WRITE)*1024 B; the launch "
+                        "stores BOTH the pre-activation (saved for backward) and the activated spectrum, hence "
+                        "traffic > algorithmic_bytes (which counts one output)",
         "us_per_launch": round(t * 1e6, 2), "flops_per_launch": flops, "algorithmic_bytes_per_launch": bytes_alg,
         "hbm_frac": round(bytes_alg / t / 1e9 / HBM_PEAK_GBS, 4),
         "note": "FLOP-bound (128 FLOP/B >> 20 FLOP/B ridge): hbm_frac is reported because north_star asks for it",

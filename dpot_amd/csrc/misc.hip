@@ -13,48 +13,56 @@ namespace dpot {
 __global__ __launch_bounds__(256) void patchify_kernel(const float* __restrict__ x, const float* __restrict__ gx,
                                                        const float* __restrict__ gy, const float* __restrict__ gt,
                                                        float* __restrict__ A, int X, int Y, int T, int C, int P) {
-  extern __shared__ float sm[];  // [P][P*T*C]
+  extern __shared__ float sm[];  // [P][P*T*C + 1]: row i of the site, contiguous as in memory (+1: rows on distinct banks)
   const int w = Y / P, h = X / P;
   const int site = blockIdx.x;
   const int py = site % w, px = (site / w) % h, b = site / (w * h);
-  const int run = P * T * C;
-  for (int idx = threadIdx.x; idx < P * run; idx += 256) {
-    const int i = idx / run, r = idx % run;
-    sm[idx] = x[(((long long)b * X + px * P + i) * Y + py * P) * T * C + r];
+  const int TC = T * C, run = P * TC, rp = run + 1;
+  for (int i = 0; i < P; ++i) {
+    const float* src = x + (((long long)b * X + px * P + i) * Y + py * P) * TC;
+    for (int r = threadIdx.x; r < run; r += 256) sm[i * rp + r] = src[r];
   }
   __syncthreads();
   const int PP = P * P, K0 = (C + 3) * PP;
   float* out = A + (long long)site * T * K0;
-  for (int idx = threadIdx.x; idx < T * K0; idx += 256) {
-    const int t = idx / K0, k = idx % K0;
-    const int c = k / PP, i = (k % PP) / P, j = k % P;
-    float v;
-    if (c < C) v = sm[i * run + (j * T + t) * C + c];
-    else if (c == C) v = gx[px * P + i];
-    else if (c == C + 1) v = gy[py * P + j];
-    else v = gt[t];
-    out[idx] = v;
+  // one (c,i,j) decomposition per column k, reused for the T rows (integer division is ~30 VALU instructions)
+  for (int k = threadIdx.x; k < K0; k += 256) {
+    const int c = k / PP, rem = k - c * PP;
+    const int i = rem / P, j = rem - i * P;
+    if (c < C) {
+      const float* s0 = sm + i * rp + j * TC + c;
+      for (int t = 0; t < T; ++t) out[(long long)t * K0 + k] = s0[t * C];
+    } else if (c == C) {
+      const float v = gx[px * P + i];
+      for (int t = 0; t < T; ++t) out[(long long)t * K0 + k] = v;
+    } else if (c == C + 1) {
+      const float v = gy[py * P + j];
+      for (int t = 0; t < T; ++t) out[(long long)t * K0 + k] = v;
+    } else {
+      for (int t = 0; t < T; ++t) out[(long long)t * K0 + k] = gt[t];
+    }
   }
 }
 
 __global__ __launch_bounds__(256) void unpatchify_kernel(const float* __restrict__ dA, float* __restrict__ dx, int X,
                                                          int Y, int T, int C, int P) {
-  extern __shared__ float sm[];  // [P][P*T*C]
+  extern __shared__ float sm[];  // [P][P*T*C + 1]
   const int w = Y / P, h = X / P;
   const int site = blockIdx.x;
   const int py = site % w, px = (site / w) % h, b = site / (w * h);
-  const int run = P * T * C;
+  const int TC = T * C, run = P * TC, rp = run + 1;
   const int PP = P * P, K0 = (C + 3) * PP, KC = C * PP;
   const float* in = dA + (long long)site * T * K0;
-  for (int idx = threadIdx.x; idx < T * KC; idx += 256) {
-    const int t = idx / KC, k = idx % KC;
-    const int c = k / PP, i = (k % PP) / P, j = k % P;
-    sm[i * run + (j * T + t) * C + c] = in[(long long)t * K0 + k];
+  for (int k = threadIdx.x; k < KC; k += 256) {
+    const int c = k / PP, rem = k - c * PP;
+    const int i = rem / P, j = rem - i * P;
+    float* d0 = sm + i * rp + j * TC + c;
+    for (int t = 0; t < T; ++t) d0[t * C] = in[(long long)t * K0 + k];
   }
   __syncthreads();
-  for (int idx = threadIdx.x; idx < P * run; idx += 256) {
-    const int i = idx / run, r = idx % run;
-    dx[(((long long)b * X + px * P + i) * Y + py * P) * T * C + r] = sm[idx];
+  for (int i = 0; i < P; ++i) {
+    float* dst = dx + (((long long)b * X + px * P + i) * Y + py * P) * TC;
+    for (int r = threadIdx.x; r < run; r += 256) dst[r] = sm[i * rp + r];
   }
 }
 
@@ -266,7 +274,7 @@ extern "C" int dpot_patchify(const float* x, const float* gx, const float* gy, c
                              int X, int Y, int T, int C, int P, dpot_stream_t stream) {
   DPOT_REQUIRE(x && gx && gy && gt && A, "patchify: null pointer");
   DPOT_REQUIRE(B > 0 && P > 0 && X % P == 0 && Y % P == 0 && T > 0 && C > 0, "patchify: bad shape");
-  const size_t lds = sizeof(float) * (size_t)P * P * T * C;
+  const size_t lds = sizeof(float) * (size_t)P * ((size_t)P * T * C + 1);
   DPOT_REQUIRE(lds <= 64 * 1024, "patchify: patch slab of %zu bytes exceeds 64 KiB", lds);
   const long long sites = (long long)B * (X / P) * (Y / P);
   DPOT_REQUIRE(sites < (1ll << 31), "patchify: too many sites");
@@ -279,7 +287,7 @@ extern "C" int dpot_unpatchify(const float* dA, float* dx, int B, int X, int Y, 
                                dpot_stream_t stream) {
   DPOT_REQUIRE(dA && dx, "unpatchify: null pointer");
   DPOT_REQUIRE(B > 0 && P > 0 && X % P == 0 && Y % P == 0 && T > 0 && C > 0, "unpatchify: bad shape");
-  const size_t lds = sizeof(float) * (size_t)P * P * T * C;
+  const size_t lds = sizeof(float) * (size_t)P * ((size_t)P * T * C + 1);
   DPOT_REQUIRE(lds <= 64 * 1024, "unpatchify: patch slab of %zu bytes exceeds 64 KiB", lds);
   const long long sites = (long long)B * (X / P) * (Y / P);
   hipLaunchKernelGGL(unpatchify_kernel, dim3((unsigned)sites), dim3(256), lds, as_stream(stream), dA, dx, X, Y, T, C,

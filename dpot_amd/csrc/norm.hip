@@ -195,17 +195,167 @@ __global__ __launch_bounds__(GN_THREADS) void groupnorm_bwd_kernel(const float* 
   }
 }
 
-__global__ void groupnorm_param_grad_kernel(const float* __restrict__ part, float* __restrict__ dgamma,
-                                            float* __restrict__ dbeta, int B, int E) {
-  const int c = blockIdx.x * 256 + threadIdx.x;
-  if (c >= E) return;
-  float sg = 0.f, sb = 0.f;
-  for (int b = 0; b < B; ++b) {
-    sg += part[((long long)0 * B + b) * E + c];
-    sb += part[((long long)1 * B + b) * E + c];
+// dgamma/dbeta = sum over samples of the per-sample partials; block = 64 channels x 4 sample lanes, fixed order
+__global__ __launch_bounds__(256) void groupnorm_param_grad_kernel(const float* __restrict__ part,
+                                                                   float* __restrict__ dgamma,
+                                                                   float* __restrict__ dbeta, int B, int E) {
+  __shared__ float red[2][4][64];
+  const int tc = threadIdx.x & 63, tr = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + tc;
+  float sg0 = 0.f, sg1 = 0.f, sb0 = 0.f, sb1 = 0.f;
+  if (c < E) {
+    int b = tr;
+    for (; b + 4 < B; b += 8) {
+      sg0 += part[((long long)0 * B + b) * E + c];
+      sg1 += part[((long long)0 * B + b + 4) * E + c];
+      sb0 += part[((long long)1 * B + b) * E + c];
+      sb1 += part[((long long)1 * B + b + 4) * E + c];
+    }
+    for (; b < B; b += 4) {
+      sg0 += part[((long long)0 * B + b) * E + c];
+      sb0 += part[((long long)1 * B + b) * E + c];
+    }
   }
-  dgamma[c] = sg;
-  dbeta[c] = sb;
+  red[0][tr][tc] = sg0 + sg1;
+  red[1][tr][tc] = sb0 + sb1;
+  __syncthreads();
+  if (tr == 0 && c < E) {
+    dgamma[c] = (red[0][0][tc] + red[0][1][tc]) + (red[0][2][tc] + red[0][3][tc]);
+    dbeta[c] = (red[1][0][tc] + red[1][1][tc]) + (red[1][2][tc] + red[1][3][tc]);
+  }
+}
+
+// ---- register-resident variants: the (b, group) slab is read from HBM exactly once --------------------
+// usable when the channel quads of a group map 1:1 onto the TJ lanes (cg/4 a power of two <= 64) and the
+// T/TT tokens a thread owns fit in ITEMS registers-quads (DPOT-Ti/S/M at 128^2: ITEMS = 4 / 8)
+template <int ITEMS>
+__global__ __launch_bounds__(GN_THREADS) void groupnorm_fwd_cached_kernel(const float* __restrict__ x,
+                                                                          const float* __restrict__ gamma,
+                                                                          const float* __restrict__ beta,
+                                                                          float* __restrict__ y, float* __restrict__ mean,
+                                                                          float* __restrict__ rstd, int T, int E, int G,
+                                                                          float eps) {
+  __shared__ double shd[16];
+  const int g = blockIdx.x, b = blockIdx.y;
+  const int cg = E / G, TJ = cg / 4, TT = GN_THREADS / TJ;
+  const int tj = threadIdx.x % TJ, tt = threadIdx.x / TJ;
+  const float* xs = x + (long long)b * T * E + g * cg + tj * 4;
+  float* ys = y + (long long)b * T * E + g * cg + tj * 4;
+  const double n = (double)T * cg;
+  float4 v[ITEMS];
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < ITEMS; ++i) {
+    const int t = tt + i * TT;
+    v[i] = *reinterpret_cast<const float4*>(xs + (long long)(t < T ? t : T - 1) * E);   // clamped, masked below
+    if (t < T) s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
+  }
+  const float mu = (float)(block_sum_d((double)s, shd) / n);
+  float q = 0.f;
+#pragma unroll
+  for (int i = 0; i < ITEMS; ++i) {
+    if (tt + i * TT < T) {
+      const float d0 = v[i].x - mu, d1 = v[i].y - mu, d2 = v[i].z - mu, d3 = v[i].w - mu;
+      q = fmaf(d0, d0, q); q = fmaf(d1, d1, q); q = fmaf(d2, d2, q); q = fmaf(d3, d3, q);
+    }
+  }
+  const float var = (float)(block_sum_d((double)q, shd) / n);
+  const float rs = 1.0f / sqrtf(var + eps);
+  if (threadIdx.x == 0) {
+    mean[b * G + g] = mu;
+    rstd[b * G + g] = rs;
+  }
+  float4 ga = *reinterpret_cast<const float4*>(gamma + g * cg + tj * 4);
+  const float4 be = *reinterpret_cast<const float4*>(beta + g * cg + tj * 4);
+  ga.x *= rs; ga.y *= rs; ga.z *= rs; ga.w *= rs;
+#pragma unroll
+  for (int i = 0; i < ITEMS; ++i) {
+    const int t = tt + i * TT;
+    if (t < T)
+      *reinterpret_cast<float4*>(ys + (long long)t * E) =
+          make_float4(fmaf(v[i].x - mu, ga.x, be.x), fmaf(v[i].y - mu, ga.y, be.y), fmaf(v[i].z - mu, ga.z, be.z),
+                      fmaf(v[i].w - mu, ga.w, be.w));
+  }
+}
+
+template <int ITEMS>
+__global__ __launch_bounds__(GN_THREADS) void groupnorm_bwd_cached_kernel(
+    const float* __restrict__ dy, const float* __restrict__ x, const float* __restrict__ mean,
+    const float* __restrict__ rstd, const float* __restrict__ gamma, const float* __restrict__ add,
+    float* __restrict__ dx, float* __restrict__ part, int B, int T, int E, int G) {
+  __shared__ float red[2][GN_THREADS][4];
+  __shared__ double shd[16];
+  const int g = blockIdx.x, b = blockIdx.y;
+  const int cg = E / G, TJ = cg / 4, TT = GN_THREADS / TJ;
+  const int tj = threadIdx.x % TJ, tt = threadIdx.x / TJ;
+  const long long off = (long long)b * T * E + g * cg + tj * 4;
+  const float mu = mean[b * G + g], rs = rstd[b * G + g];
+  const double n = (double)T * cg;
+  float4 d[ITEMS], xh[ITEMS];
+  float a_dy[4] = {0.f, 0.f, 0.f, 0.f}, a_dyx[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int i = 0; i < ITEMS; ++i) {
+    const int t = tt + i * TT;
+    const long long o = off + (long long)(t < T ? t : T - 1) * E;
+    d[i] = *reinterpret_cast<const float4*>(dy + o);
+    const float4 xv = *reinterpret_cast<const float4*>(x + o);
+    xh[i] = make_float4((xv.x - mu) * rs, (xv.y - mu) * rs, (xv.z - mu) * rs, (xv.w - mu) * rs);
+    if (t < T) {
+      a_dy[0] += d[i].x; a_dy[1] += d[i].y; a_dy[2] += d[i].z; a_dy[3] += d[i].w;
+      a_dyx[0] = fmaf(d[i].x, xh[i].x, a_dyx[0]); a_dyx[1] = fmaf(d[i].y, xh[i].y, a_dyx[1]);
+      a_dyx[2] = fmaf(d[i].z, xh[i].z, a_dyx[2]); a_dyx[3] = fmaf(d[i].w, xh[i].w, a_dyx[3]);
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    red[0][threadIdx.x][k] = a_dyx[k];
+    red[1][threadIdx.x][k] = a_dy[k];
+  }
+  __syncthreads();
+  double s1 = 0.0, s2 = 0.0;
+  if (tt < 4) {   // thread (tj, k = tt) reduces channel 4*tj + k over the token lanes, fixed order
+    const int k = tt;
+    float sg = 0.f, sb = 0.f;
+    for (int r = 0; r < TT; ++r) {
+      sg += red[0][r * TJ + tj][k];
+      sb += red[1][r * TJ + tj][k];
+    }
+    const int c = g * cg + tj * 4 + k;
+    part[((long long)0 * B + b) * E + c] = sg;
+    part[((long long)1 * B + b) * E + c] = sb;
+    const float ga = gamma[c];
+    s1 = (double)ga * sb;
+    s2 = (double)ga * sg;
+  }
+  const float m1 = (float)(block_sum_d(s1, shd) / n);
+  const float m2 = (float)(block_sum_d(s2, shd) / n);
+  const float4 ga = *reinterpret_cast<const float4*>(gamma + g * cg + tj * 4);
+#pragma unroll
+  for (int i = 0; i < ITEMS; ++i) {
+    const int t = tt + i * TT;
+    if (t < T) {
+      const long long o = off + (long long)t * E;
+      float4 r = make_float4(rs * (ga.x * d[i].x - m1 - xh[i].x * m2), rs * (ga.y * d[i].y - m1 - xh[i].y * m2),
+                             rs * (ga.z * d[i].z - m1 - xh[i].z * m2), rs * (ga.w * d[i].w - m1 - xh[i].w * m2));
+      if (add) {
+        const float4 a = *reinterpret_cast<const float4*>(add + o);
+        r.x += a.x; r.y += a.y; r.z += a.z; r.w += a.w;
+      }
+      *reinterpret_cast<float4*>(dx + o) = r;
+    }
+  }
+}
+
+// ITEMS (4 or 8) if the cached kernels apply, else 0
+static int gn_cached_items(int T, int E, int G) {
+  const int cg = E / G;
+  if (cg % 4) return 0;
+  const int tj = cg / 4;
+  if (tj < 1 || tj > 64 || (tj & (tj - 1))) return 0;
+  const int tt = GN_THREADS / tj;
+  if (T <= 4 * tt) return 4;
+  if (T <= 8 * tt) return 8;
+  return 0;
 }
 
 }  // namespace dpot
@@ -217,7 +367,14 @@ extern "C" int dpot_groupnorm_fwd(const float* x, const float* gamma, const floa
   DPOT_REQUIRE(x && gamma && beta && y && mean && rstd, "groupnorm_fwd: null pointer");
   DPOT_REQUIRE(B > 0 && T > 0 && E > 0 && G > 0 && E % G == 0 && B <= 65535, "groupnorm_fwd: bad shape");
   const bool vec = ((E / G) % 4 == 0) && aligned16(x) && aligned16(y) && aligned16(gamma) && aligned16(beta);
-  if (vec)
+  const int items = vec ? gn_cached_items(T, E, G) : 0;
+  if (items == 4)
+    hipLaunchKernelGGL(groupnorm_fwd_cached_kernel<4>, dim3(G, B), dim3(GN_THREADS), 0, as_stream(stream), x, gamma, beta,
+                       y, mean, rstd, T, E, G, eps);
+  else if (items == 8)
+    hipLaunchKernelGGL(groupnorm_fwd_cached_kernel<8>, dim3(G, B), dim3(GN_THREADS), 0, as_stream(stream), x, gamma, beta,
+                       y, mean, rstd, T, E, G, eps);
+  else if (vec)
     hipLaunchKernelGGL(groupnorm_fwd_kernel<4>, dim3(G, B), dim3(GN_THREADS), 0, as_stream(stream), x, gamma, beta, y,
                        mean, rstd, T, E, G, eps);
   else
@@ -233,7 +390,14 @@ extern "C" int dpot_groupnorm_bwd(const float* dy, const float* x, const float* 
   DPOT_REQUIRE(B > 0 && T > 0 && E > 0 && G > 0 && E % G == 0 && B <= 65535, "groupnorm_bwd: bad shape");
   const bool vec = ((E / G) % 4 == 0) && aligned16(x) && aligned16(dy) && aligned16(dx) && aligned16(gamma) &&
                    (add == nullptr || aligned16(add));
-  if (vec)
+  const int items = vec ? gn_cached_items(T, E, G) : 0;
+  if (items == 4)
+    hipLaunchKernelGGL(groupnorm_bwd_cached_kernel<4>, dim3(G, B), dim3(GN_THREADS), 0, as_stream(stream), dy, x, mean,
+                       rstd, gamma, add, dx, part, B, T, E, G);
+  else if (items == 8)
+    hipLaunchKernelGGL(groupnorm_bwd_cached_kernel<8>, dim3(G, B), dim3(GN_THREADS), 0, as_stream(stream), dy, x, mean,
+                       rstd, gamma, add, dx, part, B, T, E, G);
+  else if (vec)
     hipLaunchKernelGGL(groupnorm_bwd_kernel<4>, dim3(G, B), dim3(GN_THREADS), 0, as_stream(stream), dy, x, mean, rstd,
                        gamma, add, dx, part, B, T, E, G);
   else
@@ -241,7 +405,7 @@ extern "C" int dpot_groupnorm_bwd(const float* dy, const float* x, const float* 
                        gamma, add, dx, part, B, T, E, G);
   int rc = check_launch("groupnorm_bwd_kernel");
   if (rc) return rc;
-  hipLaunchKernelGGL(groupnorm_param_grad_kernel, dim3(cdiv(E, 256)), dim3(256), 0, as_stream(stream),
+  hipLaunchKernelGGL(groupnorm_param_grad_kernel, dim3(cdiv(E, 64)), dim3(256), 0, as_stream(stream),
                      (const float*)part, dgamma, dbeta, B, E);
   return check_launch("groupnorm_param_grad_kernel");
 }
