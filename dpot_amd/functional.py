@@ -18,7 +18,7 @@ from typing import Optional
 
 import torch
 
-from . import ops
+from . import ops, streams
 from .ops import EPI_ACT, EPI_DACT
 
 Tensor = torch.Tensor
@@ -210,40 +210,48 @@ class BlockFn(torch.autograd.Function):
         dev = dout.device
         dout = dout.contiguous()
         do2 = dout.view(M, E)
+        # Critical path on the current stream: dgrad GEMMs, GroupNorm, DFTs.  Everything that only produces parameter
+        # gradients (wgrad GEMMs + split-K reductions, bias column sums, un-packing) runs on the side stream.
         # channel MLP
+        with streams.side(dev):
+            df2w = s_f2w.done(ops.linear_bwd_weight(do2, Hh, out=s_f2w.out()).view(E, mh, 1, 1))
+            df2b = s_f2b.done(ops.colsum(do2, M, E, out=s_f2b.out()))
         dHpre = ops.linear_bwd_data(do2, f2w, act=act, aux=Hpre)               # [M, mh]
-        df2w = s_f2w.done(ops.linear_bwd_weight(do2, Hh, out=s_f2w.out()).view(E, mh, 1, 1))
-        df2b = s_f2b.done(ops.colsum(do2, M, E, out=s_f2b.out()))
+        with streams.side(dev):
+            df1w = s_f1w.done(ops.linear_bwd_weight(dHpre, xn2.view(M, E), out=s_f1w.out()).view(mh, E, 1, 1))
+            df1b = s_f1b.done(ops.colsum(dHpre, M, mh, out=s_f1b.out()))
         dxn2 = ops.linear_bwd_data(dHpre, f1w)                                 # [M, E]
-        df1w = s_f1w.done(ops.linear_bwd_weight(dHpre, xn2.view(M, E), out=s_f1w.out()).view(mh, E, 1, 1))
-        df1b = s_f1b.done(ops.colsum(dHpre, M, mh, out=s_f1b.out()))
         dy1, dn2w, dn2b = ops.groupnorm_bwd(dxn2.view(B, tok, E), y1, mean2, rstd2, n2w, out_dgamma=s_n2w.out(),
                                             out_dbeta=s_n2b.out())
         dn2w, dn2b = s_n2w.done(dn2w), s_n2b.done(dn2b)
         # AFNO mixer
         dO2 = ops.rfft2(dy1, h, w, nb, mx, my, 1)                              # adjoint of irfft2
         kw = dict(lda=2 * E, ldb=2 * bs, ldc=2 * E, batch=nb, strideA=2 * bs, strideB=4 * bs * bs, strideC=2 * bs)
-        dO1pre = torch.empty(Mm, 2 * E, dtype=torch.float32, device=dev)
-        ops.gemm(dO2, wb2, dO1pre, Mm, 2 * bs, 2 * bs, transB=True, act=act, mode=EPI_DACT, aux=O1pre, ldaux=2 * E,
-                 strideAux=2 * bs, **kw)
         sk = ops.auto_splitk(2 * bs, 2 * bs, Mm, nb)
         wkw = dict(transA=True, lda=2 * E, ldb=2 * E, ldc=2 * bs, batch=nb, strideA=2 * bs, strideB=2 * bs,
                    strideC=4 * bs * bs, splitk=sk)
-        dwb2 = torch.empty(nb, 2 * bs, 2 * bs, dtype=torch.float32, device=dev)
-        ops.gemm(O1, dO2, dwb2, 2 * bs, 2 * bs, Mm, **wkw)
-        dbb2 = ops.colsum(dO2, Mm, 2 * E)
+        with streams.side(dev):
+            dwb2 = torch.empty(nb, 2 * bs, 2 * bs, dtype=torch.float32, device=dev)
+            ops.gemm(O1, dO2, dwb2, 2 * bs, 2 * bs, Mm, **wkw)
+            dbb2 = ops.colsum(dO2, Mm, 2 * E)
+            dw2, db2 = ops.afno_unpack_grad(dwb2, dbb2, nb, bs, out_dw=s_w2.out(), out_db=s_b2.out())
+            dw2, db2 = s_w2.done(dw2), s_b2.done(db2)
+        dO1pre = torch.empty(Mm, 2 * E, dtype=torch.float32, device=dev)
+        ops.gemm(dO2, wb2, dO1pre, Mm, 2 * bs, 2 * bs, transB=True, act=act, mode=EPI_DACT, aux=O1pre, ldaux=2 * E,
+                 strideAux=2 * bs, **kw)
+        with streams.side(dev):
+            dwb1 = torch.empty(nb, 2 * bs, 2 * bs, dtype=torch.float32, device=dev)
+            ops.gemm(S, dO1pre, dwb1, 2 * bs, 2 * bs, Mm, **wkw)
+            dbb1 = ops.colsum(dO1pre, Mm, 2 * E)
+            dw1, db1 = ops.afno_unpack_grad(dwb1, dbb1, nb, bs, out_dw=s_w1.out(), out_db=s_b1.out())
+            dw1, db1 = s_w1.done(dw1), s_b1.done(db1)
         dS = torch.empty(Mm, 2 * E, dtype=torch.float32, device=dev)
         ops.gemm(dO1pre, wb1, dS, Mm, 2 * bs, 2 * bs, transB=True, **kw)
-        dwb1 = torch.empty(nb, 2 * bs, 2 * bs, dtype=torch.float32, device=dev)
-        ops.gemm(S, dO1pre, dwb1, 2 * bs, 2 * bs, Mm, **wkw)
-        dbb1 = ops.colsum(dO1pre, Mm, 2 * E)
-        dw1, db1 = ops.afno_unpack_grad(dwb1, dbb1, nb, bs, out_dw=s_w1.out(), out_db=s_b1.out())
-        dw2, db2 = ops.afno_unpack_grad(dwb2, dbb2, nb, bs, out_dw=s_w2.out(), out_db=s_b2.out())
-        dw1, db1, dw2, db2 = s_w1.done(dw1), s_b1.done(db1), s_w2.done(dw2), s_b2.done(db2)
         dxn1 = ops.irfft2(dS, B, h, w, E, nb, mx, my, 0, res=dy1)              # adjoint of rfft2, + skip path
         dx, dn1w, dn1b = ops.groupnorm_bwd(dxn1, x, mean1, rstd1, n1w, add=dout, out_dgamma=s_n1w.out(),
                                            out_dbeta=s_n1b.out())
         dn1w, dn1b = s_n1w.done(dn1w), s_n1b.done(dn1b)
+        streams.join(dev)      # the side stream's readers of this frame's tensors are done before they can be freed
         return (dx, dn1w, dn1b, dw1, db1, dw2, db2, dn2w, dn2b, df1w, df1b, df2w, df2b, None, None, None, None, None)
 
 
