@@ -36,6 +36,7 @@ class GemmDesc(C.Structure):
         ("workspace", c_fp),
         ("tile", C.c_int32),
         ("tag", C.c_int32),
+        ("colsum_out", c_fp), ("strideColsum", c_i64), ("colsum_of", C.c_int32),
     ]
 
 

@@ -57,7 +57,11 @@ struct GemmArgs {
   int batch, splits, ktiles_per_split;
   int tilesM, tilesN;
   int evec;  // epilogue may use 16-byte accesses
-  float* ws;  // split-K partials [split][batch][M][N]
+  float* ws;  // split-K partials [split][batch][M][N] (+ [split][batch][L] column-sum partials)
+  // fused bias gradient: column sums over k of one operand (wgrad: dW = dY^T X and db = colsum(dY) read the same dY)
+  float* cs_out;      // [batch][L], L = M (cs_of == 1, A stored [K,M]) or N (cs_of == 2, B stored [K,N])
+  long long sCs;
+  int cs_of;
   EpiArgs e;
 };
 
@@ -288,6 +292,8 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmArgs p) {
   const int tm_idx = tile / p.tilesN, tn_idx = tile % p.tilesN;
   const int m0 = tm_idx * BM, n0 = tn_idx * BN;
   const int zb = blockIdx.z / p.splits, zs = blockIdx.z % p.splits;
+  const bool cs_on = (p.cs_of == 1 && tn_idx == 0) || (p.cs_of == 2 && tm_idx == 0);
+  float cs_acc = 0.f;
 
   const float* A = p.A + zb * p.sA;
   const float* B = p.B + zb * p.sB;
@@ -328,6 +334,16 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmArgs p) {
     __syncthreads();
     for (int kt = 0; kt < nk; ++kt) {
       if (kt + 1 < nk) gload(kbeg + (kt + 1) * BK);
+      if (cs_on) {   // uniform per workgroup: only the first tile column (row) of the grid sums the operand
+        if constexpr (TA) {
+          if (p.cs_of == 1)
+            for (int k = tid / BM; k < BK; k += 256 / BM) cs_acc += As[k * BM + tid % BM];
+        }
+        if constexpr (!TB) {
+          if (p.cs_of == 2)
+            for (int k = tid / BN; k < BK; k += 256 / BN) cs_acc += Bs[k * BN + tid % BN];
+        }
+      }
 #pragma unroll
       for (int kk = 0; kk < BK; kk += 8) {
         float4 af[TM], bf[TN];
@@ -355,6 +371,25 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmArgs p) {
 
   // ---- epilogue (the operand slabs in LDS are dead: reuse them as per-wave staging)
   __syncthreads();
+  if (cs_on) {
+    // combine the k-lanes in a fixed order; one value per operand column owned by this tile
+    const int R = p.cs_of == 1 ? BM : BN;
+    smem[tid] = cs_acc;
+    __syncthreads();
+    if (tid < R) {
+      float s = 0.f;
+      for (int l = 0; l < 256 / R; ++l) s += smem[l * R + tid];
+      const int L = p.cs_of == 1 ? p.M : p.N;
+      const int g = (p.cs_of == 1 ? m0 : n0) + tid;
+      if (g < L) {
+        if (p.splits > 1)
+          p.ws[(long long)p.splits * p.batch * p.M * p.N + ((long long)zs * p.batch + zb) * L + g] = s;
+        else
+          p.cs_out[zb * p.sCs + g] = s;
+      }
+    }
+    __syncthreads();
+  }
   float* stage = smem + wave * (32 * EPI_LD);
   // explicit (i, j) instances: a `#pragma unroll` over loops that contain the non-unrolled epilogue loop is
   // declined by the compiler and would turn acc[i][j] into a scratch array
@@ -383,9 +418,19 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmArgs p) {
 }
 
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ ws, int splits, int batch,
-                                                            const EpiArgs e) {
+                                                            const EpiArgs e, float* __restrict__ cs_out,
+                                                            long long sCs, int csL) {
   const long long MN = (long long)e.M * e.N;
   const long long total = MN * batch;
+  if (cs_out) {   // column-sum partials [split][batch][csL] live behind the matrix partials
+    const float* wc = ws + (long long)splits * total;
+    const long long nc = (long long)batch * csL;
+    for (long long idx = blockIdx.x * 256ll + threadIdx.x; idx < nc; idx += (long long)gridDim.x * 256) {
+      float v = 0.f;
+      for (int s = 0; s < splits; ++s) v += wc[(long long)s * nc + idx];
+      cs_out[(idx / csL) * sCs + idx % csL] = v;
+    }
+  }
   for (long long idx = blockIdx.x * 256ll + threadIdx.x; idx < total; idx += (long long)gridDim.x * 256) {
     float v = 0.f;
     int s = 0;
@@ -430,7 +475,8 @@ extern "C" int dpot_gemm_auto_splitk(int M, int N, int K, int batch) {
 
 extern "C" int64_t dpot_gemm_workspace_bytes(const dpot_gemm_desc* d) {
   if (!d || d->splitk <= 1) return 0;
-  return (int64_t)d->splitk * d->batch * d->M * d->N * (int64_t)sizeof(float);
+  const int64_t L = d->colsum_of == 1 ? d->M : d->colsum_of == 2 ? d->N : 0;
+  return (int64_t)d->splitk * d->batch * ((int64_t)d->M * d->N + L) * (int64_t)sizeof(float);
 }
 
 template <int BMN, bool VEC>
@@ -459,6 +505,9 @@ extern "C" int dpot_gemm_f32(const dpot_gemm_desc* d, dpot_stream_t stream) {
   DPOT_REQUIRE(d->epi_mode != DPOT_EPI_DACT || d->aux != nullptr, "gemm: DACT epilogue needs aux");
   const int splits = d->splitk > 1 ? d->splitk : 1;
   DPOT_REQUIRE(splits == 1 || d->workspace != nullptr, "gemm: split-K needs a workspace");
+  DPOT_REQUIRE(d->colsum_of == 0 || (d->colsum_out != nullptr && ((d->colsum_of == 1 && d->transA) ||
+                                                                     (d->colsum_of == 2 && !d->transB))),
+               "gemm: fused column sums need colsum_out and a [K,M]-stored A (colsum_of=1) or [K,N]-stored B (=2)");
 
   GemmArgs p;
   p.A = d->A; p.B = d->B;
@@ -475,6 +524,7 @@ extern "C" int dpot_gemm_f32(const dpot_gemm_desc* d, dpot_stream_t stream) {
   const bool vecB = aligned16(d->B) && (d->ldb % 4 == 0) && (contB % 4 == 0) && (d->strideB % 4 == 0);
   const bool vec = vecA && vecB;
   p.ws = d->workspace;
+  p.cs_out = d->colsum_out; p.sCs = d->strideColsum; p.cs_of = d->colsum_of;
   EpiArgs& e = p.e;
   e.C = d->C; e.ldc = d->ldc; e.sC = d->strideC;
   e.bias = d->bias; e.sBias = d->strideBias;
@@ -508,7 +558,8 @@ extern "C" int dpot_gemm_f32(const dpot_gemm_desc* d, dpot_stream_t stream) {
     int blocks = (int)((total + 255) / 256);
     if (blocks > 4096) blocks = 4096;
     hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, s, (const float*)d->workspace, splits,
-                       d->batch, e);
+                       d->batch, e, d->colsum_of ? d->colsum_out : (float*)nullptr, (long long)d->strideColsum,
+                       d->colsum_of == 1 ? d->M : d->N);
     rc = check_launch("splitk_reduce_kernel");
   }
   return rc;

@@ -152,8 +152,12 @@ class EmbedFn(torch.autograd.Function):
         else:
             dtaw, dgamma = s_taw.done(dws), None
         # first (PxP / stride P) conv
-        db0 = s_b0.done(ops.colsum(dHpre, M0, hid, ld=hidp, out=s_b0.out()))
-        dw0p = ops.linear_bwd_weight(dHpre, A0)                                # [hidp, K0] (padded: 16-byte loads)
+        if hid == hidp:
+            dw0p, db0 = ops.linear_bwd_wb(dHpre, A0, None, s_b0.out())          # [hidp, K0] (padded: 16-byte loads)
+            db0 = s_b0.done(db0)
+        else:
+            db0 = s_b0.done(ops.colsum(dHpre, M0, hid, ld=hidp, out=s_b0.out()))
+            dw0p = ops.linear_bwd_weight(dHpre, A0)
         dw0 = s_w0.done(ops.copy2d_pad(dw0p, hidp, K0, hid, K0, out=s_w0.out()).view(hid, Cc + 3, P, P))
         dx = None
         if ctx.needs_input_grad[0]:
@@ -214,12 +218,12 @@ class BlockFn(torch.autograd.Function):
         # gradients (wgrad GEMMs + split-K reductions, bias column sums, un-packing) runs on the side stream.
         # channel MLP
         with streams.side(dev):
-            df2w = s_f2w.done(ops.linear_bwd_weight(do2, Hh, out=s_f2w.out()).view(E, mh, 1, 1))
-            df2b = s_f2b.done(ops.colsum(do2, M, E, out=s_f2b.out()))
+            df2w, df2b = ops.linear_bwd_wb(do2, Hh, s_f2w.out(), s_f2b.out())
+            df2w, df2b = s_f2w.done(df2w.view(E, mh, 1, 1)), s_f2b.done(df2b)
         dHpre = ops.linear_bwd_data(do2, f2w, act=act, aux=Hpre)               # [M, mh]
         with streams.side(dev):
-            df1w = s_f1w.done(ops.linear_bwd_weight(dHpre, xn2.view(M, E), out=s_f1w.out()).view(mh, E, 1, 1))
-            df1b = s_f1b.done(ops.colsum(dHpre, M, mh, out=s_f1b.out()))
+            df1w, df1b = ops.linear_bwd_wb(dHpre, xn2.view(M, E), s_f1w.out(), s_f1b.out())
+            df1w, df1b = s_f1w.done(df1w.view(mh, E, 1, 1)), s_f1b.done(df1b)
         dxn2 = ops.linear_bwd_data(dHpre, f1w)                                 # [M, E]
         dy1, dn2w, dn2b = ops.groupnorm_bwd(dxn2.view(B, tok, E), y1, mean2, rstd2, n2w, out_dgamma=s_n2w.out(),
                                             out_dbeta=s_n2b.out())
@@ -232,8 +236,8 @@ class BlockFn(torch.autograd.Function):
                    strideC=4 * bs * bs, splitk=sk)
         with streams.side(dev):
             dwb2 = torch.empty(nb, 2 * bs, 2 * bs, dtype=torch.float32, device=dev)
-            ops.gemm(O1, dO2, dwb2, 2 * bs, 2 * bs, Mm, **wkw)
-            dbb2 = ops.colsum(dO2, Mm, 2 * E)
+            dbb2 = torch.empty(2 * E, dtype=torch.float32, device=dev)
+            ops.gemm(O1, dO2, dwb2, 2 * bs, 2 * bs, Mm, colsum_out=dbb2, colsum_of=2, strideColsum=2 * bs, **wkw)
             dw2, db2 = ops.afno_unpack_grad(dwb2, dbb2, nb, bs, out_dw=s_w2.out(), out_db=s_b2.out())
             dw2, db2 = s_w2.done(dw2), s_b2.done(db2)
         dO1pre = torch.empty(Mm, 2 * E, dtype=torch.float32, device=dev)
@@ -241,8 +245,8 @@ class BlockFn(torch.autograd.Function):
                  strideAux=2 * bs, **kw)
         with streams.side(dev):
             dwb1 = torch.empty(nb, 2 * bs, 2 * bs, dtype=torch.float32, device=dev)
-            ops.gemm(S, dO1pre, dwb1, 2 * bs, 2 * bs, Mm, **wkw)
-            dbb1 = ops.colsum(dO1pre, Mm, 2 * E)
+            dbb1 = torch.empty(2 * E, dtype=torch.float32, device=dev)
+            ops.gemm(S, dO1pre, dwb1, 2 * bs, 2 * bs, Mm, colsum_out=dbb1, colsum_of=2, strideColsum=2 * bs, **wkw)
             dw1, db1 = ops.afno_unpack_grad(dwb1, dbb1, nb, bs, out_dw=s_w1.out(), out_db=s_b1.out())
             dw1, db1 = s_w1.done(dw1), s_b1.done(db1)
         dS = torch.empty(Mm, 2 * E, dtype=torch.float32, device=dev)
@@ -326,11 +330,11 @@ class HeadFn(torch.autograd.Function):
             else:
                 dZ = ops.pixel_shuffle(dpred.contiguous(), B, h, w, P, co, inverse=True)  # [Mp, co]
                 dVpre = ops.linear_bwd_data(dZ, o4w2, act=act, aux=Vpre)                  # [Mp, old]
-                do4w = s_o4w.done(ops.linear_bwd_weight(dZ, V, out=s_o4w.out()).view(co, old, 1, 1))
-                do4b = s_o4b.done(ops.colsum(dZ, Mp, co, out=s_o4b.out()))
+                do4w, do4b = ops.linear_bwd_wb(dZ, V, s_o4w.out(), s_o4b.out())
+                do4w, do4b = s_o4w.done(do4w.view(co, old, 1, 1)), s_o4b.done(do4b)
                 dUpre = ops.linear_bwd_data(dVpre, o2w2, act=act, aux=Upre.view(Mp, old))  # [Mp, old]
-                do2w = s_o2w.done(ops.linear_bwd_weight(dVpre, U.view(Mp, old), out=s_o2w.out()).view(old, old, 1, 1))
-                do2b = s_o2b.done(ops.colsum(dVpre, Mp, old, out=s_o2b.out()))
+                do2w, do2b = ops.linear_bwd_wb(dVpre, U.view(Mp, old), s_o2w.out(), s_o2b.out())
+                do2w, do2b = s_o2w.done(do2w.view(old, old, 1, 1)), s_o2b.done(do2b)
                 do0b = s_o0b.done(ops.colsum(dUpre, Mp, old, out=s_o0b.out()))
             dU2 = dUpre.view(M, PP * old)
             dx_out = torch.empty(M, E, dtype=torch.float32, device=dev)
@@ -346,14 +350,14 @@ class HeadFn(torch.autograd.Function):
             s_c0w, s_c0b, s_c2w, s_c2b, s_c4w, s_c4b = [_Sink(p, n) for p, n in zip(ctx.cls_params, ctx.cls_needed)]
             dcls = dcls.contiguous()
             dc2pre = ops.linear_bwd_data(dcls, c4w, act=act, aux=c2pre)
-            dc4w = s_c4w.done(ops.linear_bwd_weight(dcls, c2, out=s_c4w.out()))
-            dc4b = s_c4b.done(ops.colsum(dcls, B, dcls.shape[1], out=s_c4b.out()))
+            dc4w, dc4b = ops.linear_bwd_wb(dcls, c2, s_c4w.out(), s_c4b.out())
+            dc4w, dc4b = s_c4w.done(dc4w), s_c4b.done(dc4b)
             dc1pre = ops.linear_bwd_data(dc2pre, c2w, act=act, aux=c1pre)
-            dc2w = s_c2w.done(ops.linear_bwd_weight(dc2pre, c1, out=s_c2w.out()))
-            dc2b = s_c2b.done(ops.colsum(dc2pre, B, E, out=s_c2b.out()))
+            dc2w, dc2b = ops.linear_bwd_wb(dc2pre, c1, s_c2w.out(), s_c2b.out())
+            dc2w, dc2b = s_c2w.done(dc2w), s_c2b.done(dc2b)
             dcm = ops.linear_bwd_data(dc1pre, c0w)
-            dc0w = s_c0w.done(ops.linear_bwd_weight(dc1pre, cm, out=s_c0w.out()))
-            dc0b = s_c0b.done(ops.colsum(dc1pre, B, E, out=s_c0b.out()))
+            dc0w, dc0b = ops.linear_bwd_wb(dc1pre, cm, s_c0w.out(), s_c0b.out())
+            dc0w, dc0b = s_c0w.done(dc0w), s_c0b.done(dc0b)
             dx = ops.token_mean_bwd(dcm, tok, add=dx_out)
         return (dx, do0w, do0b, do2w, do2b, do4w, do4b, dc0w, dc0b, dc2w, dc2b, dc4w, dc4b, None, None, None, None)
 

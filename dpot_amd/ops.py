@@ -52,7 +52,8 @@ def gemm(A: Tensor, B: Tensor, C_: Tensor, M: int, N: int, K: int, *, transA: bo
          aux: Optional[Tensor] = None, ldaux: int = 0, strideAux: int = 0,
          preact: Optional[Tensor] = None, ldpre: int = 0, stridePre: int = 0,
          res: Optional[Tensor] = None, ldres: int = 0, res_div: int = 0, res_mod: int = 0, strideRes: int = 0,
-         accumulate: bool = False, splitk: int = 1, tile: int = 0, tag: int = 0) -> Tensor:
+         accumulate: bool = False, splitk: int = 1, tile: int = 0, tag: int = 0,
+         colsum_out: Optional[Tensor] = None, colsum_of: int = 0, strideColsum: int = 0) -> Tensor:
     """C = epilogue(A @ B) on the matrix cores; see include/dpot_hip.h for the exact semantics."""
     lib = _lib.load()
     d = GemmDesc()
@@ -69,9 +70,11 @@ def gemm(A: Tensor, B: Tensor, C_: Tensor, M: int, N: int, K: int, *, transA: bo
     d.accumulate = int(accumulate)
     d.tile = tile
     d.tag = tag
+    d.colsum_out, d.colsum_of, d.strideColsum = _p(colsum_out), (colsum_of if colsum_out is not None else 0), strideColsum
     ws = None
     if splitk > 1:
-        ws = torch.empty(splitk * batch * M * N, dtype=torch.float32, device=A.device)
+        L = M if d.colsum_of == 1 else N if d.colsum_of == 2 else 0
+        ws = torch.empty(splitk * batch * (M * N + L), dtype=torch.float32, device=A.device)
         d.splitk, d.workspace = splitk, ws.data_ptr()
     else:
         d.splitk, d.workspace = 1, None
@@ -110,15 +113,24 @@ def _out(out: Optional[Tensor], shape, device) -> Tensor:
     return out.view(shape)
 
 
-def linear_bwd_weight(dy: Tensor, x: Tensor, out: Optional[Tensor] = None, n_rows: Optional[int] = None) -> Tensor:
-    """dW[N,K] = dy[M,N]^T @ x[M,K]   (split-K over the token dimension); n_rows < N computes only dW[:n_rows]."""
+def linear_bwd_weight(dy: Tensor, x: Tensor, out: Optional[Tensor] = None, n_rows: Optional[int] = None,
+                      bias_out: Optional[Tensor] = None) -> Tensor:
+    """dW[N,K] = dy[M,N]^T @ x[M,K]   (split-K over the token dimension); n_rows < N computes only dW[:n_rows].
+    bias_out [N]: also db = colsum(dy), produced by the same kernel from the dy tiles it stages anyway."""
     M, N = dy.shape
     N = n_rows or N
     K = x.shape[1]
     dW = _out(out, (N, K), dy.device)
     gemm(dy, x, dW, N, K, M, transA=True, transB=False, lda=dy.stride(0), ldb=x.stride(0), ldc=K,
-         splitk=auto_splitk(N, K, M))
+         splitk=auto_splitk(N, K, M), colsum_out=bias_out, colsum_of=1)
     return dW
+
+
+def linear_bwd_wb(dy: Tensor, x: Tensor, out_w: Optional[Tensor] = None,
+                  out_b: Optional[Tensor] = None) -> Tuple[Tensor, Tensor]:
+    """(dW, db) of y = x W^T + b in one launch (+ the split-K reduction): db rides on the dy tiles of the wgrad GEMM"""
+    db = _out(out_b, (dy.shape[1],), dy.device)
+    return linear_bwd_weight(dy, x, out=out_w, bias_out=db), db
 
 
 # ------------------------------------------------------------------------------------------------------

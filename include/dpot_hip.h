@@ -113,6 +113,12 @@ typedef struct dpot_gemm_desc {
   float* workspace;
   int32_t tile; /* 0 = auto, 64 or 128 = force BMxBN tile */
   int32_t tag;  /* 1 = launch the separately-named AFNO-mixer instantiation (profiling identity only) */
+  /* fused bias gradient: colsum_out[b*strideColsum + j] = sum_k of operand column j;  colsum_of = 1: columns of A
+   * (needs transA = 1, j < M), 2: columns of B (needs transB = 0, j < N), 0: off.  With split-K the workspace grows by
+   * splitk*batch*L floats (dpot_gemm_workspace_bytes accounts for it). */
+  float* colsum_out;
+  int64_t strideColsum;
+  int32_t colsum_of;
 } dpot_gemm_desc;
 
 int dpot_gemm_f32(const dpot_gemm_desc* d, dpot_stream_t stream);

@@ -103,6 +103,29 @@ def test_gemm_batched_strided_and_splitk(ops):
     assert torch.equal(outs[0], outs[1]), "split-K reduction must be deterministic"
 
 
+@pytest.mark.parametrize("splitk", [1, 5])
+def test_gemm_fused_column_sums(ops, splitk):
+    """bias gradients ride on the wgrad GEMM: colsum_of=1 sums A's columns (A stored [K,M]), =2 B's (B stored [K,N])"""
+    nb, bs, Mm = 4, 24, 333                                  # batched mixer wgrad: db = colsum(dO) per block
+    E2 = 2 * bs * nb
+    S, dO = rnd(Mm, E2, seed=1), rnd(Mm, E2, seed=4)
+    dW = torch.empty(nb, 2 * bs, 2 * bs, device="cuda")
+    db = torch.full((E2,), float("nan"), device="cuda")
+    ops.gemm(S.cuda(), dO.cuda(), dW, 2 * bs, 2 * bs, Mm, transA=True, lda=E2, ldb=E2, ldc=2 * bs, batch=nb,
+             strideA=2 * bs, strideB=2 * bs, strideC=4 * bs * bs, splitk=splitk, colsum_out=db, colsum_of=2,
+             strideColsum=2 * bs)
+    assert_close(dW, torch.einsum("mki,mko->kio", S.double().view(Mm, nb, 2 * bs), dO.double().view(Mm, nb, 2 * bs)),
+                 "wgrad next to the column sums")
+    assert_close(db, dO.double().sum(0), "colsum of B")
+    for M, N, K in [(70000, 200, 130), (1000, 512, 512), (32, 12, 512)]:   # nn.Linear wgrad + bias grad, several tiles
+        dy, x = rnd(M, N, seed=1), rnd(M, K, seed=2)
+        dWl, dbl = ops.linear_bwd_wb(dy.cuda(), x.cuda())
+        assert_close(dWl, dy.double().t() @ x.double(), f"wgrad {M}x{N}x{K}")
+        assert_close(dbl, dy.double().sum(0), f"bias grad {M}x{N}x{K}")
+        dWl2, dbl2 = ops.linear_bwd_wb(dy.cuda(), x.cuda())
+        assert torch.equal(dbl, dbl2) and torch.equal(dWl, dWl2)
+
+
 def test_linear_bwd_weight_auto_splitk_large_k(ops):
     M, N, K = 65536, 32, 32                                  # out-layer tail wgrad: tiny output, huge contraction
     dy, x = rnd(M, N, seed=1), rnd(M, K, seed=2)
