@@ -334,3 +334,17 @@ def test_tiny_b32_properties():
         l_ref = R.rel_l2_loss(po, yy[:2].cpu(), msk[:2].cpu()).item()
     assert_close(p2, po, "tiny pred vs oracle")
     assert abs(l_gpu - l_ref) <= 1e-4 * abs(l_ref)
+
+
+@pytest.mark.parametrize("name", ["SMALL", "MEDIUM", "LARGE"])
+def test_baseline_configs_forward_vs_oracle(name):
+    """BASELINE.json configs[2..4]: DPOT-S / -M (mlp_ratio 4, 8 blocks) and -L (256^2, 32x32 patch grid, modes 64 capped
+    by the grid, embed 1536 / 16 blocks, out_layer_dim 128 = the un-fused de-embed tail) against the CPU oracle, B=1"""
+    kw = getattr(R, name)
+    m, cfg = build(kw, salt=0)
+    x = R.recipe_input((1, cfg.img_size, cfg.img_size, cfg.in_timesteps, cfg.in_channels))
+    with torch.no_grad():
+        ref, ref_cls = R.dpot_forward(R.recipe_state_dict(cfg, salt=0), x, cfg)
+        out, cls = m(x.cuda())
+    assert_close(out, ref, f"{name} pred")
+    assert_close(cls, ref_cls, f"{name} cls")
