@@ -9,7 +9,7 @@ import os
 import threading
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "lib", "libdpot_hip.so")
+LIB_PATH = os.environ.get("DPOT_HIP_LIB") or os.path.join(HERE, "lib", "libdpot_hip.so")   # override: kernel experiments
 
 c_fp = C.c_void_p       # device pointer (float*)
 c_i = C.c_int
@@ -37,6 +37,7 @@ class GemmDesc(C.Structure):
         ("tile", C.c_int32),
         ("tag", C.c_int32),
         ("colsum_out", c_fp), ("strideColsum", c_i64), ("colsum_of", C.c_int32),
+        ("precision", C.c_int32),
     ]
 
 
@@ -47,6 +48,7 @@ SIGNATURES = {
     "dpot_gemm_f32": (c_i, [C.POINTER(GemmDesc), c_fp]),
     "dpot_gemm_workspace_bytes": (c_i64, [C.POINTER(GemmDesc)]),
     "dpot_gemm_auto_splitk": (c_i, [c_i, c_i, c_i, c_i]),
+    "dpot_gemm_auto_splitk2": (c_i, [c_i, c_i, c_i, c_i, c_i]),
     "dpot_rfft2": (c_i, [c_fp, c_fp] + [c_i] * 8 + [c_fp]),
     "dpot_irfft2": (c_i, [c_fp, c_fp, c_fp] + [c_i] * 8 + [c_fp]),
     "dpot_afno_pack": (c_i, [c_fp] * 4 + [c_i, c_i, c_fp]),

@@ -34,7 +34,7 @@ def _stale(target: str, deps) -> bool:
 def build(force: bool = False, verbose: bool = True) -> str:
     hipcc = _hipcc()
     os.makedirs(LIBDIR, exist_ok=True)
-    hdrs = [os.path.join(CSRC, "common.h"), os.path.join(CSRC, "dft_fast.h"), os.path.join(os.path.dirname(HERE), "include", "dpot_hip.h")]
+    hdrs = [os.path.join(CSRC, "common.h"), os.path.join(CSRC, "dft_fast.h"), os.path.join(CSRC, "gemm_split.h"), os.path.join(os.path.dirname(HERE), "include", "dpot_hip.h")]
     objs, jobs = [], []
     for src in SOURCES:
         s = os.path.join(CSRC, src)

@@ -457,7 +457,19 @@ static int pick_tile(int M, int N, int batch, int forced) {
   return t128 >= 2 * NUM_CU ? 128 : 64;
 }
 
+// bf16x6 path: the 128x128 tile owns 120 KB of LDS (one workgroup per CU) and halves both the operand-split work
+// and the L2 traffic per MFMA of the 64x64 tile, so it wins whenever its workgroups fill the 256 CUs evenly
+static int pick_tile_split(int M, int N, int batch, int splits, int forced) {
+  if (forced == 64 || forced == 128) return forced;
+  if (M <= 64 || N <= 64) return 64;
+  const long long t128 = (long long)cdiv(M, 128) * cdiv(N, 128) * batch * splits;
+  const long long waves = (t128 + NUM_CU - 1) / NUM_CU;
+  return 4 * t128 >= 3 * waves * NUM_CU ? 128 : 64;
+}
+
 }  // namespace dpot
+
+#include "gemm_split.h"
 
 using namespace dpot;
 
@@ -470,6 +482,17 @@ extern "C" int dpot_gemm_auto_splitk(int M, int N, int K, int batch) {
   const long long smax = ktiles / 4;                // keep >= 4 K-slabs per split
   if (s > smax) s = smax;
   if (s > 512) s = 512;
+  return s < 1 ? 1 : (int)s;
+}
+
+extern "C" int dpot_gemm_auto_splitk2(int M, int N, int K, int batch, int precision) {
+  if (precision != DPOT_GEMM_BF16X6 || M <= 64 || N <= 64) return dpot_gemm_auto_splitk(M, N, K, batch);
+  const long long t128 = (long long)cdiv(M, 128) * cdiv(N, 128) * batch;
+  const int ktiles = cdiv(K, BK);
+  if (4 * t128 >= 3 * NUM_CU || ktiles < 16) return 1;
+  long long s = (NUM_CU + t128 / 2) / t128;         // one 128x128 workgroup per CU
+  const long long smax = ktiles / 8;                // keep >= 8 K-slabs per split (pipeline fill / drain)
+  if (s > smax) s = smax;
   return s < 1 ? 1 : (int)s;
 }
 
@@ -540,13 +563,20 @@ extern "C" int dpot_gemm_f32(const dpot_gemm_desc* d, dpot_stream_t stream) {
   p.evec = (d->N % 4 == 0) && vec_ok(d->C, d->ldc, d->strideC) && vec_ok(d->bias, 4, d->strideBias) &&
            vec_ok(d->aux, d->ldaux, d->strideAux) && vec_ok(d->preact, d->ldpre, d->stridePre) &&
            vec_ok(d->res, d->ldres, d->strideRes);
-  const int t = pick_tile(d->M, d->N, d->batch, d->tile);
+  const int t = d->precision == DPOT_GEMM_BF16X6 ? pick_tile_split(d->M, d->N, d->batch, splits, d->tile)
+                                                 : pick_tile(d->M, d->N, d->batch, d->tile);
   p.tilesM = cdiv(d->M, t); p.tilesN = cdiv(d->N, t);
   const long long ntiles = (long long)p.tilesM * p.tilesN;
   DPOT_REQUIRE(ntiles < (1ll << 31) && (long long)d->batch * splits <= 65535, "gemm: grid too large");
   dim3 grid((unsigned)ntiles, 1, (unsigned)(d->batch * splits));
   hipStream_t s = as_stream(stream);
-  if (t == 128) {
+  if (d->precision == DPOT_GEMM_BF16X6) {
+    if (t == 128) {
+      if (vec) launch_gemm_split<128, true>(d, p, grid, s); else launch_gemm_split<128, false>(d, p, grid, s);
+    } else {
+      if (vec) launch_gemm_split<64, true>(d, p, grid, s); else launch_gemm_split<64, false>(d, p, grid, s);
+    }
+  } else if (t == 128) {
     if (vec) launch_gemm<128, true>(d, p, grid, s); else launch_gemm<128, false>(d, p, grid, s);
   } else {
     if (vec) launch_gemm<64, true>(d, p, grid, s); else launch_gemm<64, false>(d, p, grid, s);

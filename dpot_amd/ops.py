@@ -7,6 +7,7 @@ tensors.  There is deliberately no CPU or eager-PyTorch fallback.
 from __future__ import annotations
 
 import ctypes as C
+import os
 from typing import Optional, Tuple
 
 import torch
@@ -19,6 +20,20 @@ Tensor = torch.Tensor
 ACT_IDS = {None: 0, "none": 0, "gelu": 1, "tanh": 2, "sigmoid": 3, "relu": 4, "leaky_relu": 5, "softplus": 6,
            "ELU": 7, "silu": 8}
 EPI_LINEAR, EPI_ACT, EPI_DACT = 0, 1, 2
+GEMM_F32, GEMM_BF16X6 = 0, 1
+_PRECISIONS = {"f32": GEMM_F32, "bf16x6": GEMM_BF16X6}
+# how every GEMM forms its fp32 products (include/dpot_hip.h: dpot_gemm_desc.precision); DPOT_GEMM_PRECISION=f32|bf16x6
+_gemm_precision = _PRECISIONS[os.environ.get("DPOT_GEMM_PRECISION", "f32")]
+
+
+def set_gemm_precision(name: str) -> None:
+    """'f32' = native fp32 MFMA, 'bf16x6' = fp32 emulated by 3-way bf16 operand splitting (fp32-level accuracy)"""
+    global _gemm_precision
+    _gemm_precision = _PRECISIONS[name]
+
+
+def gemm_precision() -> str:
+    return {v: k for k, v in _PRECISIONS.items()}[_gemm_precision]
 
 
 def _stream() -> int:
@@ -42,8 +57,8 @@ def _p(t: Optional[Tensor]) -> Optional[int]:
 # ------------------------------------------------------------------------------------------------------
 # GEMM
 # ------------------------------------------------------------------------------------------------------
-def auto_splitk(M: int, N: int, K: int, batch: int = 1) -> int:
-    return _lib.load().dpot_gemm_auto_splitk(M, N, K, batch)
+def auto_splitk(M: int, N: int, K: int, batch: int = 1, precision: Optional[int] = None) -> int:
+    return _lib.load().dpot_gemm_auto_splitk2(M, N, K, batch, _gemm_precision if precision is None else precision)
 
 
 def gemm(A: Tensor, B: Tensor, C_: Tensor, M: int, N: int, K: int, *, transA: bool = False, transB: bool = False,
@@ -53,7 +68,8 @@ def gemm(A: Tensor, B: Tensor, C_: Tensor, M: int, N: int, K: int, *, transA: bo
          preact: Optional[Tensor] = None, ldpre: int = 0, stridePre: int = 0,
          res: Optional[Tensor] = None, ldres: int = 0, res_div: int = 0, res_mod: int = 0, strideRes: int = 0,
          accumulate: bool = False, splitk: int = 1, tile: int = 0, tag: int = 0,
-         colsum_out: Optional[Tensor] = None, colsum_of: int = 0, strideColsum: int = 0) -> Tensor:
+         colsum_out: Optional[Tensor] = None, colsum_of: int = 0, strideColsum: int = 0,
+         precision: Optional[int] = None) -> Tensor:
     """C = epilogue(A @ B) on the matrix cores; see include/dpot_hip.h for the exact semantics."""
     lib = _lib.load()
     d = GemmDesc()
@@ -70,6 +86,7 @@ def gemm(A: Tensor, B: Tensor, C_: Tensor, M: int, N: int, K: int, *, transA: bo
     d.accumulate = int(accumulate)
     d.tile = tile
     d.tag = tag
+    d.precision = _gemm_precision if precision is None else precision
     d.colsum_out, d.colsum_of, d.strideColsum = _p(colsum_out), (colsum_of if colsum_out is not None else 0), strideColsum
     ws = None
     if splitk > 1:

@@ -119,13 +119,22 @@ typedef struct dpot_gemm_desc {
   float* colsum_out;
   int64_t strideColsum;
   int32_t colsum_of;
+  /* how the fp32 products are formed (both accumulate in fp32 and meet the rtol 1e-4 contract):
+   *   DPOT_GEMM_F32    v_mfma_f32_32x32x2_f32, native fp32 operands
+   *   DPOT_GEMM_BF16X6 fp32 emulated on the bf16 matrix cores: each operand is split a = a1+a2+a3 (bf16 each, exact
+   *                    to 2^-25) and the 6 partial products down to 2^-24 are accumulated - fp32-level accuracy at
+   *                    2.67x the fp32 MFMA rate (csrc/gemm_split.h) */
+  int32_t precision;
 } dpot_gemm_desc;
+enum { DPOT_GEMM_F32 = 0, DPOT_GEMM_BF16X6 = 1 };
 
 int dpot_gemm_f32(const dpot_gemm_desc* d, dpot_stream_t stream);
 /* bytes of workspace dpot_gemm_f32 needs for this descriptor (0 when splitk <= 1) */
 int64_t dpot_gemm_workspace_bytes(const dpot_gemm_desc* d);
 /* the split-K factor the library would pick for this shape (>= 1) */
 int dpot_gemm_auto_splitk(int M, int N, int K, int batch);
+/* the same for a given dpot_gemm_desc.precision (the bf16x6 kernel prefers fewer, larger workgroups) */
+int dpot_gemm_auto_splitk2(int M, int N, int K, int batch, int precision);
 
 /* ------------------------------------------------------------------------------------------------
  * rfft2 / irfft2, norm="ortho", over the two spatial axes of a channels-last field, done as two in-LDS
