@@ -485,7 +485,20 @@ extern "C" int dpot_gemm_auto_splitk(int M, int N, int K, int batch) {
   return s < 1 ? 1 : (int)s;
 }
 
+// DPOT_GEMM_AUTO: both kernels are fp32-accurate, so the choice is pure speed.  The bf16x6 kernel has the higher
+// roof but a longer pipeline (two slabs of prologue, 120 KB of LDS per workgroup): it pays on the large products
+// (measured in the DPOT-Tiny step: 3 GFLOP and up: channel-MLP, embed and de-embed GEMMs), not on the 2.4 GFLOP batched AFNO mixer.
+static int resolve_precision(int precision, int M, int N, int K, int batch) {
+  if (precision != DPOT_GEMM_AUTO) return precision;
+  static const double min_gflop = [] {
+    const char* e = getenv("DPOT_GEMM_AUTO_GFLOP");
+    return e ? atof(e) : 3.0;
+  }();
+  return 2.0 * M * N * K * batch >= min_gflop * 1e9 ? DPOT_GEMM_BF16X6 : DPOT_GEMM_F32;
+}
+
 extern "C" int dpot_gemm_auto_splitk2(int M, int N, int K, int batch, int precision) {
+  precision = resolve_precision(precision, M, N, K, batch);
   if (precision != DPOT_GEMM_BF16X6 || M <= 64 || N <= 64) return dpot_gemm_auto_splitk(M, N, K, batch);
   const long long t128 = (long long)cdiv(M, 128) * cdiv(N, 128) * batch;
   const int ktiles = cdiv(K, BK);
@@ -563,14 +576,16 @@ extern "C" int dpot_gemm_f32(const dpot_gemm_desc* d, dpot_stream_t stream) {
   p.evec = (d->N % 4 == 0) && vec_ok(d->C, d->ldc, d->strideC) && vec_ok(d->bias, 4, d->strideBias) &&
            vec_ok(d->aux, d->ldaux, d->strideAux) && vec_ok(d->preact, d->ldpre, d->stridePre) &&
            vec_ok(d->res, d->ldres, d->strideRes);
-  const int t = d->precision == DPOT_GEMM_BF16X6 ? pick_tile_split(d->M, d->N, d->batch, splits, d->tile)
-                                                 : pick_tile(d->M, d->N, d->batch, d->tile);
+  const int precision = resolve_precision(d->precision, d->M, d->N, d->K, d->batch);
+  DPOT_REQUIRE(precision == DPOT_GEMM_F32 || precision == DPOT_GEMM_BF16X6, "gemm: bad precision %d", d->precision);
+  const int t = precision == DPOT_GEMM_BF16X6 ? pick_tile_split(d->M, d->N, d->batch, splits, d->tile)
+                                              : pick_tile(d->M, d->N, d->batch, d->tile);
   p.tilesM = cdiv(d->M, t); p.tilesN = cdiv(d->N, t);
   const long long ntiles = (long long)p.tilesM * p.tilesN;
   DPOT_REQUIRE(ntiles < (1ll << 31) && (long long)d->batch * splits <= 65535, "gemm: grid too large");
   dim3 grid((unsigned)ntiles, 1, (unsigned)(d->batch * splits));
   hipStream_t s = as_stream(stream);
-  if (d->precision == DPOT_GEMM_BF16X6) {
+  if (precision == DPOT_GEMM_BF16X6) {
     if (t == 128) {
       if (vec) launch_gemm_split<128, true>(d, p, grid, s); else launch_gemm_split<128, false>(d, p, grid, s);
     } else {

@@ -20,14 +20,16 @@ Tensor = torch.Tensor
 ACT_IDS = {None: 0, "none": 0, "gelu": 1, "tanh": 2, "sigmoid": 3, "relu": 4, "leaky_relu": 5, "softplus": 6,
            "ELU": 7, "silu": 8}
 EPI_LINEAR, EPI_ACT, EPI_DACT = 0, 1, 2
-GEMM_F32, GEMM_BF16X6 = 0, 1
-_PRECISIONS = {"f32": GEMM_F32, "bf16x6": GEMM_BF16X6}
-# how every GEMM forms its fp32 products (include/dpot_hip.h: dpot_gemm_desc.precision); DPOT_GEMM_PRECISION=f32|bf16x6
+GEMM_F32, GEMM_BF16X6, GEMM_AUTO = 0, 1, 2
+_PRECISIONS = {"f32": GEMM_F32, "bf16x6": GEMM_BF16X6, "auto": GEMM_AUTO}
+# how every GEMM forms its fp32 products (include/dpot_hip.h: dpot_gemm_desc.precision);
+# DPOT_GEMM_PRECISION = f32 | bf16x6 | auto
 _gemm_precision = _PRECISIONS[os.environ.get("DPOT_GEMM_PRECISION", "f32")]
 
 
 def set_gemm_precision(name: str) -> None:
-    """'f32' = native fp32 MFMA, 'bf16x6' = fp32 emulated by 3-way bf16 operand splitting (fp32-level accuracy)"""
+    """'f32' = native fp32 MFMA, 'bf16x6' = fp32 emulated by 3-way bf16 operand splitting (fp32-level accuracy),
+    'auto' = per shape, whichever of the two is faster (the library's rule)"""
     global _gemm_precision
     _gemm_precision = _PRECISIONS[name]
 

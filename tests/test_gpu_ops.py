@@ -321,3 +321,82 @@ def test_sumsq_adam_noise(ops):
     got = ops.noise_inject(xx.cuda(), epsn.cuda(), 0.05)
     ref = xx + 0.05 * torch.sum(xx ** 2, dim=(1, 2, 3), keepdim=True) ** 0.5 * epsn
     assert_close(got, ref, "noise inject")
+
+
+# ------------------------------------------------------------------------------------------------------
+# bf16x6: the same fp32 GEMM computed on the bf16 matrix cores by 3-way operand splitting (csrc/gemm_split.h)
+# ------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("transA,transB", [(False, True), (False, False), (True, False), (True, True)])
+@pytest.mark.parametrize("M,N,K,tile", [(256, 256, 128, 0), (100, 35, 77, 0), (130, 260, 36, 128), (1000, 384, 520, 128),
+                                        (257, 129, 64, 64)])
+def test_gemm_bf16x6_layouts(ops, transA, transB, M, N, K, tile):
+    A, B = rnd(K, M, seed=1) if transA else rnd(M, K, seed=1), rnd(N, K, seed=2) if transB else rnd(K, N, seed=2)
+    C = torch.full((M, N), float("nan"), device="cuda")
+    ops.gemm(A.cuda(), B.cuda(), C, M, N, K, transA=transA, transB=transB, lda=A.shape[1], ldb=B.shape[1], ldc=N,
+             tile=tile, precision=ops.GEMM_BF16X6)
+    ref = (A.double().t() if transA else A.double()) @ (B.double().t() if transB else B.double())
+    assert_close(C, ref, f"bf16x6 {M}x{N}x{K} tA={transA} tB={transB}")
+
+
+def test_gemm_bf16x6_is_fp32_accurate(ops):
+    """the split GEMM must be as close to the exact (fp64) product as the native fp32 MFMA GEMM is - that is what
+    makes it an fp32 GEMM and not a reduced-precision one.  Wide dynamic range on purpose (1e-3 .. 1e3 magnitudes)."""
+    g = torch.Generator().manual_seed(5)
+    for (M, N, K) in [(512, 512, 512), (1024, 256, 4096), (384, 640, 96)]:
+        A = torch.randn(M, K, generator=g) * torch.logspace(-3, 3, K)[None, :]
+        B = torch.randn(N, K, generator=g) * torch.logspace(2, -2, K)[None, :]
+        ref = A.double() @ B.double().t()
+        errs = {}
+        for name, prec in (("f32", ops.GEMM_F32), ("bf16x6", ops.GEMM_BF16X6)):
+            C = torch.empty(M, N, device="cuda")
+            ops.gemm(A.cuda(), B.cuda(), C, M, N, K, transB=True, lda=K, ldb=K, ldc=N, precision=prec)
+            errs[name] = ((C.cpu().double() - ref).abs().max() / ref.abs().max()).item()
+        assert errs["bf16x6"] <= 1.5 * errs["f32"] + 1e-7, errs
+        assert errs["bf16x6"] < 5e-6, errs
+
+
+def test_gemm_bf16x6_epilogue_splitk_colsum(ops):
+    M, N, K = 300, 200, 4100                                  # wgrad pattern with a partial last K-slab
+    dy, x = rnd(K, M, seed=1), rnd(K, N, seed=2)
+    for splitk in (1, 7):
+        dW = torch.full((M, N), float("nan"), device="cuda")
+        db = torch.full((M,), float("nan"), device="cuda")
+        ops.gemm(dy.cuda(), x.cuda(), dW, M, N, K, transA=True, lda=M, ldb=N, ldc=N, splitk=splitk, colsum_out=db,
+                 colsum_of=1, precision=ops.GEMM_BF16X6, tile=128)
+        assert_close(dW, dy.double().t() @ x.double(), f"bf16x6 wgrad sk{splitk}")
+        assert_close(db, dy.double().sum(0), f"bf16x6 fused bias grad sk{splitk}")
+    # fused bias + GELU + saved pre-activation epilogue, batched / strided like the AFNO mixer
+    nb, bs, Mm = 4, 24, 300
+    E2 = 2 * bs * nb
+    S, Wb, bb = rnd(Mm, E2, seed=1), rnd(nb, 2 * bs, 2 * bs, seed=2, scale=0.2), rnd(nb, 2 * bs, seed=3)
+    O = torch.full((Mm, E2), float("nan"), device="cuda")
+    Opre = torch.empty_like(O)
+    ops.gemm(S.cuda(), Wb.cuda(), O, Mm, 2 * bs, 2 * bs, bias=bb.cuda(), strideBias=2 * bs, act=1, mode=ops.EPI_ACT,
+             preact=Opre, ldpre=E2, stridePre=2 * bs, lda=E2, ldb=2 * bs, ldc=E2, batch=nb, strideA=2 * bs,
+             strideB=4 * bs * bs, strideC=2 * bs, precision=ops.GEMM_BF16X6)
+    ref = torch.einsum("mki,kio->mko", S.double().view(Mm, nb, 2 * bs), Wb.double()) + bb.double()
+    assert_close(Opre, ref.reshape(Mm, E2), "bf16x6 batched preact")
+    assert_close(O, torch.nn.functional.gelu(ref).reshape(Mm, E2), "bf16x6 batched gelu")
+
+
+def test_model_step_gemm_auto_matches_f32(ops):
+    """whole DPOT-Tiny fwd+bwd with precision 'auto' (large GEMMs on bf16x6) against the native-fp32 run"""
+    from dpot_amd import DPOTNet
+    from oracle import dpot_ref as R
+    cfg = R.DPOTConfig(**R.TINY)
+    sd = R.recipe_state_dict(cfg)
+    x = R.recipe_input((4, 128, 128, 10, 4)).cuda()
+    outs = {}
+    try:
+        for prec in ("f32", "auto"):
+            ops.set_gemm_precision(prec)
+            m = DPOTNet(**R.TINY).cuda()
+            m.load_state_dict(sd)
+            pred, _ = m(x)
+            pred.square().sum().backward()
+            outs[prec] = (pred.detach(), {k: p.grad.clone() for k, p in m.named_parameters() if p.grad is not None})
+    finally:
+        ops.set_gemm_precision("f32")
+    assert_close(outs["auto"][0], outs["f32"][0].cpu(), "pred auto vs f32")
+    for k, g in outs["f32"][1].items():
+        assert_close(outs["auto"][1][k], g.cpu(), f"grad {k} auto vs f32")
