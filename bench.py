@@ -318,7 +318,9 @@ class _GraphedFwdBwd:
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
         self.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph):
+        # thread_local: the RCCL watchdog thread of the process group may touch the HIP runtime while this thread is
+        # capturing; only this thread's calls may invalidate the capture
+        with torch.cuda.graph(self.graph, capture_error_mode="thread_local"):
             self.loss = body()
 
     def replay(self):
