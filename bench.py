@@ -45,7 +45,8 @@ def parse():
     ap.add_argument("--overlap", action="store_true",
                     help="N>1: eager step with bucketed all-reduce overlapped with backward (default: graph replay of "
                          "fwd+bwd, then bucketed all-reduce, then fused Adam)")
-    ap.add_argument("--noise-scale", type=float, default=0.0)
+    ap.add_argument("--noise-scale", type=float, default=0.0005,
+                    help="train_temporal.py:205 noise injection (configs/pretrain_tiny.yaml:71 uses 0.0005)")
     ap.add_argument("--skip-cpu-baseline", action="store_true")
     ap.add_argument("--gemm-precision", default=os.environ.get("DPOT_GEMM_PRECISION", "f32"),
                     choices=("f32", "bf16x6", "auto"),
@@ -288,6 +289,29 @@ def main():
                 log(f"[bench] gemm_auto timing failed: {e}")
             finally:
                 ops.set_gemm_precision(args.gemm_precision)
+        if world == 1:
+            # forward-only (inference) rate of the same batch, SURVEY 8(d): no_grad forward, hipGraph replay
+            try:
+                with torch.no_grad():
+                    for _ in range(2):
+                        model(xx)
+                    torch.cuda.synchronize()
+                    gi = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(gi):
+                        pred_i, _ = model(xx)
+                    for _ in range(args.warmup):
+                        gi.replay()
+                    torch.cuda.synchronize()
+                    t2 = time.perf_counter()
+                    for _ in range(args.steps):
+                        gi.replay()
+                    torch.cuda.synchronize()
+                    e3 = time.perf_counter() - t2
+                out["inference"] = {"value": round(B * args.steps / e3, 2), "unit": "samples/s",
+                                    "ms_per_batch": round(e3 / args.steps * 1e3, 4),
+                                    "what": "DPOTNet forward only (no_grad), batch %d, hipGraph replay" % B}
+            except Exception as e:                             # pragma: no cover
+                log(f"[bench] inference timing failed: {e}")
         if world == 1 and not args.skip_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.cpu_seconds)
             out["speedup_vs_cpu_baseline"] = round(value / out["cpu_baseline"]["value"], 1)

@@ -175,36 +175,126 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
 }
 
 // ---- noise injection ----------------------------------------------------------------------------------------
-__global__ __launch_bounds__(1024) void chan_norm_kernel(const float* __restrict__ x, float* __restrict__ norms, int S,
-                                                         int C) {
-  __shared__ double red[1024];
-  const int b = blockIdx.x;
-  const ChanLayout L = chan_layout(C, 1024);
+// grid (NCH, B): sum of squares per channel over one chunk of the (X,Y,T) axis of sample b -> part[b][chunk][c].
+// rng (may be NULL) = {seed, offset} of the fused-noise path: block (0,0) advances the offset here, one kernel
+// BEFORE the kernel that draws from it, so that every block of that kernel sees the same new value.
+__global__ __launch_bounds__(256) void chan_sumsq_part_kernel(const float* __restrict__ x, float* __restrict__ part,
+                                                              int S, int C, int nch,
+                                                              unsigned long long* __restrict__ rng) {
+  __shared__ float red[256 * 4];
+  const int b = blockIdx.y, ch = blockIdx.x;
+  if (rng && b == 0 && ch == 0 && threadIdx.x == 0) rng[1] += 1ull;
+  const int per = (S + nch - 1) / nch;
+  const int s0 = ch * per, s1 = min(S, s0 + per);
+  const float* xb = x + (long long)b * S * C;
+  if (C == 4 && (((uintptr_t)xb) & 15u) == 0) {   // the DPOT case: one float4 = the 4 channels of a grid point
+    float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int s = s0 + threadIdx.x; s < s1; s += 256) {
+      const float4 v = reinterpret_cast<const float4*>(xb)[s];
+      a.x = fmaf(v.x, v.x, a.x); a.y = fmaf(v.y, v.y, a.y); a.z = fmaf(v.z, v.z, a.z); a.w = fmaf(v.w, v.w, a.w);
+    }
+    red[threadIdx.x * 4 + 0] = a.x; red[threadIdx.x * 4 + 1] = a.y;
+    red[threadIdx.x * 4 + 2] = a.z; red[threadIdx.x * 4 + 3] = a.w;
+    __syncthreads();
+    if (threadIdx.x < 4) {
+      double t = 0.0;
+      for (int r = 0; r < 256; ++r) t += (double)red[r * 4 + threadIdx.x];   // fixed order
+      part[((long long)b * nch + ch) * 4 + threadIdx.x] = (float)t;
+    }
+    return;
+  }
+  const ChanLayout L = chan_layout(C, 256);
   const int tc = threadIdx.x % L.CP, ts = threadIdx.x / L.CP;
-  double s2 = 0.0;
+  float s2 = 0.f;
   if (tc < C) {
-    const float* xb = x + (long long)b * S * C;
-    for (int s = ts; s < S; s += L.TS) {
+    for (int s = s0 + ts; s < s1; s += L.TS) {
       const float v = xb[(long long)s * C + tc];
-      s2 += (double)v * v;
+      s2 = fmaf(v, v, s2);
     }
   }
   red[threadIdx.x] = s2;
   __syncthreads();
   if (ts == 0 && tc < C) {
     double a = 0.0;
-    for (int r = 0; r < L.TS; ++r) a += red[r * L.CP + tc];
-    norms[(long long)b * C + tc] = sqrtf((float)a);
+    for (int r = 0; r < L.TS; ++r) a += (double)red[r * L.CP + tc];      // fixed order
+    part[((long long)b * nch + ch) * C + tc] = (float)a;
   }
 }
-__global__ void noise_axpy_kernel(const float* __restrict__ x, const float* __restrict__ eps,
-                                  const float* __restrict__ norms, float* __restrict__ out, float noise_scale, int S,
-                                  int C, long long total) {
-  for (long long idx = blockIdx.x * 256ll + threadIdx.x; idx < total; idx += (long long)gridDim.x * 256) {
-    const int c = (int)(idx % C);
-    const long long b = idx / ((long long)S * C);
-    out[idx] = fmaf(noise_scale * norms[b * C + c], eps[idx], x[idx]);
+
+// Philox4x32-10 counter-based generator (Salmon et al., SC'11) + Box-Muller: 4 standard normals per call
+__device__ __forceinline__ float4 philox_normal4(unsigned long long seed, unsigned long long offset,
+                                                 unsigned long long index) {
+  unsigned c0 = (unsigned)index, c1 = (unsigned)(index >> 32), c2 = (unsigned)offset, c3 = (unsigned)(offset >> 32);
+  unsigned k0 = (unsigned)seed, k1 = (unsigned)(seed >> 32);
+#pragma unroll
+  for (int r = 0; r < 10; ++r) {
+    const unsigned hi0 = __umulhi(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
+    const unsigned hi1 = __umulhi(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
+    c0 = hi1 ^ c1 ^ k0; c1 = lo1; c2 = hi0 ^ c3 ^ k1; c3 = lo0;
+    k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
   }
+  const float s = 2.3283064365386963e-10f;              // 2^-32
+  const float u0 = fmaf((float)c0, s, 0.5f * s), u1 = (float)c1 * s;
+  const float u2 = fmaf((float)c2, s, 0.5f * s), u3 = (float)c3 * s;
+  const float r0 = sqrtf(-2.f * __logf(u0)), r1 = sqrtf(-2.f * __logf(u2));
+  float s0, q0, s1, q1;
+  __sincosf(6.283185307179586f * u1, &s0, &q0);
+  __sincosf(6.283185307179586f * u3, &s1, &q1);
+  return make_float4(r0 * q0, r0 * s0, r1 * q1, r1 * s1);
+}
+
+// grid (G, B): norms[b][c] = sqrt(sum_chunks part) (fixed order), out = x + noise_scale * norm[c] * eps
+__global__ __launch_bounds__(256) void noise_axpy_kernel(const float* __restrict__ x, const float* __restrict__ eps,
+                                                         const float* __restrict__ part, float* __restrict__ norms,
+                                                         float* __restrict__ out, float noise_scale, int S, int C,
+                                                         int nch, const unsigned long long* __restrict__ rng) {
+  extern __shared__ float snorm[];
+  const int b = blockIdx.y;
+  for (int c = threadIdx.x; c < C; c += 256) {
+    double a = 0.0;
+    for (int k = 0; k < nch; ++k) a += (double)part[((long long)b * nch + k) * C + c];
+    const float n = sqrtf((float)a);
+    snorm[c] = noise_scale * n;
+    if (blockIdx.x == 0) norms[(long long)b * C + c] = n;
+  }
+  __syncthreads();
+  const long long n = (long long)S * C;
+  const float* xb = x + b * n;
+  float* ob = out + b * n;
+  if (eps == nullptr) {   // fused generator: no eps tensor is ever written or read (host guarantees n % 4 == 0, 16-B)
+    const unsigned long long seed = rng[0], offset = rng[1];
+    for (long long q = blockIdx.x * 256ll + threadIdx.x; q < n / 4; q += (long long)gridDim.x * 256) {
+      const float4 xv = reinterpret_cast<const float4*>(xb)[q];
+      const float4 ev = philox_normal4(seed, offset, (unsigned long long)b * (unsigned long long)(n / 4) + q);
+      const int c0 = (int)((q * 4) % C);
+      float4 o;
+      o.x = fmaf(snorm[c0], ev.x, xv.x);
+      o.y = fmaf(snorm[(c0 + 1) % C], ev.y, xv.y);
+      o.z = fmaf(snorm[(c0 + 2) % C], ev.z, xv.z);
+      o.w = fmaf(snorm[(c0 + 3) % C], ev.w, xv.w);
+      reinterpret_cast<float4*>(ob)[q] = o;
+    }
+    return;
+  }
+  const float* eb = eps + b * n;
+  if ((C & 3) == 0 || C == 1 || C == 2 || C == 4) {
+    if ((n & 3) == 0 && (C == 1 || C == 2 || (C & 3) == 0) && (((uintptr_t)xb | (uintptr_t)eb | (uintptr_t)ob) & 15u) == 0) {
+      for (long long q = blockIdx.x * 256ll + threadIdx.x; q < n / 4; q += (long long)gridDim.x * 256) {
+        const float4 xv = reinterpret_cast<const float4*>(xb)[q];
+        const float4 ev = reinterpret_cast<const float4*>(eb)[q];
+        const int c0 = (int)((q * 4) % C);
+        float4 o;
+        o.x = fmaf(snorm[c0], ev.x, xv.x);
+        o.y = fmaf(snorm[(c0 + 1) % C], ev.y, xv.y);
+        o.z = fmaf(snorm[(c0 + 2) % C], ev.z, xv.z);
+        o.w = fmaf(snorm[(c0 + 3) % C], ev.w, xv.w);
+        reinterpret_cast<float4*>(ob)[q] = o;
+      }
+      return;
+    }
+  }
+  for (long long idx = blockIdx.x * 256ll + threadIdx.x; idx < n; idx += (long long)gridDim.x * 256)
+    ob[idx] = fmaf(snorm[(int)(idx % C)], eb[idx], xb[idx]);
 }
 
 static inline unsigned grid_for(long long n, int cap = 4096) {
@@ -269,14 +359,41 @@ extern "C" int dpot_adam_step(float* p, const float* g, float* m, float* v, int6
   return check_launch("adam_kernel");
 }
 
+extern "C" int dpot_noise_chunks(int S, int C) {
+  long long n = ((long long)S * C + 8191) / 8192;
+  if (n > 64) n = 64;
+  if (n < 1) n = 1;
+  return (int)n;
+}
+
+static int noise_launch(const float* xx, const float* eps, float* out, float* norms, unsigned long long* rng,
+                        float noise_scale, int B, int S, int C, dpot_stream_t stream) {
+  const int nch = dpot_noise_chunks(S, C);
+  float* part = norms + (size_t)B * C;
+  hipLaunchKernelGGL(chan_sumsq_part_kernel, dim3(nch, B), dim3(256), 0, as_stream(stream), xx, part, S, C, nch, rng);
+  int rc = check_launch("chan_sumsq_part_kernel");
+  if (rc) return rc;
+  long long g = ((long long)S * C / 4 + 255) / 256;
+  if (g > 128) g = 128;
+  if (g < 1) g = 1;
+  hipLaunchKernelGGL(noise_axpy_kernel, dim3((unsigned)g, B), dim3(256), C * sizeof(float), as_stream(stream), xx, eps,
+                     (const float*)part, norms, out, noise_scale, S, C, nch, (const unsigned long long*)rng);
+  return check_launch("noise_axpy_kernel");
+}
+
 extern "C" int dpot_noise_inject(const float* xx, const float* eps, float* out, float* norms, float noise_scale,
                                  int B, int S, int C, dpot_stream_t stream) {
   DPOT_REQUIRE(xx && eps && out && norms && B > 0 && S > 0 && C > 0 && C <= 1024, "noise_inject: bad argument");
-  hipLaunchKernelGGL(chan_norm_kernel, dim3(B), dim3(1024), 0, as_stream(stream), xx, norms, S, C);
-  int rc = check_launch("chan_norm_kernel");
-  if (rc) return rc;
-  const long long total = (long long)B * S * C;
-  hipLaunchKernelGGL(noise_axpy_kernel, dim3(grid_for(total)), dim3(256), 0, as_stream(stream), xx, eps,
-                     (const float*)norms, out, noise_scale, S, C, total);
-  return check_launch("noise_axpy_kernel");
+  DPOT_REQUIRE(B <= 65535, "noise_inject: batch too large");
+  return noise_launch(xx, eps, out, norms, nullptr, noise_scale, B, S, C, stream);
+}
+
+extern "C" int dpot_noise_inject_rng(const float* xx, float* out, float* norms, uint64_t* rng_state, float noise_scale,
+                                     int B, int S, int C, dpot_stream_t stream) {
+  DPOT_REQUIRE(xx && out && norms && rng_state && B > 0 && S > 0 && C > 0 && C <= 1024, "noise_inject_rng: bad argument");
+  DPOT_REQUIRE(B <= 65535, "noise_inject_rng: batch too large");
+  DPOT_REQUIRE(((long long)S * C) % 4 == 0 && aligned16(xx) && aligned16(out),
+               "noise_inject_rng: needs S*C %% 4 == 0 and 16-byte aligned fields");
+  return noise_launch(xx, nullptr, out, norms, reinterpret_cast<unsigned long long*>(rng_state), noise_scale, B, S, C,
+                      stream);
 }

@@ -391,11 +391,29 @@ def adam_step(p: Tensor, g: Tensor, m: Tensor, v: Tensor, hyper: Tensor, sumsq_:
                                      hyper.data_ptr(), _p(sumsq_), grad_scale, _stream()), "adam_step")
 
 
-def noise_inject(xx: Tensor, eps: Tensor, noise_scale: float) -> Tensor:
+_rng_states = {}
+
+
+def rng_state(device) -> Tensor:
+    """{seed, offset} of the in-kernel noise generator of `device` (int64[2]); seeded from torch.initial_seed()"""
+    key = torch.device(device).index or 0
+    if key not in _rng_states:
+        _rng_states[key] = torch.tensor([torch.initial_seed() & 0x7FFFFFFFFFFFFFFF, 0], dtype=torch.int64,
+                                        device=device)
+    return _rng_states[key]
+
+
+def noise_inject(xx: Tensor, eps: Optional[Tensor], noise_scale: float) -> Tensor:
+    """xx + noise_scale * ||xx||_(X,Y,T) * eps;  eps=None: eps ~ N(0,1) is drawn inside the kernel"""
     B, Cc = xx.shape[0], xx.shape[-1]
     S = xx.numel() // (B * Cc)
     out = torch.empty_like(xx)
-    norms = torch.empty(B, Cc, dtype=torch.float32, device=xx.device)
-    check(_lib.load().dpot_noise_inject(xx.data_ptr(), eps.data_ptr(), out.data_ptr(), norms.data_ptr(), noise_scale,
+    lib = _lib.load()
+    norms = torch.empty(B * Cc * (1 + lib.dpot_noise_chunks(S, Cc)), dtype=torch.float32, device=xx.device)
+    if eps is None:
+        check(lib.dpot_noise_inject_rng(xx.data_ptr(), out.data_ptr(), norms.data_ptr(), rng_state(xx.device).data_ptr(),
+                                        noise_scale, B, S, Cc, _stream()), "noise_inject_rng")
+        return out
+    check(lib.dpot_noise_inject(xx.data_ptr(), eps.data_ptr(), out.data_ptr(), norms.data_ptr(), noise_scale,
                                         B, S, Cc, _stream()), "noise_inject")
     return out

@@ -168,8 +168,12 @@ def rollout(model: nn.Module, xx: Tensor, yy: Tensor, msk: Optional[Tensor], T_b
     for k, t in enumerate(range(0, T_ar, T_bundle)):
         y = yy[..., t:t + T_bundle, :]
         if noise_scale != 0.0:
-            eps = noise[k] if noise is not None else torch.randn_like(xx)
-            xx = _NoiseFn.apply(xx, eps, noise_scale)
+            if noise is None and not xx.requires_grad and xx.numel() % 4 == 0:
+                # first AR step of training: nothing to differentiate -> draw the noise inside the kernel
+                xx = ops.noise_inject(ops._req(xx.contiguous(), "xx"), None, noise_scale)
+            else:
+                eps = noise[k] if noise is not None else torch.randn_like(xx)
+                xx = _NoiseFn.apply(xx, eps, noise_scale)
         im, _ = model(xx)
         l = rel_l2_loss(im, y, msk)
         loss = l if loss is None else loss + l

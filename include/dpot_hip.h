@@ -261,9 +261,15 @@ int dpot_adam_step(float* p, const float* g, float* m, float* v, int64_t n, cons
                    const float* sumsq, float grad_scale, dpot_stream_t stream);
 
 /* xx_out = xx + noise_scale * ||xx||_2(over X,Y,T per (b,c)) * eps   (train_temporal.py:205)
- * xx, eps: [B, S, C]; norms: [B, C] scratch */
+ * xx, eps: [B, S, C]; norms: B*C*(1 + dpot_noise_chunks(S, C)) floats - [B, C] norms followed by the chunk partials */
+int dpot_noise_chunks(int S, int C);
 int dpot_noise_inject(const float* xx, const float* eps, float* out, float* norms, float noise_scale, int B,
                       int S, int C, dpot_stream_t stream);
+/* the same with eps ~ N(0,1) drawn inside the kernel (Philox4x32-10 + Box-Muller; no eps tensor in HBM).
+ * rng_state (DEVICE, 2 x uint64) = {seed, offset}; every call advances offset by one on the device, so a captured
+ * hipGraph draws fresh noise on every replay.  Needs S*C % 4 == 0 and 16-byte aligned xx / out. */
+int dpot_noise_inject_rng(const float* xx, float* out, float* norms, uint64_t* rng_state, float noise_scale, int B,
+                          int S, int C, dpot_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -400,3 +400,27 @@ def test_model_step_gemm_auto_matches_f32(ops):
     assert_close(outs["auto"][0], outs["f32"][0].cpu(), "pred auto vs f32")
     for k, g in outs["f32"][1].items():
         assert_close(outs["auto"][1][k], g.cpu(), f"grad {k} auto vs f32")
+
+
+def test_noise_inject_in_kernel_generator(ops):
+    """eps drawn inside the kernel (Philox4x32-10 + Box-Muller): right scale per (b,c), N(0,1) statistics, a fresh
+    draw per call (the device-side offset advances), reproducible from the same {seed, offset}"""
+    B, X, T, C = 3, 32, 10, 4
+    xx = (rnd(B, X, X, T, C, seed=3) * torch.tensor([1.0, 5.0, 0.2, 2.0])).cuda()
+    st = ops.rng_state(xx.device)
+    st.copy_(torch.tensor([1234, 0], device=st.device))
+    s = 0.05
+    o1 = ops.noise_inject(xx, None, s)
+    assert int(st[1].item()) == 1
+    o2 = ops.noise_inject(xx, None, s)
+    assert int(st[1].item()) == 2
+    st.copy_(torch.tensor([1234, 0], device=st.device))
+    o1b = ops.noise_inject(xx, None, s)
+    assert torch.equal(o1, o1b) and not torch.equal(o1, o2)
+    n = xx.double().pow(2).sum(dim=(1, 2, 3), keepdim=True).sqrt()
+    z = ((o1.double() - xx.double()) / (s * n)).cpu()                  # should be i.i.d. N(0,1)
+    assert abs(z.mean().item()) < 0.02 and abs(z.std().item() - 1.0) < 0.02
+    assert abs((z ** 3).mean().item()) < 0.05 and abs((z ** 4).mean().item() - 3.0) < 0.15
+    for c in range(C):                                                 # per-channel scale
+        assert abs(z[..., c].std().item() - 1.0) < 0.03
+    assert abs(torch.corrcoef(torch.stack([z.flatten()[:-1], z.flatten()[1:]]))[0, 1].item()) < 0.02
