@@ -348,3 +348,29 @@ def test_baseline_configs_forward_vs_oracle(name):
         out, cls = m(x.cuda())
     assert_close(out, ref, f"{name} pred")
     assert_close(cls, ref_cls, f"{name} cls")
+
+
+def test_inference_rollout_vs_oracle_and_graph_replay():
+    """evaluate.py:193-213: no-grad rollout feeding the model its own prediction; eager and hipGraph-replayed"""
+    from dpot_amd.infer import GraphedRollout, rollout_eval
+    m, cfg = build(R.MINI, salt=2)
+    m.eval()
+    B, T_ar = 3, 4
+    S = cfg.img_size
+    xx = R.recipe_input((B, S, S, cfg.in_timesteps, cfg.in_channels), salt=5)
+    yy = R.recipe_input((B, S, S, T_ar, cfg.out_channels), salt=6)
+    msk = torch.ones(B, S, S, 1, cfg.out_channels)
+    msk[1, :, :, :, 2] = 0.0                                            # one masked-out channel
+    sd = R.recipe_state_dict(cfg, salt=2)
+    with torch.no_grad():
+        loss_ref, pred_ref = R.rollout_loss(sd, xx, yy, msk, cfg)
+        full_ref = R.rel_l2_loss(pred_ref, yy, msk)
+    pred, l_steps, l_full = rollout_eval(m, xx.cuda(), yy.cuda(), msk.cuda())
+    assert_close(pred, pred_ref, "rollout pred (4 AR steps)")
+    assert_close(l_steps, loss_ref, "sum of step losses")
+    assert_close(l_full, full_ref, "full-trajectory loss")
+    g = GraphedRollout(m, xx.cuda())
+    pred_g, l_steps_g, l_full_g = g(xx.cuda(), yy.cuda(), msk.cuda())
+    assert torch.equal(pred_g, pred) and torch.equal(l_steps_g, l_steps) and torch.equal(l_full_g, l_full)
+    with pytest.raises(ValueError):
+        g(xx.cuda()[:2], yy.cuda()[:2], msk.cuda()[:2])
