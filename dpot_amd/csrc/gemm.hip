@@ -477,9 +477,12 @@ extern "C" int dpot_gemm_auto_splitk(int M, int N, int K, int batch) {
   const int t = pick_tile(M, N, batch, 0);
   const long long tiles = (long long)cdiv(M, t) * cdiv(N, t) * batch;
   const int ktiles = cdiv(K, BK);
-  if (tiles >= 4 * NUM_CU || ktiles < 8) return 1;
-  long long s = (4 * NUM_CU + tiles - 1) / tiles;   // aim at ~1024 workgroups (4 per CU)
-  const long long smax = ktiles / 4;                // keep >= 4 K-slabs per split
+  static const int per_cu = [] { const char* e = getenv("DPOT_SPLITK_WG_PER_CU"); return e ? atoi(e) : 2; }();
+  static const int min_slabs = [] { const char* e = getenv("DPOT_SPLITK_MIN_SLABS"); return e ? atoi(e) : 4; }();
+  if (tiles >= per_cu * NUM_CU || ktiles < 8) return 1;
+  long long s = (per_cu * NUM_CU + tiles - 1) / tiles;   // aim at ~512 workgroups (2 per CU; measured in the DPOT
+                                                         // step: 4 per CU costs more in workspace traffic + reduction than it gains)
+  const long long smax = ktiles / min_slabs;             // keep >= 4 K-slabs per split
   if (s > smax) s = smax;
   if (s > 512) s = 512;
   return s < 1 ? 1 : (int)s;
