@@ -451,10 +451,12 @@ constexpr int NUM_CU = 256;
 static int pick_tile(int M, int N, int batch, int forced) {
   if (forced == 64 || forced == 128) return forced;
   if (M <= 64 || N <= 64) return 64;
-  // measured (scripts/gemm_bench.py): a 128x128 tile only pays once every CU holds >= 2 workgroups (their barrier
-  // and prologue bubbles overlap); below that the 64x64 tile (4+ co-resident workgroups per CU) is faster
+  // measured in the whole train step of DPOT-Ti/S/M/L (scripts/gpu_configs.py, bench.py): the 64x64 tile (4-5
+  // co-resident workgroups per CU hide each other's barriers, prologues and epilogues) is never slower than the
+  // 128x128 tile for the native fp32 kernel, so auto picks it always; 128 stays available through desc.tile
   const long long t128 = (long long)cdiv(M, 128) * cdiv(N, 128) * batch;
-  return t128 >= 2 * NUM_CU ? 128 : 64;
+  static const int min128 = [] { const char* e = getenv("DPOT_TILE128_MIN_WG"); return e ? atoi(e) : (1 << 30); }();
+  return t128 >= min128 ? 128 : 64;
 }
 
 // bf16x6 path: the 128x128 tile owns 120 KB of LDS (one workgroup per CU) and halves both the operand-split work
