@@ -52,6 +52,7 @@ SIGNATURES = {
     "dpot_rfft2": (c_i, [c_fp, c_fp] + [c_i] * 8 + [c_fp]),
     "dpot_irfft2": (c_i, [c_fp, c_fp, c_fp] + [c_i] * 8 + [c_fp]),
     "dpot_afno_pack": (c_i, [c_fp] * 4 + [c_i, c_i, c_fp]),
+    "dpot_afno_pack_multi": (c_i, [C.POINTER(C.c_void_p)] * 4 + [c_i, c_i, c_i, c_fp]),
     "dpot_afno_unpack_grad": (c_i, [c_fp] * 4 + [c_i, c_i, c_fp]),
     "dpot_groupnorm_fwd": (c_i, [c_fp] * 6 + [c_i] * 4 + [c_f, c_fp]),
     "dpot_groupnorm_bwd": (c_i, [c_fp] * 10 + [c_i] * 4 + [c_fp]),
@@ -62,6 +63,8 @@ SIGNATURES = {
     "dpot_transpose2d": (c_i, [c_fp, c_fp, c_i, c_i, c_i, c_fp]),
     "dpot_colsum_parts": (c_i, [c_i]),
     "dpot_colsum": (c_i, [c_fp, c_i, c_i, c_i, c_fp, c_fp, c_fp]),
+    "dpot_colsum_scatter": (c_i, [c_fp, c_i, c_i, c_i, c_fp, c_i, C.POINTER(C.c_int), C.POINTER(C.c_int),
+                                  C.POINTER(C.c_void_p), c_fp]),
     "dpot_group_rowsum": (c_i, [c_fp, c_fp] + [c_i] * 4 + [c_fp]),
     "dpot_token_mean": (c_i, [c_fp, c_fp] + [c_i] * 3 + [c_fp]),
     "dpot_token_mean_bwd": (c_i, [c_fp] * 3 + [c_i] * 3 + [c_fp]),

@@ -173,10 +173,29 @@ static int pick_cc(int E, long long floats_per_channel, int tw_floats) {
 }
 
 // AFNO weight packing -------------------------------------------------------------------------------
+__device__ __forceinline__ void afno_pack_one(const float* __restrict__ w, const float* __restrict__ b,
+                                              float* __restrict__ wbig, float* __restrict__ bbig, int nb, int bs,
+                                              long long idx);
 __global__ void afno_pack_kernel(const float* __restrict__ w, const float* __restrict__ b, float* __restrict__ wbig,
                                  float* __restrict__ bbig, int nb, int bs) {
+  afno_pack_one(w, b, wbig, bbig, nb, bs, blockIdx.x * 256ll + threadIdx.x);
+}
+// every (layer, block) weight of a model in one launch: blockIdx.y = job; pointers travel by value
+constexpr int PACK_MAX_JOBS = 64;
+struct PackJobs {
+  const float* w[PACK_MAX_JOBS];
+  const float* b[PACK_MAX_JOBS];
+  float* wbig[PACK_MAX_JOBS];
+  float* bbig[PACK_MAX_JOBS];
+};
+__global__ void afno_pack_multi_kernel(const PackJobs jobs, int nb, int bs) {
+  const int j = blockIdx.y;
+  afno_pack_one(jobs.w[j], jobs.b[j], jobs.wbig[j], jobs.bbig[j], nb, bs, blockIdx.x * 256ll + threadIdx.x);
+}
+__device__ __forceinline__ void afno_pack_one(const float* __restrict__ w, const float* __restrict__ b,
+                                              float* __restrict__ wbig, float* __restrict__ bbig, int nb, int bs,
+                                              long long idx) {
   const long long nW = (long long)nb * 4 * bs * bs;
-  const long long idx = blockIdx.x * 256ll + threadIdx.x;
   if (idx < nW) {
     const int col = (int)(idx % (2 * bs));
     const int row = (int)((idx / (2 * bs)) % (2 * bs));
@@ -288,6 +307,25 @@ extern "C" int dpot_afno_pack(const float* w, const float* b, float* wbig, float
   hipLaunchKernelGGL(afno_pack_kernel, dim3((unsigned)cdiv64(n, 256)), dim3(256), 0, as_stream(stream), w, b, wbig,
                      bbig, nb, bs);
   return check_launch("afno_pack_kernel");
+}
+
+extern "C" int dpot_afno_pack_multi(const float* const* w, const float* const* b, float* const* wbig,
+                                    float* const* bbig, int njobs, int nb, int bs, dpot_stream_t stream) {
+  DPOT_REQUIRE(w && b && wbig && bbig && njobs > 0 && nb > 0 && bs > 0, "afno_pack_multi: bad argument");
+  const long long n = (long long)nb * 4 * bs * bs;
+  for (int j0 = 0; j0 < njobs; j0 += PACK_MAX_JOBS) {
+    const int nj = njobs - j0 < PACK_MAX_JOBS ? njobs - j0 : PACK_MAX_JOBS;
+    PackJobs jobs;
+    for (int j = 0; j < nj; ++j) {
+      DPOT_REQUIRE(w[j0 + j] && b[j0 + j] && wbig[j0 + j] && bbig[j0 + j], "afno_pack_multi: null pointer in job %d", j0 + j);
+      jobs.w[j] = w[j0 + j]; jobs.b[j] = b[j0 + j]; jobs.wbig[j] = wbig[j0 + j]; jobs.bbig[j] = bbig[j0 + j];
+    }
+    hipLaunchKernelGGL(afno_pack_multi_kernel, dim3((unsigned)cdiv64(n, 256), nj), dim3(256), 0, as_stream(stream), jobs,
+                       nb, bs);
+    int rc = check_launch("afno_pack_multi_kernel");
+    if (rc) return rc;
+  }
+  return DPOT_OK;
 }
 
 extern "C" int dpot_afno_unpack_grad(const float* dwbig, const float* dbbig, float* dw, float* db, int nb, int bs,

@@ -355,6 +355,46 @@ extern "C" int dpot_colsum(const float* X, int M, int N, int ld, float* out, flo
   return check_launch("colsum_kernel(stage 2)");
 }
 
+// stage 2 of a column sum whose result goes to several destinations (the partial-row matrix of the fused out-layer tail
+// holds five parameter gradients side by side; their slots in the flat gradient buffer are not adjacent)
+struct ScatterSegs {
+  int n;
+  int start[8], len[8];
+  float* dst[8];
+};
+__global__ __launch_bounds__(256) void colsum_scatter_kernel(const float* __restrict__ part, int parts, int N,
+                                                             const ScatterSegs segs) {
+  const int j = blockIdx.x * 256 + threadIdx.x;
+  if (j >= N) return;
+  float a = 0.f;
+  for (int r = 0; r < parts; ++r) a += part[(long long)r * N + j];      // fixed order
+  for (int s = 0; s < segs.n; ++s)
+    if (j >= segs.start[s] && j < segs.start[s] + segs.len[s]) segs.dst[s][j - segs.start[s]] = a;
+}
+
+extern "C" int dpot_colsum_scatter(const float* X, int M, int N, int ld, float* part, int nseg, const int* seg_start,
+                                   const int* seg_len, float* const* seg_dst, dpot_stream_t stream) {
+  DPOT_REQUIRE(X && part && M > 0 && N > 0 && ld >= N && nseg > 0 && nseg <= 8 && seg_start && seg_len && seg_dst,
+               "colsum_scatter: bad argument");
+  ScatterSegs segs;
+  segs.n = nseg;
+  for (int s = 0; s < nseg; ++s) {
+    DPOT_REQUIRE(seg_start[s] >= 0 && seg_len[s] > 0 && seg_start[s] + seg_len[s] <= N && seg_dst[s],
+                 "colsum_scatter: bad segment %d", s);
+    segs.start[s] = seg_start[s]; segs.len[s] = seg_len[s]; segs.dst[s] = seg_dst[s];
+  }
+  int parts = dpot_colsum_parts(M);
+  const int want = cdiv(1024, cdiv(N, N <= 16 ? 16 : N <= 32 ? 32 : 64));
+  if (parts > want) parts = want;
+  if (parts < 1) parts = 1;
+  launch_colsum(X, M, N, ld, part, parts, as_stream(stream));
+  int rc = check_launch("colsum_kernel");
+  if (rc) return rc;
+  hipLaunchKernelGGL(colsum_scatter_kernel, dim3(cdiv(N, 256)), dim3(256), 0, as_stream(stream), (const float*)part,
+                     parts, N, segs);
+  return check_launch("colsum_scatter_kernel");
+}
+
 extern "C" int dpot_group_rowsum(const float* X, float* out, int B, int R, int T, int N, dpot_stream_t stream) {
   DPOT_REQUIRE(X && out && B > 0 && R > 0 && T > 0 && N > 0 && R <= 65535, "group_rowsum: bad argument");
   hipLaunchKernelGGL(group_rowsum_kernel, dim3(cdiv(N, 64), R), dim3(256), 0, as_stream(stream), X, out, B, R, T, N);

@@ -172,7 +172,7 @@ class BlockFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, n1w, n1b, w1, b1, w2, b2, n2w, n2b, f1w, f1b, f2w, f2b, h: int, w: int, nb: int, modes: int,
-                act: int):
+                act: int, packed=None):
         x = x.contiguous()
         B, tok, E = x.shape
         bs = E // nb
@@ -184,8 +184,11 @@ class BlockFn(torch.autograd.Function):
 
         xn1, mean1, rstd1 = ops.groupnorm_fwd(x, n1w, n1b)
         S = ops.rfft2(xn1, h, w, nb, mx, my, 0)                                # [Mm, 2E]
-        wb1, bb1 = ops.afno_pack(w1, b1)
-        wb2, bb2 = ops.afno_pack(w2, b2)
+        if packed is not None:      # ((Wbig1, bbig1), (Wbig2, bbig2)) packed for all blocks at once by the model
+            (wb1, bb1), (wb2, bb2) = packed
+        else:
+            wb1, bb1 = ops.afno_pack(w1, b1)
+            wb2, bb2 = ops.afno_pack(w2, b2)
         O1 = torch.empty(Mm, 2 * E, dtype=torch.float32, device=dev)
         O1pre = torch.empty_like(O1)
         kw = dict(lda=2 * E, ldb=2 * bs, ldc=2 * E, batch=nb, strideA=2 * bs, strideB=4 * bs * bs, strideC=2 * bs,
@@ -256,7 +259,8 @@ class BlockFn(torch.autograd.Function):
                                            out_dbeta=s_n1b.out())
         dn1w, dn1b = s_n1w.done(dn1w), s_n1b.done(dn1b)
         streams.join(dev)      # the side stream's readers of this frame's tensors are done before they can be freed
-        return (dx, dn1w, dn1b, dw1, db1, dw2, db2, dn2w, dn2b, df1w, df1b, df2w, df2b, None, None, None, None, None)
+        return (dx, dn1w, dn1b, dw1, db1, dw2, db2, dn2w, dn2b, df1w, df1b, df2w, df2b, None, None, None, None, None,
+                None)
 
 
 # ======================================================================================================
@@ -321,12 +325,13 @@ class HeadFn(torch.autograd.Function):
         if dpred is not None:
             # ---- out layer
             if ctx.fused:
-                dUpre, pv = ops.out_tail_bwd(Upre, dpred.contiguous(), o2w, o2b, V, B, h, w, P, co, act)
-                do2w = s_o2w.done(pv[0:1024].view(old, old, 1, 1))
-                do4w = s_o4w.done(pv[1024:1024 + co * old].view(co, old, 1, 1))
-                do2b = s_o2b.done(pv[2048:2048 + old])
-                do0b = s_o0b.done(pv[2080:2080 + old])
-                do4b = s_o4b.done(pv[2112:2112 + co])
+                # the five small parameter gradients leave the partial-row reduction straight into their slots
+                dUpre, (g2w, g4w, g2b, g0b, g4b) = ops.out_tail_bwd(
+                    Upre, dpred.contiguous(), o2w, o2b, V, B, h, w, P, co, act,
+                    outs=(s_o2w.out(), s_o4w.out(), s_o2b.out(), s_o0b.out(), s_o4b.out()))
+                do2w = s_o2w.done(g2w.view(old, old, 1, 1))
+                do4w = s_o4w.done(g4w.view(co, old, 1, 1))
+                do2b, do0b, do4b = s_o2b.done(g2b), s_o0b.done(g0b), s_o4b.done(g4b)
             else:
                 dZ = ops.pixel_shuffle(dpred.contiguous(), B, h, w, P, co, inverse=True)  # [Mp, co]
                 dVpre = ops.linear_bwd_data(dZ, o4w2, act=act, aux=Vpre)                  # [Mp, old]

@@ -139,11 +139,16 @@ class DPOTNet(nn.Module):
                             P, self._act)
         if self.normalize:
             lat = s_sigma[:, None, :] * lat + s_mu[:, None, :]          # AdaIN (models/dpot.py:386-387)
-        for blk in self.blocks:
+        # Wbig = [[Wr, Wi], [-Wi, Wr]] of every AFNO layer, packed in ONE launch (2*depth tiny launches otherwise)
+        pk = ops.afno_pack_multi([p for blk in self.blocks for p in ((blk.filter.w1, blk.filter.b1),
+                                                                     (blk.filter.w2, blk.filter.b2))]) \
+            if len(self.blocks) else []
+        for i, blk in enumerate(self.blocks):
             f = blk.filter
             lat = BlockFn.apply(lat, blk.norm1.weight, blk.norm1.bias, f.w1, f.b1, f.w2, f.b2, blk.norm2.weight,
                                 blk.norm2.bias, blk.mlp[0].weight, blk.mlp[0].bias, blk.mlp[2].weight,
-                                blk.mlp[2].bias, h, h, self.n_blocks, self.modes, self._act)
+                                blk.mlp[2].bias, h, h, self.n_blocks, self.modes, self._act,
+                                (pk[2 * i], pk[2 * i + 1]))
         ol, ch = self.out_layer, self.cls_head
         pred, cls_pred = HeadFn.apply(lat, ol[0].weight, ol[0].bias, ol[2].weight, ol[2].bias, ol[4].weight,
                                       ol[4].bias, ch[0].weight, ch[0].bias, ch[2].weight, ch[2].bias, ch[4].weight,

@@ -181,6 +181,22 @@ def afno_pack(w: Tensor, b: Tensor) -> Tuple[Tensor, Tensor]:
     return wbig, bbig
 
 
+def afno_pack_multi(pairs) -> list:
+    """pairs = [(w [2,nb,bs,bs], b [2,nb,bs]), ...] of equal shapes -> [(wbig, bbig), ...], ONE launch for all of them"""
+    n = len(pairs)
+    _, nb, bs, _ = pairs[0][0].shape
+    dev = pairs[0][0].device
+    wbig = torch.empty(n, nb, 2 * bs, 2 * bs, dtype=torch.float32, device=dev)
+    bbig = torch.empty(n, nb, 2 * bs, dtype=torch.float32, device=dev)
+    arr = lambda ptrs: (C.c_void_p * n)(*ptrs)
+    check(_lib.load().dpot_afno_pack_multi(arr([_req(w, "w").data_ptr() for w, _ in pairs]),
+                                           arr([_req(b, "b").data_ptr() for _, b in pairs]),
+                                           arr([wbig[i].data_ptr() for i in range(n)]),
+                                           arr([bbig[i].data_ptr() for i in range(n)]), n, nb, bs, _stream()),
+          "afno_pack_multi")
+    return [(wbig[i], bbig[i]) for i in range(n)]
+
+
 def afno_unpack_grad(dwbig: Tensor, dbbig: Tensor, nb: int, bs: int, out_dw: Optional[Tensor] = None,
                      out_db: Optional[Tensor] = None) -> Tuple[Tensor, Tensor]:
     dw = _out(out_dw, (2, nb, bs, bs), dwbig.device)
@@ -347,16 +363,34 @@ def out_tail_fwd(upre: Tensor, w2: Tensor, b2: Tensor, w4p: Tensor, b4p: Tensor,
     return out
 
 
+def colsum_scatter(X: Tensor, M: int, N: int, segments) -> None:
+    """column sums of X[M,N]; segments = [(first column, tensor)]: each tensor receives its columns (one launch pair)"""
+    lib = _lib.load()
+    n = len(segments)
+    starts = (C.c_int * n)(*[s for s, _ in segments])
+    lens = (C.c_int * n)(*[t.numel() for _, t in segments])
+    dsts = (C.c_void_p * n)(*[t.data_ptr() for _, t in segments])
+    part = torch.empty(lib.dpot_colsum_parts(M) * N, dtype=torch.float32, device=X.device)
+    check(lib.dpot_colsum_scatter(X.data_ptr(), M, N, N, part.data_ptr(), n, starts, lens, dsts, _stream()),
+          "colsum_scatter")
+
+
 def out_tail_bwd(upre: Tensor, dout: Tensor, w2: Tensor, b2: Tensor, w4p: Tensor, B: int, h: int, w: int, P: int,
-                 co: int, act: int) -> Tuple[Tensor, Tensor]:
-    """returns (dupre [pixels,32], reduced partial vector [2144] = dW2 | dW4 | db2 | colsum(dupre) | db4)"""
+                 co: int, act: int, outs=None):
+    """returns (dupre [pixels,32], (dW2 [32,32], dW4 [co,32], db2 [32], colsum(dupre) [32], db4 [co])); `outs`: the five
+    destination tensors (gradient slots) or None entries for fresh ones - all written by one reduction"""
     lib = _lib.load()
     rows, cols = lib.dpot_out_tail_partial_rows(B, h, w, P), lib.dpot_out_tail_partial_cols()
     dupre = torch.empty_like(upre)
     part = torch.empty(rows, cols, dtype=torch.float32, device=upre.device)
     check(lib.dpot_out_tail_bwd(upre.data_ptr(), dout.data_ptr(), w2.data_ptr(), b2.data_ptr(), w4p.data_ptr(),
                                 dupre.data_ptr(), part.data_ptr(), B, h, w, P, co, act, _stream()), "out_tail_bwd")
-    return dupre, colsum(part, rows, cols)
+    shapes = ((32, 32), (co, 32), (32,), (32,), (co,))
+    starts = (0, 1024, 2048, 2080, 2112)
+    outs = list(outs) if outs is not None else [None] * 5
+    res = [_out(o, shp, upre.device) for o, shp in zip(outs, shapes)]
+    colsum_scatter(part, rows, cols, list(zip(starts, res)))
+    return dupre, tuple(res)
 
 
 # ------------------------------------------------------------------------------------------------------

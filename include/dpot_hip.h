@@ -163,6 +163,9 @@ int dpot_irfft2(const float* spec, const float* res, float* y, int B, int h, int
  * and the adjoint (gradients back to the reference layout).  models/dpot.py:45-48,72-94 */
 int dpot_afno_pack(const float* w, const float* b, float* wbig, float* bbig, int nb, int bs,
                    dpot_stream_t stream);
+/* njobs packs in one launch (all AFNO layers of a model): HOST arrays of njobs device pointers each */
+int dpot_afno_pack_multi(const float* const* w, const float* const* b, float* const* wbig, float* const* bbig,
+                         int njobs, int nb, int bs, dpot_stream_t stream);
 int dpot_afno_unpack_grad(const float* dwbig, const float* dbbig, float* dw, float* db, int nb, int bs,
                           dpot_stream_t stream);
 
@@ -199,6 +202,10 @@ int dpot_transpose2d(const float* src, float* dst, int nbatch, int R, int C, dpo
  * with parts = dpot_colsum_parts(M) */
 int dpot_colsum_parts(int M);
 int dpot_colsum(const float* X, int M, int N, int ld, float* out, float* part, dpot_stream_t stream);
+/* the same sums, delivered to up to 8 destinations: columns [seg_start[s], seg_start[s]+seg_len[s]) -> seg_dst[s]
+ * (HOST arrays of nseg entries; seg_dst holds device pointers).  part: dpot_colsum_parts(M) * N floats. */
+int dpot_colsum_scatter(const float* X, int M, int N, int ld, float* part, int nseg, const int* seg_start,
+                        const int* seg_len, float* const* seg_dst, dpot_stream_t stream);
 /* out[r, n] = sum_{b,t} X[((b*R + r)*T + t)*N + n]   (pos_embed gradient: sum over batch and time) */
 int dpot_group_rowsum(const float* X, float* out, int B, int R, int T, int N, dpot_stream_t stream);
 /* y[b,e] = mean_t x[b,t,e]  and its adjoint dx[b,t,e] = dy[b,e]/T (+ add[b,t,e]) */
