@@ -446,6 +446,41 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
   }
 }
 
+// split-K reduction of the AFNO mixer wgrad that also undoes the [[Wr, Wi], [-Wi, Wr]] packing:
+//   dWr = dWbig[0:bs, 0:bs] + dWbig[bs:, bs:],  dWi = dWbig[0:bs, bs:] - dWbig[bs:, 0:bs]   -> dw[2, nb, bs, bs]
+//   db[part, k, c] = colsum partials of the B operand, [nb][2bs] = [re | im]                -> db[2, nb, bs]
+__global__ __launch_bounds__(256) void splitk_reduce_afno_kernel(const float* __restrict__ ws, int splits, int nb,
+                                                                 int bs, float* __restrict__ dw,
+                                                                 float* __restrict__ db) {
+  const int n2 = 2 * bs;
+  const long long MN = (long long)n2 * n2, total = MN * nb;
+  const long long nw = (long long)nb * bs * bs;
+  for (long long idx = blockIdx.x * 256ll + threadIdx.x; idx < nw; idx += (long long)gridDim.x * 256) {
+    const int o = (int)(idx % bs), i = (int)((idx / bs) % bs), k = (int)(idx / ((long long)bs * bs));
+    const float* base = ws + (long long)k * MN;
+    float rr = 0.f, ii = 0.f, ri = 0.f, ir = 0.f;
+    for (int s = 0; s < splits; ++s) {           // fixed order
+      const float* W = base + (long long)s * total;
+      rr += W[(long long)i * n2 + o];
+      ii += W[(long long)(bs + i) * n2 + bs + o];
+      ri += W[(long long)i * n2 + bs + o];
+      ir += W[(long long)(bs + i) * n2 + o];
+    }
+    dw[idx] = rr + ii;
+    dw[nw + idx] = ri - ir;
+  }
+  if (db) {
+    const float* wc = ws + (long long)splits * total;
+    const long long nc = (long long)nb * n2;
+    for (long long idx = blockIdx.x * 256ll + threadIdx.x; idx < nc; idx += (long long)gridDim.x * 256) {
+      float v = 0.f;
+      for (int s = 0; s < splits; ++s) v += wc[(long long)s * nc + idx];
+      const int c = (int)(idx % bs), part = (int)((idx / bs) & 1), k = (int)(idx / n2);
+      db[((long long)part * nb + k) * bs + c] = v;
+    }
+  }
+}
+
 constexpr int NUM_CU = 256;
 
 static int pick_tile(int M, int N, int batch, int forced) {
@@ -544,6 +579,10 @@ extern "C" int dpot_gemm_f32(const dpot_gemm_desc* d, dpot_stream_t stream) {
   DPOT_REQUIRE(d->ldb >= (d->transB ? d->K : d->N), "gemm: ldb=%d too small", d->ldb);
   DPOT_REQUIRE(d->ldc >= d->N, "gemm: ldc=%d too small", d->ldc);
   DPOT_REQUIRE(d->epi_mode != DPOT_EPI_DACT || d->aux != nullptr, "gemm: DACT epilogue needs aux");
+  DPOT_REQUIRE(d->epi_mode != DPOT_EPI_AFNO_WGRAD ||
+                   (d->splitk > 1 && d->M == d->N && d->M % 2 == 0 && !d->bias && !d->res && !d->preact &&
+                    !d->accumulate && (d->colsum_of == 0 || d->colsum_of == 2)),
+               "gemm: the AFNO wgrad epilogue needs split-K, M == N == 2*bs and no other epilogue term");
   const int splits = d->splitk > 1 ? d->splitk : 1;
   DPOT_REQUIRE(splits == 1 || d->workspace != nullptr, "gemm: split-K needs a workspace");
   DPOT_REQUIRE(d->colsum_of == 0 || (d->colsum_out != nullptr && ((d->colsum_of == 1 && d->transA) ||
@@ -603,7 +642,14 @@ extern "C" int dpot_gemm_f32(const dpot_gemm_desc* d, dpot_stream_t stream) {
   }
   int rc = check_launch("gemm_f32_kernel");
   if (rc != DPOT_OK) return rc;
-  if (splits > 1) {
+  if (splits > 1 && d->epi_mode == DPOT_EPI_AFNO_WGRAD) {
+    const int bs = d->M / 2;
+    long long blocks = ((long long)d->batch * bs * bs + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(splitk_reduce_afno_kernel, dim3((unsigned)blocks), dim3(256), 0, s, (const float*)d->workspace,
+                       splits, d->batch, bs, d->C, d->colsum_of ? d->colsum_out : (float*)nullptr);
+    rc = check_launch("splitk_reduce_afno_kernel");
+  } else if (splits > 1) {
     const long long total = (long long)d->M * d->N * d->batch;
     int blocks = (int)((total + 255) / 256);
     if (blocks > 4096) blocks = 4096;

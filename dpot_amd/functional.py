@@ -234,23 +234,20 @@ class BlockFn(torch.autograd.Function):
         # AFNO mixer
         dO2 = ops.rfft2(dy1, h, w, nb, mx, my, 1)                              # adjoint of irfft2
         kw = dict(lda=2 * E, ldb=2 * bs, ldc=2 * E, batch=nb, strideA=2 * bs, strideB=4 * bs * bs, strideC=2 * bs)
-        sk = ops.auto_splitk(2 * bs, 2 * bs, Mm, nb)
+        sk = max(2, ops.auto_splitk(2 * bs, 2 * bs, Mm, nb))
         wkw = dict(transA=True, lda=2 * E, ldb=2 * E, ldc=2 * bs, batch=nb, strideA=2 * bs, strideB=2 * bs,
-                   strideC=4 * bs * bs, splitk=sk)
+                   strideC=4 * bs * bs, splitk=sk, mode=ops.EPI_AFNO_WGRAD)
         with streams.side(dev):
-            dwb2 = torch.empty(nb, 2 * bs, 2 * bs, dtype=torch.float32, device=dev)
-            dbb2 = torch.empty(2 * E, dtype=torch.float32, device=dev)
-            ops.gemm(O1, dO2, dwb2, 2 * bs, 2 * bs, Mm, colsum_out=dbb2, colsum_of=2, strideColsum=2 * bs, **wkw)
-            dw2, db2 = ops.afno_unpack_grad(dwb2, dbb2, nb, bs, out_dw=s_w2.out(), out_db=s_b2.out())
+            # wgrad of Wbig; its split-K reduction writes dw / db in the parameters' own [2, nb, bs, ...] layout
+            dw2, db2 = ops._out(s_w2.out(), (2, nb, bs, bs), dev), ops._out(s_b2.out(), (2, nb, bs), dev)
+            ops.gemm(O1, dO2, dw2, 2 * bs, 2 * bs, Mm, colsum_out=db2, colsum_of=2, **wkw)
             dw2, db2 = s_w2.done(dw2), s_b2.done(db2)
         dO1pre = torch.empty(Mm, 2 * E, dtype=torch.float32, device=dev)
         ops.gemm(dO2, wb2, dO1pre, Mm, 2 * bs, 2 * bs, transB=True, act=act, mode=EPI_DACT, aux=O1pre, ldaux=2 * E,
                  strideAux=2 * bs, **kw)
         with streams.side(dev):
-            dwb1 = torch.empty(nb, 2 * bs, 2 * bs, dtype=torch.float32, device=dev)
-            dbb1 = torch.empty(2 * E, dtype=torch.float32, device=dev)
-            ops.gemm(S, dO1pre, dwb1, 2 * bs, 2 * bs, Mm, colsum_out=dbb1, colsum_of=2, strideColsum=2 * bs, **wkw)
-            dw1, db1 = ops.afno_unpack_grad(dwb1, dbb1, nb, bs, out_dw=s_w1.out(), out_db=s_b1.out())
+            dw1, db1 = ops._out(s_w1.out(), (2, nb, bs, bs), dev), ops._out(s_b1.out(), (2, nb, bs), dev)
+            ops.gemm(S, dO1pre, dw1, 2 * bs, 2 * bs, Mm, colsum_out=db1, colsum_of=2, **wkw)
             dw1, db1 = s_w1.done(dw1), s_b1.done(db1)
         dS = torch.empty(Mm, 2 * E, dtype=torch.float32, device=dev)
         ops.gemm(dO1pre, wb1, dS, Mm, 2 * bs, 2 * bs, transB=True, **kw)

@@ -19,7 +19,7 @@ Tensor = torch.Tensor
 
 ACT_IDS = {None: 0, "none": 0, "gelu": 1, "tanh": 2, "sigmoid": 3, "relu": 4, "leaky_relu": 5, "softplus": 6,
            "ELU": 7, "silu": 8}
-EPI_LINEAR, EPI_ACT, EPI_DACT = 0, 1, 2
+EPI_LINEAR, EPI_ACT, EPI_DACT, EPI_AFNO_WGRAD = 0, 1, 2, 3
 GEMM_F32, GEMM_BF16X6, GEMM_AUTO = 0, 1, 2
 _PRECISIONS = {"f32": GEMM_F32, "bf16x6": GEMM_BF16X6, "auto": GEMM_AUTO}
 # how every GEMM forms its fp32 products (include/dpot_hip.h: dpot_gemm_desc.precision);

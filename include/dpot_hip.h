@@ -56,7 +56,11 @@ enum {
 enum {
   DPOT_EPI_LINEAR = 0, /* v                                  */
   DPOT_EPI_ACT = 1,    /* act(v)                             */
-  DPOT_EPI_DACT = 2    /* v * act'(aux[m,n])  (backward)     */
+  DPOT_EPI_DACT = 2,   /* v * act'(aux[m,n])  (backward)     */
+  /* weight gradient of the AFNO block-diagonal complex MLP (split-K only, M = N = 2*bs, batch = nb): the split-K
+   * reduction also undoes the Wbig = [[Wr, Wi], [-Wi, Wr]] packing - C receives dw[2, nb, bs, bs]
+   * (dWr = TL + BR, dWi = TR - BL of the 2bs x 2bs product) and colsum_out (colsum_of = 2) receives db[2, nb, bs] */
+  DPOT_EPI_AFNO_WGRAD = 3
 };
 
 int dpot_version(void);

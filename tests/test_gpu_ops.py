@@ -402,6 +402,24 @@ def test_model_step_gemm_auto_matches_f32(ops):
         assert_close(outs["auto"][1][k], g.cpu(), f"grad {k} auto vs f32")
 
 
+@pytest.mark.parametrize("precision", [0, 1])
+def test_gemm_afno_wgrad_epilogue(ops, precision):
+    """split-K reduction that un-packs dWbig -> dw[2,nb,bs,bs], db[2,nb,bs] == wgrad GEMM followed by afno_unpack_grad"""
+    nb, bs, Mm = 3, 40, 700
+    E2 = 2 * bs * nb
+    S, dO = rnd(Mm, E2, seed=1), rnd(Mm, E2, seed=4)
+    dw = torch.full((2, nb, bs, bs), float("nan"), device="cuda")
+    db = torch.full((2, nb, bs), float("nan"), device="cuda")
+    ops.gemm(S.cuda(), dO.cuda(), dw, 2 * bs, 2 * bs, Mm, transA=True, lda=E2, ldb=E2, ldc=2 * bs, batch=nb,
+             strideA=2 * bs, strideB=2 * bs, strideC=4 * bs * bs, splitk=5, colsum_out=db, colsum_of=2,
+             mode=ops.EPI_AFNO_WGRAD, precision=precision)
+    dWbig = torch.einsum("mki,mko->kio", S.double().view(Mm, nb, 2 * bs), dO.double().view(Mm, nb, 2 * bs))
+    ref_w = torch.stack([dWbig[:, :bs, :bs] + dWbig[:, bs:, bs:], dWbig[:, :bs, bs:] - dWbig[:, bs:, :bs]])
+    ref_b = dO.double().sum(0).view(nb, 2, bs).permute(1, 0, 2)
+    assert_close(dw, ref_w, "AFNO wgrad un-packed by the split-K reduction")
+    assert_close(db, ref_b, "AFNO bias grad")
+
+
 def test_noise_inject_in_kernel_generator(ops):
     """eps drawn inside the kernel (Philox4x32-10 + Box-Muller): right scale per (b,c), N(0,1) statistics, a fresh
     draw per call (the device-side offset advances), reproducible from the same {seed, offset}"""
