@@ -81,6 +81,14 @@ MINI = dict(img_size=32, patch_size=8, in_channels=3, out_channels=3, in_timeste
             n_blocks=4, embed_dim=64, out_layer_dim=16, depth=2, modes=32, mlp_ratio=1, n_cls=5)
 
 
+# constructor variants pinned by tests/golden/g10_*.npz (oracle/make_golden.py::g10_variant)
+GOLDEN_VARIANTS = {
+    "g10_bundle": dict(MINI, out_timesteps=2, out_channels=2, in_channels=3),
+    "g10_mlpagg": dict(MINI, time_agg="mlp", n_blocks=2, mlp_ratio=2),
+    "g10_leaky_modes1": dict(MINI, act="leaky_relu", modes=1, out_layer_dim=16, n_cls=5),
+}
+
+
 def _act(name: str):
     table = {
         "gelu": lambda v: F.gelu(v),                    # exact erf GELU (nn.GELU() default)

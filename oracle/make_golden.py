@@ -22,6 +22,8 @@ Fixture index:
   g6_rollout         3-step AR rollout train step (loss, grad norms, Adam)     train_temporal.py:189-230
   g7_loss            SimpleLpLoss with a partial mask                          utils/criterion.py:38-59
   g8_dp              2-rank data-parallel equivalence numbers                  train_temporal_parallel.py:243-244
+  g10_*              constructor variants (temporal bundling out_timesteps=2, time_agg='mlp', other activation /
+                     mlp_ratio / block count / 1 kept mode): outputs + subsampled gradients   models/dpot.py:246-326
 """
 from __future__ import annotations
 
@@ -381,6 +383,33 @@ def smoke_reference_main():
     save("g9_refmain", pred=npy(y_ref), cls=npy(c_ref))
 
 
+VARIANTS = R.GOLDEN_VARIANTS
+
+
+def g10_variant(name):
+    cfg = R.DPOTConfig(**VARIANTS[name])
+    sd0 = R.recipe_state_dict(cfg, salt=13)
+    m = ref_model(cfg, sd0)
+    x = R.recipe_input((2, cfg.img_size, cfg.img_size, cfg.in_timesteps, cfg.in_channels), salt=61)
+    xr = x.clone().requires_grad_(True)
+    y_ref, c_ref = m(xr)
+    up_y = R.recipe_input(tuple(y_ref.shape), salt=62) * 0.3
+    up_c = R.recipe_input(tuple(c_ref.shape), salt=63) * 0.3
+    ((y_ref * up_y).sum() + (c_ref * up_c).sum()).backward()
+    sd = leaf_sd(sd0)
+    xo = x.clone().requires_grad_(True)
+    y_o, c_o = R.dpot_forward(sd, xo, cfg)
+    ((y_o * up_y).sum() + (c_o * up_c).sum()).backward()
+    check(name + ".pred", y_o, y_ref)
+    check(name + ".cls", c_o, c_ref)
+    check(name + ".dx", xo.grad, xr.grad, rtol=5e-5)
+    arrays = {}
+    for k, p in m.named_parameters():
+        check(name + ".d" + k, sd[k].grad, p.grad, rtol=1e-4)
+        arrays["d." + k] = sub(p.grad, 5)
+    save(name, pred=npy(y_ref), cls=npy(c_ref), dx=sub(xr.grad, 3), **arrays)
+
+
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
     g1_afno("g1_afno_trunc", B=2, h=16, E=64, nb=4, modes=5, stride=1)
@@ -394,4 +423,6 @@ if __name__ == "__main__":
     g7_loss()
     g8_dp()
     smoke_reference_main()
+    for v in VARIANTS:
+        g10_variant(v)
     print("all fixtures written; oracle == reference on every case")

@@ -184,6 +184,25 @@ def test_full_mini_model_golden(name, normalize):
             assert_close(g[k[2:]], fx[k], k)
 
 
+@pytest.mark.parametrize("name", sorted(R.GOLDEN_VARIANTS))
+def test_constructor_variants_golden(name):
+    """temporal bundling (out_timesteps=2), time_agg='mlp', mlp_ratio / n_blocks / activation / 1 kept mode"""
+    fx = load(name)
+    m, cfg = build(R.GOLDEN_VARIANTS[name], salt=13)
+    x = R.recipe_input((2, cfg.img_size, cfg.img_size, cfg.in_timesteps, cfg.in_channels), salt=61)
+    x = x.cuda().requires_grad_(True)
+    y, c = m(x)
+    assert tuple(y.shape) == (2, cfg.img_size, cfg.img_size, cfg.out_timesteps, cfg.out_channels)
+    up_y = (R.recipe_input(tuple(y.shape), salt=62) * 0.3).cuda()
+    up_c = (R.recipe_input(tuple(c.shape), salt=63) * 0.3).cuda()
+    ((y * up_y).sum() + (c * up_c).sum()).backward()
+    assert_close(y, fx["pred"], "pred")
+    assert_close(c, fx["cls"], "cls")
+    assert_sub(x.grad, fx, "dx", "dx")
+    for k, g in grads_of(m).items():
+        assert_sub(g, fx, "d." + k, "d." + k)
+
+
 def test_reference_main_config_golden():
     fx = load("g9_refmain")
     kw = dict(img_size=20, patch_size=5, in_channels=3, out_channels=3, in_timesteps=6, out_timesteps=1, embed_dim=32,

@@ -92,6 +92,25 @@ def test_full_mini_model_and_grads():
                 assert_close(sd[k[2:]].grad, fx[k], name + "." + k)
 
 
+def test_constructor_variants():
+    """temporal bundling (out_timesteps=2), time_agg='mlp', mlp_ratio / n_blocks / activation / 1 kept mode"""
+    for name, kw in R.GOLDEN_VARIANTS.items():
+        fx = load(name)
+        cfg = R.DPOTConfig(**kw)
+        sd = leaf(R.recipe_state_dict(cfg, salt=13))
+        x = R.recipe_input((2, cfg.img_size, cfg.img_size, cfg.in_timesteps, cfg.in_channels), salt=61)
+        x.requires_grad_(True)
+        y, c = R.dpot_forward(sd, x, cfg)
+        up_y = R.recipe_input(tuple(y.shape), salt=62) * 0.3
+        up_c = R.recipe_input(tuple(c.shape), salt=63) * 0.3
+        ((y * up_y).sum() + (c * up_c).sum()).backward()
+        assert_close(y, fx["pred"], name + ".pred")
+        assert_close(c, fx["cls"], name + ".cls")
+        assert_sub(x.grad, fx, "dx", name + ".dx")
+        for k in sd:
+            assert_sub(sd[k].grad, fx, "d." + k, name + ".d." + k)
+
+
 def test_tiny_forward():
     fx = load("g5_tiny")
     cfg = R.DPOTConfig(**R.TINY)
