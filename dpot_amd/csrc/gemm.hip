@@ -539,7 +539,7 @@ static int resolve_precision(int precision, int M, int N, int K, int batch) {
 
 extern "C" int dpot_gemm_auto_splitk2(int M, int N, int K, int batch, int precision) {
   precision = resolve_precision(precision, M, N, K, batch);
-  if (precision != DPOT_GEMM_BF16X6 || M <= 64 || N <= 64) return dpot_gemm_auto_splitk(M, N, K, batch);
+  if (precision == DPOT_GEMM_F32 || M <= 64 || N <= 64) return dpot_gemm_auto_splitk(M, N, K, batch);
   const long long t128 = (long long)cdiv(M, 128) * cdiv(N, 128) * batch;
   const int ktiles = cdiv(K, BK);
   if (4 * t128 >= 3 * NUM_CU || ktiles < 16) return 1;
@@ -622,7 +622,7 @@ extern "C" int dpot_gemm_f32(const dpot_gemm_desc* d, dpot_stream_t stream) {
            vec_ok(d->res, d->ldres, d->strideRes);
   const int precision = resolve_precision(d->precision, d->M, d->N, d->K, d->batch);
   DPOT_REQUIRE(precision == DPOT_GEMM_F32 || precision == DPOT_GEMM_BF16X6, "gemm: bad precision %d", d->precision);
-  const int t = precision == DPOT_GEMM_BF16X6 ? pick_tile_split(d->M, d->N, d->batch, splits, d->tile)
+  const int t = precision != DPOT_GEMM_F32 ? pick_tile_split(d->M, d->N, d->batch, splits, d->tile)
                                               : pick_tile(d->M, d->N, d->batch, d->tile);
   p.tilesM = cdiv(d->M, t); p.tilesN = cdiv(d->N, t);
   const long long ntiles = (long long)p.tilesM * p.tilesN;
@@ -631,9 +631,9 @@ extern "C" int dpot_gemm_f32(const dpot_gemm_desc* d, dpot_stream_t stream) {
   hipStream_t s = as_stream(stream);
   if (precision == DPOT_GEMM_BF16X6) {
     if (t == 128) {
-      if (vec) launch_gemm_split<128, true>(d, p, grid, s); else launch_gemm_split<128, false>(d, p, grid, s);
+      if (vec) launch_gemm_split<128, true, 3>(d, p, grid, s); else launch_gemm_split<128, false, 3>(d, p, grid, s);
     } else {
-      if (vec) launch_gemm_split<64, true>(d, p, grid, s); else launch_gemm_split<64, false>(d, p, grid, s);
+      if (vec) launch_gemm_split<64, true, 3>(d, p, grid, s); else launch_gemm_split<64, false, 3>(d, p, grid, s);
     }
   } else if (t == 128) {
     if (vec) launch_gemm<128, true>(d, p, grid, s); else launch_gemm<128, false>(d, p, grid, s);

@@ -31,16 +31,6 @@ typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 constexpr int XLD = 40;  // bf16 elements per LDS row
-#ifdef DPOT_X_NOSPLIT
-constexpr bool DPOT_X_DOSPLIT = false;
-#else
-constexpr bool DPOT_X_DOSPLIT = true;
-#endif
-#ifdef DPOT_X_NOGLOAD
-constexpr bool DPOT_X_DOGLOAD = false;
-#else
-constexpr bool DPOT_X_DOGLOAD = true;
-#endif
 
 __device__ __forceinline__ unsigned pk_bf16(float lo, float hi) {
   f32x2 v = {lo, hi};
@@ -57,6 +47,17 @@ __device__ __forceinline__ void split3(float a, float b, unsigned& p1, unsigned&
   a -= __uint_as_float(p2 << 16);
   b -= __uint_as_float(p2 & 0xffff0000u);
   p3 = pk_bf16(a, b);
+}
+
+// NPL planes: 3 = the full split above, 1 = plain bf16 rounding (the reduced-precision "bf16" GEMM mode)
+template <int NPL>
+__device__ __forceinline__ void splitn(float a, float b, unsigned& p1, unsigned& p2, unsigned& p3) {
+  if constexpr (NPL == 3) {
+    split3(a, b, p1, p2, p3);
+  } else {
+    p1 = pk_bf16(a, b);
+    p2 = p3 = 0u;
+  }
 }
 
 template <int I>
@@ -143,28 +144,21 @@ __device__ __forceinline__ void load_kcontig_x(float4 (&reg)[R / 32], const floa
 // ---- split + store, in R/32 equal pieces (4 elements -> 18 VALU + the stores) so that the caller can spread them
 //      between the MFMAs.  lds = plane 0 of the operand; planes are R*XLD elements apart.
 // K-contiguous source (same thread -> (row, k-quad) map as load_kcontig): piece P = reg[P]
-template <int R, int P>
+template <int R, int P, int NPL>
 __device__ __forceinline__ void split_piece_kcontig(__bf16* lds, const float4 (&reg)[R / 32], int tid) {
   const int f = tid + 256 * P;
   unsigned a1, a2, a3, b1, b2, b3;
-#ifdef DPOT_X_NOVALU
-  a1 = __float_as_uint(reg[P].x); a2 = __float_as_uint(reg[P].y); a3 = a1;
-  b1 = __float_as_uint(reg[P].z); b2 = __float_as_uint(reg[P].w); b3 = b1;
-#else
-  split3(reg[P].x, reg[P].y, a1, a2, a3);
-  split3(reg[P].z, reg[P].w, b1, b2, b3);
-#endif
+  splitn<NPL>(reg[P].x, reg[P].y, a1, a2, a3);
+  splitn<NPL>(reg[P].z, reg[P].w, b1, b2, b3);
   __bf16* dst = lds + xrow(f) * XLD + ((f & 7) << 2);
-#ifdef DPOT_X_NOLDSW
-  asm volatile("" ::"v"(a1), "v"(b1), "v"(a2), "v"(b2), "v"(a3), "v"(b3), "v"(dst));
-#else
   *reinterpret_cast<uint2*>(dst) = make_uint2(a1, b1);
-  *reinterpret_cast<uint2*>(dst + R * XLD) = make_uint2(a2, b2);
-  *reinterpret_cast<uint2*>(dst + 2 * R * XLD) = make_uint2(a3, b3);
-#endif
+  if constexpr (NPL == 3) {
+    *reinterpret_cast<uint2*>(dst + R * XLD) = make_uint2(a2, b2);
+    *reinterpret_cast<uint2*>(dst + 2 * R * XLD) = make_uint2(a3, b3);
+  }
 }
 // row-contiguous patch, transposed in registers: R = 128: piece P = patch row P (4 k);  R = 64: rows 2P, 2P+1 (2 k)
-template <int R, int P>
+template <int R, int P, int NPL>
 __device__ __forceinline__ void split_piece_rpatch(__bf16* lds, const float4 (&reg)[R / 32], int tid) {
   constexpr int NK = R / 32, KG = 32 / NK;
   const int kofs = (tid % KG) * NK;
@@ -172,22 +166,26 @@ __device__ __forceinline__ void split_piece_rpatch(__bf16* lds, const float4 (&r
   if constexpr (NK == 4) {
     __bf16* dst = lds + (row + P) * XLD + kofs;
     unsigned a1, a2, a3, b1, b2, b3;
-    split3(f4c<P>(reg[0]), f4c<P>(reg[1]), a1, a2, a3);
-    split3(f4c<P>(reg[2]), f4c<P>(reg[3]), b1, b2, b3);
+    splitn<NPL>(f4c<P>(reg[0]), f4c<P>(reg[1]), a1, a2, a3);
+    splitn<NPL>(f4c<P>(reg[2]), f4c<P>(reg[3]), b1, b2, b3);
     *reinterpret_cast<uint2*>(dst) = make_uint2(a1, b1);
-    *reinterpret_cast<uint2*>(dst + R * XLD) = make_uint2(a2, b2);
-    *reinterpret_cast<uint2*>(dst + 2 * R * XLD) = make_uint2(a3, b3);
+    if constexpr (NPL == 3) {
+      *reinterpret_cast<uint2*>(dst + R * XLD) = make_uint2(a2, b2);
+      *reinterpret_cast<uint2*>(dst + 2 * R * XLD) = make_uint2(a3, b3);
+    }
   } else {
     __bf16* dst = lds + (row + 2 * P) * XLD + kofs;
     unsigned a1, a2, a3, b1, b2, b3;
-    split3(f4c<2 * P>(reg[0]), f4c<2 * P>(reg[1]), a1, a2, a3);
-    split3(f4c<2 * P + 1>(reg[0]), f4c<2 * P + 1>(reg[1]), b1, b2, b3);
+    splitn<NPL>(f4c<2 * P>(reg[0]), f4c<2 * P>(reg[1]), a1, a2, a3);
+    splitn<NPL>(f4c<2 * P + 1>(reg[0]), f4c<2 * P + 1>(reg[1]), b1, b2, b3);
     *reinterpret_cast<unsigned*>(dst) = a1;
-    *reinterpret_cast<unsigned*>(dst + R * XLD) = a2;
-    *reinterpret_cast<unsigned*>(dst + 2 * R * XLD) = a3;
     *reinterpret_cast<unsigned*>(dst + XLD) = b1;
-    *reinterpret_cast<unsigned*>(dst + XLD + R * XLD) = b2;
-    *reinterpret_cast<unsigned*>(dst + XLD + 2 * R * XLD) = b3;
+    if constexpr (NPL == 3) {
+      *reinterpret_cast<unsigned*>(dst + R * XLD) = a2;
+      *reinterpret_cast<unsigned*>(dst + 2 * R * XLD) = a3;
+      *reinterpret_cast<unsigned*>(dst + XLD + R * XLD) = b2;
+      *reinterpret_cast<unsigned*>(dst + XLD + 2 * R * XLD) = b3;
+    }
   }
 }
 
@@ -200,15 +198,16 @@ __device__ __forceinline__ void patch_rowsum(float4& cs, const float4 (&reg)[R /
   }
 }
 
-template <int BM, int BN, bool TA, bool TB, bool VEC, int TAG>
+template <int BM, int BN, bool TA, bool TB, bool VEC, int TAG, int NPL>
 __global__ __launch_bounds__(256) void gemm_f32x_kernel(const GemmArgs p) {
   static_assert(BM == BN, "square tiles only");
+  static_assert(NPL == 3 || NPL == 1, "3 planes = bf16x6 (fp32-accurate), 1 plane = plain bf16");
   constexpr bool A_KC = !TA;
   constexpr bool B_KC = TB;
   constexpr int TM = BM / 64, TN = BN / 64;
   constexpr int WM = BM / 2, WN = BN / 2;
   constexpr int NP = BM / 32;                                              // split pieces / staging float4 per operand
-  constexpr int A_ELEMS = 3 * BM * XLD, B_ELEMS = 3 * BN * XLD;          // bf16 elements per buffer
+  constexpr int A_ELEMS = NPL * BM * XLD, B_ELEMS = NPL * BN * XLD;      // bf16 elements per buffer
   constexpr int BUF_BYTES = 2 * (A_ELEMS + B_ELEMS);
   constexpr int STAGE_BYTES = 4 * 32 * EPI_LD * 4;
   // two DISTINCT arrays (not one array indexed by kt & 1): the compiler must know that the split's stores into one
@@ -276,16 +275,16 @@ __global__ __launch_bounds__(256) void gemm_f32x_kernel(const GemmArgs p) {
 
 #define DPOT_SPLIT_A(P, BUF)                                                                                 \
   do {                                                                                                       \
-    if constexpr ((P) < NP && DPOT_X_DOSPLIT) {                                                                                \
-      if constexpr (A_KC) split_piece_kcontig<BM, (P) < NP ? (P) : 0>(reinterpret_cast<__bf16*>(BUF), ra, tid);         \
-      else split_piece_rpatch<BM, (P) < NP ? (P) : 0>(reinterpret_cast<__bf16*>(BUF), ra, tid);                         \
+    if constexpr ((P) < NP) {                                                                                \
+      if constexpr (A_KC) split_piece_kcontig<BM, (P) < NP ? (P) : 0, NPL>(reinterpret_cast<__bf16*>(BUF), ra, tid);         \
+      else split_piece_rpatch<BM, (P) < NP ? (P) : 0, NPL>(reinterpret_cast<__bf16*>(BUF), ra, tid);                         \
     }                                                                                                        \
   } while (0)
 #define DPOT_SPLIT_B(P, BUF)                                                                                 \
   do {                                                                                                       \
-    if constexpr ((P) < NP && DPOT_X_DOSPLIT) {                                                                                \
-      if constexpr (B_KC) split_piece_kcontig<BN, (P) < NP ? (P) : 0>(reinterpret_cast<__bf16*>(BUF) + A_ELEMS, rb, tid); \
-      else split_piece_rpatch<BN, (P) < NP ? (P) : 0>(reinterpret_cast<__bf16*>(BUF) + A_ELEMS, rb, tid);               \
+    if constexpr ((P) < NP) {                                                                                \
+      if constexpr (B_KC) split_piece_kcontig<BN, (P) < NP ? (P) : 0, NPL>(reinterpret_cast<__bf16*>(BUF) + A_ELEMS, rb, tid); \
+      else split_piece_rpatch<BN, (P) < NP ? (P) : 0, NPL>(reinterpret_cast<__bf16*>(BUF) + A_ELEMS, rb, tid);               \
     }                                                                                                        \
   } while (0)
   // fragment reads: split plane S of the wave's A rows / B columns, k-step KK (0 or 16)
@@ -319,22 +318,35 @@ __global__ __launch_bounds__(256) void gemm_f32x_kernel(const GemmArgs p) {
     if (kt + 1 < nk) fixup(kbeg + (kt + 1) * BK);
     bf16x8 c0[TM], c1[TM], c2[TM], d0[TN], d1[TN], d2[TN];     // k-step 1
     __builtin_amdgcn_sched_barrier(0);
-    DPOT_SPLIT_A(0, nxt); DPOT_TERM(a2, b0); DPOT_UNIT_END();
-    DPOT_SPLIT_A(1, nxt); DPOT_TERM(a0, b2); DPOT_UNIT_END();
-    DPOT_SPLIT_A(2, nxt); DPOT_RD_A(c2, cur, 2, 16); DPOT_TERM(a1, b1); DPOT_UNIT_END();
-    DPOT_SPLIT_A(3, nxt); DPOT_RD_B(d0, cur, 0, 16); DPOT_TERM(a1, b0); DPOT_UNIT_END();
-    if constexpr (DPOT_X_DOGLOAD) gloadA(kbeg + (kt + 2) * BK);
-    DPOT_SPLIT_B(0, nxt); DPOT_RD_A(c0, cur, 0, 16); DPOT_RD_B(d2, cur, 2, 16); DPOT_TERM(a0, b1); DPOT_UNIT_END();
-    DPOT_SPLIT_B(1, nxt); DPOT_RD_A(c1, cur, 1, 16); DPOT_RD_B(d1, cur, 1, 16); DPOT_TERM(a0, b0); DPOT_UNIT_END();
-    DPOT_SPLIT_B(2, nxt); DPOT_TERM(c2, d0); DPOT_UNIT_END();
-    DPOT_SPLIT_B(3, nxt); DPOT_TERM(c0, d2); DPOT_UNIT_END();
-    if constexpr (DPOT_X_DOGLOAD) gloadB(kbeg + (kt + 2) * BK);
-    __syncthreads();
-    __builtin_amdgcn_sched_barrier(0);
-    DPOT_RD_A(a2, nxt, 2, 0); DPOT_RD_B(b0, nxt, 0, 0); DPOT_TERM(c1, d1); DPOT_UNIT_END();
-    DPOT_RD_A(a0, nxt, 0, 0); DPOT_RD_B(b2, nxt, 2, 0); DPOT_TERM(c1, d0); DPOT_UNIT_END();
-    DPOT_RD_A(a1, nxt, 1, 0); DPOT_RD_B(b1, nxt, 1, 0); DPOT_TERM(c0, d1); DPOT_UNIT_END();
-    DPOT_TERM(c0, d0); DPOT_UNIT_END();
+    if constexpr (NPL == 3) {
+      DPOT_SPLIT_A(0, nxt); DPOT_TERM(a2, b0); DPOT_UNIT_END();
+      DPOT_SPLIT_A(1, nxt); DPOT_TERM(a0, b2); DPOT_UNIT_END();
+      DPOT_SPLIT_A(2, nxt); DPOT_RD_A(c2, cur, 2, 16); DPOT_TERM(a1, b1); DPOT_UNIT_END();
+      DPOT_SPLIT_A(3, nxt); DPOT_RD_B(d0, cur, 0, 16); DPOT_TERM(a1, b0); DPOT_UNIT_END();
+      gloadA(kbeg + (kt + 2) * BK);
+      DPOT_SPLIT_B(0, nxt); DPOT_RD_A(c0, cur, 0, 16); DPOT_RD_B(d2, cur, 2, 16); DPOT_TERM(a0, b1); DPOT_UNIT_END();
+      DPOT_SPLIT_B(1, nxt); DPOT_RD_A(c1, cur, 1, 16); DPOT_RD_B(d1, cur, 1, 16); DPOT_TERM(a0, b0); DPOT_UNIT_END();
+      DPOT_SPLIT_B(2, nxt); DPOT_TERM(c2, d0); DPOT_UNIT_END();
+      DPOT_SPLIT_B(3, nxt); DPOT_TERM(c0, d2); DPOT_UNIT_END();
+      gloadB(kbeg + (kt + 2) * BK);
+      __syncthreads();
+      __builtin_amdgcn_sched_barrier(0);
+      DPOT_RD_A(a2, nxt, 2, 0); DPOT_RD_B(b0, nxt, 0, 0); DPOT_TERM(c1, d1); DPOT_UNIT_END();
+      DPOT_RD_A(a0, nxt, 0, 0); DPOT_RD_B(b2, nxt, 2, 0); DPOT_TERM(c1, d0); DPOT_UNIT_END();
+      DPOT_RD_A(a1, nxt, 1, 0); DPOT_RD_B(b1, nxt, 1, 0); DPOT_TERM(c0, d1); DPOT_UNIT_END();
+      DPOT_TERM(c0, d0); DPOT_UNIT_END();
+    } else {
+      // plain bf16: one product per k-step; the (cheap) rounding of slab kt+1 rides on the first k-step
+      DPOT_RD_A(c0, cur, 0, 16); DPOT_RD_B(d0, cur, 0, 16);
+      DPOT_SPLIT_A(0, nxt); DPOT_SPLIT_A(1, nxt); DPOT_SPLIT_A(2, nxt); DPOT_SPLIT_A(3, nxt);
+      gloadA(kbeg + (kt + 2) * BK);
+      DPOT_TERM(a0, b0);
+      DPOT_SPLIT_B(0, nxt); DPOT_SPLIT_B(1, nxt); DPOT_SPLIT_B(2, nxt); DPOT_SPLIT_B(3, nxt);
+      gloadB(kbeg + (kt + 2) * BK);
+      __syncthreads();
+      DPOT_RD_A(a0, nxt, 0, 0); DPOT_RD_B(b0, nxt, 0, 0);
+      DPOT_TERM(c0, d0);
+    }
     // keep the accumulators in AGPRs across the loop edge (otherwise the allocator parks them in VGPRs and copies
     // all 64 of them into AGPRs and back around every slab)
 #pragma unroll
@@ -352,8 +364,10 @@ __global__ __launch_bounds__(256) void gemm_f32x_kernel(const GemmArgs p) {
     gloadA(kbeg + BK);
     gloadB(kbeg + BK);
     __syncthreads();
-    DPOT_RD_A(a2, buf0, 2, 0); DPOT_RD_B(b0, buf0, 0, 0); DPOT_RD_A(a0, buf0, 0, 0); DPOT_RD_B(b2, buf0, 2, 0);
-    DPOT_RD_A(a1, buf0, 1, 0); DPOT_RD_B(b1, buf0, 1, 0);
+    DPOT_RD_A(a0, buf0, 0, 0); DPOT_RD_B(b0, buf0, 0, 0);
+    if constexpr (NPL == 3) {
+      DPOT_RD_A(a2, buf0, 2, 0); DPOT_RD_B(b2, buf0, 2, 0); DPOT_RD_A(a1, buf0, 1, 0); DPOT_RD_B(b1, buf0, 1, 0);
+    }
     // no conditional step inside the loop: a phi of the accumulators there is legalised through VGPRs (64 AGPR->VGPR
     // and 64 VGPR->AGPR copies per slab)
     int kt = 0;
@@ -424,18 +438,18 @@ __global__ __launch_bounds__(256) void gemm_f32x_kernel(const GemmArgs p) {
 #undef DPOT_EPI_FRAG
 }
 
-template <int BMN, bool VEC>
+template <int BMN, bool VEC, int NPL>
 static void launch_gemm_split(const dpot_gemm_desc* d, const GemmArgs& p, dim3 grid, hipStream_t s) {
   const int key = (d->transA ? 2 : 0) | (d->transB ? 1 : 0);
   if (d->tag == 1 && key == 0) {
-    hipLaunchKernelGGL((gemm_f32x_kernel<BMN, BMN, false, false, VEC, 1>), grid, dim3(256), 0, s, p);
+    hipLaunchKernelGGL((gemm_f32x_kernel<BMN, BMN, false, false, VEC, 1, NPL>), grid, dim3(256), 0, s, p);
     return;
   }
   switch (key) {
-    case 0: hipLaunchKernelGGL((gemm_f32x_kernel<BMN, BMN, false, false, VEC, 0>), grid, dim3(256), 0, s, p); break;
-    case 1: hipLaunchKernelGGL((gemm_f32x_kernel<BMN, BMN, false, true, VEC, 0>), grid, dim3(256), 0, s, p); break;
-    case 2: hipLaunchKernelGGL((gemm_f32x_kernel<BMN, BMN, true, false, VEC, 0>), grid, dim3(256), 0, s, p); break;
-    default: hipLaunchKernelGGL((gemm_f32x_kernel<BMN, BMN, true, true, VEC, 0>), grid, dim3(256), 0, s, p); break;
+    case 0: hipLaunchKernelGGL((gemm_f32x_kernel<BMN, BMN, false, false, VEC, 0, NPL>), grid, dim3(256), 0, s, p); break;
+    case 1: hipLaunchKernelGGL((gemm_f32x_kernel<BMN, BMN, false, true, VEC, 0, NPL>), grid, dim3(256), 0, s, p); break;
+    case 2: hipLaunchKernelGGL((gemm_f32x_kernel<BMN, BMN, true, false, VEC, 0, NPL>), grid, dim3(256), 0, s, p); break;
+    default: hipLaunchKernelGGL((gemm_f32x_kernel<BMN, BMN, true, true, VEC, 0, NPL>), grid, dim3(256), 0, s, p); break;
   }
 }
 

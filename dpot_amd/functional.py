@@ -199,11 +199,13 @@ class BlockFn(torch.autograd.Function):
         ops.gemm(O1, wb2, O2, Mm, 2 * bs, 2 * bs, bias=bb2, **kw)
         y1 = ops.irfft2(O2, B, h, w, E, nb, mx, my, 1, res=xn1)                # + x_orig (the normalised input)
         xn2, mean2, rstd2 = ops.groupnorm_fwd(y1, n2w, n2b)
-        Hh, Hpre = ops.linear_fwd(xn2.view(M, E), f1w, f1b, act=act, save_pre=True)
-        out, _ = ops.linear_fwd(Hh, f2w, f2b, res=x.view(M, E))
+        mp = ops.mlp_precision()                                               # channel-MLP GEMM precision override
+        Hh, Hpre = ops.linear_fwd(xn2.view(M, E), f1w, f1b, act=act, save_pre=True, precision=mp)
+        out, _ = ops.linear_fwd(Hh, f2w, f2b, res=x.view(M, E), precision=mp)
         ctx.save_for_backward(x, mean1, rstd1, S, O1pre, O1, y1, mean2, rstd2, xn2, Hpre, Hh, wb1, wb2, n1w, n2w, f1w,
                               f2w)
         ctx.dims = (B, tok, E, h, w, nb, bs, mx, my, mh, act)
+        ctx.mlp_precision = mp
         ctx.sinks = _sinks(ctx, (n1w, n1b, w1, b1, w2, b2, n2w, n2b, f1w, f1b, f2w, f2b), 1)
         return out.view(B, tok, E)
 
@@ -214,6 +216,7 @@ class BlockFn(torch.autograd.Function):
         B, tok, E, h, w, nb, bs, mx, my, mh, act = ctx.dims
         s_n1w, s_n1b, s_w1, s_b1, s_w2, s_b2, s_n2w, s_n2b, s_f1w, s_f1b, s_f2w, s_f2b = ctx.sinks
         M, Mm = B * tok, B * mx * my
+        mp = ctx.mlp_precision
         dev = dout.device
         dout = dout.contiguous()
         do2 = dout.view(M, E)
@@ -221,13 +224,13 @@ class BlockFn(torch.autograd.Function):
         # gradients (wgrad GEMMs + split-K reductions, bias column sums, un-packing) runs on the side stream.
         # channel MLP
         with streams.side(dev):
-            df2w, df2b = ops.linear_bwd_wb(do2, Hh, s_f2w.out(), s_f2b.out())
+            df2w, df2b = ops.linear_bwd_wb(do2, Hh, s_f2w.out(), s_f2b.out(), precision=mp)
             df2w, df2b = s_f2w.done(df2w.view(E, mh, 1, 1)), s_f2b.done(df2b)
-        dHpre = ops.linear_bwd_data(do2, f2w, act=act, aux=Hpre)               # [M, mh]
+        dHpre = ops.linear_bwd_data(do2, f2w, act=act, aux=Hpre, precision=mp)  # [M, mh]
         with streams.side(dev):
-            df1w, df1b = ops.linear_bwd_wb(dHpre, xn2.view(M, E), s_f1w.out(), s_f1b.out())
+            df1w, df1b = ops.linear_bwd_wb(dHpre, xn2.view(M, E), s_f1w.out(), s_f1b.out(), precision=mp)
             df1w, df1b = s_f1w.done(df1w.view(mh, E, 1, 1)), s_f1b.done(df1b)
-        dxn2 = ops.linear_bwd_data(dHpre, f1w)                                 # [M, E]
+        dxn2 = ops.linear_bwd_data(dHpre, f1w, precision=mp)                   # [M, E]
         dy1, dn2w, dn2b = ops.groupnorm_bwd(dxn2.view(B, tok, E), y1, mean2, rstd2, n2w, out_dgamma=s_n2w.out(),
                                             out_dbeta=s_n2b.out())
         dn2w, dn2b = s_n2w.done(dn2w), s_n2b.done(dn2b)

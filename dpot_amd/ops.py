@@ -38,6 +38,21 @@ def gemm_precision() -> str:
     return {v: k for k, v in _PRECISIONS.items()}[_gemm_precision]
 
 
+# precision of the channel-MLP GEMMs only (Block.mlp, models/dpot.py:157-161); None = follow the global setting.
+# BASELINE.json configs[2] asks for a "bf16 channel-MLP on MFMA": 'bf16x6' here puts exactly those GEMMs on the bf16
+# matrix cores at fp32 accuracy.   DPOT_MLP_PRECISION = f32 | bf16x6 | auto
+_mlp_precision = _PRECISIONS[os.environ["DPOT_MLP_PRECISION"]] if os.environ.get("DPOT_MLP_PRECISION") else None
+
+
+def set_mlp_precision(name: Optional[str]) -> None:
+    global _mlp_precision
+    _mlp_precision = None if name is None else _PRECISIONS[name]
+
+
+def mlp_precision() -> Optional[int]:
+    return _mlp_precision
+
+
 def _stream() -> int:
     return torch.cuda.current_stream().cuda_stream
 
@@ -103,7 +118,7 @@ def gemm(A: Tensor, B: Tensor, C_: Tensor, M: int, N: int, K: int, *, transA: bo
 
 def linear_fwd(x: Tensor, W: Tensor, bias: Optional[Tensor], act: int = 0, save_pre: bool = False,
                res: Optional[Tensor] = None, res_div: int = 0, res_mod: int = 0,
-               ldw: Optional[int] = None) -> Tuple[Tensor, Optional[Tensor]]:
+               ldw: Optional[int] = None, precision: Optional[int] = None) -> Tuple[Tensor, Optional[Tensor]]:
     """y[M,N] = act(x[M,K] @ W[N,K]^T + bias) (+ res)   -  nn.Linear / 1x1-conv semantics."""
     M, K = x.shape
     N = W.shape[0]
@@ -111,17 +126,18 @@ def linear_fwd(x: Tensor, W: Tensor, bias: Optional[Tensor], act: int = 0, save_
     pre = torch.empty_like(y) if save_pre else None
     gemm(x, W, y, M, N, K, transB=True, lda=x.stride(0), ldb=ldw or W.stride(0), ldc=N, bias=bias, act=act,
          mode=EPI_ACT if act else EPI_LINEAR, preact=pre, ldpre=N, res=res, ldres=N, res_div=res_div,
-         res_mod=res_mod)
+         res_mod=res_mod, precision=precision)
     return y, pre
 
 
-def linear_bwd_data(dy: Tensor, W: Tensor, act: int = 0, aux: Optional[Tensor] = None) -> Tensor:
+def linear_bwd_data(dy: Tensor, W: Tensor, act: int = 0, aux: Optional[Tensor] = None,
+                    precision: Optional[int] = None) -> Tensor:
     """dx[M,K] = dy[M,N] @ W[N,K]  (optionally times act'(aux[M,K]))."""
     M, N = dy.shape
     K = W.shape[1]
     dx = torch.empty(M, K, dtype=torch.float32, device=dy.device)
     gemm(dy, W, dx, M, K, N, transB=False, lda=dy.stride(0), ldb=W.stride(0), ldc=K, act=act,
-         mode=EPI_DACT if aux is not None else EPI_LINEAR, aux=aux, ldaux=K)
+         mode=EPI_DACT if aux is not None else EPI_LINEAR, aux=aux, ldaux=K, precision=precision)
     return dx
 
 
@@ -133,7 +149,7 @@ def _out(out: Optional[Tensor], shape, device) -> Tensor:
 
 
 def linear_bwd_weight(dy: Tensor, x: Tensor, out: Optional[Tensor] = None, n_rows: Optional[int] = None,
-                      bias_out: Optional[Tensor] = None) -> Tensor:
+                      bias_out: Optional[Tensor] = None, precision: Optional[int] = None) -> Tensor:
     """dW[N,K] = dy[M,N]^T @ x[M,K]   (split-K over the token dimension); n_rows < N computes only dW[:n_rows].
     bias_out [N]: also db = colsum(dy), produced by the same kernel from the dy tiles it stages anyway."""
     M, N = dy.shape
@@ -141,15 +157,15 @@ def linear_bwd_weight(dy: Tensor, x: Tensor, out: Optional[Tensor] = None, n_row
     K = x.shape[1]
     dW = _out(out, (N, K), dy.device)
     gemm(dy, x, dW, N, K, M, transA=True, transB=False, lda=dy.stride(0), ldb=x.stride(0), ldc=K,
-         splitk=auto_splitk(N, K, M), colsum_out=bias_out, colsum_of=1)
+         splitk=auto_splitk(N, K, M, precision=precision), colsum_out=bias_out, colsum_of=1, precision=precision)
     return dW
 
 
-def linear_bwd_wb(dy: Tensor, x: Tensor, out_w: Optional[Tensor] = None,
-                  out_b: Optional[Tensor] = None) -> Tuple[Tensor, Tensor]:
+def linear_bwd_wb(dy: Tensor, x: Tensor, out_w: Optional[Tensor] = None, out_b: Optional[Tensor] = None,
+                  precision: Optional[int] = None) -> Tuple[Tensor, Tensor]:
     """(dW, db) of y = x W^T + b in one launch (+ the split-K reduction): db rides on the dy tiles of the wgrad GEMM"""
     db = _out(out_b, (dy.shape[1],), dy.device)
-    return linear_bwd_weight(dy, x, out=out_w, bias_out=db), db
+    return linear_bwd_weight(dy, x, out=out_w, bias_out=db, precision=precision), db
 
 
 # ------------------------------------------------------------------------------------------------------
