@@ -4,7 +4,8 @@
 //
 // Design (gfx950):
 //   * v_mfma_f32_32x32x2_f32 - exact fp32 (k-ordered fma chain), 157 TF peak, same numerics class as the
-//     reference's fp32 CPU path (north_star tolerance rtol 1e-4 leaves no room for bf16 here)
+//     reference's fp32 CPU path (north_star tolerance rtol 1e-4 leaves no room for plain bf16; gemm_split.h holds
+//     the fp32-accurate bf16x6 variant selected by desc.precision)
 //   * 256 threads = 4 waves in a 2x2 grid; each wave owns a (BM/2)x(BN/2) sub-tile = (BM/64)x(BN/64)
 //     accumulators of 32x32 (16 VGPRs each)
 //   * BK = 32 K-slab staged through LDS; global loads for slab t+1 are issued before the MFMAs of slab t
@@ -16,7 +17,8 @@
 //     together (clamped addresses), only the stores are predicated
 //   * blockIdx -> tile mapping is XCD aware: the 8 XCDs get contiguous chunks of tile space so that
 //     workgroups sharing an A row-panel / the whole weight matrix hit the same 4 MiB L2
-//   * tile size is picked to minimise wave quantisation over the 256 CUs (128x128 unless 64x64 balances better)
+//   * 64x64 tiles by default (4-5 co-resident workgroups per CU hide each other's barriers / prologues / epilogues;
+//     measured never slower than 128x128 in the DPOT-Ti/S/M/L steps); 128x128 stays selectable through desc.tile
 //   * split-K (wgrad: K = tokens*batch is huge, M x N small) writes partials to a workspace that a second
 //     kernel reduces in fixed order - deterministic, no atomics
 #include "common.h"
