@@ -632,10 +632,13 @@ extern "C" int dpot_gemm_f32(const dpot_gemm_desc* d, dpot_stream_t stream) {
   dim3 grid((unsigned)ntiles, 1, (unsigned)(d->batch * splits));
   hipStream_t s = as_stream(stream);
   if (precision == DPOT_GEMM_BF16X6) {
-    if (t == 128) {
-      if (vec) launch_gemm_split<128, true, 3>(d, p, grid, s); else launch_gemm_split<128, false, 3>(d, p, grid, s);
+    static const int waves128 = [] { const char* e = getenv("DPOT_X_WAVES"); return e ? atoi(e) : 8; }();
+    if (t == 128 && waves128 == 8) {
+      if (vec) launch_gemm_split<128, true, 3, 8>(d, p, grid, s); else launch_gemm_split<128, false, 3, 8>(d, p, grid, s);
+    } else if (t == 128) {
+      if (vec) launch_gemm_split<128, true, 3, 4>(d, p, grid, s); else launch_gemm_split<128, false, 3, 4>(d, p, grid, s);
     } else {
-      if (vec) launch_gemm_split<64, true, 3>(d, p, grid, s); else launch_gemm_split<64, false, 3>(d, p, grid, s);
+      if (vec) launch_gemm_split<64, true, 3, 4>(d, p, grid, s); else launch_gemm_split<64, false, 3, 4>(d, p, grid, s);
     }
   } else if (t == 128) {
     if (vec) launch_gemm<128, true>(d, p, grid, s); else launch_gemm<128, false>(d, p, grid, s);

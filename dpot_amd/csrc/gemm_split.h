@@ -69,12 +69,13 @@ __device__ __forceinline__ float f4c(const float4& v) {
 }
 
 // ---- row-contiguous source (element (r, k) at base[k*ld + r]): per-thread patches --------------------------
-//   R = 128: patch = 4 k x 4 rows, kq = tid & 7 (k = 4kq + j), rg = tid >> 3 (rows 4rg .. 4rg+3), reg[j] = k-row j
-//   R =  64: patch = 2 k x 4 rows, kp = tid & 15 (k = 2kp + j), rg = tid >> 4,                     reg[j] = k-row j
-template <int R, bool VEC>
-__device__ __forceinline__ void load_rpatch(float4 (&reg)[R / 32], const float* __restrict__ base, int ld, int r0,
+//   16 elements / thread (R = 128, 256 threads): patch = 4 k x 4 rows, kq = tid & 7 (k = 4kq + j), rg = tid >> 3
+//    8 elements / thread (R = 64 with 256 threads, R = 128 with 512): patch = 2 k x 4 rows, kp = tid & 15, rg = tid >> 4
+//   rows 4rg .. 4rg+3, reg[j] = k-row j
+template <int R, bool VEC, int NT>
+__device__ __forceinline__ void load_rpatch(float4 (&reg)[R * 8 / NT], const float* __restrict__ base, int ld, int r0,
                                             int rmax, int k0, int kmax, int tid) {
-  constexpr int NK = R / 32;                 // k-rows per patch (4 or 2)
+  constexpr int NK = R * 8 / NT;             // k-rows per patch (4 or 2)
   constexpr int KG = 32 / NK;                // patches along k (8 or 16)
   const int kb = k0 + (tid % KG) * NK;
   const int r = r0 + (tid / KG) * 4;
@@ -93,19 +94,19 @@ __device__ __forceinline__ void load_rpatch(float4 (&reg)[R / 32], const float* 
 }
 
 // zero the k >= kmax part of the registers of a partial slab (called under a workgroup-uniform branch)
-template <int R>
-__device__ __forceinline__ void mask_tail_rpatch(float4 (&reg)[R / 32], int k0, int kmax, int tid) {
-  constexpr int NK = R / 32, KG = 32 / NK;
+template <int R, int NT>
+__device__ __forceinline__ void mask_tail_rpatch(float4 (&reg)[R * 8 / NT], int k0, int kmax, int tid) {
+  constexpr int NK = R * 8 / NT, KG = 32 / NK;
   const int kb = k0 + (tid % KG) * NK;
 #pragma unroll
   for (int j = 0; j < NK; ++j)
     if (kb + j >= kmax) reg[j] = make_float4(0.f, 0.f, 0.f, 0.f);
 }
-template <int R>
-__device__ __forceinline__ void mask_tail_kcontig(float4 (&reg)[R / 32], int k0, int kmax, int tid) {
+template <int R, int NT>
+__device__ __forceinline__ void mask_tail_kcontig(float4 (&reg)[R * 8 / NT], int k0, int kmax, int tid) {
 #pragma unroll
-  for (int i = 0; i < R / 32; ++i) {
-    const int k = k0 + (((tid + 256 * i) & 7) << 2);
+  for (int i = 0; i < R * 8 / NT; ++i) {
+    const int k = k0 + (((tid + NT * i) & 7) << 2);
     if (k + 0 >= kmax) reg[i].x = 0.f;
     if (k + 1 >= kmax) reg[i].y = 0.f;
     if (k + 2 >= kmax) reg[i].z = 0.f;
@@ -121,12 +122,12 @@ __device__ __forceinline__ int xrow(int f) {
   const int q = f >> 3;
   return (q & ~7) | ((q & 1) << 2) | ((q >> 1) & 3);
 }
-template <int R, bool VEC>
-__device__ __forceinline__ void load_kcontig_x(float4 (&reg)[R / 32], const float* __restrict__ base, int ld, int r0,
-                                               int rmax, int k0, int kmax, int tid) {
+template <int R, bool VEC, int NT>
+__device__ __forceinline__ void load_kcontig_x(float4 (&reg)[R * 8 / NT], const float* __restrict__ base, int ld,
+                                               int r0, int rmax, int k0, int kmax, int tid) {
 #pragma unroll
-  for (int i = 0; i < R / 32; ++i) {
-    const int f = tid + 256 * i;
+  for (int i = 0; i < R * 8 / NT; ++i) {
+    const int f = tid + NT * i;
     const int r = r0 + xrow(f);
     const int k = k0 + ((f & 7) << 2);
     const float* row = base + (long long)min(r, rmax - 1) * ld;
@@ -144,9 +145,9 @@ __device__ __forceinline__ void load_kcontig_x(float4 (&reg)[R / 32], const floa
 // ---- split + store, in R/32 equal pieces (4 elements -> 18 VALU + the stores) so that the caller can spread them
 //      between the MFMAs.  lds = plane 0 of the operand; planes are R*XLD elements apart.
 // K-contiguous source (same thread -> (row, k-quad) map as load_kcontig): piece P = reg[P]
-template <int R, int P, int NPL>
-__device__ __forceinline__ void split_piece_kcontig(__bf16* lds, const float4 (&reg)[R / 32], int tid) {
-  const int f = tid + 256 * P;
+template <int R, int P, int NPL, int NT>
+__device__ __forceinline__ void split_piece_kcontig(__bf16* lds, const float4 (&reg)[R * 8 / NT], int tid) {
+  const int f = tid + NT * P;
   unsigned a1, a2, a3, b1, b2, b3;
   splitn<NPL>(reg[P].x, reg[P].y, a1, a2, a3);
   splitn<NPL>(reg[P].z, reg[P].w, b1, b2, b3);
@@ -158,9 +159,9 @@ __device__ __forceinline__ void split_piece_kcontig(__bf16* lds, const float4 (&
   }
 }
 // row-contiguous patch, transposed in registers: R = 128: piece P = patch row P (4 k);  R = 64: rows 2P, 2P+1 (2 k)
-template <int R, int P, int NPL>
-__device__ __forceinline__ void split_piece_rpatch(__bf16* lds, const float4 (&reg)[R / 32], int tid) {
-  constexpr int NK = R / 32, KG = 32 / NK;
+template <int R, int P, int NPL, int NT>
+__device__ __forceinline__ void split_piece_rpatch(__bf16* lds, const float4 (&reg)[R * 8 / NT], int tid) {
+  constexpr int NK = R * 8 / NT, KG = 32 / NK;
   const int kofs = (tid % KG) * NK;
   const int row = (tid / KG) * 4;
   if constexpr (NK == 4) {
@@ -190,26 +191,29 @@ __device__ __forceinline__ void split_piece_rpatch(__bf16* lds, const float4 (&r
 }
 
 // sum over the patch's k of its 4 rows (fused bias gradient)
-template <int R>
-__device__ __forceinline__ void patch_rowsum(float4& cs, const float4 (&reg)[R / 32]) {
+template <int NR>
+__device__ __forceinline__ void patch_rowsum(float4& cs, const float4 (&reg)[NR]) {
 #pragma unroll
-  for (int j = 0; j < R / 32; ++j) {
+  for (int j = 0; j < NR; ++j) {
     cs.x += reg[j].x; cs.y += reg[j].y; cs.z += reg[j].z; cs.w += reg[j].w;
   }
 }
 
-template <int BM, int BN, bool TA, bool TB, bool VEC, int TAG, int NPL>
-__global__ __launch_bounds__(256) void gemm_f32x_kernel(const GemmArgs p) {
+// NW waves per workgroup: 4 (2x2 wave grid) or 8 (2x4: two waves per SIMD on the 128x128 tile, so that one wave's
+// operand split overlaps the other's MFMAs)
+template <int BM, int BN, bool TA, bool TB, bool VEC, int TAG, int NPL, int NW>
+__global__ __launch_bounds__(64 * NW) void gemm_f32x_kernel(const GemmArgs p) {
+  constexpr int NT = 64 * NW, WCOLS = NW / 2;
   static_assert(BM == BN, "square tiles only");
   static_assert(NPL == 3 || NPL == 1, "3 planes = bf16x6 (fp32-accurate), 1 plane = plain bf16");
   constexpr bool A_KC = !TA;
   constexpr bool B_KC = TB;
-  constexpr int TM = BM / 64, TN = BN / 64;
-  constexpr int WM = BM / 2, WN = BN / 2;
-  constexpr int NP = BM / 32;                                              // split pieces / staging float4 per operand
+  constexpr int WM = BM / 2, WN = BN / WCOLS;
+  constexpr int TM = WM / 32, TN = WN / 32;
+  constexpr int NP = BM * 8 / NT;                                          // split pieces / staging float4 per operand
   constexpr int A_ELEMS = NPL * BM * XLD, B_ELEMS = NPL * BN * XLD;      // bf16 elements per buffer
   constexpr int BUF_BYTES = 2 * (A_ELEMS + B_ELEMS);
-  constexpr int STAGE_BYTES = 4 * 32 * EPI_LD * 4;
+  constexpr int STAGE_BYTES = NW * 32 * EPI_LD * 4;
   // two DISTINCT arrays (not one array indexed by kt & 1): the compiler must know that the split's stores into one
   // buffer cannot alias the fragment reads of the other, or it keeps all stores ahead of all reads
   __shared__ __attribute__((aligned(16))) unsigned char buf0[BUF_BYTES > STAGE_BYTES ? BUF_BYTES : STAGE_BYTES];
@@ -218,7 +222,7 @@ __global__ __launch_bounds__(256) void gemm_f32x_kernel(const GemmArgs p) {
 
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
-  const int wm = wave >> 1, wn = wave & 1;
+  const int wm = wave / WCOLS, wn = wave % WCOLS;
   const int li = lane & 31, kh = lane >> 5;
 
   const int ntiles = p.tilesM * p.tilesN;
@@ -252,39 +256,39 @@ __global__ __launch_bounds__(256) void gemm_f32x_kernel(const GemmArgs p) {
 
   float4 ra[NP], rb[NP];
   auto gloadA = [&](int k0) __attribute__((always_inline)) {
-    if constexpr (A_KC) load_kcontig_x<BM, VEC>(ra, A, p.lda, m0, p.M, k0, kend, tid);
-    else load_rpatch<BM, VEC>(ra, A, p.lda, m0, p.M, k0, kend, tid);
+    if constexpr (A_KC) load_kcontig_x<BM, VEC, NT>(ra, A, p.lda, m0, p.M, k0, kend, tid);
+    else load_rpatch<BM, VEC, NT>(ra, A, p.lda, m0, p.M, k0, kend, tid);
   };
   auto gloadB = [&](int k0) __attribute__((always_inline)) {
-    if constexpr (B_KC) load_kcontig_x<BN, VEC>(rb, B, p.ldb, n0, p.N, k0, kend, tid);
-    else load_rpatch<BN, VEC>(rb, B, p.ldb, n0, p.N, k0, kend, tid);
+    if constexpr (B_KC) load_kcontig_x<BN, VEC, NT>(rb, B, p.ldb, n0, p.N, k0, kend, tid);
+    else load_rpatch<BN, VEC, NT>(rb, B, p.ldb, n0, p.N, k0, kend, tid);
   };
   // uniform-branch work on a freshly loaded slab: zero the k >= kend part of a partial slab, bias-gradient sums
   auto fixup = [&](int k0) __attribute__((always_inline)) {
     if (k0 + BK > kend) {
-      if constexpr (A_KC) mask_tail_kcontig<BM>(ra, k0, kend, tid); else mask_tail_rpatch<BM>(ra, k0, kend, tid);
-      if constexpr (B_KC) mask_tail_kcontig<BN>(rb, k0, kend, tid); else mask_tail_rpatch<BN>(rb, k0, kend, tid);
+      if constexpr (A_KC) mask_tail_kcontig<BM, NT>(ra, k0, kend, tid); else mask_tail_rpatch<BM, NT>(ra, k0, kend, tid);
+      if constexpr (B_KC) mask_tail_kcontig<BN, NT>(rb, k0, kend, tid); else mask_tail_rpatch<BN, NT>(rb, k0, kend, tid);
     }
     if (cs_on) {
       // both candidates are summed and the wanted one is picked BY VALUE at the end: a run-time choice here makes
       // hipcc merge the two calls into one over selected pointers, which sends ra / rb / cs to scratch
-      if constexpr (TA) patch_rowsum<BM>(csA, ra);
-      if constexpr (!TB) patch_rowsum<BN>(csB, rb);
+      if constexpr (TA) patch_rowsum<NP>(csA, ra);
+      if constexpr (!TB) patch_rowsum<NP>(csB, rb);
     }
   };
 
 #define DPOT_SPLIT_A(P, BUF)                                                                                 \
   do {                                                                                                       \
     if constexpr ((P) < NP) {                                                                                \
-      if constexpr (A_KC) split_piece_kcontig<BM, (P) < NP ? (P) : 0, NPL>(reinterpret_cast<__bf16*>(BUF), ra, tid);         \
-      else split_piece_rpatch<BM, (P) < NP ? (P) : 0, NPL>(reinterpret_cast<__bf16*>(BUF), ra, tid);                         \
+      if constexpr (A_KC) split_piece_kcontig<BM, (P) < NP ? (P) : 0, NPL, NT>(reinterpret_cast<__bf16*>(BUF), ra, tid);         \
+      else split_piece_rpatch<BM, (P) < NP ? (P) : 0, NPL, NT>(reinterpret_cast<__bf16*>(BUF), ra, tid);                         \
     }                                                                                                        \
   } while (0)
 #define DPOT_SPLIT_B(P, BUF)                                                                                 \
   do {                                                                                                       \
     if constexpr ((P) < NP) {                                                                                \
-      if constexpr (B_KC) split_piece_kcontig<BN, (P) < NP ? (P) : 0, NPL>(reinterpret_cast<__bf16*>(BUF) + A_ELEMS, rb, tid); \
-      else split_piece_rpatch<BN, (P) < NP ? (P) : 0, NPL>(reinterpret_cast<__bf16*>(BUF) + A_ELEMS, rb, tid);               \
+      if constexpr (B_KC) split_piece_kcontig<BN, (P) < NP ? (P) : 0, NPL, NT>(reinterpret_cast<__bf16*>(BUF) + A_ELEMS, rb, tid); \
+      else split_piece_rpatch<BN, (P) < NP ? (P) : 0, NPL, NT>(reinterpret_cast<__bf16*>(BUF) + A_ELEMS, rb, tid);               \
     }                                                                                                        \
   } while (0)
   // fragment reads: split plane S of the wave's A rows / B columns, k-step KK (0 or 16)
@@ -303,8 +307,8 @@ __global__ __launch_bounds__(256) void gemm_f32x_kernel(const GemmArgs p) {
   do {                                                                                                       \
     _Pragma("unroll") for (int g = 0; g < TM * TN; ++g) {                                                    \
       __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                                     \
-      __builtin_amdgcn_sched_group_barrier(0x002, TM * TN == 4 ? 6 : 24, 0);                                 \
-      __builtin_amdgcn_sched_group_barrier(0x090, TM * TN == 4 ? 2 : 8, 0);                                  \
+      __builtin_amdgcn_sched_group_barrier(0x002, 24 / (TM * TN), 0);                                        \
+      __builtin_amdgcn_sched_group_barrier(0x090, 8 / (TM * TN), 0);                                         \
     }                                                                                                        \
     __builtin_amdgcn_sched_barrier(0);                                                                       \
   } while (0)
@@ -388,7 +392,7 @@ __global__ __launch_bounds__(256) void gemm_f32x_kernel(const GemmArgs p) {
   // ---- epilogue (operand planes are dead: reuse the LDS as per-wave staging; the loop ended on a barrier)
   if (cs_on) {
     // lanes sharing a row group differ in the low KG bits of tid: butterfly in a fixed order
-    constexpr int KG = BM == 128 ? 8 : 16;
+    constexpr int KG = 32 / NP;
     const bool ofA = p.cs_of == 1;
     float cs[4] = {ofA ? csA.x : csB.x, ofA ? csA.y : csB.y, ofA ? csA.z : csB.z, ofA ? csA.w : csB.w};
 #pragma unroll
@@ -438,18 +442,19 @@ __global__ __launch_bounds__(256) void gemm_f32x_kernel(const GemmArgs p) {
 #undef DPOT_EPI_FRAG
 }
 
-template <int BMN, bool VEC, int NPL>
+template <int BMN, bool VEC, int NPL, int NW>
 static void launch_gemm_split(const dpot_gemm_desc* d, const GemmArgs& p, dim3 grid, hipStream_t s) {
   const int key = (d->transA ? 2 : 0) | (d->transB ? 1 : 0);
+  const dim3 blk(64 * NW);
   if (d->tag == 1 && key == 0) {
-    hipLaunchKernelGGL((gemm_f32x_kernel<BMN, BMN, false, false, VEC, 1, NPL>), grid, dim3(256), 0, s, p);
+    hipLaunchKernelGGL((gemm_f32x_kernel<BMN, BMN, false, false, VEC, 1, NPL, NW>), grid, blk, 0, s, p);
     return;
   }
   switch (key) {
-    case 0: hipLaunchKernelGGL((gemm_f32x_kernel<BMN, BMN, false, false, VEC, 0, NPL>), grid, dim3(256), 0, s, p); break;
-    case 1: hipLaunchKernelGGL((gemm_f32x_kernel<BMN, BMN, false, true, VEC, 0, NPL>), grid, dim3(256), 0, s, p); break;
-    case 2: hipLaunchKernelGGL((gemm_f32x_kernel<BMN, BMN, true, false, VEC, 0, NPL>), grid, dim3(256), 0, s, p); break;
-    default: hipLaunchKernelGGL((gemm_f32x_kernel<BMN, BMN, true, true, VEC, 0, NPL>), grid, dim3(256), 0, s, p); break;
+    case 0: hipLaunchKernelGGL((gemm_f32x_kernel<BMN, BMN, false, false, VEC, 0, NPL, NW>), grid, blk, 0, s, p); break;
+    case 1: hipLaunchKernelGGL((gemm_f32x_kernel<BMN, BMN, false, true, VEC, 0, NPL, NW>), grid, blk, 0, s, p); break;
+    case 2: hipLaunchKernelGGL((gemm_f32x_kernel<BMN, BMN, true, false, VEC, 0, NPL, NW>), grid, blk, 0, s, p); break;
+    default: hipLaunchKernelGGL((gemm_f32x_kernel<BMN, BMN, true, true, VEC, 0, NPL, NW>), grid, blk, 0, s, p); break;
   }
 }
 
