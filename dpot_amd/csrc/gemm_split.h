@@ -284,9 +284,14 @@ __global__ __launch_bounds__(64 * NW) void gemm_f32x_kernel(const GemmArgs p) {
       else split_piece_rpatch<BM, (P) < NP ? (P) : 0, NPL, NT>(reinterpret_cast<__bf16*>(BUF), ra, tid);                         \
     }                                                                                                        \
   } while (0)
+#ifdef DPOT_X_NOSPLITB   /* experiment: upper bound of what pre-split B planes would give */
+#define DPOT_X_DOB false
+#else
+#define DPOT_X_DOB true
+#endif
 #define DPOT_SPLIT_B(P, BUF)                                                                                 \
   do {                                                                                                       \
-    if constexpr ((P) < NP) {                                                                                \
+    if constexpr ((P) < NP && DPOT_X_DOB) {                                                                                \
       if constexpr (B_KC) split_piece_kcontig<BN, (P) < NP ? (P) : 0, NPL, NT>(reinterpret_cast<__bf16*>(BUF) + A_ELEMS, rb, tid); \
       else split_piece_rpatch<BN, (P) < NP ? (P) : 0, NPL, NT>(reinterpret_cast<__bf16*>(BUF) + A_ELEMS, rb, tid);               \
     }                                                                                                        \
