@@ -126,7 +126,9 @@ def linear_fwd(x: Tensor, W: Tensor, bias: Optional[Tensor], act: int = 0, save_
     pre = torch.empty_like(y) if save_pre else None
     gemm(x, W, y, M, N, K, transB=True, lda=x.stride(0), ldb=ldw or W.stride(0), ldc=N, bias=bias, act=act,
          mode=EPI_ACT if act else EPI_LINEAR, preact=pre, ldpre=N, res=res, ldres=N, res_div=res_div,
-         res_mod=res_mod, precision=precision)
+         res_mod=res_mod, precision=precision,
+         # a handful of rows (the cls head: M = batch) fills 8 workgroups; split K so that more CUs take part
+         splitk=auto_splitk(M, N, K, precision=precision) if M <= 64 else 1)
     return y, pre
 
 
