@@ -84,7 +84,7 @@ def gemm(A: Tensor, B: Tensor, C_: Tensor, M: int, N: int, K: int, *, transA: bo
          aux: Optional[Tensor] = None, ldaux: int = 0, strideAux: int = 0,
          preact: Optional[Tensor] = None, ldpre: int = 0, stridePre: int = 0,
          res: Optional[Tensor] = None, ldres: int = 0, res_div: int = 0, res_mod: int = 0, strideRes: int = 0,
-         accumulate: bool = False, splitk: int = 1, tile: int = 0, tag: int = 0,
+         accumulate: bool = False, splitk: Optional[int] = None, tile: int = 0, tag: int = 0,
          colsum_out: Optional[Tensor] = None, colsum_of: int = 0, strideColsum: int = 0,
          precision: Optional[int] = None) -> Tensor:
     """C = epilogue(A @ B) on the matrix cores; see include/dpot_hip.h for the exact semantics."""
@@ -104,6 +104,11 @@ def gemm(A: Tensor, B: Tensor, C_: Tensor, M: int, N: int, K: int, *, transA: bo
     d.tile = tile
     d.tag = tag
     d.precision = _gemm_precision if precision is None else precision
+    if splitk is None:
+        # launches that cannot fill the chip (<= 128 output tiles: the embed fold's T small products, the cls head,
+        # pos-embed terms) are latency bound - spread their K over more workgroups; big grids stay un-split
+        small = ((M + 63) // 64) * ((N + 63) // 64) * batch <= 128
+        splitk = auto_splitk(M, N, K, batch, precision=d.precision) if small else 1
     d.colsum_out, d.colsum_of, d.strideColsum = _p(colsum_out), (colsum_of if colsum_out is not None else 0), strideColsum
     ws = None
     if splitk > 1:
@@ -126,9 +131,7 @@ def linear_fwd(x: Tensor, W: Tensor, bias: Optional[Tensor], act: int = 0, save_
     pre = torch.empty_like(y) if save_pre else None
     gemm(x, W, y, M, N, K, transB=True, lda=x.stride(0), ldb=ldw or W.stride(0), ldc=N, bias=bias, act=act,
          mode=EPI_ACT if act else EPI_LINEAR, preact=pre, ldpre=N, res=res, ldres=N, res_div=res_div,
-         res_mod=res_mod, precision=precision,
-         # a handful of rows (the cls head: M = batch) fills 8 workgroups; split K so that more CUs take part
-         splitk=auto_splitk(M, N, K, precision=precision) if M <= 64 else 1)
+         res_mod=res_mod, precision=precision)
     return y, pre
 
 
