@@ -393,3 +393,25 @@ def test_inference_rollout_vs_oracle_and_graph_replay():
     assert torch.equal(pred_g, pred) and torch.equal(l_steps_g, l_steps) and torch.equal(l_full_g, l_full)
     with pytest.raises(ValueError):
         g(xx.cuda()[:2], yy.cuda()[:2], msk.cuda()[:2])
+
+
+def test_graphed_step_draws_fresh_noise_every_replay():
+    """train_temporal.py:205 inside the captured step: the in-kernel generator's device-side offset advances on each
+    replay, so two replays of the same batch from the same weights see different noise (and no noise = same loss)"""
+    from dpot_amd import ops
+    from dpot_amd.train import FlatParams, FusedAdam, GraphedTrainStep
+    m, cfg = build(R.MINI, salt=1)
+    S = cfg.img_size
+    xx = R.recipe_input((2, S, S, cfg.in_timesteps, cfg.in_channels), salt=3).cuda()
+    yy = R.recipe_input((2, S, S, 1, cfg.out_channels), salt=4).cuda()
+    msk = torch.ones(2, S, S, 1, cfg.out_channels, device="cuda")
+    opt = FusedAdam(FlatParams(m), lr=0.0, betas=(0.9, 0.9), weight_decay=0.0, max_norm=1e4)   # lr 0: weights frozen
+    st = ops.rng_state(xx.device)
+    g = GraphedTrainStep(m, opt, xx, yy, msk, noise_scale=0.05, warmup=1)
+    off0 = int(st[1].item())
+    l1 = g.replay(0.0).item()
+    l2 = g.replay(0.0).item()
+    assert int(st[1].item()) == off0 + 2
+    assert l1 != l2 and abs(l1 - l2) < 0.2 * abs(l1)
+    g0 = GraphedTrainStep(m, opt, xx, yy, msk, noise_scale=0.0, warmup=1)
+    assert g0.replay(0.0).item() == g0.replay(0.0).item()
