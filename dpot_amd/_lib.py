@@ -82,9 +82,13 @@ SIGNATURES = {
     "dpot_rel_l2_bwd": (c_i, [c_fp] * 6 + [c_i] * 4 + [c_fp]),
     "dpot_sumsq": (c_i, [c_fp, c_i64, c_fp, c_fp, c_i, c_fp]),
     "dpot_adam_step": (c_i, [c_fp] * 4 + [c_i64, c_fp, c_fp, c_f, c_fp]),
+    "dpot_adam_stage": (c_i, [c_fp, c_fp] + [c_f] * 6 + [c_i, c_fp]),
     "dpot_noise_chunks": (c_i, [c_i, c_i]),
     "dpot_noise_inject": (c_i, [c_fp] * 4 + [c_f] + [c_i] * 3 + [c_fp]),
     "dpot_noise_inject_rng": (c_i, [c_fp] * 4 + [c_f] + [c_i] * 3 + [c_fp]),
+    "dpot_noise_inject_bwd": (c_i, [c_fp] * 7 + [c_f] + [c_i] * 3 + [c_fp]),
+    "dpot_window_slide": (c_i, [c_fp] * 3 + [c_i64] + [c_i] * 3 + [c_fp]),
+    "dpot_window_slide_bwd": (c_i, [c_fp] * 3 + [c_i64] + [c_i] * 3 + [c_fp]),
 }
 
 _lib = None

@@ -174,6 +174,20 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
   }
 }
 
+// host side of a step without a host buffer: all hyper-parameters travel BY VALUE in the kernarg segment of this
+// one-thread launch (copied at enqueue time), and the step counter / bias corrections live on the device - so a host
+// that runs several graph replays ahead of the GPU can never overwrite the values a queued step still has to read
+__global__ void adam_stage_kernel(float* __restrict__ hyper, long long* __restrict__ step, float lr, float b1,
+                                  float b2, float eps, float wd, float max_norm, int advance) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  const long long t = step[0] + advance;
+  step[0] = t;
+  hyper[0] = lr; hyper[1] = b1; hyper[2] = b2; hyper[3] = eps; hyper[4] = wd;
+  hyper[5] = (float)(1.0 - pow((double)b1, (double)t));
+  hyper[6] = (float)(1.0 - pow((double)b2, (double)t));
+  hyper[7] = max_norm;
+}
+
 // ---- noise injection ----------------------------------------------------------------------------------------
 // grid (NCH, B): sum of squares per channel over one chunk of the (X,Y,T) axis of sample b -> part[b][chunk][c].
 // rng (may be NULL) = {seed, offset} of the fused-noise path: block (0,0) advances the offset here, one kernel
@@ -297,6 +311,93 @@ __global__ __launch_bounds__(256) void noise_axpy_kernel(const float* __restrict
     ob[idx] = fmaf(snorm[(int)(idx % C)], eb[idx], xb[idx]);
 }
 
+// ---- backward of the noise injection (AR steps > 0: xx depends on earlier predictions) -----------------------
+// y = x + s * n(x) * eps, n = ||x||_2 over (X,Y,T) per (b,c)  ->  dx = g + s * x / n * sum_s(g * eps)
+// grid (NCH, B): part[b][chunk][c] = sum over the chunk of g * eps; eps is read, or re-drawn from the generator
+// state {seed, offset} the forward used (rng != NULL; needs S*C % 4 == 0, like the forward)
+__global__ __launch_bounds__(256) void noise_bwd_part_kernel(const float* __restrict__ g, const float* __restrict__ eps,
+                                                             const unsigned long long* __restrict__ rng,
+                                                             float* __restrict__ part, int S, int C, int nch) {
+  __shared__ float red[256];
+  const int b = blockIdx.y, ch = blockIdx.x;
+  const long long n = (long long)S * C;
+  const long long per = ((n / 4 + nch - 1) / nch) * 4;          // chunk of the flattened (s, c) axis, multiple of 4
+  const long long i0 = ch * per, i1 = min(n, i0 + per);
+  const float* gb = g + b * n;
+  // one pass per channel (C is the handful of PDE field components): threads stride over the chunk's grid points,
+  // the 256 partial sums are combined in a fixed order
+  for (int c = 0; c < C; ++c) {
+    float a = 0.f;
+    // elements of channel c inside [i0, i1): idx = s*C + c
+    long long sfirst = (i0 - c + C - 1) / C;
+    if (sfirst < 0) sfirst = 0;
+    for (long long sidx = sfirst + threadIdx.x; sidx * C + c < i1; sidx += 256) {
+      const long long idx = sidx * C + c;
+      float e;
+      if (rng) {
+        const float4 ev = philox_normal4(rng[0], rng[1], (unsigned long long)b * (unsigned long long)(n / 4) + idx / 4);
+        const int k = (int)(idx & 3);
+        e = k == 0 ? ev.x : k == 1 ? ev.y : k == 2 ? ev.z : ev.w;
+      } else {
+        e = eps[b * n + idx];
+      }
+      a = fmaf(gb[idx], e, a);
+    }
+    red[threadIdx.x] = a;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      double t = 0.0;
+      for (int r = 0; r < 256; ++r) t += (double)red[r];         // fixed order
+      part[((long long)b * nch + ch) * C + c] = (float)t;
+    }
+    __syncthreads();
+  }
+}
+// grid (G, B): dx = g + s * x / n[b,c] * sum_chunks part[b][.][c]
+__global__ __launch_bounds__(256) void noise_bwd_apply_kernel(const float* __restrict__ x, const float* __restrict__ g,
+                                                              const float* __restrict__ norms,
+                                                              const float* __restrict__ part, float* __restrict__ dx,
+                                                              float noise_scale, int S, int C, int nch) {
+  extern __shared__ float coef[];
+  const int b = blockIdx.y;
+  for (int c = threadIdx.x; c < C; c += 256) {
+    double a = 0.0;
+    for (int k = 0; k < nch; ++k) a += (double)part[((long long)b * nch + k) * C + c];
+    const float nrm = norms[(long long)b * C + c];
+    coef[c] = nrm > 1e-30f ? noise_scale * (float)a / nrm : 0.f;
+  }
+  __syncthreads();
+  const long long n = (long long)S * C;
+  for (long long idx = blockIdx.x * 256ll + threadIdx.x; idx < n; idx += (long long)gridDim.x * 256)
+    dx[b * n + idx] = fmaf(coef[(int)(idx % C)], x[b * n + idx], g[b * n + idx]);
+}
+
+// ---- AR window slide (train_temporal.py:219: xx = cat(xx[..., T_bundle:, :], im)) -----------------------------
+// rows = B*X*Y; xx [rows, T, C], im [rows, Tb, C] -> out [rows, T, C]
+__global__ __launch_bounds__(256) void window_slide_kernel(const float* __restrict__ xx, const float* __restrict__ im,
+                                                           float* __restrict__ out, long long rows, int T, int Tb,
+                                                           int C) {
+  const int TC = T * C, keep = (T - Tb) * C, TbC = Tb * C;
+  const long long total = rows * TC;
+  for (long long idx = blockIdx.x * 256ll + threadIdx.x; idx < total; idx += (long long)gridDim.x * 256) {
+    const long long r = idx / TC;
+    const int j = (int)(idx - r * TC);
+    out[idx] = j < keep ? xx[r * TC + j + TbC] : im[r * TbC + (j - keep)];
+  }
+}
+__global__ __launch_bounds__(256) void window_slide_bwd_kernel(const float* __restrict__ dout, float* __restrict__ dxx,
+                                                               float* __restrict__ dim, long long rows, int T, int Tb,
+                                                               int C) {
+  const int TC = T * C, keep = (T - Tb) * C, TbC = Tb * C;
+  const long long total = rows * TC;
+  for (long long idx = blockIdx.x * 256ll + threadIdx.x; idx < total; idx += (long long)gridDim.x * 256) {
+    const long long r = idx / TC;
+    const int j = (int)(idx - r * TC);
+    if (dxx) dxx[idx] = j >= TbC ? dout[r * TC + j - TbC] : 0.f;
+    if (dim && j >= keep) dim[r * TbC + (j - keep)] = dout[idx];
+  }
+}
+
 static inline unsigned grid_for(long long n, int cap = 4096) {
   long long g = (n + 255) / 256;
   if (g > cap) g = cap;
@@ -359,6 +460,15 @@ extern "C" int dpot_adam_step(float* p, const float* g, float* m, float* v, int6
   return check_launch("adam_kernel");
 }
 
+extern "C" int dpot_adam_stage(float* hyper, int64_t* step, float lr, float beta1, float beta2, float eps,
+                               float weight_decay, float max_norm, int advance, dpot_stream_t stream) {
+  DPOT_REQUIRE(hyper && step, "adam_stage: null pointer");
+  DPOT_REQUIRE(advance >= 0, "adam_stage: advance must be >= 0");
+  hipLaunchKernelGGL(adam_stage_kernel, dim3(1), dim3(64), 0, as_stream(stream), hyper,
+                     reinterpret_cast<long long*>(step), lr, beta1, beta2, eps, weight_decay, max_norm, advance);
+  return check_launch("adam_stage_kernel");
+}
+
 extern "C" int dpot_noise_chunks(int S, int C) {
   long long n = ((long long)S * C + 8191) / 8192;
   if (n > 64) n = 64;
@@ -379,6 +489,41 @@ static int noise_launch(const float* xx, const float* eps, float* out, float* no
   hipLaunchKernelGGL(noise_axpy_kernel, dim3((unsigned)g, B), dim3(256), C * sizeof(float), as_stream(stream), xx, eps,
                      (const float*)part, norms, out, noise_scale, S, C, nch, (const unsigned long long*)rng);
   return check_launch("noise_axpy_kernel");
+}
+
+extern "C" int dpot_noise_inject_bwd(const float* xx, const float* eps, const uint64_t* rng_state, const float* g,
+                                     const float* norms, float* dx, float* part, float noise_scale, int B, int S, int C,
+                                     dpot_stream_t stream) {
+  DPOT_REQUIRE(xx && g && norms && dx && part && B > 0 && S > 0 && C > 0 && C <= 1024, "noise_inject_bwd: bad argument");
+  DPOT_REQUIRE((eps != nullptr) != (rng_state != nullptr), "noise_inject_bwd: exactly one of eps / rng_state");
+  DPOT_REQUIRE(B <= 65535, "noise_inject_bwd: batch too large");
+  DPOT_REQUIRE(rng_state == nullptr || ((long long)S * C) % 4 == 0, "noise_inject_bwd: rng path needs S*C %% 4 == 0");
+  const int nch = dpot_noise_chunks(S, C);
+  hipLaunchKernelGGL(noise_bwd_part_kernel, dim3(nch, B), dim3(256), 0, as_stream(stream), g, eps,
+                     reinterpret_cast<const unsigned long long*>(rng_state), part, S, C, nch);
+  int rc = check_launch("noise_bwd_part_kernel");
+  if (rc) return rc;
+  long long gr = ((long long)S * C + 255) / 256;
+  if (gr > 256) gr = 256;
+  hipLaunchKernelGGL(noise_bwd_apply_kernel, dim3((unsigned)gr, B), dim3(256), C * sizeof(float), as_stream(stream), xx,
+                     g, norms, (const float*)part, dx, noise_scale, S, C, nch);
+  return check_launch("noise_bwd_apply_kernel");
+}
+
+extern "C" int dpot_window_slide(const float* xx, const float* im, float* out, int64_t rows, int T, int Tb, int C,
+                                 dpot_stream_t stream) {
+  DPOT_REQUIRE(xx && im && out && rows > 0 && T > 0 && Tb > 0 && Tb <= T && C > 0, "window_slide: bad argument");
+  hipLaunchKernelGGL(window_slide_kernel, dim3(grid_for(rows * T * C, 8192)), dim3(256), 0, as_stream(stream), xx, im,
+                     out, (long long)rows, T, Tb, C);
+  return check_launch("window_slide_kernel");
+}
+
+extern "C" int dpot_window_slide_bwd(const float* dout, float* dxx, float* dim, int64_t rows, int T, int Tb, int C,
+                                     dpot_stream_t stream) {
+  DPOT_REQUIRE(dout && (dxx || dim) && rows > 0 && T > 0 && Tb > 0 && Tb <= T && C > 0, "window_slide_bwd: bad argument");
+  hipLaunchKernelGGL(window_slide_bwd_kernel, dim3(grid_for(rows * T * C, 8192)), dim3(256), 0, as_stream(stream), dout,
+                     dxx, dim, (long long)rows, T, Tb, C);
+  return check_launch("window_slide_bwd_kernel");
 }
 
 extern "C" int dpot_noise_inject(const float* xx, const float* eps, float* out, float* norms, float noise_scale,

@@ -211,7 +211,7 @@ __global__ void add_kernel(const float* __restrict__ a, const float* __restrict_
 __global__ void bias_add_kernel(const float* __restrict__ x, const float* __restrict__ v, float* __restrict__ y, int N,
                                 long long total) {
   for (long long i = blockIdx.x * 256ll + threadIdx.x; i < total; i += (long long)gridDim.x * 256)
-    y[i] = x[i] + v[i % N];
+    y[i] = (x ? x[i] : 0.f) + v[i % N];
 }
 
 __global__ void scale_shift_kernel(const float* __restrict__ x, const float* __restrict__ scale,
@@ -423,7 +423,7 @@ extern "C" int dpot_add(const float* a, const float* b, float* y, int64_t n, dpo
 }
 
 extern "C" int dpot_bias_add(const float* x, const float* v, float* y, int R, int N, dpot_stream_t stream) {
-  DPOT_REQUIRE(x && v && y && R > 0 && N > 0, "bias_add: bad argument");
+  DPOT_REQUIRE(v && y && R > 0 && N > 0, "bias_add: bad argument");   // x == NULL: y = v tiled R times
   const long long total = (long long)R * N;
   hipLaunchKernelGGL(bias_add_kernel, dim3(grid_for(total)), dim3(256), 0, as_stream(stream), x, v, y, N, total);
   return check_launch("bias_add_kernel");

@@ -34,21 +34,34 @@ class BucketedGradReducer:
         self.is_cuda = flat.grad.is_cuda
         self.overlap = overlap and self.is_cuda
         self.stream = torch.cuda.Stream() if self.overlap else None
-        # contiguous buckets over the flat buffer, cut at parameter boundaries, roughly equal bytes
+        # contiguous buckets over the flat buffer (execution order), roughly equal bytes, cut only BETWEEN STAGES
+        # (embed+time-agg | block 0 | ... | block N-1 | out layer): a bucket is then final exactly when the backward
+        # of its first stage has run, which is where the segmented hipGraph step (train.SegmentedTrainStep) cuts
         n_params = len(flat.params)
         ends = [flat.offsets[i + 1] if i + 1 < n_params else flat.total for i in range(n_params)]
-        target = flat.total / max(1, n_buckets)
+        self.stage_of: List[int] = [self._stage(n) for n in flat.names]       # -1 = cls_head tail
+        target = flat.n_head / max(1, n_buckets)
+        stage_bytes = {}
+        for i in range(n_params):
+            lo = flat.offsets[i]
+            stage_bytes[self.stage_of[i]] = stage_bytes.get(self.stage_of[i], 0) + ends[i] - lo
         self.bucket_of: List[int] = [0] * n_params
         self.ranges: List[List[int]] = []
         start, b = 0, 0
         for i in range(n_params):
             self.bucket_of[i] = b
+            last_of_stage = i == n_params - 1 or self.stage_of[i + 1] != self.stage_of[i]
+            nxt = stage_bytes[self.stage_of[i + 1]] if (last_of_stage and i + 1 < n_params) else 0
+            cur = ends[i] - start
+            # close at a stage end once the bucket is big enough, or when swallowing the next stage would overshoot;
             # the cls_head tail (no gradient in single-loss training) always gets a bucket of its own
-            if ends[i] - start >= target or i == n_params - 1 or ends[i] == flat.n_head:
+            if i == n_params - 1 or ends[i] == flat.n_head or \
+                    (last_of_stage and (cur >= target or cur + nxt > 1.5 * target)):
                 self.ranges.append([start, ends[i]])
                 start = ends[i]
                 b += 1
         self.n_buckets = len(self.ranges)
+        self.tail_bucket = self.bucket_of[-1] if flat.n_head < flat.total else -1
         self.members = [[i for i in range(n_params) if self.bucket_of[i] == k] for k in range(self.n_buckets)]
         self._pending = [0] * self.n_buckets
         self._seen: List[bool] = [False] * n_params
@@ -57,9 +70,35 @@ class BucketedGradReducer:
         self._hooks = []
         # two notification sources: (a) the HIP stage backwards write gradients straight into the flat buffer and
         # call FlatParams.fire(i); (b) ordinary autograd accumulation (foreign graphs) -> post-accumulate hooks
+        self._attached = True
+        self.skip_zero_tail = True
         flat.callbacks.append(self._on_ready)
         for i, p in enumerate(flat.params):
             self._hooks.append(p.register_post_accumulate_grad_hook(self._make_hook(i)))
+
+    # -- hipGraph capture ----------------------------------------------------------------------------------
+    def detach(self) -> None:
+        """ignore gradient-ready notifications (while a backward is being CAPTURED: a collective must never be
+        issued from inside a stream capture; the segmented step launches the buckets itself between replays)"""
+        self._attached = False
+
+    def attach(self) -> None:
+        self._attached = True
+
+    @staticmethod
+    def _stage(name: str) -> int:
+        """execution-order stage of a parameter: 0 = embed (patch_embed, pos_embed, time_agg_layer, scale_feats),
+        1 + i = blocks.i, 10**6 = out_layer, -1 = cls_head"""
+        if name.startswith("blocks."):
+            return 1 + int(name.split(".")[1])
+        if name.startswith("out_layer."):
+            return 10 ** 6
+        if name.startswith("cls_head."):
+            return -1
+        return 0
+
+    def first_stage_of_bucket(self, k: int) -> int:
+        return self.stage_of[self.members[k][0]]
 
     # -- set-up ------------------------------------------------------------------------------------------
     def broadcast_parameters(self, src: int = 0) -> None:
@@ -75,7 +114,7 @@ class BucketedGradReducer:
         self._work = []
 
     def _on_ready(self, i: int) -> None:
-        if self._seen[i]:
+        if not self._attached or self._seen[i]:
             return
         self._seen[i] = True
         k = self.bucket_of[i]
@@ -102,11 +141,23 @@ class BucketedGradReducer:
         else:
             self._work.append(dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.pg, async_op=True))
 
+    def reduce_bucket(self, k: int) -> None:
+        """explicitly launch the all-reduce of bucket k (segmented hipGraph step: called after the graph segment
+        that finalises the bucket's gradients has been enqueued)"""
+        self._launch(k)
+
     def finish(self) -> None:
         """reduce whatever has not been reduced yet (parameters that received no gradient this step still take
         part: their slice is zero, as with DDP + `0.0 * cls_loss`), then make the compute stream wait."""
         for k in range(self.n_buckets):
             if not self._launched[k]:
+                if k == self.tail_bucket and self.skip_zero_tail and not any(
+                        self._seen[i] or self.fp.filled[i] for i in self.members[k]):
+                    # cls_head received no gradient on this rank - and (same program on every rank) on no rank:
+                    # its slice is zero everywhere, SUM of zeros is zero: no collective needed (DDP + `0.0*cls_loss`
+                    # all-reduces those zeros, train_temporal_parallel.py:243; the result is identical)
+                    self._launched[k] = True
+                    continue
                 self._launch(k)
         if self.overlap:
             torch.cuda.current_stream().wait_stream(self.stream)
@@ -118,6 +169,32 @@ class BucketedGradReducer:
         for h in self._hooks:
             h.remove()
         self._hooks = []
+
+
+def dp_lr_step_index(opt_step: int, world: int) -> int:
+    """accelerate's AcceleratedScheduler (split_batches=False) steps the wrapped LR scheduler `world` times per
+    optimiser step, and train_temporal_parallel.py:150 sizes OneCycleLR with the UNSHARDED loader length
+    (epochs * len(train_loader) before accelerator.prepare) - so the schedule still spans the run.  Index into that
+    schedule for the lr used by optimiser step `opt_step` (0-based): scheduler.step() has been called opt_step*world
+    times when the step's optimizer.step() runs."""
+    return opt_step * world
+
+
+def dp_one_cycle_lr(opt_step: int, world: int, total_steps_unsharded: int, max_lr: float, **kw) -> float:
+    from .train import one_cycle_lr
+    return one_cycle_lr(min(dp_lr_step_index(opt_step, world), total_steps_unsharded - 1), total_steps_unsharded,
+                        max_lr, **kw)
+
+
+def gather_eval_metric(value: torch.Tensor, process_group=None) -> torch.Tensor:
+    """train_temporal_parallel.py:294-295 `accelerator.gather_for_metrics((loss,))`: every rank's scalar, in rank
+    order, on every rank ([world] tensor; the reference then sums it)."""
+    value = value.detach().reshape(1)
+    if dist.is_initialized() and dist.get_world_size(process_group) > 1:
+        out = [torch.empty_like(value) for _ in range(dist.get_world_size(process_group))]
+        dist.all_gather(out, value, group=process_group)
+        return torch.cat(out)
+    return value.clone()
 
 
 def shard_indices(n_samples: int, batch_size: int, rank: int, world: int, epoch: int, seed: int = 0,

@@ -62,17 +62,51 @@ class _Sink:
             fp.fire(i)
         return None
 
+    def skip(self) -> None:
+        """this use delivers no gradient (its branch of the backward did not run): release the pending count so the
+        parameter can still be reported final (data-parallel bucket accounting)"""
+        if self.fp is None:
+            return
+        fp, i = self.fp, self.i
+        fp.pending[i] -= 1
+        if fp.pending[i] == 0 and fp.filled[i]:
+            fp.fire(i)
+
 
 def _sinks(ctx, params, first_index: int):
     return [_Sink(p, ctx.needs_input_grad[first_index + k]) for k, p in enumerate(params)]
 
 
 # ======================================================================================================
+def embed_derived(pos, w0, b0, w2, b2, taw, tagamma, tt, T: int):
+    """weight-only products of the embed stage (they depend on no activation, so a T_ar-step rollout computes them
+    once per optimiser step, see DPOTNet.weights_scope): padded conv weights, pos+bias, the cos-scaled aggregation
+    weights and the folded [1x1 conv -> TimeAggregator] matrices V / c described in EmbedFn.forward"""
+    hid, E = w0.shape[0], w2.shape[0]
+    K0 = w0[0].numel()
+    hidp = _pad4(hid)
+    tok = pos.shape[2] * pos.shape[3]
+    dev = pos.device
+    w0p = ops.copy2d_pad(w0, hid, K0, hidp, K0)                                # zero rows hid..hidp
+    b0p = ops.copy2d_pad(b0, 1, hid, 1, hidp).view(hidp)
+    w2p = ops.copy2d_pad(w2, E, hid, E, hidp)                                  # zero cols hid..hidp
+    posT = ops.transpose2d(pos, 1, E, tok).view(tok, E)                        # [tok, E]
+    posb = ops.bias_add(posT, b2)                                              # pos + conv bias
+    ws = ops.timeagg_scale_w(taw, tagamma, tt) if tagamma is not None else taw
+    V = torch.empty(T * hidp, E, dtype=torch.float32, device=dev)
+    ops.gemm(w2p, ws, V, hidp, E, E, transA=True, lda=hidp, ldb=E, ldc=E, batch=T, strideA=0, strideB=E * E,
+             strideC=hidp * E)
+    wsum = ops.colsum(ws, T, E * E).view(E, E)
+    cc = torch.empty(tok, E, dtype=torch.float32, device=dev)
+    ops.gemm(posb, wsum, cc, tok, E, E, lda=E, ldb=E, ldc=E)
+    return w0p, b0p, w2p, posb, ws, V, wsum, cc
+
+
 class EmbedFn(torch.autograd.Function):
     """x[B,X,Y,T,C] -> latent [B, h*w, E]"""
 
     @staticmethod
-    def forward(ctx, x, pos, w0, b0, w2, b2, taw, tagamma, gx, gy, gt, tt, P: int, act: int):
+    def forward(ctx, x, pos, w0, b0, w2, b2, taw, tagamma, gx, gy, gt, tt, P: int, act: int, derived=None):
         x = x.contiguous()
         B, X, Y, T, Cc = x.shape
         h, w = X // P, Y // P
@@ -84,9 +118,9 @@ class EmbedFn(torch.autograd.Function):
         M = B * tok
 
         A0 = ops.patchify(x, gx, gy, gt, P)                                    # [M0, K0], rows (b,px,py,t)
-        w0p = ops.copy2d_pad(w0, hid, K0, hidp, K0)                            # zero rows hid..hidp
-        b0p = ops.copy2d_pad(b0, 1, hid, 1, hidp).view(hidp)
-        w2p = ops.copy2d_pad(w2, E, hid, E, hidp)                              # zero cols hid..hidp
+        if derived is None:
+            derived = embed_derived(pos, w0, b0, w2, b2, taw, tagamma, tt, T)
+        w0p, b0p, w2p, posb, ws, V, wsum, cc = derived
         Hh, Hpre = ops.linear_fwd(A0, w0p, b0p, act=act, save_pre=True)        # [M0, hidp]
         # Everything after the activation is LINEAR (1x1 conv hid->E, + pos_embed, TimeAggregator), and the hidden
         # width is only hid = out_channels*P+3 (35).  Instead of materialising z[M0, E] (168 MB at B=32) and
@@ -95,15 +129,6 @@ class EmbedFn(torch.autograd.Function):
         #     c[tok,j]  = sum_i (pos[tok,i] + b2[i]) * sum_t ws[t,i,j]       (token-dependent constant)
         #     y[m,j]    = sum_{t,h} H[m,(t,h)] * V[(t,h),j] + c[tok(m),j]    (K = T*hidp = 360 instead of 5120)
         # Same result up to fp32 re-association; 15x fewer FLOPs for this stage, and its backward.
-        posT = ops.transpose2d(pos, 1, E, tok).view(tok, E)                    # [tok, E]
-        posb = ops.bias_add(posT, b2)                                          # pos + conv bias
-        ws = ops.timeagg_scale_w(taw, tagamma, tt) if tagamma is not None else taw
-        V = torch.empty(T * hidp, E, dtype=torch.float32, device=dev)
-        ops.gemm(w2p, ws, V, hidp, E, E, transA=True, lda=hidp, ldb=E, ldc=E, batch=T, strideA=0, strideB=E * E,
-                 strideC=hidp * E)
-        wsum = ops.colsum(ws, T, E * E).view(E, E)
-        cc = torch.empty(tok, E, dtype=torch.float32, device=dev)
-        ops.gemm(posb, wsum, cc, tok, E, E, lda=E, ldb=E, ldc=E)
         Yl = torch.empty(M, E, dtype=torch.float32, device=dev)
         ops.gemm(Hh, V, Yl, M, E, T * hidp, lda=T * hidp, ldb=E, ldc=E, res=cc, ldres=E, res_mod=tok)
         ctx.save_for_backward(A0, Hpre, Hh, w0p, w2p, ws, V, wsum, posb, taw, tagamma, tt)
@@ -163,60 +188,83 @@ class EmbedFn(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             dA0 = ops.linear_bwd_data(dHpre, w0p)                              # [M0, K0]
             dx = ops.unpatchify(dA0, B, X, Y, T, Cc, P)
-        return dx, dpos, dw0, db0, dw2, db2, dtaw, dgamma, None, None, None, None, None, None
+        return dx, dpos, dw0, db0, dw2, db2, dtaw, dgamma, None, None, None, None, None, None, None
 
 
 # ======================================================================================================
+def _block_parts(x, n1w, n1b, n2w, n2b, f1w, f1b, packed, dims, mp, need_out, f2w=None, f2b=None):
+    """forward of one Block up to (and optionally including) the second channel-MLP GEMM; returns every intermediate
+    the backward needs.  Called by BlockFn.forward, and again by BlockFn.backward when activations are recomputed."""
+    B, tok, E, h, w, nb, bs, mx, my, mh, act = dims
+    Mm, M = B * mx * my, B * tok
+    dev = x.device
+    (wb1, bb1), (wb2, bb2) = packed
+    xn1, mean1, rstd1 = ops.groupnorm_fwd(x, n1w, n1b)
+    S = ops.rfft2(xn1, h, w, nb, mx, my, 0)                                # [Mm, 2E]
+    O1 = torch.empty(Mm, 2 * E, dtype=torch.float32, device=dev)
+    O1pre = torch.empty_like(O1)
+    kw = dict(lda=2 * E, ldb=2 * bs, ldc=2 * E, batch=nb, strideA=2 * bs, strideB=4 * bs * bs, strideC=2 * bs,
+              strideBias=2 * bs, tag=1)
+    ops.gemm(S, wb1, O1, Mm, 2 * bs, 2 * bs, bias=bb1, act=act, mode=EPI_ACT, preact=O1pre, ldpre=2 * E,
+             stridePre=2 * bs, **kw)
+    O2 = torch.empty_like(O1)
+    ops.gemm(O1, wb2, O2, Mm, 2 * bs, 2 * bs, bias=bb2, **kw)
+    y1 = ops.irfft2(O2, B, h, w, E, nb, mx, my, 1, res=xn1)                # + x_orig (the normalised input)
+    del O2, xn1
+    xn2, mean2, rstd2 = ops.groupnorm_fwd(y1, n2w, n2b)
+    Hh, Hpre = ops.linear_fwd(xn2.view(M, E), f1w, f1b, act=act, save_pre=True, precision=mp)
+    out = None
+    if need_out:
+        out, _ = ops.linear_fwd(Hh, f2w, f2b, res=x.view(M, E), precision=mp)
+    return out, (mean1, rstd1, S, O1pre, O1, y1, mean2, rstd2, xn2, Hpre, Hh)
+
+
 class BlockFn(torch.autograd.Function):
-    """x[B,tok,E] -> x + MLP(GN2(GN1(x) + irfft2(Mix(rfft2(GN1(x))))))"""
+    """x[B,tok,E] -> x + MLP(GN2(GN1(x) + irfft2(Mix(rfft2(GN1(x))))))
+
+    ``recompute=True`` (activation recomputation, for long auto-regressive rollouts at 256^2: SURVEY 7 risk "T_ar>1
+    backward"): only the block INPUT is kept; the backward re-runs the forward kernels (everything but the last GEMM)
+    to rebuild the 11 intermediates.  Same kernels, same order -> bit-identical gradients, ~1/20 of the memory."""
 
     @staticmethod
     def forward(ctx, x, n1w, n1b, w1, b1, w2, b2, n2w, n2b, f1w, f1b, f2w, f2b, h: int, w: int, nb: int, modes: int,
-                act: int, packed=None):
+                act: int, packed=None, recompute: bool = False):
         x = x.contiguous()
         B, tok, E = x.shape
         bs = E // nb
         mx, my = min(modes, h), min(modes, w // 2 + 1)
-        Mm = B * mx * my
         mh = f1w.shape[0]
-        M = B * tok
-        dev = x.device
-
-        xn1, mean1, rstd1 = ops.groupnorm_fwd(x, n1w, n1b)
-        S = ops.rfft2(xn1, h, w, nb, mx, my, 0)                                # [Mm, 2E]
-        if packed is not None:      # ((Wbig1, bbig1), (Wbig2, bbig2)) packed for all blocks at once by the model
-            (wb1, bb1), (wb2, bb2) = packed
-        else:
-            wb1, bb1 = ops.afno_pack(w1, b1)
-            wb2, bb2 = ops.afno_pack(w2, b2)
-        O1 = torch.empty(Mm, 2 * E, dtype=torch.float32, device=dev)
-        O1pre = torch.empty_like(O1)
-        kw = dict(lda=2 * E, ldb=2 * bs, ldc=2 * E, batch=nb, strideA=2 * bs, strideB=4 * bs * bs, strideC=2 * bs,
-                  strideBias=2 * bs, tag=1)
-        ops.gemm(S, wb1, O1, Mm, 2 * bs, 2 * bs, bias=bb1, act=act, mode=EPI_ACT, preact=O1pre, ldpre=2 * E,
-                 stridePre=2 * bs, **kw)
-        O2 = torch.empty_like(O1)
-        ops.gemm(O1, wb2, O2, Mm, 2 * bs, 2 * bs, bias=bb2, **kw)
-        y1 = ops.irfft2(O2, B, h, w, E, nb, mx, my, 1, res=xn1)                # + x_orig (the normalised input)
-        xn2, mean2, rstd2 = ops.groupnorm_fwd(y1, n2w, n2b)
+        if packed is None:      # ((Wbig1, bbig1), (Wbig2, bbig2)); normally packed for all blocks at once by the model
+            packed = (ops.afno_pack(w1, b1), ops.afno_pack(w2, b2))
+        dims = (B, tok, E, h, w, nb, bs, mx, my, mh, act)
         mp = ops.mlp_precision()                                               # channel-MLP GEMM precision override
-        Hh, Hpre = ops.linear_fwd(xn2.view(M, E), f1w, f1b, act=act, save_pre=True, precision=mp)
-        out, _ = ops.linear_fwd(Hh, f2w, f2b, res=x.view(M, E), precision=mp)
-        ctx.save_for_backward(x, mean1, rstd1, S, O1pre, O1, y1, mean2, rstd2, xn2, Hpre, Hh, wb1, wb2, n1w, n2w, f1w,
-                              f2w)
-        ctx.dims = (B, tok, E, h, w, nb, bs, mx, my, mh, act)
+        out, parts = _block_parts(x, n1w, n1b, n2w, n2b, f1w, f1b, packed, dims, mp, True, f2w, f2b)
+        wb1, wb2 = packed[0][0], packed[1][0]
+        if recompute:
+            ctx.save_for_backward(x, wb1, packed[0][1], wb2, packed[1][1], n1w, n1b, n2w, n2b, f1w, f1b, f2w)
+        else:
+            ctx.save_for_backward(x, *parts, wb1, wb2, n1w, n2w, f1w, f2w)
+        ctx.recompute = recompute
+        ctx.dims = dims
         ctx.mlp_precision = mp
         ctx.sinks = _sinks(ctx, (n1w, n1b, w1, b1, w2, b2, n2w, n2b, f1w, f1b, f2w, f2b), 1)
         return out.view(B, tok, E)
 
     @staticmethod
     def backward(ctx, dout):
-        (x, mean1, rstd1, S, O1pre, O1, y1, mean2, rstd2, xn2, Hpre, Hh, wb1, wb2, n1w, n2w, f1w,
-         f2w) = ctx.saved_tensors
+        mp = ctx.mlp_precision
+        if ctx.recompute:
+            x, wb1, bb1, wb2, bb2, n1w, n1b, n2w, n2b, f1w, f1b, f2w = ctx.saved_tensors
+            with torch.no_grad():
+                _, parts = _block_parts(x, n1w, n1b, n2w, n2b, f1w, f1b, ((wb1, bb1), (wb2, bb2)), ctx.dims, mp,
+                                        False)
+            mean1, rstd1, S, O1pre, O1, y1, mean2, rstd2, xn2, Hpre, Hh = parts
+        else:
+            (x, mean1, rstd1, S, O1pre, O1, y1, mean2, rstd2, xn2, Hpre, Hh, wb1, wb2, n1w, n2w, f1w,
+             f2w) = ctx.saved_tensors
         B, tok, E, h, w, nb, bs, mx, my, mh, act = ctx.dims
         s_n1w, s_n1b, s_w1, s_b1, s_w2, s_b2, s_n2w, s_n2b, s_f1w, s_f1b, s_f2w, s_f2b = ctx.sinks
         M, Mm = B * tok, B * mx * my
-        mp = ctx.mlp_precision
         dev = dout.device
         dout = dout.contiguous()
         do2 = dout.view(M, E)
@@ -260,15 +308,31 @@ class BlockFn(torch.autograd.Function):
         dn1w, dn1b = s_n1w.done(dn1w), s_n1b.done(dn1b)
         streams.join(dev)      # the side stream's readers of this frame's tensors are done before they can be freed
         return (dx, dn1w, dn1b, dw1, db1, dw2, db2, dn2w, dn2b, df1w, df1b, df2w, df2b, None, None, None, None, None,
-                None)
+                None, None)
 
 
 # ======================================================================================================
+def head_derived(o0w, o0b, o4w, o4b, P: int):
+    """weight-only layouts of the de-embed stage: ConvTranspose2d(k=s=P) weight as the GEMM matrix whose columns are
+    ordered (i, j, o) - the GEMM result IS the pixel-major [pixels, old] matrix -, its bias repeated per pixel, and
+    the zero-padded last 1x1 conv of the fused tail (None when the fused tail does not apply)"""
+    E, old = o0w.shape[0], o0w.shape[1]
+    co = o4w.shape[0]
+    PP = P * P
+    wt = ops.transpose2d(o0w, E, old, PP).view(E, PP * old)
+    bexp = ops.tile_vec(o0b, PP)
+    w4p = b4p = None
+    if old == 32 and 0 < co <= 32:
+        w4p, b4p = ops.out_tail_pad(o4w, o4b, co)
+    return wt, bexp, w4p, b4p
+
+
 class HeadFn(torch.autograd.Function):
     """x[B,tok,E] -> (pred [B,X,Y,T_out*C_out], cls_pred [B,n_cls])"""
 
     @staticmethod
-    def forward(ctx, x, o0w, o0b, o2w, o2b, o4w, o4b, c0w, c0b, c2w, c2b, c4w, c4b, h: int, w: int, P: int, act: int):
+    def forward(ctx, x, o0w, o0b, o2w, o2b, o4w, o4b, c0w, c0b, c2w, c2b, c4w, c4b, h: int, w: int, P: int, act: int,
+                derived=None):
         ctx.set_materialize_grads(False)      # an unused output (cls_pred in train_temporal.py:226) costs nothing
         x = x.contiguous()
         B, tok, E = x.shape
@@ -276,17 +340,16 @@ class HeadFn(torch.autograd.Function):
         PP = P * P
         M, Mp = B * tok, B * tok * PP
         dev = x.device
-        # ConvTranspose2d(k=s=P) as GEMM with columns ordered (i, j, o): the result IS the pixel-major [Mp, old] matrix
-        wt = ops.transpose2d(o0w, E, old, PP).view(E, PP * old)
-        bexp = o0b.repeat(PP)
         fused = ops.out_tail_supported(old, co, Mp)
+        if derived is None:
+            derived = head_derived(o0w, o0b, o4w, o4b, P)
+        wt, bexp, w4p, b4p = derived
         if fused:
             # GEMM writes only the pre-activation; the whole per-pixel tail (act, 1x1, act, 1x1, pixel shuffle) is one
             # kernel that reads it once (csrc/tail.hip)
             U = V = Vpre = None
             Upre = torch.empty(M, PP * old, dtype=torch.float32, device=dev)
             ops.gemm(x, wt, Upre, M, PP * old, E, lda=E, ldb=PP * old, ldc=PP * old, bias=bexp)
-            w4p, b4p = ops.out_tail_pad(o4w, o4b, co)
             pred = ops.out_tail_fwd(Upre, o2w, o2b, w4p, b4p, B, h, w, P, co, act)  # [B, X, Y, co]
             V = w4p                                                            # (saved slot reused: padded W4)
         else:
@@ -349,6 +412,9 @@ class HeadFn(torch.autograd.Function):
                      splitk=ops.auto_splitk(E, PP * old, M))
             do0w = s_o0w.done(ops.transpose2d(dwt, E, PP, old, out=s_o0w.out()).view(E, old, P, P))
             dx_out = dx_out.view(B, tok, E)
+        else:
+            for sk in ctx.sinks:
+                sk.skip()
         dx = dx_out
         if dcls is not None:
             # ---- cls head
@@ -364,7 +430,8 @@ class HeadFn(torch.autograd.Function):
             dc0w, dc0b = ops.linear_bwd_wb(dc1pre, cm, s_c0w.out(), s_c0b.out())
             dc0w, dc0b = s_c0w.done(dc0w), s_c0b.done(dc0b)
             dx = ops.token_mean_bwd(dcm, tok, add=dx_out)
-        return (dx, do0w, do0b, do2w, do2b, do4w, do4b, dc0w, dc0b, dc2w, dc2b, dc4w, dc4b, None, None, None, None)
+        return (dx, do0w, do0b, do2w, do2b, do4w, do4b, dc0w, dc0b, dc2w, dc2b, dc4w, dc4b, None, None, None, None,
+                None)
 
 
 # ======================================================================================================

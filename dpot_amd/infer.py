@@ -11,12 +11,15 @@
 """
 from __future__ import annotations
 
+import contextlib
+import warnings
 from collections import OrderedDict
 from typing import Dict, Iterable, Mapping, Optional, Tuple, Union
 
 import torch
 import torch.nn as nn
 
+from . import ops
 from .functional import rel_l2_loss
 
 Tensor = torch.Tensor
@@ -73,8 +76,12 @@ def load_components_from_pretrained(model: nn.Module, state_dict: Union[str, Map
             model.time_agg_layer.load_state_dict(_sub(sd, "time_agg_layer."))
         elif name == "out" and hasattr(model, "out_layer"):
             model.out_layer.load_state_dict(_sub(sd, "out_layer."))
+        elif name in COMPONENTS:
+            # utils/utilities.py:163 prints 'Submodule does not exists' and carries on: fine-tune configs list e.g.
+            # 'scale_feats' for models built with normalize=False
+            warnings.warn(f"load_components_from_pretrained: this model has no {name!r} component - skipped")
         else:
-            raise KeyError(f"no such component in this model: {name!r} (known: {COMPONENTS})")
+            raise KeyError(f"unknown component {name!r} (known: {COMPONENTS})")
 
 
 # ------------------------------------------------------------------------------------------------------
@@ -83,17 +90,22 @@ def rollout_eval(model: nn.Module, xx: Tensor, yy: Tensor, msk: Optional[Tensor]
                  step=None) -> Tuple[Tensor, Tensor, Tensor]:
     """evaluate.py:193-213.  Returns (pred [B,X,Y,T_ar,C], sum of the per-step losses, loss of the whole rollout).
     `step(xx) -> im` defaults to the model's forward (a GraphedRollout passes its graph replay)."""
+    # weight-only products (packed AFNO weights, folded embed matrices, ...) once per rollout, not once per AR step
+    scope = model.weights_scope() if (step is None and hasattr(model, "weights_scope")) else contextlib.nullcontext()
     step = step or (lambda x: model(x)[0])
     T_ar = yy.shape[-2]
     loss_steps = None
     preds = []
-    for t in range(0, T_ar, T_bundle):
-        y = yy[..., t:t + T_bundle, :]
-        im = step(xx)
-        l = rel_l2_loss(im, y.contiguous(), msk)
-        loss_steps = l if loss_steps is None else loss_steps + l
-        preds.append(im)
-        xx = torch.cat((xx[..., T_bundle:, :], im), dim=-2)
+    xx = xx.contiguous()
+    with scope:
+        for t in range(0, T_ar, T_bundle):
+            y = yy[..., t:t + T_bundle, :]
+            im = step(xx)
+            l = rel_l2_loss(im, y.contiguous(), msk)
+            loss_steps = l if loss_steps is None else loss_steps + l
+            preds.append(im)
+            if t + T_bundle < T_ar:
+                xx = ops.window_slide(xx, im.contiguous())               # xx[..., T_bundle:, :] ++ im, one kernel
     pred = preds[0] if len(preds) == 1 else torch.cat(preds, dim=-2)
     loss_full = rel_l2_loss(pred.contiguous(), yy.contiguous(), msk)
     return pred, loss_steps, loss_full

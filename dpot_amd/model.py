@@ -19,7 +19,9 @@ import torch
 import torch.nn as nn
 
 from . import _lib, ops
-from .functional import BlockFn, EmbedFn, HeadFn
+import contextlib
+
+from .functional import BlockFn, EmbedFn, HeadFn, embed_derived, head_derived
 
 ACTIVATIONS = ("gelu", "tanh", "sigmoid", "relu", "leaky_relu", "softplus", "ELU", "silu")
 
@@ -112,7 +114,49 @@ class DPOTNet(nn.Module):
             self.register_buffer(name, torch.tensor(np.linspace(0, 1, n), dtype=torch.float32), persistent=False)
         self.register_buffer("_tt", torch.linspace(0, 1, in_timesteps), persistent=False)
 
+        # activation recomputation inside every Block (functional.BlockFn): keep only block inputs between forward
+        # and backward - for long auto-regressive rollouts at 256^2 (BASELINE configs[4])
+        self.recompute_blocks = False
+        self._scope_depth = 0
+        self._scope_cache = None
+        # optional callable(b, lat) -> lat, called with the latent ENTERING stage b (1..depth = block b-1,
+        # depth+1 = the head); train.SegmentedTrainStep cuts the autograd graph there
+        self._boundary_hook = None
+
     # ------------------------------------------------------------------------------------------------
+    @contextlib.contextmanager
+    def weights_scope(self):
+        """Inside this scope the weight-only products of the forward (block-diagonal complex weights packed as real
+        GEMM matrices, padded / transposed conv weights, the folded embed matrices) are computed by the FIRST forward
+        call and re-used by the following ones: an auto-regressive rollout calls the model T_ar times per optimiser
+        step on unchanged weights (train_temporal.py:201-219, evaluate.py:193-213).  The caller promises not to
+        modify parameters inside the scope; outside a scope every forward derives them afresh."""
+        self._scope_depth += 1
+        if self._scope_depth == 1:
+            self._scope_cache = None
+        try:
+            yield self
+        finally:
+            self._scope_depth -= 1
+            if self._scope_depth == 0:
+                self._scope_cache = None
+
+    def _derived_weights(self):
+        if self._scope_depth > 0 and self._scope_cache is not None:
+            return self._scope_cache
+        pe, ta, ol = self.patch_embed.proj, self.time_agg_layer, self.out_layer
+        emb = embed_derived(self.pos_embed, pe[0].weight, pe[0].bias, pe[2].weight, pe[2].bias, ta.w,
+                            ta.gamma if self.time_agg == "exp_mlp" else None, self._tt, self.in_timesteps)
+        # Wbig = [[Wr, Wi], [-Wi, Wr]] of every AFNO layer, packed in ONE launch (2*depth tiny launches otherwise)
+        pk = ops.afno_pack_multi([p for blk in self.blocks for p in ((blk.filter.w1, blk.filter.b1),
+                                                                     (blk.filter.w2, blk.filter.b2))]) \
+            if len(self.blocks) else []
+        head = head_derived(ol[0].weight, ol[0].bias, ol[4].weight, ol[4].bias, self.patch_size)
+        d = (emb, pk, head)
+        if self._scope_depth > 0:
+            self._scope_cache = d
+        return d
+
     def forward(self, x):
         if not x.is_cuda:
             raise _lib.DpotHipError("DPOTNet (dpot_amd) runs on MI355X only: move the model and the input to 'cuda'. "
@@ -134,25 +178,28 @@ class DPOTNet(nn.Module):
         pe, ta = self.patch_embed.proj, self.time_agg_layer
         P = self.patch_size
         h = self.latent_size[0]
+        d_emb, pk, d_head = self._derived_weights()
         lat = EmbedFn.apply(x, self.pos_embed, pe[0].weight, pe[0].bias, pe[2].weight, pe[2].bias, ta.w,
                             ta.gamma if self.time_agg == "exp_mlp" else None, self._gx, self._gy, self._gt, self._tt,
-                            P, self._act)
+                            P, self._act, d_emb)
         if self.normalize:
             lat = s_sigma[:, None, :] * lat + s_mu[:, None, :]          # AdaIN (models/dpot.py:386-387)
-        # Wbig = [[Wr, Wi], [-Wi, Wr]] of every AFNO layer, packed in ONE launch (2*depth tiny launches otherwise)
-        pk = ops.afno_pack_multi([p for blk in self.blocks for p in ((blk.filter.w1, blk.filter.b1),
-                                                                     (blk.filter.w2, blk.filter.b2))]) \
-            if len(self.blocks) else []
+        recompute = self.recompute_blocks and torch.is_grad_enabled()
+        hook = self._boundary_hook
         for i, blk in enumerate(self.blocks):
+            if hook is not None:
+                lat = hook(i + 1, lat)
             f = blk.filter
             lat = BlockFn.apply(lat, blk.norm1.weight, blk.norm1.bias, f.w1, f.b1, f.w2, f.b2, blk.norm2.weight,
                                 blk.norm2.bias, blk.mlp[0].weight, blk.mlp[0].bias, blk.mlp[2].weight,
                                 blk.mlp[2].bias, h, h, self.n_blocks, self.modes, self._act,
-                                (pk[2 * i], pk[2 * i + 1]))
+                                (pk[2 * i], pk[2 * i + 1]), recompute)
+        if hook is not None:
+            lat = hook(len(self.blocks) + 1, lat)
         ol, ch = self.out_layer, self.cls_head
         pred, cls_pred = HeadFn.apply(lat, ol[0].weight, ol[0].bias, ol[2].weight, ol[2].bias, ol[4].weight,
                                       ol[4].bias, ch[0].weight, ch[0].bias, ch[2].weight, ch[2].bias, ch[4].weight,
-                                      ch[4].bias, h, h, P, self._act)
+                                      ch[4].bias, h, h, P, self._act, d_head)
         pred = pred.view(B, X, Y, self.out_timesteps, self.out_channels)
         if self.normalize:
             pred = pred * sigma + mu

@@ -340,6 +340,14 @@ def bias_add(x: Tensor, v: Tensor) -> Tensor:
     return y
 
 
+def tile_vec(v: Tensor, reps: int) -> Tensor:
+    """v [N] repeated `reps` times -> [reps * N]"""
+    N = v.numel()
+    y = torch.empty(reps * N, dtype=torch.float32, device=v.device)
+    check(_lib.load().dpot_bias_add(None, v.data_ptr(), y.data_ptr(), reps, N, _stream()), "tile_vec")
+    return y
+
+
 def scale_shift(x: Tensor, scale: Tensor, shift: Tensor) -> Tensor:
     B, T, E = x.shape
     y = torch.empty_like(x)
@@ -446,6 +454,14 @@ def adam_step(p: Tensor, g: Tensor, m: Tensor, v: Tensor, hyper: Tensor, sumsq_:
                                      hyper.data_ptr(), _p(sumsq_), grad_scale, _stream()), "adam_step")
 
 
+def adam_stage(hyper: Tensor, step: Tensor, lr: float, beta1: float, beta2: float, eps: float, weight_decay: float,
+               max_norm: float, advance: int = 1) -> None:
+    """step[0] += advance; hyper <- {lr, betas, eps, wd, bias corrections(step), max_norm}; every value travels by
+    value in the launch packet (no host buffer that a later step could overwrite)"""
+    check(_lib.load().dpot_adam_stage(hyper.data_ptr(), step.data_ptr(), lr, beta1, beta2, eps, weight_decay,
+                                      max_norm, advance, _stream()), "adam_stage")
+
+
 _rng_states = {}
 
 
@@ -458,8 +474,9 @@ def rng_state(device) -> Tensor:
     return _rng_states[key]
 
 
-def noise_inject(xx: Tensor, eps: Optional[Tensor], noise_scale: float) -> Tensor:
-    """xx + noise_scale * ||xx||_(X,Y,T) * eps;  eps=None: eps ~ N(0,1) is drawn inside the kernel"""
+def noise_inject(xx: Tensor, eps: Optional[Tensor], noise_scale: float, return_norms: bool = False):
+    """xx + noise_scale * ||xx||_(X,Y,T) * eps;  eps=None: eps ~ N(0,1) is drawn inside the kernel.
+    return_norms: also return the scratch tensor whose first B*C floats are the per-(b,c) norms (for the backward)"""
     B, Cc = xx.shape[0], xx.shape[-1]
     S = xx.numel() // (B * Cc)
     out = torch.empty_like(xx)
@@ -468,7 +485,43 @@ def noise_inject(xx: Tensor, eps: Optional[Tensor], noise_scale: float) -> Tenso
     if eps is None:
         check(lib.dpot_noise_inject_rng(xx.data_ptr(), out.data_ptr(), norms.data_ptr(), rng_state(xx.device).data_ptr(),
                                         noise_scale, B, S, Cc, _stream()), "noise_inject_rng")
-        return out
-    check(lib.dpot_noise_inject(xx.data_ptr(), eps.data_ptr(), out.data_ptr(), norms.data_ptr(), noise_scale,
-                                        B, S, Cc, _stream()), "noise_inject")
+    else:
+        check(lib.dpot_noise_inject(xx.data_ptr(), eps.data_ptr(), out.data_ptr(), norms.data_ptr(), noise_scale,
+                                    B, S, Cc, _stream()), "noise_inject")
+    return (out, norms) if return_norms else out
+
+
+def noise_inject_bwd(xx: Tensor, eps: Optional[Tensor], rng_snapshot: Optional[Tensor], g: Tensor, norms: Tensor,
+                     noise_scale: float) -> Tensor:
+    """d/dxx of noise_inject: g + noise_scale * xx / ||xx|| * sum(g * eps); eps given, or re-drawn from the
+    generator state the forward used (rng_snapshot = clone of rng_state() taken right after the forward call)"""
+    B, Cc = xx.shape[0], xx.shape[-1]
+    S = xx.numel() // (B * Cc)
+    lib = _lib.load()
+    dx = torch.empty_like(xx)
+    part = torch.empty(B * Cc * lib.dpot_noise_chunks(S, Cc), dtype=torch.float32, device=xx.device)
+    check(lib.dpot_noise_inject_bwd(xx.data_ptr(), _p(eps), _p(rng_snapshot), g.data_ptr(), norms.data_ptr(),
+                                    dx.data_ptr(), part.data_ptr(), noise_scale, B, S, Cc, _stream()),
+          "noise_inject_bwd")
+    return dx
+
+
+def window_slide(xx: Tensor, im: Tensor) -> Tensor:
+    """cat(xx[..., Tb:, :], im) along the time axis of [B,X,Y,T,C] (train_temporal.py:219)"""
+    T, Cc = xx.shape[-2], xx.shape[-1]
+    Tb = im.shape[-2]
+    rows = xx.numel() // (T * Cc)
+    out = torch.empty_like(xx)
+    check(_lib.load().dpot_window_slide(xx.data_ptr(), im.data_ptr(), out.data_ptr(), rows, T, Tb, Cc, _stream()),
+          "window_slide")
     return out
+
+
+def window_slide_bwd(dout: Tensor, Tb: int, need_xx: bool, need_im: bool):
+    T, Cc = dout.shape[-2], dout.shape[-1]
+    rows = dout.numel() // (T * Cc)
+    dxx = torch.empty_like(dout) if need_xx else None
+    dim = torch.empty(dout.shape[:-2] + (Tb, Cc), dtype=torch.float32, device=dout.device) if need_im else None
+    check(_lib.load().dpot_window_slide_bwd(dout.data_ptr(), _p(dxx), _p(dim), rows, T, Tb, Cc, _stream()),
+          "window_slide_bwd")
+    return dxx, dim

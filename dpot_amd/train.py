@@ -10,6 +10,7 @@
 """
 from __future__ import annotations
 
+import contextlib
 import math
 from typing import Callable, Dict, Iterable, List, Optional, Sequence, Tuple
 
@@ -30,9 +31,22 @@ class FlatParams:
     single-GPU training, train_temporal.py:226) at the end, so the optimiser can address 'everything with a
     gradient' as one contiguous prefix."""
 
+    # forward execution order of DPOTNet's sub-modules (registration order puts time_agg_layer after the blocks):
+    # gradients then become final from the END of the buffer towards its start, so contiguous buckets can be
+    # all-reduced while the rest of the backward still runs (dp.py)
+    EXEC_ORDER = ("patch_embed.", "pos_embed", "time_agg_layer.", "scale_feats_", "blocks.", "out_layer.")
+
+    @classmethod
+    def _exec_rank(cls, name: str):
+        for i, pre in enumerate(cls.EXEC_ORDER):
+            if name.startswith(pre):
+                return (i, int(name.split(".")[1])) if pre == "blocks." else (i, 0)
+        return (len(cls.EXEC_ORDER), 0)
+
     def __init__(self, model: nn.Module, tail_prefixes: Sequence[str] = ("cls_head.",)):
         named = [(n, p) for n, p in model.named_parameters() if p.requires_grad]
         head = [(n, p) for n, p in named if not any(n.startswith(t) for t in tail_prefixes)]
+        head.sort(key=lambda np_: self._exec_rank(np_[0]))                     # stable: registration order within a module
         tail = [(n, p) for n, p in named if any(n.startswith(t) for t in tail_prefixes)]
         self.names = [n for n, _ in head + tail]
         self.params = [p for _, p in head + tail]
@@ -81,7 +95,13 @@ class FlatParams:
 class FusedAdam:
     """Adam with L2 weight decay folded into the gradient (utils/optimizer.py:9-52 semantics) + global-norm clip
     (train_temporal.py:228), as ONE kernel over the flat buffer.  ``update_tail=False`` reproduces the single-GPU
-    reference where cls_head has no gradient and is therefore skipped by the optimiser."""
+    reference where cls_head has no gradient and is therefore skipped by the optimiser.
+
+    Host/device protocol of a step: ``stage_hyper(lr)`` enqueues a one-thread kernel that receives lr / betas / eps /
+    weight decay / max_norm BY VALUE, advances the DEVICE-side step counter and derives the bias corrections from
+    it; ``launch()`` (capturable) enqueues ||g||^2 + the fused clip+Adam kernel, which read those values from device
+    memory.  There is no host staging buffer, so a host that runs many (graph-replayed) steps ahead of the GPU
+    cannot disturb a step that is still queued."""
 
     def __init__(self, flat: FlatParams, lr: float = 1e-3, betas: Tuple[float, float] = (0.9, 0.999),
                  eps: float = 1e-8, weight_decay: float = 0.0, max_norm: Optional[float] = None,
@@ -94,10 +114,10 @@ class FusedAdam:
         self.exp_avg = torch.zeros_like(flat.flat)
         self.exp_avg_sq = torch.zeros_like(flat.flat)
         self.hyper = torch.zeros(8, dtype=torch.float32, device=dev)
-        self._hyper_host = torch.zeros(8, dtype=torch.float32).pin_memory() if dev.type == "cuda" else torch.zeros(8)
+        self.step_dev = torch.zeros(1, dtype=torch.int64, device=dev)     # the step counter the kernels use
         self.sumsq = torch.zeros(1, dtype=torch.float32, device=dev)
         self._part = torch.zeros(1024, dtype=torch.float32, device=dev)
-        self.step_count = 0
+        self.step_count = 0                       # host mirror of step_dev (number of steps ENQUEUED)
         self.param_groups = [{"lr": lr}]          # minimal torch.optim surface for LR schedulers / logging
 
     @property
@@ -107,19 +127,14 @@ class FusedAdam:
     def zero_grad(self) -> None:
         self.fp.zero_grad()
 
-    def stage_hyper(self, lr: Optional[float] = None) -> None:
-        """host side of a step: advance the step counter and ship {lr, betas, eps, wd, bias corrections, max_norm}
-        to the device (async copy from pinned memory - safe to call right before a graph replay)."""
+    def stage_hyper(self, lr: Optional[float] = None, advance: int = 1) -> None:
+        """host side of a step (NOT capturable by design: call it right before a graph replay)"""
         if lr is not None:
             self.lr = lr
             self.param_groups[0]["lr"] = lr
-        self.step_count += 1
-        b1, b2 = self.betas
-        h = self._hyper_host
-        h[0], h[1], h[2], h[3], h[4] = self.lr, b1, b2, self.eps, self.weight_decay
-        h[5], h[6] = 1.0 - b1 ** self.step_count, 1.0 - b2 ** self.step_count
-        h[7] = self.max_norm if self.max_norm is not None else 0.0
-        self.hyper.copy_(h, non_blocking=True)
+        self.step_count += advance
+        ops.adam_stage(self.hyper, self.step_dev, self.lr, self.betas[0], self.betas[1], self.eps, self.weight_decay,
+                       self.max_norm if self.max_norm is not None else 0.0, advance)
 
     def launch(self, grad_scale: float = 1.0) -> None:
         """device side of a step (capturable): ||g||^2 then fused clip + Adam."""
@@ -136,8 +151,72 @@ class FusedAdam:
         self.launch(grad_scale)
 
     def grad_norm(self, grad_scale: float = 1.0) -> Tensor:
-        """global gradient norm of the last step (device tensor; reading it synchronises)"""
+        """global gradient norm of the gradients currently in the flat buffer (device tensor; reading it
+        synchronises).  With clipping enabled this is the value the last step used; without, it is computed here."""
+        if self.max_norm is None:
+            ops.sumsq(self.fp.grad[:self.n_active], self.sumsq, self._part)
         return self.sumsq.sqrt() * grad_scale
+
+    # -- snapshot / restore (graph warm-up, tests) --------------------------------------------------------
+    def snapshot(self):
+        return (self.fp.flat.clone(), self.exp_avg.clone(), self.exp_avg_sq.clone(), self.step_dev.clone(),
+                self.step_count, self.lr)
+
+    def restore(self, snap) -> None:
+        flat, m, v, sd, sc, lr = snap
+        self.fp.flat.copy_(flat)
+        self.exp_avg.copy_(m)
+        self.exp_avg_sq.copy_(v)
+        self.step_dev.copy_(sd)
+        self.step_count, self.lr = sc, lr
+        self.param_groups[0]["lr"] = lr
+
+    # -- checkpoint format of the reference: torch.optim state_dict (train_temporal.py:244,281) ------------
+    def state_dict(self, model: nn.Module) -> dict:
+        """{'state': {i: {'step', 'exp_avg', 'exp_avg_sq'}}, 'param_groups': [...]} with i = index of the parameter
+        in ``model.parameters()`` order - what ``torch.save({'optimizer': optimizer.state_dict()})`` of the
+        reference's Adam (utils/optimizer.py:101-164) holds.  Parameters the optimiser never updates (cls_head in
+        single-GPU training) have no state entry, as in the reference."""
+        order = {id(p): i for i, p in enumerate(model.parameters())}
+        n_act = self.n_active
+        state = {}
+        step = int(self.step_dev.item())
+        for p, off in zip(self.fp.params, self.fp.offsets):
+            if off >= n_act or step == 0:
+                continue
+            n = p.numel()
+            state[order[id(p)]] = {"step": step,
+                                   "exp_avg": self.exp_avg[off:off + n].view(p.shape).clone(),
+                                   "exp_avg_sq": self.exp_avg_sq[off:off + n].view(p.shape).clone()}
+        group = {"lr": self.lr, "betas": tuple(self.betas), "eps": self.eps, "weight_decay": self.weight_decay,
+                 "amsgrad": False, "params": list(range(len(order)))}
+        return {"state": state, "param_groups": [group]}
+
+    def load_state_dict(self, sd: dict, model: nn.Module) -> None:
+        order = {id(p): i for i, p in enumerate(model.parameters())}
+        steps = set()
+        with torch.no_grad():
+            self.exp_avg.zero_()
+            self.exp_avg_sq.zero_()
+            for p, off in zip(self.fp.params, self.fp.offsets):
+                st = sd["state"].get(order[id(p)])
+                if st is None:
+                    continue
+                n = p.numel()
+                self.exp_avg[off:off + n].copy_(st["exp_avg"].reshape(-1))
+                self.exp_avg_sq[off:off + n].copy_(st["exp_avg_sq"].reshape(-1))
+                steps.add(int(st["step"]))
+        if len(steps) > 1:
+            raise ValueError(f"per-parameter step counts differ ({sorted(steps)}): the fused optimiser keeps one")
+        step = steps.pop() if steps else 0
+        self.step_dev.fill_(step)
+        self.step_count = step
+        g = sd.get("param_groups", [{}])[0]
+        self.lr = g.get("lr", self.lr)
+        self.betas = tuple(g.get("betas", self.betas))
+        self.eps = g.get("eps", self.eps)
+        self.weight_decay = g.get("weight_decay", self.weight_decay)
+        self.param_groups[0]["lr"] = self.lr
 
 
 # ------------------------------------------------------------------------------------------------------
@@ -162,47 +241,76 @@ def one_cycle_lr(step: int, total_steps: int, max_lr: float, pct_start: float = 
 def rollout(model: nn.Module, xx: Tensor, yy: Tensor, msk: Optional[Tensor], T_bundle: int = 1,
             noise_scale: float = 0.0, noise: Optional[List[Tensor]] = None) -> Tuple[Tensor, Tensor]:
     """auto-regressive rollout with summed per-step loss (train_temporal.py:201-219)"""
+    scope = model.weights_scope() if hasattr(model, "weights_scope") else contextlib.nullcontext()
+    with scope:
+        return _rollout(model, xx, yy, msk, T_bundle, noise_scale, noise)
+
+
+def _rollout(model, xx, yy, msk, T_bundle, noise_scale, noise):
     loss = None
     preds = []
     T_ar = yy.shape[-2]
+    xx = ops._req(xx.contiguous(), "xx")
     for k, t in enumerate(range(0, T_ar, T_bundle)):
         y = yy[..., t:t + T_bundle, :]
         if noise_scale != 0.0:
             if noise is None and not xx.requires_grad and xx.numel() % 4 == 0:
                 # first AR step of training: nothing to differentiate -> draw the noise inside the kernel
-                xx = ops.noise_inject(ops._req(xx.contiguous(), "xx"), None, noise_scale)
+                xx = ops.noise_inject(xx, None, noise_scale)
             else:
-                eps = noise[k] if noise is not None else torch.randn_like(xx)
-                xx = _NoiseFn.apply(xx, eps, noise_scale)
+                xx = _NoiseFn.apply(xx, noise[k] if noise is not None else None, noise_scale)
         im, _ = model(xx)
         l = rel_l2_loss(im, y, msk)
         loss = l if loss is None else loss + l
         preds.append(im)
         if t + T_bundle < T_ar:
-            xx = torch.cat((xx[..., T_bundle:, :], im), dim=-2)
+            xx = _SlideFn.apply(xx, im)
     pred = preds[0] if len(preds) == 1 else torch.cat(preds, dim=-2)
     return loss, pred
 
 
 class _NoiseFn(torch.autograd.Function):
-    """xx + noise_scale * ||xx|| * eps (train_temporal.py:205).  The reference lets autograd differentiate through
-    the norm as well; that term is O(noise_scale) and is kept here through a straight-through identity gradient
-    plus the exact norm term only when xx requires grad (AR steps > 0)."""
+    """xx + noise_scale * ||xx|| * eps (train_temporal.py:205) for AR steps whose input carries a gradient.  Like
+    the reference's autograd, the backward differentiates through the norm as well:
+    d/dxx = g + s * xx / ||xx|| * sum(g * eps)  (csrc/loss_opt.hip noise_bwd_*).  eps=None: drawn by the in-kernel
+    generator in forward and RE-drawn in backward from a 16-byte copy of the generator state (no eps tensor)."""
 
     @staticmethod
     def forward(ctx, xx, eps, noise_scale):
-        ctx.save_for_backward(xx, eps)
-        ctx.noise_scale = noise_scale
-        return ops.noise_inject(xx.contiguous(), eps.contiguous(), noise_scale)
+        xx = xx.contiguous()
+        rng = None
+        if eps is None and xx.numel() % 4 != 0:
+            eps = torch.randn_like(xx)                      # shapes the in-kernel generator does not cover
+        if eps is not None:
+            eps = eps.contiguous()
+        out, norms = ops.noise_inject(xx, eps, noise_scale, return_norms=True)
+        if eps is None:
+            rng = ops.rng_state(xx.device).clone()         # {seed, offset} this call drew from
+        ctx.save_for_backward(xx, eps if eps is not None else xx.new_empty(0), norms,
+                              rng if rng is not None else xx.new_empty(0))
+        ctx.noise_scale, ctx.has_eps = noise_scale, eps is not None
+        return out
 
     @staticmethod
     def backward(ctx, g):
-        xx, eps = ctx.saved_tensors
-        # d/dxx [xx + s * n(xx) * eps],  n = ||xx||_2 over (X,Y,T) per (b,c):  g + s * xx / n * sum(g * eps)
-        dims = tuple(range(1, xx.dim() - 1))
-        n = torch.sum(xx ** 2, dim=dims, keepdim=True) ** 0.5
-        corr = ctx.noise_scale * xx / n.clamp_min(1e-30) * torch.sum(g * eps, dim=dims, keepdim=True)
-        return g + corr, None, None
+        xx, eps, norms, rng = ctx.saved_tensors
+        dx = ops.noise_inject_bwd(xx, eps if ctx.has_eps else None, None if ctx.has_eps else rng, g.contiguous(),
+                                  norms, ctx.noise_scale)
+        return dx, None, None
+
+
+class _SlideFn(torch.autograd.Function):
+    """xx <- cat(xx[..., T_bundle:, :], im) (train_temporal.py:219) as one kernel each way"""
+
+    @staticmethod
+    def forward(ctx, xx, im):
+        ctx.Tb = im.shape[-2]
+        return ops.window_slide(ops._req(xx.contiguous(), "xx"), ops._req(im.contiguous(), "im"))
+
+    @staticmethod
+    def backward(ctx, dout):
+        dxx, dim = ops.window_slide_bwd(dout.contiguous(), ctx.Tb, ctx.needs_input_grad[0], ctx.needs_input_grad[1])
+        return dxx, dim
 
 
 def train_step(model: nn.Module, opt: FusedAdam, xx: Tensor, yy: Tensor, msk: Optional[Tensor], T_bundle: int = 1,
@@ -234,18 +342,26 @@ class GraphedTrainStep:
         self.model, self.opt = model, opt
         self.xx, self.yy = xx.clone(), yy.clone()
         self.msk = msk.clone() if msk is not None else None
-        self.reducer, self.grad_scale = reducer, grad_scale
+        if reducer is not None and getattr(reducer, "world", 1) > 1:
+            raise ValueError("GraphedTrainStep captures the WHOLE step into one graph and cannot hold collectives: "
+                             "use SegmentedTrainStep for data-parallel training")
+        self.reducer, self.grad_scale = None, grad_scale
         self.T_bundle, self.noise_scale = T_bundle, noise_scale
+        # eager warm-up on a side stream (allocator + lazy inits).  The warm-up iterations are NOT training steps:
+        # parameters, Adam moments and the step counter are restored afterwards (a fine-tune of a pretrained
+        # checkpoint must not receive unscheduled full-lr updates before its first replay)
+        snap = opt.snapshot()
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
-            for _ in range(warmup):                 # eager warm-up on a side stream (allocator + lazy inits)
+            for _ in range(warmup):
                 self._body(stage=True)
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
+        opt.restore(snap)
         self.graph = torch.cuda.CUDAGraph()
         opt.zero_grad()
-        with torch.cuda.graph(self.graph):
+        with torch.cuda.graph(self.graph, capture_error_mode="thread_local"):
             self.loss, self.pred = self._body(stage=False)
         self.warmup_steps = warmup
 
@@ -254,12 +370,8 @@ class GraphedTrainStep:
         if stage:
             opt.stage_hyper(opt.lr)
         opt.zero_grad()
-        if self.reducer is not None:
-            self.reducer.begin_step()
         loss, pred = rollout(self.model, self.xx, self.yy, self.msk, self.T_bundle, self.noise_scale)
         loss.backward()
-        if self.reducer is not None:
-            self.reducer.finish()
         opt.launch(self.grad_scale)
         return loss.detach(), pred.detach()
 
@@ -272,4 +384,116 @@ class GraphedTrainStep:
     def replay(self, lr: Optional[float] = None) -> Tensor:
         self.opt.stage_hyper(lr)
         self.graph.replay()
+        return self.loss
+
+
+class SegmentedTrainStep:
+    """The data-parallel train step (T_ar = 1 rollout step) as a CHAIN of hipGraphs, cut where a gradient bucket
+    becomes final, so that the RCCL all-reduce of bucket k runs on the reducer's side stream while the compute stream
+    replays the backward of the earlier stages - the overlap torch-DDP gets from autograd hooks
+    (train_temporal_parallel.py:244), without a collective inside a capture and without eager launch overhead.
+
+        segment 0      zero_grad, forward, loss, backward of [out layer .. first stage of the LAST bucket]
+        segment j      backward of the stages of the j-th bucket from the end
+        optimiser      ||g||^2 + fused clip + Adam          (after the compute stream has joined the side stream)
+
+    The autograd graph is cut at the bucket boundaries (``DPOTNet._boundary_hook``): each cut replaces the latent by a
+    detached leaf; the next segment continues with ``out.backward(leaf.grad)``.  All segments share one memory pool
+    and are always replayed in capture order."""
+
+    def __init__(self, model: nn.Module, opt: FusedAdam, reducer, xx: Tensor, yy: Tensor, msk: Optional[Tensor],
+                 noise_scale: float = 0.0, warmup: int = 2):
+        assert yy.shape[-2] == getattr(model, "out_timesteps", yy.shape[-2]), "SegmentedTrainStep: T_ar = T_bundle only"
+        self.model, self.opt, self.reducer = model, opt, reducer
+        self.xx, self.yy = xx.clone(), yy.clone()
+        self.msk = msk.clone() if msk is not None else None
+        self.noise_scale = noise_scale
+        self.grad_scale = reducer.grad_scale
+        depth = len(model.blocks)
+        norm = lambda st: depth + 1 if st == 10 ** 6 else st          # stage number -> boundary index
+        # buckets in backward order (tail excluded); a bucket whose first stage is b > 0 needs a cut at boundary b
+        self.bwd_buckets = [k for k in range(reducer.n_buckets - 1, -1, -1) if k != reducer.tail_bucket]
+        self.cut_at = sorted({norm(reducer.first_stage_of_bucket(k)) for k in self.bwd_buckets} - {0})
+        snap = opt.snapshot()
+        reducer.detach()
+        try:
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                for _ in range(warmup):
+                    opt.stage_hyper(opt.lr)
+                    for fn in self._segment_fns():
+                        fn()
+                    opt.launch(self.grad_scale)
+            torch.cuda.current_stream().wait_stream(side)
+            torch.cuda.synchronize()
+            opt.restore(snap)
+            self.graphs: List[torch.cuda.CUDAGraph] = []
+            pool = torch.cuda.graph_pool_handle()
+            for fn in self._segment_fns():
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g, pool=pool, capture_error_mode="thread_local"):
+                    fn()
+                self.graphs.append(g)
+            self.opt_graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self.opt_graph, pool=pool, capture_error_mode="thread_local"):
+                opt.launch(self.grad_scale)
+        finally:
+            reducer.attach()
+            model._boundary_hook = None
+        self.tail_has_grad = reducer.tail_bucket >= 0 and any(opt.fp.filled[i]
+                                                              for i in reducer.members[reducer.tail_bucket])
+        assert len(self.graphs) == len(self.bwd_buckets), (len(self.graphs), self.bwd_buckets)
+
+    def _segment_fns(self):
+        """generator of the segment bodies; segment j+1 may only be built after segment j has run"""
+        cuts = []
+        cut_at = set(self.cut_at)
+
+        def hook(b, lat):
+            if b in cut_at and lat.requires_grad:
+                leaf = lat.detach().requires_grad_(True)
+                cuts.append((lat, leaf))
+                return leaf
+            return lat
+
+        def first():
+            self.opt.zero_grad()
+            self.model._boundary_hook = hook
+            try:
+                loss, pred = rollout(self.model, self.xx, self.yy, self.msk, 1, self.noise_scale)
+            finally:
+                self.model._boundary_hook = None
+            loss.backward()
+            self.loss, self.pred = loss.detach(), pred.detach()
+
+        yield first
+        # one further segment per cut, from the last cut to the first
+        n = len(self.cut_at)
+        for j in range(n - 1, -1, -1):
+            def seg(j=j):
+                out, leaf = cuts[j]
+                out.backward(leaf.grad)
+                leaf.grad = None
+            yield seg
+
+    def stage(self, xx: Tensor, yy: Tensor, msk: Optional[Tensor] = None) -> None:
+        self.xx.copy_(xx, non_blocking=True)
+        self.yy.copy_(yy, non_blocking=True)
+        if msk is not None and self.msk is not None:
+            self.msk.copy_(msk, non_blocking=True)
+
+    def replay(self, lr: Optional[float] = None) -> Tensor:
+        red = self.reducer
+        self.opt.stage_hyper(lr)
+        red.begin_step()
+        for g, k in zip(self.graphs, self.bwd_buckets):
+            g.replay()
+            red.reduce_bucket(k)              # side stream waits for the compute stream, then all-reduces bucket k
+        if self.tail_has_grad:
+            red.reduce_bucket(red.tail_bucket)
+        else:
+            red._launched[red.tail_bucket] = True
+        red.finish()                          # compute stream joins the side stream
+        self.opt_graph.replay()
         return self.loss

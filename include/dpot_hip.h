@@ -218,7 +218,8 @@ int dpot_token_mean_bwd(const float* dy, const float* add, float* dx, int B, int
                         dpot_stream_t stream);
 /* y = a + b (n floats) */
 int dpot_add(const float* a, const float* b, float* y, int64_t n, dpot_stream_t stream);
-/* y[r, n] = x[r, n] + v[n]   (row-broadcast add; pos_embed + conv bias folded ahead of the TimeAggregator) */
+/* y[r, n] = x[r, n] + v[n]   (row-broadcast add; pos_embed + conv bias folded ahead of the TimeAggregator);
+ * x == NULL: y = v tiled R times (the ConvTranspose bias repeated per output pixel of a patch) */
 int dpot_bias_add(const float* x, const float* v, float* y, int R, int N, dpot_stream_t stream);
 /* y[b,t,e] = x[b,t,e] * scale[b,e] + shift[b,e]  (AdaIN, models/dpot.py:386-387) */
 int dpot_scale_shift(const float* x, const float* scale, const float* shift, float* y, int B, int T, int E,
@@ -271,6 +272,13 @@ int dpot_sumsq(const float* g, int64_t n, float* out, float* part, int accumulat
 int dpot_adam_step(float* p, const float* g, float* m, float* v, int64_t n, const float* hyper,
                    const float* sumsq, float grad_scale, dpot_stream_t stream);
 
+/* Host side of an optimiser step (utils/optimizer.py:139-141: state['step'] += 1, bias corrections) as ONE one-thread
+ * launch whose arguments travel by value: step[0] += advance (DEVICE int64), hyper = {lr, beta1, beta2, eps,
+ * weight_decay, 1-beta1^step, 1-beta2^step, max_norm (0 = no clip)}.  No host buffer is read when the kernel runs,
+ * so the host may enqueue any number of steps ahead (hipGraph replays included). */
+int dpot_adam_stage(float* hyper, int64_t* step, float lr, float beta1, float beta2, float eps,
+                    float weight_decay, float max_norm, int advance, dpot_stream_t stream);
+
 /* xx_out = xx + noise_scale * ||xx||_2(over X,Y,T per (b,c)) * eps   (train_temporal.py:205)
  * xx, eps: [B, S, C]; norms: B*C*(1 + dpot_noise_chunks(S, C)) floats - [B, C] norms followed by the chunk partials */
 int dpot_noise_chunks(int S, int C);
@@ -281,6 +289,22 @@ int dpot_noise_inject(const float* xx, const float* eps, float* out, float* norm
  * hipGraph draws fresh noise on every replay.  Needs S*C % 4 == 0 and 16-byte aligned xx / out. */
 int dpot_noise_inject_rng(const float* xx, float* out, float* norms, uint64_t* rng_state, float noise_scale, int B,
                           int S, int C, dpot_stream_t stream);
+
+/* backward of the noise injection for AR steps whose input depends on earlier predictions:
+ * dx = g + noise_scale * xx / norms[b,c] * sum_(X,Y,T)(g * eps).  eps: the tensor the forward used, or NULL with
+ * rng_state = a copy of the generator state {seed, offset} the forward drew from.  norms: [B, C] written by the
+ * forward.  part: B * C * dpot_noise_chunks(S, C) floats of scratch. */
+int dpot_noise_inject_bwd(const float* xx, const float* eps, const uint64_t* rng_state, const float* g,
+                          const float* norms, float* dx, float* part, float noise_scale, int B, int S, int C,
+                          dpot_stream_t stream);
+
+/* auto-regressive window slide (train_temporal.py:219  xx = cat(xx[..., T_bundle:, :], im)):
+ * xx [rows, T, C], im [rows, Tb, C] -> out [rows, T, C] (rows = B*X*Y); bwd: dxx (first Tb steps zero) and dim
+ * (either may be NULL) from dout. */
+int dpot_window_slide(const float* xx, const float* im, float* out, int64_t rows, int T, int Tb, int C,
+                      dpot_stream_t stream);
+int dpot_window_slide_bwd(const float* dout, float* dxx, float* dim, int64_t rows, int T, int Tb, int C,
+                          dpot_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -272,11 +272,13 @@ def test_train_step_vs_oracle_two_steps_and_graph():
     for a, b in zip(losses, ref_losses):
         assert abs(a - b) <= 2e-4 * abs(b), (losses, ref_losses)
     eager_params = {k: v.detach().clone() for k, v in m.state_dict().items()}
-    # graphed: warm-up steps are real steps -> 0 warm-up iterations beyond capture is not possible; use a fresh model
+    # graphed (the eager warm-up inside GraphedTrainStep is rolled back: it is not a training step)
     m2, _ = build(kw, salt=23)
     opt2 = FusedAdam(FlatParams(m2), lr=lr, betas=(0.9, 0.9), weight_decay=1e-6, max_norm=10000.0)
-    gs = GraphedTrainStep(m2, opt2, xx, yy, msk, warmup=1)            # 1 eager step (= step 1) ...
-    l2 = gs.replay(lr).item()                                          # ... + 1 replayed step (= step 2)
+    gs = GraphedTrainStep(m2, opt2, xx, yy, msk, warmup=1)
+    l1 = gs.replay(lr).item()
+    l2 = gs.replay(lr).item()
+    assert abs(l1 - losses[0]) <= 1e-6 * abs(losses[0])
     assert abs(l2 - losses[1]) <= 1e-6 * abs(losses[1])
     for k, v in m2.state_dict().items():
         assert (v - eager_params[k]).abs().max().item() <= 1e-6, k

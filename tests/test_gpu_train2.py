@@ -1,0 +1,275 @@
+"""GPU tests of the step machinery added in round 2: device-side Adam step counter (no host staging buffer), optimiser
+checkpoint format, the HIP noise-injection backward and window slide, the segmented (bucket-overlapped) data-parallel
+graph step, and the data-parallel path driven by the HIP backward in two processes sharing the one GPU."""
+import os
+import socket
+import sys
+from collections import OrderedDict
+
+import numpy as np
+import pytest
+import torch
+
+from helpers import RTOL, assert_close, load
+from oracle import dpot_ref as R
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def build(kw, salt):
+    from dpot_amd import DPOTNet
+    cfg = R.DPOTConfig(**kw)
+    m = DPOTNet(**kw)
+    m.load_state_dict(R.recipe_state_dict(cfg, salt=salt))
+    return m.cuda(), cfg
+
+
+def _batch(cfg, B, T_ar=1, salt=1):
+    S = cfg.img_size
+    xx = R.recipe_input((B, S, S, cfg.in_timesteps, cfg.in_channels), salt=salt).cuda()
+    yy = R.recipe_input((B, S, S, T_ar, cfg.out_channels), salt=salt + 1).cuda()
+    msk = torch.ones(B, S, S, 1, cfg.out_channels, device="cuda")
+    return xx, yy, msk
+
+
+def _opt(m, **kw):
+    from dpot_amd.train import FlatParams, FusedAdam
+    args = dict(lr=1e-3, betas=(0.9, 0.9), weight_decay=1e-6, max_norm=10000.0)
+    args.update(kw)
+    return FusedAdam(FlatParams(m), **args)
+
+
+# ------------------------------------------------------------------------------------------------------
+def test_replays_without_host_sync_match_synced_run():
+    """lr / bias corrections of step k must not be overwritten by the host staging step k+n.
+    Replaying N steps back to back WITHOUT any synchronisation must give exactly the parameters of a run that
+    synchronises after every step (different lr every step, fast-changing bias corrections in the first steps)."""
+    from dpot_amd.train import GraphedTrainStep
+    lrs = [1e-3 * (1 + 3 * (i % 5)) for i in range(24)]
+    outs = []
+    for sync in (True, False):
+        m, cfg = build(R.MINI, salt=5)
+        xx, yy, msk = _batch(cfg, 2)
+        opt = _opt(m)
+        g = GraphedTrainStep(m, opt, xx, yy, msk, warmup=1)
+        for lr in lrs:
+            g.replay(lr)
+            if sync:
+                torch.cuda.synchronize()
+        torch.cuda.synchronize()
+        assert int(opt.step_dev.item()) == len(lrs) == opt.step_count
+        outs.append(opt.fp.flat.clone())
+    assert torch.equal(outs[0], outs[1])
+
+
+def test_graph_warmup_does_not_train():
+    """the eager warm-up iterations of GraphedTrainStep leave parameters, moments and the step
+    counter untouched"""
+    from dpot_amd.train import GraphedTrainStep
+    m, cfg = build(R.MINI, salt=5)
+    xx, yy, msk = _batch(cfg, 2)
+    opt = _opt(m)
+    before = opt.fp.flat.clone()
+    GraphedTrainStep(m, opt, xx, yy, msk, warmup=3)
+    assert torch.equal(opt.fp.flat, before) and int(opt.step_dev.item()) == 0 and opt.step_count == 0
+    assert float(opt.exp_avg.abs().max()) == 0.0
+
+
+def test_optimizer_state_dict_roundtrip_and_reference_layout():
+    """FusedAdam.state_dict has the layout of the reference's torch-style Adam (utils/optimizer.py:101-164) and
+    resuming from it continues the run bit for bit"""
+    from dpot_amd.train import train_step
+    m, cfg = build(R.MINI, salt=8)
+    xx, yy, msk = _batch(cfg, 2)
+    opt = _opt(m)
+    for _ in range(3):
+        train_step(m, opt, xx, yy, msk, lr=2e-3)
+    sd_opt = opt.state_dict(m)
+    sd_model = OrderedDict((k, v.clone()) for k, v in m.state_dict().items())
+    names = [n for n, _ in m.named_parameters()]
+    assert sd_opt["param_groups"][0]["params"] == list(range(len(names)))
+    for i, n in enumerate(names):
+        if n.startswith("cls_head."):
+            assert i not in sd_opt["state"]                  # never updated in single-GPU training
+        else:
+            st = sd_opt["state"][i]
+            assert st["step"] == 3 and st["exp_avg"].shape == dict(m.named_parameters())[n].shape
+    train_step(m, opt, xx, yy, msk, lr=2e-3)
+    want = opt.fp.flat.clone()
+    m2, _ = build(R.MINI, salt=8)
+    m2.load_state_dict(sd_model)
+    opt2 = _opt(m2)
+    opt2.load_state_dict(sd_opt, m2)
+    train_step(m2, opt2, xx, yy, msk, lr=2e-3)
+    assert torch.equal(opt2.fp.flat, want)
+
+
+def test_grad_norm_without_clipping():
+    from dpot_amd.train import train_step
+    m, cfg = build(R.MINI, salt=8)
+    xx, yy, msk = _batch(cfg, 2)
+    opt = _opt(m, max_norm=None)
+    train_step(m, opt, xx, yy, msk)
+    n = opt.fp.n_head
+    assert abs(opt.grad_norm().item() - opt.fp.grad[:n].double().norm().item()) <= 1e-5 * opt.grad_norm().item()
+
+
+# ------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("shape", [(2, 8, 8, 4, 3), (3, 16, 16, 10, 4)])
+def test_noise_backward_and_window_slide_vs_autograd(shape):
+    from dpot_amd import ops
+    from dpot_amd.train import _NoiseFn, _SlideFn
+    g = torch.Generator().manual_seed(3)
+    xx = torch.randn(*shape, generator=g).cuda()
+    eps = torch.randn(*shape, generator=g).cuda()
+    up = torch.randn(*shape, generator=g).cuda()
+    s = 0.3
+    # explicit eps: against torch autograd of the reference expression (train_temporal.py:205)
+    a = xx.clone().requires_grad_(True)
+    (_NoiseFn.apply(a, eps, s) * up).sum().backward()
+    b = xx.clone().requires_grad_(True)
+    ref = b + s * torch.sum(b ** 2, dim=(1, 2, 3), keepdim=True) ** 0.5 * eps
+    (ref * up).sum().backward()
+    assert_close(a.grad, b.grad, "noise bwd (eps given)")
+    # in-kernel generator: the backward re-draws the forward's noise from the saved generator state
+    if xx.numel() % 4 == 0:
+        c = xx.clone().requires_grad_(True)
+        out = _NoiseFn.apply(c, None, s)
+        (out * up).sum().backward()
+        n = torch.sum(xx ** 2, dim=(1, 2, 3), keepdim=True) ** 0.5
+        eps_used = (out.detach() - xx) / (s * n)
+        want = up + s * xx / n * torch.sum(up * eps_used, dim=(1, 2, 3), keepdim=True)
+        assert_close(c.grad, want, "noise bwd (in-kernel generator)", rtol=1e-3, atol_scale=1e-3)
+    # window slide
+    Tb = 2 if shape[3] > 2 else 1
+    im = torch.randn(*shape[:3], Tb, shape[4], generator=g).cuda()
+    a, ai = xx.clone().requires_grad_(True), im.clone().requires_grad_(True)
+    o = _SlideFn.apply(a, ai)
+    (o * up).sum().backward()
+    b, bi = xx.clone().requires_grad_(True), im.clone().requires_grad_(True)
+    o_ref = torch.cat((b[..., Tb:, :], bi), dim=-2)
+    (o_ref * up).sum().backward()
+    assert torch.equal(o, o_ref) and torch.equal(a.grad, b.grad) and torch.equal(ai.grad, bi.grad)
+
+
+def test_rollout_with_noise_gradient_vs_oracle():
+    """T_ar=3 rollout with explicit noise tensors: loss and every gradient vs the oracle (which differentiates through
+    the noise norm exactly as the reference's autograd does)"""
+    from dpot_amd.train import rollout
+    m, cfg = build(R.MINI, salt=12)
+    xx, yy, msk = _batch(cfg, 2, T_ar=3)
+    g = torch.Generator().manual_seed(5)
+    noise = [torch.randn(*xx.shape, generator=g) for _ in range(3)]
+    sd = OrderedDict((k, v.clone().requires_grad_(True)) for k, v in R.recipe_state_dict(cfg, salt=12).items())
+    l_ref, _ = R.rollout_loss(sd, xx.cpu(), yy.cpu(), msk.cpu(), cfg, noise_scale=0.05, noise=noise)
+    l_ref.backward()
+    loss, _ = rollout(m, xx, yy, msk, noise_scale=0.05, noise=[n.cuda() for n in noise])
+    loss.backward()
+    assert abs(loss.item() - l_ref.item()) <= RTOL * abs(l_ref.item())
+    for k, p in m.named_parameters():
+        if sd[k].grad is not None:
+            assert_close(p.grad, sd[k].grad, "noise rollout d" + k)
+
+
+# ------------------------------------------------------------------------------------------------------
+def test_segmented_graph_step_equals_eager_step():
+    """the bucket-segmented hipGraph chain (train.SegmentedTrainStep) reproduces the eager step bit for bit (world 1:
+    the collectives are no-ops, the graph cuts / leaf hand-over / shared pool are what is tested)"""
+    from dpot_amd.dp import BucketedGradReducer
+    from dpot_amd.train import SegmentedTrainStep, train_step
+    kw = dict(R.MINI, depth=4)
+    m1, cfg = build(kw, salt=3)
+    xx, yy, msk = _batch(cfg, 2)
+    opt1 = _opt(m1, update_tail=True)
+    for lr in (1e-3, 2e-3, 5e-4):
+        l_e, _ = train_step(m1, opt1, xx, yy, msk, lr=lr)
+    m2, _ = build(kw, salt=3)
+    opt2 = _opt(m2, update_tail=True)
+    red = BucketedGradReducer(opt2.fp, n_buckets=8, overlap=True)
+    assert red.n_buckets >= 3
+    seg = SegmentedTrainStep(m2, opt2, red, xx, yy, msk, warmup=1)
+    assert len(seg.graphs) == red.n_buckets - 1 and len(seg.graphs) >= 2       # really cut into several graphs
+    for lr in (1e-3, 2e-3, 5e-4):
+        l_s = seg.replay(lr)
+    assert l_s.item() == l_e.item()
+    assert torch.equal(opt1.fp.flat, opt2.fp.flat)
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _dp_worker(rank, world, port, out_dir, segmented):
+    import torch.distributed as dist
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.cuda.set_device(0)                                 # both ranks share the one GPU of the test box
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from dpot_amd import DPOTNet
+    from dpot_amd.dp import BucketedGradReducer
+    from dpot_amd.train import FlatParams, FusedAdam, SegmentedTrainStep, rollout
+    cfg = R.DPOTConfig(**R.MINI)
+    sd = R.recipe_state_dict(cfg, salt=17)
+    model = DPOTNet(**R.MINI)
+    if rank == 0:
+        model.load_state_dict(sd)
+    model.cuda()
+    fp = FlatParams(model)
+    red = BucketedGradReducer(fp, n_buckets=3, overlap=True)
+    red.broadcast_parameters(0)
+    B = 4
+    xx = R.recipe_input((B, cfg.img_size, cfg.img_size, cfg.in_timesteps, cfg.in_channels), salt=81)
+    yy = R.recipe_input((B, cfg.img_size, cfg.img_size, 1, cfg.out_channels), salt=82)
+    msk = torch.ones(B, cfg.img_size, cfg.img_size, 1, cfg.out_channels)
+    sl = slice(2 * rank, 2 * rank + 2)
+    xs, ys, ms = xx[sl].cuda(), yy[sl].cuda(), msk[sl].cuda()
+    if segmented:
+        opt = FusedAdam(fp, lr=0.0, betas=(0.9, 0.9), weight_decay=0.0, max_norm=1e4, update_tail=True)
+        seg = SegmentedTrainStep(model, opt, red, xs, ys, ms, warmup=1)
+        seg.replay(0.0)                                      # lr 0: weights stay, the flat gradient is what we check
+        launched = len(seg.graphs)
+    else:
+        fp.zero_grad()
+        red.begin_step()
+        loss, _ = rollout(model, xs, ys, ms)
+        loss.backward()                                      # HIP backward -> _Sink -> FlatParams.fire -> reducer
+        launched = sum(red._launched)
+        red.finish()
+    torch.cuda.synchronize()
+    g = (fp.grad * red.grad_scale).cpu()
+    if rank == 0:
+        np.savez(os.path.join(out_dir, f"dp_{int(segmented)}.npz"),
+                 gnorm=np.float64(torch.sqrt((g.double() ** 2).sum()).item()), names=np.array(fp.names),
+                 norms=np.array([g[o:o + p.numel()].norm().item() for p, o in zip(fp.params, fp.offsets)]),
+                 launched=launched, n_buckets=red.n_buckets)
+    ref = g.clone()
+    dist.broadcast(ref, src=0)
+    assert torch.equal(ref, g)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+@pytest.mark.parametrize("segmented", [False, True])
+def test_two_process_dp_hip_backward_vs_golden(tmp_path, segmented):
+    """two processes on the one GPU, gloo collectives: the HIP backward's gradient-ready notifications drive the
+    bucketed reducer (eager), resp. the segmented graph chain launches the buckets between replays; the averaged
+    gradients match the golden numbers generated from the reference under DDP semantics (g8)"""
+    import torch.multiprocessing as mp
+    port = _free_port()
+    mp.spawn(_dp_worker, args=(2, port, str(tmp_path), segmented), nprocs=2, join=True)
+    got = np.load(os.path.join(str(tmp_path), f"dp_{int(segmented)}.npz"))
+    fx = load("g8_dp")
+    assert abs(float(got["gnorm"]) - float(fx["grad_norm"])) <= RTOL * float(fx["grad_norm"])
+    want = dict(zip([str(n) for n in fx["names"]], fx["grad_norms"]))
+    for n, v in zip(got["names"], got["norms"]):
+        assert abs(v - want[str(n)]) <= RTOL * want[str(n)] + 1e-7, n
+    if not segmented:
+        assert int(got["launched"]) >= int(got["n_buckets"]) - 1     # buckets went out DURING the backward
