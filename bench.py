@@ -63,56 +63,73 @@ def parse():
 
 # ------------------------------------------------------------------------------------------------------
 def mixer_roofline(model, B: int):
-    """Time the AFNO mixer kernel (one MLP layer of the block-diagonal complex MLP = one launch of the tagged MFMA
-    GEMM instantiation) with HIP events on the launch stream, on the real layer-0 weights and a real-sized spectrum."""
+    """Time the AFNO mixer kernel - both layers of the block-diagonal complex MLP, one launch of
+    dpot::afno_mlp2_kernel (csrc/afno_mlp.hip) - with HIP events on the launch stream, in the form the train step runs
+    (pre-activation and activated spectrum also stored for the backward), on a real-sized spectrum and random data."""
     from dpot_amd import ops
     E, nb, h = model.embed_dim, model.n_blocks, model.latent_size[0]
     bs = E // nb
+    N = 2 * bs
     mx, my = min(model.modes, h), min(model.modes, h // 2 + 1)
     Mm = B * mx * my
-    f = model.blocks[0].filter
+    fused = ops.afno_mlp2_supported(nb, bs)
     with torch.no_grad():
         S = torch.randn(Mm, 2 * E, device="cuda")
-        wb1, bb1 = ops.afno_pack(f.w1.detach(), f.b1.detach())
-        wb1.normal_(0, 0.05)                                   # random data, not the near-zero init (DVFS-honest)
-        O1, O1pre = torch.empty_like(S), torch.empty_like(S)
-        kw = dict(lda=2 * E, ldb=2 * bs, ldc=2 * E, batch=nb, strideA=2 * bs, strideB=4 * bs * bs, strideC=2 * bs,
-                  strideBias=2 * bs, bias=bb1, act=1, mode=ops.EPI_ACT, preact=O1pre, ldpre=2 * E, stridePre=2 * bs,
-                  tag=1)
-        for _ in range(5):
-            ops.gemm(S, wb1, O1, Mm, 2 * bs, 2 * bs, **kw)
-        reps = 50
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        for _ in range(reps):
-            ops.gemm(S, wb1, O1, Mm, 2 * bs, 2 * bs, **kw)
-        e1.record()
-        e1.synchronize()
-        t = e0.elapsed_time(e1) * 1e-3 / reps
-    flops = 2.0 * Mm * (2 * bs) * (2 * bs) * nb                # = 75.5 MFLOP/sample: half of SURVEY 8(d)'s 151.0 (2 layers)
-    # algorithmic bytes of one layer launch: spectrum in + spectrum out + the block weights once
-    bytes_alg = 2.0 * Mm * 2 * E * 4 + nb * (2 * bs) * (2 * bs) * 4
+        W1 = torch.randn(nb, N, N, device="cuda") * 0.05          # random data, not the near-zero init (DVFS-honest)
+        W2 = torch.randn(nb, N, N, device="cuda") * 0.05
+        b1 = torch.randn(nb, N, device="cuda") * 0.1
+        b2 = torch.randn(nb, N, device="cuda") * 0.1
+
+        def run(train: bool):
+            if fused:
+                return ops.afno_mlp2(S, W1, b1, W2, b2, nb, bs, 1, mode=0, want_pre=train, want_mid=train)
+            O1, O1pre, O2 = torch.empty_like(S), torch.empty_like(S), torch.empty_like(S)
+            kw = dict(lda=2 * E, ldb=N, ldc=2 * E, batch=nb, strideA=N, strideB=N * N, strideC=N, strideBias=N, tag=1)
+            ops.gemm(S, W1, O1, Mm, N, N, bias=b1, act=1, mode=ops.EPI_ACT, preact=O1pre, ldpre=2 * E, stridePre=N, **kw)
+            ops.gemm(O1, W2, O2, Mm, N, N, bias=b2, **kw)
+
+        def timeit(train: bool, reps: int = 50):
+            for _ in range(5):
+                run(train)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(reps):
+                run(train)
+            e1.record()
+            e1.synchronize()
+            return e0.elapsed_time(e1) * 1e-3 / reps
+
+        t = timeit(True)
+        t_inf = timeit(False)
+    flops = 2 * 2.0 * Mm * N * N * nb                          # = 151.0 MFLOP/sample (SURVEY 8d, both MLP layers)
+    # algorithmic bytes (SURVEY 8d): spectrum in + spectrum out + the weights of both layers once
+    bytes_alg = 2.0 * Mm * 2 * E * 4 + 2 * nb * N * N * 4
     achieved = flops / t / 1e12
     # HBM traffic per launch from the L2 memory-side counters: collected in separate rocprofv3 --pmc passes
-    # (scripts/gpu_pmc.sh -> profiles/r01_pmc_mixer.json; bench.py itself cannot run the profiler).  Units and the
+    # (scripts/gpu_pmc.sh -> profiles/r02_pmc_mixer.json; bench.py itself cannot run the profiler).  Units and the
     # gfx950 correction follow MI355X_MICROARCH.md section HBM: bytes = (2 * FETCH_SIZE + WRITE_SIZE) * 1024
     traffic = None
     try:
-        pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_mixer.json")))
-        traffic = (2.0 * pmc["FETCH_SIZE"]["mean"] + pmc["WRITE_SIZE"]["max"]) * 1024.0
+        pmc = json.load(open(os.path.join(ROOT, "profiles", "r02_pmc_mixer.json")))
+        traffic = (2.0 * pmc["FETCH_SIZE"]["mean"] + pmc["WRITE_SIZE"]["mean"]) * 1024.0
     except Exception:
         pass
     return {
-        "kernel": "dpot::gemm_f32_kernel<64,64,NN,vec,TAG=1> (AFNO mixer: one layer of the block-diagonal complex MLP "
-                  "as a real MFMA GEMM, bias+GELU fused)",
+        "kernel": ("dpot::afno_mlp2_kernel<RT,NT> (AFNO mixer: BOTH layers of the block-diagonal complex MLP in one "
+                   "launch - X W1 + b1 -> GELU -> W2 + b2 on v_mfma_f32_16x16x4_f32, intermediate kept in LDS)")
+        if fused else "dpot::gemm_f32_kernel<64,64,NN,vec,TAG=1> x 2 (un-fused fallback)",
         "bound": "mfma", "achieved": round(achieved, 2), "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
         "frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": traffic,
-        "traffic_note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), (2*FETCH+WRITE)*1024 B; the launch "
-                        "stores BOTH the pre-activation (saved for backward) and the activated spectrum, hence "
-                        "traffic > algorithmic_bytes (which counts one output)",
+        "traffic_note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), (2*FETCH+WRITE)*1024 B; the training "
+                        "form of the launch also stores the pre-activation and the activated spectrum (saved for the "
+                        "backward): 3 spectrum-sized writes instead of the 1 that algorithmic_bytes counts",
         "us_per_launch": round(t * 1e6, 2), "flops_per_launch": flops, "algorithmic_bytes_per_launch": bytes_alg,
         "hbm_frac": round(bytes_alg / t / 1e9 / HBM_PEAK_GBS, 4),
-        "note": "FLOP-bound (128 FLOP/B >> 20 FLOP/B ridge): hbm_frac is reported because north_star asks for it",
+        "inference_form": {"us_per_launch": round(t_inf * 1e6, 2), "achieved": round(flops / t_inf / 1e12, 2),
+                           "frac": round(flops / t_inf / 1e12 / FP32_MFMA_PEAK_TFLOPS, 4),
+                           "what": "same launch without the two saved-for-backward stores (no_grad forward)"},
+        "note": "FLOP-bound (128 FLOP/B >> 20 FLOP/B ridge): hbm_frac is reported because north_star asks for it; "
+                "round 1 ran this as two launches of the generic GEMM (2 x 34.4 us, frac 0.446)",
     }
 
 

@@ -1,0 +1,299 @@
+// afno_mlp.hip - the AFNO mixer's block-diagonal complex 2-layer MLP (models/dpot.py:72-94) as ONE kernel:
+//
+//      Y1 = f(X Wa + ba)          f = act (forward)  or  (.) * act'(aux)  (backward data path, no biases)
+//      Y2 = Y1 Wb + bb
+//
+// X = the spectrum [M = B*mx*my, 2E] in the "planar per channel block" layout: block k owns columns k*N .. (k+1)*N,
+// N = 2*bs = [re(bs) | im(bs)], and the complex weights are the real N x N matrices [[Wr, Wi], [-Wi, Wr]] (dft.hip
+// afno_pack) - so per block this is two chained real GEMMs with K = N = 2*bs (256 for DPOT-Ti/S/M, 192 for DPOT-L).
+// The backward data path  dS = ((dO2 W2^T) * act'(O1pre)) W1^T  is the same chain with transposed weights.
+//
+// Why one kernel (round 1 ran two launches of the generic 64x64-tile GEMM, 0.44 of the fp32-MFMA roof):
+//   * K is only 256: a 64x64 tile is 8 K-slabs long, so prologue / epilogue / wave quantisation (1152 tiles over 256
+//     CUs = 4.5 rounds) cost as much as the MFMAs.  Here a workgroup owns a PANEL of R = 16*RT rows x all N columns
+//     and runs both layers back to back: 2*N/16 slabs of MFMA work per prologue, the intermediate Y1 never leaves the
+//     CU (it is the A operand of layer 2, kept in LDS), one launch.
+//   * R is chosen per problem so that the panels fill the 256 CUs evenly (DPOT-Tiny, B=32: 18432 block-rows / 256 CUs
+//     = 72 -> R = 80: 232 workgroups, one per CU, 90 % of them busy to the end); v_mfma_f32_16x16x4_f32 (exact fp32,
+//     same rate as 32x32x2) gives the 16-row granularity that needs.
+//   * operands reach LDS by LDS-DMA (global_load_lds_dwordx4): a K-slab is 16 deep, so a (16 rows x 16 k) fragment
+//     block is exactly 1 KiB = one wave-instruction; lane l fetches (row l&15, k 4*(l>>4)..+3), which makes the LDS image
+//     of a block lane-linear in MFMA operand order: fragments are read back with one conflict-free ds_read_b128 per
+//     block (4 k-steps).  Weights are packed K-contiguous (Wt[n][k]) for this.  Two LDS buffers, one barrier per slab:
+//     wait own DMA (vmcnt 0) -> barrier -> issue slab t+1 -> 4*RT*NT MFMAs of slab t.
+//   * 4 waves, wave w owns all R rows x columns [16*NT*w, 16*NT*(w+1)): RT x NT accumulators of 16x16 (80 AGPRs at
+//     RT=5, NT=4).  Epilogues bounce each 16-row tile through a per-wave LDS slab so that bias / aux loads and all
+//     global stores are 16-byte accesses, 64*NT bytes contiguous per row.
+#include "common.h"
+
+namespace dpot {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+struct AfnoMlpArgs {
+  const float* X;     // [M, ldx]
+  const float* Wa;    // [nb][N][N], Wt[n][k] (K-contiguous)
+  const float* Wb;
+  const float* ba;    // [nb][N] or NULL
+  const float* bb;
+  const float* aux;   // mode 1: pre-activation of the forward [M, ldo]
+  float* pre;         // optional: X Wa + ba            [M, ldo]
+  float* mid;         // optional: Y1                   [M, ldo]
+  float* Y;           // Y2                             [M, ldo]
+  int ldx, ldo;
+  int M, nb, panels, act, mode;
+};
+
+__device__ __forceinline__ void glds16(const float* g, float* l) {
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                   (__attribute__((address_space(3))) void*)l, 16, 0, 0);
+}
+
+template <int RT, int NT>
+__global__ __launch_bounds__(256) void afno_mlp2_kernel(const AfnoMlpArgs p) {
+  constexpr int N = 64 * NT;        // = K
+  constexpr int NCT = 4 * NT;       // 16-column tiles of the panel = K-slabs
+  constexpr int NSLAB = NCT;
+  constexpr int BFL = NCT * 256;    // floats of one weight slab  (N x 16)
+  constexpr int AFL = RT * 256;     // floats of one X slab       (16*RT x 16)
+  constexpr int WCOLS = 16 * NT;    // columns per wave
+  // ONE shared array (a second LDS object makes hipcc wait vmcnt(0) before every fragment read of a DMA pipeline)
+  __shared__ __attribute__((aligned(16))) float lds[2 * BFL + 2 * AFL + RT * NCT * 256];
+  float* const Bb = lds;                    // [2][NCT][256]
+  float* const Ab = lds + 2 * BFL;          // [2][RT][256]
+  float* const Y1 = Ab + 2 * AFL;           // [RT][NCT][256]
+  float* const stage_all = lds + BFL;       // epilogue staging = weight buffer 1 (dead at those points): [4][16][WCOLS]
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int fr = lane & 15, fq = lane >> 4;           // fragment row / k-quad of this lane (MFMA A/B operand layout)
+
+  // XCD-contiguous work-item order: items are (block k, panel) with k major, so a chiplet's L2 holds few blocks' weights
+  const int nitems = p.nb * p.panels;
+  int item;
+  {
+    const int bid = blockIdx.x, xcd = bid & 7, slot = bid >> 3;
+    const int q = nitems >> 3, r = nitems & 7;
+    item = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + slot;
+  }
+  const int kblk = item / p.panels, panel = item - kblk * p.panels;
+  const int row0 = panel * (16 * RT);
+  const float* X = p.X + (long long)kblk * N;
+  const float* Wa = p.Wa + (long long)kblk * N * N;
+  const float* Wb = p.Wb + (long long)kblk * N * N;
+
+  // ---- LDS-DMA of one K-slab: the RT X-blocks and the NCT weight blocks, dealt round-robin to the 4 waves
+  // lane l of a block fetches (row l&15 of the block, k = 4*(l>>4) .. +3) -> LDS chunk l of the block
+  long long xoff[(RT + 3) / 4];
+#pragma unroll
+  for (int n = 0; n < (RT + 3) / 4; ++n) {
+    const int i = wave + 4 * n;
+    int row = row0 + 16 * i + fr;
+    row = row < p.M ? row : p.M - 1;                  // clamped: rows past M only feed outputs that are never stored
+    xoff[n] = (long long)row * p.ldx + 4 * fq;
+  }
+  const int woff = fr * N + 4 * fq;                   // + (16*c)*N + 16*t for column tile c, slab t
+  auto issue_w = [&](const float* __restrict__ W, int t, float* dstbuf) __attribute__((always_inline)) {
+#pragma unroll
+    for (int n = 0; n < NT; ++n) {
+      const int c = wave + 4 * n;
+      glds16(W + woff + (16 * c) * N + 16 * t, dstbuf + c * 256);
+    }
+  };
+  auto issue_x = [&](int t, float* dstbuf) __attribute__((always_inline)) {
+#pragma unroll
+    for (int n = 0; n < (RT + 3) / 4; ++n) {
+      const int i = wave + 4 * n;
+      if (i < RT) glds16(X + xoff[n] + 16 * t, dstbuf + i * 256);       // wave-uniform predicate
+    }
+  };
+
+  f32x4 acc[RT][NT];
+  auto zero_acc = [&]() __attribute__((always_inline)) {
+#pragma unroll
+    for (int i = 0; i < RT; ++i)
+#pragma unroll
+      for (int j = 0; j < NT; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  };
+  auto mma_slab = [&](const f32x4 (&af)[RT], const float* Bslab) __attribute__((always_inline)) {
+    f32x4 bf[NT];
+#pragma unroll
+    for (int j = 0; j < NT; ++j) bf[j] = *reinterpret_cast<const f32x4*>(Bslab + (wave * NT + j) * 256 + lane * 4);
+    // row-tile major: the first MFMAs need only af[0] and the weight fragments, the other X fragments land behind them
+#pragma unroll
+    for (int i = 0; i < RT; ++i)
+#pragma unroll
+      for (int s = 0; s < 4; ++s)
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i][s], bf[j][s], acc[i][j], 0, 0, 0);
+  };
+  auto slab_sync = [&]() __attribute__((always_inline)) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // my DMA pieces of the coming slab have landed ...
+    __builtin_amdgcn_s_barrier();                      // ... everybody's have, and nobody still reads the other buffer
+    asm volatile("" ::: "memory");
+  };
+
+  // ---- epilogue of one layer: acc (+bias) -> [pre] -> f -> [mid] -> Y1 in LDS (layer 1) / -> Y (layer 2)
+  float* const stage = stage_all + wave * (16 * WCOLS);
+  auto epilogue = [&](bool first, const float* __restrict__ bias) __attribute__((always_inline)) {
+    const int colw = 16 * NT * wave;                   // first column of this wave inside the block
+    // (fully unrolled over the row tiles: a dynamic index into acc would send the accumulators to scratch)
+#pragma unroll
+    for (int i = 0; i < RT; ++i) {
+      // C/D layout of a 16x16 tile: col = lane&15, row = 4*(lane>>4) + e
+#pragma unroll
+      for (int j = 0; j < NT; ++j) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) stage[(4 * fq + e) * WCOLS + 16 * j + fr] = acc[i][j][e];
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll 1
+      for (int it = 0; it < NT; ++it) {
+        const int g = it * 64 + lane;                  // 16-byte chunk of the 16 x WCOLS tile, row-major
+        const int r = g / (4 * NT), c4 = g - r * (4 * NT);
+        const f32x4 t = *reinterpret_cast<const f32x4*>(stage + g * 4);
+        float v[4] = {t[0], t[1], t[2], t[3]};
+        const int row = row0 + 16 * i + r;
+        const int col = colw + 4 * c4;                 // column inside the block
+        const bool ok = row < p.M;
+        const int rowc = ok ? row : p.M - 1;
+        const long long go = (long long)rowc * p.ldo + (long long)kblk * N + col;
+        if (bias) {
+          const float4 b4 = *reinterpret_cast<const float4*>(bias + kblk * N + col);
+          v[0] += b4.x; v[1] += b4.y; v[2] += b4.z; v[3] += b4.w;
+        }
+        if (first) {
+          if (p.mode == 0) {
+            if (p.pre && ok) *reinterpret_cast<float4*>(p.pre + go) = make_float4(v[0], v[1], v[2], v[3]);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = act_fwd(p.act, v[e]);
+          } else {
+            const float4 x4 = *reinterpret_cast<const float4*>(p.aux + go);
+            v[0] *= act_bwd(p.act, x4.x); v[1] *= act_bwd(p.act, x4.y);
+            v[2] *= act_bwd(p.act, x4.z); v[3] *= act_bwd(p.act, x4.w);
+          }
+          if (p.mid && ok) *reinterpret_cast<float4*>(p.mid + go) = make_float4(v[0], v[1], v[2], v[3]);
+          // A operand of layer 2: K-slab s = col/16, chunk (k-quad, row) at a row position rotated by s
+          const int s = col >> 4, kq = (col >> 2) & 3;
+          *reinterpret_cast<f32x4*>(Y1 + ((i * NCT + s) * 64 + kq * 16 + ((r + s) & 15)) * 4) =
+              (f32x4){v[0], v[1], v[2], v[3]};
+        } else {
+          if (ok) *reinterpret_cast<float4*>(p.Y + go) = make_float4(v[0], v[1], v[2], v[3]);
+        }
+      }
+      __builtin_amdgcn_wave_barrier();
+    }
+  };
+
+  // ================= layer 1:  acc = X[panel, :] Wa =================
+  zero_acc();
+  issue_x(0, Ab);
+  issue_w(Wa, 0, Bb);
+#pragma unroll 1
+  for (int t = 0; t < NSLAB; ++t) {
+    slab_sync();
+    const int cur = t & 1;
+    if (t + 1 < NSLAB) {
+      issue_x(t + 1, Ab + (cur ^ 1) * AFL);
+      issue_w(Wa, t + 1, Bb + (cur ^ 1) * BFL);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    f32x4 af[RT];
+#pragma unroll
+    for (int i = 0; i < RT; ++i) af[i] = *reinterpret_cast<const f32x4*>(Ab + cur * AFL + i * 256 + lane * 4);
+    mma_slab(af, Bb + cur * BFL);
+  }
+  __syncthreads();                    // weight buffer 1 (last slab) is dead: it becomes the epilogue staging area
+  issue_w(Wb, 0, Bb);                 // layer-2 weights start streaming under the epilogue (buffer 0)
+  epilogue(true, p.ba);
+  __syncthreads();                    // Y1 complete
+
+  // ================= layer 2:  acc = Y1 Wb =================
+  zero_acc();
+#pragma unroll 1
+  for (int u = 0; u < NSLAB; ++u) {
+    slab_sync();
+    const int cur = u & 1;
+    if (u + 1 < NSLAB) issue_w(Wb, u + 1, Bb + (cur ^ 1) * BFL);
+    __builtin_amdgcn_sched_barrier(0);
+    f32x4 af[RT];
+#pragma unroll
+    for (int i = 0; i < RT; ++i)
+      af[i] = *reinterpret_cast<const f32x4*>(Y1 + ((i * NCT + u) * 64 + fq * 16 + ((fr + u) & 15)) * 4);
+    mma_slab(af, Bb + cur * BFL);
+  }
+  __syncthreads();
+  epilogue(false, p.bb);
+}
+
+constexpr int AFNO_NUM_CU = 256;
+
+// rows per panel (multiple of 16, <= 80): fewest rounds of (panels * nb) workgroups over the CUs, one workgroup per CU
+static int pick_rt(int M, int nb) {
+  static const int forced = [] { const char* e = getenv("DPOT_AFNO_MLP_RT"); return e ? atoi(e) : 0; }();
+  if (forced >= 1 && forced <= 5) return forced;
+  long long best_cost = -1;
+  int best = 5;
+  for (int rt = 5; rt >= 1; --rt) {
+    const long long panels = (M + 16 * rt - 1) / (16 * rt);
+    const long long rounds = (panels * nb + AFNO_NUM_CU - 1) / AFNO_NUM_CU;
+    // one round costs the panel's MFMA time plus a fixed prologue / epilogue share (~12 rows' worth)
+    const long long cost = rounds * (16 * rt + 12);
+    if (best_cost < 0 || cost < best_cost) {
+      best_cost = cost;
+      best = rt;
+    }
+  }
+  return best;
+}
+
+template <int NT>
+static int launch_nt(const AfnoMlpArgs& p, int rt, hipStream_t s) {
+  const dim3 grid((unsigned)(p.nb * p.panels)), blk(256);
+  switch (rt) {
+    case 1: hipLaunchKernelGGL((afno_mlp2_kernel<1, NT>), grid, blk, 0, s, p); break;
+    case 2: hipLaunchKernelGGL((afno_mlp2_kernel<2, NT>), grid, blk, 0, s, p); break;
+    case 3: hipLaunchKernelGGL((afno_mlp2_kernel<3, NT>), grid, blk, 0, s, p); break;
+    case 4: hipLaunchKernelGGL((afno_mlp2_kernel<4, NT>), grid, blk, 0, s, p); break;
+    default: hipLaunchKernelGGL((afno_mlp2_kernel<5, NT>), grid, blk, 0, s, p); break;
+  }
+  return check_launch("afno_mlp2_kernel");
+}
+
+}  // namespace dpot
+
+using namespace dpot;
+
+extern "C" int dpot_afno_mlp2_supported(int nb, int bs) {
+  const int N = 2 * bs;
+  return nb > 0 && (N == 64 || N == 128 || N == 192 || N == 256) ? 1 : 0;
+}
+
+extern "C" int dpot_afno_mlp2(const float* X, const float* WaT, const float* ba, const float* WbT, const float* bb,
+                              const float* aux, float* pre, float* mid, float* Y, int M, int nb, int bs, int ldx,
+                              int ldo, int act, int mode, dpot_stream_t stream) {
+  DPOT_REQUIRE(X && WaT && WbT && Y && M > 0, "afno_mlp2: bad argument");
+  DPOT_REQUIRE(dpot_afno_mlp2_supported(nb, bs), "afno_mlp2: unsupported block size bs=%d (2*bs must be 64/128/192/256)", bs);
+  DPOT_REQUIRE(mode == 0 || (mode == 1 && aux != nullptr), "afno_mlp2: mode 1 (backward) needs aux");
+  const int N = 2 * bs;
+  DPOT_REQUIRE(ldx >= nb * N && ldo >= nb * N && ldx % 4 == 0 && ldo % 4 == 0, "afno_mlp2: bad leading dimension");
+  DPOT_REQUIRE(aligned16(X) && aligned16(WaT) && aligned16(WbT) && aligned16(Y) && aligned16(ba) && aligned16(bb) &&
+                   aligned16(aux) && aligned16(pre) && aligned16(mid),
+               "afno_mlp2: pointers must be 16-byte aligned");
+  AfnoMlpArgs p;
+  p.X = X; p.Wa = WaT; p.Wb = WbT; p.ba = ba; p.bb = bb; p.aux = aux; p.pre = pre; p.mid = mid; p.Y = Y;
+  p.ldx = ldx; p.ldo = ldo; p.M = M; p.nb = nb; p.act = act; p.mode = mode;
+  const int rt = pick_rt(M, nb);
+  p.panels = (M + 16 * rt - 1) / (16 * rt);
+  hipStream_t s = as_stream(stream);
+  switch (N / 64) {
+    case 1: return launch_nt<1>(p, rt, s);
+    case 2: return launch_nt<2>(p, rt, s);
+    case 3: return launch_nt<3>(p, rt, s);
+    default: return launch_nt<4>(p, rt, s);
+  }
+}

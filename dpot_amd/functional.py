@@ -198,17 +198,22 @@ def _block_parts(x, n1w, n1b, n2w, n2b, f1w, f1b, packed, dims, mp, need_out, f2
     B, tok, E, h, w, nb, bs, mx, my, mh, act = dims
     Mm, M = B * mx * my, B * tok
     dev = x.device
-    (wb1, bb1), (wb2, bb2) = packed
+    (wb1, bb1, wb1T), (wb2, bb2, wb2T) = packed
     xn1, mean1, rstd1 = ops.groupnorm_fwd(x, n1w, n1b)
     S = ops.rfft2(xn1, h, w, nb, mx, my, 0)                                # [Mm, 2E]
-    O1 = torch.empty(Mm, 2 * E, dtype=torch.float32, device=dev)
-    O1pre = torch.empty_like(O1)
-    kw = dict(lda=2 * E, ldb=2 * bs, ldc=2 * E, batch=nb, strideA=2 * bs, strideB=4 * bs * bs, strideC=2 * bs,
-              strideBias=2 * bs, tag=1)
-    ops.gemm(S, wb1, O1, Mm, 2 * bs, 2 * bs, bias=bb1, act=act, mode=EPI_ACT, preact=O1pre, ldpre=2 * E,
-             stridePre=2 * bs, **kw)
-    O2 = torch.empty_like(O1)
-    ops.gemm(O1, wb2, O2, Mm, 2 * bs, 2 * bs, bias=bb2, **kw)
+    if wb1T is not None:
+        # both layers of the block-diagonal complex MLP in ONE launch; the activated spectrum never leaves the CU
+        # except as the copy saved for the backward (csrc/afno_mlp.hip)
+        O2, O1pre, O1 = ops.afno_mlp2(S, wb1T, bb1, wb2T, bb2, nb, bs, act, mode=0, want_pre=True, want_mid=True)
+    else:
+        O1 = torch.empty(Mm, 2 * E, dtype=torch.float32, device=dev)
+        O1pre = torch.empty_like(O1)
+        kw = dict(lda=2 * E, ldb=2 * bs, ldc=2 * E, batch=nb, strideA=2 * bs, strideB=4 * bs * bs, strideC=2 * bs,
+                  strideBias=2 * bs, tag=1)
+        ops.gemm(S, wb1, O1, Mm, 2 * bs, 2 * bs, bias=bb1, act=act, mode=EPI_ACT, preact=O1pre, ldpre=2 * E,
+                 stridePre=2 * bs, **kw)
+        O2 = torch.empty_like(O1)
+        ops.gemm(O1, wb2, O2, Mm, 2 * bs, 2 * bs, bias=bb2, **kw)
     y1 = ops.irfft2(O2, B, h, w, E, nb, mx, my, 1, res=xn1)                # + x_orig (the normalised input)
     del O2, xn1
     xn2, mean2, rstd2 = ops.groupnorm_fwd(y1, n2w, n2b)
@@ -234,14 +239,16 @@ class BlockFn(torch.autograd.Function):
         bs = E // nb
         mx, my = min(modes, h), min(modes, w // 2 + 1)
         mh = f1w.shape[0]
-        if packed is None:      # ((Wbig1, bbig1), (Wbig2, bbig2)); normally packed for all blocks at once by the model
-            packed = (ops.afno_pack(w1, b1), ops.afno_pack(w2, b2))
+        if packed is None:      # ((Wbig1, bbig1, Wbig1^T), (Wbig2, ...)); normally packed for all blocks by the model
+            packed = (ops.afno_pack3(w1, b1), ops.afno_pack3(w2, b2))
         dims = (B, tok, E, h, w, nb, bs, mx, my, mh, act)
         mp = ops.mlp_precision()                                               # channel-MLP GEMM precision override
         out, parts = _block_parts(x, n1w, n1b, n2w, n2b, f1w, f1b, packed, dims, mp, True, f2w, f2b)
         wb1, wb2 = packed[0][0], packed[1][0]
+        ctx.fused_mixer = packed[0][2] is not None
+        opt_t = (packed[0][2], packed[1][2]) if ctx.fused_mixer else ()
         if recompute:
-            ctx.save_for_backward(x, wb1, packed[0][1], wb2, packed[1][1], n1w, n1b, n2w, n2b, f1w, f1b, f2w)
+            ctx.save_for_backward(x, wb1, packed[0][1], wb2, packed[1][1], n1w, n1b, n2w, n2b, f1w, f1b, f2w, *opt_t)
         else:
             ctx.save_for_backward(x, *parts, wb1, wb2, n1w, n2w, f1w, f2w)
         ctx.recompute = recompute
@@ -254,10 +261,11 @@ class BlockFn(torch.autograd.Function):
     def backward(ctx, dout):
         mp = ctx.mlp_precision
         if ctx.recompute:
-            x, wb1, bb1, wb2, bb2, n1w, n1b, n2w, n2b, f1w, f1b, f2w = ctx.saved_tensors
+            x, wb1, bb1, wb2, bb2, n1w, n1b, n2w, n2b, f1w, f1b, f2w, *wts = ctx.saved_tensors
+            wb1T, wb2T = wts if ctx.fused_mixer else (None, None)
             with torch.no_grad():
-                _, parts = _block_parts(x, n1w, n1b, n2w, n2b, f1w, f1b, ((wb1, bb1), (wb2, bb2)), ctx.dims, mp,
-                                        False)
+                _, parts = _block_parts(x, n1w, n1b, n2w, n2b, f1w, f1b, ((wb1, bb1, wb1T), (wb2, bb2, wb2T)),
+                                        ctx.dims, mp, False)
             mean1, rstd1, S, O1pre, O1, y1, mean2, rstd2, xn2, Hpre, Hh = parts
         else:
             (x, mean1, rstd1, S, O1pre, O1, y1, mean2, rstd2, xn2, Hpre, Hh, wb1, wb2, n1w, n2w, f1w,
@@ -293,15 +301,21 @@ class BlockFn(torch.autograd.Function):
             dw2, db2 = ops._out(s_w2.out(), (2, nb, bs, bs), dev), ops._out(s_b2.out(), (2, nb, bs), dev)
             ops.gemm(O1, dO2, dw2, 2 * bs, 2 * bs, Mm, colsum_out=db2, colsum_of=2, **wkw)
             dw2, db2 = s_w2.done(dw2), s_b2.done(db2)
-        dO1pre = torch.empty(Mm, 2 * E, dtype=torch.float32, device=dev)
-        ops.gemm(dO2, wb2, dO1pre, Mm, 2 * bs, 2 * bs, transB=True, act=act, mode=EPI_DACT, aux=O1pre, ldaux=2 * E,
-                 strideAux=2 * bs, **kw)
+        if ctx.fused_mixer:
+            # data path of both layers in one launch: dO1pre = (dO2 W2^T) * act'(O1pre), dS = dO1pre W1^T.  The packed
+            # Wbig[k][n] IS the K-contiguous form of the transposed weight the backward multiplies by.
+            dS, _, dO1pre = ops.afno_mlp2(dO2, wb2, None, wb1, None, nb, bs, act, mode=1, aux=O1pre, want_mid=True)
+        else:
+            dO1pre = torch.empty(Mm, 2 * E, dtype=torch.float32, device=dev)
+            ops.gemm(dO2, wb2, dO1pre, Mm, 2 * bs, 2 * bs, transB=True, act=act, mode=EPI_DACT, aux=O1pre,
+                     ldaux=2 * E, strideAux=2 * bs, **kw)
         with streams.side(dev):
             dw1, db1 = ops._out(s_w1.out(), (2, nb, bs, bs), dev), ops._out(s_b1.out(), (2, nb, bs), dev)
             ops.gemm(S, dO1pre, dw1, 2 * bs, 2 * bs, Mm, colsum_out=db1, colsum_of=2, **wkw)
             dw1, db1 = s_w1.done(dw1), s_b1.done(db1)
-        dS = torch.empty(Mm, 2 * E, dtype=torch.float32, device=dev)
-        ops.gemm(dO1pre, wb1, dS, Mm, 2 * bs, 2 * bs, transB=True, **kw)
+        if not ctx.fused_mixer:
+            dS = torch.empty(Mm, 2 * E, dtype=torch.float32, device=dev)
+            ops.gemm(dO1pre, wb1, dS, Mm, 2 * bs, 2 * bs, transB=True, **kw)
         dxn1 = ops.irfft2(dS, B, h, w, E, nb, mx, my, 0, res=dy1)              # adjoint of rfft2, + skip path
         dx, dn1w, dn1b = ops.groupnorm_bwd(dxn1, x, mean1, rstd1, n1w, add=dout, out_dgamma=s_n1w.out(),
                                            out_dbeta=s_n1b.out())

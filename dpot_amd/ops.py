@@ -202,6 +202,14 @@ def afno_pack(w: Tensor, b: Tensor) -> Tuple[Tensor, Tensor]:
     return wbig, bbig
 
 
+def afno_pack3(w: Tensor, b: Tensor) -> Tuple[Tensor, Tensor, Optional[Tensor]]:
+    """(Wbig, bbig, Wbig^T or None): the per-layer form of what afno_pack_multi returns"""
+    _, nb, bs, _ = w.shape
+    wbig, bbig = afno_pack(w, b)
+    wT = transpose2d(wbig, nb, 2 * bs, 2 * bs) if afno_mlp2_supported(nb, bs) else None
+    return wbig, bbig, wT
+
+
 def afno_pack_multi(pairs) -> list:
     """pairs = [(w [2,nb,bs,bs], b [2,nb,bs]), ...] of equal shapes -> [(wbig, bbig), ...], ONE launch for all of them"""
     n = len(pairs)
@@ -215,7 +223,27 @@ def afno_pack_multi(pairs) -> list:
                                            arr([wbig[i].data_ptr() for i in range(n)]),
                                            arr([bbig[i].data_ptr() for i in range(n)]), n, nb, bs, _stream()),
           "afno_pack_multi")
-    return [(wbig[i], bbig[i]) for i in range(n)]
+    # K-contiguous copies Wt[n][k] = Wbig[k][n] for the fused 2-layer kernel (afno_mlp2): one transpose launch for all
+    wbigT = transpose2d(wbig, n * nb, 2 * bs, 2 * bs).view(n, nb, 2 * bs, 2 * bs) if afno_mlp2_supported(nb, bs) else None
+    return [(wbig[i], bbig[i], wbigT[i] if wbigT is not None else None) for i in range(n)]
+
+
+def afno_mlp2_supported(nb: int, bs: int) -> bool:
+    return bool(_lib.load().dpot_afno_mlp2_supported(nb, bs)) and os.environ.get("DPOT_AFNO_FUSED", "1") != "0"
+
+
+def afno_mlp2(X: Tensor, WaT: Tensor, ba: Optional[Tensor], WbT: Tensor, bb: Optional[Tensor], nb: int, bs: int,
+              act: int, mode: int = 0, aux: Optional[Tensor] = None, want_pre: bool = False, want_mid: bool = False):
+    """both layers of the AFNO block-diagonal complex MLP in one launch (csrc/afno_mlp.hip).
+    mode 0: pre = X Wa + ba, mid = act(pre), Y = mid Wb + bb;  mode 1: mid = (X Wa) * act'(aux), Y = mid Wb.
+    X / outputs: [M, nb*2*bs]; WaT / WbT: [nb, 2bs, 2bs] K-contiguous (Wt[n][k]).  Returns (Y, pre | None, mid | None)."""
+    M, ld = X.shape
+    Y = torch.empty_like(X)
+    pre = torch.empty_like(X) if want_pre else None
+    mid = torch.empty_like(X) if want_mid else None
+    check(_lib.load().dpot_afno_mlp2(X.data_ptr(), WaT.data_ptr(), _p(ba), WbT.data_ptr(), _p(bb), _p(aux), _p(pre),
+                                     _p(mid), Y.data_ptr(), M, nb, bs, ld, ld, act, mode, _stream()), "afno_mlp2")
+    return Y, pre, mid
 
 
 def afno_unpack_grad(dwbig: Tensor, dbbig: Tensor, nb: int, bs: int, out_dw: Optional[Tensor] = None,

@@ -151,11 +151,11 @@ class FusedAdam:
         self.launch(grad_scale)
 
     def grad_norm(self, grad_scale: float = 1.0) -> Tensor:
-        """global gradient norm of the gradients currently in the flat buffer (device tensor; reading it
-        synchronises).  With clipping enabled this is the value the last step used; without, it is computed here."""
-        if self.max_norm is None:
-            ops.sumsq(self.fp.grad[:self.n_active], self.sumsq, self._part)
-        return self.sumsq.sqrt() * grad_scale
+        """global norm of the gradients currently in the flat buffer (device tensor; reading it synchronises):
+        after a step, the value its clip used (train_temporal.py:228 returns it from clip_grad_norm_)"""
+        out = torch.empty_like(self.sumsq)
+        ops.sumsq(self.fp.grad[:self.n_active], out, self._part)
+        return out.sqrt() * grad_scale
 
     # -- snapshot / restore (graph warm-up, tests) --------------------------------------------------------
     def snapshot(self):

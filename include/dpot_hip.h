@@ -290,6 +290,18 @@ int dpot_noise_inject(const float* xx, const float* eps, float* out, float* norm
 int dpot_noise_inject_rng(const float* xx, float* out, float* norms, uint64_t* rng_state, float noise_scale, int B,
                           int S, int C, dpot_stream_t stream);
 
+/* The AFNO mixer's 2-layer block-diagonal complex MLP (models/dpot.py:72-94) as ONE launch (csrc/afno_mlp.hip):
+ *   mode 0 (forward):        pre = X Wa + ba;  mid = act(pre);          Y = mid Wb + bb
+ *   mode 1 (backward data):  mid = (X Wa) * act'(aux);                  Y = mid Wb         (ba = bb = NULL)
+ * X [M, ldx], outputs / aux [M, ldo]: block k owns columns k*N..(k+1)*N, N = 2*bs = [re | im].  WaT / WbT: [nb][N][N]
+ * K-CONTIGUOUS real weights Wt[n][k] = W[k][n] of the packed complex matrices (dpot_afno_pack gives W = Wbig[k][n]; its
+ * transpose feeds the forward, Wbig itself is the Wt of the backward's W^T).  pre / mid may be NULL (inference).
+ * Supported when 2*bs is 64, 128, 192 or 256 (dpot_afno_mlp2_supported); everything 16-byte aligned. */
+int dpot_afno_mlp2_supported(int nb, int bs);
+int dpot_afno_mlp2(const float* X, const float* WaT, const float* ba, const float* WbT, const float* bb,
+                   const float* aux, float* pre, float* mid, float* Y, int M, int nb, int bs, int ldx, int ldo,
+                   int act, int mode, dpot_stream_t stream);
+
 /* backward of the noise injection for AR steps whose input depends on earlier predictions:
  * dx = g + noise_scale * xx / norms[b,c] * sum_(X,Y,T)(g * eps).  eps: the tensor the forward used, or NULL with
  * rng_state = a copy of the generator state {seed, offset} the forward drew from.  norms: [B, C] written by the

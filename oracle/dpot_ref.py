@@ -251,7 +251,12 @@ def time_aggregate(sd: Dict[str, Tensor], z: Tensor, cfg: DPOTConfig) -> Tensor:
         return torch.einsum("tij,...ti->...j", w, z)
     T = z.shape[-2]
     t = torch.linspace(0, 1, T).unsqueeze(-1)                               # [T,1]
-    t_embed = torch.cos(t @ sd["time_agg_layer.gamma"])                      # [T,E]
+    gamma = sd["time_agg_layer.gamma"]
+    if gamma.dtype == torch.float32:
+        t_embed = torch.cos(t @ gamma)                                       # [T,E]
+    else:
+        # float64 diagnostic runs (scripts/diag_grad64.py): same fp32 linspace, fp64 phase
+        t_embed = torch.cos(t.to(gamma.dtype) @ gamma)
     return torch.einsum("tij,...ti->...j", w, z * t_embed)
 
 

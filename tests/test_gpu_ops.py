@@ -468,3 +468,44 @@ def test_noise_inject_in_kernel_generator(ops):
     for c in range(C):                                                 # per-channel scale
         assert abs(z[..., c].std().item() - 1.0) < 0.03
     assert abs(torch.corrcoef(torch.stack([z.flatten()[:-1], z.flatten()[1:]]))[0, 1].item()) < 0.02
+
+
+# ------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("nb,bs,M", [(4, 128, 4608), (4, 128, 333), (16, 96, 544), (8, 128, 144), (2, 64, 100),
+                                     (3, 32, 17), (4, 128, 1)])
+@pytest.mark.parametrize("act", ["gelu", "silu"])
+def test_afno_mlp2_fused_two_layers(ops, nb, bs, M, act):
+    """the fused 2-layer block-diagonal complex MLP (csrc/afno_mlp.hip): forward (pre, mid, Y) and the backward data
+    path (mid = dO1pre, Y = dS) against float64 torch, incl. ragged panels (M not a multiple of the panel height),
+    DPOT-Tiny's full size (M = 32*16*9) and DPOT-L's 192-wide blocks"""
+    assert ops.afno_mlp2_supported(nb, bs)
+    N = 2 * bs
+    X = rnd(M, nb * N, seed=1)
+    W1 = rnd(nb, N, N, seed=2, scale=1.0 / math.sqrt(N))          # W[k][n]
+    W2 = rnd(nb, N, N, seed=3, scale=1.0 / math.sqrt(N))
+    b1, b2 = rnd(nb, N, seed=4, scale=0.3), rnd(nb, N, seed=5, scale=0.3)
+    f = ACTS[act]
+    Xd = X.double().view(M, nb, N)
+    pre_ref = torch.einsum("mkn,kno->mko", Xd, W1.double()) + b1.double()
+    mid_ref = f(pre_ref)
+    Y_ref = torch.einsum("mkn,kno->mko", mid_ref, W2.double()) + b2.double()
+    W1T = W1.transpose(1, 2).contiguous().cuda()
+    W2T = W2.transpose(1, 2).contiguous().cuda()
+    Y, pre, mid = ops.afno_mlp2(X.cuda(), W1T, b1.cuda(), W2T, b2.cuda(), nb, bs, ops.ACT_IDS[act], mode=0,
+                                want_pre=True, want_mid=True)
+    assert_close(pre, pre_ref.reshape(M, -1), "pre")
+    assert_close(mid, mid_ref.reshape(M, -1), "mid")
+    assert_close(Y, Y_ref.reshape(M, -1), "Y")
+    Yi, p_none, m_none = ops.afno_mlp2(X.cuda(), W1T, b1.cuda(), W2T, b2.cuda(), nb, bs, ops.ACT_IDS[act], mode=0)
+    assert p_none is None and m_none is None and torch.equal(Yi, Y)          # inference form: same numbers, no stores
+    # backward data path: dO1pre = (dO2 W2^T) * act'(pre), dS = dO1pre W1^T; the K-contiguous form of W^T is W itself
+    dO2 = rnd(M, nb * N, seed=6)
+    pr = pre_ref.clone().requires_grad_(True)
+    (f(pr)).backward(torch.ones_like(pr))
+    dact = pr.grad
+    dmid_ref = torch.einsum("mko,kno->mkn", dO2.double().view(M, nb, N), W2.double()) * dact
+    dS_ref = torch.einsum("mko,kno->mkn", dmid_ref, W1.double())
+    dS, _, dmid = ops.afno_mlp2(dO2.cuda(), W2.cuda(), None, W1.cuda(), None, nb, bs, ops.ACT_IDS[act], mode=1,
+                                aux=pre_ref.float().reshape(M, -1).contiguous().cuda(), want_mid=True)
+    assert_close(dmid, dmid_ref.reshape(M, -1), "dO1pre")
+    assert_close(dS, dS_ref.reshape(M, -1), "dS")

@@ -50,8 +50,8 @@ def test_full_model_gradients_vs_oracle(name, B):
     for k, p in m.named_parameters():
         assert p.grad is not None, k
         worst = max(worst, assert_close(p.grad, sd[k].grad, f"{name} d{k}"))
-        n_ref = sd[k].grad.norm().item()
-        assert _rel(p.grad.norm().item(), n_ref) <= RTOL, f"{name} |d{k}|"
+        n_ref = sd[k].grad.double().norm().item()            # float64 accumulation: torch's fp32 norm of a 10M-element
+        assert _rel(p.grad.double().norm().item(), n_ref) <= RTOL, f"{name} |d{k}|"   # tensor is itself off by ~5e-4
     print(f"[{name}] worst normalised gradient error {worst:.2e}")
 
 
@@ -73,51 +73,80 @@ def _oracle_rollout_ckpt(sd, xx, yy, msk, cfg):
     return loss, torch.cat(preds, dim=-2)
 
 
-@pytest.mark.parametrize("name,T_ar,B", [("LARGE", 20, 1), ("TINY", 5, 2)])
-def test_long_rollout_train_step_vs_oracle(name, T_ar, B):
-    """BASELINE configs[4]: DPOT-Large 256^2, modes 64, 20-step auto-regressive rollout (configs/pretrain_large.yaml,
-    train_temporal.py:201-230): loss, global grad norm, per-tensor grad norms vs the CPU oracle; run with activation
-    recomputation (BlockFn re-runs its forward in backward), which must reproduce the plain run bit for bit"""
+def _gpu_rollout_grads(kw, salt, xx, yy, msk, recompute):
     from dpot_amd.train import FlatParams, FusedAdam, rollout
-    kw = getattr(R, name)
+    torch.cuda.empty_cache()
+    torch.cuda.reset_peak_memory_stats()
+    m, _ = build(kw, salt=salt)
+    m.recompute_blocks = recompute
+    fp = FlatParams(m)
+    opt = FusedAdam(fp, lr=1e-3, betas=(0.9, 0.9), weight_decay=1e-6, max_norm=10000.0)
+    opt.zero_grad()
+    loss, pred = rollout(m, xx.cuda(), yy.cuda(), msk.cuda())
+    loss.backward()
+    torch.cuda.synchronize()
+    peak = torch.cuda.max_memory_allocated() / 2 ** 30
+    norms = {k: p.grad.double().norm().item() for k, p in m.named_parameters()}
+    return loss.item(), opt.grad_norm().item(), norms, pred.detach(), fp.grad.clone(), peak
+
+
+def test_large_20_step_rollout_vs_reference_golden():
+    """BASELINE configs[4]: DPOT-Large 256^2, modes 64, 20-step auto-regressive rollout (configs/pretrain_large.yaml,
+    train_temporal.py:201-230), B=1: loss, global grad norm, per-tensor grad norms and the 20-step prediction against
+    golden numbers produced by the imported reference (oracle/make_golden_large.py - the CPU run takes ~10 min, so it
+    is a committed fixture); with activation recomputation (BlockFn re-runs its forward in backward) and without -
+    the two must agree bit for bit"""
+    from helpers import assert_sub, load
+    fx = load("g11_large_rollout")
+    T_ar, B = int(fx["T_ar"]), int(fx["B"])
+    cfg = R.DPOTConfig(**R.LARGE)
+    S = cfg.img_size
+    xx = R.recipe_input((B, S, S, cfg.in_timesteps, cfg.in_channels), salt=81)
+    yy = R.recipe_input((B, S, S, T_ar, cfg.out_channels), salt=82)
+    msk = torch.ones(B, S, S, 1, cfg.out_channels)
+    res = {}
+    for recompute in (True, False):
+        loss, gn, norms, pred, flat, peak = _gpu_rollout_grads(R.LARGE, 6, xx, yy, msk, recompute)
+        print(f"[LARGE T_ar={T_ar} B={B}] recompute={recompute}: loss {loss:.6f} (reference {float(fx['loss']):.6f}), "
+              f"|g| {gn:.6e} (reference {float(fx['grad_norm']):.6e}), peak memory {peak:.2f} GiB")
+        assert _rel(loss, float(fx["loss"])) <= RTOL
+        assert _rel(gn, float(fx["grad_norm"])) <= RTOL
+        assert_sub(pred, fx, "pred", "20-step prediction")
+        for n, want in zip(fx["names"], fx["grad_norms"]):
+            assert _rel(norms[str(n)], float(want)) <= RTOL + 1e-7 / (float(want) + 1e-30), str(n)
+        res[recompute] = (loss, flat, peak)
+        del pred
+    assert res[True][0] == res[False][0]
+    assert torch.equal(res[True][1], res[False][1]), "recomputation must not change a single bit"
+    assert res[True][2] < 0.6 * res[False][2], "recomputation should cut the activation memory"
+
+
+def test_tiny_5_step_rollout_vs_oracle():
+    """T_ar=5 DPOT-Tiny rollout (B=2) against the CPU oracle run live: loss, grad norms, prediction; +- recomputation"""
+    kw, T_ar, B = R.TINY, 5, 2
     cfg = R.DPOTConfig(**kw)
     S = cfg.img_size
     xx = R.recipe_input((B, S, S, cfg.in_timesteps, cfg.in_channels), salt=81)
     yy = R.recipe_input((B, S, S, T_ar, cfg.out_channels), salt=82)
     msk = torch.ones(B, S, S, 1, cfg.out_channels)
-    # oracle
     sd = OrderedDict((k, v.clone().requires_grad_(True)) for k, v in R.recipe_state_dict(cfg, salt=6).items())
     loss_ref, pred_ref = _oracle_rollout_ckpt(sd, xx, yy, msk, cfg)
     loss_ref.backward()
-    ref_norms = {k: v.grad.norm().item() for k, v in sd.items() if v.grad is not None}
+    ref_norms = {k: v.grad.double().norm().item() for k, v in sd.items() if v.grad is not None}
     ref_total = sum(v ** 2 for v in ref_norms.values()) ** 0.5
-    results = {}
+    res = {}
     for recompute in (True, False):
-        torch.cuda.empty_cache()
-        torch.cuda.reset_peak_memory_stats()
-        m, _ = build(kw, salt=6)
-        m.recompute_blocks = recompute
-        fp = FlatParams(m)
-        opt = FusedAdam(fp, lr=1e-3, betas=(0.9, 0.9), weight_decay=1e-6, max_norm=10000.0)
-        opt.zero_grad()
-        loss, pred = rollout(m, xx.cuda(), yy.cuda(), msk.cuda())
-        loss.backward()
-        torch.cuda.synchronize()
-        peak = torch.cuda.max_memory_allocated() / 2 ** 30
-        results[recompute] = (loss.item(), fp.grad.clone(), peak)
-        print(f"[{name} T_ar={T_ar} B={B}] recompute={recompute}: loss {loss.item():.6f} (oracle "
-              f"{loss_ref.item():.6f}), |g| {opt.grad_norm().item():.6e} (oracle {ref_total:.6e}), "
-              f"peak memory {peak:.2f} GiB")
-        assert _rel(loss.item(), loss_ref.item()) <= RTOL
-        assert _rel(opt.grad_norm().item(), ref_total) <= RTOL
-        assert_close(pred, pred_ref, f"{name} rollout pred")
-        for k, p in m.named_parameters():
-            if k in ref_norms:
-                assert _rel(p.grad.norm().item(), ref_norms[k]) <= RTOL + 1e-7 / (ref_norms[k] + 1e-30), k
-        del m, fp, opt, loss, pred
-    assert results[True][0] == results[False][0]
-    assert torch.equal(results[True][1], results[False][1]), "recomputation must not change a single bit"
-    assert results[True][2] < 0.6 * results[False][2], "recomputation should cut the activation memory"
+        loss, gn, norms, pred, flat, peak = _gpu_rollout_grads(kw, 6, xx, yy, msk, recompute)
+        print(f"[TINY T_ar={T_ar} B={B}] recompute={recompute}: loss {loss:.6f} (oracle {loss_ref.item():.6f}), "
+              f"|g| {gn:.6e} (oracle {ref_total:.6e}), peak memory {peak:.2f} GiB")
+        assert _rel(loss, loss_ref.item()) <= RTOL
+        assert _rel(gn, ref_total) <= RTOL
+        assert_close(pred, pred_ref, "rollout pred")
+        for k, want in ref_norms.items():
+            assert _rel(norms[k], want) <= RTOL + 1e-7 / (want + 1e-30), k
+        res[recompute] = (loss, flat, peak)
+    assert res[True][0] == res[False][0] and torch.equal(res[True][1], res[False][1])
+    assert res[True][2] < res[False][2]
 
 
 def test_recompute_with_noise_and_graph_capture():
