@@ -80,21 +80,33 @@ def mixer_roofline(model, B: int):
         b1 = torch.randn(nb, N, device="cuda") * 0.1
         b2 = torch.randn(nb, N, device="cuda") * 0.1
 
+        if fused:
+            W1f, _ = ops.afno_block_weights(W1)
+            W2f, _ = ops.afno_block_weights(W2)
+
         def run(train: bool):
             if fused:
-                return ops.afno_mlp2(S, W1, b1, W2, b2, nb, bs, 1, mode=0, want_pre=train, want_mid=train)
+                return ops.afno_mlp2(S, W1f, b1, W2f, b2, nb, bs, 1, mode=0, want_pre=train, want_mid=train)
             O1, O1pre, O2 = torch.empty_like(S), torch.empty_like(S), torch.empty_like(S)
             kw = dict(lda=2 * E, ldb=N, ldc=2 * E, batch=nb, strideA=N, strideB=N * N, strideC=N, strideBias=N, tag=1)
             ops.gemm(S, W1, O1, Mm, N, N, bias=b1, act=1, mode=ops.EPI_ACT, preact=O1pre, ldpre=2 * E, stridePre=N, **kw)
             ops.gemm(O1, W2, O2, Mm, N, N, bias=b2, **kw)
 
         def timeit(train: bool, reps: int = 50):
-            for _ in range(5):
+            # `reps` launches captured in one hipGraph: the host cost of a Python -> ctypes launch (tens of us) must
+            # not be what the events measure
+            for _ in range(3):
                 run(train)
+            torch.cuda.synchronize()
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                for _ in range(reps):
+                    run(train)
+            g.replay()
+            torch.cuda.synchronize()
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
-            for _ in range(reps):
-                run(train)
+            g.replay()
             e1.record()
             e1.synchronize()
             return e0.elapsed_time(e1) * 1e-3 / reps

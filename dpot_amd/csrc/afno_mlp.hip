@@ -16,11 +16,17 @@
 //   * R is chosen per problem so that the panels fill the 256 CUs evenly (DPOT-Tiny, B=32: 18432 block-rows / 256 CUs
 //     = 72 -> R = 80: 232 workgroups, one per CU, 90 % of them busy to the end); v_mfma_f32_16x16x4_f32 (exact fp32,
 //     same rate as 32x32x2) gives the 16-row granularity that needs.
-//   * operands reach LDS by LDS-DMA (global_load_lds_dwordx4): a K-slab is 16 deep, so a (16 rows x 16 k) fragment
-//     block is exactly 1 KiB = one wave-instruction; lane l fetches (row l&15, k 4*(l>>4)..+3), which makes the LDS image
-//     of a block lane-linear in MFMA operand order: fragments are read back with one conflict-free ds_read_b128 per
-//     block (4 k-steps).  Weights are packed K-contiguous (Wt[n][k]) for this.  Two LDS buffers, one barrier per slab:
-//     wait own DMA (vmcnt 0) -> barrier -> issue slab t+1 -> 4*RT*NT MFMAs of slab t.
+//   * operands reach LDS by LDS-DMA (global_load_lds_dwordx4, 1 KiB per wave-instruction), always as FULL 128-byte
+//     lines read by adjacent lanes (a first version fetched "fragment shaped" 16 rows x 64 B per instruction: 64
+//     separate 16-byte L1 accesses each - the kernel was bound by the CU's load path at 2x the MFMA time):
+//       - weights are pre-packed in FRAGMENT-BLOCK-MAJOR order (dpot_afno_block_weights): the (16 n x 16 k) block of
+//         column tile c / K-slab t is 1 KiB contiguous, chunk l = (n = l&15, k = 4*(l>>4)..+3) = the MFMA operand
+//         order, so one DMA instruction streams it and one conflict-free ds_read_b128 per lane reads it back;
+//       - X rows (the spectrum, row-major) are fetched 32 k at a time: one instruction = 8 rows x 128 B, lane
+//         (r = l>>3, c = l&7) fetching chunk c ^ (r>>1) of its row - the XOR swizzle on the SOURCE address makes the
+//         lane-linear LDS image [16 rows][128 B] conflict-free for the fragment reads (row, chunk (4h+q) ^ (row>>1)).
+//     Two LDS buffers each, one barrier per 16-k slab: wait own DMA (vmcnt 0) -> barrier -> issue slab t+1 (and every
+//     other slab the next X super-slab) -> 4*RT*NT MFMAs of slab t.
 //   * 4 waves, wave w owns all R rows x columns [16*NT*w, 16*NT*(w+1)): RT x NT accumulators of 16x16 (80 AGPRs at
 //     RT=5, NT=4).  Epilogues bounce each 16-row tile through a per-wave LDS slab so that bias / aux loads and all
 //     global stores are 16-byte accesses, 64*NT bytes contiguous per row.
@@ -32,7 +38,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 struct AfnoMlpArgs {
   const float* X;     // [M, ldx]
-  const float* Wa;    // [nb][N][N], Wt[n][k] (K-contiguous)
+  const float* Wa;    // [nb][N/16 column tiles][N/16 slabs][256]: fragment-block-major (dpot_afno_block_weights)
   const float* Wb;
   const float* ba;    // [nb][N] or NULL
   const float* bb;
@@ -55,12 +61,13 @@ __global__ __launch_bounds__(256) void afno_mlp2_kernel(const AfnoMlpArgs p) {
   constexpr int NCT = 4 * NT;       // 16-column tiles of the panel = K-slabs
   constexpr int NSLAB = NCT;
   constexpr int BFL = NCT * 256;    // floats of one weight slab  (N x 16)
-  constexpr int AFL = RT * 256;     // floats of one X slab       (16*RT x 16)
+  constexpr int AFL = RT * 512;     // floats of one X super-slab (16*RT rows x 32 k)
+  constexpr int NXI = 2 * RT;       // DMA instructions per X super-slab (8 rows x 128 B each)
   constexpr int WCOLS = 16 * NT;    // columns per wave
   // ONE shared array (a second LDS object makes hipcc wait vmcnt(0) before every fragment read of a DMA pipeline)
   __shared__ __attribute__((aligned(16))) float lds[2 * BFL + 2 * AFL + RT * NCT * 256];
   float* const Bb = lds;                    // [2][NCT][256]
-  float* const Ab = lds + 2 * BFL;          // [2][RT][256]
+  float* const Ab = lds + 2 * BFL;          // [2][RT][16 rows][32 k], chunk-swizzled
   float* const Y1 = Ab + 2 * AFL;           // [RT][NCT][256]
   float* const stage_all = lds + BFL;       // epilogue staging = weight buffer 1 (dead at those points): [4][16][WCOLS]
 
@@ -83,29 +90,32 @@ __global__ __launch_bounds__(256) void afno_mlp2_kernel(const AfnoMlpArgs p) {
   const float* Wa = p.Wa + (long long)kblk * N * N;
   const float* Wb = p.Wb + (long long)kblk * N * N;
 
-  // ---- LDS-DMA of one K-slab: the RT X-blocks and the NCT weight blocks, dealt round-robin to the 4 waves
-  // lane l of a block fetches (row l&15 of the block, k = 4*(l>>4) .. +3) -> LDS chunk l of the block
-  long long xoff[(RT + 3) / 4];
-#pragma unroll
-  for (int n = 0; n < (RT + 3) / 4; ++n) {
-    const int i = wave + 4 * n;
-    int row = row0 + 16 * i + fr;
-    row = row < p.M ? row : p.M - 1;                  // clamped: rows past M only feed outputs that are never stored
-    xoff[n] = (long long)row * p.ldx + 4 * fq;
-  }
-  const int woff = fr * N + 4 * fq;                   // + (16*c)*N + 16*t for column tile c, slab t
-  auto issue_w = [&](const float* __restrict__ W, int t, float* dstbuf) __attribute__((always_inline)) {
+  // ---- LDS-DMA.  Weights: block (c, t) is 1 KiB contiguous in global memory, lane l fetches its chunk l.
+  // X: instruction n of a super-slab = rows 8n .. 8n+7 of the panel, lane (r = l>>3, c = l&7) fetches 16-byte chunk
+  // c ^ ((row_in_tile>>1)&7) of its row.  Pieces are dealt round-robin to the 4 waves.
+  const float* Wa_l = Wa + lane * 4;
+  const float* Wb_l = Wb + lane * 4;
+  auto issue_w = [&](const float* __restrict__ Wl, int t, float* dstbuf) __attribute__((always_inline)) {
 #pragma unroll
     for (int n = 0; n < NT; ++n) {
       const int c = wave + 4 * n;
-      glds16(W + woff + (16 * c) * N + 16 * t, dstbuf + c * 256);
+      glds16(Wl + (c * NSLAB + t) * 256, dstbuf + c * 256);
     }
   };
-  auto issue_x = [&](int t, float* dstbuf) __attribute__((always_inline)) {
+  long long xoff[(NXI + 3) / 4];
 #pragma unroll
-    for (int n = 0; n < (RT + 3) / 4; ++n) {
-      const int i = wave + 4 * n;
-      if (i < RT) glds16(X + xoff[n] + 16 * t, dstbuf + i * 256);       // wave-uniform predicate
+  for (int n = 0; n < (NXI + 3) / 4; ++n) {
+    const int q = wave + 4 * n;                       // instruction index: rows 8q .. 8q+7 of the panel
+    const int rt = (8 * q + (lane >> 3)) & 15;        // row inside its 16-row tile
+    int row = row0 + 8 * q + (lane >> 3);
+    row = row < p.M ? row : p.M - 1;                  // clamped: rows past M only feed outputs that are never stored
+    xoff[n] = (long long)row * p.ldx + 4 * ((lane & 7) ^ ((rt >> 1) & 7));
+  }
+  auto issue_x = [&](int T, float* dstbuf) __attribute__((always_inline)) {
+#pragma unroll
+    for (int n = 0; n < (NXI + 3) / 4; ++n) {
+      const int q = wave + 4 * n;
+      if (q < NXI) glds16(X + xoff[n] + 32 * T, dstbuf + q * 256);        // wave-uniform predicate
     }
   };
 
@@ -192,23 +202,27 @@ __global__ __launch_bounds__(256) void afno_mlp2_kernel(const AfnoMlpArgs p) {
   // ================= layer 1:  acc = X[panel, :] Wa =================
   zero_acc();
   issue_x(0, Ab);
-  issue_w(Wa, 0, Bb);
+  issue_w(Wa_l, 0, Bb);
+  // this lane's X fragment chunk inside a row tile, for the even / odd 16-k half of a super-slab
+  const int xfrag0 = fr * 32 + 4 * ((fq) ^ ((fr >> 1) & 7));
+  const int xfrag1 = fr * 32 + 4 * ((4 + fq) ^ ((fr >> 1) & 7));
 #pragma unroll 1
   for (int t = 0; t < NSLAB; ++t) {
     slab_sync();
-    const int cur = t & 1;
+    const int cur = t & 1, T = t >> 1;
     if (t + 1 < NSLAB) {
-      issue_x(t + 1, Ab + (cur ^ 1) * AFL);
-      issue_w(Wa, t + 1, Bb + (cur ^ 1) * BFL);
+      if (t & 1) issue_x(T + 1, Ab + ((T + 1) & 1) * AFL);
+      issue_w(Wa_l, t + 1, Bb + (cur ^ 1) * BFL);
     }
     __builtin_amdgcn_sched_barrier(0);
     f32x4 af[RT];
+    const float* xs = Ab + (T & 1) * AFL + ((t & 1) ? xfrag1 : xfrag0);
 #pragma unroll
-    for (int i = 0; i < RT; ++i) af[i] = *reinterpret_cast<const f32x4*>(Ab + cur * AFL + i * 256 + lane * 4);
+    for (int i = 0; i < RT; ++i) af[i] = *reinterpret_cast<const f32x4*>(xs + i * 512);
     mma_slab(af, Bb + cur * BFL);
   }
   __syncthreads();                    // weight buffer 1 (last slab) is dead: it becomes the epilogue staging area
-  issue_w(Wb, 0, Bb);                 // layer-2 weights start streaming under the epilogue (buffer 0)
+  issue_w(Wb_l, 0, Bb);               // layer-2 weights start streaming under the epilogue (buffer 0)
   epilogue(true, p.ba);
   __syncthreads();                    // Y1 complete
 
@@ -218,7 +232,7 @@ __global__ __launch_bounds__(256) void afno_mlp2_kernel(const AfnoMlpArgs p) {
   for (int u = 0; u < NSLAB; ++u) {
     slab_sync();
     const int cur = u & 1;
-    if (u + 1 < NSLAB) issue_w(Wb, u + 1, Bb + (cur ^ 1) * BFL);
+    if (u + 1 < NSLAB) issue_w(Wb_l, u + 1, Bb + (cur ^ 1) * BFL);
     __builtin_amdgcn_sched_barrier(0);
     f32x4 af[RT];
 #pragma unroll
@@ -228,6 +242,26 @@ __global__ __launch_bounds__(256) void afno_mlp2_kernel(const AfnoMlpArgs p) {
   }
   __syncthreads();
   epilogue(false, p.bb);
+}
+
+// Wbig [J][N][N] (row-major, as dpot_afno_pack writes it: W[k][n]) -> fragment-block-major copies
+//   fwd[j][c][t][4*l + e] = W[k = 16t + 4(l>>4) + e][n = 16c + (l&15)]     (Wt = W^T: the forward multiplies by W)
+//   bwd[j][c][t][4*l + e] = W[16c + (l&15)][16t + 4(l>>4) + e]             (Wt = W:   the backward multiplies by W^T)
+__global__ __launch_bounds__(256) void afno_block_weights_kernel(const float* __restrict__ W, float* __restrict__ fwd,
+                                                                 float* __restrict__ bwd, int N, long long total) {
+  const int nct = N / 16;
+  for (long long idx = blockIdx.x * 256ll + threadIdx.x; idx < total; idx += (long long)gridDim.x * 256) {
+    const int e = (int)(idx & 3), l = (int)((idx >> 2) & 63);
+    long long blk = idx >> 8;
+    const int t = (int)(blk % nct);
+    blk /= nct;
+    const int c = (int)(blk % nct);
+    const long long j = blk / nct;
+    const int a = 16 * c + (l & 15), b = 16 * t + 4 * (l >> 4) + e;
+    const float* Wj = W + j * (long long)N * N;
+    if (fwd) fwd[idx] = Wj[(long long)b * N + a];
+    if (bwd) bwd[idx] = Wj[(long long)a * N + b];
+  }
 }
 
 constexpr int AFNO_NUM_CU = 256;
@@ -271,6 +305,17 @@ using namespace dpot;
 extern "C" int dpot_afno_mlp2_supported(int nb, int bs) {
   const int N = 2 * bs;
   return nb > 0 && (N == 64 || N == 128 || N == 192 || N == 256) ? 1 : 0;
+}
+
+extern "C" int dpot_afno_block_weights(const float* wbig, float* fwd, float* bwd, int nmat, int N,
+                                       dpot_stream_t stream) {
+  DPOT_REQUIRE(wbig && (fwd || bwd) && nmat > 0 && N > 0 && N % 16 == 0, "afno_block_weights: bad argument");
+  const long long total = (long long)nmat * N * N;
+  long long g = (total + 255) / 256;
+  if (g > 8192) g = 8192;
+  hipLaunchKernelGGL(afno_block_weights_kernel, dim3((unsigned)g), dim3(256), 0, as_stream(stream), wbig, fwd, bwd, N,
+                     total);
+  return check_launch("afno_block_weights_kernel");
 }
 
 extern "C" int dpot_afno_mlp2(const float* X, const float* WaT, const float* ba, const float* WbT, const float* bb,

@@ -198,7 +198,7 @@ def _block_parts(x, n1w, n1b, n2w, n2b, f1w, f1b, packed, dims, mp, need_out, f2
     B, tok, E, h, w, nb, bs, mx, my, mh, act = dims
     Mm, M = B * mx * my, B * tok
     dev = x.device
-    (wb1, bb1, wb1T), (wb2, bb2, wb2T) = packed
+    (wb1, bb1, wb1T, _), (wb2, bb2, wb2T, _) = packed          # w*T: fragment-block-major W for the fused kernel
     xn1, mean1, rstd1 = ops.groupnorm_fwd(x, n1w, n1b)
     S = ops.rfft2(xn1, h, w, nb, mx, my, 0)                                # [Mm, 2E]
     if wb1T is not None:
@@ -239,13 +239,14 @@ class BlockFn(torch.autograd.Function):
         bs = E // nb
         mx, my = min(modes, h), min(modes, w // 2 + 1)
         mh = f1w.shape[0]
-        if packed is None:      # ((Wbig1, bbig1, Wbig1^T), (Wbig2, ...)); normally packed for all blocks by the model
+        if packed is None:      # ((Wbig1, bbig1, blocked W1, blocked W1^T), (...)); normally packed by the model
             packed = (ops.afno_pack3(w1, b1), ops.afno_pack3(w2, b2))
         dims = (B, tok, E, h, w, nb, bs, mx, my, mh, act)
         mp = ops.mlp_precision()                                               # channel-MLP GEMM precision override
         out, parts = _block_parts(x, n1w, n1b, n2w, n2b, f1w, f1b, packed, dims, mp, True, f2w, f2b)
-        wb1, wb2 = packed[0][0], packed[1][0]
         ctx.fused_mixer = packed[0][2] is not None
+        # weights the backward data path multiplies by: blocked W^T (fused kernel) or the plain Wbig (generic GEMM)
+        wb1, wb2 = (packed[0][3], packed[1][3]) if ctx.fused_mixer else (packed[0][0], packed[1][0])
         opt_t = (packed[0][2], packed[1][2]) if ctx.fused_mixer else ()
         if recompute:
             ctx.save_for_backward(x, wb1, packed[0][1], wb2, packed[1][1], n1w, n1b, n2w, n2b, f1w, f1b, f2w, *opt_t)
@@ -264,8 +265,8 @@ class BlockFn(torch.autograd.Function):
             x, wb1, bb1, wb2, bb2, n1w, n1b, n2w, n2b, f1w, f1b, f2w, *wts = ctx.saved_tensors
             wb1T, wb2T = wts if ctx.fused_mixer else (None, None)
             with torch.no_grad():
-                _, parts = _block_parts(x, n1w, n1b, n2w, n2b, f1w, f1b, ((wb1, bb1, wb1T), (wb2, bb2, wb2T)),
-                                        ctx.dims, mp, False)
+                _, parts = _block_parts(x, n1w, n1b, n2w, n2b, f1w, f1b,
+                                        ((wb1, bb1, wb1T, None), (wb2, bb2, wb2T, None)), ctx.dims, mp, False)
             mean1, rstd1, S, O1pre, O1, y1, mean2, rstd2, xn2, Hpre, Hh = parts
         else:
             (x, mean1, rstd1, S, O1pre, O1, y1, mean2, rstd2, xn2, Hpre, Hh, wb1, wb2, n1w, n2w, f1w,
@@ -302,8 +303,8 @@ class BlockFn(torch.autograd.Function):
             ops.gemm(O1, dO2, dw2, 2 * bs, 2 * bs, Mm, colsum_out=db2, colsum_of=2, **wkw)
             dw2, db2 = s_w2.done(dw2), s_b2.done(db2)
         if ctx.fused_mixer:
-            # data path of both layers in one launch: dO1pre = (dO2 W2^T) * act'(O1pre), dS = dO1pre W1^T.  The packed
-            # Wbig[k][n] IS the K-contiguous form of the transposed weight the backward multiplies by.
+            # data path of both layers in one launch: dO1pre = (dO2 W2^T) * act'(O1pre), dS = dO1pre W1^T
+            # (wb1 / wb2 hold the fragment-block-major W^T here)
             dS, _, dO1pre = ops.afno_mlp2(dO2, wb2, None, wb1, None, nb, bs, act, mode=1, aux=O1pre, want_mid=True)
         else:
             dO1pre = torch.empty(Mm, 2 * E, dtype=torch.float32, device=dev)

@@ -202,12 +202,14 @@ def afno_pack(w: Tensor, b: Tensor) -> Tuple[Tensor, Tensor]:
     return wbig, bbig
 
 
-def afno_pack3(w: Tensor, b: Tensor) -> Tuple[Tensor, Tensor, Optional[Tensor]]:
-    """(Wbig, bbig, Wbig^T or None): the per-layer form of what afno_pack_multi returns"""
+def afno_pack3(w: Tensor, b: Tensor):
+    """(Wbig, bbig, blocked W | None, blocked W^T | None): the per-layer form of what afno_pack_multi returns"""
     _, nb, bs, _ = w.shape
     wbig, bbig = afno_pack(w, b)
-    wT = transpose2d(wbig, nb, 2 * bs, 2 * bs) if afno_mlp2_supported(nb, bs) else None
-    return wbig, bbig, wT
+    if afno_mlp2_supported(nb, bs):
+        wf, wb = afno_block_weights(wbig)
+        return wbig, bbig, wf, wb
+    return wbig, bbig, None, None
 
 
 def afno_pack_multi(pairs) -> list:
@@ -223,9 +225,21 @@ def afno_pack_multi(pairs) -> list:
                                            arr([wbig[i].data_ptr() for i in range(n)]),
                                            arr([bbig[i].data_ptr() for i in range(n)]), n, nb, bs, _stream()),
           "afno_pack_multi")
-    # K-contiguous copies Wt[n][k] = Wbig[k][n] for the fused 2-layer kernel (afno_mlp2): one transpose launch for all
-    wbigT = transpose2d(wbig, n * nb, 2 * bs, 2 * bs).view(n, nb, 2 * bs, 2 * bs) if afno_mlp2_supported(nb, bs) else None
-    return [(wbig[i], bbig[i], wbigT[i] if wbigT is not None else None) for i in range(n)]
+    # fragment-block-major copies for the fused 2-layer kernel (afno_mlp2): one launch for all layers
+    if afno_mlp2_supported(nb, bs):
+        wf, wb = afno_block_weights(wbig.view(n * nb, 2 * bs, 2 * bs))
+        wf, wb = wf.view(n, nb, 2 * bs, 2 * bs), wb.view(n, nb, 2 * bs, 2 * bs)
+        return [(wbig[i], bbig[i], wf[i], wb[i]) for i in range(n)]
+    return [(wbig[i], bbig[i], None, None) for i in range(n)]
+
+
+def afno_block_weights(wbig: Tensor) -> Tuple[Tensor, Tensor]:
+    """wbig [J, N, N] (W[k][n]) -> (fwd, bwd): fragment-block-major W and W^T (dpot_afno_block_weights)"""
+    J, N, _ = wbig.shape
+    fwd, bwd = torch.empty_like(wbig), torch.empty_like(wbig)
+    check(_lib.load().dpot_afno_block_weights(wbig.data_ptr(), fwd.data_ptr(), bwd.data_ptr(), J, N, _stream()),
+          "afno_block_weights")
+    return fwd, bwd
 
 
 def afno_mlp2_supported(nb: int, bs: int) -> bool:
@@ -236,7 +250,8 @@ def afno_mlp2(X: Tensor, WaT: Tensor, ba: Optional[Tensor], WbT: Tensor, bb: Opt
               act: int, mode: int = 0, aux: Optional[Tensor] = None, want_pre: bool = False, want_mid: bool = False):
     """both layers of the AFNO block-diagonal complex MLP in one launch (csrc/afno_mlp.hip).
     mode 0: pre = X Wa + ba, mid = act(pre), Y = mid Wb + bb;  mode 1: mid = (X Wa) * act'(aux), Y = mid Wb.
-    X / outputs: [M, nb*2*bs]; WaT / WbT: [nb, 2bs, 2bs] K-contiguous (Wt[n][k]).  Returns (Y, pre | None, mid | None)."""
+    X / outputs: [M, nb*2*bs]; WaT / WbT: [nb, 2bs, 2bs] fragment-block-major weights from afno_block_weights (`fwd`
+    to multiply by W, `bwd` to multiply by W^T).  Returns (Y, pre | None, mid | None)."""
     M, ld = X.shape
     Y = torch.empty_like(X)
     pre = torch.empty_like(X) if want_pre else None

@@ -293,14 +293,18 @@ int dpot_noise_inject_rng(const float* xx, float* out, float* norms, uint64_t* r
 /* The AFNO mixer's 2-layer block-diagonal complex MLP (models/dpot.py:72-94) as ONE launch (csrc/afno_mlp.hip):
  *   mode 0 (forward):        pre = X Wa + ba;  mid = act(pre);          Y = mid Wb + bb
  *   mode 1 (backward data):  mid = (X Wa) * act'(aux);                  Y = mid Wb         (ba = bb = NULL)
- * X [M, ldx], outputs / aux [M, ldo]: block k owns columns k*N..(k+1)*N, N = 2*bs = [re | im].  WaT / WbT: [nb][N][N]
- * K-CONTIGUOUS real weights Wt[n][k] = W[k][n] of the packed complex matrices (dpot_afno_pack gives W = Wbig[k][n]; its
- * transpose feeds the forward, Wbig itself is the Wt of the backward's W^T).  pre / mid may be NULL (inference).
- * Supported when 2*bs is 64, 128, 192 or 256 (dpot_afno_mlp2_supported); everything 16-byte aligned. */
+ * X [M, ldx], outputs / aux [M, ldo]: block k owns columns k*N..(k+1)*N, N = 2*bs = [re | im].  Wa / Wb: the real
+ * N x N matrices of the packed complex weights in FRAGMENT-BLOCK-MAJOR order, as written by dpot_afno_block_weights
+ * from dpot_afno_pack's Wbig: its `fwd` output for mode 0 (multiply by Wbig), its `bwd` output for mode 1 (multiply
+ * by Wbig^T).  pre / mid may be NULL (inference).  Supported when 2*bs is 64, 128, 192 or 256
+ * (dpot_afno_mlp2_supported); everything 16-byte aligned. */
 int dpot_afno_mlp2_supported(int nb, int bs);
-int dpot_afno_mlp2(const float* X, const float* WaT, const float* ba, const float* WbT, const float* bb,
+int dpot_afno_mlp2(const float* X, const float* Wa, const float* ba, const float* Wb, const float* bb,
                    const float* aux, float* pre, float* mid, float* Y, int M, int nb, int bs, int ldx, int ldo,
                    int act, int mode, dpot_stream_t stream);
+/* wbig [nmat][N][N] (row-major W[k][n]) -> [nmat][N/16][N/16][256] blocks of (16 n x 16 k), chunk l of a block =
+ * (n = l&15, k = 4*(l>>4)..+3): fwd holds W (for X W), bwd holds W^T (for X W^T).  Either output may be NULL. */
+int dpot_afno_block_weights(const float* wbig, float* fwd, float* bwd, int nmat, int N, dpot_stream_t stream);
 
 /* backward of the noise injection for AR steps whose input depends on earlier predictions:
  * dx = g + noise_scale * xx / norms[b,c] * sum_(X,Y,T)(g * eps).  eps: the tensor the forward used, or NULL with

@@ -1,0 +1,40 @@
+"""micro-benchmark of the fused AFNO MLP kernel (csrc/afno_mlp.hip): hipGraph of 50 launches, event timed.
+   DPOT_AFNO_MLP_RT=1..5 forces the panel height (16*RT rows)."""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from dpot_amd import ops
+
+def bench(nb, bs, M, reps=50):
+    N = 2 * bs
+    S = torch.randn(M, nb * N, device="cuda")
+    W1 = torch.randn(nb, N, N, device="cuda") * 0.05
+    W2 = torch.randn(nb, N, N, device="cuda") * 0.05
+    b1 = torch.randn(nb, N, device="cuda") * 0.1
+    b2 = torch.randn(nb, N, device="cuda") * 0.1
+    W1f, W1b = ops.afno_block_weights(W1)
+    W2f, W2b = ops.afno_block_weights(W2)
+    pre = torch.randn(M, nb * N, device="cuda")
+    forms = {"fwd-train": lambda: ops.afno_mlp2(S, W1f, b1, W2f, b2, nb, bs, 1, mode=0, want_pre=True, want_mid=True),
+             "fwd-infer": lambda: ops.afno_mlp2(S, W1f, b1, W2f, b2, nb, bs, 1, mode=0),
+             "bwd-data": lambda: ops.afno_mlp2(S, W2b, None, W1b, None, nb, bs, 1, mode=1, aux=pre, want_mid=True)}
+    flops = 2 * 2.0 * M * N * N * nb
+    out = []
+    for name, fn in forms.items():
+        for _ in range(3):
+            fn()
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            for _ in range(reps):
+                fn()
+        g.replay(); torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(); g.replay(); e1.record(); e1.synchronize()
+        t = e0.elapsed_time(e1) * 1e-3 / reps
+        out.append(f"{name} {t*1e6:7.1f} us {flops/t/1e12:6.1f} TF")
+    print(f"RT={os.environ.get('DPOT_AFNO_MLP_RT','auto')} nb={nb} bs={bs} M={M}: " + " | ".join(out), flush=True)
+
+if __name__ == "__main__":
+    for nb, bs, M in ((4, 128, 4608), (8, 128, 2304), (16, 96, 2176)):
+        bench(nb, bs, M)

@@ -489,8 +489,8 @@ def test_afno_mlp2_fused_two_layers(ops, nb, bs, M, act):
     pre_ref = torch.einsum("mkn,kno->mko", Xd, W1.double()) + b1.double()
     mid_ref = f(pre_ref)
     Y_ref = torch.einsum("mkn,kno->mko", mid_ref, W2.double()) + b2.double()
-    W1T = W1.transpose(1, 2).contiguous().cuda()
-    W2T = W2.transpose(1, 2).contiguous().cuda()
+    W1T, W1B = ops.afno_block_weights(W1.cuda())                 # blocked W (forward), blocked W^T (backward)
+    W2T, W2B = ops.afno_block_weights(W2.cuda())
     Y, pre, mid = ops.afno_mlp2(X.cuda(), W1T, b1.cuda(), W2T, b2.cuda(), nb, bs, ops.ACT_IDS[act], mode=0,
                                 want_pre=True, want_mid=True)
     assert_close(pre, pre_ref.reshape(M, -1), "pre")
@@ -498,14 +498,14 @@ def test_afno_mlp2_fused_two_layers(ops, nb, bs, M, act):
     assert_close(Y, Y_ref.reshape(M, -1), "Y")
     Yi, p_none, m_none = ops.afno_mlp2(X.cuda(), W1T, b1.cuda(), W2T, b2.cuda(), nb, bs, ops.ACT_IDS[act], mode=0)
     assert p_none is None and m_none is None and torch.equal(Yi, Y)          # inference form: same numbers, no stores
-    # backward data path: dO1pre = (dO2 W2^T) * act'(pre), dS = dO1pre W1^T; the K-contiguous form of W^T is W itself
+    # backward data path: dO1pre = (dO2 W2^T) * act'(pre), dS = dO1pre W1^T
     dO2 = rnd(M, nb * N, seed=6)
     pr = pre_ref.clone().requires_grad_(True)
     (f(pr)).backward(torch.ones_like(pr))
     dact = pr.grad
     dmid_ref = torch.einsum("mko,kno->mkn", dO2.double().view(M, nb, N), W2.double()) * dact
     dS_ref = torch.einsum("mko,kno->mkn", dmid_ref, W1.double())
-    dS, _, dmid = ops.afno_mlp2(dO2.cuda(), W2.cuda(), None, W1.cuda(), None, nb, bs, ops.ACT_IDS[act], mode=1,
+    dS, _, dmid = ops.afno_mlp2(dO2.cuda(), W2B, None, W1B, None, nb, bs, ops.ACT_IDS[act], mode=1,
                                 aux=pre_ref.float().reshape(M, -1).contiguous().cuda(), want_mid=True)
     assert_close(dmid, dmid_ref.reshape(M, -1), "dO1pre")
     assert_close(dS, dS_ref.reshape(M, -1), "dS")
