@@ -55,21 +55,37 @@ __device__ __forceinline__ void glds16(const float* g, float* l) {
                                    (__attribute__((address_space(3))) void*)l, 16, 0, 0);
 }
 
+// 6 waves: waves 0-3 compute (wave w owns all R rows x columns [16*NT*w, 16*NT*(w+1)): RT x NT accumulators of 16x16),
+// waves 4-5 only issue the LDS-DMA.  A DMA piece costs the issuing wave 60-180 cycles of VMEM issue; inside the compute
+// waves' instruction stream that time comes straight out of the MFMA pipe (measured: 26 % of the wave cycles parked,
+// MFMA pipe 51 % busy), in a separate wave it runs beside the MFMAs.
+//
+// One workgroup barrier per 16-k slab, the loaders run TWO slabs ahead through a ring of three weight buffers (and two
+// X super-slab buffers): at barrier B_t every slab <= t+1 has landed, so a compute wave fetches the fragments of slab
+// t+1 into a second register set WHILE the MFMAs of slab t run - no LDS latency and no DMA latency behind a barrier.
+//   loader:   [issue slabs 0,1, X 0]  { vmcnt(0); B_t; issue slab t+2 (-> ring[(t+2)%3]), X super-slab on even t }
+//   compute:  B_0, read frags 0       { (t>0: B_t); read frags t+1; MFMAs of slab t }
+// Ring buffer (t+2)%3 was last read (as fragments of slab t-1) during iteration t-2: free at B_t.  The layer-2 weights
+// continue in the same ring (global slab index NSLAB + u); ring buffer (NSLAB-1)%3 is idle from B_(NSLAB-1) to the end
+// of epilogue 1 and after layer 2's last fragment read - it is the epilogues' staging area.
 template <int RT, int NT>
-__global__ __launch_bounds__(256) void afno_mlp2_kernel(const AfnoMlpArgs p) {
+__global__ __launch_bounds__(384) void afno_mlp2_kernel(const AfnoMlpArgs p) {
   constexpr int N = 64 * NT;        // = K
   constexpr int NCT = 4 * NT;       // 16-column tiles of the panel = K-slabs
   constexpr int NSLAB = NCT;
   constexpr int BFL = NCT * 256;    // floats of one weight slab  (N x 16)
   constexpr int AFL = RT * 512;     // floats of one X super-slab (16*RT rows x 32 k)
   constexpr int NXI = 2 * RT;       // DMA instructions per X super-slab (8 rows x 128 B each)
-  constexpr int WCOLS = 16 * NT;    // columns per wave
+  constexpr int WCOLS = 16 * NT;    // columns per compute wave
+  static_assert(NSLAB % 2 == 0, "slab loop is unrolled by two");
   // ONE shared array (a second LDS object makes hipcc wait vmcnt(0) before every fragment read of a DMA pipeline)
-  __shared__ __attribute__((aligned(16))) float lds[2 * BFL + 2 * AFL + RT * NCT * 256];
-  float* const Bb = lds;                    // [2][NCT][256]
-  float* const Ab = lds + 2 * BFL;          // [2][RT][16 rows][32 k], chunk-swizzled
+  __shared__ __attribute__((aligned(16))) float lds[3 * BFL + 2 * AFL + RT * NCT * 256];
+  float* const Bb = lds;                    // [3][NCT][256]
+  float* const Ab = lds + 3 * BFL;          // [2][RT][16 rows][32 k], chunk-swizzled
   float* const Y1 = Ab + 2 * AFL;           // [RT][NCT][256]
-  float* const stage_all = lds + BFL;       // epilogue staging = weight buffer 1 (dead at those points): [4][16][WCOLS]
+  // epilogue staging [4][16][WCOLS] = the ring buffer that is idle while the epilogues run: during epilogue 1 the ring
+  // holds the layer-2 slabs 0 and 1 (buffers NSLAB % 3, (NSLAB+1) % 3), the third one last held layer-1 slab NSLAB-1
+  float* const stage_all = lds + ((NSLAB - 1) % 3) * BFL;
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -86,39 +102,65 @@ __global__ __launch_bounds__(256) void afno_mlp2_kernel(const AfnoMlpArgs p) {
   }
   const int kblk = item / p.panels, panel = item - kblk * p.panels;
   const int row0 = panel * (16 * RT);
-  const float* X = p.X + (long long)kblk * N;
-  const float* Wa = p.Wa + (long long)kblk * N * N;
-  const float* Wb = p.Wb + (long long)kblk * N * N;
 
-  // ---- LDS-DMA.  Weights: block (c, t) is 1 KiB contiguous in global memory, lane l fetches its chunk l.
-  // X: instruction n of a super-slab = rows 8n .. 8n+7 of the panel, lane (r = l>>3, c = l&7) fetches 16-byte chunk
-  // c ^ ((row_in_tile>>1)&7) of its row.  Pieces are dealt round-robin to the 4 waves.
-  const float* Wa_l = Wa + lane * 4;
-  const float* Wb_l = Wb + lane * 4;
-  auto issue_w = [&](const float* __restrict__ Wl, int t, float* dstbuf) __attribute__((always_inline)) {
-#pragma unroll
-    for (int n = 0; n < NT; ++n) {
-      const int c = wave + 4 * n;
-      glds16(Wl + (c * NSLAB + t) * 256, dstbuf + c * 256);
-    }
+  auto bar = [&]() __attribute__((always_inline)) {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
   };
-  long long xoff[(NXI + 3) / 4];
+
+  if (wave >= 4) {
+    // ================================ loader waves ================================
+    const int L = wave - 4;
+    const float* X = p.X + (long long)kblk * N;
+    const float* Wa_l = p.Wa + (long long)kblk * N * N + lane * 4;
+    const float* Wb_l = p.Wb + (long long)kblk * N * N + lane * 4;
+    // weights: block (c, t) is 1 KiB contiguous in global memory, lane l fetches its chunk l
+    auto issue_w = [&](const float* __restrict__ Wl, int t, float* dstbuf) __attribute__((always_inline)) {
 #pragma unroll
-  for (int n = 0; n < (NXI + 3) / 4; ++n) {
-    const int q = wave + 4 * n;                       // instruction index: rows 8q .. 8q+7 of the panel
-    const int rt = (8 * q + (lane >> 3)) & 15;        // row inside its 16-row tile
-    int row = row0 + 8 * q + (lane >> 3);
-    row = row < p.M ? row : p.M - 1;                  // clamped: rows past M only feed outputs that are never stored
-    xoff[n] = (long long)row * p.ldx + 4 * ((lane & 7) ^ ((rt >> 1) & 7));
+      for (int n = 0; n < NCT / 2; ++n) {
+        const int c = L + 2 * n;
+        glds16(Wl + (c * NSLAB + t) * 256, dstbuf + c * 256);
+      }
+    };
+    // X: instruction q of a super-slab = rows 8q .. 8q+7 of the panel, lane (r = l>>3, c = l&7) fetches 16-byte
+    // chunk c ^ ((row_in_tile>>1)&7) of its row
+    long long xoff[(NXI + 1) / 2];
+#pragma unroll
+    for (int n = 0; n < (NXI + 1) / 2; ++n) {
+      const int q = L + 2 * n;
+      const int rt = (8 * q + (lane >> 3)) & 15;        // row inside its 16-row tile
+      int row = row0 + 8 * q + (lane >> 3);
+      row = row < p.M ? row : p.M - 1;                  // clamped: rows past M only feed outputs that are never stored
+      xoff[n] = (long long)row * p.ldx + 4 * ((lane & 7) ^ ((rt >> 1) & 7));
+    }
+    auto issue_x = [&](int T, float* dstbuf) __attribute__((always_inline)) {
+#pragma unroll
+      for (int n = 0; n < (NXI + 1) / 2; ++n) {
+        const int q = L + 2 * n;
+        if (q < NXI) glds16(X + xoff[n] + 32 * T, dstbuf + q * 256);      // wave-uniform predicate
+      }
+    };
+    issue_x(0, Ab);
+    issue_w(Wa_l, 0, Bb);
+    issue_w(Wa_l, 1, Bb + BFL);
+    int ring = 2;                                       // ring buffer of global slab index g + 2
+#pragma unroll 1
+    for (int g = 0; g < 2 * NSLAB; ++g) {               // g = global slab index (layer 1: 0..NSLAB-1, layer 2: the rest)
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // everything issued so far (slabs <= g+1) has landed
+      bar();                                            // B_g  (g == NSLAB: the barrier after epilogue 1)
+      const int nx = g + 2;
+      if (nx < 2 * NSLAB) {
+        if (nx < NSLAB) issue_w(Wa_l, nx, Bb + ring * BFL); else issue_w(Wb_l, nx - NSLAB, Bb + ring * BFL);
+      }
+      ring = ring == 2 ? 0 : ring + 1;
+      if (g < NSLAB && (g & 1) == 0 && (g >> 1) + 1 < NSLAB / 2) issue_x((g >> 1) + 1, Ab + (((g >> 1) + 1) & 1) * AFL);
+    }
+    bar();                                              // S2: end of layer 2
+    return;
   }
-  auto issue_x = [&](int T, float* dstbuf) __attribute__((always_inline)) {
-#pragma unroll
-    for (int n = 0; n < (NXI + 3) / 4; ++n) {
-      const int q = wave + 4 * n;
-      if (q < NXI) glds16(X + xoff[n] + 32 * T, dstbuf + q * 256);        // wave-uniform predicate
-    }
-  };
 
+  // ================================ compute waves ================================
   f32x4 acc[RT][NT];
   auto zero_acc = [&]() __attribute__((always_inline)) {
 #pragma unroll
@@ -126,11 +168,7 @@ __global__ __launch_bounds__(256) void afno_mlp2_kernel(const AfnoMlpArgs p) {
 #pragma unroll
       for (int j = 0; j < NT; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
   };
-  auto mma_slab = [&](const f32x4 (&af)[RT], const float* Bslab) __attribute__((always_inline)) {
-    f32x4 bf[NT];
-#pragma unroll
-    for (int j = 0; j < NT; ++j) bf[j] = *reinterpret_cast<const f32x4*>(Bslab + (wave * NT + j) * 256 + lane * 4);
-    // row-tile major: the first MFMAs need only af[0] and the weight fragments, the other X fragments land behind them
+  auto mma = [&](const f32x4 (&af)[RT], const f32x4 (&bf)[NT]) __attribute__((always_inline)) {
 #pragma unroll
     for (int i = 0; i < RT; ++i)
 #pragma unroll
@@ -139,10 +177,25 @@ __global__ __launch_bounds__(256) void afno_mlp2_kernel(const AfnoMlpArgs p) {
         for (int j = 0; j < NT; ++j)
           acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i][s], bf[j][s], acc[i][j], 0, 0, 0);
   };
-  auto slab_sync = [&]() __attribute__((always_inline)) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // my DMA pieces of the coming slab have landed ...
-    __builtin_amdgcn_s_barrier();                      // ... everybody's have, and nobody still reads the other buffer
-    asm volatile("" ::: "memory");
+  // weight fragments of global slab g (ring buffer g % 3), this wave's NT column tiles
+  auto read_w = [&](f32x4 (&bf)[NT], int ringbuf) __attribute__((always_inline)) {
+#pragma unroll
+    for (int j = 0; j < NT; ++j)
+      bf[j] = *reinterpret_cast<const f32x4*>(Bb + ringbuf * BFL + (wave * NT + j) * 256 + lane * 4);
+  };
+  // X fragments of layer-1 slab t: super-slab t/2, 16-k half t&1, chunk (4h + q) ^ (row>>1) of row fr
+  const int xfrag0 = fr * 32 + 4 * ((fq) ^ ((fr >> 1) & 7));
+  const int xfrag1 = fr * 32 + 4 * ((4 + fq) ^ ((fr >> 1) & 7));
+  auto read_x = [&](f32x4 (&af)[RT], int t) __attribute__((always_inline)) {
+    const float* xs = Ab + ((t >> 1) & 1) * AFL + ((t & 1) ? xfrag1 : xfrag0);
+#pragma unroll
+    for (int i = 0; i < RT; ++i) af[i] = *reinterpret_cast<const f32x4*>(xs + i * 512);
+  };
+  // layer-2 A fragments from Y1: K-slab u, chunk (k-quad, row rotated by u)
+  auto read_y = [&](f32x4 (&af)[RT], int u) __attribute__((always_inline)) {
+#pragma unroll
+    for (int i = 0; i < RT; ++i)
+      af[i] = *reinterpret_cast<const f32x4*>(Y1 + ((i * NCT + u) * 64 + fq * 16 + ((fr + u) & 15)) * 4);
   };
 
   // ---- epilogue of one layer: acc (+bias) -> [pre] -> f -> [mid] -> Y1 in LDS (layer 1) / -> Y (layer 2)
@@ -199,48 +252,57 @@ __global__ __launch_bounds__(256) void afno_mlp2_kernel(const AfnoMlpArgs p) {
     }
   };
 
-  // ================= layer 1:  acc = X[panel, :] Wa =================
+  f32x4 afA[RT], bfA[NT], afB[RT], bfB[NT];            // two fragment sets: slab t in use, slab t+1 arriving
+  // ================= layer 1:  acc = X[panel, :] Wa  (global slabs 0 .. NSLAB-1) =================
   zero_acc();
-  issue_x(0, Ab);
-  issue_w(Wa_l, 0, Bb);
-  // this lane's X fragment chunk inside a row tile, for the even / odd 16-k half of a super-slab
-  const int xfrag0 = fr * 32 + 4 * ((fq) ^ ((fr >> 1) & 7));
-  const int xfrag1 = fr * 32 + 4 * ((4 + fq) ^ ((fr >> 1) & 7));
+  bar();                                               // B_0: slabs 0 and 1 and X super-slab 0 have landed
+  read_x(afA, 0);
+  read_w(bfA, 0);
+  {
+    int r1 = 1, r2 = 2;                                // ring buffers of slabs t+1, t+2
 #pragma unroll 1
-  for (int t = 0; t < NSLAB; ++t) {
-    slab_sync();
-    const int cur = t & 1, T = t >> 1;
-    if (t + 1 < NSLAB) {
-      if (t & 1) issue_x(T + 1, Ab + ((T + 1) & 1) * AFL);
-      issue_w(Wa_l, t + 1, Bb + (cur ^ 1) * BFL);
+    for (int t = 0; t < NSLAB; t += 2) {
+      if (t > 0) bar();                                // B_t
+      read_x(afB, t + 1);
+      read_w(bfB, r1);
+      mma(afA, bfA);
+      bar();                                           // B_(t+1)
+      if (t + 2 < NSLAB) {
+        read_x(afA, t + 2);
+        read_w(bfA, r2);
+      }
+      mma(afB, bfB);
+      const int r3 = r1 == 0 ? 2 : r1 - 1;             // (r + 2) % 3 == (r - 1) % 3
+      r1 = r3;
+      r2 = r2 == 0 ? 2 : r2 - 1;
     }
-    __builtin_amdgcn_sched_barrier(0);
-    f32x4 af[RT];
-    const float* xs = Ab + (T & 1) * AFL + ((t & 1) ? xfrag1 : xfrag0);
-#pragma unroll
-    for (int i = 0; i < RT; ++i) af[i] = *reinterpret_cast<const f32x4*>(xs + i * 512);
-    mma_slab(af, Bb + cur * BFL);
   }
-  __syncthreads();                    // weight buffer 1 (last slab) is dead: it becomes the epilogue staging area
-  issue_w(Wb_l, 0, Bb);               // layer-2 weights start streaming under the epilogue (buffer 0)
-  epilogue(true, p.ba);
-  __syncthreads();                    // Y1 complete
+  epilogue(true, p.ba);                                // staging = the ring buffer of slab NSLAB-1 (read at t = NSLAB-2)
+  bar();                                               // B_NSLAB (S1): Y1 complete, layer-2 slabs 0, 1 landed
 
-  // ================= layer 2:  acc = Y1 Wb =================
+  // ================= layer 2:  acc = Y1 Wb  (global slabs NSLAB .. 2*NSLAB-1) =================
   zero_acc();
+  {
+    int r0 = NSLAB % 3, r1 = (NSLAB + 1) % 3, r2 = (NSLAB + 2) % 3;
+    read_y(afA, 0);
+    read_w(bfA, r0);
 #pragma unroll 1
-  for (int u = 0; u < NSLAB; ++u) {
-    slab_sync();
-    const int cur = u & 1;
-    if (u + 1 < NSLAB) issue_w(Wb_l, u + 1, Bb + (cur ^ 1) * BFL);
-    __builtin_amdgcn_sched_barrier(0);
-    f32x4 af[RT];
-#pragma unroll
-    for (int i = 0; i < RT; ++i)
-      af[i] = *reinterpret_cast<const f32x4*>(Y1 + ((i * NCT + u) * 64 + fq * 16 + ((fr + u) & 15)) * 4);
-    mma_slab(af, Bb + cur * BFL);
+    for (int u = 0; u < NSLAB; u += 2) {
+      if (u > 0) bar();                                // B_(NSLAB+u)
+      read_y(afB, u + 1);
+      read_w(bfB, r1);
+      mma(afA, bfA);
+      bar();                                           // B_(NSLAB+u+1)
+      if (u + 2 < NSLAB) {
+        read_y(afA, u + 2);
+        read_w(bfA, r2);
+      }
+      mma(afB, bfB);
+      r1 = r1 == 0 ? 2 : r1 - 1;
+      r2 = r2 == 0 ? 2 : r2 - 1;
+    }
   }
-  __syncthreads();
+  bar();                                               // S2: every wave is done with Y1 and the ring
   epilogue(false, p.bb);
 }
 
@@ -287,7 +349,7 @@ static int pick_rt(int M, int nb) {
 
 template <int NT>
 static int launch_nt(const AfnoMlpArgs& p, int rt, hipStream_t s) {
-  const dim3 grid((unsigned)(p.nb * p.panels)), blk(256);
+  const dim3 grid((unsigned)(p.nb * p.panels)), blk(384);
   switch (rt) {
     case 1: hipLaunchKernelGGL((afno_mlp2_kernel<1, NT>), grid, blk, 0, s, p); break;
     case 2: hipLaunchKernelGGL((afno_mlp2_kernel<2, NT>), grid, blk, 0, s, p); break;
