@@ -30,6 +30,8 @@
 //   * 4 waves, wave w owns all R rows x columns [16*NT*w, 16*NT*(w+1)): RT x NT accumulators of 16x16 (80 AGPRs at
 //     RT=5, NT=4).  Epilogues bounce each 16-row tile through a per-wave LDS slab so that bias / aux loads and all
 //     global stores are 16-byte accesses, 64*NT bytes contiguous per row.
+#include <type_traits>
+
 #include "common.h"
 
 namespace dpot {
@@ -50,28 +52,39 @@ struct AfnoMlpArgs {
   int M, nb, panels, act, mode;
 };
 
+template <int N>
+__device__ __forceinline__ void wait_vm() {
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
 __device__ __forceinline__ void glds16(const float* g, float* l) {
+#ifdef DPOT_ABL_NODMA
+  return;
+#endif
   __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
                                    (__attribute__((address_space(3))) void*)l, 16, 0, 0);
 }
 
-// 6 waves: waves 0-3 compute (wave w owns all R rows x columns [16*NT*w, 16*NT*(w+1)): RT x NT accumulators of 16x16),
-// waves 4-5 only issue the LDS-DMA.  A DMA piece costs the issuing wave 60-180 cycles of VMEM issue; inside the compute
+// NW + 2 waves: waves 0 .. NW-1 compute (wave w owns all R rows x the two 16-column tiles 2w, 2w+1: RT x 2 accumulators
+// of 16x16; NW = N/32 = 8 for 2*bs = 256: TWO compute waves per SIMD, which share the matrix pipe during the slabs at no
+// loss and overlap each other's LDS / VALU latencies in the epilogues), the last two waves only issue the LDS-DMA.  A DMA piece costs the issuing wave 60-180 cycles of VMEM issue; inside the compute
 // waves' instruction stream that time comes straight out of the MFMA pipe (measured: 26 % of the wave cycles parked,
 // MFMA pipe 51 % busy), in a separate wave it runs beside the MFMAs.
 //
-// One workgroup barrier per 16-k slab, the loaders run TWO slabs ahead through a ring of three weight buffers (and two
-// X super-slab buffers): at barrier B_t every slab <= t+1 has landed, so a compute wave fetches the fragments of slab
-// t+1 into a second register set WHILE the MFMAs of slab t run - no LDS latency and no DMA latency behind a barrier.
-//   loader:   [issue slabs 0,1, X 0]  { vmcnt(0); B_t; issue slab t+2 (-> ring[(t+2)%3]), X super-slab on even t }
-//   compute:  B_0, read frags 0       { (t>0: B_t); read frags t+1; MFMAs of slab t }
-// Ring buffer (t+2)%3 was last read (as fragments of slab t-1) during iteration t-2: free at B_t.  The layer-2 weights
-// continue in the same ring (global slab index NSLAB + u); ring buffer (NSLAB-1)%3 is idle from B_(NSLAB-1) to the end
-// of epilogue 1 and after layer 2's last fragment read - it is the epilogues' staging area.
-template <int RT, int NT>
-__global__ __launch_bounds__(384) void afno_mlp2_kernel(const AfnoMlpArgs p) {
-  constexpr int N = 64 * NT;        // = K
-  constexpr int NCT = 4 * NT;       // 16-column tiles of the panel = K-slabs
+// One workgroup barrier per 16-k slab; ring of three weight buffers and two X super-slab buffers.  At barrier B_t every
+// slab <= t+1 has landed, so a compute wave fetches the fragments of slab t+1 into a second register set WHILE the MFMAs
+// of slab t run - no LDS latency and no DMA latency behind a barrier.
+//   loader:   [issue slabs 0,1,2, X 0,1]  { B_t; issue slab t+3 (-> ring[t%3]), X super-slab on odd t; vmcnt(newest batch) }
+//   compute:  B_0, read frags 0           { (t>0: B_t); read frags t+1; MFMAs of slab t }
+// The layer-2 weights continue in the same ring (global slab index NSLAB + u).  The epilogues stage through the ring
+// buffer (NSLAB-1)%3: epilogue 1 runs between B_(NSLAB-1) and B_NSLAB, when the loaders fill the two OTHER buffers (slab
+// NSLAB+1 -> ring[(NSLAB+1)%3] after B_(NSLAB-2), slab NSLAB+2 -> ring[(NSLAB+2)%3] = ring[(NSLAB-1)%3] only after
+// B_NSLAB); epilogue 2 runs after the last fragment read.
+template <int RT, int NW, int ACTK>
+__global__ __launch_bounds__(64 * (NW + 2)) void afno_mlp2_kernel(const AfnoMlpArgs p) {
+  constexpr int NT = 2;             // 16-column tiles per compute wave
+  constexpr int N = 32 * NW;        // = K
+  constexpr int NCT = 2 * NW;       // 16-column tiles of the panel = K-slabs
   constexpr int NSLAB = NCT;
   constexpr int BFL = NCT * 256;    // floats of one weight slab  (N x 16)
   constexpr int AFL = RT * 512;     // floats of one X super-slab (16*RT rows x 32 k)
@@ -85,7 +98,7 @@ __global__ __launch_bounds__(384) void afno_mlp2_kernel(const AfnoMlpArgs p) {
   float* const Y1 = Ab + 2 * AFL;           // [RT][NCT][256]
   // epilogue staging [4][16][WCOLS] = the ring buffer that is idle while the epilogues run: during epilogue 1 the ring
   // holds the layer-2 slabs 0 and 1 (buffers NSLAB % 3, (NSLAB+1) % 3), the third one last held layer-1 slab NSLAB-1
-  float* const stage_all = lds + ((NSLAB - 1) % 3) * BFL;
+  float* const stage_all = lds + ((NSLAB - 1) % 3) * BFL;      // [NW][16][WCOLS]
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -104,14 +117,16 @@ __global__ __launch_bounds__(384) void afno_mlp2_kernel(const AfnoMlpArgs p) {
   const int row0 = panel * (16 * RT);
 
   auto bar = [&]() __attribute__((always_inline)) {
+#ifndef DPOT_ABL_NOBAR   /* timing experiments only (scripts/afno_variants.sh): results are wrong without the barriers */
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
+#endif
   };
 
-  if (wave >= 4) {
+  if (wave >= NW) {
     // ================================ loader waves ================================
-    const int L = wave - 4;
+    const int L = wave - NW;
     const float* X = p.X + (long long)kblk * N;
     const float* Wa_l = p.Wa + (long long)kblk * N * N + lane * 4;
     const float* Wb_l = p.Wb + (long long)kblk * N * N + lane * 4;
@@ -141,20 +156,38 @@ __global__ __launch_bounds__(384) void afno_mlp2_kernel(const AfnoMlpArgs p) {
         if (q < NXI) glds16(X + xoff[n] + 32 * T, dstbuf + q * 256);      // wave-uniform predicate
       }
     };
+    // The loaders run THREE slabs ahead: after barrier B_g they issue slab g+3 into ring[(g+3)%3] = the buffer of slab
+    // g, whose fragments the compute waves already hold in registers (read during iteration g-1).  Before the next
+    // barrier they wait for everything EXCEPT that newest batch (counted vmcnt): a batch has two slab periods (~2 us) to
+    // land - one period is about the DMA's issue-to-landed latency, and waiting for the newest batch made the loaders
+    // the last wave at every barrier (measured: 6.8 of 56 us).
+    constexpr int WB = NCT / 2, XB = RT;               // pieces per batch and loader wave: weight slab, X super-slab
+    auto issue_slab = [&](int g, float* dst) __attribute__((always_inline)) {       // global slab index g
+      if (g < NSLAB) issue_w(Wa_l, g, dst); else issue_w(Wb_l, g - NSLAB, dst);
+    };
     issue_x(0, Ab);
-    issue_w(Wa_l, 0, Bb);
-    issue_w(Wa_l, 1, Bb + BFL);
-    int ring = 2;                                       // ring buffer of global slab index g + 2
+    issue_slab(0, Bb);
+    issue_slab(1, Bb + BFL);
+    if (NSLAB / 2 > 1) issue_x(1, Ab + AFL);           // newest batch of the prologue: X super-slab 1 + slab 2
+    issue_slab(2, Bb + 2 * BFL);
+    if (NSLAB / 2 > 1) wait_vm<WB + XB>(); else wait_vm<WB>();
+    bar();                                              // P: slabs 0, 1 and X super-slab 0 have landed
+    int ring = 0;                                       // ring buffer of global slab index g + 3 (= g % 3)
 #pragma unroll 1
     for (int g = 0; g < 2 * NSLAB; ++g) {               // g = global slab index (layer 1: 0..NSLAB-1, layer 2: the rest)
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // everything issued so far (slabs <= g+1) has landed
       bar();                                            // B_g  (g == NSLAB: the barrier after epilogue 1)
-      const int nx = g + 2;
-      if (nx < 2 * NSLAB) {
-        if (nx < NSLAB) issue_w(Wa_l, nx, Bb + ring * BFL); else issue_w(Wb_l, nx - NSLAB, Bb + ring * BFL);
-      }
+      const int nx = g + 3;
+      const int T1 = (g + 3) >> 1;                      // X super-slab first needed by slab g+3 (g odd)
+      // after B_(NSLAB-1) the target ring[(NSLAB+2)%3] is epilogue 1's staging area: that slab goes out one barrier late
+      const bool has_w = nx < 2 * NSLAB && g != NSLAB - 1;
+      const bool has_x = (g & 1) && g + 3 < NSLAB && T1 >= 2;
+      if (has_x) issue_x(T1, Ab + (T1 & 1) * AFL);
+      if (g == NSLAB) issue_slab(nx - 1, Bb + (ring == 0 ? 2 : ring - 1) * BFL);
+      if (has_w) issue_slab(nx, Bb + ring * BFL);
       ring = ring == 2 ? 0 : ring + 1;
-      if (g < NSLAB && (g & 1) == 0 && (g >> 1) + 1 < NSLAB / 2) issue_x((g >> 1) + 1, Ab + (((g >> 1) + 1) & 1) * AFL);
+      if (has_w && has_x) wait_vm<WB + XB>();
+      else if (has_w) wait_vm<WB>();
+      else wait_vm<0>();
     }
     bar();                                              // S2: end of layer 2
     return;
@@ -195,16 +228,37 @@ __global__ __launch_bounds__(384) void afno_mlp2_kernel(const AfnoMlpArgs p) {
   auto read_y = [&](f32x4 (&af)[RT], int u) __attribute__((always_inline)) {
 #pragma unroll
     for (int i = 0; i < RT; ++i)
-      af[i] = *reinterpret_cast<const f32x4*>(Y1 + ((i * NCT + u) * 64 + fq * 16 + ((fr + u) & 15)) * 4);
+      af[i] = *reinterpret_cast<const f32x4*>(Y1 + ((i * NCT + u) * 64 + fq * 16 + ((fr + u + 8 * (fq >> 1)) & 15)) * 4);
   };
 
   // ---- epilogue of one layer: acc (+bias) -> [pre] -> f -> [mid] -> Y1 in LDS (layer 1) / -> Y (layer 2)
   float* const stage = stage_all + wave * (16 * WCOLS);
   auto epilogue = [&](bool first, const float* __restrict__ bias) __attribute__((always_inline)) {
     const int colw = 16 * NT * wave;                   // first column of this wave inside the block
-    // (fully unrolled over the row tiles: a dynamic index into acc would send the accumulators to scratch)
+#ifdef DPOT_ABL_NOEPI
+    if (p.M > 0) {
+      float sacc = 0.f;
 #pragma unroll
-    for (int i = 0; i < RT; ++i) {
+      for (int i = 0; i < RT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j) sacc += acc[i][j][0] + acc[i][j][1] + acc[i][j][2] + acc[i][j][3];
+      if (sacc == 12345.678f) p.Y[lane] = sacc;
+      return;
+    }
+#endif
+    // bias of the chunk this lane handles in pass `it` (the same for every row tile): loaded ONCE - a load inside the
+    // chunk loop puts a full L2 round trip in front of every 16 bytes of epilogue (measured: 23 of 70 us)
+    float4 b4[NT];
+#pragma unroll
+    for (int it = 0; it < NT; ++it) {
+      const int g = it * 64 + lane;
+      const int c4 = g % (4 * NT);
+      b4[it] = bias ? *reinterpret_cast<const float4*>(bias + kblk * N + colw + 4 * c4) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    // one row tile; the tile index is a compile-time constant (a dynamic index into acc would send the accumulators
+    // to scratch, and hipcc declines to unroll a loop over a body of this size)
+    auto tile = [&](auto Ic) __attribute__((always_inline)) {
+      constexpr int i = decltype(Ic)::value;
       // C/D layout of a 16x16 tile: col = lane&15, row = 4*(lane>>4) + e
 #pragma unroll
       for (int j = 0; j < NT; ++j) {
@@ -214,7 +268,7 @@ __global__ __launch_bounds__(384) void afno_mlp2_kernel(const AfnoMlpArgs p) {
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
       __builtin_amdgcn_wave_barrier();
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-#pragma unroll 1
+#pragma unroll
       for (int it = 0; it < NT; ++it) {
         const int g = it * 64 + lane;                  // 16-byte chunk of the 16 x WCOLS tile, row-major
         const int r = g / (4 * NT), c4 = g - r * (4 * NT);
@@ -225,79 +279,92 @@ __global__ __launch_bounds__(384) void afno_mlp2_kernel(const AfnoMlpArgs p) {
         const bool ok = row < p.M;
         const int rowc = ok ? row : p.M - 1;
         const long long go = (long long)rowc * p.ldo + (long long)kblk * N + col;
-        if (bias) {
-          const float4 b4 = *reinterpret_cast<const float4*>(bias + kblk * N + col);
-          v[0] += b4.x; v[1] += b4.y; v[2] += b4.z; v[3] += b4.w;
-        }
+        v[0] += b4[it].x; v[1] += b4[it].y; v[2] += b4[it].z; v[3] += b4[it].w;
         if (first) {
           if (p.mode == 0) {
             if (p.pre && ok) *reinterpret_cast<float4*>(p.pre + go) = make_float4(v[0], v[1], v[2], v[3]);
 #pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = act_fwd(p.act, v[e]);
+            for (int e = 0; e < 4; ++e) v[e] = ACTK == DPOT_ACT_GELU ? gelu_fwd(v[e]) : act_fwd(p.act, v[e]);
           } else {
             const float4 x4 = *reinterpret_cast<const float4*>(p.aux + go);
-            v[0] *= act_bwd(p.act, x4.x); v[1] *= act_bwd(p.act, x4.y);
-            v[2] *= act_bwd(p.act, x4.z); v[3] *= act_bwd(p.act, x4.w);
+            const float xs[4] = {x4.x, x4.y, x4.z, x4.w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] *= ACTK == DPOT_ACT_GELU ? gelu_bwd(xs[e]) : act_bwd(p.act, xs[e]);
           }
           if (p.mid && ok) *reinterpret_cast<float4*>(p.mid + go) = make_float4(v[0], v[1], v[2], v[3]);
-          // A operand of layer 2: K-slab s = col/16, chunk (k-quad, row) at a row position rotated by s
+          // A operand of layer 2: K-slab s = col/16, chunk (k-quad, row) at a row position rotated by s + 8*(kq/2):
+          // the fragment reads (16 rows x k-quads {0,1} or {2,3} per lane group) stay conflict free and the 8 lanes of a
+          // row here spread over 4 bank groups instead of 2
           const int s = col >> 4, kq = (col >> 2) & 3;
-          *reinterpret_cast<f32x4*>(Y1 + ((i * NCT + s) * 64 + kq * 16 + ((r + s) & 15)) * 4) =
+          *reinterpret_cast<f32x4*>(Y1 + ((i * NCT + s) * 64 + kq * 16 + ((r + s + 8 * (kq >> 1)) & 15)) * 4) =
               (f32x4){v[0], v[1], v[2], v[3]};
         } else {
           if (ok) *reinterpret_cast<float4*>(p.Y + go) = make_float4(v[0], v[1], v[2], v[3]);
         }
       }
       __builtin_amdgcn_wave_barrier();
-    }
+    };
+    tile(std::integral_constant<int, 0>{});
+    if constexpr (RT > 1) tile(std::integral_constant<int, 1>{});
+    if constexpr (RT > 2) tile(std::integral_constant<int, 2>{});
+    if constexpr (RT > 3) tile(std::integral_constant<int, 3>{});
+    if constexpr (RT > 4) tile(std::integral_constant<int, 4>{});
   };
 
   f32x4 afA[RT], bfA[NT], afB[RT], bfB[NT];            // two fragment sets: slab t in use, slab t+1 arriving
   // ================= layer 1:  acc = X[panel, :] Wa  (global slabs 0 .. NSLAB-1) =================
   zero_acc();
-  bar();                                               // B_0: slabs 0 and 1 and X super-slab 0 have landed
+  bar();                                               // P: slabs 0 and 1 and X super-slab 0 have landed
   read_x(afA, 0);
   read_w(bfA, 0);
   {
     int r1 = 1, r2 = 2;                                // ring buffers of slabs t+1, t+2
 #pragma unroll 1
     for (int t = 0; t < NSLAB; t += 2) {
-      if (t > 0) bar();                                // B_t
+      bar();                                           // B_t
+#ifndef DPOT_ABL_NOLDS
       read_x(afB, t + 1);
       read_w(bfB, r1);
+#endif
       mma(afA, bfA);
       bar();                                           // B_(t+1)
-      if (t + 2 < NSLAB) {
-        read_x(afA, t + 2);
-        read_w(bfA, r2);
-      }
+#ifndef DPOT_ABL_NOLDS
+      if (t + 2 < NSLAB) read_x(afA, t + 2);
+      read_w(bfA, r2);                                 // t + 2 == NSLAB: the first weight slab of layer 2
       mma(afB, bfB);
-      const int r3 = r1 == 0 ? 2 : r1 - 1;             // (r + 2) % 3 == (r - 1) % 3
-      r1 = r3;
+#else
+      mma(afA, bfA);
+#endif
+      r1 = r1 == 0 ? 2 : r1 - 1;                       // (r + 2) % 3 == (r - 1) % 3
       r2 = r2 == 0 ? 2 : r2 - 1;
     }
   }
   epilogue(true, p.ba);                                // staging = the ring buffer of slab NSLAB-1 (read at t = NSLAB-2)
-  bar();                                               // B_NSLAB (S1): Y1 complete, layer-2 slabs 0, 1 landed
+  bar();                                               // B_NSLAB (S1): Y1 complete
 
   // ================= layer 2:  acc = Y1 Wb  (global slabs NSLAB .. 2*NSLAB-1) =================
   zero_acc();
   {
-    int r0 = NSLAB % 3, r1 = (NSLAB + 1) % 3, r2 = (NSLAB + 2) % 3;
-    read_y(afA, 0);
-    read_w(bfA, r0);
+    int r1 = (NSLAB + 1) % 3, r2 = (NSLAB + 2) % 3;
+    read_y(afA, 0);                                    // (bfA: fetched during the last slab of layer 1)
 #pragma unroll 1
     for (int u = 0; u < NSLAB; u += 2) {
       if (u > 0) bar();                                // B_(NSLAB+u)
+#ifndef DPOT_ABL_NOLDS
       read_y(afB, u + 1);
       read_w(bfB, r1);
+#endif
       mma(afA, bfA);
       bar();                                           // B_(NSLAB+u+1)
+#ifndef DPOT_ABL_NOLDS
       if (u + 2 < NSLAB) {
         read_y(afA, u + 2);
         read_w(bfA, r2);
       }
       mma(afB, bfB);
+#else
+      mma(afA, bfA);
+#endif
       r1 = r1 == 0 ? 2 : r1 - 1;
       r2 = r2 == 0 ? 2 : r2 - 1;
     }
@@ -347,17 +414,22 @@ static int pick_rt(int M, int nb) {
   return best;
 }
 
-template <int NT>
-static int launch_nt(const AfnoMlpArgs& p, int rt, hipStream_t s) {
-  const dim3 grid((unsigned)(p.nb * p.panels)), blk(384);
+template <int NW, int ACTK>
+static int launch_rt(const AfnoMlpArgs& p, int rt, hipStream_t s) {
+  const dim3 grid((unsigned)(p.nb * p.panels)), blk(64 * (NW + 2));
   switch (rt) {
-    case 1: hipLaunchKernelGGL((afno_mlp2_kernel<1, NT>), grid, blk, 0, s, p); break;
-    case 2: hipLaunchKernelGGL((afno_mlp2_kernel<2, NT>), grid, blk, 0, s, p); break;
-    case 3: hipLaunchKernelGGL((afno_mlp2_kernel<3, NT>), grid, blk, 0, s, p); break;
-    case 4: hipLaunchKernelGGL((afno_mlp2_kernel<4, NT>), grid, blk, 0, s, p); break;
-    default: hipLaunchKernelGGL((afno_mlp2_kernel<5, NT>), grid, blk, 0, s, p); break;
+    case 1: hipLaunchKernelGGL((afno_mlp2_kernel<1, NW, ACTK>), grid, blk, 0, s, p); break;
+    case 2: hipLaunchKernelGGL((afno_mlp2_kernel<2, NW, ACTK>), grid, blk, 0, s, p); break;
+    case 3: hipLaunchKernelGGL((afno_mlp2_kernel<3, NW, ACTK>), grid, blk, 0, s, p); break;
+    case 4: hipLaunchKernelGGL((afno_mlp2_kernel<4, NW, ACTK>), grid, blk, 0, s, p); break;
+    default: hipLaunchKernelGGL((afno_mlp2_kernel<5, NW, ACTK>), grid, blk, 0, s, p); break;
   }
   return check_launch("afno_mlp2_kernel");
+}
+template <int NW>
+static int launch_nw(const AfnoMlpArgs& p, int rt, hipStream_t s) {
+  // GELU (the DPOT default) gets its own instantiation; every other activation goes through the run-time switch
+  return p.act == DPOT_ACT_GELU ? launch_rt<NW, DPOT_ACT_GELU>(p, rt, s) : launch_rt<NW, -1>(p, rt, s);
 }
 
 }  // namespace dpot
@@ -398,9 +470,9 @@ extern "C" int dpot_afno_mlp2(const float* X, const float* WaT, const float* ba,
   p.panels = (M + 16 * rt - 1) / (16 * rt);
   hipStream_t s = as_stream(stream);
   switch (N / 64) {
-    case 1: return launch_nt<1>(p, rt, s);
-    case 2: return launch_nt<2>(p, rt, s);
-    case 3: return launch_nt<3>(p, rt, s);
-    default: return launch_nt<4>(p, rt, s);
+    case 1: return launch_nw<2>(p, rt, s);
+    case 2: return launch_nw<4>(p, rt, s);
+    case 3: return launch_nw<6>(p, rt, s);
+    default: return launch_nw<8>(p, rt, s);
   }
 }
