@@ -35,6 +35,23 @@ def bench(nb, bs, M, reps=50):
         out.append(f"{name} {t*1e6:7.1f} us {flops/t/1e12:6.1f} TF")
     print(f"RT={os.environ.get('DPOT_AFNO_MLP_RT','auto')} nb={nb} bs={bs} M={M}: " + " | ".join(out), flush=True)
 
+def tiny_train(n=30):
+    """the DPOT-Tiny (B=32) mixer launch in its training form, eagerly, n times (for rocprofv3 --pmc passes)"""
+    nb, bs, M = 4, 128, 4608
+    N = 2 * bs
+    S = torch.randn(M, nb * N, device="cuda")
+    W1f, _ = ops.afno_block_weights(torch.randn(nb, N, N, device="cuda") * 0.05)
+    W2f, _ = ops.afno_block_weights(torch.randn(nb, N, N, device="cuda") * 0.05)
+    b1 = torch.randn(nb, N, device="cuda") * 0.1
+    b2 = torch.randn(nb, N, device="cuda") * 0.1
+    for _ in range(n):
+        ops.afno_mlp2(S, W1f, b1, W2f, b2, nb, bs, 1, mode=0, want_pre=True, want_mid=True)
+    torch.cuda.synchronize()
+
+
 if __name__ == "__main__":
-    for nb, bs, M in ((4, 128, 4608), (8, 128, 2304), (16, 96, 2176)):
-        bench(nb, bs, M)
+    if len(sys.argv) > 1 and sys.argv[1] == "tiny-train":
+        tiny_train()
+    else:
+        for nb, bs, M in ((4, 128, 4608), (8, 128, 2304), (16, 96, 2176)):
+            bench(nb, bs, M)
