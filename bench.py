@@ -53,6 +53,7 @@ def parse():
     ap.add_argument("--noise-scale", type=float, default=0.0005,
                     help="train_temporal.py:205 noise injection (configs/pretrain_tiny.yaml:71 uses 0.0005)")
     ap.add_argument("--skip-cpu-baseline", action="store_true")
+    ap.add_argument("--no-pipeline", action="store_true", help="skip the input-pipeline-inclusive timing")
     ap.add_argument("--gemm-precision", default=os.environ.get("DPOT_GEMM_PRECISION", "f32"),
                     choices=("f32", "bf16x6", "auto"),
                     help="how the GEMMs form their fp32 products for the headline number (f32 = native fp32 MFMA)")
@@ -372,6 +373,43 @@ def main():
                                     "what": "DPOTNet forward only (no_grad), batch %d, hipGraph replay" % B}
             except Exception as e:                             # pragma: no cover
                 log(f"[bench] inference timing failed: {e}")
+        if world == 1 and graphed is not None and not args.no_pipeline:
+            # input-pipeline-inclusive rate (never `value`): raw 64x64 single-channel trajectories in host memory (the
+            # ns2d_fno_1e-5 shape) -> pinned staging -> ONE H2D copy per batch on a copy stream -> device-side bilinear
+            # resize to 128^2 + channel pad with ones + temporal window (csrc/data.hip) -> double-buffered batch slots;
+            # the step reads slot k while slot k+1 is filled (dpot_amd/data.py)
+            try:
+                import numpy as np
+                from dpot_amd.data import DeviceBatcher, random_window_start
+                Traw = 20
+                rng = np.random.default_rng(0)
+                gx = np.linspace(0, 1, 64, dtype=np.float32)
+                pool = [np.ascontiguousarray((np.sin(6 * gx[:, None, None] + i) * np.cos(4 * gx[None, :, None] + 0.3 * i)
+                                              * np.linspace(1, 2, Traw, dtype=np.float32)[None, None, :])[..., None])
+                        for i in range(4 * B)]
+                db = DeviceBatcher(B, 128, 10, 1, 4, max_raw_floats_per_sample=64 * 64 * Traw)
+                pick = lambda: ([pool[int(rng.integers(len(pool)))] for _ in range(B)],
+                                [random_window_start(Traw, 10, 1, rng) for _ in range(B)])
+                db.submit(*pick())
+                n_pipe = max(args.steps, 40)
+                torch.cuda.synchronize()
+                tp = time.perf_counter()
+                for _ in range(n_pipe):
+                    db.submit(*pick())
+                    bx, by, bm = db.get()
+                    graphed.stage(bx, by, bm)
+                    db.release()
+                    one_step()
+                torch.cuda.synchronize()
+                ep = time.perf_counter() - tp
+                out["pipeline_inclusive"] = {
+                    "value": round(B * n_pipe / ep, 2), "unit": "samples/s", "ms_per_step": round(ep / n_pipe * 1e3, 4),
+                    "steps": n_pipe, "h2d_MB_per_batch": round(db.h2d_bytes / (n_pipe + 1) / 1e6, 2),
+                    "what": "host raw [64,64,20,1] samples -> pinned -> H2D (copy stream) -> device resize/pad/window "
+                            "(double buffered) -> staged into the step's graph inputs -> train step; PCIe + host "
+                            "batching inclusive, single host thread"}
+            except Exception as e:                             # pragma: no cover
+                log(f"[bench] pipeline-inclusive timing failed: {type(e).__name__}: {e}")
         if world == 1 and not args.skip_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.cpu_seconds)
             out["speedup_vs_cpu_baseline"] = round(value / out["cpu_baseline"]["value"], 1)

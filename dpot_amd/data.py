@@ -1,0 +1,143 @@
+"""Input pipeline for the DPOT step, MI355X side (reference: utils/griddataset.py:27-174 and the
+DataLoader of train_temporal.py:106-109).
+
+The reference resizes / pads / windows every sample on CPU workers (F.interpolate per sample) and ships finished
+[B,res,res,T,C] batches (2.9 MB per sample at 128^2) through a DataLoader - at the GPU step's ~9 k samples/s that
+pipeline is the bottleneck.  Here the CPU side only hands over the RAW trajectories ([H,W,T,C] as stored, e.g. 64x64
+for ns2d_fno: 16x fewer bytes than the padded 128x128x4 batch):
+
+    host:    raw samples -> one pinned staging buffer -> ONE async H2D copy on a copy stream
+    device:  dpot_resize_pad_window (csrc/data.hip): bilinear resize to res x res, channel pad with ones, temporal
+             window [t0, t0+t_in+t_ar) -> xx, yy written straight into one of two (n_buffers) batch slots
+    step:    the compute stream waits on the slot's event; while it trains on slot k the copy stream fills slot k+1
+
+HDF5 reading (h5py is not available in this image) stays with the caller: `DeviceBatcher.submit` takes numpy arrays /
+CPU tensors.  Dataset mixing and index sharding are host logic (`MixedIndex`, dp.shard_indices).
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import List, Optional, Sequence, Tuple
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import SampleDesc, check
+
+Tensor = torch.Tensor
+
+
+def random_window_start(T: int, t_in: int, t_ar: int, rng: np.random.Generator) -> int:
+    """griddataset.py:151  start_idx = np.random.randint(max(T - (t_in + t_ar) + 1, 1))"""
+    return int(rng.integers(max(T - (t_in + t_ar) + 1, 1)))
+
+
+def target_mask(res: int, size_orig: Sequence[int], n_channels: int) -> Tensor:
+    """griddataset.py:103-117: evaluation mask [res, res, 1, n_channels] - ones on the grid points that exist at the
+    dataset's own resolution and on its own channels (size_orig = [H, W, T, C_pred])"""
+    msk = torch.zeros(res, res, 1, n_channels)
+    kx, ky = res // size_orig[0], res // size_orig[1]
+    kx, ky = max(kx, 1), max(ky, 1)
+    msk[::kx, ::ky, :, :size_orig[-1]] = 1
+    return msk
+
+
+class MixedIndex:
+    """index arithmetic of MixedTemporalDataset (griddataset.py:50-56,133-141): datasets are concatenated, dataset d
+    is repeated data_weights[d] times; global index -> (dataset, sample)"""
+
+    def __init__(self, sizes: Sequence[int], weights: Optional[Sequence[int]] = None):
+        self.sizes = list(sizes)
+        self.weights = list(weights) if weights is not None else [1] * len(self.sizes)
+        self.cumulative = np.cumsum([s * w for s, w in zip(self.sizes, self.weights)])
+
+    def __len__(self) -> int:
+        return int(self.cumulative[-1])
+
+    def locate(self, idx: int) -> Tuple[int, int]:
+        d = int(np.searchsorted(self.cumulative, idx + 1))
+        local = idx if d == 0 else idx - int(self.cumulative[d - 1])
+        return d, int(local // self.weights[d])
+
+
+def resize_pad_window(samples: Sequence[Tensor], starts: Sequence[int], res: int, t_in: int, t_ar: int,
+                      n_channels: int, out_xx: Optional[Tensor] = None, out_yy: Optional[Tensor] = None):
+    """samples: CUDA tensors [H,W,T,C] (fp32, contiguous), one per batch entry -> (xx [B,res,res,t_in,Cmax],
+    yy [B,res,res,t_ar,Cmax]) through ONE launch of csrc/data.hip (per 64 samples)"""
+    B = len(samples)
+    dev = samples[0].device
+    xx = out_xx if out_xx is not None else torch.empty(B, res, res, t_in, n_channels, dtype=torch.float32, device=dev)
+    yy = out_yy if out_yy is not None else (
+        torch.empty(B, res, res, t_ar, n_channels, dtype=torch.float32, device=dev) if t_ar > 0 else None)
+    descs = (SampleDesc * B)()
+    for i, (s, t0) in enumerate(zip(samples, starts)):
+        if not (s.is_cuda and s.dtype == torch.float32 and s.is_contiguous() and s.dim() == 4):
+            raise _lib.DpotHipError("resize_pad_window: samples must be contiguous float32 CUDA tensors [H,W,T,C]")
+        descs[i].data, (descs[i].H, descs[i].W, descs[i].T, descs[i].C) = s.data_ptr(), s.shape
+        descs[i].t0 = int(t0)
+    check(_lib.load().dpot_resize_pad_window(descs, B, xx.data_ptr(), yy.data_ptr() if yy is not None else None, res,
+                                             t_in, t_ar, n_channels, torch.cuda.current_stream().cuda_stream),
+          "resize_pad_window")
+    return xx, yy
+
+
+class DeviceBatcher:
+    """Double-buffered batch producer: raw samples in, device-resident (xx, yy, msk) out, overlapped with the step."""
+
+    def __init__(self, batch: int, res: int, t_in: int, t_ar: int, n_channels: int, max_raw_floats_per_sample: int,
+                 device="cuda", n_buffers: int = 2):
+        self.B, self.res, self.t_in, self.t_ar, self.C = batch, res, t_in, t_ar, n_channels
+        self.dev = torch.device(device)
+        self.n = n_buffers
+        cap = batch * max_raw_floats_per_sample
+        self.stream = torch.cuda.Stream(device=self.dev)
+        self.host = [torch.empty(cap, dtype=torch.float32).pin_memory() for _ in range(n_buffers)]
+        self.raw = [torch.empty(cap, dtype=torch.float32, device=self.dev) for _ in range(n_buffers)]
+        self.xx = [torch.empty(batch, res, res, t_in, n_channels, device=self.dev) for _ in range(n_buffers)]
+        self.yy = [torch.empty(batch, res, res, t_ar, n_channels, device=self.dev) for _ in range(n_buffers)]
+        self.msk = torch.ones(batch, res, res, 1, n_channels, device=self.dev)      # training mask (griddataset.py:157)
+        self.ready = [torch.cuda.Event() for _ in range(n_buffers)]       # slot filled (recorded on the copy stream)
+        self.consumed = [None] * n_buffers                                # slot's last reader (recorded on compute)
+        self.k = 0
+        self.pending: List[int] = []
+        self.h2d_bytes = 0
+
+    def submit(self, samples: Sequence, starts: Sequence[int]) -> None:
+        """enqueue one batch: samples = numpy arrays / CPU tensors [H,W,T,C] (or [H,W,T]); returns immediately"""
+        assert len(samples) == self.B and len(starts) == self.B
+        slot = self.k % self.n
+        self.k += 1
+        if self.consumed[slot] is not None:
+            self.consumed[slot].synchronize()          # host buffer / device slot are free again (normally long since)
+        host, off, views = self.host[slot], 0, []
+        for s in samples:
+            t = torch.as_tensor(s, dtype=torch.float32)
+            if t.dim() == 3:
+                t = t.unsqueeze(-1)                    # griddataset.py:145 "augment channel dim"
+            n = t.numel()
+            if off + n > host.numel():
+                raise ValueError("DeviceBatcher: raw samples exceed max_raw_floats_per_sample")
+            host[off:off + n].copy_(t.reshape(-1))
+            views.append((off, tuple(t.shape)))
+            off += n
+        with torch.cuda.stream(self.stream):
+            self.raw[slot][:off].copy_(host[:off], non_blocking=True)            # ONE H2D copy for the batch
+            devs = [self.raw[slot][o:o + int(np.prod(shp))].view(shp) for o, shp in views]
+            resize_pad_window(devs, starts, self.res, self.t_in, self.t_ar, self.C, self.xx[slot], self.yy[slot])
+            self.ready[slot].record(self.stream)
+        self.h2d_bytes += off * 4
+        self.pending.append(slot)
+
+    def get(self) -> Tuple[Tensor, Tensor, Tensor]:
+        """the oldest submitted batch; the CURRENT stream waits for it (no host synchronisation).  The tensors stay
+        valid until `n_buffers` further submits; call `release()` after the step that reads them was enqueued."""
+        slot = self.pending.pop(0)
+        torch.cuda.current_stream().wait_event(self.ready[slot])
+        self._last = slot
+        return self.xx[slot], self.yy[slot], self.msk
+
+    def release(self) -> None:
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream())
+        self.consumed[self._last] = ev
