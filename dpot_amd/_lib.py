@@ -44,7 +44,7 @@ class GemmDesc(C.Structure):
 class SampleDesc(C.Structure):
     """mirror of struct dpot_sample_desc"""
     _fields_ = [("data", c_fp), ("H", C.c_int32), ("W", C.c_int32), ("T", C.c_int32), ("C", C.c_int32),
-                ("t0", C.c_int32)]
+                ("t0", C.c_int32), ("reserved", C.c_int32)]
 
 
 # name -> (restype, argtypes); every symbol include/dpot_hip.h declares
@@ -98,7 +98,7 @@ SIGNATURES = {
     "dpot_noise_inject_bwd": (c_i, [c_fp] * 7 + [c_f] + [c_i] * 3 + [c_fp]),
     "dpot_window_slide": (c_i, [c_fp] * 3 + [c_i64] + [c_i] * 3 + [c_fp]),
     "dpot_window_slide_bwd": (c_i, [c_fp] * 3 + [c_i64] + [c_i] * 3 + [c_fp]),
-    "dpot_resize_pad_window": (c_i, [C.POINTER(SampleDesc), c_i, c_fp, c_fp] + [c_i] * 4 + [c_fp]),
+    "dpot_resize_pad_window": (c_i, [c_fp, c_i, c_fp, c_fp] + [c_i] * 4 + [c_fp]),
 }
 
 _lib = None

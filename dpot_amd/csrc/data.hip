@@ -5,16 +5,11 @@
 //                                                                                              yy [res,res,t_ar,Cmax]
 // Only the t_in + t_ar frames of the window are resized (the reference resizes the whole trajectory and slices it
 // afterwards).  Samples of one batch may come from different datasets (different H, W, T, C): the per-sample geometry
-// travels by value in the launch packet.  HBM-bound: reads the window of the raw sample once, writes xx / yy once.
+// is a small table in DEVICE memory that the caller uploads together with the raw samples (one H2D copy per batch).
+// HBM-bound: reads the window of the raw sample once, writes xx / yy once.
 #include "common.h"
 
 namespace dpot {
-
-constexpr int DATA_MAX_JOBS = 64;
-struct WindowJobs {
-  const float* src[DATA_MAX_JOBS];
-  int H[DATA_MAX_JOBS], W[DATA_MAX_JOBS], T[DATA_MAX_JOBS], C[DATA_MAX_JOBS], t0[DATA_MAX_JOBS];
-};
 
 // ATen's area_pixel_compute_source_index (align_corners = false, not cubic) in float, as upsample_bilinear2d uses it
 __device__ __forceinline__ void src_index(int dst, float scale, int in_size, int& i0, int& i1, float& l0, float& l1) {
@@ -27,41 +22,62 @@ __device__ __forceinline__ void src_index(int dst, float scale, int in_size, int
   l0 = 1.f - l1;
 }
 
-// grid (chunks of the res*res pixel grid, job); one thread = one output pixel, all window frames and channels
-__global__ __launch_bounds__(256) void resize_pad_window_kernel(const WindowJobs jobs, float* __restrict__ xx,
-                                                                float* __restrict__ yy, int res, int t_in, int t_ar,
-                                                                int Cmax, int job0) {
+// grid (chunks of the output frames, job); one thread = one (pixel, frame) of xx or yy = n_channels contiguous floats, so
+// adjacent lanes write adjacent 4*Cmax-byte pieces (fully coalesced; one float4 per lane at Cmax = 4) and read adjacent
+// frames of the same four source pixels
+__global__ __launch_bounds__(256) void resize_pad_window_kernel(const dpot_sample_desc* __restrict__ jobs,
+                                                                float* __restrict__ xx, float* __restrict__ yy, int res,
+                                                                int t_in, int t_ar, int Cmax) {
+  // (the job table lives in device memory: a by-value table indexed by blockIdx.y is copied to scratch by every thread)
   const int j = blockIdx.y;
-  const int H = jobs.H[j], W = jobs.W[j], T = jobs.T[j], C = jobs.C[j], t0 = jobs.t0[j];
-  const float* __restrict__ src = jobs.src[j];
-  const int pix = blockIdx.x * 256 + threadIdx.x;
-  if (pix >= res * res) return;
-  const int oy = pix / res, ox = pix - oy * res;         // oy indexes the FIRST spatial axis (H), ox the second (W)
+  const dpot_sample_desc job = jobs[j];
+  const int H = job.H, W = job.W, T = job.T, C = job.C, t0 = job.t0;
+  const float* __restrict__ src = job.data;
+  if (H <= 0 || W <= 0 || C <= 0 || C > Cmax || t0 < 0 || t0 + t_in + t_ar > T) return;   // malformed entry: skip
+  const long long npix = (long long)res * res;
+  const long long nx = npix * t_in, total = npix * (t_in + t_ar);
   const float sh = (float)H / (float)res, sw = (float)W / (float)res;
-  int h0, h1, w0, w1;
-  float hl0, hl1, wl0, wl1;
-  src_index(oy, sh, H, h0, h1, hl0, hl1);
-  src_index(ox, sw, W, w0, w1, wl0, wl1);
   const long long TC = (long long)T * C;
-  const float* p00 = src + ((long long)h0 * W + w0) * TC;
-  const float* p01 = src + ((long long)h0 * W + w1) * TC;
-  const float* p10 = src + ((long long)h1 * W + w0) * TC;
-  const float* p11 = src + ((long long)h1 * W + w1) * TC;
-  const long long b = job0 + j;
-  float* xo = xx + (b * res * res + pix) * (long long)t_in * Cmax;
-  float* yo = yy ? yy + (b * res * res + pix) * (long long)t_ar * Cmax : nullptr;
-  const int nt = t_in + t_ar;
-  for (int t = 0; t < nt; ++t) {
-    float* o = t < t_in ? xo + (long long)t * Cmax : (yo ? yo + (long long)(t - t_in) * Cmax : nullptr);
-    if (!o) break;
+  const long long b = j;
+  for (long long item = blockIdx.x * 256ll + threadIdx.x; item < total; item += (long long)gridDim.x * 256) {
+    int pix, t;
+    float* o;
+    if (item < nx) {
+      pix = (int)(item / t_in);
+      t = (int)(item - (long long)pix * t_in);
+      o = xx + ((b * npix + pix) * t_in + t) * Cmax;
+    } else {
+      const long long it = item - nx;
+      pix = (int)(it / t_ar);
+      const int ty = (int)(it - (long long)pix * t_ar);
+      t = t_in + ty;
+      o = yy + ((b * npix + pix) * t_ar + ty) * Cmax;
+    }
+    const int oy = pix / res, ox = pix - oy * res;       // oy indexes the FIRST spatial axis (H), ox the second (W)
+    int h0, h1, w0, w1;
+    float hl0, hl1, wl0, wl1;
+    src_index(oy, sh, H, h0, h1, hl0, hl1);
+    src_index(ox, sw, W, w0, w1, wl0, wl1);
     const long long so = (long long)(t0 + t) * C;
-    for (int c = 0; c < Cmax; ++c) {
-      float v = 1.f;                                     // channels the dataset does not have are ones (griddataset.py:98)
-      if (c < C) {
-        const float v00 = p00[so + c], v01 = p01[so + c], v10 = p10[so + c], v11 = p11[so + c];
-        v = hl0 * (wl0 * v00 + wl1 * v01) + hl1 * (wl0 * v10 + wl1 * v11);
+    const float* p00 = src + ((long long)h0 * W + w0) * TC + so;
+    const float* p01 = src + ((long long)h0 * W + w1) * TC + so;
+    const float* p10 = src + ((long long)h1 * W + w0) * TC + so;
+    const float* p11 = src + ((long long)h1 * W + w1) * TC + so;
+    float v[4];
+    for (int c0 = 0; c0 < Cmax; c0 += 4) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int c = c0 + e;
+        v[e] = 1.f;                                      // channels the dataset does not have are ones (griddataset.py:98)
+        if (c < C) v[e] = hl0 * (wl0 * p00[c] + wl1 * p01[c]) + hl1 * (wl0 * p10[c] + wl1 * p11[c]);
       }
-      o[c] = v;
+      if (Cmax == 4) {
+        *reinterpret_cast<float4*>(o) = make_float4(v[0], v[1], v[2], v[3]);
+      } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          if (c0 + e < Cmax) o[c0 + e] = v[e];
+      }
     }
   }
 }
@@ -70,27 +86,16 @@ __global__ __launch_bounds__(256) void resize_pad_window_kernel(const WindowJobs
 
 using namespace dpot;
 
-extern "C" int dpot_resize_pad_window(const dpot_sample_desc* samples, int nsamples, float* xx, float* yy, int res,
+extern "C" int dpot_resize_pad_window(const dpot_sample_desc* samples_dev, int nsamples, float* xx, float* yy, int res,
                                       int t_in, int t_ar, int n_channels, dpot_stream_t stream) {
-  DPOT_REQUIRE(samples && nsamples > 0 && xx && res > 0 && t_in > 0 && t_ar >= 0 && n_channels > 0,
+  DPOT_REQUIRE(samples_dev && nsamples > 0 && nsamples <= 65535 && xx && res > 0 && t_in > 0 && t_ar >= 0 &&
+                   n_channels > 0,
                "resize_pad_window: bad argument");
   DPOT_REQUIRE(t_ar == 0 || yy != nullptr, "resize_pad_window: t_ar > 0 needs yy");
-  for (int j0 = 0; j0 < nsamples; j0 += DATA_MAX_JOBS) {
-    const int nj = nsamples - j0 < DATA_MAX_JOBS ? nsamples - j0 : DATA_MAX_JOBS;
-    WindowJobs jobs;
-    for (int j = 0; j < nj; ++j) {
-      const dpot_sample_desc& s = samples[j0 + j];
-      DPOT_REQUIRE(s.data && s.H > 0 && s.W > 0 && s.T > 0 && s.C > 0 && s.C <= n_channels,
-                   "resize_pad_window: sample %d has a bad shape (C=%d, n_channels=%d)", j0 + j, s.C, n_channels);
-      DPOT_REQUIRE(s.t0 >= 0 && s.t0 + t_in + t_ar <= s.T,
-                   "resize_pad_window: sample %d: window [%d, %d) exceeds its %d frames", j0 + j, s.t0,
-                   s.t0 + t_in + t_ar, s.T);
-      jobs.src[j] = s.data; jobs.H[j] = s.H; jobs.W[j] = s.W; jobs.T[j] = s.T; jobs.C[j] = s.C; jobs.t0[j] = s.t0;
-    }
-    hipLaunchKernelGGL(resize_pad_window_kernel, dim3((unsigned)cdiv(res * res, 256), nj), dim3(256), 0,
-                       as_stream(stream), jobs, xx, yy, res, t_in, t_ar, n_channels, j0);
-    int rc = check_launch("resize_pad_window_kernel");
-    if (rc) return rc;
-  }
-  return DPOT_OK;
+  DPOT_REQUIRE(n_channels != 4 || (aligned16(xx) && aligned16(yy)), "resize_pad_window: outputs must be 16-byte aligned");
+  long long blocks = ((long long)res * res * (t_in + t_ar) + 255) / 256;
+  if (blocks > 1024) blocks = 1024;
+  hipLaunchKernelGGL(resize_pad_window_kernel, dim3((unsigned)blocks, nsamples), dim3(256), 0, as_stream(stream),
+                     samples_dev, xx, yy, res, t_in, t_ar, n_channels);
+  return check_launch("resize_pad_window_kernel");
 }

@@ -61,23 +61,38 @@ class MixedIndex:
         return d, int(local // self.weights[d])
 
 
+DESC_BYTES = C.sizeof(SampleDesc)          # 32
+DESC_FLOATS = DESC_BYTES // 4
+
+
+def _fill_table(table: np.ndarray, ptrs: Sequence[int], shapes: Sequence[Sequence[int]], starts: Sequence[int],
+                t_in: int, t_ar: int, n_channels: int) -> None:
+    """write the dpot_sample_desc records into `table` (uint8 view of host memory), validating what the kernel assumes"""
+    descs = (SampleDesc * len(ptrs)).from_buffer(table)
+    for i, (ptr, (H, W, T, Cc), t0) in enumerate(zip(ptrs, shapes, starts)):
+        if Cc > n_channels or t0 < 0 or t0 + t_in + t_ar > T:
+            raise ValueError(f"sample {i}: shape {(H, W, T, Cc)}, window [{t0}, {t0 + t_in + t_ar}) - needs C <= "
+                             f"{n_channels} and the window inside its {T} frames")
+        descs[i].data, descs[i].H, descs[i].W, descs[i].T, descs[i].C, descs[i].t0 = ptr, H, W, T, Cc, int(t0)
+
+
 def resize_pad_window(samples: Sequence[Tensor], starts: Sequence[int], res: int, t_in: int, t_ar: int,
                       n_channels: int, out_xx: Optional[Tensor] = None, out_yy: Optional[Tensor] = None):
     """samples: CUDA tensors [H,W,T,C] (fp32, contiguous), one per batch entry -> (xx [B,res,res,t_in,Cmax],
-    yy [B,res,res,t_ar,Cmax]) through ONE launch of csrc/data.hip (per 64 samples)"""
+    yy [B,res,res,t_ar,Cmax]) through ONE launch of csrc/data.hip"""
     B = len(samples)
     dev = samples[0].device
     xx = out_xx if out_xx is not None else torch.empty(B, res, res, t_in, n_channels, dtype=torch.float32, device=dev)
     yy = out_yy if out_yy is not None else (
         torch.empty(B, res, res, t_ar, n_channels, dtype=torch.float32, device=dev) if t_ar > 0 else None)
-    descs = (SampleDesc * B)()
-    for i, (s, t0) in enumerate(zip(samples, starts)):
+    for s in samples:
         if not (s.is_cuda and s.dtype == torch.float32 and s.is_contiguous() and s.dim() == 4):
             raise _lib.DpotHipError("resize_pad_window: samples must be contiguous float32 CUDA tensors [H,W,T,C]")
-        descs[i].data, (descs[i].H, descs[i].W, descs[i].T, descs[i].C) = s.data_ptr(), s.shape
-        descs[i].t0 = int(t0)
-    check(_lib.load().dpot_resize_pad_window(descs, B, xx.data_ptr(), yy.data_ptr() if yy is not None else None, res,
-                                             t_in, t_ar, n_channels, torch.cuda.current_stream().cuda_stream),
+    host = np.zeros(B * DESC_BYTES, dtype=np.uint8)
+    _fill_table(host, [s.data_ptr() for s in samples], [tuple(s.shape) for s in samples], starts, t_in, t_ar, n_channels)
+    table = torch.from_numpy(host).to(dev)
+    check(_lib.load().dpot_resize_pad_window(table.data_ptr(), B, xx.data_ptr(), yy.data_ptr() if yy is not None else None,
+                                             res, t_in, t_ar, n_channels, torch.cuda.current_stream().cuda_stream),
           "resize_pad_window")
     return xx, yy
 
@@ -90,7 +105,8 @@ class DeviceBatcher:
         self.B, self.res, self.t_in, self.t_ar, self.C = batch, res, t_in, t_ar, n_channels
         self.dev = torch.device(device)
         self.n = n_buffers
-        cap = batch * max_raw_floats_per_sample
+        self.head = batch * DESC_FLOATS                # the descriptor table rides at the head of the staging buffer
+        cap = self.head + batch * max_raw_floats_per_sample
         self.stream = torch.cuda.Stream(device=self.dev)
         self.host = [torch.empty(cap, dtype=torch.float32).pin_memory() for _ in range(n_buffers)]
         self.raw = [torch.empty(cap, dtype=torch.float32, device=self.dev) for _ in range(n_buffers)]
@@ -110,23 +126,29 @@ class DeviceBatcher:
         self.k += 1
         if self.consumed[slot] is not None:
             self.consumed[slot].synchronize()          # host buffer / device slot are free again (normally long since)
-        host, off, views = self.host[slot], 0, []
+        host, off, offs, shapes = self.host[slot], self.head, [], []
+        hnp = host.numpy()
         for s in samples:
-            t = torch.as_tensor(s, dtype=torch.float32)
-            if t.dim() == 3:
-                t = t.unsqueeze(-1)                    # griddataset.py:145 "augment channel dim"
-            n = t.numel()
-            if off + n > host.numel():
+            a = np.asarray(s, dtype=np.float32) if not torch.is_tensor(s) else s.detach().float().numpy()
+            if a.ndim == 3:
+                a = a[..., None]                       # griddataset.py:145 "augment channel dim"
+            n = a.size
+            if off + n > hnp.size:
                 raise ValueError("DeviceBatcher: raw samples exceed max_raw_floats_per_sample")
-            host[off:off + n].copy_(t.reshape(-1))
-            views.append((off, tuple(t.shape)))
+            hnp[off:off + n] = a.reshape(-1)
+            offs.append(off)
+            shapes.append(a.shape)
             off += n
+        base = self.raw[slot].data_ptr()
+        _fill_table(hnp[:self.head].view(np.uint8), [base + 4 * o for o in offs], shapes, starts, self.t_in, self.t_ar,
+                    self.C)
         with torch.cuda.stream(self.stream):
-            self.raw[slot][:off].copy_(host[:off], non_blocking=True)            # ONE H2D copy for the batch
-            devs = [self.raw[slot][o:o + int(np.prod(shp))].view(shp) for o, shp in views]
-            resize_pad_window(devs, starts, self.res, self.t_in, self.t_ar, self.C, self.xx[slot], self.yy[slot])
+            self.raw[slot][:off].copy_(host[:off], non_blocking=True)            # ONE H2D copy: table + raw samples
+            check(_lib.load().dpot_resize_pad_window(base, self.B, self.xx[slot].data_ptr(), self.yy[slot].data_ptr(),
+                                                     self.res, self.t_in, self.t_ar, self.C, self.stream.cuda_stream),
+                  "resize_pad_window")
             self.ready[slot].record(self.stream)
-        self.h2d_bytes += off * 4
+        self.h2d_bytes += (off - self.head) * 4
         self.pending.append(slot)
 
     def get(self) -> Tuple[Tensor, Tensor, Tensor]:

@@ -325,17 +325,19 @@ int dpot_window_slide_bwd(const float* dout, float* dxx, float* dim, int64_t row
 /* ------------------------------------------------------------------------------------------------
  * input pipeline, device side (utils/griddataset.py:88-101 pad_data, :125-174 __getitem__)
  * ------------------------------------------------------------------------------------------------ */
-/* one raw trajectory of a dataset, already in device memory: data [H, W, T, C] fp32, window start t0 */
+/* one raw trajectory of a dataset, already in device memory: data [H, W, T, C] fp32, window start t0 (32 bytes) */
 typedef struct dpot_sample_desc {
   const float* data;
   int32_t H, W, T, C;
   int32_t t0;
+  int32_t reserved;
 } dpot_sample_desc;
 /* For every sample b: bilinear resize of the frames t0 .. t0+t_in+t_ar-1 to res x res (F.interpolate(mode='bilinear'),
  * align_corners=False semantics), channels C..n_channels-1 filled with ones, written as
  * xx[b] = [res, res, t_in, n_channels] and yy[b] = [res, res, t_ar, n_channels] (yy may be NULL when t_ar == 0).
- * `samples` is a HOST array (copied by value into the launch packets); one launch per 64 samples. */
-int dpot_resize_pad_window(const dpot_sample_desc* samples, int nsamples, float* xx, float* yy, int res, int t_in,
+ * `samples_dev` is a DEVICE array of nsamples descriptors (upload it with the raw samples, one H2D copy per batch);
+ * the caller validates it (C <= n_channels, t0 + t_in + t_ar <= T) - a malformed entry is skipped by the kernel. */
+int dpot_resize_pad_window(const dpot_sample_desc* samples_dev, int nsamples, float* xx, float* yy, int res, int t_in,
                            int t_ar, int n_channels, dpot_stream_t stream);
 
 #ifdef __cplusplus
