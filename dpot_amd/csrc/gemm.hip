@@ -623,7 +623,8 @@ extern "C" int dpot_gemm_f32(const dpot_gemm_desc* d, dpot_stream_t stream) {
            vec_ok(d->aux, d->ldaux, d->strideAux) && vec_ok(d->preact, d->ldpre, d->stridePre) &&
            vec_ok(d->res, d->ldres, d->strideRes);
   const int precision = resolve_precision(d->precision, d->M, d->N, d->K, d->batch);
-  DPOT_REQUIRE(precision == DPOT_GEMM_F32 || precision == DPOT_GEMM_BF16X6, "gemm: bad precision %d", d->precision);
+  DPOT_REQUIRE(precision == DPOT_GEMM_F32 || precision == DPOT_GEMM_BF16X6 || precision == DPOT_GEMM_BF16,
+               "gemm: bad precision %d", d->precision);
   const int t = precision != DPOT_GEMM_F32 ? pick_tile_split(d->M, d->N, d->batch, splits, d->tile)
                                               : pick_tile(d->M, d->N, d->batch, d->tile);
   p.tilesM = cdiv(d->M, t); p.tilesN = cdiv(d->N, t);
@@ -631,7 +632,15 @@ extern "C" int dpot_gemm_f32(const dpot_gemm_desc* d, dpot_stream_t stream) {
   DPOT_REQUIRE(ntiles < (1ll << 31) && (long long)d->batch * splits <= 65535, "gemm: grid too large");
   dim3 grid((unsigned)ntiles, 1, (unsigned)(d->batch * splits));
   hipStream_t s = as_stream(stream);
-  if (precision == DPOT_GEMM_BF16X6) {
+  if (precision == DPOT_GEMM_BF16) {
+    // reduced precision on request (BASELINE configs[2] "bf16 channel-MLP on MFMA"): operands rounded to bf16 between
+    // the global load and the LDS store, ONE product per k-step on v_mfma_f32_32x32x16_bf16, fp32 accumulation
+    if (t == 128) {
+      if (vec) launch_gemm_split<128, true, 1, 8>(d, p, grid, s); else launch_gemm_split<128, false, 1, 8>(d, p, grid, s);
+    } else {
+      if (vec) launch_gemm_split<64, true, 1, 4>(d, p, grid, s); else launch_gemm_split<64, false, 1, 4>(d, p, grid, s);
+    }
+  } else if (precision == DPOT_GEMM_BF16X6) {
     static const int waves128 = [] { const char* e = getenv("DPOT_X_WAVES"); return e ? atoi(e) : 8; }();
     if (t == 128 && waves128 == 8) {
       if (vec) launch_gemm_split<128, true, 3, 8>(d, p, grid, s); else launch_gemm_split<128, false, 3, 8>(d, p, grid, s);

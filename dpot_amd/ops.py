@@ -20,8 +20,8 @@ Tensor = torch.Tensor
 ACT_IDS = {None: 0, "none": 0, "gelu": 1, "tanh": 2, "sigmoid": 3, "relu": 4, "leaky_relu": 5, "softplus": 6,
            "ELU": 7, "silu": 8}
 EPI_LINEAR, EPI_ACT, EPI_DACT, EPI_AFNO_WGRAD = 0, 1, 2, 3
-GEMM_F32, GEMM_BF16X6, GEMM_AUTO = 0, 1, 2
-_PRECISIONS = {"f32": GEMM_F32, "bf16x6": GEMM_BF16X6, "auto": GEMM_AUTO}
+GEMM_F32, GEMM_BF16X6, GEMM_AUTO, GEMM_BF16 = 0, 1, 2, 3
+_PRECISIONS = {"f32": GEMM_F32, "bf16x6": GEMM_BF16X6, "auto": GEMM_AUTO, "bf16": GEMM_BF16}
 # how every GEMM forms its fp32 products (include/dpot_hip.h: dpot_gemm_desc.precision);
 # DPOT_GEMM_PRECISION = f32 | bf16x6 | auto
 _gemm_precision = _PRECISIONS[os.environ.get("DPOT_GEMM_PRECISION", "f32")]
@@ -40,7 +40,8 @@ def gemm_precision() -> str:
 
 # precision of the channel-MLP GEMMs only (Block.mlp, models/dpot.py:157-161); None = follow the global setting.
 # BASELINE.json configs[2] asks for a "bf16 channel-MLP on MFMA": 'bf16x6' here puts exactly those GEMMs on the bf16
-# matrix cores at fp32 accuracy.   DPOT_MLP_PRECISION = f32 | bf16x6 | auto
+# matrix cores at fp32 accuracy; 'bf16' is the plain reduced-precision form (operands rounded to bf16, fp32
+# accumulation - NOT within the 1e-4 parity tolerance, opt-in only).   DPOT_MLP_PRECISION = f32 | bf16x6 | auto | bf16
 _mlp_precision = _PRECISIONS[os.environ["DPOT_MLP_PRECISION"]] if os.environ.get("DPOT_MLP_PRECISION") else None
 
 

@@ -128,10 +128,12 @@ typedef struct dpot_gemm_desc {
    *   DPOT_GEMM_BF16X6 fp32 emulated on the bf16 matrix cores: each operand is split a = a1+a2+a3 (bf16 each, exact
    *                    to 2^-25) and the 6 partial products down to 2^-24 are accumulated - fp32-level accuracy at
    *                    2.67x the fp32 MFMA rate (csrc/gemm_split.h)
-   *   DPOT_GEMM_AUTO   the library picks per shape (bf16x6 for products >= 3 GFLOP, where its longer pipeline pays) */
+   *   DPOT_GEMM_AUTO   the library picks per shape (bf16x6 for products >= 3 GFLOP, where its longer pipeline pays)
+   *   DPOT_GEMM_BF16   REDUCED precision, only on explicit request (BASELINE configs[2]: "bf16 channel-MLP on MFMA"):
+   *                    operands rounded to bf16, one product per k-step, fp32 accumulation (relative error ~4e-3) */
   int32_t precision;
 } dpot_gemm_desc;
-enum { DPOT_GEMM_F32 = 0, DPOT_GEMM_BF16X6 = 1, DPOT_GEMM_AUTO = 2 };
+enum { DPOT_GEMM_F32 = 0, DPOT_GEMM_BF16X6 = 1, DPOT_GEMM_AUTO = 2, DPOT_GEMM_BF16 = 3 };
 
 int dpot_gemm_f32(const dpot_gemm_desc* d, dpot_stream_t stream);
 /* bytes of workspace dpot_gemm_f32 needs for this descriptor (0 when splitk <= 1) */

@@ -509,3 +509,35 @@ def test_afno_mlp2_fused_two_layers(ops, nb, bs, M, act):
                                 aux=pre_ref.float().reshape(M, -1).contiguous().cuda(), want_mid=True)
     assert_close(dmid, dmid_ref.reshape(M, -1), "dO1pre")
     assert_close(dS, dS_ref.reshape(M, -1), "dS")
+
+
+def test_plain_bf16_mlp_mode_is_reduced_precision_but_sane(ops):
+    """BASELINE configs[2] "bf16 channel-MLP on MFMA": precision 'bf16' rounds the GEMM operands to bf16 (one product per
+    k-step, fp32 accumulation): error ~ 2^-8 per product, i.e. OUTSIDE the 1e-4 parity tolerance (it is opt-in), but
+    within the bf16 bound against the fp32 result; forward and backward of a DPOT-Small sized MLP GEMM + a model step"""
+    M, K, N = 4096, 1024, 1024
+    A, W = rnd(M, K, seed=1), rnd(N, K, seed=2, scale=1.0 / math.sqrt(K))
+    ref = A.double() @ W.double().t()
+    y32, _ = ops.linear_fwd(A.cuda(), W.cuda(), None)
+    y16, _ = ops.linear_fwd(A.cuda(), W.cuda(), None, precision=ops.GEMM_BF16)
+    e32 = (y32.cpu().double() - ref).norm() / ref.norm()
+    e16 = (y16.cpu().double() - ref).norm() / ref.norm()
+    assert e32 < 1e-6 and 1e-4 < e16 < 8e-3, (e32.item(), e16.item())
+    dW = ops.linear_bwd_weight(y16, A.cuda(), precision=ops.GEMM_BF16)                # TN, split-K
+    dref = y16.cpu().double().t() @ A.double()
+    assert (dW.cpu().double() - dref).norm() / dref.norm() < 8e-3
+    from dpot_amd import DPOTNet
+    cfg = R.DPOTConfig(**R.MINI)
+    m = DPOTNet(**R.MINI).cuda()
+    m.load_state_dict(R.recipe_state_dict(cfg, salt=4))
+    x = R.recipe_input((2, cfg.img_size, cfg.img_size, cfg.in_timesteps, cfg.in_channels), salt=9).cuda()
+    try:
+        y_ref, _ = m(x)
+        ops.set_mlp_precision("bf16")
+        y_b, _ = m(x)
+        (y_b ** 2).sum().backward()
+        rel = ((y_b - y_ref).norm() / y_ref.norm()).item()
+        assert 1e-6 < rel < 2e-2, rel
+        assert all(torch.isfinite(p.grad).all() for p in m.parameters() if p.grad is not None)
+    finally:
+        ops.set_mlp_precision(None)
