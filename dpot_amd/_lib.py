@@ -41,6 +41,12 @@ class GemmDesc(C.Structure):
     ]
 
 
+class PackJob(C.Structure):
+    """mirror of struct dpot_pack_job"""
+    _fields_ = [("src", c_fp), ("dst", c_fp), ("rows", C.c_int32), ("K", C.c_int32), ("ld", C.c_int32),
+                ("trans", C.c_int32)]
+
+
 class SampleDesc(C.Structure):
     """mirror of struct dpot_sample_desc"""
     _fields_ = [("data", c_fp), ("H", C.c_int32), ("W", C.c_int32), ("T", C.c_int32), ("C", C.c_int32),
@@ -99,6 +105,9 @@ SIGNATURES = {
     "dpot_window_slide": (c_i, [c_fp] * 3 + [c_i64] + [c_i] * 3 + [c_fp]),
     "dpot_window_slide_bwd": (c_i, [c_fp] * 3 + [c_i64] + [c_i] * 3 + [c_fp]),
     "dpot_resize_pad_window": (c_i, [c_fp, c_i, c_fp, c_fp] + [c_i] * 4 + [c_fp]),
+    "dpot_panel_pack_weights": (c_i, [c_fp, c_i, c_i, c_fp]),
+    "dpot_gemm_panel_supported": (c_i, [c_i, c_i, c_i]),
+    "dpot_gemm_panel": (c_i, [c_fp, c_i, c_fp, c_fp, c_fp, c_i, c_fp, c_i, c_fp, c_i, c_fp, c_i] + [c_i] * 5 + [c_fp]),
 }
 
 _lib = None

@@ -192,7 +192,12 @@ class EmbedFn(torch.autograd.Function):
 
 
 # ======================================================================================================
-def _block_parts(x, n1w, n1b, n2w, n2b, f1w, f1b, packed, dims, mp, need_out, f2w=None, f2b=None):
+def _mlp_panel_ok(mlp_pk, M, E, mh, mp) -> bool:
+    return (mlp_pk is not None and mp in (None, ops.GEMM_F32) and ops.panel_enabled()
+            and ops.gemm_panel_supported(M, mh, E) and ops.gemm_panel_supported(M, E, mh))
+
+
+def _block_parts(x, n1w, n1b, n2w, n2b, f1w, f1b, packed, dims, mp, need_out, f2w=None, f2b=None, mlp_pk=None):
     """forward of one Block up to (and optionally including) the second channel-MLP GEMM; returns every intermediate
     the backward needs.  Called by BlockFn.forward, and again by BlockFn.backward when activations are recomputed."""
     B, tok, E, h, w, nb, bs, mx, my, mh, act = dims
@@ -217,10 +222,17 @@ def _block_parts(x, n1w, n1b, n2w, n2b, f1w, f1b, packed, dims, mp, need_out, f2
     y1 = ops.irfft2(O2, B, h, w, E, nb, mx, my, 1, res=xn1)                # + x_orig (the normalised input)
     del O2, xn1
     xn2, mean2, rstd2 = ops.groupnorm_fwd(y1, n2w, n2b)
-    Hh, Hpre = ops.linear_fwd(xn2.view(M, E), f1w, f1b, act=act, save_pre=True, precision=mp)
+    panel = _mlp_panel_ok(mlp_pk, M, E, mh, mp)
+    if panel:      # static-weight panel GEMM (csrc/gemm_panel.hip): weights pre-packed once per optimiser step
+        Hh, Hpre = ops.gemm_panel(xn2.view(M, E), mlp_pk[0], mh, bias=f1b, act=act, mode=EPI_ACT, save_pre=True)
+    else:
+        Hh, Hpre = ops.linear_fwd(xn2.view(M, E), f1w, f1b, act=act, save_pre=True, precision=mp)
     out = None
     if need_out:
-        out, _ = ops.linear_fwd(Hh, f2w, f2b, res=x.view(M, E), precision=mp)
+        if panel:
+            out, _ = ops.gemm_panel(Hh, mlp_pk[2], E, bias=f2b, res=x.view(M, E))
+        else:
+            out, _ = ops.linear_fwd(Hh, f2w, f2b, res=x.view(M, E), precision=mp)
     return out, (mean1, rstd1, S, O1pre, O1, y1, mean2, rstd2, xn2, Hpre, Hh)
 
 
@@ -233,7 +245,7 @@ class BlockFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, n1w, n1b, w1, b1, w2, b2, n2w, n2b, f1w, f1b, f2w, f2b, h: int, w: int, nb: int, modes: int,
-                act: int, packed=None, recompute: bool = False):
+                act: int, packed=None, recompute: bool = False, mlp_pk=None):
         x = x.contiguous()
         B, tok, E = x.shape
         bs = E // nb
@@ -243,7 +255,8 @@ class BlockFn(torch.autograd.Function):
             packed = (ops.afno_pack3(w1, b1), ops.afno_pack3(w2, b2))
         dims = (B, tok, E, h, w, nb, bs, mx, my, mh, act)
         mp = ops.mlp_precision()                                               # channel-MLP GEMM precision override
-        out, parts = _block_parts(x, n1w, n1b, n2w, n2b, f1w, f1b, packed, dims, mp, True, f2w, f2b)
+        out, parts = _block_parts(x, n1w, n1b, n2w, n2b, f1w, f1b, packed, dims, mp, True, f2w, f2b, mlp_pk)
+        ctx.mlp_pk = mlp_pk if _mlp_panel_ok(mlp_pk, B * tok, E, mh, mp) else None
         ctx.fused_mixer = packed[0][2] is not None
         # weights the backward data path multiplies by: blocked W^T (fused kernel) or the plain Wbig (generic GEMM)
         wb1, wb2 = (packed[0][3], packed[1][3]) if ctx.fused_mixer else (packed[0][0], packed[1][0])
@@ -266,7 +279,8 @@ class BlockFn(torch.autograd.Function):
             wb1T, wb2T = wts if ctx.fused_mixer else (None, None)
             with torch.no_grad():
                 _, parts = _block_parts(x, n1w, n1b, n2w, n2b, f1w, f1b,
-                                        ((wb1, bb1, wb1T, None), (wb2, bb2, wb2T, None)), ctx.dims, mp, False)
+                                        ((wb1, bb1, wb1T, None), (wb2, bb2, wb2T, None)), ctx.dims, mp, False,
+                                        mlp_pk=ctx.mlp_pk)
             mean1, rstd1, S, O1pre, O1, y1, mean2, rstd2, xn2, Hpre, Hh = parts
         else:
             (x, mean1, rstd1, S, O1pre, O1, y1, mean2, rstd2, xn2, Hpre, Hh, wb1, wb2, n1w, n2w, f1w,
@@ -283,11 +297,18 @@ class BlockFn(torch.autograd.Function):
         with streams.side(dev):
             df2w, df2b = ops.linear_bwd_wb(do2, Hh, s_f2w.out(), s_f2b.out(), precision=mp)
             df2w, df2b = s_f2w.done(df2w.view(E, mh, 1, 1)), s_f2b.done(df2b)
-        dHpre = ops.linear_bwd_data(do2, f2w, act=act, aux=Hpre, precision=mp)  # [M, mh]
+        mlp_pk = ctx.mlp_pk
+        if mlp_pk is not None:
+            dHpre, _ = ops.gemm_panel(do2, mlp_pk[3], mh, act=act, mode=EPI_DACT, aux=Hpre)       # do2 W2, * act'(Hpre)
+        else:
+            dHpre = ops.linear_bwd_data(do2, f2w, act=act, aux=Hpre, precision=mp)  # [M, mh]
         with streams.side(dev):
             df1w, df1b = ops.linear_bwd_wb(dHpre, xn2.view(M, E), s_f1w.out(), s_f1b.out(), precision=mp)
             df1w, df1b = s_f1w.done(df1w.view(mh, E, 1, 1)), s_f1b.done(df1b)
-        dxn2 = ops.linear_bwd_data(dHpre, f1w, precision=mp)                   # [M, E]
+        if mlp_pk is not None:
+            dxn2, _ = ops.gemm_panel(dHpre, mlp_pk[1], E)                      # dHpre W1
+        else:
+            dxn2 = ops.linear_bwd_data(dHpre, f1w, precision=mp)               # [M, E]
         dy1, dn2w, dn2b = ops.groupnorm_bwd(dxn2.view(B, tok, E), y1, mean2, rstd2, n2w, out_dgamma=s_n2w.out(),
                                             out_dbeta=s_n2b.out())
         dn2w, dn2b = s_n2w.done(dn2w), s_n2b.done(dn2b)
@@ -323,7 +344,7 @@ class BlockFn(torch.autograd.Function):
         dn1w, dn1b = s_n1w.done(dn1w), s_n1b.done(dn1b)
         streams.join(dev)      # the side stream's readers of this frame's tensors are done before they can be freed
         return (dx, dn1w, dn1b, dw1, db1, dw2, db2, dn2w, dn2b, df1w, df1b, df2w, df2b, None, None, None, None, None,
-                None, None)
+                None, None, None)
 
 
 # ======================================================================================================

@@ -152,10 +152,31 @@ class DPOTNet(nn.Module):
                                                                      (blk.filter.w2, blk.filter.b2))]) \
             if len(self.blocks) else []
         head = head_derived(ol[0].weight, ol[0].bias, ol[4].weight, ol[4].bias, self.patch_size)
-        d = (emb, pk, head)
+        d = (emb, pk, head, self._mlp_panel_packs())
         if self._scope_depth > 0:
             self._scope_cache = d
         return d
+
+    def _mlp_panel_packs(self):
+        """fragment-block-major copies of the channel-MLP weights for the panel GEMM (csrc/gemm_panel.hip): W1, W1^T,
+        W2, W2^T per block (forward x W^T and data gradient dy W), all refreshed by ONE launch per optimiser step"""
+        if not (len(self.blocks) and ops.panel_enabled()):
+            return None
+        E, mh = self.embed_dim, self.blocks[0].mlp[0].weight.shape[0]
+        if not (ops.gemm_panel_supported(1, mh, E) and ops.gemm_panel_supported(1, E, mh)):
+            return None
+        key = tuple(b.mlp[i].weight.data_ptr() for b in self.blocks for i in (0, 2))
+        pp = getattr(self, "_panel_packs", None)
+        if pp is None or pp.key_all != key:
+            jobs = []
+            for b in self.blocks:
+                w1, w2 = b.mlp[0].weight, b.mlp[2].weight                       # [mh, E, 1, 1], [E, mh, 1, 1]
+                jobs += [(w1, mh, E, E, False), (w1, E, mh, E, True), (w2, E, mh, mh, False), (w2, mh, E, mh, True)]
+            pp = ops.PanelPacks(jobs)
+            pp.key_all = key
+            self._panel_packs = pp
+        pp.refresh()
+        return [tuple(pp.bufs[4 * i:4 * i + 4]) for i in range(len(self.blocks))]
 
     def forward(self, x):
         if not x.is_cuda:
@@ -178,7 +199,7 @@ class DPOTNet(nn.Module):
         pe, ta = self.patch_embed.proj, self.time_agg_layer
         P = self.patch_size
         h = self.latent_size[0]
-        d_emb, pk, d_head = self._derived_weights()
+        d_emb, pk, d_head, mlp_pk = self._derived_weights()
         lat = EmbedFn.apply(x, self.pos_embed, pe[0].weight, pe[0].bias, pe[2].weight, pe[2].bias, ta.w,
                             ta.gamma if self.time_agg == "exp_mlp" else None, self._gx, self._gy, self._gt, self._tt,
                             P, self._act, d_emb)
@@ -193,7 +214,7 @@ class DPOTNet(nn.Module):
             lat = BlockFn.apply(lat, blk.norm1.weight, blk.norm1.bias, f.w1, f.b1, f.w2, f.b2, blk.norm2.weight,
                                 blk.norm2.bias, blk.mlp[0].weight, blk.mlp[0].bias, blk.mlp[2].weight,
                                 blk.mlp[2].bias, h, h, self.n_blocks, self.modes, self._act,
-                                (pk[2 * i], pk[2 * i + 1]), recompute)
+                                (pk[2 * i], pk[2 * i + 1]), recompute, mlp_pk[i] if mlp_pk is not None else None)
         if hook is not None:
             lat = hook(len(self.blocks) + 1, lat)
         ol, ch = self.out_layer, self.cls_head

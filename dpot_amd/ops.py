@@ -122,6 +122,54 @@ def gemm(A: Tensor, B: Tensor, C_: Tensor, M: int, N: int, K: int, *, transA: bo
     return C_
 
 
+# ------------------------------------------------------------------------------------------------------
+# panel GEMM with pre-packed static weights (csrc/gemm_panel.hip)
+# ------------------------------------------------------------------------------------------------------
+def panel_enabled() -> bool:
+    return os.environ.get("DPOT_PANEL_GEMM", "1") != "0" and _gemm_precision == GEMM_F32 and _mlp_precision in (None, GEMM_F32)
+
+
+def gemm_panel_supported(M: int, N: int, K: int) -> bool:
+    return bool(_lib.load().dpot_gemm_panel_supported(M, N, K))
+
+
+class PanelPacks:
+    """Fragment-block-major copies of a set of static weights, refreshed by ONE launch (dpot_panel_pack_weights) from a
+    job table that lives in device memory.  jobs = [(src tensor, rows, K, ld, trans)]; the destination buffers are
+    allocated once, so the table stays valid while the sources do not move."""
+
+    def __init__(self, jobs):
+        import numpy as np
+        dev = jobs[0][0].device
+        self.bufs = [torch.empty(rows * K, dtype=torch.float32, device=dev) for _, rows, K, _, _ in jobs]
+        self.key = tuple(j[0].data_ptr() for j in jobs)
+        host = np.zeros(len(jobs) * C.sizeof(_lib.PackJob), dtype=np.uint8)
+        tab = (_lib.PackJob * len(jobs)).from_buffer(host)
+        for i, ((src, rows, K, ld, trans), dst) in enumerate(zip(jobs, self.bufs)):
+            tab[i].src, tab[i].dst, tab[i].rows, tab[i].K, tab[i].ld, tab[i].trans = src.data_ptr(), dst.data_ptr(), rows, K, ld, int(trans)
+        self.table = torch.from_numpy(host).to(dev)
+        self.n = len(jobs)
+        self.max_elems = max(rows * K for _, rows, K, _, _ in jobs)
+
+    def refresh(self) -> None:
+        check(_lib.load().dpot_panel_pack_weights(self.table.data_ptr(), self.n, self.max_elems, _stream()),
+              "panel_pack_weights")
+
+
+def gemm_panel(A: Tensor, Wpacked: Tensor, N: int, *, bias: Optional[Tensor] = None, act: int = 0,
+               mode: int = EPI_LINEAR, aux: Optional[Tensor] = None, res: Optional[Tensor] = None,
+               save_pre: bool = False) -> Tuple[Tensor, Optional[Tensor]]:
+    """C[M,N] = epilogue(A[M,K] @ Wt^T), Wt packed by PanelPacks (rows = N).  Returns (C, pre | None)."""
+    M, K = A.shape
+    out = torch.empty(M, N, dtype=torch.float32, device=A.device)
+    pre = torch.empty_like(out) if save_pre else None
+    check(_lib.load().dpot_gemm_panel(A.data_ptr(), A.stride(0), Wpacked.data_ptr(), _p(bias), _p(aux),
+                                      aux.stride(0) if aux is not None else 0, _p(res),
+                                      res.stride(0) if res is not None else 0, _p(pre), N, out.data_ptr(), N, M, N, K,
+                                      act, mode, _stream()), "gemm_panel")
+    return out, pre
+
+
 def linear_fwd(x: Tensor, W: Tensor, bias: Optional[Tensor], act: int = 0, save_pre: bool = False,
                res: Optional[Tensor] = None, res_div: int = 0, res_mod: int = 0,
                ldw: Optional[int] = None, precision: Optional[int] = None) -> Tuple[Tensor, Optional[Tensor]]:

@@ -325,6 +325,26 @@ int dpot_window_slide_bwd(const float* dout, float* dxx, float* dim, int64_t row
                           dpot_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * panel GEMM with a pre-packed static weight (csrc/gemm_panel.hip): forward and data gradient of the channel-MLP
+ * ------------------------------------------------------------------------------------------------ */
+/* one weight to pack: the logical matrix Wt [rows, K] (row n, k) = trans ? src[k*ld + n] : src[n*ld + k]
+ * -> dst [rows/16][K/16][256] fragment-block-major (chunk l of a block = (row l&15, k 4*(l>>4)..+3)).  32 bytes. */
+typedef struct dpot_pack_job {
+  const float* src;
+  float* dst;
+  int32_t rows, K, ld, trans;
+} dpot_pack_job;
+/* packs every weight of the DEVICE table jobs_dev[0..njobs) in one launch; max_elems = the largest rows*K */
+int dpot_panel_pack_weights(const dpot_pack_job* jobs_dev, int njobs, int max_elems, dpot_stream_t stream);
+/* C[M,N] = epilogue(A[M,K] @ Wt^T) with Wt packed by dpot_panel_pack_weights (rows = N).  epi_mode / act as for
+ * dpot_gemm_f32: LINEAR, ACT (pre-activation optionally saved to `pre`), DACT (times act'(aux)); bias [N], res [M,ldres]
+ * and pre may be NULL.  Needs K % 32 == 0 and N % 64 == 0 (dpot_gemm_panel_supported), 16-byte aligned operands. */
+int dpot_gemm_panel_supported(int M, int N, int K);
+int dpot_gemm_panel(const float* A, int lda, const float* Wpacked, const float* bias, const float* aux, int ldaux,
+                    const float* res, int ldres, float* pre, int ldpre, float* C, int ldc, int M, int N, int K,
+                    int act, int epi_mode, dpot_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
  * input pipeline, device side (utils/griddataset.py:88-101 pad_data, :125-174 __getitem__)
  * ------------------------------------------------------------------------------------------------ */
 /* one raw trajectory of a dataset, already in device memory: data [H, W, T, C] fp32, window start t0 (32 bytes) */

@@ -541,3 +541,29 @@ def test_plain_bf16_mlp_mode_is_reduced_precision_but_sane(ops):
         assert all(torch.isfinite(p.grad).all() for p in m.parameters() if p.grad is not None)
     finally:
         ops.set_mlp_precision(None)
+
+
+@pytest.mark.parametrize("M,N,K", [(8192, 512, 512), (333, 256, 96), (100, 64, 32), (4096, 1024, 4096), (1000, 192, 64),
+                                   (77, 1536, 6144 // 4)])
+def test_gemm_panel_static_weight(ops, M, N, K):
+    """panel GEMM (csrc/gemm_panel.hip) with a pre-packed weight: forward form x W^T (+bias, GELU, pre-activation),
+    data-gradient form dy W (* act'(aux)) through the transposed pack, residual epilogue, ragged panels"""
+    assert ops.gemm_panel_supported(M, N, K)
+    A, W = rnd(M, K, seed=1), rnd(N, K, seed=2, scale=1.0 / math.sqrt(K))            # W [N, K] = nn.Linear layout
+    b, R_ = rnd(N, seed=3, scale=0.3), rnd(M, N, seed=4)
+    Wd = W.cuda()
+    pk = ops.PanelPacks([(Wd, N, K, K, False), (Wd, K, N, K, True)])                 # W (forward), W^T (dgrad)
+    pk.refresh()
+    pre_ref = A.double() @ W.double().t() + b.double()
+    y, pre = ops.gemm_panel(A.cuda(), pk.bufs[0], N, bias=b.cuda(), act=1, mode=ops.EPI_ACT, save_pre=True)
+    assert_close(pre, pre_ref, "pre")
+    assert_close(y, torch.nn.functional.gelu(pre_ref), "gelu(pre)")
+    y2, _ = ops.gemm_panel(A.cuda(), pk.bufs[0], N, bias=b.cuda(), res=R_.cuda())
+    assert_close(y2, pre_ref + R_.double(), "linear + residual")
+    if dpot_ok := ops.gemm_panel_supported(M, K, N):
+        dY, aux = rnd(M, N, seed=5), rnd(M, K, seed=6)
+        pr = aux.double().clone().requires_grad_(True)
+        torch.nn.functional.gelu(pr).backward(torch.ones_like(pr))
+        dx_ref = (dY.double() @ W.double()) * pr.grad
+        dx, _ = ops.gemm_panel(dY.cuda(), pk.bufs[1], K, act=1, mode=ops.EPI_DACT, aux=aux.cuda())
+        assert_close(dx, dx_ref, "dgrad * gelu'")
