@@ -271,26 +271,21 @@ static int panel_chunk_cols(int N) {
   return 0;
 }
 
-// rows per panel: fewest rounds of (panels * chunks) workgroups; small panels leave room for two workgroups per CU
+// rows per panel.  Measured (scripts/panel_bench.py, profiles/r02_panel_gemm_bench.txt): 64-row panels (RT = 4) win on
+// every DPOT shape - M = 8192 then gives exactly one workgroup per CU and column chunk; shorter panels that would fit two
+// workgroups per CU (20 waves) are slower, taller ones re-balance worse.  Other heights only when they save a round.
 static int panel_pick_rt(int M, int nchunks, int nc) {
   static const int forced = [] { const char* e = getenv("DPOT_PANEL_RT"); return e ? atoi(e) : 0; }();
   if (forced >= 1 && forced <= 5) return forced;
+  (void)nc;
   double best_cost = -1;
   int best = 4;
-  for (int rt = 5; rt >= 1; --rt) {
+  const int order[5] = {4, 5, 3, 2, 1};
+  for (int o = 0; o < 5; ++o) {
+    const int rt = order[o];
     const long long panels = (M + 16 * rt - 1) / (16 * rt);
-    const long long lds = (3LL * nc * 16 + 2LL * rt * 512) * 4;
-    long long per_cu = 163840 / lds;
-    if (per_cu > 3) per_cu = 3;
-    if (per_cu < 1) per_cu = 1;
-    const long long items = panels * nchunks;
-    const long long slots = PANEL_NUM_CU * per_cu;
-    const long long rounds = (items + slots - 1) / slots;
-    long long eff = (items + PANEL_NUM_CU - 1) / PANEL_NUM_CU;      // workgroups that really share a CU
-    if (eff > per_cu) eff = per_cu;
-    // co-resident workgroups share the matrix pipe: a round lasts `eff` panels of MFMA time; the fixed prologue /
-    // epilogue share (~10 rows' worth) is hidden behind the neighbours when eff > 1
-    const double cost = rounds * (eff * 16.0 * rt + 10.0 / eff);
+    const long long rounds = (panels * nchunks + PANEL_NUM_CU - 1) / PANEL_NUM_CU;
+    const double cost = rounds * (16.0 * rt + 10.0) * (rt == 4 ? 1.0 : 1.08);
     if (best_cost < 0 || cost < best_cost) {
       best_cost = cost;
       best = rt;

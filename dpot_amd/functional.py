@@ -348,14 +348,14 @@ class BlockFn(torch.autograd.Function):
 
 
 # ======================================================================================================
-def head_derived(o0w, o0b, o4w, o4b, P: int):
+def head_derived(o0w, o0b, o4w, o4b, P: int, wt_out=None):
     """weight-only layouts of the de-embed stage: ConvTranspose2d(k=s=P) weight as the GEMM matrix whose columns are
     ordered (i, j, o) - the GEMM result IS the pixel-major [pixels, old] matrix -, its bias repeated per pixel, and
     the zero-padded last 1x1 conv of the fused tail (None when the fused tail does not apply)"""
     E, old = o0w.shape[0], o0w.shape[1]
     co = o4w.shape[0]
     PP = P * P
-    wt = ops.transpose2d(o0w, E, old, PP).view(E, PP * old)
+    wt = ops.transpose2d(o0w, E, old, PP, out=wt_out).view(E, PP * old)
     bexp = ops.tile_vec(o0b, PP)
     w4p = b4p = None
     if old == 32 and 0 < co <= 32:
@@ -379,20 +379,32 @@ class HeadFn(torch.autograd.Function):
         fused = ops.out_tail_supported(old, co, Mp)
         if derived is None:
             derived = head_derived(o0w, o0b, o4w, o4b, P)
-        wt, bexp, w4p, b4p = derived
+        wt, bexp, w4p, b4p = derived[:4]
+        head_pk = derived[4] if len(derived) > 4 else None
+        if head_pk is not None and not (ops.panel_enabled() and ops.gemm_panel_supported(M, PP * old, E)
+                                        and ops.gemm_panel_supported(M, E, PP * old)):
+            head_pk = None
+        ctx.head_pk = head_pk
         if fused:
             # GEMM writes only the pre-activation; the whole per-pixel tail (act, 1x1, act, 1x1, pixel shuffle) is one
             # kernel that reads it once (csrc/tail.hip)
             U = V = Vpre = None
             Upre = torch.empty(M, PP * old, dtype=torch.float32, device=dev)
-            ops.gemm(x, wt, Upre, M, PP * old, E, lda=E, ldb=PP * old, ldc=PP * old, bias=bexp)
+            if head_pk is not None:
+                Upre, _ = ops.gemm_panel(x.view(M, E), head_pk[0], PP * old, bias=bexp)
+            else:
+                ops.gemm(x, wt, Upre, M, PP * old, E, lda=E, ldb=PP * old, ldc=PP * old, bias=bexp)
             pred = ops.out_tail_fwd(Upre, o2w, o2b, w4p, b4p, B, h, w, P, co, act)  # [B, X, Y, co]
             V = w4p                                                            # (saved slot reused: padded W4)
         else:
-            U = torch.empty(M, PP * old, dtype=torch.float32, device=dev)
-            Upre = torch.empty_like(U)
-            ops.gemm(x, wt, U, M, PP * old, E, lda=E, ldb=PP * old, ldc=PP * old, bias=bexp, act=act, mode=EPI_ACT,
-                     preact=Upre, ldpre=PP * old)
+            if head_pk is not None:
+                U, Upre = ops.gemm_panel(x.view(M, E), head_pk[0], PP * old, bias=bexp, act=act, mode=EPI_ACT,
+                                         save_pre=True)
+            else:
+                U = torch.empty(M, PP * old, dtype=torch.float32, device=dev)
+                Upre = torch.empty_like(U)
+                ops.gemm(x, wt, U, M, PP * old, E, lda=E, ldb=PP * old, ldc=PP * old, bias=bexp, act=act,
+                         mode=EPI_ACT, preact=Upre, ldpre=PP * old)
             V, Vpre = ops.linear_fwd(U.view(Mp, old), o2w, o2b, act=act, save_pre=True)
             Z, _ = ops.linear_fwd(V, o4w, o4b)                                 # [Mp, co]
             pred = ops.pixel_shuffle(Z, B, h, w, P, co)                        # [B, X, Y, co]
@@ -441,8 +453,11 @@ class HeadFn(torch.autograd.Function):
                 do2w, do2b = s_o2w.done(do2w.view(old, old, 1, 1)), s_o2b.done(do2b)
                 do0b = s_o0b.done(ops.colsum(dUpre, Mp, old, out=s_o0b.out()))
             dU2 = dUpre.view(M, PP * old)
-            dx_out = torch.empty(M, E, dtype=torch.float32, device=dev)
-            ops.gemm(dU2, wt, dx_out, M, E, PP * old, transB=True, lda=PP * old, ldb=PP * old, ldc=E)
+            if ctx.head_pk is not None:
+                dx_out, _ = ops.gemm_panel(dU2, ctx.head_pk[1], E)
+            else:
+                dx_out = torch.empty(M, E, dtype=torch.float32, device=dev)
+                ops.gemm(dU2, wt, dx_out, M, E, PP * old, transB=True, lda=PP * old, ldb=PP * old, ldc=E)
             dwt = torch.empty(E, PP * old, dtype=torch.float32, device=dev)
             ops.gemm(x, dU2, dwt, E, PP * old, M, transA=True, lda=E, ldb=PP * old, ldc=PP * old,
                      splitk=ops.auto_splitk(E, PP * old, M))

@@ -151,32 +151,50 @@ class DPOTNet(nn.Module):
         pk = ops.afno_pack_multi([p for blk in self.blocks for p in ((blk.filter.w1, blk.filter.b1),
                                                                      (blk.filter.w2, blk.filter.b2))]) \
             if len(self.blocks) else []
-        head = head_derived(ol[0].weight, ol[0].bias, ol[4].weight, ol[4].bias, self.patch_size)
-        d = (emb, pk, head, self._mlp_panel_packs())
+        PP_old = self.patch_size ** 2 * ol[0].weight.shape[1]
+        wt_buf = getattr(self, "_wt_buf", None)
+        if wt_buf is None or wt_buf.device != ol[0].weight.device or wt_buf.numel() != self.embed_dim * PP_old:
+            wt_buf = self._wt_buf = torch.empty(self.embed_dim, PP_old, dtype=torch.float32, device=ol[0].weight.device)
+        head = head_derived(ol[0].weight, ol[0].bias, ol[4].weight, ol[4].bias, self.patch_size, wt_out=wt_buf)
+        mlp_pk, head_pk = self._panel_packs_refresh(wt_buf)
+        d = (emb, pk, head + (head_pk,), mlp_pk)
         if self._scope_depth > 0:
             self._scope_cache = d
         return d
 
-    def _mlp_panel_packs(self):
-        """fragment-block-major copies of the channel-MLP weights for the panel GEMM (csrc/gemm_panel.hip): W1, W1^T,
-        W2, W2^T per block (forward x W^T and data gradient dy W), all refreshed by ONE launch per optimiser step"""
-        if not (len(self.blocks) and ops.panel_enabled()):
-            return None
-        E, mh = self.embed_dim, self.blocks[0].mlp[0].weight.shape[0]
-        if not (ops.gemm_panel_supported(1, mh, E) and ops.gemm_panel_supported(1, E, mh)):
-            return None
-        key = tuple(b.mlp[i].weight.data_ptr() for b in self.blocks for i in (0, 2))
+    def _panel_packs_refresh(self, wt):
+        """fragment-block-major copies of the static weights of the panel GEMM (csrc/gemm_panel.hip), refreshed by ONE
+        launch per optimiser step: per block W1, W1^T, W2, W2^T (channel-MLP forward x W^T and data gradient dy W) and the
+        de-embed matrix wt [E, P*P*old] both ways.  Returns (per-block tuples | None, (wt fwd, wt bwd) | None)."""
+        if not ops.panel_enabled():
+            return None, None
+        E = self.embed_dim
+        n_out = wt.shape[1]
+        use_mlp = use_head = False
+        if len(self.blocks):
+            mh = self.blocks[0].mlp[0].weight.shape[0]
+            use_mlp = ops.gemm_panel_supported(1, mh, E) and ops.gemm_panel_supported(1, E, mh)
+        use_head = ops.gemm_panel_supported(1, n_out, E) and ops.gemm_panel_supported(1, E, n_out)
+        if not (use_mlp or use_head):
+            return None, None
+        key = tuple(b.mlp[i].weight.data_ptr() for b in self.blocks for i in (0, 2)) + (wt.data_ptr(), use_mlp, use_head)
         pp = getattr(self, "_panel_packs", None)
         if pp is None or pp.key_all != key:
             jobs = []
-            for b in self.blocks:
-                w1, w2 = b.mlp[0].weight, b.mlp[2].weight                       # [mh, E, 1, 1], [E, mh, 1, 1]
-                jobs += [(w1, mh, E, E, False), (w1, E, mh, E, True), (w2, E, mh, mh, False), (w2, mh, E, mh, True)]
+            if use_mlp:
+                for b in self.blocks:
+                    w1, w2 = b.mlp[0].weight, b.mlp[2].weight                   # [mh, E, 1, 1], [E, mh, 1, 1]
+                    jobs += [(w1, mh, E, E, False), (w1, E, mh, E, True), (w2, E, mh, mh, False), (w2, mh, E, mh, True)]
+            if use_head:
+                jobs += [(wt, n_out, E, n_out, True), (wt, E, n_out, n_out, False)]
             pp = ops.PanelPacks(jobs)
             pp.key_all = key
             self._panel_packs = pp
         pp.refresh()
-        return [tuple(pp.bufs[4 * i:4 * i + 4]) for i in range(len(self.blocks))]
+        nb = len(self.blocks) if use_mlp else 0
+        mlp_pk = [tuple(pp.bufs[4 * i:4 * i + 4]) for i in range(nb)] if use_mlp else None
+        head_pk = tuple(pp.bufs[4 * nb:4 * nb + 2]) if use_head else None
+        return mlp_pk, head_pk
 
     def forward(self, x):
         if not x.is_cuda:
