@@ -126,7 +126,9 @@ def gemm(A: Tensor, B: Tensor, C_: Tensor, M: int, N: int, K: int, *, transA: bo
 # panel GEMM with pre-packed static weights (csrc/gemm_panel.hip)
 # ------------------------------------------------------------------------------------------------------
 def panel_enabled() -> bool:
-    return os.environ.get("DPOT_PANEL_GEMM", "1") != "0" and _gemm_precision == GEMM_F32 and _mlp_precision in (None, GEMM_F32)
+    """the panel kernel is an fp32 kernel: used while the global GEMM precision is 'f32' (the channel-MLP override of
+    set_mlp_precision is checked where it applies, functional._mlp_panel_ok)"""
+    return os.environ.get("DPOT_PANEL_GEMM", "1") != "0" and _gemm_precision == GEMM_F32
 
 
 def gemm_panel_supported(M: int, N: int, K: int) -> bool:
