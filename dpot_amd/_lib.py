@@ -83,9 +83,9 @@ SIGNATURES = {
     "dpot_group_rowsum": (c_i, [c_fp, c_fp] + [c_i] * 4 + [c_fp]),
     "dpot_token_mean": (c_i, [c_fp, c_fp] + [c_i] * 3 + [c_fp]),
     "dpot_token_mean_bwd": (c_i, [c_fp] * 3 + [c_i] * 3 + [c_fp]),
-    "dpot_add": (c_i, [c_fp] * 3 + [c_i64, c_fp]),
     "dpot_bias_add": (c_i, [c_fp] * 3 + [c_i, c_i, c_fp]),
     "dpot_scale_shift": (c_i, [c_fp] * 4 + [c_i] * 3 + [c_fp]),
+    "dpot_scale_shift_bwd": (c_i, [c_fp] * 6 + [c_i] * 3 + [c_fp]),
     "dpot_timeagg_scale_w": (c_i, [c_fp] * 4 + [c_i, c_i, c_fp]),
     "dpot_timeagg_scale_w_bwd": (c_i, [c_fp] * 6 + [c_i, c_i, c_fp]),
     "dpot_out_tail_partial_rows": (c_i, [c_i] * 4),

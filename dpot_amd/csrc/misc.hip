@@ -203,11 +203,6 @@ __global__ void token_mean_bwd_kernel(const float* __restrict__ dy, const float*
   }
 }
 
-__global__ void add_kernel(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ y,
-                           long long n) {
-  for (long long i = blockIdx.x * 256ll + threadIdx.x; i < n; i += (long long)gridDim.x * 256) y[i] = a[i] + b[i];
-}
-
 __global__ void bias_add_kernel(const float* __restrict__ x, const float* __restrict__ v, float* __restrict__ y, int N,
                                 long long total) {
   for (long long i = blockIdx.x * 256ll + threadIdx.x; i < total; i += (long long)gridDim.x * 256)
@@ -257,6 +252,35 @@ __global__ __launch_bounds__(256) void timeagg_scale_w_bwd_kernel(const float* _
     dg += s * (-sn) * tv;
   }
   if (dgamma && threadIdx.x == 0) dgamma[i] = dg;
+}
+
+// adjoint of y = x * scale[b,e] + shift[b,e]: dx = dy * scale; dscale[b,e] = sum_t dy*x; dshift[b,e] = sum_t dy
+// grid (ceil(E/64), B), block 256 = 64 channels x 4 token lanes; fixed-order combination -> deterministic
+__global__ __launch_bounds__(256) void scale_shift_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ x,
+                                                              const float* __restrict__ scale, float* __restrict__ dx,
+                                                              float* __restrict__ dscale, float* __restrict__ dshift,
+                                                              int T, int E) {
+  __shared__ float s1[256], s2[256];
+  const int b = blockIdx.y, e = blockIdx.x * 64 + (threadIdx.x & 63), tl = threadIdx.x >> 6;
+  float a1 = 0.f, a2 = 0.f;
+  if (e < E) {
+    const float sc = scale[(long long)b * E + e];
+    for (int t = tl; t < T; t += 4) {
+      const long long idx = ((long long)b * T + t) * E + e;
+      const float g = dy[idx];
+      dx[idx] = g * sc;
+      a1 = fmaf(g, x[idx], a1);
+      a2 += g;
+    }
+  }
+  s1[threadIdx.x] = a1;
+  s2[threadIdx.x] = a2;
+  __syncthreads();
+  if (tl == 0 && e < E) {
+    const int c = threadIdx.x;
+    dscale[(long long)b * E + e] = (s1[c] + s1[c + 64]) + (s1[c + 128] + s1[c + 192]);
+    dshift[(long long)b * E + e] = (s2[c] + s2[c + 64]) + (s2[c + 128] + s2[c + 192]);
+  }
 }
 
 static inline unsigned grid_for(long long n, int cap = 8192) {
@@ -416,12 +440,6 @@ extern "C" int dpot_token_mean_bwd(const float* dy, const float* add, float* dx,
   return check_launch("token_mean_bwd_kernel");
 }
 
-extern "C" int dpot_add(const float* a, const float* b, float* y, int64_t n, dpot_stream_t stream) {
-  DPOT_REQUIRE(a && b && y && n > 0, "add: bad argument");
-  hipLaunchKernelGGL(add_kernel, dim3(grid_for(n)), dim3(256), 0, as_stream(stream), a, b, y, (long long)n);
-  return check_launch("add_kernel");
-}
-
 extern "C" int dpot_bias_add(const float* x, const float* v, float* y, int R, int N, dpot_stream_t stream) {
   DPOT_REQUIRE(v && y && R > 0 && N > 0, "bias_add: bad argument");   // x == NULL: y = v tiled R times
   const long long total = (long long)R * N;
@@ -436,6 +454,15 @@ extern "C" int dpot_scale_shift(const float* x, const float* scale, const float*
   hipLaunchKernelGGL(scale_shift_kernel, dim3(grid_for(total)), dim3(256), 0, as_stream(stream), x, scale, shift, y, T,
                      E, total);
   return check_launch("scale_shift_kernel");
+}
+
+extern "C" int dpot_scale_shift_bwd(const float* dy, const float* x, const float* scale, float* dx, float* dscale,
+                                    float* dshift, int B, int T, int E, dpot_stream_t stream) {
+  DPOT_REQUIRE(dy && x && scale && dx && dscale && dshift && B > 0 && B <= 65535 && T > 0 && E > 0,
+               "scale_shift_bwd: bad argument");
+  hipLaunchKernelGGL(scale_shift_bwd_kernel, dim3((unsigned)cdiv(E, 64), B), dim3(256), 0, as_stream(stream), dy, x,
+                     scale, dx, dscale, dshift, T, E);
+  return check_launch("scale_shift_bwd_kernel");
 }
 
 extern "C" int dpot_timeagg_scale_w(const float* w, const float* gamma, const float* tt, float* ws, int T, int E,

@@ -518,5 +518,20 @@ class RelL2Fn(torch.autograd.Function):
         return dx, None, None
 
 
+class AdaINFn(torch.autograd.Function):
+    """lat * scale[b,:] + shift[b,:]   (models/dpot.py:386-387, the normalize=True branch)"""
+
+    @staticmethod
+    def forward(ctx, lat, scale, shift):
+        lat, scale, shift = lat.contiguous(), scale.contiguous(), shift.contiguous()
+        ctx.save_for_backward(lat, scale)
+        return ops.scale_shift(lat, scale, shift)
+
+    @staticmethod
+    def backward(ctx, g):
+        lat, scale = ctx.saved_tensors
+        return ops.scale_shift_bwd(g.contiguous(), lat, scale)
+
+
 def rel_l2_loss(x: Tensor, y: Tensor, mask: Optional[Tensor] = None) -> Tensor:
     return RelL2Fn.apply(x, y, mask)

@@ -21,7 +21,7 @@ import torch.nn as nn
 from . import _lib, ops
 import contextlib
 
-from .functional import BlockFn, EmbedFn, HeadFn, embed_derived, head_derived
+from .functional import AdaINFn, BlockFn, EmbedFn, HeadFn, embed_derived, head_derived
 
 ACTIVATIONS = ("gelu", "tanh", "sigmoid", "relu", "leaky_relu", "softplus", "ELU", "silu")
 
@@ -222,7 +222,7 @@ class DPOTNet(nn.Module):
                             ta.gamma if self.time_agg == "exp_mlp" else None, self._gx, self._gy, self._gt, self._tt,
                             P, self._act, d_emb)
         if self.normalize:
-            lat = s_sigma[:, None, :] * lat + s_mu[:, None, :]          # AdaIN (models/dpot.py:386-387)
+            lat = AdaINFn.apply(lat, s_sigma, s_mu)                     # AdaIN (models/dpot.py:386-387)
         recompute = self.recompute_blocks and torch.is_grad_enabled()
         hook = self._boundary_hook
         for i, blk in enumerate(self.blocks):

@@ -420,12 +420,6 @@ def token_mean_bwd(dy: Tensor, T: int, add: Optional[Tensor] = None) -> Tensor:
     return dx
 
 
-def add(a: Tensor, b: Tensor) -> Tensor:
-    y = torch.empty_like(a)
-    check(_lib.load().dpot_add(a.data_ptr(), b.data_ptr(), y.data_ptr(), a.numel(), _stream()), "add")
-    return y
-
-
 def bias_add(x: Tensor, v: Tensor) -> Tensor:
     """y[r, n] = x[r, n] + v[n]"""
     R, N = x.shape
@@ -448,6 +442,16 @@ def scale_shift(x: Tensor, scale: Tensor, shift: Tensor) -> Tensor:
     check(_lib.load().dpot_scale_shift(x.data_ptr(), scale.data_ptr(), shift.data_ptr(), y.data_ptr(), B, T, E,
                                        _stream()), "scale_shift")
     return y
+
+
+def scale_shift_bwd(dy: Tensor, x: Tensor, scale: Tensor):
+    B, T, E = x.shape
+    dx = torch.empty_like(x)
+    dscale = torch.empty(B, E, dtype=torch.float32, device=x.device)
+    dshift = torch.empty_like(dscale)
+    check(_lib.load().dpot_scale_shift_bwd(dy.data_ptr(), x.data_ptr(), scale.data_ptr(), dx.data_ptr(),
+                                           dscale.data_ptr(), dshift.data_ptr(), B, T, E, _stream()), "scale_shift_bwd")
+    return dx, dscale, dshift
 
 
 def timeagg_scale_w(w: Tensor, gamma: Tensor, tt: Tensor) -> Tensor:

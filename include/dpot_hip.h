@@ -218,14 +218,15 @@ int dpot_group_rowsum(const float* X, float* out, int B, int R, int T, int N, dp
 int dpot_token_mean(const float* x, float* y, int B, int T, int E, dpot_stream_t stream);
 int dpot_token_mean_bwd(const float* dy, const float* add, float* dx, int B, int T, int E,
                         dpot_stream_t stream);
-/* y = a + b (n floats) */
-int dpot_add(const float* a, const float* b, float* y, int64_t n, dpot_stream_t stream);
 /* y[r, n] = x[r, n] + v[n]   (row-broadcast add; pos_embed + conv bias folded ahead of the TimeAggregator);
  * x == NULL: y = v tiled R times (the ConvTranspose bias repeated per output pixel of a patch) */
 int dpot_bias_add(const float* x, const float* v, float* y, int R, int N, dpot_stream_t stream);
 /* y[b,t,e] = x[b,t,e] * scale[b,e] + shift[b,e]  (AdaIN, models/dpot.py:386-387) */
 int dpot_scale_shift(const float* x, const float* scale, const float* shift, float* y, int B, int T, int E,
                      dpot_stream_t stream);
+/* its adjoint: dx = dy * scale, dscale[b,e] = sum_t dy * x, dshift[b,e] = sum_t dy */
+int dpot_scale_shift_bwd(const float* dy, const float* x, const float* scale, float* dx, float* dscale,
+                         float* dshift, int B, int T, int E, dpot_stream_t stream);
 
 /* TimeAggregator 'exp_mlp' (models/dpot.py:229-232): ws[t,i,j] = w[t,i,j] * cos(tt[t] * gamma[i]) and the
  * adjoint: dw = dws * cos(.), dgamma[i] = sum_{t,j} dws[t,i,j] * w[t,i,j] * (-sin(tt[t]*gamma[i])) * tt[t] */

@@ -250,10 +250,13 @@ def test_small_data_movement_ops(ops):
     dy, addt = rnd(3, 64, seed=7), rnd(3, 50, 64, seed=8)
     assert_close(ops.token_mean_bwd(dy.cuda(), 50, add=addt.cuda()), dy.double()[:, None, :] / 50 + addt.double(),
                  "token_mean_bwd")
-    assert_close(ops.add(xt.cuda(), addt.cuda()), xt.double() + addt.double(), "add")
     sc, sh = rnd(3, 64, seed=9), rnd(3, 64, seed=10)
     assert_close(ops.scale_shift(xt.cuda(), sc.cuda(), sh.cuda()), xt.double() * sc.double()[:, None] + sh.double()[:, None],
                  "scale_shift")
+    dxs, dsc, dsh = ops.scale_shift_bwd(addt.cuda(), xt.cuda(), sc.cuda())
+    assert_close(dxs, addt.double() * sc.double()[:, None], "scale_shift_bwd dx")
+    assert_close(dsc, (addt.double() * xt.double()).sum(1), "scale_shift_bwd dscale")
+    assert_close(dsh, addt.double().sum(1), "scale_shift_bwd dshift")
 
 
 def test_timeagg_scale(ops):
