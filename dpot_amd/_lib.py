@@ -47,6 +47,11 @@ class PackJob(C.Structure):
                 ("trans", C.c_int32)]
 
 
+class AfnoPackJob(C.Structure):
+    """mirror of struct dpot_afno_pack_job"""
+    _fields_ = [("w", c_fp), ("b", c_fp), ("wbig", c_fp), ("bbig", c_fp), ("fwd", c_fp), ("bwd", c_fp)]
+
+
 class SampleDesc(C.Structure):
     """mirror of struct dpot_sample_desc"""
     _fields_ = [("data", c_fp), ("H", C.c_int32), ("W", C.c_int32), ("T", C.c_int32), ("C", C.c_int32),
@@ -69,6 +74,7 @@ SIGNATURES = {
     "dpot_afno_mlp2_supported": (c_i, [c_i, c_i]),
     "dpot_afno_mlp2": (c_i, [c_fp] * 9 + [c_i] * 7 + [c_fp]),
     "dpot_afno_block_weights": (c_i, [c_fp] * 3 + [c_i, c_i, c_fp]),
+    "dpot_afno_pack_all": (c_i, [c_fp, c_i, c_i, c_i, c_fp]),
     "dpot_groupnorm_fwd": (c_i, [c_fp] * 6 + [c_i] * 4 + [c_f, c_fp]),
     "dpot_groupnorm_bwd": (c_i, [c_fp] * 10 + [c_i] * 4 + [c_fp]),
     "dpot_patchify": (c_i, [c_fp] * 5 + [c_i] * 6 + [c_fp]),

@@ -393,6 +393,40 @@ __global__ __launch_bounds__(256) void afno_block_weights_kernel(const float* __
   }
 }
 
+// Everything the mixer needs from the parameters of ONE AFNO layer, in one pass (job table in DEVICE memory, one job per
+// layer): w [2, nb, bs, bs], b [2, nb, bs] (models/dpot.py:45-48) ->
+//   wbig [nb][N][N] = [[Wr, Wi], [-Wi, Wr]] (row-major W[k][n]; the generic GEMM fallback and the tests use it),
+//   bbig [nb][N] = [br | bi],  fwd / bwd = fragment-block-major W and W^T (see afno_block_weights_kernel)
+__global__ __launch_bounds__(256) void afno_pack_all_kernel(const dpot_afno_pack_job* __restrict__ jobs, int nb, int bs) {
+  const dpot_afno_pack_job job = jobs[blockIdx.y];
+  const int N = 2 * bs, nct = N / 16;
+  const long long nW = (long long)nb * N * N;
+  const long long plane = (long long)nb * bs * bs;
+  for (long long idx = blockIdx.x * 256ll + threadIdx.x; idx < nW; idx += (long long)gridDim.x * 256) {
+    const int c = (int)(idx % N);
+    const int r = (int)((idx / N) % N);
+    const int k = (int)(idx / ((long long)N * N));
+    const int i = r % bs, o = c % bs;
+    const bool rim = r >= bs, cim = c >= bs;
+    const long long wi = ((long long)k * bs + i) * bs + o;
+    float v;
+    if (!rim && !cim) v = job.w[wi];
+    else if (!rim && cim) v = job.w[plane + wi];
+    else if (rim && !cim) v = -job.w[plane + wi];
+    else v = job.w[wi];
+    if (job.wbig) job.wbig[idx] = v;
+    const long long base = (long long)k * N * N;
+    if (job.bwd)   // Wt = W: block (row tile r/16, slab c/16), chunk (row r%16, k-quad (c%16)/4)
+      job.bwd[base + ((((long long)(r >> 4) * nct + (c >> 4)) * 64 + ((c & 15) >> 2) * 16 + (r & 15)) << 2) + (c & 3)] = v;
+    if (job.fwd)   // Wt = W^T: block (row tile c/16, slab r/16), chunk (row c%16, k-quad (r%16)/4)
+      job.fwd[base + ((((long long)(c >> 4) * nct + (r >> 4)) * 64 + ((r & 15) >> 2) * 16 + (c & 15)) << 2) + (r & 3)] = v;
+  }
+  for (long long idx = blockIdx.x * 256ll + threadIdx.x; idx < (long long)nb * N; idx += (long long)gridDim.x * 256) {
+    const int ci = (int)(idx % bs), part = (int)((idx / bs) & 1), k = (int)(idx / N);
+    job.bbig[idx] = job.b[((long long)part * nb + k) * bs + ci];
+  }
+}
+
 constexpr int AFNO_NUM_CU = 256;
 
 // rows per panel (multiple of 16, <= 80): fewest rounds of (panels * nb) workgroups over the CUs, one workgroup per CU
@@ -450,6 +484,15 @@ extern "C" int dpot_afno_block_weights(const float* wbig, float* fwd, float* bwd
   hipLaunchKernelGGL(afno_block_weights_kernel, dim3((unsigned)g), dim3(256), 0, as_stream(stream), wbig, fwd, bwd, N,
                      total);
   return check_launch("afno_block_weights_kernel");
+}
+
+extern "C" int dpot_afno_pack_all(const dpot_afno_pack_job* jobs_dev, int njobs, int nb, int bs, dpot_stream_t stream) {
+  DPOT_REQUIRE(jobs_dev && njobs > 0 && njobs <= 65535 && nb > 0 && bs > 0, "afno_pack_all: bad argument");
+  DPOT_REQUIRE((2 * bs) % 16 == 0, "afno_pack_all: 2*bs must be a multiple of 16 for the blocked copies");
+  long long g = ((long long)nb * 4 * bs * bs + 255) / 256;
+  if (g > 1024) g = 1024;
+  hipLaunchKernelGGL(afno_pack_all_kernel, dim3((unsigned)g, njobs), dim3(256), 0, as_stream(stream), jobs_dev, nb, bs);
+  return check_launch("afno_pack_all_kernel");
 }
 
 extern "C" int dpot_afno_mlp2(const float* X, const float* WaT, const float* ba, const float* WbT, const float* bb,

@@ -147,10 +147,14 @@ class DPOTNet(nn.Module):
         pe, ta, ol = self.patch_embed.proj, self.time_agg_layer, self.out_layer
         emb = embed_derived(self.pos_embed, pe[0].weight, pe[0].bias, pe[2].weight, pe[2].bias, ta.w,
                             ta.gamma if self.time_agg == "exp_mlp" else None, self._tt, self.in_timesteps)
-        # Wbig = [[Wr, Wi], [-Wi, Wr]] of every AFNO layer, packed in ONE launch (2*depth tiny launches otherwise)
-        pk = ops.afno_pack_multi([p for blk in self.blocks for p in ((blk.filter.w1, blk.filter.b1),
-                                                                     (blk.filter.w2, blk.filter.b2))]) \
-            if len(self.blocks) else []
+        # Wbig = [[Wr, Wi], [-Wi, Wr]] of every AFNO layer + its fragment-block-major forms, ONE launch for all layers
+        pk = []
+        if len(self.blocks):
+            pairs = [p for blk in self.blocks for p in ((blk.filter.w1, blk.filter.b1), (blk.filter.w2, blk.filter.b2))]
+            ap = getattr(self, "_afno_packs", None)
+            if ap is None or ap.key != tuple(t.data_ptr() for p in pairs for t in p):
+                ap = self._afno_packs = ops.AfnoPacks(pairs)
+            pk = ap.refresh()
         PP_old = self.patch_size ** 2 * ol[0].weight.shape[1]
         wt_buf = getattr(self, "_wt_buf", None)
         if wt_buf is None or wt_buf.device != ol[0].weight.device or wt_buf.numel() != self.embed_dim * PP_old:

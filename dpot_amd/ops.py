@@ -284,6 +284,40 @@ def afno_pack_multi(pairs) -> list:
     return [(wbig[i], bbig[i], None, None) for i in range(n)]
 
 
+class AfnoPacks:
+    """Packed forms of ALL AFNO layers of a model, refreshed by ONE launch (dpot_afno_pack_all) from a device-resident
+    job table: persistent output buffers, so the table is built once per parameter placement.
+    pairs = [(w [2,nb,bs,bs], b [2,nb,bs]), ...];  self.items[i] = (wbig, bbig, fwd | None, bwd | None)"""
+
+    def __init__(self, pairs):
+        import numpy as np
+        n = len(pairs)
+        _, nb, bs, _ = pairs[0][0].shape
+        dev = pairs[0][0].device
+        N = 2 * bs
+        self.nb, self.bs, self.n = nb, bs, n
+        self.key = tuple(t.data_ptr() for p in pairs for t in p)
+        fused = afno_mlp2_supported(nb, bs)
+        wbig = torch.empty(n, nb, N, N, dtype=torch.float32, device=dev)
+        bbig = torch.empty(n, nb, N, dtype=torch.float32, device=dev)
+        fwd = torch.empty_like(wbig) if fused else None
+        bwd = torch.empty_like(wbig) if fused else None
+        host = np.zeros(n * C.sizeof(_lib.AfnoPackJob), dtype=np.uint8)
+        tab = (_lib.AfnoPackJob * n).from_buffer(host)
+        for i, (w, b) in enumerate(pairs):
+            tab[i].w, tab[i].b = _req(w, "w").data_ptr(), _req(b, "b").data_ptr()
+            tab[i].wbig, tab[i].bbig = wbig[i].data_ptr(), bbig[i].data_ptr()
+            tab[i].fwd = fwd[i].data_ptr() if fused else None
+            tab[i].bwd = bwd[i].data_ptr() if fused else None
+        self.table = torch.from_numpy(host).to(dev)
+        self.items = [(wbig[i], bbig[i], fwd[i] if fused else None, bwd[i] if fused else None) for i in range(n)]
+
+    def refresh(self):
+        check(_lib.load().dpot_afno_pack_all(self.table.data_ptr(), self.n, self.nb, self.bs, _stream()),
+              "afno_pack_all")
+        return self.items
+
+
 def afno_block_weights(wbig: Tensor) -> Tuple[Tensor, Tensor]:
     """wbig [J, N, N] (W[k][n]) -> (fwd, bwd): fragment-block-major W and W^T (dpot_afno_block_weights)"""
     J, N, _ = wbig.shape

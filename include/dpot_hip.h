@@ -309,6 +309,19 @@ int dpot_afno_mlp2(const float* X, const float* Wa, const float* ba, const float
  * (n = l&15, k = 4*(l>>4)..+3): fwd holds W (for X W), bwd holds W^T (for X W^T).  Either output may be NULL. */
 int dpot_afno_block_weights(const float* wbig, float* fwd, float* bwd, int nmat, int N, dpot_stream_t stream);
 
+/* one AFNO layer to pack (DEVICE table entry, 48 bytes): parameters w [2,nb,bs,bs], b [2,nb,bs] -> wbig [nb,N,N]
+ * (W[k][n], may be NULL), bbig [nb,N], fwd / bwd fragment-block-major W / W^T for dpot_afno_mlp2 (may be NULL) */
+typedef struct dpot_afno_pack_job {
+  const float* w;
+  const float* b;
+  float* wbig;
+  float* bbig;
+  float* fwd;
+  float* bwd;
+} dpot_afno_pack_job;
+/* dpot_afno_pack + dpot_afno_block_weights for every layer of a model in ONE launch; the table lives in device memory */
+int dpot_afno_pack_all(const dpot_afno_pack_job* jobs_dev, int njobs, int nb, int bs, dpot_stream_t stream);
+
 /* backward of the noise injection for AR steps whose input depends on earlier predictions:
  * dx = g + noise_scale * xx / norms[b,c] * sum_(X,Y,T)(g * eps).  eps: the tensor the forward used, or NULL with
  * rng_state = a copy of the generator state {seed, offset} the forward drew from.  norms: [B, C] written by the
