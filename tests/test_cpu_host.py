@@ -145,3 +145,54 @@ def test_flat_params_views():
         assert p.grad.data_ptr() == fp.grad.data_ptr() + 4 * o
     m.load_state_dict(R.recipe_state_dict(R.DPOTConfig(**R.MINI)))       # in-place: views stay attached
     assert fp.params[0].data_ptr() == fp.flat.data_ptr() + 4 * fp.offsets[0]
+
+
+def test_dp_lr_rule_matches_accelerate_stepping():
+    """train_temporal_parallel.py:150,185: OneCycleLR sized by the UNSHARDED loader, stepped `world` times per optimiser
+    step by accelerate's AcceleratedScheduler (split_batches=False) - dp.dp_one_cycle_lr gives the lr each optimiser
+    step actually uses"""
+    from dpot_amd.dp import dp_one_cycle_lr
+    world, total, max_lr, pct = 4, 240, 1e-3, 0.25
+    p = torch.nn.Parameter(torch.zeros(1))
+    opt = torch.optim.SGD([p], lr=max_lr)
+    sched = torch.optim.lr_scheduler.OneCycleLR(opt, max_lr=max_lr, div_factor=1e4, pct_start=pct,
+                                                final_div_factor=1e4, total_steps=total)
+    for step in range(total // world):
+        used = opt.param_groups[0]["lr"]                     # the lr optimizer.step() sees at this update
+        assert abs(dp_one_cycle_lr(step, world, total, max_lr, pct_start=pct) - used) <= 1e-9 * max_lr + 1e-12, step
+        opt.step()
+        for _ in range(world):                               # AcceleratedScheduler.step: num_processes steps
+            if sched.last_epoch < total - 1:
+                sched.step()
+
+
+def test_flat_params_execution_order_and_stage_buckets():
+    """FlatParams lays parameters out by forward execution stage (time_agg before the blocks, out_layer last before the
+    cls_head tail); BucketedGradReducer cuts buckets only at stage boundaries"""
+    from dpot_amd import DPOTNet
+    from dpot_amd.dp import BucketedGradReducer
+    from dpot_amd.train import FlatParams
+    m = DPOTNet(**dict(R.MINI, depth=4))
+    fp = FlatParams(m)
+    stages = [BucketedGradReducer._stage(n) for n in fp.names]
+    head = [s for s in stages if s >= 0]
+    assert head == sorted(head) and stages[-1] == -1 and fp.names[0].startswith("patch_embed.")
+    assert fp.names.index("time_agg_layer.w") < fp.names.index("blocks.0.norm1.weight")
+    red = BucketedGradReducer(fp, n_buckets=8)
+    for k in range(red.n_buckets):
+        st = {red.stage_of[i] for i in red.members[k]}
+        nxt = {red.stage_of[i] for i in red.members[k + 1]} if k + 1 < red.n_buckets else set()
+        assert not (st & nxt), "a stage must not straddle two buckets"
+    assert red.tail_bucket == red.n_buckets - 1
+
+
+def test_load_components_warns_for_absent_known_component():
+    import warnings
+    from dpot_amd import DPOTNet
+    from dpot_amd.infer import load_components_from_pretrained
+    cfg = R.DPOTConfig(**R.MINI)
+    m = DPOTNet(**R.MINI)                                    # normalize=False: no scale_feats
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        load_components_from_pretrained(m, R.recipe_state_dict(cfg, salt=1), ["blocks", "scale_feats"])
+    assert any("scale_feats" in str(x.message) for x in w)
