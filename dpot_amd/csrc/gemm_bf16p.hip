@@ -1,0 +1,292 @@
+// gemm_bf16p.hip - bf16 "panel" GEMM on v_mfma_f32_32x32x16_bf16 for the channel-MLP of the larger DPOT models
+// (BASELINE configs[2]: "bf16 channel-MLP on MFMA"; DPOT-M / -L spend 83-89 % of their FLOPs there):
+//
+//      C[M, N] (fp32) = epilogue( A[M, K] @ W[K, N] )        bf16 operands, fp32 accumulation
+//
+// Both operands are PRE-PACKED bf16 in fragment-block-major order - the (32 rows x 16 k) block of row tile r / K-slab t is
+// 1 KiB contiguous, chunk l of a block = (row l&31, k 8*(l>>5)..+7) = the MFMA A/B operand order - so the GEMM loop is
+// LDS-DMA + ds_read_b128 + MFMA only (the round-1 attempt converted inside a register-staged loop and was load-bound: a
+// plain-bf16 instantiation of gemm_split.h is no faster than its 6-product form):
+//   * weights are packed once per optimiser step (dpot_bf16_pack_jobs, all weights in one launch, W and W^T);
+//   * activations are packed by dpot_bf16_pack_rows: one HBM pass (4 B read, 2 B written per element) per GEMM operand,
+//     ~10 % of the GEMM's own time at K = 1024;
+//   * workgroup tile 128 x 256, 8 compute waves in a 2 x 4 grid (wave tile 64 x 64 = 2 x 2 accumulators of 32x32) + 4
+//     loader waves issuing the DMA (24 KiB per 32-k slab), ring of three slab buffers, loaders three slabs ahead with
+//     counted vmcnt, ONE barrier per slab, fragments of slab t+1 fetched into a second register set under the MFMAs of
+//     slab t (the structure of csrc/gemm_panel.hip / afno_mlp.hip);
+//   * the fused epilogue of the fp32 kernels (gemm_epi.h): bias, pre-activation save, activation, act'(aux), residual.
+#include "common.h"
+#include "gemm_epi.h"
+
+namespace dpot {
+
+typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+
+struct Bf16pArgs {
+  const unsigned short* A;   // packed [Mtiles][K/16][512]
+  const unsigned short* W;   // packed [N/32][K/16][512]
+  int M, N, K, tilesM, tilesN;
+  EpiArgs e;
+};
+
+template <int N>
+__device__ __forceinline__ void bwait_vm() {
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+__device__ __forceinline__ void bglds16(const void* g, void* l) {
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                   (__attribute__((address_space(3))) void*)l, 16, 0, 0);
+}
+
+constexpr int PB_ROWT = 4;      // 32-row tiles per workgroup (128 rows)
+constexpr int PB_COLT = 8;      // 32-column tiles per workgroup (256 columns)
+constexpr int PB_NLOAD = 4;     // loader waves
+constexpr int PB_SLABB = (PB_ROWT + PB_COLT) * 2 * 1024;        // bytes of one 32-k slab: 24 KiB
+
+__global__ __launch_bounds__(64 * (8 + PB_NLOAD)) void gemm_bf16p_kernel(const Bf16pArgs p) {
+  // ring of 3 slabs; the epilogue stages through it afterwards (8 waves x 32 x EPI_LD floats = 36 KiB)
+  __shared__ __attribute__((aligned(16))) unsigned char lds[3 * PB_SLABB];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int nslab = p.K >> 5;                       // 32-k slabs (K % 32 == 0)
+  const int ks16 = p.K >> 4;                        // 16-k blocks per row tile
+
+  // XCD-contiguous tile order, column-tile major: workgroups sharing a weight chunk sit on one chiplet's L2
+  const int ntiles = p.tilesM * p.tilesN;
+  int tile;
+  {
+    const int bid = blockIdx.x, xcd = bid & 7, slot = bid >> 3;
+    const int q = ntiles >> 3, r = ntiles & 7;
+    tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + slot;
+  }
+  const int tn = tile / p.tilesM, tm = tile - tn * p.tilesM;
+  const int rt0 = tm * PB_ROWT, ct0 = tn * PB_COLT;  // first 32-row tile / 32-column tile
+  const int mtiles = (p.M + 31) >> 5;
+
+  auto bar = [&]() __attribute__((always_inline)) {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+  };
+
+  if (wave >= 8) {
+    // ================================ loader waves: 24 blocks per slab, 6 per wave ================================
+    const int L = wave - 8;
+    // block b of a slab: b < 8: A (row tile b>>1, k-half b&1); else W (column tile (b-8)>>1, k-half (b-8)&1)
+    const unsigned short* src[6];
+    int dst[6];
+#pragma unroll
+    for (int n = 0; n < 6; ++n) {
+      const int b = L + PB_NLOAD * n;
+      if (b < 2 * PB_ROWT) {
+        int rt = rt0 + (b >> 1);
+        rt = rt < mtiles ? rt : mtiles - 1;          // clamped: rows past M only feed outputs that are never stored
+        src[n] = p.A + ((long long)rt * ks16 + (b & 1)) * 512 + lane * 8;
+      } else {
+        const int c = b - 2 * PB_ROWT;
+        src[n] = p.W + ((long long)(ct0 + (c >> 1)) * ks16 + (c & 1)) * 512 + lane * 8;
+      }
+      dst[n] = b * 1024;
+    }
+    auto issue = [&](int t, int ring) __attribute__((always_inline)) {
+#pragma unroll
+      for (int n = 0; n < 6; ++n) bglds16(src[n] + (long long)t * 1024, lds + ring * PB_SLABB + dst[n]);
+    };
+    issue(0, 0);
+    if (nslab > 1) issue(1, 1);
+    if (nslab > 2) issue(2, 2);
+    if (nslab > 2) bwait_vm<6>(); else bwait_vm<0>();
+    bar();                                              // P
+    int ring = 0;
+#pragma unroll 1
+    for (int g = 0; g < nslab; ++g) {
+      bar();                                            // B_g
+      if (g + 3 < nslab) {
+        issue(g + 3, ring);
+        bwait_vm<6>();
+      } else {
+        bwait_vm<0>();
+      }
+      ring = ring == 2 ? 0 : ring + 1;
+    }
+    bar();                                              // S
+    return;
+  }
+
+  // ================================ compute waves ================================
+  const int wm = wave >> 2, wn = wave & 3;
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  // fragments of one slab: a[i][ks], b[j][ks]  (ks = 16-k half of the 32-k slab)
+  auto read_frags = [&](bf16x8_t (&a)[2][2], bf16x8_t (&b)[2][2], int ring) __attribute__((always_inline)) {
+    const unsigned char* base = lds + ring * PB_SLABB + lane * 16;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks)
+        a[i][ks] = *reinterpret_cast<const bf16x8_t*>(base + ((2 * wm + i) * 2 + ks) * 1024);
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks)
+        b[j][ks] = *reinterpret_cast<const bf16x8_t*>(base + (2 * PB_ROWT + (2 * wn + j) * 2 + ks) * 1024);
+  };
+  auto mma = [&](const bf16x8_t (&a)[2][2], const bf16x8_t (&b)[2][2]) __attribute__((always_inline)) {
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][ks], b[j][ks], acc[i][j], 0, 0, 0);
+  };
+
+  bf16x8_t aA[2][2], bA[2][2], aB[2][2], bB[2][2];
+  bar();                                               // P
+  read_frags(aA, bA, 0);
+  {
+    int r1 = 1, r2 = 2;
+#pragma unroll 1
+    for (int t = 0; t < nslab; t += 2) {
+      bar();                                           // B_t
+      if (t + 1 < nslab) read_frags(aB, bB, r1);
+      mma(aA, bA);
+      if (t + 1 < nslab) {
+        bar();                                         // B_(t+1)
+        if (t + 2 < nslab) read_frags(aA, bA, r2);
+        mma(aB, bB);
+      }
+      r1 = r1 == 0 ? 2 : r1 - 1;
+      r2 = r2 == 0 ? 2 : r2 - 1;
+    }
+  }
+  bar();                                               // S: all DMA landed and read; the ring becomes epilogue staging
+
+  float* stage = reinterpret_cast<float*>(lds) + wave * (32 * EPI_LD);
+  const int m0 = (rt0 + 2 * wm) * 32, n0 = (ct0 + 2 * wn) * 32;
+  epi_fragment(p.e, 1, 0, m0, n0, acc[0][0], stage, lane);
+  epi_fragment(p.e, 1, 0, m0, n0 + 32, acc[0][1], stage, lane);
+  epi_fragment(p.e, 1, 0, m0 + 32, n0, acc[1][0], stage, lane);
+  epi_fragment(p.e, 1, 0, m0 + 32, n0 + 32, acc[1][1], stage, lane);
+}
+
+__device__ __forceinline__ unsigned pack2(float lo, float hi) {
+  f32x2_t v = {lo, hi};
+  bf16x2_t r = __builtin_convertvector(v, bf16x2_t);   // v_cvt_pk_bf16_f32 (round to nearest even)
+  return __builtin_bit_cast(unsigned, r);
+}
+
+// activations: src fp32 [R, K] row-major (ld) -> [ceil(R/32)][K/16][64 chunks][8 bf16]; rows past R are zero.
+// one thread = one 16-byte chunk (row, 8 consecutive k); a wave covers 4 rows x 128 k (512 B per row: full lines)
+__global__ __launch_bounds__(256) void bf16_pack_rows_kernel(const float* __restrict__ src, int ld, int R, int K,
+                                                             uint4* __restrict__ dst, long long nchunks) {
+  const int kc_per_row = K >> 3;
+  for (long long c = blockIdx.x * 256ll + threadIdx.x; c < nchunks; c += (long long)gridDim.x * 256) {
+    const int kc = (int)(c % kc_per_row);
+    const int row = (int)(c / kc_per_row);
+    uint4 o = make_uint4(0u, 0u, 0u, 0u);
+    if (row < R) {
+      const float4 x0 = *reinterpret_cast<const float4*>(src + (long long)row * ld + 8 * kc);
+      const float4 x1 = *reinterpret_cast<const float4*>(src + (long long)row * ld + 8 * kc + 4);
+      o = make_uint4(pack2(x0.x, x0.y), pack2(x0.z, x0.w), pack2(x1.x, x1.y), pack2(x1.z, x1.w));
+    }
+    // block (row tile, 16-k slab kc>>1), chunk (row & 31) + 32 * (kc & 1)
+    dst[((long long)(row >> 5) * (K >> 4) + (kc >> 1)) * 64 + (row & 31) + 32 * (kc & 1)] = o;
+  }
+}
+
+// weights (job table in device memory): logical Wt [rows, K] (row n, k) = trans ? src[k*ld + n] : src[n*ld + k]
+__global__ __launch_bounds__(256) void bf16_pack_jobs_kernel(const dpot_pack_job* __restrict__ jobs) {
+  const dpot_pack_job job = jobs[blockIdx.y];
+  const int kc_per_row = job.K >> 3;
+  const long long nchunks = (long long)job.rows * kc_per_row;
+  uint4* dst = reinterpret_cast<uint4*>(job.dst);
+  for (long long c = blockIdx.x * 256ll + threadIdx.x; c < nchunks; c += (long long)gridDim.x * 256) {
+    int row, kc;
+    if (job.trans) {               // adjacent threads: adjacent rows (contiguous in the [K][rows] source)
+      row = (int)(c % job.rows);
+      kc = (int)(c / job.rows);
+    } else {
+      kc = (int)(c % kc_per_row);
+      row = (int)(c / kc_per_row);
+    }
+    float v[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int k = 8 * kc + e;
+      v[e] = job.trans ? job.src[(long long)k * job.ld + row] : job.src[(long long)row * job.ld + k];
+    }
+    dst[((long long)(row >> 5) * (job.K >> 4) + (kc >> 1)) * 64 + (row & 31) + 32 * (kc & 1)] =
+        make_uint4(pack2(v[0], v[1]), pack2(v[2], v[3]), pack2(v[4], v[5]), pack2(v[6], v[7]));
+  }
+}
+
+}  // namespace dpot
+
+using namespace dpot;
+
+extern "C" int dpot_gemm_bf16p_supported(int M, int N, int K) {
+  return M > 0 && N > 0 && N % 256 == 0 && K >= 32 && K % 32 == 0 ? 1 : 0;
+}
+
+extern "C" int64_t dpot_bf16_packed_elems(int rows, int K) { return (int64_t)((rows + 31) / 32) * 32 * K; }
+
+extern "C" int dpot_bf16_pack_rows(const float* src, int ld, int rows, int K, void* dst, dpot_stream_t stream) {
+  DPOT_REQUIRE(src && dst && rows > 0 && K > 0 && K % 16 == 0 && ld >= K && ld % 4 == 0 && aligned16(src) &&
+                   aligned16(dst),
+               "bf16_pack_rows: bad argument (K %% 16, 16-byte aligned rows)");
+  const long long nchunks = (long long)((rows + 31) / 32) * 32 * (K >> 3);
+  long long g = (nchunks + 255) / 256;
+  if (g > 8192) g = 8192;
+  hipLaunchKernelGGL(bf16_pack_rows_kernel, dim3((unsigned)g), dim3(256), 0, as_stream(stream), src, ld, rows, K,
+                     reinterpret_cast<uint4*>(dst), nchunks);
+  return check_launch("bf16_pack_rows_kernel");
+}
+
+extern "C" int dpot_bf16_pack_jobs(const dpot_pack_job* jobs_dev, int njobs, int max_elems, dpot_stream_t stream) {
+  DPOT_REQUIRE(jobs_dev && njobs > 0 && njobs <= 65535 && max_elems > 0, "bf16_pack_jobs: bad argument");
+  long long g = ((long long)max_elems / 8 + 255) / 256;
+  if (g > 2048) g = 2048;
+  hipLaunchKernelGGL(bf16_pack_jobs_kernel, dim3((unsigned)g, njobs), dim3(256), 0, as_stream(stream), jobs_dev);
+  return check_launch("bf16_pack_jobs_kernel");
+}
+
+extern "C" int dpot_gemm_bf16p(const void* Apacked, const void* Wpacked, const float* bias, const float* aux, int ldaux,
+                               const float* res, int ldres, float* pre, int ldpre, float* C, int ldc, int M, int N, int K,
+                               int act, int epi_mode, dpot_stream_t stream) {
+  DPOT_REQUIRE(Apacked && Wpacked && C, "gemm_bf16p: null operand");
+  DPOT_REQUIRE(dpot_gemm_bf16p_supported(M, N, K), "gemm_bf16p: unsupported shape M=%d N=%d K=%d (N %% 256, K %% 32)", M, N, K);
+  DPOT_REQUIRE(epi_mode == DPOT_EPI_LINEAR || epi_mode == DPOT_EPI_ACT || (epi_mode == DPOT_EPI_DACT && aux),
+               "gemm_bf16p: bad epilogue mode");
+  DPOT_REQUIRE(ldc >= N && ldc % 4 == 0 && (!aux || ldaux % 4 == 0) && (!res || ldres % 4 == 0) && (!pre || ldpre % 4 == 0),
+               "gemm_bf16p: leading dimensions must be multiples of 4");
+  DPOT_REQUIRE(aligned16(Apacked) && aligned16(Wpacked) && aligned16(bias) && aligned16(aux) && aligned16(res) &&
+                   aligned16(pre) && aligned16(C),
+               "gemm_bf16p: pointers must be 16-byte aligned");
+  Bf16pArgs p;
+  p.A = reinterpret_cast<const unsigned short*>(Apacked);
+  p.W = reinterpret_cast<const unsigned short*>(Wpacked);
+  p.M = M; p.N = N; p.K = K;
+  p.tilesM = (M + 32 * PB_ROWT - 1) / (32 * PB_ROWT);
+  p.tilesN = N / (32 * PB_COLT);
+  EpiArgs& e = p.e;
+  e.C = C; e.ldc = ldc; e.sC = 0;
+  e.bias = bias; e.sBias = 0;
+  e.aux = aux; e.ldaux = ldaux; e.sAux = 0;
+  e.pre = pre; e.ldpre = ldpre; e.sPre = 0;
+  e.res = res; e.ldres = ldres; e.res_div = 0; e.res_mod = 0; e.sRes = 0;
+  e.act = act; e.mode = epi_mode; e.accumulate = 0;
+  e.M = M; e.N = N;
+  hipLaunchKernelGGL(gemm_bf16p_kernel, dim3((unsigned)(p.tilesM * p.tilesN)), dim3(64 * (8 + PB_NLOAD)), 0,
+                     as_stream(stream), p);
+  return check_launch("gemm_bf16p_kernel");
+}

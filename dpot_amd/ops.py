@@ -140,10 +140,16 @@ class PanelPacks:
     job table that lives in device memory.  jobs = [(src tensor, rows, K, ld, trans)]; the destination buffers are
     allocated once, so the table stays valid while the sources do not move."""
 
-    def __init__(self, jobs):
+    def __init__(self, jobs, bf16: bool = False):
         import numpy as np
         dev = jobs[0][0].device
-        self.bufs = [torch.empty(rows * K, dtype=torch.float32, device=dev) for _, rows, K, _, _ in jobs]
+        self.bf16 = bf16
+        if bf16:       # csrc/gemm_bf16p.hip: rows padded to 32, bf16 elements
+            lib = _lib.load()
+            self.bufs = [torch.empty(lib.dpot_bf16_packed_elems(rows, K), dtype=torch.bfloat16, device=dev)
+                         for _, rows, K, _, _ in jobs]
+        else:
+            self.bufs = [torch.empty(rows * K, dtype=torch.float32, device=dev) for _, rows, K, _, _ in jobs]
         self.key = tuple(j[0].data_ptr() for j in jobs)
         host = np.zeros(len(jobs) * C.sizeof(_lib.PackJob), dtype=np.uint8)
         tab = (_lib.PackJob * len(jobs)).from_buffer(host)
@@ -154,8 +160,8 @@ class PanelPacks:
         self.max_elems = max(rows * K for _, rows, K, _, _ in jobs)
 
     def refresh(self) -> None:
-        check(_lib.load().dpot_panel_pack_weights(self.table.data_ptr(), self.n, self.max_elems, _stream()),
-              "panel_pack_weights")
+        fn = _lib.load().dpot_bf16_pack_jobs if self.bf16 else _lib.load().dpot_panel_pack_weights
+        check(fn(self.table.data_ptr(), self.n, self.max_elems, _stream()), "pack_weights")
 
 
 def gemm_panel(A: Tensor, Wpacked: Tensor, N: int, *, bias: Optional[Tensor] = None, act: int = 0,
@@ -169,6 +175,32 @@ def gemm_panel(A: Tensor, Wpacked: Tensor, N: int, *, bias: Optional[Tensor] = N
                                       aux.stride(0) if aux is not None else 0, _p(res),
                                       res.stride(0) if res is not None else 0, _p(pre), N, out.data_ptr(), N, M, N, K,
                                       act, mode, _stream()), "gemm_panel")
+    return out, pre
+
+
+def gemm_bf16p_supported(M: int, N: int, K: int) -> bool:
+    return bool(_lib.load().dpot_gemm_bf16p_supported(M, N, K))
+
+
+def bf16_pack_rows(x: Tensor) -> Tensor:
+    """fp32 [M, K] -> bf16 fragment-block-major operand of gemm_bf16p (one pass; rows padded to 32 with zeros)"""
+    M, K = x.shape
+    lib = _lib.load()
+    out = torch.empty(lib.dpot_bf16_packed_elems(M, K), dtype=torch.bfloat16, device=x.device)
+    check(lib.dpot_bf16_pack_rows(x.data_ptr(), x.stride(0), M, K, out.data_ptr(), _stream()), "bf16_pack_rows")
+    return out
+
+
+def gemm_bf16p(Ap: Tensor, Wp: Tensor, M: int, N: int, K: int, *, bias: Optional[Tensor] = None, act: int = 0,
+               mode: int = EPI_LINEAR, aux: Optional[Tensor] = None, res: Optional[Tensor] = None,
+               save_pre: bool = False) -> Tuple[Tensor, Optional[Tensor]]:
+    """C[M,N] fp32 = epilogue(A @ Wt^T) on the bf16 matrix cores; Ap = bf16_pack_rows(A), Wp = a bf16 PanelPacks buffer"""
+    out = torch.empty(M, N, dtype=torch.float32, device=Ap.device)
+    pre = torch.empty_like(out) if save_pre else None
+    check(_lib.load().dpot_gemm_bf16p(Ap.data_ptr(), Wp.data_ptr(), _p(bias), _p(aux),
+                                      aux.stride(0) if aux is not None else 0, _p(res),
+                                      res.stride(0) if res is not None else 0, _p(pre), N, out.data_ptr(), N, M, N, K,
+                                      act, mode, _stream()), "gemm_bf16p")
     return out, pre
 
 

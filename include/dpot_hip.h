@@ -359,6 +359,23 @@ int dpot_gemm_panel(const float* A, int lda, const float* Wpacked, const float* 
                     int act, int epi_mode, dpot_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * bf16 panel GEMM (csrc/gemm_bf16p.hip): REDUCED precision (operands rounded to bf16, fp32 accumulation), opt-in -
+ * BASELINE configs[2] "bf16 channel-MLP on MFMA".  Both operands pre-packed bf16, fragment-block-major:
+ * [ceil(rows/32)][K/16][64 chunks][8 bf16], chunk l = (row l&31, k 8*(l>>5)..+7); rows past the matrix are zero.
+ * ------------------------------------------------------------------------------------------------ */
+int64_t dpot_bf16_packed_elems(int rows, int K);      /* bf16 elements of a packed [rows, K] operand */
+/* activations: src fp32 [rows, K] row-major (ld) -> dst packed bf16 (one HBM pass); K % 16 == 0 */
+int dpot_bf16_pack_rows(const float* src, int ld, int rows, int K, void* dst, dpot_stream_t stream);
+/* static weights: a DEVICE table of dpot_pack_job (dst = packed bf16), all weights in one launch */
+int dpot_bf16_pack_jobs(const dpot_pack_job* jobs_dev, int njobs, int max_elems, dpot_stream_t stream);
+/* C[M,N] (fp32) = epilogue(A @ Wt^T), A = packed [M, K], Wt = packed [N, K]; epilogue as dpot_gemm_panel.
+ * Needs N % 256 == 0 and K % 32 == 0 (dpot_gemm_bf16p_supported). */
+int dpot_gemm_bf16p_supported(int M, int N, int K);
+int dpot_gemm_bf16p(const void* Apacked, const void* Wpacked, const float* bias, const float* aux, int ldaux,
+                    const float* res, int ldres, float* pre, int ldpre, float* C, int ldc, int M, int N, int K, int act,
+                    int epi_mode, dpot_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
  * input pipeline, device side (utils/griddataset.py:88-101 pad_data, :125-174 __getitem__)
  * ------------------------------------------------------------------------------------------------ */
 /* one raw trajectory of a dataset, already in device memory: data [H, W, T, C] fp32, window start t0 (32 bytes) */

@@ -1,0 +1,29 @@
+"""micro-benchmark: bf16 panel GEMM (csrc/gemm_bf16p.hip) incl. its activation pack vs the fp32 panel / generic kernels"""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from dpot_amd import ops
+
+def timeit(fn, reps=20):
+    for _ in range(3): fn()
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        for _ in range(reps): fn()
+    g.replay(); torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record(); g.replay(); e1.record(); e1.synchronize()
+    return e0.elapsed_time(e1) * 1e-3 / reps
+
+for M, N, K in ((8192, 512, 512), (8192, 1024, 1024), (8192, 4096, 1024), (8192, 1024, 4096), (4096, 6144, 1536), (4096, 1536, 6144)):
+    A = torch.randn(M, K, device="cuda"); W = torch.randn(N, K, device="cuda") * 0.05; b = torch.randn(N, device="cuda")
+    pb = ops.PanelPacks([(W, N, K, K, False)], bf16=True); pb.refresh()
+    pf = ops.PanelPacks([(W, N, K, K, False)]); pf.refresh()
+    Ap = ops.bf16_pack_rows(A)
+    t_g = timeit(lambda: ops.gemm_bf16p(Ap, pb.bufs[0], M, N, K, bias=b, act=1, mode=ops.EPI_ACT, save_pre=True))
+    t_p = timeit(lambda: ops.bf16_pack_rows(A))
+    t_f = timeit(lambda: ops.gemm_panel(A, pf.bufs[0], N, bias=b, act=1, mode=ops.EPI_ACT, save_pre=True))
+    t_x = timeit(lambda: ops.linear_fwd(A, W, b, act=1, save_pre=True, precision=ops.GEMM_BF16X6))
+    fl = 2.0 * M * N * K
+    print(f"M={M} N={N} K={K}: bf16p {t_g*1e6:7.1f} us {fl/t_g/1e12:6.1f} TF (+ pack A {t_p*1e6:6.1f} us -> {fl/(t_g+t_p)/1e12:6.1f} TF) | "
+          f"fp32 panel {t_f*1e6:7.1f} us {fl/t_f/1e12:6.1f} TF | bf16x6 {t_x*1e6:7.1f} us {fl/t_x/1e12:6.1f} TF", flush=True)

@@ -570,3 +570,33 @@ def test_gemm_panel_static_weight(ops, M, N, K):
         dx_ref = (dY.double() @ W.double()) * pr.grad
         dx, _ = ops.gemm_panel(dY.cuda(), pk.bufs[1], K, act=1, mode=ops.EPI_DACT, aux=aux.cuda())
         assert_close(dx, dx_ref, "dgrad * gelu'")
+
+
+@pytest.mark.parametrize("M,N,K", [(8192, 1024, 1024), (300, 256, 64), (4096, 512, 2048), (129, 768, 96), (1, 256, 32)])
+def test_gemm_bf16_panel(ops, M, N, K):
+    """bf16 panel GEMM (csrc/gemm_bf16p.hip): packed bf16 operands, fp32 accumulation.  Checked against an fp64 product of
+    the bf16-ROUNDED operands (exactly what the kernel multiplies: error there is fp32 accumulation only) and, loosely,
+    against the un-rounded product; epilogues as for the fp32 panel kernel; ragged M."""
+    assert ops.gemm_bf16p_supported(M, N, K)
+    A, W = rnd(M, K, seed=1), rnd(N, K, seed=2, scale=1.0 / math.sqrt(K))
+    b, R_ = rnd(N, seed=3, scale=0.3), rnd(M, N, seed=4)
+    Wd = W.cuda()
+    pk = ops.PanelPacks([(Wd, N, K, K, False), (Wd, K, N, K, True)] if K % 256 == 0 else [(Wd, N, K, K, False)], bf16=True)
+    pk.refresh()
+    Ab, Wb = A.bfloat16().double(), W.bfloat16().double()
+    pre_ref = Ab @ Wb.t() + b.double()
+    Ap = ops.bf16_pack_rows(A.cuda())
+    y, pre = ops.gemm_bf16p(Ap, pk.bufs[0], M, N, K, bias=b.cuda(), act=1, mode=ops.EPI_ACT, save_pre=True)
+    assert_close(pre, pre_ref, "pre (vs product of the rounded operands)", rtol=2e-5, atol_scale=2e-5)
+    assert_close(y, torch.nn.functional.gelu(pre_ref), "gelu", rtol=2e-5, atol_scale=2e-5)
+    full = A.double() @ W.double().t() + b.double()
+    assert ((pre.cpu().double() - full).norm() / full.norm()).item() < 8e-3
+    y2, _ = ops.gemm_bf16p(Ap, pk.bufs[0], M, N, K, bias=b.cuda(), res=R_.cuda())
+    assert_close(y2, pre_ref + R_.double(), "linear + residual", rtol=2e-5, atol_scale=2e-5)
+    if K % 256 == 0:                                                 # data-gradient form through the transposed pack
+        dY, aux = rnd(M, N, seed=5), rnd(M, K, seed=6)
+        pr = aux.double().clone().requires_grad_(True)
+        torch.nn.functional.gelu(pr).backward(torch.ones_like(pr))
+        dx_ref = (dY.bfloat16().double() @ Wb) * pr.grad
+        dx, _ = ops.gemm_bf16p(ops.bf16_pack_rows(dY.cuda()), pk.bufs[1], M, K, N, act=1, mode=ops.EPI_DACT, aux=aux.cuda())
+        assert_close(dx, dx_ref, "dgrad * gelu'", rtol=2e-5, atol_scale=2e-5)
