@@ -28,6 +28,8 @@ struct Bf16pArgs {
   const unsigned short* A;   // packed [Mtiles][K/16][512]
   const unsigned short* W;   // packed [N/32][K/16][512]
   int M, N, K, tilesM, tilesN;
+  int splits, slabs_per_split;   // split-K (weight gradients: K = tokens): blockIdx.y = split, partials go to ws
+  float* ws;                     // [splits][M][N]
   EpiArgs e;
 };
 
@@ -51,8 +53,11 @@ __global__ __launch_bounds__(64 * (8 + PB_NLOAD)) void gemm_bf16p_kernel(const B
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int nslab = p.K >> 5;                       // 32-k slabs (K % 32 == 0)
   const int ks16 = p.K >> 4;                        // 16-k blocks per row tile
+  const int zs = blockIdx.y;                        // split-K index
+  const int slab0 = zs * p.slabs_per_split;         // first 32-k slab of this split (K % 32 == 0)
+  int nslab = (p.K >> 5) - slab0;
+  nslab = nslab < p.slabs_per_split ? nslab : p.slabs_per_split;
 
   // XCD-contiguous tile order, column-tile major: workgroups sharing a weight chunk sit on one chiplet's L2
   const int ntiles = p.tilesM * p.tilesN;
@@ -84,10 +89,10 @@ __global__ __launch_bounds__(64 * (8 + PB_NLOAD)) void gemm_bf16p_kernel(const B
       if (b < 2 * PB_ROWT) {
         int rt = rt0 + (b >> 1);
         rt = rt < mtiles ? rt : mtiles - 1;          // clamped: rows past M only feed outputs that are never stored
-        src[n] = p.A + ((long long)rt * ks16 + (b & 1)) * 512 + lane * 8;
+        src[n] = p.A + ((long long)rt * ks16 + 2 * slab0 + (b & 1)) * 512 + lane * 8;
       } else {
         const int c = b - 2 * PB_ROWT;
-        src[n] = p.W + ((long long)(ct0 + (c >> 1)) * ks16 + (c & 1)) * 512 + lane * 8;
+        src[n] = p.W + ((long long)(ct0 + (c >> 1)) * ks16 + 2 * slab0 + (c & 1)) * 512 + lane * 8;
       }
       dst[n] = b * 1024;
     }
@@ -173,6 +178,24 @@ __global__ __launch_bounds__(64 * (8 + PB_NLOAD)) void gemm_bf16p_kernel(const B
 
   float* stage = reinterpret_cast<float*>(lds) + wave * (32 * EPI_LD);
   const int m0 = (rt0 + 2 * wm) * 32, n0 = (ct0 + 2 * wn) * 32;
+  if (p.splits > 1) {
+    // split-K partial: raw accumulator fragments to the workspace (C/D layout: col = lane&31, row = perm(r, lane>>5));
+    // dpot::splitk_reduce_kernel (gemm.hip) sums the splits in a fixed order and applies the epilogue
+    float* ws = p.ws + (long long)zs * p.M * p.N;
+    const int li = lane & 31, kh = lane >> 5;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const int n = n0 + 32 * j + li;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int m = m0 + 32 * i + 4 * kh + (r & 3) + 8 * (r >> 2);
+          if (m < p.M && n < p.N) ws[(long long)m * p.N + n] = acc[i][j][r];
+        }
+      }
+    return;
+  }
   epi_fragment(p.e, 1, 0, m0, n0, acc[0][0], stage, lane);
   epi_fragment(p.e, 1, 0, m0, n0 + 32, acc[0][1], stage, lane);
   epi_fragment(p.e, 1, 0, m0 + 32, n0, acc[1][0], stage, lane);
@@ -187,17 +210,34 @@ __device__ __forceinline__ unsigned pack2(float lo, float hi) {
 
 // activations: src fp32 [R, K] row-major (ld) -> [ceil(R/32)][K/16][64 chunks][8 bf16]; rows past R are zero.
 // one thread = one 16-byte chunk (row, 8 consecutive k); a wave covers 4 rows x 128 k (512 B per row: full lines)
+// trans: the logical operand is the TRANSPOSE of the stored matrix (src [K, R] row-major): element (row, k) =
+// src[k*ld + row] (weight gradients: rows = features, k = tokens); adjacent threads then take adjacent rows, so each of
+// a thread's 8 loads is part of a contiguous row segment of the source
 __global__ __launch_bounds__(256) void bf16_pack_rows_kernel(const float* __restrict__ src, int ld, int R, int K,
-                                                             uint4* __restrict__ dst, long long nchunks) {
+                                                             uint4* __restrict__ dst, long long nchunks, int trans) {
   const int kc_per_row = K >> 3;
+  const int Rp = (R + 31) & ~31;
   for (long long c = blockIdx.x * 256ll + threadIdx.x; c < nchunks; c += (long long)gridDim.x * 256) {
-    const int kc = (int)(c % kc_per_row);
-    const int row = (int)(c / kc_per_row);
+    int kc, row;
+    if (trans) {
+      row = (int)(c % Rp);
+      kc = (int)(c / Rp);
+    } else {
+      kc = (int)(c % kc_per_row);
+      row = (int)(c / kc_per_row);
+    }
     uint4 o = make_uint4(0u, 0u, 0u, 0u);
     if (row < R) {
-      const float4 x0 = *reinterpret_cast<const float4*>(src + (long long)row * ld + 8 * kc);
-      const float4 x1 = *reinterpret_cast<const float4*>(src + (long long)row * ld + 8 * kc + 4);
-      o = make_uint4(pack2(x0.x, x0.y), pack2(x0.z, x0.w), pack2(x1.x, x1.y), pack2(x1.z, x1.w));
+      if (trans) {
+        float v[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = src[(long long)(8 * kc + e) * ld + row];
+        o = make_uint4(pack2(v[0], v[1]), pack2(v[2], v[3]), pack2(v[4], v[5]), pack2(v[6], v[7]));
+      } else {
+        const float4 x0 = *reinterpret_cast<const float4*>(src + (long long)row * ld + 8 * kc);
+        const float4 x1 = *reinterpret_cast<const float4*>(src + (long long)row * ld + 8 * kc + 4);
+        o = make_uint4(pack2(x0.x, x0.y), pack2(x0.z, x0.w), pack2(x1.x, x1.y), pack2(x1.z, x1.w));
+      }
     }
     // block (row tile, 16-k slab kc>>1), chunk (row & 31) + 32 * (kc & 1)
     dst[((long long)(row >> 5) * (K >> 4) + (kc >> 1)) * 64 + (row & 31) + 32 * (kc & 1)] = o;
@@ -240,15 +280,16 @@ extern "C" int dpot_gemm_bf16p_supported(int M, int N, int K) {
 
 extern "C" int64_t dpot_bf16_packed_elems(int rows, int K) { return (int64_t)((rows + 31) / 32) * 32 * K; }
 
-extern "C" int dpot_bf16_pack_rows(const float* src, int ld, int rows, int K, void* dst, dpot_stream_t stream) {
-  DPOT_REQUIRE(src && dst && rows > 0 && K > 0 && K % 16 == 0 && ld >= K && ld % 4 == 0 && aligned16(src) &&
-                   aligned16(dst),
-               "bf16_pack_rows: bad argument (K %% 16, 16-byte aligned rows)");
+extern "C" int dpot_bf16_pack_rows(const float* src, int ld, int rows, int K, int trans, void* dst,
+                                   dpot_stream_t stream) {
+  DPOT_REQUIRE(src && dst && rows > 0 && K > 0 && K % 16 == 0 && aligned16(dst), "bf16_pack_rows: bad argument (K %% 16)");
+  DPOT_REQUIRE(trans ? ld >= rows : (ld >= K && ld % 4 == 0 && aligned16(src)),
+               "bf16_pack_rows: bad leading dimension / alignment");
   const long long nchunks = (long long)((rows + 31) / 32) * 32 * (K >> 3);
   long long g = (nchunks + 255) / 256;
   if (g > 8192) g = 8192;
   hipLaunchKernelGGL(bf16_pack_rows_kernel, dim3((unsigned)g), dim3(256), 0, as_stream(stream), src, ld, rows, K,
-                     reinterpret_cast<uint4*>(dst), nchunks);
+                     reinterpret_cast<uint4*>(dst), nchunks, trans);
   return check_launch("bf16_pack_rows_kernel");
 }
 
@@ -260,9 +301,28 @@ extern "C" int dpot_bf16_pack_jobs(const dpot_pack_job* jobs_dev, int njobs, int
   return check_launch("bf16_pack_jobs_kernel");
 }
 
+namespace dpot {
+// defined in gemm.hip: fixed-order reduction of split-K partials + epilogue
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ ws, int splits, int batch,
+                                                            const EpiArgs e, float* __restrict__ cs_out,
+                                                            long long sCs, int csL);
+}
+
+extern "C" int dpot_gemm_bf16p_splitk(int M, int N, int K) {
+  // weight-gradient shapes: few output tiles, long K.  Aim at >= 256 workgroups, keep >= 16 slabs (512 k) per split
+  const long long tiles = (long long)((M + 127) / 128) * (N / 256);
+  const int nslab = K >> 5;
+  if (tiles >= 192 || nslab < 32) return 1;
+  long long s = (256 + tiles - 1) / tiles;
+  const long long smax = nslab / 16;
+  if (s > smax) s = smax;
+  if (s > 16) s = 16;
+  return s < 1 ? 1 : (int)s;
+}
+
 extern "C" int dpot_gemm_bf16p(const void* Apacked, const void* Wpacked, const float* bias, const float* aux, int ldaux,
                                const float* res, int ldres, float* pre, int ldpre, float* C, int ldc, int M, int N, int K,
-                               int act, int epi_mode, dpot_stream_t stream) {
+                               int act, int epi_mode, int splitk, float* workspace, dpot_stream_t stream) {
   DPOT_REQUIRE(Apacked && Wpacked && C, "gemm_bf16p: null operand");
   DPOT_REQUIRE(dpot_gemm_bf16p_supported(M, N, K), "gemm_bf16p: unsupported shape M=%d N=%d K=%d (N %% 256, K %% 32)", M, N, K);
   DPOT_REQUIRE(epi_mode == DPOT_EPI_LINEAR || epi_mode == DPOT_EPI_ACT || (epi_mode == DPOT_EPI_DACT && aux),
@@ -286,7 +346,21 @@ extern "C" int dpot_gemm_bf16p(const void* Apacked, const void* Wpacked, const f
   e.res = res; e.ldres = ldres; e.res_div = 0; e.res_mod = 0; e.sRes = 0;
   e.act = act; e.mode = epi_mode; e.accumulate = 0;
   e.M = M; e.N = N;
-  hipLaunchKernelGGL(gemm_bf16p_kernel, dim3((unsigned)(p.tilesM * p.tilesN)), dim3(64 * (8 + PB_NLOAD)), 0,
+  const int nslab = K >> 5;
+  p.splits = splitk > 1 ? splitk : 1;
+  DPOT_REQUIRE(p.splits == 1 || workspace != nullptr, "gemm_bf16p: split-K needs a workspace of splitk*M*N floats");
+  DPOT_REQUIRE(p.splits <= nslab && p.splits <= 65535, "gemm_bf16p: too many splits");
+  p.slabs_per_split = (nslab + p.splits - 1) / p.splits;
+  p.splits = (nslab + p.slabs_per_split - 1) / p.slabs_per_split;       // no empty split
+  p.ws = workspace;
+  hipLaunchKernelGGL(gemm_bf16p_kernel, dim3((unsigned)(p.tilesM * p.tilesN), p.splits), dim3(64 * (8 + PB_NLOAD)), 0,
                      as_stream(stream), p);
-  return check_launch("gemm_bf16p_kernel");
+  int rc = check_launch("gemm_bf16p_kernel");
+  if (rc != DPOT_OK || p.splits == 1) return rc;
+  const long long total = (long long)M * N;
+  int blocks = (int)((total + 255) / 256);
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, as_stream(stream), (const float*)workspace, p.splits,
+                     1, e, (float*)nullptr, 0ll, 0);
+  return check_launch("splitk_reduce_kernel");
 }

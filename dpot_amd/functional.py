@@ -192,9 +192,19 @@ class EmbedFn(torch.autograd.Function):
 
 
 # ======================================================================================================
-def _mlp_panel_ok(mlp_pk, M, E, mh, mp) -> bool:
-    return (mlp_pk is not None and mp in (None, ops.GEMM_F32) and ops.panel_enabled()
-            and ops.gemm_panel_supported(M, mh, E) and ops.gemm_panel_supported(M, E, mh))
+def _mlp_panel_mode(mlp_pk, M, E, mh, mp) -> int:
+    """which pre-packed-weight kernel the channel MLP runs on: 0 = none (generic split GEMM), 1 = fp32 panel
+    (csrc/gemm_panel.hip), 2 = bf16 panel (csrc/gemm_bf16p.hip; the packs are bf16 then)"""
+    if mlp_pk is None:
+        return 0
+    if mlp_pk[0].dtype == torch.bfloat16:
+        eff = mp if mp is not None else ops.effective_mlp_precision()
+        ok = (eff == ops.GEMM_BF16 and ops.gemm_bf16p_supported(M, mh, E) and ops.gemm_bf16p_supported(M, E, mh)
+              and ops.gemm_bf16p_supported(E, mh, M) and ops.gemm_bf16p_supported(mh, E, M))
+        return 2 if ok else 0
+    ok = (mp in (None, ops.GEMM_F32) and ops.panel_enabled()
+          and ops.gemm_panel_supported(M, mh, E) and ops.gemm_panel_supported(M, E, mh))
+    return 1 if ok else 0
 
 
 def _block_parts(x, n1w, n1b, n2w, n2b, f1w, f1b, packed, dims, mp, need_out, f2w=None, f2b=None, mlp_pk=None):
@@ -222,14 +232,19 @@ def _block_parts(x, n1w, n1b, n2w, n2b, f1w, f1b, packed, dims, mp, need_out, f2
     y1 = ops.irfft2(O2, B, h, w, E, nb, mx, my, 1, res=xn1)                # + x_orig (the normalised input)
     del O2, xn1
     xn2, mean2, rstd2 = ops.groupnorm_fwd(y1, n2w, n2b)
-    panel = _mlp_panel_ok(mlp_pk, M, E, mh, mp)
-    if panel:      # static-weight panel GEMM (csrc/gemm_panel.hip): weights pre-packed once per optimiser step
+    panel = _mlp_panel_mode(mlp_pk, M, E, mh, mp)
+    if panel == 2:   # bf16 matrix cores: weights pre-packed bf16 once per step, activations packed in one pass each
+        Hh, Hpre = ops.gemm_bf16p(ops.bf16_pack_rows(xn2.view(M, E)), mlp_pk[0], M, mh, E, bias=f1b, act=act,
+                                  mode=EPI_ACT, save_pre=True)
+    elif panel:    # static-weight panel GEMM (csrc/gemm_panel.hip): weights pre-packed once per optimiser step
         Hh, Hpre = ops.gemm_panel(xn2.view(M, E), mlp_pk[0], mh, bias=f1b, act=act, mode=EPI_ACT, save_pre=True)
     else:
         Hh, Hpre = ops.linear_fwd(xn2.view(M, E), f1w, f1b, act=act, save_pre=True, precision=mp)
     out = None
     if need_out:
-        if panel:
+        if panel == 2:
+            out, _ = ops.gemm_bf16p(ops.bf16_pack_rows(Hh), mlp_pk[2], M, E, mh, bias=f2b, res=x.view(M, E))
+        elif panel:
             out, _ = ops.gemm_panel(Hh, mlp_pk[2], E, bias=f2b, res=x.view(M, E))
         else:
             out, _ = ops.linear_fwd(Hh, f2w, f2b, res=x.view(M, E), precision=mp)
@@ -256,7 +271,7 @@ class BlockFn(torch.autograd.Function):
         dims = (B, tok, E, h, w, nb, bs, mx, my, mh, act)
         mp = ops.mlp_precision()                                               # channel-MLP GEMM precision override
         out, parts = _block_parts(x, n1w, n1b, n2w, n2b, f1w, f1b, packed, dims, mp, True, f2w, f2b, mlp_pk)
-        ctx.mlp_pk = mlp_pk if _mlp_panel_ok(mlp_pk, B * tok, E, mh, mp) else None
+        ctx.mlp_pk = mlp_pk if _mlp_panel_mode(mlp_pk, B * tok, E, mh, mp) else None
         ctx.fused_mixer = packed[0][2] is not None
         # weights the backward data path multiplies by: blocked W^T (fused kernel) or the plain Wbig (generic GEMM)
         wb1, wb2 = (packed[0][3], packed[1][3]) if ctx.fused_mixer else (packed[0][0], packed[1][0])
@@ -294,18 +309,33 @@ class BlockFn(torch.autograd.Function):
         # Critical path on the current stream: dgrad GEMMs, GroupNorm, DFTs.  Everything that only produces parameter
         # gradients (wgrad GEMMs + split-K reductions, bias column sums, un-packing) runs on the side stream.
         # channel MLP
-        with streams.side(dev):
-            df2w, df2b = ops.linear_bwd_wb(do2, Hh, s_f2w.out(), s_f2b.out(), precision=mp)
-            df2w, df2b = s_f2w.done(df2w.view(E, mh, 1, 1)), s_f2b.done(df2b)
         mlp_pk = ctx.mlp_pk
-        if mlp_pk is not None:
+        bf16p = mlp_pk is not None and mlp_pk[0].dtype == torch.bfloat16
+
+        def wgrad(dy, xin, s_w, s_b, shape):
+            n, k = dy.shape[1], xin.shape[1]
+            if bf16p:   # dW[n, k] = dy^T xin on the bf16 matrix cores: both operands packed transposed (k-dim = tokens),
+                #         split-K over the tokens with a fixed-order reduction; the bias gradient is a column sum
+                dw, _ = ops.gemm_bf16p(ops.bf16_pack_rows(dy, trans=True), ops.bf16_pack_rows(xin, trans=True), n, k, M,
+                                       out=s_w.out())
+                db = ops.colsum(dy, M, n, out=s_b.out())
+            else:
+                dw, db = ops.linear_bwd_wb(dy, xin, s_w.out(), s_b.out(), precision=mp)
+            return s_w.done(dw.view(shape)), s_b.done(db)
+
+        with streams.side(dev):
+            df2w, df2b = wgrad(do2, Hh, s_f2w, s_f2b, (E, mh, 1, 1))
+        if bf16p:
+            dHpre, _ = ops.gemm_bf16p(ops.bf16_pack_rows(do2), mlp_pk[3], M, mh, E, act=act, mode=EPI_DACT, aux=Hpre)
+        elif mlp_pk is not None:
             dHpre, _ = ops.gemm_panel(do2, mlp_pk[3], mh, act=act, mode=EPI_DACT, aux=Hpre)       # do2 W2, * act'(Hpre)
         else:
             dHpre = ops.linear_bwd_data(do2, f2w, act=act, aux=Hpre, precision=mp)  # [M, mh]
         with streams.side(dev):
-            df1w, df1b = ops.linear_bwd_wb(dHpre, xn2.view(M, E), s_f1w.out(), s_f1b.out(), precision=mp)
-            df1w, df1b = s_f1w.done(df1w.view(mh, E, 1, 1)), s_f1b.done(df1b)
-        if mlp_pk is not None:
+            df1w, df1b = wgrad(dHpre, xn2.view(M, E), s_f1w, s_f1b, (mh, E, 1, 1))
+        if bf16p:
+            dxn2, _ = ops.gemm_bf16p(ops.bf16_pack_rows(dHpre), mlp_pk[1], M, E, mh)
+        elif mlp_pk is not None:
             dxn2, _ = ops.gemm_panel(dHpre, mlp_pk[1], E)                      # dHpre W1
         else:
             dxn2 = ops.linear_bwd_data(dHpre, f1w, precision=mp)               # [M, E]

@@ -15,6 +15,8 @@ The model only runs on a CUDA (ROCm) device; calling it with CPU tensors raises 
 from __future__ import annotations
 
 import numpy as np
+import os
+
 import torch
 import torch.nn as nn
 
@@ -167,37 +169,55 @@ class DPOTNet(nn.Module):
         return d
 
     def _panel_packs_refresh(self, wt):
-        """fragment-block-major copies of the static weights of the panel GEMM (csrc/gemm_panel.hip), refreshed by ONE
-        launch per optimiser step: per block W1, W1^T, W2, W2^T (channel-MLP forward x W^T and data gradient dy W) and the
-        de-embed matrix wt [E, P*P*old] both ways.  Returns (per-block tuples | None, (wt fwd, wt bwd) | None)."""
-        if not ops.panel_enabled():
-            return None, None
+        """fragment-block-major copies of the static weights of the panel GEMMs, refreshed by ONE launch each per
+        optimiser step: per block W1, W1^T, W2, W2^T (channel-MLP forward x W^T and data gradient dy W) - fp32 for
+        csrc/gemm_panel.hip, or bf16 for csrc/gemm_bf16p.hip when the channel-MLP precision is 'bf16' - and the de-embed
+        matrix wt [E, P*P*old] both ways (fp32).  Returns (per-block tuples | None, (wt fwd, wt bwd) | None)."""
         E = self.embed_dim
         n_out = wt.shape[1]
-        use_mlp = use_head = False
-        if len(self.blocks):
-            mh = self.blocks[0].mlp[0].weight.shape[0]
-            use_mlp = ops.gemm_panel_supported(1, mh, E) and ops.gemm_panel_supported(1, E, mh)
-        use_head = ops.gemm_panel_supported(1, n_out, E) and ops.gemm_panel_supported(1, E, n_out)
-        if not (use_mlp or use_head):
-            return None, None
-        key = tuple(b.mlp[i].weight.data_ptr() for b in self.blocks for i in (0, 2)) + (wt.data_ptr(), use_mlp, use_head)
-        pp = getattr(self, "_panel_packs", None)
-        if pp is None or pp.key_all != key:
+        mlp_pk = head_pk = None
+        nb = len(self.blocks)
+
+        def mlp_jobs():
             jobs = []
-            if use_mlp:
-                for b in self.blocks:
-                    w1, w2 = b.mlp[0].weight, b.mlp[2].weight                   # [mh, E, 1, 1], [E, mh, 1, 1]
-                    jobs += [(w1, mh, E, E, False), (w1, E, mh, E, True), (w2, E, mh, mh, False), (w2, mh, E, mh, True)]
+            for b in self.blocks:
+                w1, w2 = b.mlp[0].weight, b.mlp[2].weight                   # [mh, E, 1, 1], [E, mh, 1, 1]
+                jobs += [(w1, mh, E, E, False), (w1, E, mh, E, True), (w2, E, mh, mh, False), (w2, mh, E, mh, True)]
+            return jobs
+
+        def cached(attr, key, make_jobs, bf16):
+            pp = getattr(self, attr, None)
+            if pp is None or pp.key_all != key:
+                pp = ops.PanelPacks(make_jobs(), bf16=bf16)
+                pp.key_all = key
+                setattr(self, attr, pp)
+            pp.refresh()
+            return pp
+
+        wkey = tuple(b.mlp[i].weight.data_ptr() for b in self.blocks for i in (0, 2))
+        f32_mlp = False
+        if nb:
+            mh = self.blocks[0].mlp[0].weight.shape[0]
+            if (ops.effective_mlp_precision() == ops.GEMM_BF16 and os.environ.get("DPOT_BF16_PANEL", "1") != "0"
+                    and ops.gemm_bf16p_supported(128, mh, E) and ops.gemm_bf16p_supported(128, E, mh)):
+                pp = cached("_panel_packs_bf16", wkey, mlp_jobs, True)
+                mlp_pk = [tuple(pp.bufs[4 * i:4 * i + 4]) for i in range(nb)]
+            elif ops.panel_enabled():
+                f32_mlp = ops.gemm_panel_supported(1, mh, E) and ops.gemm_panel_supported(1, E, mh)
+        use_head = (ops.panel_enabled() and ops.gemm_panel_supported(1, n_out, E)
+                    and ops.gemm_panel_supported(1, E, n_out))
+        if f32_mlp or use_head:
+            def jobs32():
+                jobs = mlp_jobs() if f32_mlp else []
+                if use_head:
+                    jobs += [(wt, n_out, E, n_out, True), (wt, E, n_out, n_out, False)]
+                return jobs
+            pp = cached("_panel_packs", wkey + (wt.data_ptr(), f32_mlp, use_head), jobs32, False)
+            n0 = 4 * nb if f32_mlp else 0
+            if f32_mlp:
+                mlp_pk = [tuple(pp.bufs[4 * i:4 * i + 4]) for i in range(nb)]
             if use_head:
-                jobs += [(wt, n_out, E, n_out, True), (wt, E, n_out, n_out, False)]
-            pp = ops.PanelPacks(jobs)
-            pp.key_all = key
-            self._panel_packs = pp
-        pp.refresh()
-        nb = len(self.blocks) if use_mlp else 0
-        mlp_pk = [tuple(pp.bufs[4 * i:4 * i + 4]) for i in range(nb)] if use_mlp else None
-        head_pk = tuple(pp.bufs[4 * nb:4 * nb + 2]) if use_head else None
+                head_pk = tuple(pp.bufs[n0:n0 + 2])
         return mlp_pk, head_pk
 
     def forward(self, x):

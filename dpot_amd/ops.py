@@ -50,6 +50,11 @@ def set_mlp_precision(name: Optional[str]) -> None:
     _mlp_precision = None if name is None else _PRECISIONS[name]
 
 
+def effective_mlp_precision() -> int:
+    """precision the channel-MLP GEMMs run in: the override if set, else the global GEMM precision"""
+    return _mlp_precision if _mlp_precision is not None else _gemm_precision
+
+
 def mlp_precision() -> Optional[int]:
     return _mlp_precision
 
@@ -182,26 +187,37 @@ def gemm_bf16p_supported(M: int, N: int, K: int) -> bool:
     return bool(_lib.load().dpot_gemm_bf16p_supported(M, N, K))
 
 
-def bf16_pack_rows(x: Tensor) -> Tensor:
-    """fp32 [M, K] -> bf16 fragment-block-major operand of gemm_bf16p (one pass; rows padded to 32 with zeros)"""
-    M, K = x.shape
+def bf16_pack_rows(x: Tensor, trans: bool = False) -> Tensor:
+    """fp32 [M, K] -> bf16 fragment-block-major operand of gemm_bf16p (one pass; rows padded to 32 with zeros).
+    trans: pack x^T instead (x stored [K, rows]: weight gradients - rows = features, k = tokens)"""
     lib = _lib.load()
+    if trans:
+        K, M = x.shape
+    else:
+        M, K = x.shape
     out = torch.empty(lib.dpot_bf16_packed_elems(M, K), dtype=torch.bfloat16, device=x.device)
-    check(lib.dpot_bf16_pack_rows(x.data_ptr(), x.stride(0), M, K, out.data_ptr(), _stream()), "bf16_pack_rows")
+    check(lib.dpot_bf16_pack_rows(x.data_ptr(), x.stride(0), M, K, int(trans), out.data_ptr(), _stream()),
+          "bf16_pack_rows")
     return out
 
 
 def gemm_bf16p(Ap: Tensor, Wp: Tensor, M: int, N: int, K: int, *, bias: Optional[Tensor] = None, act: int = 0,
                mode: int = EPI_LINEAR, aux: Optional[Tensor] = None, res: Optional[Tensor] = None,
-               save_pre: bool = False) -> Tuple[Tensor, Optional[Tensor]]:
-    """C[M,N] fp32 = epilogue(A @ Wt^T) on the bf16 matrix cores; Ap = bf16_pack_rows(A), Wp = a bf16 PanelPacks buffer"""
-    out = torch.empty(M, N, dtype=torch.float32, device=Ap.device)
-    pre = torch.empty_like(out) if save_pre else None
-    check(_lib.load().dpot_gemm_bf16p(Ap.data_ptr(), Wp.data_ptr(), _p(bias), _p(aux),
-                                      aux.stride(0) if aux is not None else 0, _p(res),
-                                      res.stride(0) if res is not None else 0, _p(pre), N, out.data_ptr(), N, M, N, K,
-                                      act, mode, _stream()), "gemm_bf16p")
-    return out, pre
+               save_pre: bool = False, out: Optional[Tensor] = None,
+               splitk: Optional[int] = None) -> Tuple[Tensor, Optional[Tensor]]:
+    """C[M,N] fp32 = epilogue(A @ Wt^T) on the bf16 matrix cores; Ap / Wp: packed bf16 operands (bf16_pack_rows, or a
+    bf16 PanelPacks buffer).  splitk=None: the library's choice (weight gradients use split-K)."""
+    lib = _lib.load()
+    C_ = _out(out, (M, N), Ap.device)
+    pre = torch.empty_like(C_) if save_pre else None
+    if splitk is None:
+        splitk = lib.dpot_gemm_bf16p_splitk(M, N, K)
+    ws = torch.empty(splitk * M * N, dtype=torch.float32, device=Ap.device) if splitk > 1 else None
+    check(lib.dpot_gemm_bf16p(Ap.data_ptr(), Wp.data_ptr(), _p(bias), _p(aux),
+                              aux.stride(0) if aux is not None else 0, _p(res),
+                              res.stride(0) if res is not None else 0, _p(pre), N, C_.data_ptr(), N, M, N, K,
+                              act, mode, splitk, _p(ws), _stream()), "gemm_bf16p")
+    return C_, pre
 
 
 def linear_fwd(x: Tensor, W: Tensor, bias: Optional[Tensor], act: int = 0, save_pre: bool = False,

@@ -364,8 +364,9 @@ int dpot_gemm_panel(const float* A, int lda, const float* Wpacked, const float* 
  * [ceil(rows/32)][K/16][64 chunks][8 bf16], chunk l = (row l&31, k 8*(l>>5)..+7); rows past the matrix are zero.
  * ------------------------------------------------------------------------------------------------ */
 int64_t dpot_bf16_packed_elems(int rows, int K);      /* bf16 elements of a packed [rows, K] operand */
-/* activations: src fp32 [rows, K] row-major (ld) -> dst packed bf16 (one HBM pass); K % 16 == 0 */
-int dpot_bf16_pack_rows(const float* src, int ld, int rows, int K, void* dst, dpot_stream_t stream);
+/* activations: src fp32 [rows, K] row-major (ld) - or, trans != 0, its transpose stored [K, rows] (weight gradients:
+ * rows = features, k = tokens) - -> dst packed bf16 (one HBM pass); K % 16 == 0 */
+int dpot_bf16_pack_rows(const float* src, int ld, int rows, int K, int trans, void* dst, dpot_stream_t stream);
 /* static weights: a DEVICE table of dpot_pack_job (dst = packed bf16), all weights in one launch */
 int dpot_bf16_pack_jobs(const dpot_pack_job* jobs_dev, int njobs, int max_elems, dpot_stream_t stream);
 /* C[M,N] (fp32) = epilogue(A @ Wt^T), A = packed [M, K], Wt = packed [N, K]; epilogue as dpot_gemm_panel.
@@ -373,7 +374,10 @@ int dpot_bf16_pack_jobs(const dpot_pack_job* jobs_dev, int njobs, int max_elems,
 int dpot_gemm_bf16p_supported(int M, int N, int K);
 int dpot_gemm_bf16p(const void* Apacked, const void* Wpacked, const float* bias, const float* aux, int ldaux,
                     const float* res, int ldres, float* pre, int ldpre, float* C, int ldc, int M, int N, int K, int act,
-                    int epi_mode, dpot_stream_t stream);
+                    int epi_mode, int splitk, float* workspace, dpot_stream_t stream);
+/* split-K factor the library recommends for a shape (weight gradients: few output tiles, K = tokens); splitk > 1 needs
+ * a workspace of splitk*M*N floats, summed in a fixed order by a second launch (deterministic) */
+int dpot_gemm_bf16p_splitk(int M, int N, int K);
 
 /* ------------------------------------------------------------------------------------------------
  * input pipeline, device side (utils/griddataset.py:88-101 pad_data, :125-174 __getitem__)

@@ -27,3 +27,18 @@ for M, N, K in ((8192, 512, 512), (8192, 1024, 1024), (8192, 4096, 1024), (8192,
     fl = 2.0 * M * N * K
     print(f"M={M} N={N} K={K}: bf16p {t_g*1e6:7.1f} us {fl/t_g/1e12:6.1f} TF (+ pack A {t_p*1e6:6.1f} us -> {fl/(t_g+t_p)/1e12:6.1f} TF) | "
           f"fp32 panel {t_f*1e6:7.1f} us {fl/t_f/1e12:6.1f} TF | bf16x6 {t_x*1e6:7.1f} us {fl/t_x/1e12:6.1f} TF", flush=True)
+
+print("weight-gradient form: dW[n,k] = dy^T x, tokens = GEMM k-dim, both operands packed transposed, split-K", flush=True)
+for T, N, K in ((8192, 4096, 1024), (8192, 1024, 4096), (4096, 6144, 1536), (4096, 1536, 6144), (8192, 1024, 1024)):
+    dy = torch.randn(T, N, device="cuda"); x = torch.randn(T, K, device="cuda")
+    dyp, xp = ops.bf16_pack_rows(dy, trans=True), ops.bf16_pack_rows(x, trans=True)
+    out = torch.empty(N, K, device="cuda")
+    sk = ops._lib.load().dpot_gemm_bf16p_splitk(N, K, T)
+    t_g = timeit(lambda: ops.gemm_bf16p(dyp, xp, N, K, T, out=out))
+    t_p = timeit(lambda: (ops.bf16_pack_rows(dy, trans=True), ops.bf16_pack_rows(x, trans=True)))
+    t_x = timeit(lambda: ops.linear_bwd_weight(dy, x, precision=ops.GEMM_BF16X6))
+    t_f = timeit(lambda: ops.linear_bwd_weight(dy, x))
+    fl = 2.0 * T * N * K
+    print(f"tokens={T} n={N} k={K} splitk={sk}: bf16p {t_g*1e6:7.1f} us {fl/t_g/1e12:6.1f} TF (+ packs {t_p*1e6:6.1f} us -> "
+          f"{fl/(t_g+t_p)/1e12:6.1f} TF) | fp32 split {t_f*1e6:7.1f} us {fl/t_f/1e12:6.1f} TF | bf16x6 {t_x*1e6:7.1f} us "
+          f"{fl/t_x/1e12:6.1f} TF", flush=True)

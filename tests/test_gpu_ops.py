@@ -600,3 +600,56 @@ def test_gemm_bf16_panel(ops, M, N, K):
         dx_ref = (dY.bfloat16().double() @ Wb) * pr.grad
         dx, _ = ops.gemm_bf16p(ops.bf16_pack_rows(dY.cuda()), pk.bufs[1], M, K, N, act=1, mode=ops.EPI_DACT, aux=aux.cuda())
         assert_close(dx, dx_ref, "dgrad * gelu'", rtol=2e-5, atol_scale=2e-5)
+
+
+@pytest.mark.parametrize("M,N,K,splitk", [(1024, 512, 2048, None), (256, 256, 4096, 4), (1536, 768, 1000 * 32, None),
+                                          (96, 256, 96, 1), (512, 256, 2048 + 32, 3)])
+def test_gemm_bf16_panel_wgrad_splitk(ops, M, N, K, splitk):
+    """weight-gradient form of the bf16 panel GEMM: dW[n, k] = dy^T x with BOTH operands packed transposed (the GEMM's
+    k-dimension = tokens) and split-K over it (fixed-order reduction: deterministic); ragged last split"""
+    dy, x = rnd(K, M, seed=1), rnd(K, N, seed=2)                           # [tokens, features]
+    ref = dy.bfloat16().double().t() @ x.bfloat16().double()
+    dyp, xp = ops.bf16_pack_rows(dy.cuda(), trans=True), ops.bf16_pack_rows(x.cuda(), trans=True)
+    # the transposed pack is the row pack of the transposed matrix
+    assert torch.equal(dyp, ops.bf16_pack_rows(dy.t().contiguous().cuda()))
+    out = torch.full((M, N), float("nan"), device="cuda")
+    dw, _ = ops.gemm_bf16p(dyp, xp, M, N, K, out=out, splitk=splitk)
+    assert dw.data_ptr() == out.data_ptr()
+    assert_close(dw, ref, "dW", rtol=3e-5, atol_scale=3e-5)
+    dw2, _ = ops.gemm_bf16p(dyp, xp, M, N, K, splitk=splitk)
+    assert torch.equal(dw, dw2), "split-K reduction must be deterministic"
+
+
+def test_bf16_panel_model_step_matches_bf16_split_path(ops, monkeypatch):
+    """channel-MLP precision 'bf16' routes fc1 / fc2 forward, data and weight gradients through csrc/gemm_bf16p.hip when
+    the shapes allow it (E, mlp hidden multiples of 256).  Same arithmetic as the generic plain-bf16 GEMM (operands
+    rounded to bf16, fp32 accumulation) -> outputs and gradients agree to accumulation-order level, and sit within the
+    bf16 bound of the fp32 model."""
+    from dpot_amd import DPOTNet
+    kw = dict(R.MINI, embed_dim=256, out_layer_dim=32, depth=2, mlp_ratio=1, n_blocks=4)
+    cfg = R.DPOTConfig(**kw)
+    x = R.recipe_input((2, cfg.img_size, cfg.img_size, cfg.in_timesteps, cfg.in_channels), salt=9).cuda()
+
+    def run(prec, panel):
+        monkeypatch.setenv("DPOT_BF16_PANEL", "1" if panel else "0")
+        m = DPOTNet(**kw).cuda()
+        m.load_state_dict(R.recipe_state_dict(cfg, salt=4))
+        ops.set_mlp_precision(prec)
+        try:
+            y, _ = m(x)
+            (y ** 2).sum().backward()
+            used = getattr(m, "_panel_packs_bf16", None) is not None
+        finally:
+            ops.set_mlp_precision(None)
+        return y.detach(), {n: p.grad.clone() for n, p in m.named_parameters() if p.grad is not None}, used
+
+    y32, g32, _ = run(None, False)
+    yb, gb, used_b = run("bf16", False)
+    yp, gp, used_p = run("bf16", True)
+    assert used_p and not used_b
+    rel = lambda a, b: ((a.double() - b.double()).norm() / b.double().norm().clamp_min(1e-30)).item()
+    assert rel(yp, yb) < 2e-4, rel(yp, yb)
+    assert 1e-6 < rel(yp, y32) < 2e-2
+    for n in g32:
+        assert rel(gp[n], gb[n]) < 3e-3, (n, rel(gp[n], gb[n]))
+        assert rel(gp[n], g32[n]) < 5e-2, (n, rel(gp[n], g32[n]))
