@@ -118,6 +118,12 @@ SIGNATURES = {
     "dpot_gemm_bf16p_supported": (c_i, [c_i, c_i, c_i]),
     "dpot_gemm_bf16p": (c_i, [c_fp, c_fp, c_fp, c_fp, c_i, c_fp, c_i, c_fp, c_i, c_fp, c_i] + [c_i] * 6 + [c_fp, c_fp]),
     "dpot_gemm_bf16p_splitk": (c_i, [c_i, c_i, c_i]),
+    "dpot_embed_supported": (c_i, [c_i] * 5),
+    "dpot_embed_wfrag_elems": (c_i, []),
+    "dpot_embed_pack_w0": (c_i, [c_fp, c_i, c_fp, c_fp]),
+    "dpot_embed_fwd": (c_i, [c_fp] * 5 + [c_i] * 6 + [c_fp]),
+    "dpot_embed_wgrad_ws_elems": (c_i, [c_i] * 3),
+    "dpot_embed_wgrad": (c_i, [c_fp] * 4 + [c_i] * 7 + [c_fp]),
     "dpot_gemm_panel_supported": (c_i, [c_i, c_i, c_i]),
     "dpot_gemm_panel": (c_i, [c_fp, c_i, c_fp, c_fp, c_fp, c_i, c_fp, c_i, c_fp, c_i, c_fp, c_i] + [c_i] * 5 + [c_fp]),
 }

@@ -202,17 +202,35 @@ __global__ __launch_bounds__(256) void chan_sumsq_part_kernel(const float* __res
   const int s0 = ch * per, s1 = min(S, s0 + per);
   const float* xb = x + (long long)b * S * C;
   if (C == 4 && (((uintptr_t)xb) & 15u) == 0) {   // the DPOT case: one float4 = the 4 channels of a grid point
-    float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
-    for (int s = s0 + threadIdx.x; s < s1; s += 256) {
-      const float4 v = reinterpret_cast<const float4*>(xb)[s];
+    float4 a = make_float4(0.f, 0.f, 0.f, 0.f), a1 = a, a2 = a, a3 = a;
+    const float4* x4 = reinterpret_cast<const float4*>(xb);
+    int s = s0 + threadIdx.x;
+    for (; s + 768 < s1; s += 1024) {      // four loads in flight per thread (one at a time is latency bound: 0.9 TB/s)
+      const float4 v = x4[s], v1 = x4[s + 256], v2 = x4[s + 512], v3 = x4[s + 768];
+      a.x = fmaf(v.x, v.x, a.x); a.y = fmaf(v.y, v.y, a.y); a.z = fmaf(v.z, v.z, a.z); a.w = fmaf(v.w, v.w, a.w);
+      a1.x = fmaf(v1.x, v1.x, a1.x); a1.y = fmaf(v1.y, v1.y, a1.y); a1.z = fmaf(v1.z, v1.z, a1.z); a1.w = fmaf(v1.w, v1.w, a1.w);
+      a2.x = fmaf(v2.x, v2.x, a2.x); a2.y = fmaf(v2.y, v2.y, a2.y); a2.z = fmaf(v2.z, v2.z, a2.z); a2.w = fmaf(v2.w, v2.w, a2.w);
+      a3.x = fmaf(v3.x, v3.x, a3.x); a3.y = fmaf(v3.y, v3.y, a3.y); a3.z = fmaf(v3.z, v3.z, a3.z); a3.w = fmaf(v3.w, v3.w, a3.w);
+    }
+    for (; s < s1; s += 256) {
+      const float4 v = x4[s];
       a.x = fmaf(v.x, v.x, a.x); a.y = fmaf(v.y, v.y, a.y); a.z = fmaf(v.z, v.z, a.z); a.w = fmaf(v.w, v.w, a.w);
     }
-    red[threadIdx.x * 4 + 0] = a.x; red[threadIdx.x * 4 + 1] = a.y;
-    red[threadIdx.x * 4 + 2] = a.z; red[threadIdx.x * 4 + 3] = a.w;
+    a.x = (a.x + a1.x) + (a2.x + a3.x); a.y = (a.y + a1.y) + (a2.y + a3.y);
+    a.z = (a.z + a1.z) + (a2.z + a3.z); a.w = (a.w + a1.w) + (a2.w + a3.w);
+    // fixed-shape reduction (bit-reproducible): xor-butterfly inside each wave, then the 4 wave sums in order
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) {
+      a.x += __shfl_xor(a.x, o); a.y += __shfl_xor(a.y, o); a.z += __shfl_xor(a.z, o); a.w += __shfl_xor(a.w, o);
+    }
+    if ((threadIdx.x & 63) == 0) {
+      const int wv = threadIdx.x >> 6;
+      red[wv * 4 + 0] = a.x; red[wv * 4 + 1] = a.y; red[wv * 4 + 2] = a.z; red[wv * 4 + 3] = a.w;
+    }
     __syncthreads();
     if (threadIdx.x < 4) {
       double t = 0.0;
-      for (int r = 0; r < 256; ++r) t += (double)red[r * 4 + threadIdx.x];   // fixed order
+      for (int r = 0; r < 4; ++r) t += (double)red[r * 4 + threadIdx.x];
       part[((long long)b * nch + ch) * 4 + threadIdx.x] = (float)t;
     }
     return;
@@ -250,10 +268,11 @@ __device__ __forceinline__ float4 philox_normal4(unsigned long long seed, unsign
   const float s = 2.3283064365386963e-10f;              // 2^-32
   const float u0 = fmaf((float)c0, s, 0.5f * s), u1 = (float)c1 * s;
   const float u2 = fmaf((float)c2, s, 0.5f * s), u3 = (float)c3 * s;
-  const float r0 = sqrtf(-2.f * __logf(u0)), r1 = sqrtf(-2.f * __logf(u2));
-  float s0, q0, s1, q1;
-  __sincosf(6.283185307179586f * u1, &s0, &q0);
-  __sincosf(6.283185307179586f * u3, &s1, &q1);
+  // -2 ln u = -2 ln2 * log2 u (v_log_f32); v_sin_f32 / v_cos_f32 take their argument in revolutions, u1 in [0, 1)
+  const float r0 = __builtin_amdgcn_sqrtf(-1.3862943611198906f * __builtin_amdgcn_logf(u0));
+  const float r1 = __builtin_amdgcn_sqrtf(-1.3862943611198906f * __builtin_amdgcn_logf(u2));
+  const float s0 = __builtin_amdgcn_sinf(u1), q0 = __builtin_amdgcn_cosf(u1);
+  const float s1 = __builtin_amdgcn_sinf(u3), q1 = __builtin_amdgcn_cosf(u3);
   return make_float4(r0 * q0, r0 * s0, r1 * q1, r1 * s1);
 }
 
@@ -277,9 +296,31 @@ __global__ __launch_bounds__(256) void noise_axpy_kernel(const float* __restrict
   float* ob = out + b * n;
   if (eps == nullptr) {   // fused generator: no eps tensor is ever written or read (host guarantees n % 4 == 0, 16-B)
     const unsigned long long seed = rng[0], offset = rng[1];
+    const unsigned long long base = (unsigned long long)b * (unsigned long long)(n / 4);
+    if (C == 4) {        // the DPOT case: one float4 = the 4 channels of a grid point (no index arithmetic at all)
+      const float4 sn = make_float4(snorm[0], snorm[1], snorm[2], snorm[3]);
+      // two float4 per thread and trip, both loads issued before the generator (one dependent load per ~200-instruction
+      // trip leaves the kernel latency bound)
+      const long long n4 = n / 4;
+      for (long long q = blockIdx.x * 512ll + threadIdx.x; q < n4; q += (long long)gridDim.x * 512) {
+        const long long q1 = q + 256;
+        const bool two = q1 < n4;
+        const float4 xv = reinterpret_cast<const float4*>(xb)[q];
+        const float4 xw = reinterpret_cast<const float4*>(xb)[two ? q1 : q];
+        const float4 ev = philox_normal4(seed, offset, base + q);
+        reinterpret_cast<float4*>(ob)[q] =
+            make_float4(fmaf(sn.x, ev.x, xv.x), fmaf(sn.y, ev.y, xv.y), fmaf(sn.z, ev.z, xv.z), fmaf(sn.w, ev.w, xv.w));
+        if (two) {
+          const float4 ew = philox_normal4(seed, offset, base + q1);
+          reinterpret_cast<float4*>(ob)[q1] =
+              make_float4(fmaf(sn.x, ew.x, xw.x), fmaf(sn.y, ew.y, xw.y), fmaf(sn.z, ew.z, xw.z), fmaf(sn.w, ew.w, xw.w));
+        }
+      }
+      return;
+    }
     for (long long q = blockIdx.x * 256ll + threadIdx.x; q < n / 4; q += (long long)gridDim.x * 256) {
       const float4 xv = reinterpret_cast<const float4*>(xb)[q];
-      const float4 ev = philox_normal4(seed, offset, (unsigned long long)b * (unsigned long long)(n / 4) + q);
+      const float4 ev = philox_normal4(seed, offset, base + q);
       const int c0 = (int)((q * 4) % C);
       float4 o;
       o.x = fmaf(snorm[c0], ev.x, xv.x);
@@ -483,8 +524,8 @@ static int noise_launch(const float* xx, const float* eps, float* out, float* no
   hipLaunchKernelGGL(chan_sumsq_part_kernel, dim3(nch, B), dim3(256), 0, as_stream(stream), xx, part, S, C, nch, rng);
   int rc = check_launch("chan_sumsq_part_kernel");
   if (rc) return rc;
-  long long g = ((long long)S * C / 4 + 255) / 256;
-  if (g > 128) g = 128;
+  long long g = ((long long)S * C / 4 + 511) / 512;       // 2 float4 per thread (every thread's loads issue up front)
+  if (g > 2048) g = 2048;
   if (g < 1) g = 1;
   hipLaunchKernelGGL(noise_axpy_kernel, dim3((unsigned)g, B), dim3(256), C * sizeof(float), as_stream(stream), xx, eps,
                      (const float*)part, norms, out, noise_scale, S, C, nch, (const unsigned long long*)rng);

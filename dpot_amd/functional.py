@@ -78,7 +78,14 @@ def _sinks(ctx, params, first_index: int):
 
 
 # ======================================================================================================
-def embed_derived(pos, w0, b0, w2, b2, taw, tagamma, tt, T: int):
+def embed_grid_matrix(gx, gy, gt, X: int, Y: int, T: int, Cc: int, P: int):
+    """[tok*T, 3*P*P]: the unit-grid columns of the patch matrix (input channels C..C+2 = x, y, t coordinates,
+    models/dpot.py:356-357) - batch independent, constant for a model"""
+    z = torch.zeros(1, X, Y, T, Cc, dtype=torch.float32, device=gx.device)
+    return ops.patchify(z, gx, gy, gt, P)[:, Cc * P * P:].contiguous()
+
+
+def embed_derived(pos, w0, b0, w2, b2, taw, tagamma, tt, T: int, grid=None):
     """weight-only products of the embed stage (they depend on no activation, so a T_ar-step rollout computes them
     once per optimiser step, see DPOTNet.weights_scope): padded conv weights, pos+bias, the cos-scaled aggregation
     weights and the folded [1x1 conv -> TimeAggregator] matrices V / c described in EmbedFn.forward"""
@@ -99,7 +106,15 @@ def embed_derived(pos, w0, b0, w2, b2, taw, tagamma, tt, T: int):
     wsum = ops.colsum(ws, T, E * E).view(E, E)
     cc = torch.empty(tok, E, dtype=torch.float32, device=dev)
     ops.gemm(posb, wsum, cc, tok, E, E, lda=E, ldb=E, ldc=E)
-    return w0p, b0p, w2p, posb, ws, V, wsum, cc
+    wfrag = bt = None
+    if grid is not None:
+        # implicit-GEMM patch embedding (csrc/embed.hip): data-channel weights in fragment order, and the unit-grid
+        # channels folded into a bias table  bt[(tok,t), n] = b0[n] + sum_{c>=C,i,j} grid[(tok,t),(c,i,j)] w0[n,c,i,j]
+        kg = grid.shape[1]
+        wfrag = ops.embed_pack_w0(w0)
+        bt = torch.empty(grid.shape[0], hidp, dtype=torch.float32, device=dev)
+        ops.gemm(grid, w0p[:, K0 - kg:], bt, grid.shape[0], hidp, kg, transB=True, lda=kg, ldb=K0, ldc=hidp, bias=b0p)
+    return w0p, b0p, w2p, posb, ws, V, wsum, cc, wfrag, bt, grid
 
 
 class EmbedFn(torch.autograd.Function):
@@ -117,11 +132,16 @@ class EmbedFn(torch.autograd.Function):
         dev = x.device
         M = B * tok
 
-        A0 = ops.patchify(x, gx, gy, gt, P)                                    # [M0, K0], rows (b,px,py,t)
+        implicit = derived is not None and derived[8] is not None
+        A0 = None if implicit else ops.patchify(x, gx, gy, gt, P)               # [M0, K0], rows (b,px,py,t)
+        streams.prep_join(dev)        # derived weights of this step (DPOTNet.weights_scope) are ready past this point
         if derived is None:
             derived = embed_derived(pos, w0, b0, w2, b2, taw, tagamma, tt, T)
-        w0p, b0p, w2p, posb, ws, V, wsum, cc = derived
-        Hh, Hpre = ops.linear_fwd(A0, w0p, b0p, act=act, save_pre=True)        # [M0, hidp]
+        w0p, b0p, w2p, posb, ws, V, wsum, cc, wfrag, bt, grid = derived
+        if implicit:   # rows gathered from x inside the kernel; grid channels + bias come from the table bt
+            Hh, Hpre = ops.embed_fwd(x, wfrag, bt, hidp, act)
+        else:
+            Hh, Hpre = ops.linear_fwd(A0, w0p, b0p, act=act, save_pre=True)    # [M0, hidp]
         # Everything after the activation is LINEAR (1x1 conv hid->E, + pos_embed, TimeAggregator), and the hidden
         # width is only hid = out_channels*P+3 (35).  Instead of materialising z[M0, E] (168 MB at B=32) and
         # contracting it with ws[T*E, E] (K = 5120), the 1x1 conv is folded INTO the aggregation weights every step:
@@ -131,14 +151,16 @@ class EmbedFn(torch.autograd.Function):
         # Same result up to fp32 re-association; 15x fewer FLOPs for this stage, and its backward.
         Yl = torch.empty(M, E, dtype=torch.float32, device=dev)
         ops.gemm(Hh, V, Yl, M, E, T * hidp, lda=T * hidp, ldb=E, ldc=E, res=cc, ldres=E, res_mod=tok)
-        ctx.save_for_backward(A0, Hpre, Hh, w0p, w2p, ws, V, wsum, posb, taw, tagamma, tt)
+        ctx.implicit = implicit
+        ctx.save_for_backward(x if implicit else A0, Hpre, Hh, w0p, w2p, ws, V, wsum, posb, taw, tagamma, tt,
+                              grid if implicit else x.new_empty(0))
         ctx.dims = (B, X, Y, T, Cc, P, h, w, hid, hidp, E, K0, act)
         ctx.sinks = _sinks(ctx, (pos, w0, b0, w2, b2, taw, tagamma), 1)
         return Yl.view(B, tok, E)
 
     @staticmethod
     def backward(ctx, dY):
-        A0, Hpre, Hh, w0p, w2p, ws, V, wsum, posb, taw, tagamma, tt = ctx.saved_tensors
+        A0, Hpre, Hh, w0p, w2p, ws, V, wsum, posb, taw, tagamma, tt, grid = ctx.saved_tensors
         B, X, Y, T, Cc, P, h, w, hid, hidp, E, K0, act = ctx.dims
         s_pos, s_w0, s_b0, s_w2, s_b2, s_taw, s_gamma = ctx.sinks
         tok = h * w
@@ -177,13 +199,24 @@ class EmbedFn(torch.autograd.Function):
         else:
             dtaw, dgamma = s_taw.done(dws), None
         # first (PxP / stride P) conv
-        if hid == hidp:
+        if ctx.implicit:
+            # data channels: implicit weight-gradient GEMM over x (A0 holds x here); unit-grid channels: the grid matrix
+            # is batch independent -> contract it with the batch-summed dHpre; both land in the gradient slot itself
+            db0 = s_b0.done(ops.colsum(dHpre, M0, hid, ld=hidp, out=s_b0.out()))
+            dw0 = ops._out(s_w0.out(), (hid, K0), dev)
+            ops.embed_wgrad(A0, dHpre, dw0, hid)
+            dHs = ops.group_rowsum(dHpre, B, tok * T, 1, hidp)                 # [tok*T, hidp]
+            kg = grid.shape[1]
+            ops.gemm(dHs, grid, dw0[:, K0 - kg:], hid, kg, tok * T, transA=True, lda=hidp, ldb=kg, ldc=K0)
+            dw0 = s_w0.done(dw0.view(hid, Cc + 3, P, P))
+        elif hid == hidp:
             dw0p, db0 = ops.linear_bwd_wb(dHpre, A0, None, s_b0.out())          # [hidp, K0] (padded: 16-byte loads)
             db0 = s_b0.done(db0)
         else:
             db0 = s_b0.done(ops.colsum(dHpre, M0, hid, ld=hidp, out=s_b0.out()))
             dw0p = ops.linear_bwd_weight(dHpre, A0)
-        dw0 = s_w0.done(ops.copy2d_pad(dw0p, hidp, K0, hid, K0, out=s_w0.out()).view(hid, Cc + 3, P, P))
+        if not ctx.implicit:
+            dw0 = s_w0.done(ops.copy2d_pad(dw0p, hidp, K0, hid, K0, out=s_w0.out()).view(hid, Cc + 3, P, P))
         dx = None
         if ctx.needs_input_grad[0]:
             dA0 = ops.linear_bwd_data(dHpre, w0p)                              # [M0, K0]

@@ -20,10 +20,10 @@ import os
 import torch
 import torch.nn as nn
 
-from . import _lib, ops
+from . import _lib, ops, streams
 import contextlib
 
-from .functional import AdaINFn, BlockFn, EmbedFn, HeadFn, embed_derived, head_derived
+from .functional import AdaINFn, BlockFn, EmbedFn, HeadFn, embed_derived, embed_grid_matrix, head_derived
 
 ACTIVATIONS = ("gelu", "tanh", "sigmoid", "relu", "leaky_relu", "softplus", "ELU", "silu")
 
@@ -134,21 +134,36 @@ class DPOTNet(nn.Module):
         step on unchanged weights (train_temporal.py:201-219, evaluate.py:193-213).  The caller promises not to
         modify parameters inside the scope; outside a scope every forward derives them afresh."""
         self._scope_depth += 1
+        dev = self.pos_embed.device
         if self._scope_depth == 1:
             self._scope_cache = None
+            if dev.type == "cuda":
+                # weight-only work starts NOW on the prep stream, under the batch-only head of the step (noise, patch
+                # gathering); EmbedFn joins before the first kernel that reads a derived weight
+                with streams.prep(dev):
+                    self._derived_weights()
         try:
             yield self
         finally:
             self._scope_depth -= 1
             if self._scope_depth == 0:
                 self._scope_cache = None
+                if dev.type == "cuda":
+                    streams.prep_join(dev)
 
     def _derived_weights(self):
         if self._scope_depth > 0 and self._scope_cache is not None:
             return self._scope_cache
         pe, ta, ol = self.patch_embed.proj, self.time_agg_layer, self.out_layer
+        grid = None
+        if ops.embed_supported(self.in_channels, self.patch_size, self.in_timesteps, pe[0].weight.shape[0],
+                               self.img_size // self.patch_size):
+            grid = getattr(self, "_embed_grid", None)
+            if grid is None or grid.device != self._gx.device:
+                grid = self._embed_grid = embed_grid_matrix(self._gx, self._gy, self._gt, self.img_size, self.img_size,
+                                                            self.in_timesteps, self.in_channels, self.patch_size)
         emb = embed_derived(self.pos_embed, pe[0].weight, pe[0].bias, pe[2].weight, pe[2].bias, ta.w,
-                            ta.gamma if self.time_agg == "exp_mlp" else None, self._tt, self.in_timesteps)
+                            ta.gamma if self.time_agg == "exp_mlp" else None, self._tt, self.in_timesteps, grid=grid)
         # Wbig = [[Wr, Wi], [-Wi, Wr]] of every AFNO layer + its fragment-block-major forms, ONE launch for all layers
         pk = []
         if len(self.blocks):

@@ -442,6 +442,40 @@ def patchify(x: Tensor, gx: Tensor, gy: Tensor, gt: Tensor, P: int) -> Tensor:
     return A
 
 
+def embed_supported(Cc: int, P: int, T: int, hid: int, w: int) -> bool:
+    """shapes the implicit-GEMM patch embedding covers (csrc/embed.hip); DPOT_EMBED_IMPLICIT=0 disables it"""
+    return (os.environ.get("DPOT_EMBED_IMPLICIT", "1") != "0"
+            and bool(_lib.load().dpot_embed_supported(Cc, P, T, hid, w)))
+
+
+def embed_pack_w0(w0: Tensor) -> Tensor:
+    lib = _lib.load()
+    wf = torch.empty(lib.dpot_embed_wfrag_elems(), dtype=torch.float32, device=w0.device)
+    check(lib.dpot_embed_pack_w0(w0.data_ptr(), w0.shape[0], wf.data_ptr(), _stream()), "embed_pack_w0")
+    return wf
+
+
+def embed_fwd(x: Tensor, wfrag: Tensor, btab: Tensor, hidp: int, act: int) -> Tuple[Tensor, Tensor]:
+    """(Hh, Hpre) [B*tok*T, hidp] of the patch convolution, gathered from x[B,X,Y,T,4] (no patch matrix)"""
+    B, X, Y, T, _ = x.shape
+    M0 = B * (X // 8) * (Y // 8) * T
+    hpre = torch.empty(M0, hidp, dtype=torch.float32, device=x.device)
+    hh = torch.empty_like(hpre)
+    check(_lib.load().dpot_embed_fwd(x.data_ptr(), wfrag.data_ptr(), btab.data_ptr(), hpre.data_ptr(), hh.data_ptr(),
+                                     B, X, Y, T, hidp, act, _stream()), "embed_fwd")
+    return hh, hpre
+
+
+def embed_wgrad(x: Tensor, dhpre: Tensor, dw0: Tensor, hid: int) -> Tensor:
+    """data-channel columns of the patch-conv weight gradient: dw0[hid, K0][:, :4*64] (deterministic two-launch sum)"""
+    lib = _lib.load()
+    B, X, Y, T, _ = x.shape
+    ws = torch.empty(lib.dpot_embed_wgrad_ws_elems(B, X, Y), dtype=torch.float32, device=x.device)
+    check(lib.dpot_embed_wgrad(x.data_ptr(), dhpre.data_ptr(), ws.data_ptr(), dw0.data_ptr(), dw0.stride(0), hid, B, X,
+                               Y, T, dhpre.shape[1], _stream()), "embed_wgrad")
+    return dw0
+
+
 def unpatchify(dA: Tensor, B: int, X: int, Y: int, T: int, Cc: int, P: int) -> Tensor:
     dx = torch.empty(B, X, Y, T, Cc, dtype=torch.float32, device=dA.device)
     check(_lib.load().dpot_unpatchify(dA.data_ptr(), dx.data_ptr(), B, X, Y, T, Cc, P, _stream()), "unpatchify")

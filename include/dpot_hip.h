@@ -197,6 +197,23 @@ int dpot_patchify(const float* x, const float* gx, const float* gy, const float*
 /* adjoint w.r.t. x: dA[(b,px,py,t), (c,i,j)] -> dx[B,X,Y,T,C]  (grid columns ignored) */
 int dpot_unpatchify(const float* dA, float* dx, int B, int X, int Y, int T, int C, int P,
                     dpot_stream_t stream);
+
+/* ---- implicit-GEMM patch embedding (csrc/embed.hip): the P x P / stride-P conv of PatchEmbed.proj[0]
+ * (models/dpot.py:198-202) gathered from x[B, X, Y, T, C] itself - no patch matrix.  Fast path for C = 4, P = 8, T <= 10,
+ * hid <= 48, patch-grid width % 4 == 0 (dpot_embed_supported); other shapes use dpot_patchify + dpot_gemm_f32.
+ *   wfrag: the DATA-channel weights w0[:, 0:C] in MFMA fragment order (dpot_embed_pack_w0, dpot_embed_wfrag_elems floats)
+ *   btab [tok*T, hidp]: bias + the contribution of the three unit-grid channels (batch independent, one small GEMM per
+ *                       optimiser step on the host side)
+ *   fwd:   hpre[(b,px,py,t), n] = sum_{c<C,i,j} x[b,px*P+i,py*P+j,t,c] w0[n,c,i,j] + btab[(px,py,t), n];  hh = act(hpre)
+ *   wgrad: dw0[n*ldw + c*P*P + i*P + j] = sum_rows dhpre[row, n] * x[...]   for n < hid, c < C   (deterministic) */
+int dpot_embed_supported(int C, int P, int T, int hid, int w);
+int dpot_embed_wfrag_elems(void);
+int dpot_embed_pack_w0(const float* w0, int hid, float* wfrag, dpot_stream_t stream);
+int dpot_embed_fwd(const float* x, const float* wfrag, const float* btab, float* hpre, float* hh, int B, int X, int Y,
+                   int T, int hidp, int act, dpot_stream_t stream);
+int dpot_embed_wgrad_ws_elems(int B, int X, int Y);
+int dpot_embed_wgrad(const float* x, const float* dhpre, float* workspace, float* dw0, int ldw, int hid, int B, int X,
+                     int Y, int T, int hidp, dpot_stream_t stream);
 /* z[(b,px,py,i,j), Cc] <-> out[b, px*P+i, py*P+j, Cc]   (ConvTranspose2d k=s=P pixel order) */
 int dpot_pixel_shuffle(const float* z, float* out, int B, int h, int w, int P, int Cc, int inverse,
                        dpot_stream_t stream);
@@ -367,7 +384,7 @@ int64_t dpot_bf16_packed_elems(int rows, int K);      /* bf16 elements of a pack
 /* activations: src fp32 [rows, K] row-major (ld) - or, trans != 0, its transpose stored [K, rows] (weight gradients:
  * rows = features, k = tokens) - -> dst packed bf16 (one HBM pass); K % 16 == 0 */
 int dpot_bf16_pack_rows(const float* src, int ld, int rows, int K, int trans, void* dst, dpot_stream_t stream);
-/* static weights: a DEVICE table of dpot_pack_job (dst = packed bf16), all weights in one launch */
+/* static weights: a DEVICE table of dpot_pack_job entries whose dst is the packed bf16 buffer, all weights in one launch */
 int dpot_bf16_pack_jobs(const dpot_pack_job* jobs_dev, int njobs, int max_elems, dpot_stream_t stream);
 /* C[M,N] (fp32) = epilogue(A @ Wt^T), A = packed [M, K], Wt = packed [N, K]; epilogue as dpot_gemm_panel.
  * Needs N % 256 == 0 and K % 32 == 0 (dpot_gemm_bf16p_supported). */

@@ -32,3 +32,9 @@ for k, v in sorted(c.items(), key=lambda x: -x[1][1]):
 print("GEMM launches with fewer than 256 workgroups:")
 for wgs, us, name in small:
     print(f"   {wgs:4d} WGs {us:7.1f} us  {name}")
+if len(sys.argv) > 2 and sys.argv[2] == "--seq":
+    print("dispatch sequence of the step (start offset, duration, workgroups, kernel):")
+    t0 = step[0][1]
+    for name, s, e, g0, g1, g2, w in step:
+        n = re.sub(r"\(.*$", "", name).replace("void ", "").replace("dpot::", "")
+        print(f"{(s - t0) / 1e3:9.1f} us {(e - s) / 1e3:8.2f} us  wgs={(g0 // max(w, 1)) * g1 * g2:6d}  {n[:90]}")

@@ -653,3 +653,51 @@ def test_bf16_panel_model_step_matches_bf16_split_path(ops, monkeypatch):
     for n in g32:
         assert rel(gp[n], gb[n]) < 3e-3, (n, rel(gp[n], gb[n]))
         assert rel(gp[n], g32[n]) < 5e-2, (n, rel(gp[n], g32[n]))
+
+
+@pytest.mark.parametrize("B,X,Y,T,hid,act", [(2, 32, 32, 10, 35, 1), (3, 16, 64, 4, 35, 1), (1, 24, 32, 7, 16, 2),
+                                             (2, 32, 32, 9, 48, 1), (5, 8, 32, 1, 3, 0)])
+def test_implicit_patch_embed_matches_patch_matrix_path(ops, B, X, Y, T, hid, act):
+    """csrc/embed.hip: the patch conv gathered from x (data channels) + the unit-grid channels folded into a bias table
+    == patchify + GEMM on the materialised patch matrix (the round-1 path, itself pinned to the oracle); forward
+    (Hpre, Hh) and the weight gradient incl. the grid-channel columns.  Ragged row tiles (4T % 16 != 0), T = 1,
+    the widest hidden layer, several groups per workgroup."""
+    from dpot_amd import functional as F
+    Cc, P = 4, 8
+    assert ops.embed_supported(Cc, P, T, hid, Y // P)
+    K0 = (Cc + 3) * P * P
+    hidp = (hid + 3) // 4 * 4
+    x = rnd(B, X, Y, T, Cc, seed=1).cuda()
+    w0 = rnd(hid, Cc + 3, P, P, seed=2, scale=1.0 / math.sqrt(K0)).cuda()
+    b0 = rnd(hid, seed=3, scale=0.2).cuda()
+    gx = torch.linspace(0, 1, X).cuda()
+    gy = torch.linspace(0, 1, Y).cuda()
+    gt = torch.linspace(0, 1, T).cuda()
+    A0 = ops.patchify(x, gx, gy, gt, P)
+    w0p = ops.copy2d_pad(w0, hid, K0, hidp, K0)
+    b0p = ops.copy2d_pad(b0, 1, hid, 1, hidp).view(hidp)
+    Hh_ref, Hpre_ref = ops.linear_fwd(A0, w0p, b0p, act=act, save_pre=True)
+    grid = F.embed_grid_matrix(gx, gy, gt, X, Y, T, Cc, P)
+    assert torch.equal(grid, A0[:grid.shape[0], Cc * P * P:])
+    wfrag = ops.embed_pack_w0(w0)
+    bt = torch.empty(grid.shape[0], hidp, device="cuda")
+    ops.gemm(grid, w0p[:, Cc * P * P:], bt, grid.shape[0], hidp, grid.shape[1], transB=True, lda=grid.shape[1], ldb=K0,
+             ldc=hidp, bias=b0p)
+    Hh, Hpre = ops.embed_fwd(x, wfrag, bt, hidp, act)
+    ref64 = A0.double() @ w0p.double().t() + b0p.double()
+    assert_close(Hpre, ref64, "Hpre vs fp64", rtol=2e-5, atol_scale=2e-6)
+    assert_close(Hpre, Hpre_ref, "Hpre vs patch-matrix path", rtol=2e-5, atol_scale=2e-6)
+    assert_close(Hh[:, :hid], Hh_ref[:, :hid], "Hh", rtol=2e-5, atol_scale=2e-6)
+    # weight gradient
+    dH = rnd(A0.shape[0], hidp, seed=5).cuda()
+    dw_ref = dH.double().t() @ A0.double()                              # [hidp, K0]
+    dw0 = torch.full((hid, K0), float("nan"), device="cuda")
+    ops.embed_wgrad(x, dH, dw0, hid)
+    tokT = grid.shape[0]
+    dHs = ops.group_rowsum(dH, B, tokT, 1, hidp)
+    kg = grid.shape[1]
+    ops.gemm(dHs, grid, dw0[:, K0 - kg:], hid, kg, tokT, transA=True, lda=hidp, ldb=kg, ldc=K0)
+    assert_close(dw0, dw_ref[:hid], "dW0 (data + grid columns)", rtol=3e-5, atol_scale=3e-6)
+    dw0b = torch.empty_like(dw0)
+    ops.embed_wgrad(x, dH, dw0b, hid)
+    assert torch.equal(dw0b[:, :Cc * P * P], dw0[:, :Cc * P * P]), "implicit wgrad must be deterministic"
