@@ -112,11 +112,11 @@ SIGNATURES = {
     "dpot_window_slide_bwd": (c_i, [c_fp] * 3 + [c_i64] + [c_i] * 3 + [c_fp]),
     "dpot_resize_pad_window": (c_i, [c_fp, c_i, c_fp, c_fp] + [c_i] * 4 + [c_fp]),
     "dpot_panel_pack_weights": (c_i, [c_fp, c_i, c_i, c_fp]),
-    "dpot_bf16_packed_elems": (c_i64, [c_i, c_i]),
-    "dpot_bf16_pack_rows": (c_i, [c_fp, c_i, c_i, c_i, c_i, c_fp, c_fp]),
-    "dpot_bf16_pack_jobs": (c_i, [c_fp, c_i, c_i, c_fp]),
+    "dpot_bf16_packed_elems": (c_i64, [c_i, c_i, c_i]),
+    "dpot_bf16_pack_rows": (c_i, [c_fp, c_i, c_i, c_i, c_i, c_i, c_fp, c_fp]),
+    "dpot_bf16_pack_jobs": (c_i, [c_fp, c_i, c_i, c_i, c_fp]),
     "dpot_gemm_bf16p_supported": (c_i, [c_i, c_i, c_i]),
-    "dpot_gemm_bf16p": (c_i, [c_fp, c_fp, c_fp, c_fp, c_i, c_fp, c_i, c_fp, c_i, c_fp, c_i] + [c_i] * 6 + [c_fp, c_fp]),
+    "dpot_gemm_bf16p": (c_i, [c_fp, c_fp, c_fp, c_fp, c_i, c_fp, c_i, c_fp, c_i, c_fp, c_i] + [c_i] * 7 + [c_fp, c_fp]),
     "dpot_gemm_bf16p_splitk": (c_i, [c_i, c_i, c_i]),
     "dpot_embed_supported": (c_i, [c_i] * 5),
     "dpot_embed_wfrag_elems": (c_i, []),

@@ -202,17 +202,191 @@ __global__ __launch_bounds__(64 * (8 + PB_NLOAD)) void gemm_bf16p_kernel(const B
   epi_fragment(p.e, 1, 0, m0 + 32, n0 + 32, acc[1][1], stage, lane);
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// bf16x6: the fp32-accurate form.  Operands packed as THREE bf16 planes (x = x1 + x2 + x3, 8 significand bits each, see
+// gemm_split.h), block (32 rows x 16 k) = 3 KiB = plane-major 3 x 1 KiB; six of the nine plane products are accumulated
+// (x1y1, x1y2, x2y1, x2y2, x1y3, x3y1; the dropped ones are < 2^-24 relative).  Same tile / wave grid as above, but
+//   * 16-k slabs (36 KiB: 12 A + 24 W blocks), ring of three, one barrier per slab;
+//   * no loader waves: the fragments of a slab are 12 x ds_read_b128 = 48 VGPRs, double buffered 96 + 64 accumulators -
+//     more than the 168 registers a 12-wave workgroup leaves per wave - so the 8 compute waves (256 registers each) issue
+//     the LDS-DMA themselves: 5 one-KiB pieces per wave and slab (4 waves re-load a piece twice to keep the per-wave
+//     count, and with it the `vmcnt` immediate, uniform), three slabs ahead;
+//   * 24 MFMAs (32x32x16 bf16) per wave and slab against 12 fragment reads: the matrix pipe is the bound
+//     (2.5 PF / 6 = 417 TFLOP/s fp32-equivalent).
+// ---------------------------------------------------------------------------------------------------------------------
+constexpr int X6_SLABB = (PB_ROWT + PB_COLT) * 3 * 1024;     // bytes of one 16-k slab: 36 KiB
+constexpr int X6_NI = 5;                                      // DMA instructions per wave and slab
+
+__global__ __launch_bounds__(512) void gemm_bf16x6p_kernel(const Bf16pArgs p) {
+  __shared__ __attribute__((aligned(16))) unsigned char lds[3 * X6_SLABB];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int ks16 = p.K >> 4;                        // 16-k blocks per row tile
+  const int zs = blockIdx.y;
+  const int slab0 = zs * p.slabs_per_split;         // in 16-k slabs
+  int nslab = ks16 - slab0;
+  nslab = nslab < p.slabs_per_split ? nslab : p.slabs_per_split;
+
+  const int ntiles = p.tilesM * p.tilesN;
+  int tile;
+  {
+    const int bid = blockIdx.x, xcd = bid & 7, slot = bid >> 3;
+    const int q = ntiles >> 3, r = ntiles & 7;
+    tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + slot;
+  }
+  const int tn = tile / p.tilesM, tm = tile - tn * p.tilesM;
+  const int rt0 = tm * PB_ROWT, ct0 = tn * PB_COLT;
+  const int mtiles = (p.M + 31) >> 5;
+
+  auto bar = [&]() __attribute__((always_inline)) {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+  };
+
+  // this wave's DMA pieces of a slab: piece b = (unit u = b / 3, plane b % 3); units 0-3: A row tiles, 4-11: W col tiles
+  const unsigned short* src[X6_NI];
+  int dst[X6_NI];
+#pragma unroll
+  for (int n = 0; n < X6_NI; ++n) {
+    int b = wave + 8 * n;
+    if (b >= 36) b -= 32;                            // waves 4-7: a second copy of their first piece (uniform count)
+    const int u = b / 3, pl = b - 3 * u;
+    if (u < PB_ROWT) {
+      int rt = rt0 + u;
+      rt = rt < mtiles ? rt : mtiles - 1;
+      src[n] = p.A + (((long long)rt * ks16 + slab0) * 3 + pl) * 512 + lane * 8;
+    } else {
+      src[n] = p.W + (((long long)(ct0 + u - PB_ROWT) * ks16 + slab0) * 3 + pl) * 512 + lane * 8;
+    }
+    dst[n] = b * 1024;
+  }
+  auto issue = [&](int t, int ring) __attribute__((always_inline)) {
+#pragma unroll
+    for (int n = 0; n < X6_NI; ++n) bglds16(src[n] + (long long)t * 1536, lds + ring * X6_SLABB + dst[n]);
+  };
+
+  const int wm = wave >> 2, wn = wave & 3;
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  auto read_frags = [&](bf16x8_t (&a)[2][3], bf16x8_t (&b)[2][3], int ring) __attribute__((always_inline)) {
+    const unsigned char* base = lds + ring * X6_SLABB + lane * 16;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int pl = 0; pl < 3; ++pl)
+        a[i][pl] = *reinterpret_cast<const bf16x8_t*>(base + ((2 * wm + i) * 3 + pl) * 1024);
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int pl = 0; pl < 3; ++pl)
+        b[j][pl] = *reinterpret_cast<const bf16x8_t*>(base + ((PB_ROWT + 2 * wn + j) * 3 + pl) * 1024);
+  };
+  auto mma = [&](const bf16x8_t (&a)[2][3], const bf16x8_t (&b)[2][3]) __attribute__((always_inline)) {
+    // smallest terms first; every accumulator sees the same order on every slab (deterministic)
+    constexpr int PA[6] = {2, 0, 1, 1, 0, 0};
+    constexpr int PBn[6] = {0, 2, 1, 0, 1, 0};
+#pragma unroll
+    for (int t = 0; t < 6; ++t)
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][PA[t]], b[j][PBn[t]], acc[i][j], 0, 0, 0);
+  };
+
+  bf16x8_t aA[2][3], bA[2][3], aB[2][3], bB[2][3];
+  issue(0, 0);
+  if (nslab > 1) issue(1, 1);
+  if (nslab > 2) issue(2, 2);
+  if (nslab > 2) bwait_vm<2 * X6_NI>(); else if (nslab > 1) bwait_vm<X6_NI>(); else bwait_vm<0>();
+  bar();                                               // P: slab 0 landed everywhere
+  read_frags(aA, bA, 0);
+  {
+    int ring = 0;                                      // ring slot of slab t
+    auto step = [&](int t, bf16x8_t (&ca)[2][3], bf16x8_t (&cb)[2][3], bf16x8_t (&na)[2][3], bf16x8_t (&nb)[2][3])
+        __attribute__((always_inline)) {
+      // own DMA still in flight here: slabs t+1 and t+2 (if they exist); slab t+1 must have landed before B_t
+      if (t + 2 < nslab) bwait_vm<X6_NI>(); else bwait_vm<0>();
+      bar();                                           // B_t: slab t+1 landed; every wave holds slab t in registers
+      if (t + 3 < nslab) issue(t + 3, ring);           // slot of slab t is free
+      const int rn = ring == 2 ? 0 : ring + 1;
+      if (t + 1 < nslab) read_frags(na, nb, rn);
+      mma(ca, cb);
+      ring = rn;
+    };
+#pragma unroll 1
+    for (int t = 0; t < nslab; t += 2) {
+      step(t, aA, bA, aB, bB);
+      if (t + 1 < nslab) step(t + 1, aB, bB, aA, bA);
+    }
+  }
+  bar();                                               // S: the ring becomes epilogue staging
+
+  float* stage = reinterpret_cast<float*>(lds) + wave * (32 * EPI_LD);
+  const int m0 = (rt0 + 2 * wm) * 32, n0 = (ct0 + 2 * wn) * 32;
+  if (p.splits > 1) {
+    float* ws = p.ws + (long long)zs * p.M * p.N;
+    const int li = lane & 31, kh = lane >> 5;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const int n = n0 + 32 * j + li;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int m = m0 + 32 * i + 4 * kh + (r & 3) + 8 * (r >> 2);
+          if (m < p.M && n < p.N) ws[(long long)m * p.N + n] = acc[i][j][r];
+        }
+      }
+    return;
+  }
+  epi_fragment(p.e, 1, 0, m0, n0, acc[0][0], stage, lane);
+  epi_fragment(p.e, 1, 0, m0, n0 + 32, acc[0][1], stage, lane);
+  epi_fragment(p.e, 1, 0, m0 + 32, n0, acc[1][0], stage, lane);
+  epi_fragment(p.e, 1, 0, m0 + 32, n0 + 32, acc[1][1], stage, lane);
+}
+
 __device__ __forceinline__ unsigned pack2(float lo, float hi) {
   f32x2_t v = {lo, hi};
   bf16x2_t r = __builtin_convertvector(v, bf16x2_t);   // v_cvt_pk_bf16_f32 (round to nearest even)
   return __builtin_bit_cast(unsigned, r);
 }
 
-// activations: src fp32 [R, K] row-major (ld) -> [ceil(R/32)][K/16][64 chunks][8 bf16]; rows past R are zero.
+// 8 consecutive k of one row -> NPL packed planes (16 bytes each); plane p holds bf16(x - sum of the planes before it)
+template <int NPL>
+__device__ __forceinline__ void pack8(const float (&v)[8], uint4 (&o)[NPL]) {
+  float r[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) r[e] = v[e];
+#pragma unroll
+  for (int pl = 0; pl < NPL; ++pl) {
+    unsigned w[4];
+#pragma unroll
+    for (int h = 0; h < 4; ++h) {
+      w[h] = pack2(r[2 * h], r[2 * h + 1]);
+      if (pl + 1 < NPL) {
+        r[2 * h] -= __uint_as_float(w[h] << 16);
+        r[2 * h + 1] -= __uint_as_float(w[h] & 0xffff0000u);
+      }
+    }
+    o[pl] = make_uint4(w[0], w[1], w[2], w[3]);
+  }
+}
+
+// activations: src fp32 [R, K] row-major (ld) -> [ceil(R/32)][K/16][NPL planes][64 chunks][8 bf16]; rows past R are zero.
 // one thread = one 16-byte chunk (row, 8 consecutive k); a wave covers 4 rows x 128 k (512 B per row: full lines)
 // trans: the logical operand is the TRANSPOSE of the stored matrix (src [K, R] row-major): element (row, k) =
 // src[k*ld + row] (weight gradients: rows = features, k = tokens); adjacent threads then take adjacent rows, so each of
 // a thread's 8 loads is part of a contiguous row segment of the source
+template <int NPL>
 __global__ __launch_bounds__(256) void bf16_pack_rows_kernel(const float* __restrict__ src, int ld, int R, int K,
                                                              uint4* __restrict__ dst, long long nchunks, int trans) {
   const int kc_per_row = K >> 3;
@@ -226,25 +400,30 @@ __global__ __launch_bounds__(256) void bf16_pack_rows_kernel(const float* __rest
       kc = (int)(c % kc_per_row);
       row = (int)(c / kc_per_row);
     }
-    uint4 o = make_uint4(0u, 0u, 0u, 0u);
+    float v[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = 0.f;
     if (row < R) {
       if (trans) {
-        float v[8];
 #pragma unroll
         for (int e = 0; e < 8; ++e) v[e] = src[(long long)(8 * kc + e) * ld + row];
-        o = make_uint4(pack2(v[0], v[1]), pack2(v[2], v[3]), pack2(v[4], v[5]), pack2(v[6], v[7]));
       } else {
         const float4 x0 = *reinterpret_cast<const float4*>(src + (long long)row * ld + 8 * kc);
         const float4 x1 = *reinterpret_cast<const float4*>(src + (long long)row * ld + 8 * kc + 4);
-        o = make_uint4(pack2(x0.x, x0.y), pack2(x0.z, x0.w), pack2(x1.x, x1.y), pack2(x1.z, x1.w));
+        v[0] = x0.x; v[1] = x0.y; v[2] = x0.z; v[3] = x0.w; v[4] = x1.x; v[5] = x1.y; v[6] = x1.z; v[7] = x1.w;
       }
     }
+    uint4 o[NPL];
+    pack8<NPL>(v, o);
     // block (row tile, 16-k slab kc>>1), chunk (row & 31) + 32 * (kc & 1)
-    dst[((long long)(row >> 5) * (K >> 4) + (kc >> 1)) * 64 + (row & 31) + 32 * (kc & 1)] = o;
+    uint4* d = dst + (((long long)(row >> 5) * (K >> 4) + (kc >> 1)) * NPL) * 64 + (row & 31) + 32 * (kc & 1);
+#pragma unroll
+    for (int pl = 0; pl < NPL; ++pl) d[pl * 64] = o[pl];
   }
 }
 
 // weights (job table in device memory): logical Wt [rows, K] (row n, k) = trans ? src[k*ld + n] : src[n*ld + k]
+template <int NPL>
 __global__ __launch_bounds__(256) void bf16_pack_jobs_kernel(const dpot_pack_job* __restrict__ jobs) {
   const dpot_pack_job job = jobs[blockIdx.y];
   const int kc_per_row = job.K >> 3;
@@ -265,8 +444,11 @@ __global__ __launch_bounds__(256) void bf16_pack_jobs_kernel(const dpot_pack_job
       const int k = 8 * kc + e;
       v[e] = job.trans ? job.src[(long long)k * job.ld + row] : job.src[(long long)row * job.ld + k];
     }
-    dst[((long long)(row >> 5) * (job.K >> 4) + (kc >> 1)) * 64 + (row & 31) + 32 * (kc & 1)] =
-        make_uint4(pack2(v[0], v[1]), pack2(v[2], v[3]), pack2(v[4], v[5]), pack2(v[6], v[7]));
+    uint4 o[NPL];
+    pack8<NPL>(v, o);
+    uint4* d = dst + (((long long)(row >> 5) * (job.K >> 4) + (kc >> 1)) * NPL) * 64 + (row & 31) + 32 * (kc & 1);
+#pragma unroll
+    for (int pl = 0; pl < NPL; ++pl) d[pl * 64] = o[pl];
   }
 }
 
@@ -278,26 +460,38 @@ extern "C" int dpot_gemm_bf16p_supported(int M, int N, int K) {
   return M > 0 && N > 0 && N % 256 == 0 && K >= 32 && K % 32 == 0 ? 1 : 0;
 }
 
-extern "C" int64_t dpot_bf16_packed_elems(int rows, int K) { return (int64_t)((rows + 31) / 32) * 32 * K; }
+extern "C" int64_t dpot_bf16_packed_elems(int rows, int K, int planes) {
+  return (int64_t)((rows + 31) / 32) * 32 * K * (planes == 3 ? 3 : 1);
+}
 
-extern "C" int dpot_bf16_pack_rows(const float* src, int ld, int rows, int K, int trans, void* dst,
+extern "C" int dpot_bf16_pack_rows(const float* src, int ld, int rows, int K, int trans, int planes, void* dst,
                                    dpot_stream_t stream) {
   DPOT_REQUIRE(src && dst && rows > 0 && K > 0 && K % 16 == 0 && aligned16(dst), "bf16_pack_rows: bad argument (K %% 16)");
+  DPOT_REQUIRE(planes == 1 || planes == 3, "bf16_pack_rows: planes must be 1 (plain bf16) or 3 (bf16x6 split)");
   DPOT_REQUIRE(trans ? ld >= rows : (ld >= K && ld % 4 == 0 && aligned16(src)),
                "bf16_pack_rows: bad leading dimension / alignment");
   const long long nchunks = (long long)((rows + 31) / 32) * 32 * (K >> 3);
   long long g = (nchunks + 255) / 256;
   if (g > 8192) g = 8192;
-  hipLaunchKernelGGL(bf16_pack_rows_kernel, dim3((unsigned)g), dim3(256), 0, as_stream(stream), src, ld, rows, K,
-                     reinterpret_cast<uint4*>(dst), nchunks, trans);
+  if (planes == 3)
+    hipLaunchKernelGGL(bf16_pack_rows_kernel<3>, dim3((unsigned)g), dim3(256), 0, as_stream(stream), src, ld, rows, K,
+                       reinterpret_cast<uint4*>(dst), nchunks, trans);
+  else
+    hipLaunchKernelGGL(bf16_pack_rows_kernel<1>, dim3((unsigned)g), dim3(256), 0, as_stream(stream), src, ld, rows, K,
+                       reinterpret_cast<uint4*>(dst), nchunks, trans);
   return check_launch("bf16_pack_rows_kernel");
 }
 
-extern "C" int dpot_bf16_pack_jobs(const dpot_pack_job* jobs_dev, int njobs, int max_elems, dpot_stream_t stream) {
+extern "C" int dpot_bf16_pack_jobs(const dpot_pack_job* jobs_dev, int njobs, int max_elems, int planes,
+                                   dpot_stream_t stream) {
   DPOT_REQUIRE(jobs_dev && njobs > 0 && njobs <= 65535 && max_elems > 0, "bf16_pack_jobs: bad argument");
+  DPOT_REQUIRE(planes == 1 || planes == 3, "bf16_pack_jobs: planes must be 1 or 3");
   long long g = ((long long)max_elems / 8 + 255) / 256;
   if (g > 2048) g = 2048;
-  hipLaunchKernelGGL(bf16_pack_jobs_kernel, dim3((unsigned)g, njobs), dim3(256), 0, as_stream(stream), jobs_dev);
+  if (planes == 3)
+    hipLaunchKernelGGL(bf16_pack_jobs_kernel<3>, dim3((unsigned)g, njobs), dim3(256), 0, as_stream(stream), jobs_dev);
+  else
+    hipLaunchKernelGGL(bf16_pack_jobs_kernel<1>, dim3((unsigned)g, njobs), dim3(256), 0, as_stream(stream), jobs_dev);
   return check_launch("bf16_pack_jobs_kernel");
 }
 
@@ -322,8 +516,9 @@ extern "C" int dpot_gemm_bf16p_splitk(int M, int N, int K) {
 
 extern "C" int dpot_gemm_bf16p(const void* Apacked, const void* Wpacked, const float* bias, const float* aux, int ldaux,
                                const float* res, int ldres, float* pre, int ldpre, float* C, int ldc, int M, int N, int K,
-                               int act, int epi_mode, int splitk, float* workspace, dpot_stream_t stream) {
+                               int act, int epi_mode, int planes, int splitk, float* workspace, dpot_stream_t stream) {
   DPOT_REQUIRE(Apacked && Wpacked && C, "gemm_bf16p: null operand");
+  DPOT_REQUIRE(planes == 1 || planes == 3, "gemm_bf16p: planes must be 1 (plain bf16) or 3 (bf16x6, fp32-accurate)");
   DPOT_REQUIRE(dpot_gemm_bf16p_supported(M, N, K), "gemm_bf16p: unsupported shape M=%d N=%d K=%d (N %% 256, K %% 32)", M, N, K);
   DPOT_REQUIRE(epi_mode == DPOT_EPI_LINEAR || epi_mode == DPOT_EPI_ACT || (epi_mode == DPOT_EPI_DACT && aux),
                "gemm_bf16p: bad epilogue mode");
@@ -346,15 +541,19 @@ extern "C" int dpot_gemm_bf16p(const void* Apacked, const void* Wpacked, const f
   e.res = res; e.ldres = ldres; e.res_div = 0; e.res_mod = 0; e.sRes = 0;
   e.act = act; e.mode = epi_mode; e.accumulate = 0;
   e.M = M; e.N = N;
-  const int nslab = K >> 5;
+  const int nslab = planes == 3 ? K >> 4 : K >> 5;     // the bf16x6 kernel steps K in 16-k slabs
   p.splits = splitk > 1 ? splitk : 1;
   DPOT_REQUIRE(p.splits == 1 || workspace != nullptr, "gemm_bf16p: split-K needs a workspace of splitk*M*N floats");
   DPOT_REQUIRE(p.splits <= nslab && p.splits <= 65535, "gemm_bf16p: too many splits");
   p.slabs_per_split = (nslab + p.splits - 1) / p.splits;
   p.splits = (nslab + p.slabs_per_split - 1) / p.slabs_per_split;       // no empty split
   p.ws = workspace;
-  hipLaunchKernelGGL(gemm_bf16p_kernel, dim3((unsigned)(p.tilesM * p.tilesN), p.splits), dim3(64 * (8 + PB_NLOAD)), 0,
-                     as_stream(stream), p);
+  if (planes == 3)
+    hipLaunchKernelGGL(gemm_bf16x6p_kernel, dim3((unsigned)(p.tilesM * p.tilesN), p.splits), dim3(512), 0,
+                       as_stream(stream), p);
+  else
+    hipLaunchKernelGGL(gemm_bf16p_kernel, dim3((unsigned)(p.tilesM * p.tilesN), p.splits), dim3(64 * (8 + PB_NLOAD)), 0,
+                       as_stream(stream), p);
   int rc = check_launch("gemm_bf16p_kernel");
   if (rc != DPOT_OK || p.splits == 1) return rc;
   const long long total = (long long)M * N;

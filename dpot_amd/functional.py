@@ -14,6 +14,7 @@ kernels, and the data-parallel reducer is notified the moment a parameter's grad
 """
 from __future__ import annotations
 
+import os
 from typing import Optional
 
 import torch
@@ -225,19 +226,46 @@ class EmbedFn(torch.autograd.Function):
 
 
 # ======================================================================================================
+X6_MIN_FLOP = 3.0e9      # 'auto': GEMMs below this stay on the native fp32 kernels (launch / pack overheads dominate)
+
+
+def mlp_pack_kind(E: int, mh: int, M: Optional[int] = None) -> Optional[str]:
+    """which pre-packed-weight kernel family the channel MLP of a model uses under the current precision settings:
+    'bf16' (opt-in reduced precision), 'bf16x6' (fp32-accurate operand split; precision 'bf16x6', or 'auto' for GEMMs of
+    >= 3 GFLOP), 'f32' (csrc/gemm_panel.hip) or None (generic kernels)"""
+    eff = ops.effective_mlp_precision()
+    Mq = 128 if M is None else M          # M = None: the model deriving its packs before it has seen a batch
+    bf_ok = ops.gemm_bf16p_supported(Mq, mh, E) and ops.gemm_bf16p_supported(Mq, E, mh)
+    if os.environ.get("DPOT_BF16_PANEL", "1") != "0" and bf_ok:
+        if eff == ops.GEMM_BF16:
+            return "bf16"
+        # the three-plane panel kernel is OPT-IN (DPOT_X6_PANEL=1): measured on MI355X it reaches 154-190 TFLOP/s
+        # fp32-equivalent against 147-178 for the register-staged split kernel (gemm_split.h) - both sit at 70-80 % of what
+        # the power-limited bf16 matrix pipe sustains (~1.4-1.5 PF / 6, profiles/r02_mfma_bf16_peak.txt) - but needs a
+        # 10 B/element pack pass per activation operand that costs more than it gains (profiles/r02_bf16x6p_bench.txt)
+        if os.environ.get("DPOT_X6_PANEL", "0") == "1" and (
+                eff == ops.GEMM_BF16X6 or (eff == ops.GEMM_AUTO and (M is None or 2.0 * M * mh * E >= X6_MIN_FLOP))):
+            return "bf16x6"
+    if eff == ops.GEMM_F32 and ops.panel_enabled() and ops.gemm_panel_supported(Mq, mh, E) \
+            and ops.gemm_panel_supported(Mq, E, mh):
+        return "f32"
+    return None
+
+
 def _mlp_panel_mode(mlp_pk, M, E, mh, mp) -> int:
     """which pre-packed-weight kernel the channel MLP runs on: 0 = none (generic split GEMM), 1 = fp32 panel
-    (csrc/gemm_panel.hip), 2 = bf16 panel (csrc/gemm_bf16p.hip; the packs are bf16 then)"""
+    (csrc/gemm_panel.hip), 2 = bf16 panel (csrc/gemm_bf16p.hip; plain bf16 or the fp32-accurate bf16x6 split, by the
+    packs' kind).  The packs were made for the precision that was current when the weights were derived; a different
+    precision at call time falls back to the generic kernels."""
     if mlp_pk is None:
         return 0
-    if mlp_pk[0].dtype == torch.bfloat16:
-        eff = mp if mp is not None else ops.effective_mlp_precision()
-        ok = (eff == ops.GEMM_BF16 and ops.gemm_bf16p_supported(M, mh, E) and ops.gemm_bf16p_supported(M, E, mh)
-              and ops.gemm_bf16p_supported(E, mh, M) and ops.gemm_bf16p_supported(mh, E, M))
-        return 2 if ok else 0
-    ok = (mp in (None, ops.GEMM_F32) and ops.panel_enabled()
-          and ops.gemm_panel_supported(M, mh, E) and ops.gemm_panel_supported(M, E, mh))
-    return 1 if ok else 0
+    kind = getattr(mlp_pk, "kind", "f32")
+    if kind != mlp_pack_kind(E, mh, M):
+        return 0
+    if kind == "f32":
+        return 1
+    ok = ops.gemm_bf16p_supported(E, mh, M) and ops.gemm_bf16p_supported(mh, E, M)     # weight-gradient shapes
+    return 2 if ok else 0
 
 
 def _block_parts(x, n1w, n1b, n2w, n2b, f1w, f1b, packed, dims, mp, need_out, f2w=None, f2b=None, mlp_pk=None):
@@ -266,9 +294,10 @@ def _block_parts(x, n1w, n1b, n2w, n2b, f1w, f1b, packed, dims, mp, need_out, f2
     del O2, xn1
     xn2, mean2, rstd2 = ops.groupnorm_fwd(y1, n2w, n2b)
     panel = _mlp_panel_mode(mlp_pk, M, E, mh, mp)
+    npl = mlp_pk.planes if panel == 2 else 0
     if panel == 2:   # bf16 matrix cores: weights pre-packed bf16 once per step, activations packed in one pass each
-        Hh, Hpre = ops.gemm_bf16p(ops.bf16_pack_rows(xn2.view(M, E)), mlp_pk[0], M, mh, E, bias=f1b, act=act,
-                                  mode=EPI_ACT, save_pre=True)
+        Hh, Hpre = ops.gemm_bf16p(ops.bf16_pack_rows(xn2.view(M, E), planes=npl), mlp_pk[0], M, mh, E, bias=f1b, act=act,
+                                  mode=EPI_ACT, save_pre=True, planes=npl)
     elif panel:    # static-weight panel GEMM (csrc/gemm_panel.hip): weights pre-packed once per optimiser step
         Hh, Hpre = ops.gemm_panel(xn2.view(M, E), mlp_pk[0], mh, bias=f1b, act=act, mode=EPI_ACT, save_pre=True)
     else:
@@ -276,7 +305,8 @@ def _block_parts(x, n1w, n1b, n2w, n2b, f1w, f1b, packed, dims, mp, need_out, f2
     out = None
     if need_out:
         if panel == 2:
-            out, _ = ops.gemm_bf16p(ops.bf16_pack_rows(Hh), mlp_pk[2], M, E, mh, bias=f2b, res=x.view(M, E))
+            out, _ = ops.gemm_bf16p(ops.bf16_pack_rows(Hh, planes=npl), mlp_pk[2], M, E, mh, bias=f2b, res=x.view(M, E),
+                                    planes=npl)
         elif panel:
             out, _ = ops.gemm_panel(Hh, mlp_pk[2], E, bias=f2b, res=x.view(M, E))
         else:
@@ -343,14 +373,16 @@ class BlockFn(torch.autograd.Function):
         # gradients (wgrad GEMMs + split-K reductions, bias column sums, un-packing) runs on the side stream.
         # channel MLP
         mlp_pk = ctx.mlp_pk
-        bf16p = mlp_pk is not None and mlp_pk[0].dtype == torch.bfloat16
+        bf16p = mlp_pk is not None and mlp_pk.kind != "f32"
+        npl = mlp_pk.planes if bf16p else 0
 
         def wgrad(dy, xin, s_w, s_b, shape):
             n, k = dy.shape[1], xin.shape[1]
             if bf16p:   # dW[n, k] = dy^T xin on the bf16 matrix cores: both operands packed transposed (k-dim = tokens),
                 #         split-K over the tokens with a fixed-order reduction; the bias gradient is a column sum
-                dw, _ = ops.gemm_bf16p(ops.bf16_pack_rows(dy, trans=True), ops.bf16_pack_rows(xin, trans=True), n, k, M,
-                                       out=s_w.out())
+                dw, _ = ops.gemm_bf16p(ops.bf16_pack_rows(dy, trans=True, planes=npl),
+                                       ops.bf16_pack_rows(xin, trans=True, planes=npl), n, k, M, out=s_w.out(),
+                                       planes=npl)
                 db = ops.colsum(dy, M, n, out=s_b.out())
             else:
                 dw, db = ops.linear_bwd_wb(dy, xin, s_w.out(), s_b.out(), precision=mp)
@@ -359,7 +391,8 @@ class BlockFn(torch.autograd.Function):
         with streams.side(dev):
             df2w, df2b = wgrad(do2, Hh, s_f2w, s_f2b, (E, mh, 1, 1))
         if bf16p:
-            dHpre, _ = ops.gemm_bf16p(ops.bf16_pack_rows(do2), mlp_pk[3], M, mh, E, act=act, mode=EPI_DACT, aux=Hpre)
+            dHpre, _ = ops.gemm_bf16p(ops.bf16_pack_rows(do2, planes=npl), mlp_pk[3], M, mh, E, act=act, mode=EPI_DACT,
+                                      aux=Hpre, planes=npl)
         elif mlp_pk is not None:
             dHpre, _ = ops.gemm_panel(do2, mlp_pk[3], mh, act=act, mode=EPI_DACT, aux=Hpre)       # do2 W2, * act'(Hpre)
         else:
@@ -367,7 +400,7 @@ class BlockFn(torch.autograd.Function):
         with streams.side(dev):
             df1w, df1b = wgrad(dHpre, xn2.view(M, E), s_f1w, s_f1b, (mh, E, 1, 1))
         if bf16p:
-            dxn2, _ = ops.gemm_bf16p(ops.bf16_pack_rows(dHpre), mlp_pk[1], M, E, mh)
+            dxn2, _ = ops.gemm_bf16p(ops.bf16_pack_rows(dHpre, planes=npl), mlp_pk[1], M, E, mh, planes=npl)
         elif mlp_pk is not None:
             dxn2, _ = ops.gemm_panel(dHpre, mlp_pk[1], E)                      # dHpre W1
         else:

@@ -23,7 +23,8 @@ import torch.nn as nn
 from . import _lib, ops, streams
 import contextlib
 
-from .functional import AdaINFn, BlockFn, EmbedFn, HeadFn, embed_derived, embed_grid_matrix, head_derived
+from .functional import (AdaINFn, BlockFn, EmbedFn, HeadFn, embed_derived, embed_grid_matrix, head_derived,
+                         mlp_pack_kind)
 
 ACTIVATIONS = ("gelu", "tanh", "sigmoid", "relu", "leaky_relu", "softplus", "ELU", "silu")
 
@@ -200,25 +201,25 @@ class DPOTNet(nn.Module):
                 jobs += [(w1, mh, E, E, False), (w1, E, mh, E, True), (w2, E, mh, mh, False), (w2, mh, E, mh, True)]
             return jobs
 
-        def cached(attr, key, make_jobs, bf16):
+        def cached(attr, key, make_jobs, bf16, planes=1):
             pp = getattr(self, attr, None)
             if pp is None or pp.key_all != key:
-                pp = ops.PanelPacks(make_jobs(), bf16=bf16)
+                pp = ops.PanelPacks(make_jobs(), bf16=bf16, planes=planes)
                 pp.key_all = key
                 setattr(self, attr, pp)
             pp.refresh()
             return pp
 
         wkey = tuple(b.mlp[i].weight.data_ptr() for b in self.blocks for i in (0, 2))
-        f32_mlp = False
+        kind = None
         if nb:
             mh = self.blocks[0].mlp[0].weight.shape[0]
-            if (ops.effective_mlp_precision() == ops.GEMM_BF16 and os.environ.get("DPOT_BF16_PANEL", "1") != "0"
-                    and ops.gemm_bf16p_supported(128, mh, E) and ops.gemm_bf16p_supported(128, E, mh)):
-                pp = cached("_panel_packs_bf16", wkey, mlp_jobs, True)
-                mlp_pk = [tuple(pp.bufs[4 * i:4 * i + 4]) for i in range(nb)]
-            elif ops.panel_enabled():
-                f32_mlp = ops.gemm_panel_supported(1, mh, E) and ops.gemm_panel_supported(1, E, mh)
+            kind = mlp_pack_kind(E, mh)
+            if kind in ("bf16", "bf16x6"):
+                planes = 3 if kind == "bf16x6" else 1
+                pp = cached("_panel_packs_" + kind, wkey, mlp_jobs, True, planes)
+                mlp_pk = [ops.MlpPacks(pp.bufs[4 * i:4 * i + 4], kind) for i in range(nb)]
+        f32_mlp = kind == "f32"
         use_head = (ops.panel_enabled() and ops.gemm_panel_supported(1, n_out, E)
                     and ops.gemm_panel_supported(1, E, n_out))
         if f32_mlp or use_head:
@@ -230,7 +231,7 @@ class DPOTNet(nn.Module):
             pp = cached("_panel_packs", wkey + (wt.data_ptr(), f32_mlp, use_head), jobs32, False)
             n0 = 4 * nb if f32_mlp else 0
             if f32_mlp:
-                mlp_pk = [tuple(pp.bufs[4 * i:4 * i + 4]) for i in range(nb)]
+                mlp_pk = [ops.MlpPacks(pp.bufs[4 * i:4 * i + 4], "f32") for i in range(nb)]
             if use_head:
                 head_pk = tuple(pp.bufs[n0:n0 + 2])
         return mlp_pk, head_pk

@@ -145,13 +145,14 @@ class PanelPacks:
     job table that lives in device memory.  jobs = [(src tensor, rows, K, ld, trans)]; the destination buffers are
     allocated once, so the table stays valid while the sources do not move."""
 
-    def __init__(self, jobs, bf16: bool = False):
+    def __init__(self, jobs, bf16: bool = False, planes: int = 1):
         import numpy as np
         dev = jobs[0][0].device
         self.bf16 = bf16
-        if bf16:       # csrc/gemm_bf16p.hip: rows padded to 32, bf16 elements
+        self.planes = planes if bf16 else 0       # 1: plain bf16, 3: bf16x6 split (fp32-accurate)
+        if bf16:       # csrc/gemm_bf16p.hip: rows padded to 32, bf16 elements, `planes` planes per 16-k block
             lib = _lib.load()
-            self.bufs = [torch.empty(lib.dpot_bf16_packed_elems(rows, K), dtype=torch.bfloat16, device=dev)
+            self.bufs = [torch.empty(lib.dpot_bf16_packed_elems(rows, K, planes), dtype=torch.bfloat16, device=dev)
                          for _, rows, K, _, _ in jobs]
         else:
             self.bufs = [torch.empty(rows * K, dtype=torch.float32, device=dev) for _, rows, K, _, _ in jobs]
@@ -165,8 +166,12 @@ class PanelPacks:
         self.max_elems = max(rows * K for _, rows, K, _, _ in jobs)
 
     def refresh(self) -> None:
-        fn = _lib.load().dpot_bf16_pack_jobs if self.bf16 else _lib.load().dpot_panel_pack_weights
-        check(fn(self.table.data_ptr(), self.n, self.max_elems, _stream()), "pack_weights")
+        lib = _lib.load()
+        if self.bf16:
+            check(lib.dpot_bf16_pack_jobs(self.table.data_ptr(), self.n, self.max_elems, self.planes, _stream()),
+                  "bf16_pack_jobs")
+        else:
+            check(lib.dpot_panel_pack_weights(self.table.data_ptr(), self.n, self.max_elems, _stream()), "pack_weights")
 
 
 def gemm_panel(A: Tensor, Wpacked: Tensor, N: int, *, bias: Optional[Tensor] = None, act: int = 0,
@@ -187,26 +192,42 @@ def gemm_bf16p_supported(M: int, N: int, K: int) -> bool:
     return bool(_lib.load().dpot_gemm_bf16p_supported(M, N, K))
 
 
-def bf16_pack_rows(x: Tensor, trans: bool = False) -> Tensor:
+class MlpPacks(tuple):
+    """(W1, W1^T, W2, W2^T) packed for one of the pre-packed-weight GEMM kernels; kind = 'f32' (csrc/gemm_panel.hip),
+    'bf16' (csrc/gemm_bf16p.hip, 1 plane: reduced precision) or 'bf16x6' (3 planes: fp32-accurate)"""
+
+    def __new__(cls, bufs, kind: str):
+        self = super().__new__(cls, bufs)
+        self.kind = kind
+        return self
+
+    @property
+    def planes(self) -> int:
+        return {"f32": 0, "bf16": 1, "bf16x6": 3}[self.kind]
+
+
+def bf16_pack_rows(x: Tensor, trans: bool = False, planes: int = 1) -> Tensor:
     """fp32 [M, K] -> bf16 fragment-block-major operand of gemm_bf16p (one pass; rows padded to 32 with zeros).
-    trans: pack x^T instead (x stored [K, rows]: weight gradients - rows = features, k = tokens)"""
+    trans: pack x^T instead (x stored [K, rows]: weight gradients - rows = features, k = tokens);
+    planes = 3: the three-plane bf16x6 split"""
     lib = _lib.load()
     if trans:
         K, M = x.shape
     else:
         M, K = x.shape
-    out = torch.empty(lib.dpot_bf16_packed_elems(M, K), dtype=torch.bfloat16, device=x.device)
-    check(lib.dpot_bf16_pack_rows(x.data_ptr(), x.stride(0), M, K, int(trans), out.data_ptr(), _stream()),
+    out = torch.empty(lib.dpot_bf16_packed_elems(M, K, planes), dtype=torch.bfloat16, device=x.device)
+    check(lib.dpot_bf16_pack_rows(x.data_ptr(), x.stride(0), M, K, int(trans), planes, out.data_ptr(), _stream()),
           "bf16_pack_rows")
     return out
 
 
 def gemm_bf16p(Ap: Tensor, Wp: Tensor, M: int, N: int, K: int, *, bias: Optional[Tensor] = None, act: int = 0,
                mode: int = EPI_LINEAR, aux: Optional[Tensor] = None, res: Optional[Tensor] = None,
-               save_pre: bool = False, out: Optional[Tensor] = None,
-               splitk: Optional[int] = None) -> Tuple[Tensor, Optional[Tensor]]:
+               save_pre: bool = False, out: Optional[Tensor] = None, splitk: Optional[int] = None,
+               planes: int = 1) -> Tuple[Tensor, Optional[Tensor]]:
     """C[M,N] fp32 = epilogue(A @ Wt^T) on the bf16 matrix cores; Ap / Wp: packed bf16 operands (bf16_pack_rows, or a
-    bf16 PanelPacks buffer).  splitk=None: the library's choice (weight gradients use split-K)."""
+    bf16 PanelPacks buffer) with the same number of planes (1: plain bf16, 3: bf16x6 = fp32-accurate).
+    splitk=None: the library's choice (weight gradients use split-K)."""
     lib = _lib.load()
     C_ = _out(out, (M, N), Ap.device)
     pre = torch.empty_like(C_) if save_pre else None
@@ -216,7 +237,7 @@ def gemm_bf16p(Ap: Tensor, Wp: Tensor, M: int, N: int, K: int, *, bias: Optional
     check(lib.dpot_gemm_bf16p(Ap.data_ptr(), Wp.data_ptr(), _p(bias), _p(aux),
                               aux.stride(0) if aux is not None else 0, _p(res),
                               res.stride(0) if res is not None else 0, _p(pre), N, C_.data_ptr(), N, M, N, K,
-                              act, mode, splitk, _p(ws), _stream()), "gemm_bf16p")
+                              act, mode, planes, splitk, _p(ws), _stream()), "gemm_bf16p")
     return C_, pre
 
 

@@ -376,22 +376,26 @@ int dpot_gemm_panel(const float* A, int lda, const float* Wpacked, const float* 
                     int act, int epi_mode, dpot_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
- * bf16 panel GEMM (csrc/gemm_bf16p.hip): REDUCED precision (operands rounded to bf16, fp32 accumulation), opt-in -
- * BASELINE configs[2] "bf16 channel-MLP on MFMA".  Both operands pre-packed bf16, fragment-block-major:
- * [ceil(rows/32)][K/16][64 chunks][8 bf16], chunk l = (row l&31, k 8*(l>>5)..+7); rows past the matrix are zero.
+ * bf16 panel GEMM (csrc/gemm_bf16p.hip) on v_mfma_f32_32x32x16_bf16, fp32 accumulation, both operands PRE-PACKED in
+ * fragment-block-major order: [ceil(rows/32)][K/16][planes][64 chunks][8 bf16], chunk l = (row l&31, k 8*(l>>5)..+7);
+ * rows past the matrix are zero.
+ *   planes = 1: operands rounded to bf16 - REDUCED precision, opt-in (BASELINE configs[2] "bf16 channel-MLP on MFMA")
+ *   planes = 3: x = x1 + x2 + x3 (three bf16 planes), six plane products accumulated ("bf16x6"): fp32-ACCURATE
+ *               (~2^-24 per product, like a native fp32 FMA chain) at up to 2.67x the fp32 matrix-core roof
  * ------------------------------------------------------------------------------------------------ */
-int64_t dpot_bf16_packed_elems(int rows, int K);      /* bf16 elements of a packed [rows, K] operand */
+int64_t dpot_bf16_packed_elems(int rows, int K, int planes);      /* bf16 elements of a packed [rows, K] operand */
 /* activations: src fp32 [rows, K] row-major (ld) - or, trans != 0, its transpose stored [K, rows] (weight gradients:
  * rows = features, k = tokens) - -> dst packed bf16 (one HBM pass); K % 16 == 0 */
-int dpot_bf16_pack_rows(const float* src, int ld, int rows, int K, int trans, void* dst, dpot_stream_t stream);
+int dpot_bf16_pack_rows(const float* src, int ld, int rows, int K, int trans, int planes, void* dst,
+                        dpot_stream_t stream);
 /* static weights: a DEVICE table of dpot_pack_job entries whose dst is the packed bf16 buffer, all weights in one launch */
-int dpot_bf16_pack_jobs(const dpot_pack_job* jobs_dev, int njobs, int max_elems, dpot_stream_t stream);
-/* C[M,N] (fp32) = epilogue(A @ Wt^T), A = packed [M, K], Wt = packed [N, K]; epilogue as dpot_gemm_panel.
- * Needs N % 256 == 0 and K % 32 == 0 (dpot_gemm_bf16p_supported). */
+int dpot_bf16_pack_jobs(const dpot_pack_job* jobs_dev, int njobs, int max_elems, int planes, dpot_stream_t stream);
+/* C[M,N] (fp32) = epilogue(A @ Wt^T), A = packed [M, K], Wt = packed [N, K] (same `planes`); epilogue as
+ * dpot_gemm_panel.  Needs N % 256 == 0 and K % 32 == 0 (dpot_gemm_bf16p_supported). */
 int dpot_gemm_bf16p_supported(int M, int N, int K);
 int dpot_gemm_bf16p(const void* Apacked, const void* Wpacked, const float* bias, const float* aux, int ldaux,
                     const float* res, int ldres, float* pre, int ldpre, float* C, int ldc, int M, int N, int K, int act,
-                    int epi_mode, int splitk, float* workspace, dpot_stream_t stream);
+                    int epi_mode, int planes, int splitk, float* workspace, dpot_stream_t stream);
 /* split-K factor the library recommends for a shape (weight gradients: few output tiles, K = tokens); splitk > 1 needs
  * a workspace of splitk*M*N floats, summed in a fixed order by a second launch (deterministic) */
 int dpot_gemm_bf16p_splitk(int M, int N, int K);

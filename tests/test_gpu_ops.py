@@ -701,3 +701,73 @@ def test_implicit_patch_embed_matches_patch_matrix_path(ops, B, X, Y, T, hid, ac
     dw0b = torch.empty_like(dw0)
     ops.embed_wgrad(x, dH, dw0b, hid)
     assert torch.equal(dw0b[:, :Cc * P * P], dw0[:, :Cc * P * P]), "implicit wgrad must be deterministic"
+
+
+@pytest.mark.parametrize("M,N,K", [(1000, 256, 96), (4096, 1024, 1024), (130, 512, 64)])
+def test_gemm_bf16x6_panel_is_fp32_accurate(ops, M, N, K):
+    """three-plane form of the bf16 panel GEMM (x = x1 + x2 + x3, six plane products): the error against fp64 is that of
+    an fp32 GEMM (<= a few 2^-24 * sqrt(K)), for every epilogue, the data-gradient form and the split-K weight-gradient
+    form; ragged M, odd slab counts (the ring / tail paths of the kernel)"""
+    assert ops.gemm_bf16p_supported(M, N, K)
+    A, W = rnd(M, K, seed=1), rnd(N, K, seed=2, scale=1.0 / math.sqrt(K))
+    b, R_ = rnd(N, seed=3, scale=0.3), rnd(M, N, seed=4)
+    Wd = W.cuda()
+    pk = ops.PanelPacks([(Wd, N, K, K, False)], bf16=True, planes=3)
+    pk.refresh()
+    Ap = ops.bf16_pack_rows(A.cuda(), planes=3)
+    ref = A.double() @ W.double().t() + b.double()
+    y32, _ = ops.linear_fwd(A.cuda(), Wd, b.cuda())                    # native fp32 MFMA for comparison
+    y, pre = ops.gemm_bf16p(Ap, pk.bufs[0], M, N, K, bias=b.cuda(), act=1, mode=ops.EPI_ACT, save_pre=True, planes=3)
+    e6 = ((pre.cpu().double() - ref).norm() / ref.norm()).item()
+    e32 = ((y32.cpu().double() - ref).norm() / ref.norm()).item()
+    assert e6 < 2.0 * e32 + 1e-7, (e6, e32)
+    assert_close(pre, ref, "pre", rtol=2e-5, atol_scale=2e-6)
+    assert_close(y, torch.nn.functional.gelu(ref), "gelu", rtol=2e-5, atol_scale=2e-6)
+    y2, _ = ops.gemm_bf16p(Ap, pk.bufs[0], M, N, K, bias=b.cuda(), res=R_.cuda(), planes=3)
+    assert_close(y2, ref + R_.double(), "linear + residual", rtol=2e-5, atol_scale=2e-6)
+    if K % 256 == 0:
+        pkT = ops.PanelPacks([(Wd, K, N, K, True)], bf16=True, planes=3)
+        pkT.refresh()
+        dY = rnd(M, N, seed=5)
+        dx, _ = ops.gemm_bf16p(ops.bf16_pack_rows(dY.cuda(), planes=3), pkT.bufs[0], M, K, N, planes=3)
+        assert_close(dx, dY.double() @ W.double(), "dgrad", rtol=2e-5, atol_scale=2e-6)
+    if M % 32 == 0 or True:
+        # weight-gradient form: rows = features (N resp. K), GEMM k-dim = tokens (M, padded to 32 by the pack)
+        Mt = (M // 32) * 32
+        if Mt >= 32 and K % 256 == 0:
+            dY = rnd(Mt, N, seed=6)
+            dw, _ = ops.gemm_bf16p(ops.bf16_pack_rows(dY.cuda(), trans=True, planes=3),
+                                   ops.bf16_pack_rows(A[:Mt].contiguous().cuda(), trans=True, planes=3), N, K, Mt,
+                                   planes=3, splitk=3 if Mt >= 96 else 1)
+            assert_close(dw, dY.double().t() @ A[:Mt].double(), "wgrad (split-K)", rtol=2e-5, atol_scale=2e-6)
+
+
+def test_bf16x6_panel_model_step_matches_fp32(ops, monkeypatch):
+    """channel-MLP precision 'bf16x6' on the three-plane panel kernel: a model step (outputs + every gradient) agrees with
+    the native-fp32 step to fp32 round-off - it is the same arithmetic to ~2^-24 per product"""
+    from dpot_amd import DPOTNet
+    kw = dict(R.MINI, embed_dim=256, out_layer_dim=32, depth=2, mlp_ratio=1, n_blocks=4)
+    cfg = R.DPOTConfig(**kw)
+    x = R.recipe_input((2, cfg.img_size, cfg.img_size, cfg.in_timesteps, cfg.in_channels), salt=9).cuda()
+
+    monkeypatch.setenv("DPOT_X6_PANEL", "1")           # opt-in: the split kernel is the default bf16x6 path
+
+    def run(prec):
+        m = DPOTNet(**kw).cuda()
+        m.load_state_dict(R.recipe_state_dict(cfg, salt=4))
+        ops.set_mlp_precision(prec)
+        try:
+            y, _ = m(x)
+            (y ** 2).sum().backward()
+            used = getattr(m, "_panel_packs_bf16x6", None) is not None
+        finally:
+            ops.set_mlp_precision(None)
+        return y.detach(), {n: p.grad.clone() for n, p in m.named_parameters() if p.grad is not None}, used
+
+    y32, g32, u0 = run(None)
+    y6, g6, u1 = run("bf16x6")
+    assert u1 and not u0
+    rel = lambda a, b: ((a.double() - b.double()).norm() / b.double().norm().clamp_min(1e-30)).item()
+    assert rel(y6, y32) < 2e-6, rel(y6, y32)
+    for n in g32:
+        assert rel(g6[n], g32[n]) < 2e-5, (n, rel(g6[n], g32[n]))
