@@ -1,45 +1,105 @@
 // dft_fast.h - register-blocked rfft2 / irfft2 for the latent grids DPOT actually uses (16x16: 128^2/patch 8;
-// 32x32: 256^2/patch 8).  Same contract as the generic kernels in dft.hip, ~8x fewer instructions:
-//   * pass 1 keeps one spatial row of a channel in VGPRs and evaluates the row DFT with compile-time twiddles
-//     (fully unrolled -> the twiddles are immediates, products by 0/1 fold away)
-//   * the half-complex intermediate crosses to the column pass through LDS, laid out so that both the writes and the
+// 32x32: 256^2/patch 8).  Same contract as the generic kernels in dft.hip:
+//   * both passes keep one line of a channel (16 / 32 points) in VGPRs and transform it with a fully unrolled
+//     radix-2 FFT whose twiddles are compile-time constants (round 1 evaluated the direct O(N^2) sums there, which left
+//     the kernels VALU-bound at 2.7 / 3.5 TB/s; the real-input / one-sided zeros and the unused outputs fold away)
+//   * the half-complex intermediate crosses between the passes through LDS, laid out so that both the writes and the
 //     reads are conflict free (channel index on the lanes)
 //   * HBM traffic stays at the algorithmic minimum: one read of the field, one write of the kept modes.
 #pragma once
+#include <type_traits>
+
 #include "common.h"
 
 namespace dpot {
 
 template <int N> struct Twid;
 template <> struct Twid<16> {
-  static __device__ __forceinline__ float c(int i) {
+  static __host__ __device__ constexpr float c(int i) {
     constexpr float t[16] = {1.0f, 0.9238795042037964f, 0.7071067690849304f, 0.3826834261417389f, 0.0f, -0.3826834261417389f, -0.7071067690849304f, -0.9238795042037964f, -1.0f, -0.9238795042037964f, -0.7071067690849304f, -0.3826834261417389f, 0.0f, 0.3826834261417389f, 0.7071067690849304f, 0.9238795042037964f};
     return t[i];
   }
-  static __device__ __forceinline__ float s(int i) {
+  static __host__ __device__ constexpr float s(int i) {
     constexpr float t[16] = {0.0f, 0.3826834261417389f, 0.7071067690849304f, 0.9238795042037964f, 1.0f, 0.9238795042037964f, 0.7071067690849304f, 0.3826834261417389f, 0.0f, -0.3826834261417389f, -0.7071067690849304f, -0.9238795042037964f, -1.0f, -0.9238795042037964f, -0.7071067690849304f, -0.3826834261417389f};
     return t[i];
   }
 };
 
 template <> struct Twid<32> {
-  static __device__ __forceinline__ float c(int i) {
+  static __host__ __device__ constexpr float c(int i) {
     constexpr float t[32] = {1.0f, 0.9807852506637573f, 0.9238795042037964f, 0.8314695954322815f, 0.7071067690849304f, 0.5555702447891235f, 0.3826834261417389f, 0.19509032368659973f, 0.0f, -0.19509032368659973f, -0.3826834261417389f, -0.5555702447891235f, -0.7071067690849304f, -0.8314695954322815f, -0.9238795042037964f, -0.9807852506637573f, -1.0f, -0.9807852506637573f, -0.9238795042037964f, -0.8314695954322815f, -0.7071067690849304f, -0.5555702447891235f, -0.3826834261417389f, -0.19509032368659973f, 0.0f, 0.19509032368659973f, 0.3826834261417389f, 0.5555702447891235f, 0.7071067690849304f, 0.8314695954322815f, 0.9238795042037964f, 0.9807852506637573f};
     return t[i];
   }
-  static __device__ __forceinline__ float s(int i) {
+  static __host__ __device__ constexpr float s(int i) {
     constexpr float t[32] = {0.0f, 0.19509032368659973f, 0.3826834261417389f, 0.5555702447891235f, 0.7071067690849304f, 0.8314695954322815f, 0.9238795042037964f, 0.9807852506637573f, 1.0f, 0.9807852506637573f, 0.9238795042037964f, 0.8314695954322815f, 0.7071067690849304f, 0.5555702447891235f, 0.3826834261417389f, 0.19509032368659973f, 0.0f, -0.19509032368659973f, -0.3826834261417389f, -0.5555702447891235f, -0.7071067690849304f, -0.8314695954322815f, -0.9238795042037964f, -0.9807852506637573f, -1.0f, -0.9807852506637573f, -0.9238795042037964f, -0.8314695954322815f, -0.7071067690849304f, -0.5555702447891235f, -0.3826834261417389f, -0.19509032368659973f};
     return t[i];
   }
 };
 
 
+// ---------------------------------------------------------------------------------------------------------------------
+// N-point complex FFT in registers (N = 16 / 32), fully unrolled decimation-in-frequency with compile-time twiddles:
+// (N/2) log2 N butterflies instead of the N^2 complex MACs of the direct sum - the direct form made these kernels
+// VALU-bound (pass 2 of rfft2 at 16x16: 1024 FMAs per (ky, channel) item, ~7 us of a 13 us kernel).  SGN = -1: forward
+// (e^{-i..}), +1: inverse.  Output X[k] is left at array index brev<N>(k).  Twiddles equal to 1, +-i, (+-1 +- i)/sqrt 2
+// are special-cased; inputs that are compile-time zeros (real input, truncated spectra) and unused outputs fold away.
+// ---------------------------------------------------------------------------------------------------------------------
 template <int N>
-__device__ __forceinline__ void fill_tw2(float2* tw2) {
-  for (int t = threadIdx.x; t < N; t += blockDim.x) {
-    const double a = (double)(2 * t) / (double)N;
-    tw2[t] = make_float2((float)cospi(a), (float)sinpi(a));
+__host__ __device__ constexpr int brev(int k) {
+  int r = 0;
+  for (int b = 1; b < N; b <<= 1) {
+    r = (r << 1) | (k & 1);
+    k >>= 1;
   }
+  return r;
+}
+
+template <int I>
+using fft_ic = std::integral_constant<int, I>;
+template <int B, int E, class F>
+__device__ __forceinline__ void fft_sfor(F&& f) {
+  if constexpr (B < E) {
+    f(fft_ic<B>{});
+    fft_sfor<B + 1, E>(f);
+  }
+}
+
+template <int N, int SGN, int LEN>
+__device__ __forceinline__ void fft_stage(float (&re)[N], float (&im)[N]) {
+  if constexpr (LEN >= 2) {
+    constexpr int H = LEN / 2;
+    fft_sfor<0, N / 2>([&](auto Q) __attribute__((always_inline)) {
+      constexpr int q = decltype(Q)::value;
+      constexpr int i = (q / H) * LEN + (q % H), j = i + H;
+      constexpr int tw = (q % H) * (N / LEN);          // twiddle angle 2 pi tw / N, tw < N/2
+      const float tr = re[i] - re[j], ti = im[i] - im[j];
+      re[i] += re[j];
+      im[i] += im[j];
+      constexpr float S = (float)SGN;
+      if constexpr (tw == 0) {
+        re[j] = tr;
+        im[j] = ti;
+      } else if constexpr (4 * tw == N) {              // w = S i
+        re[j] = -S * ti;
+        im[j] = S * tr;
+      } else if constexpr (8 * tw == N) {              // w = (1 + S i) / sqrt 2
+        re[j] = (tr - S * ti) * 0.70710678118654752f;
+        im[j] = (S * tr + ti) * 0.70710678118654752f;
+      } else if constexpr (8 * tw == 3 * N) {          // w = (-1 + S i) / sqrt 2
+        re[j] = (-tr - S * ti) * 0.70710678118654752f;
+        im[j] = (S * tr - ti) * 0.70710678118654752f;
+      } else {
+        constexpr float c = Twid<N>::c(tw), sn = S * Twid<N>::s(tw);
+        re[j] = fmaf(tr, c, -ti * sn);
+        im[j] = fmaf(tr, sn, ti * c);
+      }
+    });
+    fft_stage<N, SGN, LEN / 2>(re, im);
+  }
+}
+template <int N, int SGN>
+__device__ __forceinline__ void fft_regs(float (&re)[N], float (&im)[N]) {
+  fft_stage<N, SGN, N>(re, im);
 }
 
 __device__ __forceinline__ float colw_f(int colw, int ky, int w) {
@@ -54,11 +114,9 @@ __global__ __launch_bounds__(256) void rfft2_fast_kernel(const float* __restrict
   constexpr int WF = W / 2 + 1;
   extern __shared__ __attribute__((aligned(16))) float sm[];
   float* Z = sm;                                            // [WF][H][2][CC]
-  float2* tw2 = reinterpret_cast<float2*>(sm + WF * H * 2 * CC);  // [H] (runtime-loop variant only)
   const int b = blockIdx.y, c0 = blockIdx.x * CC;
   const int tid = threadIdx.x;
   const int bs = E / nb;
-  if constexpr (H > 16) fill_tw2<H>(tw2);
   const float* xb = x + (long long)b * H * W * E + c0;
 
   // pass 1: rows (real -> half complex)
@@ -67,18 +125,15 @@ __global__ __launch_bounds__(256) void rfft2_fast_kernel(const float* __restrict
     float v[W];
 #pragma unroll
     for (int y = 0; y < W; ++y) v[y] = xb[(long long)(xr * W + y) * E + c];
+    float vi[W];
 #pragma unroll
-    for (int ky = 0; ky < WF; ++ky) {
-      float re = 0.f, im = 0.f;
-#pragma unroll
-      for (int y = 0; y < W; ++y) {
-        const int idx = (ky * y) % W;
-        re = fmaf(v[y], Twid<W>::c(idx), re);
-        im = fmaf(-v[y], Twid<W>::s(idx), im);
-      }
-      Z[((ky * H + xr) * 2 + 0) * CC + c] = re;
-      Z[((ky * H + xr) * 2 + 1) * CC + c] = im;
-    }
+    for (int y = 0; y < W; ++y) vi[y] = 0.f;               // real input: the zero half folds away
+    fft_regs<W, -1>(v, vi);
+    fft_sfor<0, WF>([&](auto KY) __attribute__((always_inline)) {
+      constexpr int ky = decltype(KY)::value;
+      Z[((ky * H + xr) * 2 + 0) * CC + c] = v[brev<W>(ky)];
+      Z[((ky * H + xr) * 2 + 1) * CC + c] = vi[brev<W>(ky)];
+    });
   }
   __syncthreads();
 
@@ -96,36 +151,14 @@ __global__ __launch_bounds__(256) void rfft2_fast_kernel(const float* __restrict
     const float wgt = scale * colw_f(colw, ky, W);
     float* out = spec + (((long long)b * mx * my + ky) * nb + blk) * 2 * bs + ci;
     const long long kxstride = (long long)my * nb * 2 * bs;
-    if constexpr (H <= 16) {
-#pragma unroll
-      for (int kx = 0; kx < H; ++kx) {
-        if (kx < mx) {
-          float re = 0.f, im = 0.f;
-#pragma unroll
-          for (int xr = 0; xr < H; ++xr) {
-            const int idx = (kx * xr) % H;
-            const float cc_ = Twid<H>::c(idx), ss_ = Twid<H>::s(idx);
-            re = fmaf(zr[xr], cc_, fmaf(zi[xr], ss_, re));
-            im = fmaf(zi[xr], cc_, fmaf(-zr[xr], ss_, im));
-          }
-          out[kx * kxstride] = re * wgt;
-          out[kx * kxstride + bs] = im * wgt;
-        }
+    fft_regs<H, -1>(zr, zi);
+    fft_sfor<0, H>([&](auto KX) __attribute__((always_inline)) {
+      constexpr int kx = decltype(KX)::value;
+      if (kx < mx) {
+        out[kx * kxstride] = zr[brev<H>(kx)] * wgt;
+        out[kx * kxstride + bs] = zi[brev<H>(kx)] * wgt;
       }
-    } else {
-#pragma unroll 1
-      for (int kx = 0; kx < mx; ++kx) {
-        float re = 0.f, im = 0.f;
-#pragma unroll
-        for (int xr = 0; xr < H; ++xr) {
-          const float2 t = tw2[(kx * xr) & (H - 1)];
-          re = fmaf(zr[xr], t.x, fmaf(zi[xr], t.y, re));
-          im = fmaf(zi[xr], t.x, fmaf(-zr[xr], t.y, im));
-        }
-        out[kx * kxstride] = re * wgt;
-        out[kx * kxstride + bs] = im * wgt;
-      }
-    }
+    });
   }
 }
 
@@ -137,14 +170,9 @@ __global__ __launch_bounds__(256) void irfft2_fast_kernel(const float* __restric
   constexpr int WF = W / 2 + 1;
   extern __shared__ __attribute__((aligned(16))) float sm[];
   float* U = sm;                                            // [H][WF][2][CC]
-  float2* tw2 = reinterpret_cast<float2*>(sm + WF * H * 2 * CC);
   const int b = blockIdx.y, c0 = blockIdx.x * CC;
   const int tid = threadIdx.x;
   const int bs = E / nb;
-  if constexpr (H > 16) {
-    fill_tw2<H>(tw2);
-    __syncthreads();
-  }
 
   // pass A: columns, U[x,ky] = sum_kx S[kx,ky] e^{+2 pi i kx x / H}, times the column weight
   for (int it = tid; it < my * CC; it += 256) {
@@ -162,34 +190,12 @@ __global__ __launch_bounds__(256) void irfft2_fast_kernel(const float* __restric
       si[kx] = kx < mx ? bq : 0.f;
     }
     const float wgt = colw_f(colw, ky, W);
-    if constexpr (H <= 16) {
-#pragma unroll
-      for (int xr = 0; xr < H; ++xr) {
-        float ur = 0.f, ui = 0.f;
-#pragma unroll
-        for (int kx = 0; kx < H; ++kx) {
-          const int idx = (kx * xr) % H;
-          const float cc_ = Twid<H>::c(idx), ss_ = Twid<H>::s(idx);
-          ur = fmaf(sr[kx], cc_, fmaf(-si[kx], ss_, ur));
-          ui = fmaf(sr[kx], ss_, fmaf(si[kx], cc_, ui));
-        }
-        U[((xr * WF + ky) * 2 + 0) * CC + c] = ur * wgt;
-        U[((xr * WF + ky) * 2 + 1) * CC + c] = ui * wgt;
-      }
-    } else {
-#pragma unroll 1
-      for (int xr = 0; xr < H; ++xr) {
-        float ur = 0.f, ui = 0.f;
-#pragma unroll
-        for (int kx = 0; kx < H; ++kx) {
-          const float2 t = tw2[(kx * xr) & (H - 1)];
-          ur = fmaf(sr[kx], t.x, fmaf(-si[kx], t.y, ur));
-          ui = fmaf(sr[kx], t.y, fmaf(si[kx], t.x, ui));
-        }
-        U[((xr * WF + ky) * 2 + 0) * CC + c] = ur * wgt;
-        U[((xr * WF + ky) * 2 + 1) * CC + c] = ui * wgt;
-      }
-    }
+    fft_regs<H, 1>(sr, si);
+    fft_sfor<0, H>([&](auto XR) __attribute__((always_inline)) {
+      constexpr int xr = decltype(XR)::value;
+      U[((xr * WF + ky) * 2 + 0) * CC + c] = sr[brev<H>(xr)] * wgt;
+      U[((xr * WF + ky) * 2 + 1) * CC + c] = si[brev<H>(xr)] * wgt;
+    });
   }
   __syncthreads();
 
@@ -197,38 +203,38 @@ __global__ __launch_bounds__(256) void irfft2_fast_kernel(const float* __restric
   const long long base = (long long)b * H * W * E + c0;
   for (int it = tid; it < H * CC; it += 256) {
     const int c = it % CC, xr = it / CC;
-    float ur[WF], ui[WF];
+    float ur[W], ui[W];                                    // one-sided spectrum (weights applied), zero above W/2
 #pragma unroll
-    for (int ky = 0; ky < WF; ++ky) {
-      const int kc = ky < my ? ky : my - 1;
-      const float a = U[((xr * WF + kc) * 2 + 0) * CC + c], bq = U[((xr * WF + kc) * 2 + 1) * CC + c];
-      ur[ky] = ky < my ? a : 0.f;
-      ui[ky] = ky < my ? bq : 0.f;
+    for (int ky = 0; ky < W; ++ky) {
+      if (ky < WF) {
+        const int kc = ky < my ? ky : my - 1;
+        const float a = U[((xr * WF + kc) * 2 + 0) * CC + c], bq = U[((xr * WF + kc) * 2 + 1) * CC + c];
+        ur[ky] = ky < my ? a : 0.f;
+        ui[ky] = ky < my ? bq : 0.f;
+      } else {
+        ur[ky] = 0.f;
+        ui[ky] = 0.f;
+      }
     }
+    fft_regs<W, 1>(ur, ui);                                // y[yy] = Re(sum_ky V[ky] e^{+2 pi i ky yy / W})
     float q[W];
     if (res) {
 #pragma unroll
       for (int yy = 0; yy < W; ++yy) q[yy] = res[base + (long long)(xr * W + yy) * E + c];
     }
-#pragma unroll
-    for (int yy = 0; yy < W; ++yy) {
-      float acc = 0.f;
-#pragma unroll
-      for (int ky = 0; ky < WF; ++ky) {
-        const int idx = (ky * yy) % W;
-        acc = fmaf(ur[ky], Twid<W>::c(idx), fmaf(-ui[ky], Twid<W>::s(idx), acc));
-      }
-      float v = acc * scale;
+    fft_sfor<0, W>([&](auto YY) __attribute__((always_inline)) {
+      constexpr int yy = decltype(YY)::value;
+      float v = ur[brev<W>(yy)] * scale;
       if (res) v += q[yy];
       y[base + (long long)(xr * W + yy) * E + c] = v;
-    }
+    });
   }
 }
 
 template <int H, int W, int CC>
 static int launch_rfft2_fast(const float* x, float* spec, int B, int E, int nb, int mx, int my, int colw, float scale,
                              hipStream_t s) {
-  constexpr size_t lds = sizeof(float) * ((size_t)(W / 2 + 1) * H * 2 * CC + 2 * H);
+  constexpr size_t lds = sizeof(float) * ((size_t)(W / 2 + 1) * H * 2 * CC);
   hipFuncSetAttribute(reinterpret_cast<const void*>(rfft2_fast_kernel<H, W, CC>),
                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   hipLaunchKernelGGL((rfft2_fast_kernel<H, W, CC>), dim3(E / CC, B), dim3(256), lds, s, x, spec, E, nb, mx, my, colw,
@@ -238,7 +244,7 @@ static int launch_rfft2_fast(const float* x, float* spec, int B, int E, int nb, 
 template <int H, int W, int CC>
 static int launch_irfft2_fast(const float* spec, const float* res, float* y, int B, int E, int nb, int mx, int my,
                               int colw, float scale, hipStream_t s) {
-  constexpr size_t lds = sizeof(float) * ((size_t)(W / 2 + 1) * H * 2 * CC + 2 * H);
+  constexpr size_t lds = sizeof(float) * ((size_t)(W / 2 + 1) * H * 2 * CC);
   hipFuncSetAttribute(reinterpret_cast<const void*>(irfft2_fast_kernel<H, W, CC>),
                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   hipLaunchKernelGGL((irfft2_fast_kernel<H, W, CC>), dim3(E / CC, B), dim3(256), lds, s, spec, res, y, E, nb, mx, my,
@@ -249,9 +255,11 @@ static int launch_irfft2_fast(const float* spec, const float* res, float* y, int
 // returns 1 if a fast kernel was launched (rc in *rc), 0 if the shape has no fast path
 static inline int try_rfft2_fast(const float* x, float* spec, int B, int h, int w, int E, int nb, int mx, int my,
                                  int colw, float scale, hipStream_t s, int* rc) {
+  static const int forced = [] { const char* e = getenv("DPOT_DFT_CC"); return e ? atoi(e) : 0; }();
   if (h == 16 && w == 16) {
+    if (forced == 16 && E % 16 == 0) { *rc = launch_rfft2_fast<16, 16, 16>(x, spec, B, E, nb, mx, my, colw, scale, s); return 1; }
     // 64-channel slabs only when that still gives every CU >= 2 workgroups (latency hiding); else 32-channel slabs
-    if (E % 64 == 0 && (long long)B * (E / 64) >= 512) { *rc = launch_rfft2_fast<16, 16, 64>(x, spec, B, E, nb, mx, my, colw, scale, s); return 1; }
+    if (forced != 32 && E % 64 == 0 && ((long long)B * (E / 64) >= 512 || forced == 64)) { *rc = launch_rfft2_fast<16, 16, 64>(x, spec, B, E, nb, mx, my, colw, scale, s); return 1; }
     if (E % 32 == 0) { *rc = launch_rfft2_fast<16, 16, 32>(x, spec, B, E, nb, mx, my, colw, scale, s); return 1; }
   } else if (h == 32 && w == 32) {
     if (E % 16 == 0) { *rc = launch_rfft2_fast<32, 32, 16>(x, spec, B, E, nb, mx, my, colw, scale, s); return 1; }
@@ -260,8 +268,10 @@ static inline int try_rfft2_fast(const float* x, float* spec, int B, int h, int 
 }
 static inline int try_irfft2_fast(const float* spec, const float* res, float* y, int B, int h, int w, int E, int nb,
                                   int mx, int my, int colw, float scale, hipStream_t s, int* rc) {
+  static const int forced = [] { const char* e = getenv("DPOT_DFT_CC"); return e ? atoi(e) : 0; }();
   if (h == 16 && w == 16) {
-    if (E % 64 == 0 && (long long)B * (E / 64) >= 512) { *rc = launch_irfft2_fast<16, 16, 64>(spec, res, y, B, E, nb, mx, my, colw, scale, s); return 1; }
+    if (forced == 16 && E % 16 == 0) { *rc = launch_irfft2_fast<16, 16, 16>(spec, res, y, B, E, nb, mx, my, colw, scale, s); return 1; }
+    if (forced != 32 && E % 64 == 0 && ((long long)B * (E / 64) >= 512 || forced == 64)) { *rc = launch_irfft2_fast<16, 16, 64>(spec, res, y, B, E, nb, mx, my, colw, scale, s); return 1; }
     if (E % 32 == 0) { *rc = launch_irfft2_fast<16, 16, 32>(spec, res, y, B, E, nb, mx, my, colw, scale, s); return 1; }
   } else if (h == 32 && w == 32) {
     if (E % 16 == 0) { *rc = launch_irfft2_fast<32, 32, 16>(spec, res, y, B, E, nb, mx, my, colw, scale, s); return 1; }
