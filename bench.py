@@ -28,6 +28,7 @@ import torch.distributed as dist
 TINY = dict(img_size=128, patch_size=8, in_channels=4, out_channels=4, in_timesteps=10, out_timesteps=1, n_blocks=4,
             embed_dim=512, out_layer_dim=32, depth=4, modes=32, mlp_ratio=1, n_cls=12)
 FP32_MFMA_PEAK_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
+SUSTAINED_FP32_MFMA_TFLOPS = 132.8   # register-only MFMA loop, random operands (profiles/r02_mfma_f32_peak.txt)
 HBM_PEAK_GBS = 8000.0              # MI355X_MICROARCH.md: HBM3E spec
 
 
@@ -141,9 +142,81 @@ def mixer_roofline(model, B: int):
         "inference_form": {"us_per_launch": round(t_inf * 1e6, 2), "achieved": round(flops / t_inf / 1e12, 2),
                            "frac": round(flops / t_inf / 1e12 / FP32_MFMA_PEAK_TFLOPS, 4),
                            "what": "same launch without the two saved-for-backward stores (no_grad forward)"},
+        "sustained_mfma_tflops": SUSTAINED_FP32_MFMA_TFLOPS,
+        "frac_of_sustained": round(achieved / SUSTAINED_FP32_MFMA_TFLOPS, 4),
         "note": "FLOP-bound (128 FLOP/B >> 20 FLOP/B ridge): hbm_frac is reported because north_star asks for it; "
-                "round 1 ran this as two launches of the generic GEMM (2 x 34.4 us, frac 0.446)",
+                "round 1 ran this as two launches of the generic GEMM (2 x 34.4 us, frac 0.446).  `peak` is the nominal "
+                "157.3 TFLOP/s; a register-only v_mfma_f32_16x16x4_f32 loop on random data sustains 132.8 TFLOP/s on this "
+                "part (power-limited clocks; profiles/r02_mfma_f32_peak.txt) - frac_of_sustained prices against that",
+        "other_kernels": other_rooflines(model, B, timeit_graph),
     }
+
+
+def timeit_graph(fn, reps: int = 30):
+    """seconds per call of `fn`, `reps` launches captured in one hipGraph (the host cost of a Python launch excluded)"""
+    for _ in range(3):
+        fn()
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        for _ in range(reps):
+            fn()
+    g.replay()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    g.replay()
+    e1.record()
+    e1.synchronize()
+    return e0.elapsed_time(e1) * 1e-3 / reps
+
+
+def other_rooflines(model, B: int, timeit):
+    """the next kernels of the step by time share, timed the same way (random operands, graph-captured launches)"""
+    from dpot_amd import ops
+    out = []
+    try:
+        E, h = model.embed_dim, model.latent_size[0]
+        M = B * h * h
+        mh = model.blocks[0].mlp[0].weight.shape[0]
+        A = torch.randn(M, E, device="cuda")
+        W = torch.randn(mh, E, device="cuda") * 0.05
+        b = torch.randn(mh, device="cuda") * 0.1
+        dy = torch.randn(M, mh, device="cuda")
+        fl = 2.0 * M * mh * E
+        if ops.gemm_panel_supported(M, mh, E):
+            pk = ops.PanelPacks([(W, mh, E, E, False)])
+            pk.refresh()
+            t = timeit(lambda: ops.gemm_panel(A, pk.bufs[0], mh, bias=b, act=1, mode=ops.EPI_ACT, save_pre=True))
+            out.append({"kernel": "dpot::gemm_panel_kernel (channel-MLP fc1 forward: x W1^T + b -> GELU, pre-activation saved)",
+                        "shape": [M, mh, E], "bound": "mfma", "us_per_launch": round(t * 1e6, 2),
+                        "achieved": round(fl / t / 1e12, 2), "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                        "frac": round(fl / t / 1e12 / FP32_MFMA_PEAK_TFLOPS, 4),
+                        "frac_of_sustained": round(fl / t / 1e12 / SUSTAINED_FP32_MFMA_TFLOPS, 4)})
+        t = timeit(lambda: ops.linear_bwd_wb(dy, A))
+        out.append({"kernel": "dpot::gemm_f32_kernel<64,64,TN> + splitk_reduce (channel-MLP weight gradient dY^T X, bias "
+                              "gradient fused)", "shape": [mh, E, M], "bound": "mfma",
+                    "us_per_launch": round(t * 1e6, 2), "achieved": round(fl / t / 1e12, 2),
+                    "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                    "frac": round(fl / t / 1e12 / FP32_MFMA_PEAK_TFLOPS, 4),
+                    "frac_of_sustained": round(fl / t / 1e12 / SUSTAINED_FP32_MFMA_TFLOPS, 4)})
+        x = torch.randn(B, h * h, E, device="cuda")
+        nb = model.n_blocks
+        mx, my = min(model.modes, h), min(model.modes, h // 2 + 1)
+        t = timeit(lambda: ops.rfft2(x, h, h, nb, mx, my, 0))
+        by = x.numel() * 4 + B * mx * my * 2 * E * 4
+        out.append({"kernel": "dpot::rfft2_fast_kernel (field -> kept modes, register FFTs)", "bound": "hbm",
+                    "us_per_launch": round(t * 1e6, 2), "achieved": round(by / t / 1e9, 1), "peak": HBM_PEAK_GBS,
+                    "unit": "GB/s", "frac": round(by / t / 1e9 / HBM_PEAK_GBS, 4)})
+        gw, gb_ = torch.randn(E, device="cuda"), torch.randn(E, device="cuda")
+        t = timeit(lambda: ops.groupnorm_fwd(x, gw, gb_))
+        by = 2 * x.numel() * 4
+        out.append({"kernel": "dpot::groupnorm_fwd_cached_kernel", "bound": "hbm", "us_per_launch": round(t * 1e6, 2),
+                    "achieved": round(by / t / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": round(by / t / 1e9 / HBM_PEAK_GBS, 4)})
+    except Exception as e:      # the probe must never take the headline down
+        log(f"[bench] secondary roofline probe failed: {e}")
+    return out
 
 
 def cpu_baseline(seconds: float):
