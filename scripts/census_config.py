@@ -1,0 +1,22 @@
+"""eager train step of a BASELINE config under rocprofv3 (kernel census): python scripts/census_config.py M bf16"""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from dpot_amd import DPOTNet, ops
+from dpot_amd.train import FlatParams, FusedAdam, rollout
+from scripts.gpu_configs2 import CFGS
+
+key, mlp = sys.argv[1], (sys.argv[2] if len(sys.argv) > 2 else None)
+kw, B, T_ar = CFGS[key]
+ops.set_mlp_precision(mlp)
+model = DPOTNet(**kw).cuda()
+S = kw["img_size"]
+xx = torch.randn(B, S, S, 10, 4, device="cuda"); yy = torch.randn(B, S, S, T_ar, 4, device="cuda"); msk = torch.ones(B, S, S, 1, 4, device="cuda")
+opt = FusedAdam(FlatParams(model), lr=1e-4, betas=(0.9, 0.9), weight_decay=1e-6, max_norm=10000.0)
+for _ in range(4):
+    opt.zero_grad()
+    loss, _ = rollout(model, xx, yy, msk, noise_scale=0.0005)
+    loss.backward()
+    opt.step(lr=1e-4)
+torch.cuda.synchronize()
+print("ok", float(loss))
