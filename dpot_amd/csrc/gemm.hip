@@ -390,6 +390,8 @@ extern "C" int dpot_gemm_auto_splitk(int M, int N, int K, int batch) {
 // DPOT_GEMM_AUTO: both kernels are fp32-accurate, so the choice is pure speed.  The bf16x6 kernel has the higher
 // roof but a longer pipeline (two slabs of prologue, 120 KB of LDS per workgroup): it pays on the large products
 // (measured in the DPOT-Tiny step: 3 GFLOP and up: channel-MLP, embed and de-embed GEMMs), not on the 2.4 GFLOP batched AFNO mixer.
+int dpot_gemm_tn_try(const dpot_gemm_desc* d, hipStream_t s);   // gemm_tn.hip
+
 static int resolve_precision(int precision, int M, int N, int K, int batch) {
   if (precision != DPOT_GEMM_AUTO) return precision;
   static const double min_gflop = [] {
@@ -492,7 +494,13 @@ extern "C" int dpot_gemm_f32(const dpot_gemm_desc* d, dpot_stream_t stream) {
   DPOT_REQUIRE(ntiles < (1ll << 31) && (long long)d->batch * splits <= 65535, "gemm: grid too large");
   dim3 grid((unsigned)ntiles, 1, (unsigned)(d->batch * splits));
   hipStream_t s = as_stream(stream);
-  if (precision == DPOT_GEMM_BF16) {
+  // weight gradients (A^T B, both operands token-major) with split-K: the dedicated kernel of gemm_tn.hip leaves its
+  // partial sums in the workspace exactly as the generic kernel would, so the reduce launches below serve both
+  const int tn_rc = precision == DPOT_GEMM_F32 ? dpot_gemm_tn_try(d, s) : -1;
+  if (tn_rc > 0) return tn_rc;
+  if (tn_rc == 0) {
+    // launched
+  } else if (precision == DPOT_GEMM_BF16) {
     // reduced precision on request (BASELINE configs[2] "bf16 channel-MLP on MFMA"): operands rounded to bf16 between
     // the global load and the LDS store, ONE product per k-step on v_mfma_f32_32x32x16_bf16, fp32 accumulation
     if (t == 128) {

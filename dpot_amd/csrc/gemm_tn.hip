@@ -1,0 +1,239 @@
+// gemm_tn.hip - fp32 weight-gradient GEMM  C[N1, N2] = sum_t A[t, n1] * B[t, n2]   (A = dY, B = X: both stored
+// token-major, the contraction runs over the ROWS of both operands; dpot_gemm_f32 with transA = 1, transB = 0).
+//
+// Small outputs (512 x 512 at DPOT-Tiny), 8192-long contractions, 256 CUs: the work has to be split along the
+// tokens, and the kernel must make the most of each pass over its token range.  Structure:
+//   * workgroup = one 128 x 128 output tile x one token range (split-K, partial sums to the workspace; the existing
+//     fixed-order reduce kernels of gemm.hip finish: bias-gradient column sums, AFNO un-packing, accumulate ...);
+//   * 4 compute waves in a 2 x 2 grid, each 64 x 64 = 4 x 4 accumulators of v_mfma_f32_16x16x4_f32, + 2 loader waves
+//     that only issue LDS-DMA: a token row of a tile is 512 contiguous bytes, two rows per wave-instruction, the slab of
+//     32 tokens lands in LDS exactly as it lies in memory ([tok][128] for each operand);
+//   * ROW-INTERLEAVED fragments: the MFMA A operand wants, per lane, one element (row n, token k).  A ds_read_b128 at
+//     [tok = 4q + (lane >> 4)][4 * (lane & 15) .. +3] hands every lane FOUR of them - for the four 16-row tiles made of
+//     the rows n = 4 i + e (e = 0..3).  Which 16 rows form a tile is a free choice, so 64 rows of an operand cost one
+//     LDS instruction per 4-token step: 2 ds_read_b128 per 16 MFMAs.  The interleave also makes the accumulator layout
+//     store-friendly: a lane holds 4 consecutive columns of one output row -> 16-byte global stores, no LDS staging;
+//   * ring of 4 slabs of 32 tokens (128 KiB), loaders 3 slabs ahead with counted vmcnt, ONE barrier per slab (8
+//     MFMA k-steps = 128 MFMAs per wave between barriers), the first fragments of slab t+1 fetched before the barrier
+//     (the loaders guarantee slab t+1 at barrier t).  Variants measured at 512 x 512 x 8192 (split 16, incl. the reduce
+//     launch; generic kernel of gemm.hip: 57.4 us): 16-token slabs 54.1 us; 8 compute waves (two token groups added
+//     through LDS at the end) 55.8; 8-slab ring / 6 ahead 57.2 - neither wave-level parallelism nor DMA depth is the
+//     limiter, the per-slab barrier + first-fragment latency is;
+//   * bias gradients (column sums of one operand over the tokens) come from the fragments the waves read anyway.
+#include "common.h"
+#include "gemm_epi.h"
+
+namespace dpot {
+
+typedef float tn_f32x4 __attribute__((ext_vector_type(4)));
+
+struct TnArgs {
+  const float* A;        // [T, lda]  (columns = output rows n1)
+  const float* B;        // [T, ldb]  (columns = output columns n2)
+  int lda, ldb;
+  long long sA, sB;      // batch strides (elements)
+  int N1, N2, T, batch;
+  int tiles1, tiles2, splits, slabs_per_split;
+  float* ws;             // [split][batch][N1][N2] (+ [split][batch][L] column-sum partials behind)
+  int cs_of;             // 0: none, 1: column sums of A (length N1), 2: of B (length N2)
+};
+
+constexpr int TN_TOK = 32;                 // tokens per slab
+constexpr int TN_W = 128;                  // tile width (both operands)
+constexpr int TN_SLABF = 2 * TN_TOK * TN_W;  // floats per slab: A [16][128] | B [16][128]
+constexpr int TN_RING = 4;
+constexpr int TN_AHEAD = 3;                // slabs the loaders run ahead
+constexpr int TN_NI = 16;                  // DMA instructions per slab and loader wave (1 KiB each)
+
+template <int N>
+__device__ __forceinline__ void tn_wait_vm() {
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+__device__ __forceinline__ void tn_glds16(const float* g, float* l) {
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                   (__attribute__((address_space(3))) void*)l, 16, 0, 0);
+}
+
+__global__ __launch_bounds__(384) void gemm_tn_kernel(const TnArgs p) {
+  __shared__ __attribute__((aligned(16))) float lds[TN_RING * TN_SLABF];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+
+  const int ntiles = p.tiles1 * p.tiles2;
+  int tile;
+  {
+    const int bid = blockIdx.x, xcd = bid & 7, slot = bid >> 3;
+    const int q = ntiles >> 3, r = ntiles & 7;
+    tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + slot;
+  }
+  const int t1 = tile / p.tiles2, t2 = tile - t1 * p.tiles2;
+  const int zb = blockIdx.z / p.splits, zs = blockIdx.z - zb * p.splits;
+  const int nslab_all = p.T / TN_TOK;
+  const int slab0 = zs * p.slabs_per_split;
+  int nslab = nslab_all - slab0;
+  nslab = nslab < p.slabs_per_split ? nslab : p.slabs_per_split;
+  if (nslab < 0) nslab = 0;
+
+  auto bar = [&]() __attribute__((always_inline)) {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+  };
+
+  if (wave >= 4) {
+    // ---------------------------------- loader waves ----------------------------------
+    // wave L issues the tokens 16L .. 16L+15 of both operands (instruction j = tokens 16L + 2j, + 2j + 1 of one operand);
+    // lane -> (token parity lane >> 5, 16 B piece lane & 31)
+    const int L = wave - 4;
+    const float* a0 = p.A + zb * p.sA + (long long)(slab0 * TN_TOK + 16 * L + (lane >> 5)) * p.lda + t1 * TN_W + (lane & 31) * 4;
+    const float* b0 = p.B + zb * p.sB + (long long)(slab0 * TN_TOK + 16 * L + (lane >> 5)) * p.ldb + t2 * TN_W + (lane & 31) * 4;
+    const long long sa2 = 2ll * p.lda, sb2 = 2ll * p.ldb, saS = (long long)TN_TOK * p.lda, sbS = (long long)TN_TOK * p.ldb;
+    auto issue = [&](int t, int ring) __attribute__((always_inline)) {
+      float* dst = lds + ring * TN_SLABF + L * 8 * 256;
+      const float* a = a0 + t * saS;
+      const float* b = b0 + t * sbS;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) tn_glds16(a + j * sa2, dst + j * 256);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) tn_glds16(b + j * sb2, dst + TN_TOK * TN_W + j * 256);
+    };
+    if (nslab > 0) issue(0, 0);
+    if (nslab > 1) issue(1, 1);
+    if (nslab > 2) issue(2, 2);
+    if (nslab > 2) tn_wait_vm<2 * TN_NI>(); else if (nslab > 1) tn_wait_vm<TN_NI>(); else tn_wait_vm<0>();
+    bar();                                              // P: slab 0 landed
+    int ring = TN_AHEAD;                                // slot of slab g + 3
+#pragma unroll 1
+    for (int g = 0; g < nslab; ++g) {
+      // slab g + 1 must have landed before B_g (the compute waves prefetch its first fragments before B_(g+1))
+      if (g + 2 < nslab) tn_wait_vm<TN_NI>(); else tn_wait_vm<0>();
+      bar();                                            // B_g: everyone is done with slab g - 1 -> its slot is free
+      if (g + TN_AHEAD < nslab) issue(g + TN_AHEAD, ring);
+      ring = ring == TN_RING - 1 ? 0 : ring + 1;
+    }
+    return;
+  }
+
+  // ---------------------------------- compute waves ----------------------------------
+  const int wm = wave >> 1, wn = wave & 1;
+  const int i16 = lane & 15, kq = lane >> 4;
+  tn_f32x4 acc[4][4];
+#pragma unroll
+  for (int ea = 0; ea < 4; ++ea)
+#pragma unroll
+    for (int eb = 0; eb < 4; ++eb) acc[ea][eb] = tn_f32x4{0.f, 0.f, 0.f, 0.f};
+  tn_f32x4 cs = {0.f, 0.f, 0.f, 0.f};
+  const bool cs_a = p.cs_of == 1 && t2 == 0 && wn == 0;
+  const bool cs_b = p.cs_of == 2 && t1 == 0 && wm == 0;
+
+  // this lane's fragment addresses inside a slab: A [tok = 4q + kq][wm*64 + 4*i16], B likewise with wn
+  const int offA = kq * TN_W + wm * 64 + 4 * i16;
+  const int offB = TN_TOK * TN_W + kq * TN_W + wn * 64 + 4 * i16;
+  constexpr int NQ = TN_TOK / 4;                        // 4-token MFMA steps per slab
+
+  bar();                                                // P
+  tn_f32x4 fa = {0.f, 0.f, 0.f, 0.f}, fb = fa;
+  if (nslab > 0) {
+    fa = *reinterpret_cast<const tn_f32x4*>(lds + offA);
+    fb = *reinterpret_cast<const tn_f32x4*>(lds + offB);
+  }
+  int ring = 0;
+#pragma unroll 1
+  for (int g = 0; g < nslab; ++g) {
+    bar();                                              // B_g
+    const float* cur = lds + ring * TN_SLABF;
+    const int rn = ring == TN_RING - 1 ? 0 : ring + 1;
+    // the step after the last one of this slab is the first one of the next slab (landed before B_g); on the very last
+    // slab the address is clamped to this slab (the value is never used)
+    const float* nxt = g + 1 < nslab ? lds + rn * TN_SLABF : cur;
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+      const tn_f32x4 a = fa, b = fb;
+      const float* src = q + 1 < NQ ? cur + (q + 1) * 4 * TN_W : nxt;
+      fa = *reinterpret_cast<const tn_f32x4*>(src + offA);
+      fb = *reinterpret_cast<const tn_f32x4*>(src + offB);
+      if (cs_a) cs += a;
+      if (cs_b) cs += b;
+#pragma unroll
+      for (int ea = 0; ea < 4; ++ea)
+#pragma unroll
+        for (int eb = 0; eb < 4; ++eb)
+          acc[ea][eb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[ea], b[eb], acc[ea][eb], 0, 0, 0);
+    }
+    ring = rn;
+  }
+
+  // partial tile: element (n1 = 4*(4*kq + r) + ea, n2 = 4*i16 + eb) of the wave's 64 x 64 block
+  float* ws = p.ws + ((long long)zs * p.batch + zb) * p.N1 * p.N2;
+  const int n1b = t1 * TN_W + wm * 64, n2b = t2 * TN_W + wn * 64 + 4 * i16;
+#pragma unroll
+  for (int ea = 0; ea < 4; ++ea)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int n1 = n1b + 4 * (4 * kq + r) + ea;
+      *reinterpret_cast<float4*>(ws + (long long)n1 * p.N2 + n2b) =
+          make_float4(acc[ea][0][r], acc[ea][1][r], acc[ea][2][r], acc[ea][3][r]);
+    }
+  if (cs_a || cs_b) {
+    // lanes with equal i16 hold the sums over the tokens = kq (mod 4): fixed-order butterfly over kq
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      float v = cs[e];
+      v += __shfl_xor(v, 16);
+      v += __shfl_xor(v, 32);
+      cs[e] = v;
+    }
+    if (kq == 0) {
+      const int L = cs_a ? p.N1 : p.N2;
+      const int g0 = cs_a ? t1 * TN_W + wm * 64 : t2 * TN_W + wn * 64;
+      float* wc = p.ws + (long long)p.splits * p.batch * p.N1 * p.N2 + ((long long)zs * p.batch + zb) * L + g0 + 4 * i16;
+      *reinterpret_cast<float4*>(wc) = make_float4(cs[0], cs[1], cs[2], cs[3]);
+    }
+  }
+}
+
+}  // namespace dpot
+
+using namespace dpot;
+
+// split count the TN kernel wants for a shape (0: the shape is not eligible)
+extern "C" int dpot_gemm_tn_splitk(int M, int N, int K, int batch) {
+  static const int enabled = [] { const char* e = getenv("DPOT_GEMM_TN"); return e ? atoi(e) : 1; }();
+  // batched descriptors (the AFNO weight gradients: 4 x [256 x 256], 4608 tokens) stay on the generic kernel: measured
+  // 37.4 us here against 36.2 us there
+  if (!enabled || M <= 0 || N <= 0 || K <= 0 || batch != 1 || M % TN_W || N % TN_W || K % TN_TOK) return 0;
+  const long long tiles = (long long)(M / TN_W) * (N / TN_W) * batch;
+  const int nslab = K / TN_TOK;
+  long long s = (256 + tiles / 2) / tiles;            // one workgroup per CU
+  const long long smax = nslab / 4;                   // >= 4 slabs (128 tokens) per split
+  if (s > smax) s = smax;
+  if (s < 2) s = 2;                                   // the kernel always goes through the workspace + reduce
+  if (s > nslab) return 0;
+  return (int)s;
+}
+
+// called by dpot_gemm_f32 (gemm.hip) for transA && !transB, native fp32, split-K descriptors; returns -1 when the
+// descriptor is not eligible (the generic kernel runs instead), else the launch status.  The partial sums land in
+// d->workspace in the layout the generic kernel uses, so the caller's reduce launch is unchanged.
+int dpot_gemm_tn_try(const dpot_gemm_desc* d, hipStream_t s) {
+  static const int enabled = [] { const char* e = getenv("DPOT_GEMM_TN"); return e ? atoi(e) : 1; }();
+  if (!enabled || !d->transA || d->transB || d->splitk <= 1 || !d->workspace || d->batch != 1) return -1;
+  if (d->M % TN_W || d->N % TN_W || d->K % TN_TOK || d->lda % 4 || d->ldb % 4 || d->strideA % 4 || d->strideB % 4 ||
+      !aligned16(d->A) || !aligned16(d->B) || !aligned16(d->workspace) || d->N % 4)
+    return -1;
+  const int nslab = d->K / TN_TOK;
+  if (d->splitk > nslab || (long long)d->batch * d->splitk > 65535) return -1;
+  TnArgs p;
+  p.A = d->A; p.B = d->B; p.lda = d->lda; p.ldb = d->ldb; p.sA = d->strideA; p.sB = d->strideB;
+  p.N1 = d->M; p.N2 = d->N; p.T = d->K; p.batch = d->batch;
+  p.tiles1 = d->M / TN_W; p.tiles2 = d->N / TN_W;
+  p.splits = d->splitk;
+  p.slabs_per_split = (nslab + d->splitk - 1) / d->splitk;
+  if ((long long)p.slabs_per_split * (d->splitk - 1) >= nslab) return -1;      // an empty split would leave its partial unwritten
+  p.ws = d->workspace;
+  p.cs_of = d->colsum_of;
+  hipLaunchKernelGGL(gemm_tn_kernel, dim3((unsigned)(p.tiles1 * p.tiles2), 1, (unsigned)(d->batch * d->splitk)), dim3(384),
+                     0, s, p);
+  return check_launch("gemm_tn_kernel");
+}

@@ -174,11 +174,11 @@ class EmbedFn(torch.autograd.Function):
                  aux=Hpre, ldaux=T * hidp)
         dV = torch.empty(T * hidp, E, dtype=torch.float32, device=dev)
         ops.gemm(Hh, dY, dV, T * hidp, E, M, transA=True, lda=T * hidp, ldb=E, ldc=E,
-                 splitk=ops.auto_splitk(T * hidp, E, M))
+                 splitk=ops.auto_splitk(T * hidp, E, M, tn=True))
         dc = ops.group_rowsum(dY, B, tok, 1, E)                                # [tok, E]
         # c = posb wsum  ->  dwsum = posb^T dc, dposb = dc wsum^T
         dwsum = torch.empty(E, E, dtype=torch.float32, device=dev)
-        ops.gemm(posb, dc, dwsum, E, E, tok, transA=True, lda=E, ldb=E, ldc=E, splitk=ops.auto_splitk(E, E, tok))
+        ops.gemm(posb, dc, dwsum, E, E, tok, transA=True, lda=E, ldb=E, ldc=E, splitk=ops.auto_splitk(E, E, tok, tn=True))
         dposb = torch.empty(tok, E, dtype=torch.float32, device=dev)
         ops.gemm(dc, wsum, dposb, tok, E, E, transB=True, lda=E, ldb=E, ldc=E)
         dpos = s_pos.done(ops.transpose2d(dposb, 1, tok, E, out=s_pos.out()).view(1, E, h, w))
@@ -411,7 +411,7 @@ class BlockFn(torch.autograd.Function):
         # AFNO mixer
         dO2 = ops.rfft2(dy1, h, w, nb, mx, my, 1)                              # adjoint of irfft2
         kw = dict(lda=2 * E, ldb=2 * bs, ldc=2 * E, batch=nb, strideA=2 * bs, strideB=4 * bs * bs, strideC=2 * bs)
-        sk = max(2, ops.auto_splitk(2 * bs, 2 * bs, Mm, nb))
+        sk = max(2, ops.auto_splitk(2 * bs, 2 * bs, Mm, nb, tn=True))
         wkw = dict(transA=True, lda=2 * E, ldb=2 * E, ldc=2 * bs, batch=nb, strideA=2 * bs, strideB=2 * bs,
                    strideC=4 * bs * bs, splitk=sk, mode=ops.EPI_AFNO_WGRAD)
         with streams.side(dev):
@@ -556,7 +556,7 @@ class HeadFn(torch.autograd.Function):
                 ops.gemm(dU2, wt, dx_out, M, E, PP * old, transB=True, lda=PP * old, ldb=PP * old, ldc=E)
             dwt = torch.empty(E, PP * old, dtype=torch.float32, device=dev)
             ops.gemm(x, dU2, dwt, E, PP * old, M, transA=True, lda=E, ldb=PP * old, ldc=PP * old,
-                     splitk=ops.auto_splitk(E, PP * old, M))
+                     splitk=ops.auto_splitk(E, PP * old, M, tn=True))
             do0w = s_o0w.done(ops.transpose2d(dwt, E, PP, old, out=s_o0w.out()).view(E, old, P, P))
             dx_out = dx_out.view(B, tok, E)
         else:

@@ -80,8 +80,16 @@ def _p(t: Optional[Tensor]) -> Optional[int]:
 # ------------------------------------------------------------------------------------------------------
 # GEMM
 # ------------------------------------------------------------------------------------------------------
-def auto_splitk(M: int, N: int, K: int, batch: int = 1, precision: Optional[int] = None) -> int:
-    return _lib.load().dpot_gemm_auto_splitk2(M, N, K, batch, _gemm_precision if precision is None else precision)
+def auto_splitk(M: int, N: int, K: int, batch: int = 1, precision: Optional[int] = None, tn: bool = False) -> int:
+    """split-K factor for a GEMM; tn: a weight gradient (transA, not transB) - in native fp32 those run on the kernel
+    of csrc/gemm_tn.hip, which wants one 128x128 workgroup per CU"""
+    lib = _lib.load()
+    prec = _gemm_precision if precision is None else precision
+    if tn and prec == GEMM_F32:
+        s = lib.dpot_gemm_tn_splitk(M, N, K, batch)
+        if s > 0:
+            return s
+    return lib.dpot_gemm_auto_splitk2(M, N, K, batch, prec)
 
 
 def gemm(A: Tensor, B: Tensor, C_: Tensor, M: int, N: int, K: int, *, transA: bool = False, transB: bool = False,
@@ -282,7 +290,8 @@ def linear_bwd_weight(dy: Tensor, x: Tensor, out: Optional[Tensor] = None, n_row
     K = x.shape[1]
     dW = _out(out, (N, K), dy.device)
     gemm(dy, x, dW, N, K, M, transA=True, transB=False, lda=dy.stride(0), ldb=x.stride(0), ldc=K,
-         splitk=auto_splitk(N, K, M, precision=precision), colsum_out=bias_out, colsum_of=1, precision=precision)
+         splitk=auto_splitk(N, K, M, precision=precision, tn=True), colsum_out=bias_out, colsum_of=1,
+         precision=precision)
     return dW
 
 

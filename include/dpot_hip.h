@@ -138,6 +138,11 @@ enum { DPOT_GEMM_F32 = 0, DPOT_GEMM_BF16X6 = 1, DPOT_GEMM_AUTO = 2, DPOT_GEMM_BF
 int dpot_gemm_f32(const dpot_gemm_desc* d, dpot_stream_t stream);
 /* bytes of workspace dpot_gemm_f32 needs for this descriptor (0 when splitk <= 1) */
 int64_t dpot_gemm_workspace_bytes(const dpot_gemm_desc* d);
+/* weight gradients (transA = 1, transB = 0, native fp32, M % 128 == N % 128 == 0, K % 16 == 0, split-K) run on the
+ * dedicated kernel of csrc/gemm_tn.hip; this is the split count it wants for a shape (0: shape not eligible - use
+ * dpot_gemm_auto_splitk2).  Any splitk > 1 is accepted, the result does not depend on which kernel ran beyond fp32
+ * summation order. */
+int dpot_gemm_tn_splitk(int M, int N, int K, int batch);
 /* the split-K factor the library would pick for this shape (>= 1) */
 int dpot_gemm_auto_splitk(int M, int N, int K, int batch);
 /* the same for a given dpot_gemm_desc.precision (the bf16x6 kernel prefers fewer, larger workgroups) */

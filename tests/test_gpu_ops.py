@@ -771,3 +771,32 @@ def test_bf16x6_panel_model_step_matches_fp32(ops, monkeypatch):
     assert rel(y6, y32) < 2e-6, rel(y6, y32)
     for n in g32:
         assert rel(g6[n], g32[n]) < 2e-5, (n, rel(g6[n], g32[n]))
+
+
+@pytest.mark.parametrize("M,N,K,batch,cs", [(512, 512, 8192, 1, 1), (256, 256, 4608, 1, 2), (128, 384, 2048, 1, 0),
+                                            (512, 2048, 1024, 1, 0), (256, 128, 32 * 37, 1, 1)])
+def test_weight_gradient_kernel_vs_fp64(ops, M, N, K, batch, cs):
+    """csrc/gemm_tn.hip (A^T B over token-major operands, row-interleaved fragments, split-K through the workspace) against
+    fp64: dW, the fused bias-gradient column sums of either operand, operands that are column windows of wider matrices,
+    odd slab counts per split"""
+    lda, ldb = M * batch, N * batch
+    A, B = rnd(K, lda, seed=1), rnd(K, ldb, seed=2)
+    Ad, Bd = A.cuda(), B.cuda()
+
+    def run():
+        C = torch.full((batch, M, N), float("nan"), device="cuda")
+        csum = torch.full((batch, M if cs == 1 else N), float("nan"), device="cuda") if cs else None
+        sk = ops.auto_splitk(M, N, K, batch, tn=True)
+        ops.gemm(Ad, Bd, C, M, N, K, transA=True, lda=lda, ldb=ldb, ldc=N, batch=batch, strideA=M, strideB=N,
+                 strideC=M * N, splitk=sk, colsum_out=csum, colsum_of=cs, strideColsum=(M if cs == 1 else N))
+        return C, csum, sk
+
+    C, csum, sk = run()
+    assert sk >= 2 and ops._lib.load().dpot_gemm_tn_splitk(M, N, K, batch) == sk
+    for z in range(batch):
+        a, b = A[:, z * M:(z + 1) * M].double(), B[:, z * N:(z + 1) * N].double()
+        assert_close(C[z], a.t() @ b, f"dW[{z}]", rtol=2e-5, atol_scale=2e-6)
+        if cs:
+            assert_close(csum[z], (a if cs == 1 else b).sum(0), f"colsum[{z}]", rtol=2e-5, atol_scale=2e-6)
+    C2, _, _ = run()
+    assert torch.equal(C, C2), "deterministic"
