@@ -119,6 +119,8 @@ SIGNATURES = {
     "dpot_gemm_bf16p": (c_i, [c_fp, c_fp, c_fp, c_fp, c_i, c_fp, c_i, c_fp, c_i, c_fp, c_i] + [c_i] * 7 + [c_fp, c_fp]),
     "dpot_gemm_bf16p_splitk": (c_i, [c_i, c_i, c_i]),
     "dpot_gemm_tn_splitk": (c_i, [c_i] * 4),
+    "dpot_bf16_pack_both_supported": (c_i, [c_i, c_i]),
+    "dpot_bf16_pack_both": (c_i, [c_fp, c_i, c_i, c_i, c_fp, c_fp, c_fp, c_fp]),
     "dpot_embed_supported": (c_i, [c_i] * 5),
     "dpot_embed_wfrag_elems": (c_i, []),
     "dpot_embed_pack_w0": (c_i, [c_fp, c_i, c_fp, c_fp]),

@@ -422,6 +422,58 @@ __global__ __launch_bounds__(256) void bf16_pack_rows_kernel(const float* __rest
   }
 }
 
+// One pass over an activation matrix src [R, K] (tokens x features) that produces BOTH packed forms the channel MLP
+// needs - the row form (GEMM A operand: rows = tokens, k = features) and the transposed form (weight-gradient operand:
+// rows = features, k = tokens) - and, optionally, per-block partial column sums (the bias gradient).  A thread owns an
+// 8 x 8 patch: 8 row-form chunks (one per token) and 8 transposed chunks (one per feature).  Block = 32 feature groups x
+// 8 token groups = 256 features x 64 tokens.  R % 64 == 0, K % 256 == 0.
+__global__ __launch_bounds__(256) void bf16_pack_both_kernel(const float* __restrict__ src, int ld, int R, int K,
+                                                             uint4* __restrict__ drow, uint4* __restrict__ dtr,
+                                                             float* __restrict__ cpart) {
+  __shared__ float red[8][256];
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  const int c0 = blockIdx.x * 256 + tx * 8, r0 = blockIdx.y * 64 + ty * 8;
+  float v[8][8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const float4 x0 = *reinterpret_cast<const float4*>(src + (long long)(r0 + i) * ld + c0);
+    const float4 x1 = *reinterpret_cast<const float4*>(src + (long long)(r0 + i) * ld + c0 + 4);
+    v[i][0] = x0.x; v[i][1] = x0.y; v[i][2] = x0.z; v[i][3] = x0.w;
+    v[i][4] = x1.x; v[i][5] = x1.y; v[i][6] = x1.z; v[i][7] = x1.w;
+  }
+  if (drow) {   // chunk (token r, features c0..c0+7): block (r >> 5, c0 >> 4), slot (r & 31) + 32 * ((c0 >> 3) & 1)
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int r = r0 + i;
+      drow[((long long)(r >> 5) * (K >> 4) + (c0 >> 4)) * 64 + (r & 31) + 32 * ((c0 >> 3) & 1)] =
+          make_uint4(pack2(v[i][0], v[i][1]), pack2(v[i][2], v[i][3]), pack2(v[i][4], v[i][5]), pack2(v[i][6], v[i][7]));
+    }
+  }
+  if (dtr) {    // chunk (feature f, tokens r0..r0+7): block (f >> 5, r0 >> 4), slot (f & 31) + 32 * ((r0 >> 3) & 1)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int f = c0 + j;
+      dtr[((long long)(f >> 5) * (R >> 4) + (r0 >> 4)) * 64 + (f & 31) + 32 * ((r0 >> 3) & 1)] =
+          make_uint4(pack2(v[0][j], v[1][j]), pack2(v[2][j], v[3][j]), pack2(v[4][j], v[5][j]), pack2(v[6][j], v[7][j]));
+    }
+  }
+  if (cpart) {  // column sums of this block's 64 tokens, fixed order: 8 rows in the thread, then the 8 token groups
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      float a = 0.f;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) a += v[i][j];
+      red[ty][tx * 8 + j] = a;
+    }
+    __syncthreads();
+    const int c = threadIdx.x;
+    float a = 0.f;
+#pragma unroll
+    for (int g = 0; g < 8; ++g) a += red[g][c];
+    cpart[(long long)blockIdx.y * K + blockIdx.x * 256 + c] = a;
+  }
+}
+
 // weights (job table in device memory): logical Wt [rows, K] (row n, k) = trans ? src[k*ld + n] : src[n*ld + k]
 template <int NPL>
 __global__ __launch_bounds__(256) void bf16_pack_jobs_kernel(const dpot_pack_job* __restrict__ jobs) {
@@ -480,6 +532,20 @@ extern "C" int dpot_bf16_pack_rows(const float* src, int ld, int rows, int K, in
     hipLaunchKernelGGL(bf16_pack_rows_kernel<1>, dim3((unsigned)g), dim3(256), 0, as_stream(stream), src, ld, rows, K,
                        reinterpret_cast<uint4*>(dst), nchunks, trans);
   return check_launch("bf16_pack_rows_kernel");
+}
+
+extern "C" int dpot_bf16_pack_both_supported(int rows, int K) { return rows > 0 && K > 0 && rows % 64 == 0 && K % 256 == 0; }
+
+extern "C" int dpot_bf16_pack_both(const float* src, int ld, int rows, int K, void* dst_rows, void* dst_trans,
+                                   float* colsum_part, dpot_stream_t stream) {
+  DPOT_REQUIRE(src && (dst_rows || dst_trans || colsum_part), "bf16_pack_both: null pointer");
+  DPOT_REQUIRE(dpot_bf16_pack_both_supported(rows, K) && ld >= K && ld % 4 == 0 && aligned16(src) &&
+                   aligned16(dst_rows) && aligned16(dst_trans),
+               "bf16_pack_both: needs rows %% 64 == 0, K %% 256 == 0, 16-byte aligned rows");
+  DPOT_REQUIRE(rows / 64 <= 65535, "bf16_pack_both: too many rows");
+  hipLaunchKernelGGL(bf16_pack_both_kernel, dim3(K / 256, rows / 64), dim3(256), 0, as_stream(stream), src, ld, rows, K,
+                     reinterpret_cast<uint4*>(dst_rows), reinterpret_cast<uint4*>(dst_trans), colsum_part);
+  return check_launch("bf16_pack_both_kernel");
 }
 
 extern "C" int dpot_bf16_pack_jobs(const dpot_pack_job* jobs_dev, int njobs, int max_elems, int planes,

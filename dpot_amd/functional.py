@@ -295,6 +295,21 @@ def _block_parts(x, n1w, n1b, n2w, n2b, f1w, f1b, packed, dims, mp, need_out, f2
     xn2, mean2, rstd2 = ops.groupnorm_fwd(y1, n2w, n2b)
     panel = _mlp_panel_mode(mlp_pk, M, E, mh, mp)
     npl = mlp_pk.planes if panel == 2 else 0
+    both = (panel == 2 and npl == 1 and os.environ.get("DPOT_PACK_BOTH", "1") != "0"
+            and ops.bf16_pack_both_supported(M, E) and ops.bf16_pack_both_supported(M, mh))
+    if both:
+        # plain-bf16 channel MLP, one pack pass per activation: the pass that packs xn2 / Hh as the A operand of the
+        # next GEMM also writes the TRANSPOSED pack the weight gradient will need - that (bf16, half the bytes) is what
+        # the backward keeps; the fp32 xn2 / Hh are dropped right here
+        xp, xpT, _ = ops.bf16_pack_both(xn2.view(M, E))
+        del xn2
+        Hh, Hpre = ops.gemm_bf16p(xp, mlp_pk[0], M, mh, E, bias=f1b, act=act, mode=EPI_ACT, save_pre=True)
+        hp, hpT, _ = ops.bf16_pack_both(Hh, want_rows=need_out)
+        del Hh
+        out = None
+        if need_out:
+            out, _ = ops.gemm_bf16p(hp, mlp_pk[2], M, E, mh, bias=f2b, res=x.view(M, E))
+        return out, (mean1, rstd1, S, O1pre, O1, y1, mean2, rstd2, xpT, Hpre, hpT)
     if panel == 2:   # bf16 matrix cores: weights pre-packed bf16 once per step, activations packed in one pass each
         Hh, Hpre = ops.gemm_bf16p(ops.bf16_pack_rows(xn2.view(M, E), planes=npl), mlp_pk[0], M, mh, E, bias=f1b, act=act,
                                   mode=EPI_ACT, save_pre=True, planes=npl)
@@ -388,23 +403,38 @@ class BlockFn(torch.autograd.Function):
                 dw, db = ops.linear_bwd_wb(dy, xin, s_w.out(), s_b.out(), precision=mp)
             return s_w.done(dw.view(shape)), s_b.done(db)
 
-        with streams.side(dev):
-            df2w, df2b = wgrad(do2, Hh, s_f2w, s_f2b, (E, mh, 1, 1))
-        if bf16p:
-            dHpre, _ = ops.gemm_bf16p(ops.bf16_pack_rows(do2, planes=npl), mlp_pk[3], M, mh, E, act=act, mode=EPI_DACT,
-                                      aux=Hpre, planes=npl)
-        elif mlp_pk is not None:
-            dHpre, _ = ops.gemm_panel(do2, mlp_pk[3], mh, act=act, mode=EPI_DACT, aux=Hpre)       # do2 W2, * act'(Hpre)
+        if bf16p and xn2.dtype == torch.bfloat16:
+            # pack-both path (see _block_parts): xn2 / Hh ARE the transposed bf16 packs; each gradient is packed once, in
+            # both forms, and its bias column sums come out of the same pass
+            dop, dopT, df2b = ops.bf16_pack_both(do2, want_colsum=True, colsum_out=s_f2b.out())
+            df2w, _ = ops.gemm_bf16p(dopT, Hh, E, mh, M, out=s_f2w.out())
+            df2w, df2b = s_f2w.done(df2w.view(E, mh, 1, 1)), s_f2b.done(df2b)
+            dHpre, _ = ops.gemm_bf16p(dop, mlp_pk[3], M, mh, E, act=act, mode=EPI_DACT, aux=Hpre)
+            del dop, dopT
+            dhp, dhpT, df1b = ops.bf16_pack_both(dHpre, want_colsum=True, colsum_out=s_f1b.out())
+            del dHpre
+            df1w, _ = ops.gemm_bf16p(dhpT, xn2, mh, E, M, out=s_f1w.out())
+            df1w, df1b = s_f1w.done(df1w.view(mh, E, 1, 1)), s_f1b.done(df1b)
+            dxn2, _ = ops.gemm_bf16p(dhp, mlp_pk[1], M, E, mh)
+            del dhp, dhpT
         else:
-            dHpre = ops.linear_bwd_data(do2, f2w, act=act, aux=Hpre, precision=mp)  # [M, mh]
-        with streams.side(dev):
-            df1w, df1b = wgrad(dHpre, xn2.view(M, E), s_f1w, s_f1b, (mh, E, 1, 1))
-        if bf16p:
-            dxn2, _ = ops.gemm_bf16p(ops.bf16_pack_rows(dHpre, planes=npl), mlp_pk[1], M, E, mh, planes=npl)
-        elif mlp_pk is not None:
-            dxn2, _ = ops.gemm_panel(dHpre, mlp_pk[1], E)                      # dHpre W1
-        else:
-            dxn2 = ops.linear_bwd_data(dHpre, f1w, precision=mp)               # [M, E]
+            with streams.side(dev):
+                df2w, df2b = wgrad(do2, Hh, s_f2w, s_f2b, (E, mh, 1, 1))
+            if bf16p:
+                dHpre, _ = ops.gemm_bf16p(ops.bf16_pack_rows(do2, planes=npl), mlp_pk[3], M, mh, E, act=act, mode=EPI_DACT,
+                                          aux=Hpre, planes=npl)
+            elif mlp_pk is not None:
+                dHpre, _ = ops.gemm_panel(do2, mlp_pk[3], mh, act=act, mode=EPI_DACT, aux=Hpre)       # do2 W2, * act'(Hpre)
+            else:
+                dHpre = ops.linear_bwd_data(do2, f2w, act=act, aux=Hpre, precision=mp)  # [M, mh]
+            with streams.side(dev):
+                df1w, df1b = wgrad(dHpre, xn2.view(M, E), s_f1w, s_f1b, (mh, E, 1, 1))
+            if bf16p:
+                dxn2, _ = ops.gemm_bf16p(ops.bf16_pack_rows(dHpre, planes=npl), mlp_pk[1], M, E, mh, planes=npl)
+            elif mlp_pk is not None:
+                dxn2, _ = ops.gemm_panel(dHpre, mlp_pk[1], E)                      # dHpre W1
+            else:
+                dxn2 = ops.linear_bwd_data(dHpre, f1w, precision=mp)               # [M, E]
         dy1, dn2w, dn2b = ops.groupnorm_bwd(dxn2.view(B, tok, E), y1, mean2, rstd2, n2w, out_dgamma=s_n2w.out(),
                                             out_dbeta=s_n2b.out())
         dn2w, dn2b = s_n2w.done(dn2w), s_n2b.done(dn2b)

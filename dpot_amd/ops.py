@@ -229,6 +229,24 @@ def bf16_pack_rows(x: Tensor, trans: bool = False, planes: int = 1) -> Tensor:
     return out
 
 
+def bf16_pack_both_supported(rows: int, K: int) -> bool:
+    return bool(_lib.load().dpot_bf16_pack_both_supported(rows, K))
+
+
+def bf16_pack_both(x: Tensor, want_rows: bool = True, want_trans: bool = True, colsum_out: Optional[Tensor] = None,
+                   want_colsum: bool = False):
+    """one pass over x [M, K] fp32 -> (row-form pack | None, transposed pack | None, column sums | None): the two operand
+    forms the bf16 channel MLP needs of an activation (data GEMM and weight gradient) and its bias gradient"""
+    lib = _lib.load()
+    M, K = x.shape
+    pr = torch.empty(lib.dpot_bf16_packed_elems(M, K, 1), dtype=torch.bfloat16, device=x.device) if want_rows else None
+    pt = torch.empty(lib.dpot_bf16_packed_elems(K, M, 1), dtype=torch.bfloat16, device=x.device) if want_trans else None
+    part = torch.empty(M // 64, K, dtype=torch.float32, device=x.device) if want_colsum else None
+    check(lib.dpot_bf16_pack_both(x.data_ptr(), x.stride(0), M, K, _p(pr), _p(pt), _p(part), _stream()), "bf16_pack_both")
+    cs = colsum(part, M // 64, K, out=colsum_out) if want_colsum else None
+    return pr, pt, cs
+
+
 def gemm_bf16p(Ap: Tensor, Wp: Tensor, M: int, N: int, K: int, *, bias: Optional[Tensor] = None, act: int = 0,
                mode: int = EPI_LINEAR, aux: Optional[Tensor] = None, res: Optional[Tensor] = None,
                save_pre: bool = False, out: Optional[Tensor] = None, splitk: Optional[int] = None,

@@ -393,6 +393,12 @@ int64_t dpot_bf16_packed_elems(int rows, int K, int planes);      /* bf16 elemen
  * rows = features, k = tokens) - -> dst packed bf16 (one HBM pass); K % 16 == 0 */
 int dpot_bf16_pack_rows(const float* src, int ld, int rows, int K, int trans, int planes, void* dst,
                         dpot_stream_t stream);
+/* one pass that produces BOTH 1-plane packed forms of an activation (row form = GEMM A operand, transposed form =
+ * weight-gradient operand; either may be NULL) and, if colsum_part != NULL, partial column sums [rows/64, K] (the bias
+ * gradient = their sum over the first index, fixed order: dpot_colsum).  rows % 64 == 0, K % 256 == 0. */
+int dpot_bf16_pack_both_supported(int rows, int K);
+int dpot_bf16_pack_both(const float* src, int ld, int rows, int K, void* dst_rows, void* dst_trans, float* colsum_part,
+                        dpot_stream_t stream);
 /* static weights: a DEVICE table of dpot_pack_job entries whose dst is the packed bf16 buffer, all weights in one launch */
 int dpot_bf16_pack_jobs(const dpot_pack_job* jobs_dev, int njobs, int max_elems, int planes, dpot_stream_t stream);
 /* C[M,N] (fp32) = epilogue(A @ Wt^T), A = packed [M, K], Wt = packed [N, K] (same `planes`); epilogue as

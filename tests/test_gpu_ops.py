@@ -800,3 +800,48 @@ def test_weight_gradient_kernel_vs_fp64(ops, M, N, K, batch, cs):
             assert_close(csum[z], (a if cs == 1 else b).sum(0), f"colsum[{z}]", rtol=2e-5, atol_scale=2e-6)
     C2, _, _ = run()
     assert torch.equal(C, C2), "deterministic"
+
+
+@pytest.mark.parametrize("M,K", [(128, 256), (4096, 1024), (192, 768)])
+def test_bf16_pack_both_equals_the_two_single_packs(ops, M, K):
+    """the fused pass produces bit-identical row-form and transposed packs to dpot_bf16_pack_rows, and the column sums"""
+    x = rnd(M, K, seed=3).cuda()
+    pr, pt, cs = ops.bf16_pack_both(x, want_colsum=True)
+    assert torch.equal(pr, ops.bf16_pack_rows(x))
+    assert torch.equal(pt, ops.bf16_pack_rows(x, trans=True))
+    assert_close(cs, x.double().sum(0), "colsum", rtol=2e-5, atol_scale=2e-6)
+    pr2, pt2, cs2 = ops.bf16_pack_both(x, want_rows=False)
+    assert pr2 is None and cs2 is None and torch.equal(pt2, pt)
+
+
+def test_bf16_mlp_pack_both_path_matches_separate_packs(ops, monkeypatch):
+    """the bf16 channel MLP with one fused pack pass per activation (transposed packs saved for the backward instead of
+    the fp32 activations) == the same path with separate pack passes, bit for bit, forward and every gradient; also
+    under activation recomputation"""
+    from dpot_amd import DPOTNet
+    kw = dict(R.MINI, img_size=64, embed_dim=256, out_layer_dim=32, depth=2, mlp_ratio=1, n_blocks=4)
+    cfg = R.DPOTConfig(**kw)
+    x = R.recipe_input((2, cfg.img_size, cfg.img_size, cfg.in_timesteps, cfg.in_channels), salt=9).cuda()
+
+    def run(both, recompute=False):
+        monkeypatch.setenv("DPOT_PACK_BOTH", "1" if both else "0")
+        m = DPOTNet(**kw).cuda()
+        m.load_state_dict(R.recipe_state_dict(cfg, salt=4))
+        m.recompute_blocks = recompute
+        ops.set_mlp_precision("bf16")
+        try:
+            y, _ = m(x)
+            (y ** 2).sum().backward()
+        finally:
+            ops.set_mlp_precision(None)
+        return y.detach(), {n: p.grad.clone() for n, p in m.named_parameters() if p.grad is not None}
+
+    y0, g0 = run(False)
+    for rec in (False, True):
+        y1, g1 = run(True, rec)
+        assert torch.equal(y0, y1)
+        for n in g0:
+            if n.endswith("mlp.0.bias") or n.endswith("mlp.2.bias"):      # column sums: different (fixed) summation order
+                assert_close(g1[n], g0[n], n, rtol=1e-5, atol_scale=1e-6)
+            else:
+                assert torch.equal(g0[n], g1[n]), n
