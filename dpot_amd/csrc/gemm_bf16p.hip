@@ -30,6 +30,12 @@ struct Bf16pArgs {
   int M, N, K, tilesM, tilesN;
   int splits, slabs_per_split;   // split-K (weight gradients: K = tokens): blockIdx.y = split, partials go to ws
   float* ws;                     // [splits][M][N]
+  // optional extra outputs of the epilogue (1-plane packs of the FINAL output, so that the next GEMMs need no separate
+  // pack pass over it; M % 32 == 0): row form (A operand of the next data GEMM), transposed form (operand of the weight
+  // gradient), per-32-row partial column sums [M/32][N] (bias gradient).  e.C may then be NULL (no fp32 store).
+  uint4* out_rows;
+  uint4* out_trans;
+  float* cs_part;
   EpiArgs e;
 };
 
@@ -40,6 +46,91 @@ __device__ __forceinline__ void bwait_vm() {
 __device__ __forceinline__ void bglds16(const void* g, void* l) {
   __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
                                    (__attribute__((address_space(3))) void*)l, 16, 0, 0);
+}
+
+__device__ __forceinline__ unsigned pack2(float lo, float hi) {
+  f32x2_t v = {lo, hi};
+  bf16x2_t r = __builtin_convertvector(v, bf16x2_t);   // v_cvt_pk_bf16_f32 (round to nearest even)
+  return __builtin_bit_cast(unsigned, r);
+}
+
+// epilogue of one 32x32 fragment with PACKED outputs: like epi_fragment (bias, pre-activation save, act / act'(aux),
+// residual, optional fp32 store) but the final values go back into the LDS slab, from which the wave emits the bf16
+// row-form chunks (row, 8 consecutive columns), the transposed chunks (column, 8 consecutive rows) and the 32-row partial
+// column sums.  Vector path only (N % 4 == 0, aligned), M % 32 == 0.
+__device__ __forceinline__ void epi_fragment_pack(const Bf16pArgs& p, int m0f, int n0f, const f32x16& acc, float* stage,
+                                                  int lane) {
+  const EpiArgs& e = p.e;
+  const int li = lane & 31, kh = lane >> 5;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) stage[((r & 3) + 8 * (r >> 2) + 4 * kh) * EPI_LD + li] = acc[r];
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  const int c4 = (lane & 7) * 4;
+  const int n = n0f + c4;
+#pragma unroll 1
+  for (int it = 0; it < 4; ++it) {
+    const int row = it * 8 + (lane >> 3);
+    const int m = m0f + row;
+    const float4 t = *reinterpret_cast<const float4*>(&stage[row * EPI_LD + c4]);
+    float v[4] = {t.x, t.y, t.z, t.w};
+    if (e.bias) {
+      const Vec4 q = ld4(e.bias + n, true);
+#pragma unroll
+      for (int k = 0; k < 4; ++k) v[k] += q.v[k];
+    }
+    if (e.pre) *reinterpret_cast<float4*>(e.pre + (long long)m * e.ldpre + n) = make_float4(v[0], v[1], v[2], v[3]);
+    if (e.mode == DPOT_EPI_ACT) {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) v[k] = act_fwd(e.act, v[k]);
+    } else if (e.mode == DPOT_EPI_DACT) {
+      const Vec4 q = ld4(e.aux + (long long)m * e.ldaux + n, true);
+#pragma unroll
+      for (int k = 0; k < 4; ++k) v[k] *= act_bwd(e.act, q.v[k]);
+    }
+    if (e.res) {
+      const Vec4 q = ld4(e.res + (long long)m * e.ldres + n, true);
+#pragma unroll
+      for (int k = 0; k < 4; ++k) v[k] += q.v[k];
+    }
+    if (e.C) *reinterpret_cast<float4*>(e.C + (long long)m * e.ldc + n) = make_float4(v[0], v[1], v[2], v[3]);
+    *reinterpret_cast<float4*>(&stage[row * EPI_LD + c4]) = make_float4(v[0], v[1], v[2], v[3]);
+  }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  if (p.out_rows) {     // 128 chunks (row, column octet): chunk id = lane + 64 s -> row = id >> 2, octet = id & 3
+#pragma unroll
+    for (int s2 = 0; s2 < 2; ++s2) {
+      const int id = lane + 64 * s2, row = id >> 2, oc = id & 3;
+      const float4 x0 = *reinterpret_cast<const float4*>(&stage[row * EPI_LD + 8 * oc]);
+      const float4 x1 = *reinterpret_cast<const float4*>(&stage[row * EPI_LD + 8 * oc + 4]);
+      const int m = m0f + row, nn = n0f + 8 * oc;
+      p.out_rows[((long long)(m >> 5) * (p.N >> 4) + (nn >> 4)) * 64 + (m & 31) + 32 * ((nn >> 3) & 1)] =
+          make_uint4(pack2(x0.x, x0.y), pack2(x0.z, x0.w), pack2(x1.x, x1.y), pack2(x1.z, x1.w));
+    }
+  }
+  if (p.out_trans) {    // 128 chunks (column, row octet): id = lane + 64 s -> column = id & 31, octet = id >> 5
+#pragma unroll
+    for (int s2 = 0; s2 < 2; ++s2) {
+      const int id = lane + 64 * s2, col = id & 31, oc = id >> 5;
+      float x[8];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) x[i] = stage[(8 * oc + i) * EPI_LD + col];
+      const int f = n0f + col, m = m0f + 8 * oc;
+      p.out_trans[((long long)(f >> 5) * (p.M >> 4) + (m >> 4)) * 64 + (f & 31) + 32 * ((m >> 3) & 1)] =
+          make_uint4(pack2(x[0], x[1]), pack2(x[2], x[3]), pack2(x[4], x[5]), pack2(x[6], x[7]));
+    }
+  }
+  if (p.cs_part) {      // column sums of the 32 rows, fixed order: 16 rows per half-wave, then the two halves
+    float a = 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) a += stage[(16 * kh + i) * EPI_LD + li];
+    a += __shfl_xor(a, 32);
+    if (kh == 0) p.cs_part[(long long)(m0f >> 5) * p.N + n0f + li] = a;
+  }
+  __builtin_amdgcn_wave_barrier();
 }
 
 constexpr int PB_ROWT = 4;      // 32-row tiles per workgroup (128 rows)
@@ -194,6 +285,17 @@ __global__ __launch_bounds__(64 * (8 + PB_NLOAD)) void gemm_bf16p_kernel(const B
           if (m < p.M && n < p.N) ws[(long long)m * p.N + n] = acc[i][j][r];
         }
       }
+    return;
+  }
+  if (p.out_rows || p.out_trans || p.cs_part) {        // host-checked: M % 32 == 0 -> every fragment is full or empty
+    if (m0 < p.M) {
+      epi_fragment_pack(p, m0, n0, acc[0][0], stage, lane);
+      epi_fragment_pack(p, m0, n0 + 32, acc[0][1], stage, lane);
+    }
+    if (m0 + 32 < p.M) {
+      epi_fragment_pack(p, m0 + 32, n0, acc[1][0], stage, lane);
+      epi_fragment_pack(p, m0 + 32, n0 + 32, acc[1][1], stage, lane);
+    }
     return;
   }
   epi_fragment(p.e, 1, 0, m0, n0, acc[0][0], stage, lane);
@@ -354,11 +456,6 @@ __global__ __launch_bounds__(512) void gemm_bf16x6p_kernel(const Bf16pArgs p) {
   epi_fragment(p.e, 1, 0, m0 + 32, n0 + 32, acc[1][1], stage, lane);
 }
 
-__device__ __forceinline__ unsigned pack2(float lo, float hi) {
-  f32x2_t v = {lo, hi};
-  bf16x2_t r = __builtin_convertvector(v, bf16x2_t);   // v_cvt_pk_bf16_f32 (round to nearest even)
-  return __builtin_bit_cast(unsigned, r);
-}
 
 // 8 consecutive k of one row -> NPL packed planes (16 bytes each); plane p holds bf16(x - sum of the planes before it)
 template <int NPL>
@@ -582,8 +679,12 @@ extern "C" int dpot_gemm_bf16p_splitk(int M, int N, int K) {
 
 extern "C" int dpot_gemm_bf16p(const void* Apacked, const void* Wpacked, const float* bias, const float* aux, int ldaux,
                                const float* res, int ldres, float* pre, int ldpre, float* C, int ldc, int M, int N, int K,
-                               int act, int epi_mode, int planes, int splitk, float* workspace, dpot_stream_t stream) {
-  DPOT_REQUIRE(Apacked && Wpacked && C, "gemm_bf16p: null operand");
+                               int act, int epi_mode, int planes, int splitk, float* workspace, void* out_rows,
+                               void* out_trans, float* colsum_part, dpot_stream_t stream) {
+  const bool packs = out_rows || out_trans || colsum_part;
+  DPOT_REQUIRE(Apacked && Wpacked && (C || packs), "gemm_bf16p: null operand");
+  DPOT_REQUIRE(!packs || (planes == 1 && splitk <= 1 && M % 32 == 0 && aligned16(out_rows) && aligned16(out_trans)),
+               "gemm_bf16p: packed outputs need planes == 1, no split-K and M %% 32 == 0");
   DPOT_REQUIRE(planes == 1 || planes == 3, "gemm_bf16p: planes must be 1 (plain bf16) or 3 (bf16x6, fp32-accurate)");
   DPOT_REQUIRE(dpot_gemm_bf16p_supported(M, N, K), "gemm_bf16p: unsupported shape M=%d N=%d K=%d (N %% 256, K %% 32)", M, N, K);
   DPOT_REQUIRE(epi_mode == DPOT_EPI_LINEAR || epi_mode == DPOT_EPI_ACT || (epi_mode == DPOT_EPI_DACT && aux),
@@ -614,6 +715,9 @@ extern "C" int dpot_gemm_bf16p(const void* Apacked, const void* Wpacked, const f
   p.slabs_per_split = (nslab + p.splits - 1) / p.splits;
   p.splits = (nslab + p.slabs_per_split - 1) / p.slabs_per_split;       // no empty split
   p.ws = workspace;
+  p.out_rows = reinterpret_cast<uint4*>(out_rows);
+  p.out_trans = reinterpret_cast<uint4*>(out_trans);
+  p.cs_part = colsum_part;
   if (planes == 3)
     hipLaunchKernelGGL(gemm_bf16x6p_kernel, dim3((unsigned)(p.tilesM * p.tilesN), p.splits), dim3(512), 0,
                        as_stream(stream), p);

@@ -303,9 +303,9 @@ def _block_parts(x, n1w, n1b, n2w, n2b, f1w, f1b, packed, dims, mp, need_out, f2
         # the backward keeps; the fp32 xn2 / Hh are dropped right here
         xp, xpT, _ = ops.bf16_pack_both(xn2.view(M, E))
         del xn2
-        Hh, Hpre = ops.gemm_bf16p(xp, mlp_pk[0], M, mh, E, bias=f1b, act=act, mode=EPI_ACT, save_pre=True)
-        hp, hpT, _ = ops.bf16_pack_both(Hh, want_rows=need_out)
-        del Hh
+        # fc1: the epilogue emits the activated hidden layer directly in its two packed forms (no fp32 copy of it exists)
+        _, Hpre, hp, hpT, _ = ops.gemm_bf16p(xp, mlp_pk[0], M, mh, E, bias=f1b, act=act, mode=EPI_ACT, save_pre=True,
+                                             pack_rows=need_out, pack_trans=True, store=False)
         out = None
         if need_out:
             out, _ = ops.gemm_bf16p(hp, mlp_pk[2], M, E, mh, bias=f2b, res=x.view(M, E))
@@ -409,10 +409,11 @@ class BlockFn(torch.autograd.Function):
             dop, dopT, df2b = ops.bf16_pack_both(do2, want_colsum=True, colsum_out=s_f2b.out())
             df2w, _ = ops.gemm_bf16p(dopT, Hh, E, mh, M, out=s_f2w.out())
             df2w, df2b = s_f2w.done(df2w.view(E, mh, 1, 1)), s_f2b.done(df2b)
-            dHpre, _ = ops.gemm_bf16p(dop, mlp_pk[3], M, mh, E, act=act, mode=EPI_DACT, aux=Hpre)
+            # dHpre = (do2 W2) * act'(Hpre) leaves the GEMM as its two packs + bias column sums only
+            _, _, dhp, dhpT, df1b = ops.gemm_bf16p(dop, mlp_pk[3], M, mh, E, act=act, mode=EPI_DACT, aux=Hpre,
+                                                   pack_rows=True, pack_trans=True, colsum=True,
+                                                   colsum_out=s_f1b.out(), store=False)
             del dop, dopT
-            dhp, dhpT, df1b = ops.bf16_pack_both(dHpre, want_colsum=True, colsum_out=s_f1b.out())
-            del dHpre
             df1w, _ = ops.gemm_bf16p(dhpT, xn2, mh, E, M, out=s_f1w.out())
             df1w, df1b = s_f1w.done(df1w.view(mh, E, 1, 1)), s_f1b.done(df1b)
             dxn2, _ = ops.gemm_bf16p(dhp, mlp_pk[1], M, E, mh)

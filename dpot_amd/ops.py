@@ -250,21 +250,31 @@ def bf16_pack_both(x: Tensor, want_rows: bool = True, want_trans: bool = True, c
 def gemm_bf16p(Ap: Tensor, Wp: Tensor, M: int, N: int, K: int, *, bias: Optional[Tensor] = None, act: int = 0,
                mode: int = EPI_LINEAR, aux: Optional[Tensor] = None, res: Optional[Tensor] = None,
                save_pre: bool = False, out: Optional[Tensor] = None, splitk: Optional[int] = None,
-               planes: int = 1) -> Tuple[Tensor, Optional[Tensor]]:
+               planes: int = 1, pack_rows: bool = False, pack_trans: bool = False, colsum: bool = False,
+               colsum_out: Optional[Tensor] = None, store: bool = True):
     """C[M,N] fp32 = epilogue(A @ Wt^T) on the bf16 matrix cores; Ap / Wp: packed bf16 operands (bf16_pack_rows, or a
     bf16 PanelPacks buffer) with the same number of planes (1: plain bf16, 3: bf16x6 = fp32-accurate).
-    splitk=None: the library's choice (weight gradients use split-K)."""
+    splitk=None: the library's choice (weight gradients use split-K).  Returns (C, pre).
+    pack_rows / pack_trans / colsum (planes == 1, M % 32 == 0): the epilogue also emits the packed forms of the output
+    and its column sums; store=False skips the fp32 output.  Returns (C | None, pre, row pack, transposed pack, colsum)."""
     lib = _lib.load()
-    C_ = _out(out, (M, N), Ap.device)
-    pre = torch.empty_like(C_) if save_pre else None
+    packs = pack_rows or pack_trans or colsum
+    C_ = _out(out, (M, N), Ap.device) if (store or not packs) else None
+    pre = torch.empty(M, N, dtype=torch.float32, device=Ap.device) if save_pre else None
     if splitk is None:
-        splitk = lib.dpot_gemm_bf16p_splitk(M, N, K)
+        splitk = 1 if packs else lib.dpot_gemm_bf16p_splitk(M, N, K)
     ws = torch.empty(splitk * M * N, dtype=torch.float32, device=Ap.device) if splitk > 1 else None
+    pr = torch.empty(lib.dpot_bf16_packed_elems(M, N, 1), dtype=torch.bfloat16, device=Ap.device) if pack_rows else None
+    pt = torch.empty(lib.dpot_bf16_packed_elems(N, M, 1), dtype=torch.bfloat16, device=Ap.device) if pack_trans else None
+    part = torch.empty(M // 32, N, dtype=torch.float32, device=Ap.device) if colsum else None
     check(lib.dpot_gemm_bf16p(Ap.data_ptr(), Wp.data_ptr(), _p(bias), _p(aux),
                               aux.stride(0) if aux is not None else 0, _p(res),
-                              res.stride(0) if res is not None else 0, _p(pre), N, C_.data_ptr(), N, M, N, K,
-                              act, mode, planes, splitk, _p(ws), _stream()), "gemm_bf16p")
-    return C_, pre
+                              res.stride(0) if res is not None else 0, _p(pre), N, _p(C_), N, M, N, K,
+                              act, mode, planes, splitk, _p(ws), _p(pr), _p(pt), _p(part), _stream()), "gemm_bf16p")
+    if not packs:
+        return C_, pre
+    cs = globals()["colsum"](part, M // 32, N, out=colsum_out) if colsum else None
+    return C_, pre, pr, pt, cs
 
 
 def linear_fwd(x: Tensor, W: Tensor, bias: Optional[Tensor], act: int = 0, save_pre: bool = False,

@@ -406,7 +406,11 @@ int dpot_bf16_pack_jobs(const dpot_pack_job* jobs_dev, int njobs, int max_elems,
 int dpot_gemm_bf16p_supported(int M, int N, int K);
 int dpot_gemm_bf16p(const void* Apacked, const void* Wpacked, const float* bias, const float* aux, int ldaux,
                     const float* res, int ldres, float* pre, int ldpre, float* C, int ldc, int M, int N, int K, int act,
-                    int epi_mode, int planes, int splitk, float* workspace, dpot_stream_t stream);
+                    int epi_mode, int planes, int splitk, float* workspace, void* out_rows, void* out_trans,
+                    float* colsum_part, dpot_stream_t stream);
+/* out_rows / out_trans / colsum_part (all optional, planes == 1, splitk <= 1, M % 32 == 0): the epilogue also emits the
+ * 1-plane packs of the FINAL output (row form [M, N]; transposed form = rows N, k M) and partial column sums
+ * [M/32, N] - the next GEMMs of a chain then need no pack pass over this output; C may be NULL in that case. */
 /* split-K factor the library recommends for a shape (weight gradients: few output tiles, K = tokens); splitk > 1 needs
  * a workspace of splitk*M*N floats, summed in a fixed order by a second launch (deterministic) */
 int dpot_gemm_bf16p_splitk(int M, int N, int K);

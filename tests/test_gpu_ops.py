@@ -845,3 +845,23 @@ def test_bf16_mlp_pack_both_path_matches_separate_packs(ops, monkeypatch):
                 assert_close(g1[n], g0[n], n, rtol=1e-5, atol_scale=1e-6)
             else:
                 assert torch.equal(g0[n], g1[n]), n
+
+
+def test_gemm_bf16_panel_packed_epilogue_outputs(ops):
+    """the bf16 panel GEMM can emit its output as packed operands (row form, transposed form) + partial column sums:
+    bit-identical to packing the fp32 output afterwards; the fp32 store can be skipped"""
+    M, N, K = 256, 512, 256
+    A, W, b = rnd(M, K, seed=1), rnd(N, K, seed=2, scale=1.0 / math.sqrt(K)), rnd(N, seed=3, scale=0.3)
+    Wd = W.cuda()
+    pk = ops.PanelPacks([(Wd, N, K, K, False)], bf16=True)
+    pk.refresh()
+    Ap = ops.bf16_pack_rows(A.cuda())
+    y, pre = ops.gemm_bf16p(Ap, pk.bufs[0], M, N, K, bias=b.cuda(), act=1, mode=ops.EPI_ACT, save_pre=True)
+    y2, pre2, pr, pt, cs = ops.gemm_bf16p(Ap, pk.bufs[0], M, N, K, bias=b.cuda(), act=1, mode=ops.EPI_ACT, save_pre=True,
+                                          pack_rows=True, pack_trans=True, colsum=True)
+    assert torch.equal(y, y2) and torch.equal(pre, pre2)
+    assert torch.equal(pr, ops.bf16_pack_rows(y)) and torch.equal(pt, ops.bf16_pack_rows(y, trans=True))
+    assert_close(cs, y.double().sum(0), "colsum", rtol=2e-5, atol_scale=2e-6)
+    y3, _, pr3, pt3, cs3 = ops.gemm_bf16p(Ap, pk.bufs[0], M, N, K, bias=b.cuda(), act=1, mode=ops.EPI_ACT,
+                                          pack_trans=True, store=False)
+    assert y3 is None and pr3 is None and cs3 is None and torch.equal(pt3, pt)
