@@ -24,7 +24,7 @@ MODES = [("f32", None), ("auto", None), ("f32", "bf16x6"), ("f32", "bf16")]     
 def main():
     for key in (sys.argv[1:] or ["T", "S", "M", "L", "L20"]):
         kw, B, T_ar = CFGS[key]
-        for gp, mp in (MODES if T_ar == 1 else MODES[:2]):
+        for gp, mp in (MODES if T_ar == 1 else [MODES[0], MODES[1], MODES[3]]):
             torch.manual_seed(0)
             ops.set_gemm_precision(gp)
             ops.set_mlp_precision(mp)
