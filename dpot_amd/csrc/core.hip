@@ -23,5 +23,5 @@ int check_launch(const char* what) {
 
 }  // namespace dpot
 
-extern "C" int dpot_version(void) { return 100; /* 0.1.0 */ }
+extern "C" int dpot_version(void) { return 200; /* 0.2.0: round 2 ABI (panel / bf16 / weight-gradient GEMMs, fused AFNO MLP, implicit embed) */ }
 extern "C" const char* dpot_last_error(void) { return dpot::g_err; }
