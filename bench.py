@@ -82,13 +82,23 @@ def mixer_roofline(model, B: int):
         b1 = torch.randn(nb, N, device="cuda") * 0.1
         b2 = torch.randn(nb, N, device="cuda") * 0.1
 
-        if fused:
+        three = fused and ops.afno_mlp3_supported(nb, bs)
+        if three:
+            # the three-product kernel takes the (Wr, Wi) fragment packs that the model's AfnoPacks writes
+            wc1 = torch.randn(2, nb, bs, bs, device="cuda") * 0.05
+            wc2 = torch.randn(2, nb, bs, bs, device="cuda") * 0.05
+            bc1 = torch.randn(2, nb, bs, device="cuda") * 0.1
+            bc2 = torch.randn(2, nb, bs, device="cuda") * 0.1
+            pk = ops.AfnoPacks([(wc1, bc1), (wc2, bc2)])
+            (_, b1, W1f, _), (_, b2, W2f, _) = pk.refresh()
+        elif fused:
             W1f, _ = ops.afno_block_weights(W1)
             W2f, _ = ops.afno_block_weights(W2)
 
         def run(train: bool):
             if fused:
-                return ops.afno_mlp2(S, W1f, b1, W2f, b2, nb, bs, 1, mode=0, want_pre=train, want_mid=train)
+                return ops.afno_mlp2(S, W1f, b1, W2f, b2, nb, bs, 1, mode=0, want_pre=train, want_mid=train,
+                                     layout=1 if three else 0)
             O1, O1pre, O2 = torch.empty_like(S), torch.empty_like(S), torch.empty_like(S)
             kw = dict(lda=2 * E, ldb=N, ldc=2 * E, batch=nb, strideA=N, strideB=N * N, strideC=N, strideBias=N, tag=1)
             ops.gemm(S, W1, O1, Mm, N, N, bias=b1, act=1, mode=ops.EPI_ACT, preact=O1pre, ldpre=2 * E, stridePre=N, **kw)
@@ -129,9 +139,16 @@ def mixer_roofline(model, B: int):
     except Exception:
         pass
     return {
-        "kernel": ("dpot::afno_mlp2_kernel<RT,NT> (AFNO mixer: BOTH layers of the block-diagonal complex MLP in one "
+        "kernel": ("dpot::afno_mlp3_kernel<RT> (AFNO mixer: BOTH layers of the block-diagonal complex MLP in one launch, "
+                   "each complex product as THREE real ones - P1 = Sr Wr, P2 = Si Wi, P3 = (Sr+Si)(Wr+Wi) - on "
+                   "v_mfma_f32_16x16x4_f32, intermediate kept in LDS)") if three else
+                  ("dpot::afno_mlp2_kernel<RT,NT> (AFNO mixer: BOTH layers of the block-diagonal complex MLP in one "
                    "launch - X W1 + b1 -> GELU -> W2 + b2 on v_mfma_f32_16x16x4_f32, intermediate kept in LDS)")
         if fused else "dpot::gemm_f32_kernel<64,64,NN,vec,TAG=1> x 2 (un-fused fallback)",
+        "executed_flops_per_launch": flops * (0.75 if three else 1.0),
+        "flops_note": ("flops_per_launch / achieved / frac count the ALGORITHMIC work (SURVEY 8d: 151.0 MFLOP per sample = "
+                       "four real products per complex product); the kernel executes 3/4 of it (Gauss's three-product "
+                       "complex multiplication), i.e. its matrix pipes run at 0.75 x achieved") if three else None,
         "bound": "mfma", "achieved": round(achieved, 2), "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
         "frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": traffic,
         "traffic_note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), (2*FETCH+WRITE)*1024 B; the training "

@@ -72,9 +72,10 @@ SIGNATURES = {
     "dpot_afno_pack_multi": (c_i, [C.POINTER(C.c_void_p)] * 4 + [c_i, c_i, c_i, c_fp]),
     "dpot_afno_unpack_grad": (c_i, [c_fp] * 4 + [c_i, c_i, c_fp]),
     "dpot_afno_mlp2_supported": (c_i, [c_i, c_i]),
-    "dpot_afno_mlp2": (c_i, [c_fp] * 9 + [c_i] * 7 + [c_fp]),
+    "dpot_afno_mlp2": (c_i, [c_fp] * 9 + [c_i] * 8 + [c_fp]),
+    "dpot_afno_mlp3_supported": (c_i, [c_i, c_i]),
     "dpot_afno_block_weights": (c_i, [c_fp] * 3 + [c_i, c_i, c_fp]),
-    "dpot_afno_pack_all": (c_i, [c_fp, c_i, c_i, c_i, c_fp]),
+    "dpot_afno_pack_all": (c_i, [c_fp, c_i, c_i, c_i, c_i, c_fp]),
     "dpot_groupnorm_fwd": (c_i, [c_fp] * 6 + [c_i] * 4 + [c_f, c_fp]),
     "dpot_groupnorm_bwd": (c_i, [c_fp] * 10 + [c_i] * 4 + [c_fp]),
     "dpot_patchify": (c_i, [c_fp] * 5 + [c_i] * 6 + [c_fp]),

@@ -373,6 +373,321 @@ __global__ __launch_bounds__(64 * (NW + 2)) void afno_mlp2_kernel(const AfnoMlpA
   epilogue(false, p.bb);
 }
 
+// =====================================================================================================================
+// The same two-layer complex MLP with THREE real products per complex product instead of four (Gauss / Karatsuba):
+//      (Sr + i Si)(Wr + i Wi):   P1 = Sr Wr,  P2 = Si Wi,  P3 = (Sr + Si)(Wr + Wi)   ->   re = P1 - P2,  im = P3 - P1 - P2
+// 25 % fewer MFMAs (and 25 % fewer weight bytes) for bs = 128 (DPOT-Ti / S / M).  The backward data path is the same
+// complex product with (Wr^T, -Wi^T), so only the packed weights differ.  Same machinery as afno_mlp2_kernel (panels,
+// loader waves, LDS-DMA, ring of three slabs, one barrier per 16-k slab, Y1 in LDS) with these differences:
+//   * K runs over bs = 128 (8 slabs per layer); a slab holds the Wr and Wi fragments (16 tiles = 16 KiB) and - layer 1 -
+//     the Sr and Si pieces of the panel (16 rows x 64 B per DMA instruction, XOR-swizzled on the source address);
+//   * compute wave w owns column tile w (16 columns) of P1, P2 AND P3: 3 * RT accumulators, recombined in the epilogue
+//     into 16 real + 16 imaginary output columns - no cross-wave traffic;
+//   * per slab: G1 = P1 += a_r b_r, G2 = P2 += a_i b_i, a_s = a_r + a_i and b_s = b_r + b_i on the VALU, then the
+//     fragments of the next slab are fetched into the freed registers under G3 = P3 += a_s b_s  (60 MFMAs per slab
+//     and wave at RT = 5).
+// Rounding: the imaginary part is a difference of three fp32 sums instead of a sum of two - error bound ~2x the direct
+// form's, measured ~1e-6 relative on DPOT data (tests: same tolerances as the four-product kernel).
+// Packed weights (dpot_afno_pack_all, layout 1): [block][slab t][part][col tile c][4*l + e] =
+//      W_part[k = 16t + 4(l>>4) + e][n = 16c + (l&15)],   forward: (Wr, Wi);  backward: (Wr^T, -Wi^T).
+// =====================================================================================================================
+template <int RT, int ACTK>
+__global__ __launch_bounds__(640) void afno_mlp3_kernel(const AfnoMlpArgs p) {
+  constexpr int NW = 8;             // compute waves = 16-column tiles of one part
+  constexpr int BS = 128, N = 2 * BS;
+  constexpr int NSLAB = BS / 16;    // 16-k slabs per layer
+  constexpr int NCT = 16;           // 16-column tiles of Y1 (both parts)
+  constexpr int WSL = 16 * 256;     // floats of a weight slab: [part][c][256]
+  constexpr int XSL = 2 * RT * 256; // floats of an X slab: [part][row tile][16 rows][16 k]
+  constexpr int WB = 8, XB = RT;    // DMA pieces per slab and loader wave
+  __shared__ __attribute__((aligned(16))) float lds[3 * WSL + 3 * XSL + RT * NCT * 256 + 256];
+  float* const Wr_ = lds;                   // ring [3][part][c][256]
+  float* const Xb = lds + 3 * WSL;          // ring [3][part][RT][256]
+  float* const Y1 = Xb + 3 * XSL;           // [RT][NCT][256]
+  float* const sink = Y1 + RT * NCT * 256;  // 1 KiB nobody reads: target of the aux prefetch DMA
+  float* const stage_all = lds + ((NSLAB - 1) % 3) * WSL;      // epilogue staging: [NW][16][32] = one weight slab
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int fr = lane & 15, fq = lane >> 4;
+
+  const int nitems = p.nb * p.panels;
+  int item;
+  {
+    const int bid = blockIdx.x, xcd = bid & 7, slot = bid >> 3;
+    const int q = nitems >> 3, r = nitems & 7;
+    item = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + slot;
+  }
+  const int kblk = item / p.panels, panel = item - kblk * p.panels;
+  const int row0 = panel * (16 * RT);
+
+  auto bar = [&]() __attribute__((always_inline)) {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+  };
+
+  if (wave >= NW) {
+    // ================================ loader waves ================================
+    const int L = wave - NW;
+    const float* X = p.X + (long long)kblk * N;
+    const float* Wa_l = p.Wa + (long long)kblk * (NSLAB * WSL) + lane * 4;
+    const float* Wb_l = p.Wb + (long long)kblk * (NSLAB * WSL) + lane * 4;
+    auto issue_w = [&](int g, float* dstbuf) __attribute__((always_inline)) {   // global slab index g (layer 2: g >= NSLAB)
+      const float* Wl = g < NSLAB ? Wa_l + g * WSL : Wb_l + (g - NSLAB) * WSL;
+#pragma unroll
+      for (int n = 0; n < WB; ++n) {
+        const int pc = L + 2 * n;
+        glds16(Wl + pc * 256, dstbuf + pc * 256);
+      }
+    };
+    // X piece q = (part = q / RT, row tile i = q % RT): 16 rows x 64 B; lane (r = l >> 2, c = l & 3) fetches the 16-byte
+    // chunk c ^ ((r >> 2) & 3) of its row (conflict-free fragment reads of the lane-linear image)
+    long long xoff[XB];
+#pragma unroll
+    for (int n = 0; n < XB; ++n) {
+      const int q = L + 2 * n;
+      const int part = q / RT, i = q - part * RT;
+      const int r = lane >> 2;
+      int row = row0 + 16 * i + r;
+      row = row < p.M ? row : p.M - 1;                  // clamped: rows past M only feed outputs that are never stored
+      xoff[n] = (long long)row * p.ldx + part * BS + 4 * ((lane & 3) ^ ((r >> 2) & 3));
+    }
+    auto issue_x = [&](int t, float* dstbuf) __attribute__((always_inline)) {
+#pragma unroll
+      for (int n = 0; n < XB; ++n) glds16(X + xoff[n] + 16 * t, dstbuf + (L + 2 * n) * 256);
+    };
+    // three slabs ahead; before a barrier everything except the newest batch has landed (see afno_mlp2_kernel)
+    issue_x(0, Xb);
+    issue_w(0, Wr_);
+    issue_x(1, Xb + XSL);
+    issue_w(1, Wr_ + WSL);
+    issue_x(2, Xb + 2 * XSL);
+    issue_w(2, Wr_ + 2 * WSL);
+    wait_vm<WB + XB>();
+    bar();                                              // P: slabs 0 and 1 have landed
+    int ring = 0;                                       // ring buffer of global slab g + 3 (= g % 3)
+#pragma unroll 1
+    for (int g = 0; g < 2 * NSLAB; ++g) {
+      bar();                                            // B_g  (g == NSLAB: the barrier after epilogue 1)
+      const int nx = g + 3;
+      // after B_(NSLAB-1) the target ring[(NSLAB+2)%3] is epilogue 1's staging area: that slab goes out one barrier late
+      const bool has_w = nx < 2 * NSLAB && g != NSLAB - 1;
+      const bool has_x = nx < NSLAB;
+      if (has_x) issue_x(nx, Xb + ring * XSL);
+      if (g == NSLAB) issue_w(nx - 1, Wr_ + (ring == 0 ? 2 : ring - 1) * WSL);
+      if (has_w) issue_w(nx, Wr_ + ring * WSL);
+      ring = ring == 2 ? 0 : ring + 1;
+      if (has_w && has_x) wait_vm<WB + XB>();
+      else if (has_w) wait_vm<WB>();
+      else wait_vm<0>();
+    }
+    bar();                                              // S2
+    return;
+  }
+
+  // ================================ compute waves ================================
+  f32x4 P1[RT], P2[RT], P3[RT];
+  auto zero_acc = [&]() __attribute__((always_inline)) {
+#pragma unroll
+    for (int i = 0; i < RT; ++i) P1[i] = P2[i] = P3[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  };
+  // weight fragments of this wave's column tile: (b_r, b_i) of the slab in ring buffer `rb`
+  auto read_w = [&](f32x4 (&b)[2], int rb) __attribute__((always_inline)) {
+    b[0] = *reinterpret_cast<const f32x4*>(Wr_ + rb * WSL + wave * 256 + lane * 4);
+    b[1] = *reinterpret_cast<const f32x4*>(Wr_ + rb * WSL + (8 + wave) * 256 + lane * 4);
+  };
+  const int xfrag = fr * 16 + 4 * (fq ^ ((fr >> 2) & 3));
+  auto read_x = [&](f32x4 (&ar)[RT], f32x4 (&ai)[RT], int rb) __attribute__((always_inline)) {
+    const float* xs = Xb + rb * XSL + xfrag;
+#pragma unroll
+    for (int i = 0; i < RT; ++i) {
+      ar[i] = *reinterpret_cast<const f32x4*>(xs + i * 256);
+      ai[i] = *reinterpret_cast<const f32x4*>(xs + (RT + i) * 256);
+    }
+  };
+  auto read_y = [&](f32x4 (&ar)[RT], f32x4 (&ai)[RT], int u) __attribute__((always_inline)) {
+#pragma unroll
+    for (int i = 0; i < RT; ++i) {
+      ar[i] = *reinterpret_cast<const f32x4*>(Y1 + ((i * NCT + u) * 64 + fq * 16 + ((fr + u + 8 * (fq >> 1)) & 15)) * 4);
+      ai[i] = *reinterpret_cast<const f32x4*>(Y1 + ((i * NCT + u + 8) * 64 + fq * 16 + ((fr + u + 8 + 8 * (fq >> 1)) & 15)) * 4);
+    }
+  };
+  auto g12 = [&](const f32x4 (&ar)[RT], const f32x4 (&ai)[RT], const f32x4 (&b)[2]) __attribute__((always_inline)) {
+#pragma unroll
+    for (int i = 0; i < RT; ++i)
+#pragma unroll
+      for (int s2 = 0; s2 < 4; ++s2) {
+        P1[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(ar[i][s2], b[0][s2], P1[i], 0, 0, 0);
+        P2[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(ai[i][s2], b[1][s2], P2[i], 0, 0, 0);
+      }
+  };
+  auto g3 = [&](const f32x4 (&as)[RT], const f32x4& bs) __attribute__((always_inline)) {
+#pragma unroll
+    for (int i = 0; i < RT; ++i)
+#pragma unroll
+      for (int s2 = 0; s2 < 4; ++s2) P3[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(as[i][s2], bs[s2], P3[i], 0, 0, 0);
+  };
+
+  // ---- epilogue: (P1, P2, P3) -> 16 real + 16 imaginary columns (+bias) -> [pre] -> f -> [mid] -> Y1 (layer 1) / Y
+  float* const stage = stage_all + wave * 512;          // [16 rows][32]: columns 0-15 real, 16-31 imaginary
+  auto epilogue = [&](bool first, const float* __restrict__ bias) __attribute__((always_inline)) {
+    // compiler barrier: without it the bias loads and the epilogue's address arithmetic are hoisted above the slab loop,
+    // where every register is taken, and spilled across it (17 MB of scratch traffic per launch in the L2 counters)
+    // the epilogue's index arithmetic hangs off an OPAQUE copy of the lane id: everything derived from it is computed
+    // here, after the slab loops (hoisted above them - where every register is taken - it was spilled across them)
+    int ln = lane;
+    asm volatile("" : "+v"(ln)::"memory");
+    const int efr = ln & 15, efq = ln >> 4;
+    // chunk g = it*64 + lane of the 16 x 32 tile: row g / 8, staged columns 4*(g % 8) .. +3 -> block column
+    // (part = staged col / 16) * BS + 16*wave + staged col % 16
+    float4 b4[2];
+    int bcol[2];
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+      const int c4 = (it * 64 + ln) & 7;
+      bcol[it] = (c4 >> 2) * BS + 16 * wave + 4 * (c4 & 3);
+      b4[it] = bias ? *reinterpret_cast<const float4*>(bias + kblk * N + bcol[it]) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    auto tile = [&](auto Ic) __attribute__((always_inline)) {
+      constexpr int i = decltype(Ic)::value;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float re = P1[i][e] - P2[i][e];
+        const float im = P3[i][e] - P1[i][e] - P2[i][e];
+        stage[(4 * efq + e) * 32 + efr] = re;
+        stage[(4 * efq + e) * 32 + 16 + efr] = im;
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+      for (int it = 0; it < 2; ++it) {
+        const int g = it * 64 + ln;
+        const int r = g >> 3;
+        const f32x4 t = *reinterpret_cast<const f32x4*>(stage + g * 4);
+        float v[4] = {t[0] + b4[it].x, t[1] + b4[it].y, t[2] + b4[it].z, t[3] + b4[it].w};
+        const int row = row0 + 16 * i + r;
+        const int col = bcol[it];
+        const bool ok = row < p.M;
+        const int rowc = ok ? row : p.M - 1;
+        const long long go = (long long)rowc * p.ldo + (long long)kblk * N + col;
+        if (first) {
+          if (p.mode == 0) {
+            if (p.pre && ok) *reinterpret_cast<float4*>(p.pre + go) = make_float4(v[0], v[1], v[2], v[3]);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = ACTK == DPOT_ACT_GELU ? gelu_fwd(v[e]) : act_fwd(p.act, v[e]);
+          } else {
+            const float4 x4 = *reinterpret_cast<const float4*>(p.aux + go);
+            const float xs[4] = {x4.x, x4.y, x4.z, x4.w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] *= ACTK == DPOT_ACT_GELU ? gelu_bwd(xs[e]) : act_bwd(p.act, xs[e]);
+          }
+          if (p.mid && ok) *reinterpret_cast<float4*>(p.mid + go) = make_float4(v[0], v[1], v[2], v[3]);
+          const int s = col >> 4, kq = (col >> 2) & 3;
+          *reinterpret_cast<f32x4*>(Y1 + ((i * NCT + s) * 64 + kq * 16 + ((r + s + 8 * (kq >> 1)) & 15)) * 4) =
+              (f32x4){v[0], v[1], v[2], v[3]};
+        } else {
+          if (ok) *reinterpret_cast<float4*>(p.Y + go) = make_float4(v[0], v[1], v[2], v[3]);
+        }
+      }
+      __builtin_amdgcn_wave_barrier();
+    };
+    tile(std::integral_constant<int, 0>{});
+    if constexpr (RT > 1) tile(std::integral_constant<int, 1>{});
+    if constexpr (RT > 2) tile(std::integral_constant<int, 2>{});
+    if constexpr (RT > 3) tile(std::integral_constant<int, 3>{});
+    if constexpr (RT > 4) tile(std::integral_constant<int, 4>{});
+  };
+
+  // one slab: G1, G2 on the current fragments, sums on the VALU, next slab's fragments into the freed registers, G3.
+  // (B0 is dead once b_s is formed: ONE weight-fragment set.  At RT = 5 the kernel sits at the 168 VGPRs a 10-wave
+  // workgroup leaves per wave and the allocator spills ~30 registers per lane AROUND the epilogues - not in the slab
+  // loops; forming a_s in place of a_r to save 20 registers made the allocation worse, not better.)
+  f32x4 AR[RT], AI[RT], AS[RT], B0[2];
+  auto sums = [&](const f32x4 (&b)[2], f32x4& bs) __attribute__((always_inline)) {
+#pragma unroll
+    for (int i = 0; i < RT; ++i) AS[i] = AR[i] + AI[i];
+    bs = b[0] + b[1];
+  };
+
+  // backward data path: epilogue 1 multiplies by act'(aux), and aux (the forward's pre-activation, written a whole
+  // forward + half a backward ago) comes from HBM.  Pull this wave's part of it towards L2 now: LDS-DMA into a sink
+  // nobody reads (no registers, no wait; the compute waves have no counted vmcnt).
+  if (p.mode == 1) {
+    // 16 rows x (64 B real + 64 B imaginary) per row tile = 2 instructions: lane -> (row, part, 16-byte chunk)
+#pragma unroll
+    for (int i = 0; i < RT; ++i)
+#pragma unroll
+      for (int h2 = 0; h2 < 2; ++h2) {
+        const int id = h2 * 64 + lane;
+        int row = row0 + 16 * i + (id >> 3);
+        row = row < p.M ? row : p.M - 1;
+        const int part = (id >> 2) & 1, c = id & 3;
+        glds16(p.aux + (long long)row * p.ldo + (long long)kblk * N + part * BS + 16 * wave + 4 * c, sink);
+      }
+  }
+
+  // ================= layer 1 =================
+  zero_acc();
+  bar();                                               // P
+  read_x(AR, AI, 0);
+  read_w(B0, 0);
+  {
+    int r1 = 1, r2 = 2;                                // ring buffers of slabs t+1, t+2
+#pragma unroll 1
+    for (int t = 0; t < NSLAB; t += 2) {
+      f32x4 bs;
+      bar();                                           // B_t: slab t+1 has landed
+      g12(AR, AI, B0);
+      sums(B0, bs);
+      read_x(AR, AI, r1);
+      read_w(B0, r1);
+      g3(AS, bs);
+      bar();                                           // B_(t+1)
+      g12(AR, AI, B0);
+      sums(B0, bs);
+      if (t + 2 < NSLAB) read_x(AR, AI, r2);
+      read_w(B0, r2);                                  // t + 2 == NSLAB: the first weight slab of layer 2
+      g3(AS, bs);
+      r1 = r1 == 0 ? 2 : r1 - 1;
+      r2 = r2 == 0 ? 2 : r2 - 1;
+    }
+  }
+  epilogue(true, p.ba);
+  bar();                                               // B_NSLAB (S1): Y1 complete
+
+  // ================= layer 2 =================
+  zero_acc();
+  {
+    int r1 = (NSLAB + 1) % 3, r2 = (NSLAB + 2) % 3;
+    read_y(AR, AI, 0);                                 // (B0: fetched during the last slab of layer 1)
+#pragma unroll 1
+    for (int u = 0; u < NSLAB; u += 2) {
+      f32x4 bs;
+      if (u > 0) bar();                                // B_(NSLAB+u)
+      g12(AR, AI, B0);
+      sums(B0, bs);
+      read_y(AR, AI, u + 1);
+      read_w(B0, r1);
+      g3(AS, bs);
+      bar();                                           // B_(NSLAB+u+1)
+      g12(AR, AI, B0);
+      sums(B0, bs);
+      if (u + 2 < NSLAB) {
+        read_y(AR, AI, u + 2);
+        read_w(B0, r2);
+      }
+      g3(AS, bs);
+      r1 = r1 == 0 ? 2 : r1 - 1;
+      r2 = r2 == 0 ? 2 : r2 - 1;
+    }
+  }
+  bar();                                               // S2
+  epilogue(false, p.bb);
+}
+
 // Wbig [J][N][N] (row-major, as dpot_afno_pack writes it: W[k][n]) -> fragment-block-major copies
 //   fwd[j][c][t][4*l + e] = W[k = 16t + 4(l>>4) + e][n = 16c + (l&15)]     (Wt = W^T: the forward multiplies by W)
 //   bwd[j][c][t][4*l + e] = W[16c + (l&15)][16t + 4(l>>4) + e]             (Wt = W:   the backward multiplies by W^T)
@@ -397,9 +712,31 @@ __global__ __launch_bounds__(256) void afno_block_weights_kernel(const float* __
 // layer): w [2, nb, bs, bs], b [2, nb, bs] (models/dpot.py:45-48) ->
 //   wbig [nb][N][N] = [[Wr, Wi], [-Wi, Wr]] (row-major W[k][n]; the generic GEMM fallback and the tests use it),
 //   bbig [nb][N] = [br | bi],  fwd / bwd = fragment-block-major W and W^T (see afno_block_weights_kernel)
-__global__ __launch_bounds__(256) void afno_pack_all_kernel(const dpot_afno_pack_job* __restrict__ jobs, int nb, int bs) {
+// layout 1 (three-product kernel, bs = 128): fwd / bwd hold [block][slab t][part][col tile c][4*l + e] =
+//   W_part[k = 16t + 4(l>>4) + e][n = 16c + (l&15)],  fwd: (Wr, Wi),  bwd: (Wr^T, -Wi^T)  - half the size of layout 0
+__global__ __launch_bounds__(256) void afno_pack_all_kernel(const dpot_afno_pack_job* __restrict__ jobs, int nb, int bs,
+                                                            int layout) {
   const dpot_afno_pack_job job = jobs[blockIdx.y];
   const int N = 2 * bs, nct = N / 16;
+  if (layout == 1) {
+    const int nsl = bs / 16;                              // slabs = column tiles per part
+    const long long nP = (long long)nb * 2 * bs * bs;
+    const long long plane1 = (long long)nb * bs * bs;
+    for (long long idx = blockIdx.x * 256ll + threadIdx.x; idx < nP; idx += (long long)gridDim.x * 256) {
+      const int e = (int)(idx & 3), l = (int)((idx >> 2) & 63);
+      long long blk = idx >> 8;
+      const int c = (int)(blk % nsl);
+      blk /= nsl;
+      const int part = (int)(blk & 1);
+      blk >>= 1;
+      const int t = (int)(blk % nsl);
+      const int k = (int)(blk / nsl);
+      const int kk = 16 * t + 4 * (l >> 4) + e, n = 16 * c + (l & 15);
+      const float* wp = job.w + part * plane1 + (long long)k * bs * bs;
+      if (job.fwd) job.fwd[idx] = wp[(long long)kk * bs + n];
+      if (job.bwd) job.bwd[idx] = part ? -wp[(long long)n * bs + kk] : wp[(long long)n * bs + kk];
+    }
+  }
   const long long nW = (long long)nb * N * N;
   const long long plane = (long long)nb * bs * bs;
   for (long long idx = blockIdx.x * 256ll + threadIdx.x; idx < nW; idx += (long long)gridDim.x * 256) {
@@ -416,9 +753,9 @@ __global__ __launch_bounds__(256) void afno_pack_all_kernel(const dpot_afno_pack
     else v = job.w[wi];
     if (job.wbig) job.wbig[idx] = v;
     const long long base = (long long)k * N * N;
-    if (job.bwd)   // Wt = W: block (row tile r/16, slab c/16), chunk (row r%16, k-quad (c%16)/4)
+    if (job.bwd && layout == 0)   // Wt = W: block (row tile r/16, slab c/16), chunk (row r%16, k-quad (c%16)/4)
       job.bwd[base + ((((long long)(r >> 4) * nct + (c >> 4)) * 64 + ((c & 15) >> 2) * 16 + (r & 15)) << 2) + (c & 3)] = v;
-    if (job.fwd)   // Wt = W^T: block (row tile c/16, slab r/16), chunk (row c%16, k-quad (r%16)/4)
+    if (job.fwd && layout == 0)   // Wt = W^T: block (row tile c/16, slab r/16), chunk (row c%16, k-quad (r%16)/4)
       job.fwd[base + ((((long long)(c >> 4) * nct + (r >> 4)) * 64 + ((r & 15) >> 2) * 16 + (c & 15)) << 2) + (r & 3)] = v;
   }
   for (long long idx = blockIdx.x * 256ll + threadIdx.x; idx < (long long)nb * N; idx += (long long)gridDim.x * 256) {
@@ -460,6 +797,18 @@ static int launch_rt(const AfnoMlpArgs& p, int rt, hipStream_t s) {
   }
   return check_launch("afno_mlp2_kernel");
 }
+template <int ACTK>
+static int launch3_rt(const AfnoMlpArgs& p, int rt, hipStream_t s) {
+  const dim3 grid((unsigned)(p.nb * p.panels)), blk(640);
+  switch (rt) {
+    case 1: hipLaunchKernelGGL((afno_mlp3_kernel<1, ACTK>), grid, blk, 0, s, p); break;
+    case 2: hipLaunchKernelGGL((afno_mlp3_kernel<2, ACTK>), grid, blk, 0, s, p); break;
+    case 3: hipLaunchKernelGGL((afno_mlp3_kernel<3, ACTK>), grid, blk, 0, s, p); break;
+    case 4: hipLaunchKernelGGL((afno_mlp3_kernel<4, ACTK>), grid, blk, 0, s, p); break;
+    default: hipLaunchKernelGGL((afno_mlp3_kernel<5, ACTK>), grid, blk, 0, s, p); break;
+  }
+  return check_launch("afno_mlp3_kernel");
+}
 template <int NW>
 static int launch_nw(const AfnoMlpArgs& p, int rt, hipStream_t s) {
   // GELU (the DPOT default) gets its own instantiation; every other activation goes through the run-time switch
@@ -486,19 +835,25 @@ extern "C" int dpot_afno_block_weights(const float* wbig, float* fwd, float* bwd
   return check_launch("afno_block_weights_kernel");
 }
 
-extern "C" int dpot_afno_pack_all(const dpot_afno_pack_job* jobs_dev, int njobs, int nb, int bs, dpot_stream_t stream) {
+extern "C" int dpot_afno_mlp3_supported(int nb, int bs) { return nb > 0 && bs == 128 ? 1 : 0; }
+
+extern "C" int dpot_afno_pack_all(const dpot_afno_pack_job* jobs_dev, int njobs, int nb, int bs, int layout,
+                                  dpot_stream_t stream) {
   DPOT_REQUIRE(jobs_dev && njobs > 0 && njobs <= 65535 && nb > 0 && bs > 0, "afno_pack_all: bad argument");
+  DPOT_REQUIRE(layout == 0 || (layout == 1 && dpot_afno_mlp3_supported(nb, bs)), "afno_pack_all: layout 1 needs bs == 128");
   DPOT_REQUIRE((2 * bs) % 16 == 0, "afno_pack_all: 2*bs must be a multiple of 16 for the blocked copies");
   long long g = ((long long)nb * 4 * bs * bs + 255) / 256;
   if (g > 1024) g = 1024;
-  hipLaunchKernelGGL(afno_pack_all_kernel, dim3((unsigned)g, njobs), dim3(256), 0, as_stream(stream), jobs_dev, nb, bs);
+  hipLaunchKernelGGL(afno_pack_all_kernel, dim3((unsigned)g, njobs), dim3(256), 0, as_stream(stream), jobs_dev, nb, bs,
+                     layout);
   return check_launch("afno_pack_all_kernel");
 }
 
 extern "C" int dpot_afno_mlp2(const float* X, const float* WaT, const float* ba, const float* WbT, const float* bb,
                               const float* aux, float* pre, float* mid, float* Y, int M, int nb, int bs, int ldx,
-                              int ldo, int act, int mode, dpot_stream_t stream) {
+                              int ldo, int act, int mode, int layout, dpot_stream_t stream) {
   DPOT_REQUIRE(X && WaT && WbT && Y && M > 0, "afno_mlp2: bad argument");
+  DPOT_REQUIRE(layout == 0 || (layout == 1 && dpot_afno_mlp3_supported(nb, bs)), "afno_mlp2: weight layout 1 needs bs == 128");
   DPOT_REQUIRE(dpot_afno_mlp2_supported(nb, bs), "afno_mlp2: unsupported block size bs=%d (2*bs must be 64/128/192/256)", bs);
   DPOT_REQUIRE(mode == 0 || (mode == 1 && aux != nullptr), "afno_mlp2: mode 1 (backward) needs aux");
   const int N = 2 * bs;
@@ -512,6 +867,7 @@ extern "C" int dpot_afno_mlp2(const float* X, const float* WaT, const float* ba,
   const int rt = pick_rt(M, nb);
   p.panels = (M + 16 * rt - 1) / (16 * rt);
   hipStream_t s = as_stream(stream);
+  if (layout == 1) return p.act == DPOT_ACT_GELU ? launch3_rt<DPOT_ACT_GELU>(p, rt, s) : launch3_rt<-1>(p, rt, s);
   switch (N / 64) {
     case 1: return launch_nw<2>(p, rt, s);
     case 2: return launch_nw<4>(p, rt, s);

@@ -268,7 +268,8 @@ def _mlp_panel_mode(mlp_pk, M, E, mh, mp) -> int:
     return 2 if ok else 0
 
 
-def _block_parts(x, n1w, n1b, n2w, n2b, f1w, f1b, packed, dims, mp, need_out, f2w=None, f2b=None, mlp_pk=None):
+def _block_parts(x, n1w, n1b, n2w, n2b, f1w, f1b, packed, dims, mp, need_out, f2w=None, f2b=None, mlp_pk=None,
+                 afno_layout=None):
     """forward of one Block up to (and optionally including) the second channel-MLP GEMM; returns every intermediate
     the backward needs.  Called by BlockFn.forward, and again by BlockFn.backward when activations are recomputed."""
     B, tok, E, h, w, nb, bs, mx, my, mh, act = dims
@@ -280,7 +281,10 @@ def _block_parts(x, n1w, n1b, n2w, n2b, f1w, f1b, packed, dims, mp, need_out, f2
     if wb1T is not None:
         # both layers of the block-diagonal complex MLP in ONE launch; the activated spectrum never leaves the CU
         # except as the copy saved for the backward (csrc/afno_mlp.hip)
-        O2, O1pre, O1 = ops.afno_mlp2(S, wb1T, bb1, wb2T, bb2, nb, bs, act, mode=0, want_pre=True, want_mid=True)
+        # (layout 1: the (Wr, Wi) fragment packs of the three-product kernel, tagged on the tensors by ops.AfnoPacks)
+        lay = afno_layout if afno_layout is not None else getattr(wb1T, "afno_layout", 0)
+        O2, O1pre, O1 = ops.afno_mlp2(S, wb1T, bb1, wb2T, bb2, nb, bs, act, mode=0, want_pre=True, want_mid=True,
+                                      layout=lay)
     else:
         O1 = torch.empty(Mm, 2 * E, dtype=torch.float32, device=dev)
         O1pre = torch.empty_like(O1)
@@ -360,6 +364,7 @@ class BlockFn(torch.autograd.Function):
             ctx.save_for_backward(x, *parts, wb1, wb2, n1w, n2w, f1w, f2w)
         ctx.recompute = recompute
         ctx.dims = dims
+        ctx.afno_layout = getattr(packed[0][2], "afno_layout", 0) if ctx.fused_mixer else 0
         ctx.mlp_precision = mp
         ctx.sinks = _sinks(ctx, (n1w, n1b, w1, b1, w2, b2, n2w, n2b, f1w, f1b, f2w, f2b), 1)
         return out.view(B, tok, E)
@@ -373,7 +378,7 @@ class BlockFn(torch.autograd.Function):
             with torch.no_grad():
                 _, parts = _block_parts(x, n1w, n1b, n2w, n2b, f1w, f1b,
                                         ((wb1, bb1, wb1T, None), (wb2, bb2, wb2T, None)), ctx.dims, mp, False,
-                                        mlp_pk=ctx.mlp_pk)
+                                        mlp_pk=ctx.mlp_pk, afno_layout=ctx.afno_layout)
             mean1, rstd1, S, O1pre, O1, y1, mean2, rstd2, xn2, Hpre, Hh = parts
         else:
             (x, mean1, rstd1, S, O1pre, O1, y1, mean2, rstd2, xn2, Hpre, Hh, wb1, wb2, n1w, n2w, f1w,
@@ -453,7 +458,8 @@ class BlockFn(torch.autograd.Function):
         if ctx.fused_mixer:
             # data path of both layers in one launch: dO1pre = (dO2 W2^T) * act'(O1pre), dS = dO1pre W1^T
             # (wb1 / wb2 hold the fragment-block-major W^T here)
-            dS, _, dO1pre = ops.afno_mlp2(dO2, wb2, None, wb1, None, nb, bs, act, mode=1, aux=O1pre, want_mid=True)
+            dS, _, dO1pre = ops.afno_mlp2(dO2, wb2, None, wb1, None, nb, bs, act, mode=1, aux=O1pre, want_mid=True,
+                                          layout=ctx.afno_layout)
         else:
             dO1pre = torch.empty(Mm, 2 * E, dtype=torch.float32, device=dev)
             ops.gemm(dO2, wb2, dO1pre, Mm, 2 * bs, 2 * bs, transB=True, act=act, mode=EPI_DACT, aux=O1pre,

@@ -404,6 +404,7 @@ class AfnoPacks:
         self.nb, self.bs, self.n = nb, bs, n
         self.key = tuple(t.data_ptr() for p in pairs for t in p)
         fused = afno_mlp2_supported(nb, bs)
+        self.layout = 1 if fused and afno_mlp3_supported(nb, bs) else 0      # three-product (Wr, Wi) fragment packs
         wbig = torch.empty(n, nb, N, N, dtype=torch.float32, device=dev)
         bbig = torch.empty(n, nb, N, dtype=torch.float32, device=dev)
         fwd = torch.empty_like(wbig) if fused else None
@@ -417,9 +418,13 @@ class AfnoPacks:
             tab[i].bwd = bwd[i].data_ptr() if fused else None
         self.table = torch.from_numpy(host).to(dev)
         self.items = [(wbig[i], bbig[i], fwd[i] if fused else None, bwd[i] if fused else None) for i in range(n)]
+        for it in self.items:           # the fused-kernel packs remember their layout (functional._block_parts reads it)
+            for t in it[2:]:
+                if t is not None:
+                    t.afno_layout = self.layout
 
     def refresh(self):
-        check(_lib.load().dpot_afno_pack_all(self.table.data_ptr(), self.n, self.nb, self.bs, _stream()),
+        check(_lib.load().dpot_afno_pack_all(self.table.data_ptr(), self.n, self.nb, self.bs, self.layout, _stream()),
               "afno_pack_all")
         return self.items
 
@@ -437,8 +442,14 @@ def afno_mlp2_supported(nb: int, bs: int) -> bool:
     return bool(_lib.load().dpot_afno_mlp2_supported(nb, bs)) and os.environ.get("DPOT_AFNO_FUSED", "1") != "0"
 
 
+def afno_mlp3_supported(nb: int, bs: int) -> bool:
+    """the three-product (Gauss / Karatsuba) form of the fused mixer kernel: bs == 128; DPOT_AFNO_3MULT=0 disables it"""
+    return bool(_lib.load().dpot_afno_mlp3_supported(nb, bs)) and os.environ.get("DPOT_AFNO_3MULT", "1") != "0"
+
+
 def afno_mlp2(X: Tensor, WaT: Tensor, ba: Optional[Tensor], WbT: Tensor, bb: Optional[Tensor], nb: int, bs: int,
-              act: int, mode: int = 0, aux: Optional[Tensor] = None, want_pre: bool = False, want_mid: bool = False):
+              act: int, mode: int = 0, aux: Optional[Tensor] = None, want_pre: bool = False, want_mid: bool = False,
+              layout: int = 0):
     """both layers of the AFNO block-diagonal complex MLP in one launch (csrc/afno_mlp.hip).
     mode 0: pre = X Wa + ba, mid = act(pre), Y = mid Wb + bb;  mode 1: mid = (X Wa) * act'(aux), Y = mid Wb.
     X / outputs: [M, nb*2*bs]; WaT / WbT: [nb, 2bs, 2bs] fragment-block-major weights from afno_block_weights (`fwd`
@@ -448,7 +459,8 @@ def afno_mlp2(X: Tensor, WaT: Tensor, ba: Optional[Tensor], WbT: Tensor, bb: Opt
     pre = torch.empty_like(X) if want_pre else None
     mid = torch.empty_like(X) if want_mid else None
     check(_lib.load().dpot_afno_mlp2(X.data_ptr(), WaT.data_ptr(), _p(ba), WbT.data_ptr(), _p(bb), _p(aux), _p(pre),
-                                     _p(mid), Y.data_ptr(), M, nb, bs, ld, ld, act, mode, _stream()), "afno_mlp2")
+                                     _p(mid), Y.data_ptr(), M, nb, bs, ld, ld, act, mode, layout, _stream()),
+          "afno_mlp2")
     return Y, pre, mid
 
 

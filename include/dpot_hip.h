@@ -322,11 +322,16 @@ int dpot_noise_inject_rng(const float* xx, float* out, float* norms, uint64_t* r
  * N x N matrices of the packed complex weights in FRAGMENT-BLOCK-MAJOR order, as written by dpot_afno_block_weights
  * from dpot_afno_pack's Wbig: its `fwd` output for mode 0 (multiply by Wbig), its `bwd` output for mode 1 (multiply
  * by Wbig^T).  pre / mid may be NULL (inference).  Supported when 2*bs is 64, 128, 192 or 256
- * (dpot_afno_mlp2_supported); everything 16-byte aligned. */
+ * (dpot_afno_mlp2_supported); everything 16-byte aligned.
+ * layout = 1 (bs == 128, dpot_afno_mlp3_supported): the THREE-product form of the complex multiplication
+ *   P1 = Sr Wr, P2 = Si Wi, P3 = (Sr+Si)(Wr+Wi) -> re = P1 - P2, im = P3 - P1 - P2   (25 % fewer MFMAs);
+ * Wa / Wb are then the (Wr, Wi) fragment packs written by dpot_afno_pack_all(layout = 1): `fwd` for mode 0, `bwd`
+ * (= Wr^T, -Wi^T) for mode 1.  Same outputs up to fp32 rounding (tests: same tolerance as layout 0). */
 int dpot_afno_mlp2_supported(int nb, int bs);
+int dpot_afno_mlp3_supported(int nb, int bs);
 int dpot_afno_mlp2(const float* X, const float* Wa, const float* ba, const float* Wb, const float* bb,
                    const float* aux, float* pre, float* mid, float* Y, int M, int nb, int bs, int ldx, int ldo,
-                   int act, int mode, dpot_stream_t stream);
+                   int act, int mode, int layout, dpot_stream_t stream);
 /* wbig [nmat][N][N] (row-major W[k][n]) -> [nmat][N/16][N/16][256] blocks of (16 n x 16 k), chunk l of a block =
  * (n = l&15, k = 4*(l>>4)..+3): fwd holds W (for X W), bwd holds W^T (for X W^T).  Either output may be NULL. */
 int dpot_afno_block_weights(const float* wbig, float* fwd, float* bwd, int nmat, int N, dpot_stream_t stream);
@@ -342,7 +347,7 @@ typedef struct dpot_afno_pack_job {
   float* bwd;
 } dpot_afno_pack_job;
 /* dpot_afno_pack + dpot_afno_block_weights for every layer of a model in ONE launch; the table lives in device memory */
-int dpot_afno_pack_all(const dpot_afno_pack_job* jobs_dev, int njobs, int nb, int bs, dpot_stream_t stream);
+int dpot_afno_pack_all(const dpot_afno_pack_job* jobs_dev, int njobs, int nb, int bs, int layout, dpot_stream_t stream);
 
 /* backward of the noise injection for AR steps whose input depends on earlier predictions:
  * dx = g + noise_scale * xx / norms[b,c] * sum_(X,Y,T)(g * eps).  eps: the tensor the forward used, or NULL with

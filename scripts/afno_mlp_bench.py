@@ -18,6 +18,15 @@ def bench(nb, bs, M, reps=50):
     forms = {"fwd-train": lambda: ops.afno_mlp2(S, W1f, b1, W2f, b2, nb, bs, 1, mode=0, want_pre=True, want_mid=True),
              "fwd-infer": lambda: ops.afno_mlp2(S, W1f, b1, W2f, b2, nb, bs, 1, mode=0),
              "bwd-data": lambda: ops.afno_mlp2(S, W2b, None, W1b, None, nb, bs, 1, mode=1, aux=pre, want_mid=True)}
+    if bs == 128 and os.environ.get("DPOT_AFNO_3MULT", "1") != "0":
+        # the three-product kernel on (Wr, Wi) fragment packs
+        w1 = torch.randn(2, nb, bs, bs, device="cuda") * 0.05; w2 = torch.randn(2, nb, bs, bs, device="cuda") * 0.05
+        c1 = torch.randn(2, nb, bs, device="cuda") * 0.1; c2 = torch.randn(2, nb, bs, device="cuda") * 0.1
+        pk = ops.AfnoPacks([(w1, c1), (w2, c2)])
+        (_, bb1, f1, k1), (_, bb2, f2, k2) = pk.refresh()
+        forms.update({"3mult fwd-train": lambda: ops.afno_mlp2(S, f1, bb1, f2, bb2, nb, bs, 1, mode=0, want_pre=True, want_mid=True, layout=1),
+                      "3mult fwd-infer": lambda: ops.afno_mlp2(S, f1, bb1, f2, bb2, nb, bs, 1, mode=0, layout=1),
+                      "3mult bwd-data": lambda: ops.afno_mlp2(S, k2, None, k1, None, nb, bs, 1, mode=1, aux=pre, want_mid=True, layout=1)})
     flops = 2 * 2.0 * M * N * N * nb
     out = []
     for name, fn in forms.items():
@@ -44,6 +53,14 @@ def tiny_train(n=30):
     W2f, _ = ops.afno_block_weights(torch.randn(nb, N, N, device="cuda") * 0.05)
     b1 = torch.randn(nb, N, device="cuda") * 0.1
     b2 = torch.randn(nb, N, device="cuda") * 0.1
+    if ops.afno_mlp3_supported(nb, bs):            # what the model runs for bs = 128: the three-product kernel
+        pk = ops.AfnoPacks([(torch.randn(2, nb, bs, bs, device="cuda") * 0.05, torch.randn(2, nb, bs, device="cuda") * 0.1),
+                            (torch.randn(2, nb, bs, bs, device="cuda") * 0.05, torch.randn(2, nb, bs, device="cuda") * 0.1)])
+        (_, c1, f1, _), (_, c2, f2, _) = pk.refresh()
+        for _ in range(n):
+            ops.afno_mlp2(S, f1, c1, f2, c2, nb, bs, 1, mode=0, want_pre=True, want_mid=True, layout=1)
+        torch.cuda.synchronize()
+        return
     for _ in range(n):
         ops.afno_mlp2(S, W1f, b1, W2f, b2, nb, bs, 1, mode=0, want_pre=True, want_mid=True)
     torch.cuda.synchronize()

@@ -15,7 +15,7 @@ for c in ("FETCH_SIZE", "WRITE_SIZE"):
     vals = collections.defaultdict(list)
     for f in glob.glob(f"gpurun_out/pmcm_{c}/**/*counter_collection.csv", recursive=True):
         for row in csv.DictReader(open(f)):
-            if row.get("Counter_Name") == c and "afno_mlp2" in row.get("Kernel_Name", ""):
+            if row.get("Counter_Name") == c and "afno_mlp" in row.get("Kernel_Name", ""):
                 vals[row["Kernel_Name"][:60]].append(float(row["Counter_Value"]))
     for k, v in vals.items():
         res[c] = {"kernel": k, "launches": len(v), "mean": sum(v) / len(v), "min": min(v), "max": max(v)}

@@ -865,3 +865,51 @@ def test_gemm_bf16_panel_packed_epilogue_outputs(ops):
     y3, _, pr3, pt3, cs3 = ops.gemm_bf16p(Ap, pk.bufs[0], M, N, K, bias=b.cuda(), act=1, mode=ops.EPI_ACT,
                                           pack_trans=True, store=False)
     assert y3 is None and pr3 is None and cs3 is None and torch.equal(pt3, pt)
+
+
+@pytest.mark.parametrize("nb,M,act", [(4, 4608, "gelu"), (2, 333, "gelu"), (8, 100, "relu"), (1, 16, "gelu")])
+def test_afno_mlp3_three_product_form(ops, nb, M, act):
+    """the three-product (Gauss) form of the fused complex MLP for bs = 128 (csrc/afno_mlp.hip, afno_mlp3_kernel):
+    packs written by AfnoPacks (layout 1), forward (pre, mid, Y) and backward data path against float64 complex
+    arithmetic and against the four-product kernel; ragged panels"""
+    bs, N = 128, 256
+    assert ops.afno_mlp3_supported(nb, bs)
+    w1, w2 = rnd(2, nb, bs, bs, seed=2, scale=1.0 / math.sqrt(N)), rnd(2, nb, bs, bs, seed=3, scale=1.0 / math.sqrt(N))
+    b1, b2 = rnd(2, nb, bs, seed=4, scale=0.3), rnd(2, nb, bs, seed=5, scale=0.3)
+    X = rnd(M, nb * N, seed=1)
+    packs = ops.AfnoPacks([(w1.cuda(), b1.cuda()), (w2.cuda(), b2.cuda())])
+    assert packs.layout == 1
+    (wb1, bb1, f1, bw1), (wb2, bb2, f2, bw2) = packs.refresh()
+    f = ACTS[act]
+    Xc = torch.complex(X.double().view(M, nb, 2, bs)[:, :, 0], X.double().view(M, nb, 2, bs)[:, :, 1])   # [M, nb, bs]
+    W1c, W2c = torch.complex(w1[0].double(), w1[1].double()), torch.complex(w2[0].double(), w2[1].double())
+    B1c, B2c = torch.complex(b1[0].double(), b1[1].double()), torch.complex(b2[0].double(), b2[1].double())
+    pre_c = torch.einsum("mki,kio->mko", Xc, W1c) + B1c
+    planar = lambda z: torch.stack([z.real, z.imag], dim=2).reshape(M, -1)      # [M, nb, 2, bs] -> [M, nb*2*bs]
+    pre_ref = planar(pre_c)
+    mid_ref = f(pre_ref)
+    midc = torch.complex(mid_ref.view(M, nb, 2, bs)[:, :, 0], mid_ref.view(M, nb, 2, bs)[:, :, 1])
+    Y_ref = planar(torch.einsum("mki,kio->mko", midc, W2c) + B2c)
+    Y, pre, mid = ops.afno_mlp2(X.cuda(), f1, bb1, f2, bb2, nb, bs, ops.ACT_IDS[act], mode=0, want_pre=True,
+                                want_mid=True, layout=1)
+    assert_close(pre, pre_ref, "pre")
+    assert_close(mid, mid_ref, "mid")
+    assert_close(Y, Y_ref, "Y")
+    # against the four-product kernel on the same weights (Wbig packs)
+    W1T, W1B = ops.afno_block_weights(wb1)
+    W2T, W2B = ops.afno_block_weights(wb2)
+    Y4, pre4, mid4 = ops.afno_mlp2(X.cuda(), W1T, bb1, W2T, bb2, nb, bs, ops.ACT_IDS[act], mode=0, want_pre=True,
+                                   want_mid=True)
+    assert_close(Y, Y4.double(), "Y vs four-product kernel", rtol=2e-5, atol_scale=2e-5)
+    # backward data path
+    dO2 = rnd(M, nb * N, seed=6)
+    pr = pre_ref.clone().requires_grad_(True)
+    (f(pr)).backward(torch.ones_like(pr))
+    dact = pr.grad
+    Wbig1, Wbig2 = wb1.cpu().double(), wb2.cpu().double()                       # [nb, N, N], W[k][n]
+    dmid_ref = torch.einsum("mko,kno->mkn", dO2.double().view(M, nb, N), Wbig2) * dact.view(M, nb, N)
+    dS_ref = torch.einsum("mko,kno->mkn", dmid_ref, Wbig1)
+    dS, _, dmid = ops.afno_mlp2(dO2.cuda(), bw2, None, bw1, None, nb, bs, ops.ACT_IDS[act], mode=1,
+                                aux=pre_ref.float().contiguous().cuda(), want_mid=True, layout=1)
+    assert_close(dmid, dmid_ref.reshape(M, -1), "dO1pre")
+    assert_close(dS, dS_ref.reshape(M, -1), "dS")
