@@ -376,7 +376,7 @@ __global__ __launch_bounds__(64 * (NW + 2)) void afno_mlp2_kernel(const AfnoMlpA
 // =====================================================================================================================
 // The same two-layer complex MLP with THREE real products per complex product instead of four (Gauss / Karatsuba):
 //      (Sr + i Si)(Wr + i Wi):   P1 = Sr Wr,  P2 = Si Wi,  P3 = (Sr + Si)(Wr + Wi)   ->   re = P1 - P2,  im = P3 - P1 - P2
-// 25 % fewer MFMAs (and 25 % fewer weight bytes) for bs = 128 (DPOT-Ti / S / M).  The backward data path is the same
+// 25 % fewer MFMAs (and 25 % fewer weight bytes); bs = 128 (DPOT-Ti / S / M), 96 (DPOT-L) or 64.  The backward data path is the same
 // complex product with (Wr^T, -Wi^T), so only the packed weights differ.  Same machinery as afno_mlp2_kernel (panels,
 // loader waves, LDS-DMA, ring of three slabs, one barrier per 16-k slab, Y1 in LDS) with these differences:
 //   * K runs over bs = 128 (8 slabs per layer); a slab holds the Wr and Wi fragments (16 tiles = 16 KiB) and - layer 1 -
@@ -391,15 +391,15 @@ __global__ __launch_bounds__(64 * (NW + 2)) void afno_mlp2_kernel(const AfnoMlpA
 // Packed weights (dpot_afno_pack_all, layout 1): [block][slab t][part][col tile c][4*l + e] =
 //      W_part[k = 16t + 4(l>>4) + e][n = 16c + (l&15)],   forward: (Wr, Wi);  backward: (Wr^T, -Wi^T).
 // =====================================================================================================================
-template <int RT, int ACTK>
-__global__ __launch_bounds__(640) void afno_mlp3_kernel(const AfnoMlpArgs p) {
-  constexpr int NW = 8;             // compute waves = 16-column tiles of one part
-  constexpr int BS = 128, N = 2 * BS;
+template <int RT, int BS, int ACTK>
+__global__ __launch_bounds__(64 * (BS / 16 + 2)) void afno_mlp3_kernel(const AfnoMlpArgs p) {
+  constexpr int NW = BS / 16;       // compute waves = 16-column tiles of one part (8 for bs = 128, 6 for bs = 96)
+  constexpr int N = 2 * BS;
   constexpr int NSLAB = BS / 16;    // 16-k slabs per layer
-  constexpr int NCT = 16;           // 16-column tiles of Y1 (both parts)
-  constexpr int WSL = 16 * 256;     // floats of a weight slab: [part][c][256]
+  constexpr int NCT = 2 * NSLAB;    // 16-column tiles of Y1 (both parts)
+  constexpr int WSL = 2 * NW * 256; // floats of a weight slab: [part][c][256]
   constexpr int XSL = 2 * RT * 256; // floats of an X slab: [part][row tile][16 rows][16 k]
-  constexpr int WB = 8, XB = RT;    // DMA pieces per slab and loader wave
+  constexpr int WB = NW, XB = RT;   // DMA pieces per slab and loader wave
   __shared__ __attribute__((aligned(16))) float lds[3 * WSL + 3 * XSL + RT * NCT * 256 + 256];
   float* const Wr_ = lds;                   // ring [3][part][c][256]
   float* const Xb = lds + 3 * WSL;          // ring [3][part][RT][256]
@@ -496,7 +496,7 @@ __global__ __launch_bounds__(640) void afno_mlp3_kernel(const AfnoMlpArgs p) {
   // weight fragments of this wave's column tile: (b_r, b_i) of the slab in ring buffer `rb`
   auto read_w = [&](f32x4 (&b)[2], int rb) __attribute__((always_inline)) {
     b[0] = *reinterpret_cast<const f32x4*>(Wr_ + rb * WSL + wave * 256 + lane * 4);
-    b[1] = *reinterpret_cast<const f32x4*>(Wr_ + rb * WSL + (8 + wave) * 256 + lane * 4);
+    b[1] = *reinterpret_cast<const f32x4*>(Wr_ + rb * WSL + (NW + wave) * 256 + lane * 4);
   };
   const int xfrag = fr * 16 + 4 * (fq ^ ((fr >> 2) & 3));
   auto read_x = [&](f32x4 (&ar)[RT], f32x4 (&ai)[RT], int rb) __attribute__((always_inline)) {
@@ -511,7 +511,7 @@ __global__ __launch_bounds__(640) void afno_mlp3_kernel(const AfnoMlpArgs p) {
 #pragma unroll
     for (int i = 0; i < RT; ++i) {
       ar[i] = *reinterpret_cast<const f32x4*>(Y1 + ((i * NCT + u) * 64 + fq * 16 + ((fr + u + 8 * (fq >> 1)) & 15)) * 4);
-      ai[i] = *reinterpret_cast<const f32x4*>(Y1 + ((i * NCT + u + 8) * 64 + fq * 16 + ((fr + u + 8 + 8 * (fq >> 1)) & 15)) * 4);
+      ai[i] = *reinterpret_cast<const f32x4*>(Y1 + ((i * NCT + u + NSLAB) * 64 + fq * 16 + ((fr + u + NSLAB + 8 * (fq >> 1)) & 15)) * 4);
     }
   };
   auto g12 = [&](const f32x4 (&ar)[RT], const f32x4 (&ai)[RT], const f32x4 (&b)[2]) __attribute__((always_inline)) {
@@ -797,17 +797,21 @@ static int launch_rt(const AfnoMlpArgs& p, int rt, hipStream_t s) {
   }
   return check_launch("afno_mlp2_kernel");
 }
-template <int ACTK>
+template <int BS, int ACTK>
 static int launch3_rt(const AfnoMlpArgs& p, int rt, hipStream_t s) {
-  const dim3 grid((unsigned)(p.nb * p.panels)), blk(640);
+  const dim3 grid((unsigned)(p.nb * p.panels)), blk(64 * (BS / 16 + 2));
   switch (rt) {
-    case 1: hipLaunchKernelGGL((afno_mlp3_kernel<1, ACTK>), grid, blk, 0, s, p); break;
-    case 2: hipLaunchKernelGGL((afno_mlp3_kernel<2, ACTK>), grid, blk, 0, s, p); break;
-    case 3: hipLaunchKernelGGL((afno_mlp3_kernel<3, ACTK>), grid, blk, 0, s, p); break;
-    case 4: hipLaunchKernelGGL((afno_mlp3_kernel<4, ACTK>), grid, blk, 0, s, p); break;
-    default: hipLaunchKernelGGL((afno_mlp3_kernel<5, ACTK>), grid, blk, 0, s, p); break;
+    case 1: hipLaunchKernelGGL((afno_mlp3_kernel<1, BS, ACTK>), grid, blk, 0, s, p); break;
+    case 2: hipLaunchKernelGGL((afno_mlp3_kernel<2, BS, ACTK>), grid, blk, 0, s, p); break;
+    case 3: hipLaunchKernelGGL((afno_mlp3_kernel<3, BS, ACTK>), grid, blk, 0, s, p); break;
+    case 4: hipLaunchKernelGGL((afno_mlp3_kernel<4, BS, ACTK>), grid, blk, 0, s, p); break;
+    default: hipLaunchKernelGGL((afno_mlp3_kernel<5, BS, ACTK>), grid, blk, 0, s, p); break;
   }
   return check_launch("afno_mlp3_kernel");
+}
+template <int BS>
+static int launch3(const AfnoMlpArgs& p, int rt, hipStream_t s) {
+  return p.act == DPOT_ACT_GELU ? launch3_rt<BS, DPOT_ACT_GELU>(p, rt, s) : launch3_rt<BS, -1>(p, rt, s);
 }
 template <int NW>
 static int launch_nw(const AfnoMlpArgs& p, int rt, hipStream_t s) {
@@ -835,12 +839,12 @@ extern "C" int dpot_afno_block_weights(const float* wbig, float* fwd, float* bwd
   return check_launch("afno_block_weights_kernel");
 }
 
-extern "C" int dpot_afno_mlp3_supported(int nb, int bs) { return nb > 0 && bs == 128 ? 1 : 0; }
+extern "C" int dpot_afno_mlp3_supported(int nb, int bs) { return nb > 0 && (bs == 128 || bs == 96 || bs == 64) ? 1 : 0; }
 
 extern "C" int dpot_afno_pack_all(const dpot_afno_pack_job* jobs_dev, int njobs, int nb, int bs, int layout,
                                   dpot_stream_t stream) {
   DPOT_REQUIRE(jobs_dev && njobs > 0 && njobs <= 65535 && nb > 0 && bs > 0, "afno_pack_all: bad argument");
-  DPOT_REQUIRE(layout == 0 || (layout == 1 && dpot_afno_mlp3_supported(nb, bs)), "afno_pack_all: layout 1 needs bs == 128");
+  DPOT_REQUIRE(layout == 0 || (layout == 1 && dpot_afno_mlp3_supported(nb, bs)), "afno_pack_all: layout 1 needs bs in {64, 96, 128}");
   DPOT_REQUIRE((2 * bs) % 16 == 0, "afno_pack_all: 2*bs must be a multiple of 16 for the blocked copies");
   long long g = ((long long)nb * 4 * bs * bs + 255) / 256;
   if (g > 1024) g = 1024;
@@ -853,7 +857,7 @@ extern "C" int dpot_afno_mlp2(const float* X, const float* WaT, const float* ba,
                               const float* aux, float* pre, float* mid, float* Y, int M, int nb, int bs, int ldx,
                               int ldo, int act, int mode, int layout, dpot_stream_t stream) {
   DPOT_REQUIRE(X && WaT && WbT && Y && M > 0, "afno_mlp2: bad argument");
-  DPOT_REQUIRE(layout == 0 || (layout == 1 && dpot_afno_mlp3_supported(nb, bs)), "afno_mlp2: weight layout 1 needs bs == 128");
+  DPOT_REQUIRE(layout == 0 || (layout == 1 && dpot_afno_mlp3_supported(nb, bs)), "afno_mlp2: weight layout 1 needs bs in {64, 96, 128}");
   DPOT_REQUIRE(dpot_afno_mlp2_supported(nb, bs), "afno_mlp2: unsupported block size bs=%d (2*bs must be 64/128/192/256)", bs);
   DPOT_REQUIRE(mode == 0 || (mode == 1 && aux != nullptr), "afno_mlp2: mode 1 (backward) needs aux");
   const int N = 2 * bs;
@@ -867,7 +871,7 @@ extern "C" int dpot_afno_mlp2(const float* X, const float* WaT, const float* ba,
   const int rt = pick_rt(M, nb);
   p.panels = (M + 16 * rt - 1) / (16 * rt);
   hipStream_t s = as_stream(stream);
-  if (layout == 1) return p.act == DPOT_ACT_GELU ? launch3_rt<DPOT_ACT_GELU>(p, rt, s) : launch3_rt<-1>(p, rt, s);
+  if (layout == 1) return bs == 128 ? launch3<128>(p, rt, s) : bs == 96 ? launch3<96>(p, rt, s) : launch3<64>(p, rt, s);
   switch (N / 64) {
     case 1: return launch_nw<2>(p, rt, s);
     case 2: return launch_nw<4>(p, rt, s);

@@ -323,7 +323,7 @@ int dpot_noise_inject_rng(const float* xx, float* out, float* norms, uint64_t* r
  * from dpot_afno_pack's Wbig: its `fwd` output for mode 0 (multiply by Wbig), its `bwd` output for mode 1 (multiply
  * by Wbig^T).  pre / mid may be NULL (inference).  Supported when 2*bs is 64, 128, 192 or 256
  * (dpot_afno_mlp2_supported); everything 16-byte aligned.
- * layout = 1 (bs == 128, dpot_afno_mlp3_supported): the THREE-product form of the complex multiplication
+ * layout = 1 (bs in {64, 96, 128}, dpot_afno_mlp3_supported): the THREE-product form of the complex multiplication
  *   P1 = Sr Wr, P2 = Si Wi, P3 = (Sr+Si)(Wr+Wi) -> re = P1 - P2, im = P3 - P1 - P2   (25 % fewer MFMAs);
  * Wa / Wb are then the (Wr, Wi) fragment packs written by dpot_afno_pack_all(layout = 1): `fwd` for mode 0, `bwd`
  * (= Wr^T, -Wi^T) for mode 1.  Same outputs up to fp32 rounding (tests: same tolerance as layout 0). */

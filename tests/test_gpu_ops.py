@@ -867,12 +867,14 @@ def test_gemm_bf16_panel_packed_epilogue_outputs(ops):
     assert y3 is None and pr3 is None and cs3 is None and torch.equal(pt3, pt)
 
 
-@pytest.mark.parametrize("nb,M,act", [(4, 4608, "gelu"), (2, 333, "gelu"), (8, 100, "relu"), (1, 16, "gelu")])
-def test_afno_mlp3_three_product_form(ops, nb, M, act):
+@pytest.mark.parametrize("nb,bs,M,act", [(4, 128, 4608, "gelu"), (2, 128, 333, "gelu"), (8, 128, 100, "relu"),
+                                         (1, 128, 16, "gelu"), (16, 96, 2176, "gelu"), (3, 96, 50, "gelu"),
+                                         (2, 64, 200, "gelu")])
+def test_afno_mlp3_three_product_form(ops, nb, bs, M, act):
     """the three-product (Gauss) form of the fused complex MLP for bs = 128 (csrc/afno_mlp.hip, afno_mlp3_kernel):
     packs written by AfnoPacks (layout 1), forward (pre, mid, Y) and backward data path against float64 complex
     arithmetic and against the four-product kernel; ragged panels"""
-    bs, N = 128, 256
+    N = 2 * bs
     assert ops.afno_mlp3_supported(nb, bs)
     w1, w2 = rnd(2, nb, bs, bs, seed=2, scale=1.0 / math.sqrt(N)), rnd(2, nb, bs, bs, seed=3, scale=1.0 / math.sqrt(N))
     b1, b2 = rnd(2, nb, bs, seed=4, scale=0.3), rnd(2, nb, bs, seed=5, scale=0.3)
