@@ -30,6 +30,9 @@ typedef float tn_f32x4 __attribute__((ext_vector_type(4)));
 struct TnArgs {
   const float* A;        // [T, lda]  (columns = output rows n1)
   const float* B;        // [T, ldb]  (columns = output columns n2)
+  const float* A2;       // problems zb >= batch1 take their operands from (A2, B2) (same strides): the two weight
+  const float* B2;       //   gradients of an AFNO block in one launch (dpot_afno_wgrad2)
+  int batch1;
   int lda, ldb;
   long long sA, sB;      // batch strides (elements)
   int N1, N2, T, batch;
@@ -86,8 +89,12 @@ __global__ __launch_bounds__(384) void gemm_tn_kernel(const TnArgs p) {
     // wave L issues the tokens 16L .. 16L+15 of both operands (instruction j = tokens 16L + 2j, + 2j + 1 of one operand);
     // lane -> (token parity lane >> 5, 16 B piece lane & 31)
     const int L = wave - 4;
-    const float* a0 = p.A + zb * p.sA + (long long)(slab0 * TN_TOK + 16 * L + (lane >> 5)) * p.lda + t1 * TN_W + (lane & 31) * 4;
-    const float* b0 = p.B + zb * p.sB + (long long)(slab0 * TN_TOK + 16 * L + (lane >> 5)) * p.ldb + t2 * TN_W + (lane & 31) * 4;
+    const bool second = zb >= p.batch1;
+    const int zq = second ? zb - p.batch1 : zb;
+    const float* a0 = (second ? p.A2 : p.A) + zq * p.sA + (long long)(slab0 * TN_TOK + 16 * L + (lane >> 5)) * p.lda +
+                      t1 * TN_W + (lane & 31) * 4;
+    const float* b0 = (second ? p.B2 : p.B) + zq * p.sB + (long long)(slab0 * TN_TOK + 16 * L + (lane >> 5)) * p.ldb +
+                      t2 * TN_W + (lane & 31) * 4;
     const long long sa2 = 2ll * p.lda, sb2 = 2ll * p.ldb, saS = (long long)TN_TOK * p.lda, sbS = (long long)TN_TOK * p.ldb;
     auto issue = [&](int t, int ring) __attribute__((always_inline)) {
       float* dst = lds + ring * TN_SLABF + L * 8 * 256;
@@ -226,6 +233,7 @@ int dpot_gemm_tn_try(const dpot_gemm_desc* d, hipStream_t s) {
   if (d->splitk > nslab || (long long)d->batch * d->splitk > 65535) return -1;
   TnArgs p;
   p.A = d->A; p.B = d->B; p.lda = d->lda; p.ldb = d->ldb; p.sA = d->strideA; p.sB = d->strideB;
+  p.A2 = nullptr; p.B2 = nullptr; p.batch1 = d->batch;
   p.N1 = d->M; p.N2 = d->N; p.T = d->K; p.batch = d->batch;
   p.tiles1 = d->M / TN_W; p.tiles2 = d->N / TN_W;
   p.splits = d->splitk;
@@ -236,4 +244,103 @@ int dpot_gemm_tn_try(const dpot_gemm_desc* d, hipStream_t s) {
   hipLaunchKernelGGL(gemm_tn_kernel, dim3((unsigned)(p.tiles1 * p.tiles2), 1, (unsigned)(d->batch * d->splitk)), dim3(384),
                      0, s, p);
   return check_launch("gemm_tn_kernel");
+}
+
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Both weight gradients of an AFNO block's complex MLP in ONE launch: per channel block k
+//     dWbig1[k] = S[:, k]^T dO1pre[:, k],    dWbig2[k] = O1[:, k]^T dO2[:, k]        (N x N, N = 2*bs, K = Mm tokens)
+// = 2*nb independent problems of the kernel above.  One launch halves the split factor each problem needs to fill the
+// chip (18 instead of 9 slabs per workgroup, half the partial-sum traffic) against two launches of the generic kernel:
+// 2 x 36.5 us -> one launch + one reduce.  The reduce un-packs  dWr = D[0:bs,0:bs] + D[bs:,bs:],
+// dWi = D[0:bs,bs:] - D[bs:,0:bs]  and the bias gradients (column sums of dO) for both layers, fixed order.
+// ---------------------------------------------------------------------------------------------------------------------
+namespace dpot {
+__global__ __launch_bounds__(256) void afno_wgrad2_reduce_kernel(const float* __restrict__ ws, int splits, int nb, int bs,
+                                                                 float* __restrict__ dw1, float* __restrict__ db1,
+                                                                 float* __restrict__ dw2, float* __restrict__ db2) {
+  const int n2 = 2 * bs;
+  const long long MN = (long long)n2 * n2, total = MN * 2 * nb;
+  const long long nw = (long long)nb * bs * bs;
+  for (long long idx = blockIdx.x * 256ll + threadIdx.x; idx < 2 * nw; idx += (long long)gridDim.x * 256) {
+    const int layer = idx >= nw;
+    const long long q = idx - layer * nw;
+    const int o = (int)(q % bs), i = (int)((q / bs) % bs), k = (int)(q / ((long long)bs * bs));
+    const float* base = ws + (long long)(layer * nb + k) * MN;
+    float rr = 0.f, ii = 0.f, ri = 0.f, ir = 0.f;
+    for (int s = 0; s < splits; ++s) {           // fixed order
+      const float* W = base + (long long)s * total;
+      rr += W[(long long)i * n2 + o];
+      ii += W[(long long)(bs + i) * n2 + bs + o];
+      ri += W[(long long)i * n2 + bs + o];
+      ir += W[(long long)(bs + i) * n2 + o];
+    }
+    float* dw = layer ? dw2 : dw1;
+    dw[q] = rr + ii;
+    dw[nw + q] = ri - ir;
+  }
+  const float* wc = ws + (long long)splits * total;
+  const long long nc = (long long)2 * nb * n2;
+  for (long long idx = blockIdx.x * 256ll + threadIdx.x; idx < nc; idx += (long long)gridDim.x * 256) {
+    float v = 0.f;
+    for (int s = 0; s < splits; ++s) v += wc[(long long)s * nc + idx];
+    const int layer = idx >= (long long)nb * n2;
+    const long long q = idx - (long long)layer * nb * n2;
+    const int c = (int)(q % bs), part = (int)((q / bs) & 1), k = (int)(q / n2);
+    (layer ? db2 : db1)[((long long)part * nb + k) * bs + c] = v;
+  }
+}
+}  // namespace dpot
+
+extern "C" int dpot_afno_wgrad2_splitk(int Mm, int nb, int bs) {
+  static const int enabled = [] { const char* e = getenv("DPOT_AFNO_WGRAD2"); return e ? atoi(e) : 1; }();
+  const int N = 2 * bs;
+  if (!enabled || nb <= 0 || bs <= 0 || N % TN_W || Mm <= 0 || Mm % TN_TOK) return 0;
+  const long long tiles = (long long)2 * nb * (N / TN_W) * (N / TN_W);
+  const int nslab = Mm / TN_TOK;
+  long long s = (256 + tiles / 2) / tiles;
+  const long long smax = nslab / 4;
+  if (s > smax) s = smax;
+  if (s < 1) s = 1;
+  // no empty split
+  while (s > 1 && ((nslab + s - 1) / s) * (s - 1) >= nslab) --s;
+  return (int)s;
+}
+
+extern "C" int64_t dpot_afno_wgrad2_ws_elems(int nb, int bs, int splitk) {
+  const int64_t N = 2 * bs;
+  return (int64_t)splitk * 2 * nb * (N * N + N);
+}
+
+extern "C" int dpot_afno_wgrad2(const float* S, const float* dO1pre, const float* O1, const float* dO2, int ld, int Mm,
+                                int nb, int bs, float* dw1, float* db1, float* dw2, float* db2, float* workspace,
+                                int splitk, dpot_stream_t stream) {
+  DPOT_REQUIRE(S && dO1pre && O1 && dO2 && dw1 && db1 && dw2 && db2 && workspace, "afno_wgrad2: null pointer");
+  const int N = 2 * bs;
+  DPOT_REQUIRE(nb > 0 && bs > 0 && N % TN_W == 0 && Mm > 0 && Mm % TN_TOK == 0 && ld >= nb * N && ld % 4 == 0,
+               "afno_wgrad2: needs 2*bs %% 128 == 0, Mm %% 32 == 0");
+  DPOT_REQUIRE(aligned16(S) && aligned16(dO1pre) && aligned16(O1) && aligned16(dO2) && aligned16(workspace),
+               "afno_wgrad2: operands must be 16-byte aligned");
+  const int nslab = Mm / TN_TOK;
+  DPOT_REQUIRE(splitk >= 1 && splitk <= nslab && (long long)2 * nb * splitk <= 65535, "afno_wgrad2: bad split factor");
+  TnArgs p;
+  p.A = S; p.B = dO1pre; p.A2 = O1; p.B2 = dO2; p.batch1 = nb;
+  p.lda = ld; p.ldb = ld; p.sA = N; p.sB = N;
+  p.N1 = N; p.N2 = N; p.T = Mm; p.batch = 2 * nb;
+  p.tiles1 = N / TN_W; p.tiles2 = N / TN_W;
+  p.splits = splitk;
+  p.slabs_per_split = (nslab + splitk - 1) / splitk;
+  DPOT_REQUIRE((long long)p.slabs_per_split * (splitk - 1) < nslab, "afno_wgrad2: split factor leaves an empty split");
+  p.ws = workspace;
+  p.cs_of = 2;
+  hipStream_t s = as_stream(stream);
+  hipLaunchKernelGGL(gemm_tn_kernel, dim3((unsigned)(p.tiles1 * p.tiles2), 1, (unsigned)(2 * nb * splitk)), dim3(384), 0, s,
+                     p);
+  int rc = check_launch("gemm_tn_kernel");
+  if (rc) return rc;
+  long long blocks = (2ll * nb * bs * bs + 255) / 256;
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(afno_wgrad2_reduce_kernel, dim3((unsigned)blocks), dim3(256), 0, s, (const float*)workspace, splitk, nb,
+                     bs, dw1, db1, dw2, db2);
+  return check_launch("afno_wgrad2_reduce_kernel");
 }

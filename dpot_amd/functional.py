@@ -450,11 +450,14 @@ class BlockFn(torch.autograd.Function):
         sk = max(2, ops.auto_splitk(2 * bs, 2 * bs, Mm, nb, tn=True))
         wkw = dict(transA=True, lda=2 * E, ldb=2 * E, ldc=2 * bs, batch=nb, strideA=2 * bs, strideB=2 * bs,
                    strideC=4 * bs * bs, splitk=sk, mode=ops.EPI_AFNO_WGRAD)
-        with streams.side(dev):
-            # wgrad of Wbig; its split-K reduction writes dw / db in the parameters' own [2, nb, bs, ...] layout
-            dw2, db2 = ops._out(s_w2.out(), (2, nb, bs, bs), dev), ops._out(s_b2.out(), (2, nb, bs), dev)
-            ops.gemm(O1, dO2, dw2, 2 * bs, 2 * bs, Mm, colsum_out=db2, colsum_of=2, **wkw)
-            dw2, db2 = s_w2.done(dw2), s_b2.done(db2)
+        # both weight gradients of the mixer in ONE launch (csrc/gemm_tn.hip, dpot_afno_wgrad2) once dO1pre exists
+        sk2 = ops.afno_wgrad2_splitk(Mm, nb, bs) if ctx.fused_mixer and S.stride(0) == 2 * E else 0
+        if not sk2:
+            with streams.side(dev):
+                # wgrad of Wbig; its split-K reduction writes dw / db in the parameters' own [2, nb, bs, ...] layout
+                dw2, db2 = ops._out(s_w2.out(), (2, nb, bs, bs), dev), ops._out(s_b2.out(), (2, nb, bs), dev)
+                ops.gemm(O1, dO2, dw2, 2 * bs, 2 * bs, Mm, colsum_out=db2, colsum_of=2, **wkw)
+                dw2, db2 = s_w2.done(dw2), s_b2.done(db2)
         if ctx.fused_mixer:
             # data path of both layers in one launch: dO1pre = (dO2 W2^T) * act'(O1pre), dS = dO1pre W1^T
             # (wb1 / wb2 hold the fragment-block-major W^T here)
@@ -464,10 +467,16 @@ class BlockFn(torch.autograd.Function):
             dO1pre = torch.empty(Mm, 2 * E, dtype=torch.float32, device=dev)
             ops.gemm(dO2, wb2, dO1pre, Mm, 2 * bs, 2 * bs, transB=True, act=act, mode=EPI_DACT, aux=O1pre,
                      ldaux=2 * E, strideAux=2 * bs, **kw)
-        with streams.side(dev):
+        if sk2:
             dw1, db1 = ops._out(s_w1.out(), (2, nb, bs, bs), dev), ops._out(s_b1.out(), (2, nb, bs), dev)
-            ops.gemm(S, dO1pre, dw1, 2 * bs, 2 * bs, Mm, colsum_out=db1, colsum_of=2, **wkw)
-            dw1, db1 = s_w1.done(dw1), s_b1.done(db1)
+            dw2, db2 = ops._out(s_w2.out(), (2, nb, bs, bs), dev), ops._out(s_b2.out(), (2, nb, bs), dev)
+            ops.afno_wgrad2(S, dO1pre, O1, dO2, nb, bs, dw1, db1, dw2, db2, sk2)
+            dw1, db1, dw2, db2 = s_w1.done(dw1), s_b1.done(db1), s_w2.done(dw2), s_b2.done(db2)
+        else:
+            with streams.side(dev):
+                dw1, db1 = ops._out(s_w1.out(), (2, nb, bs, bs), dev), ops._out(s_b1.out(), (2, nb, bs), dev)
+                ops.gemm(S, dO1pre, dw1, 2 * bs, 2 * bs, Mm, colsum_out=db1, colsum_of=2, **wkw)
+                dw1, db1 = s_w1.done(dw1), s_b1.done(db1)
         if not ctx.fused_mixer:
             dS = torch.empty(Mm, 2 * E, dtype=torch.float32, device=dev)
             ops.gemm(dO1pre, wb1, dS, Mm, 2 * bs, 2 * bs, transB=True, **kw)

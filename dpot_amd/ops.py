@@ -438,6 +438,22 @@ def afno_block_weights(wbig: Tensor) -> Tuple[Tensor, Tensor]:
     return fwd, bwd
 
 
+def afno_wgrad2_splitk(Mm: int, nb: int, bs: int) -> int:
+    """split factor of the fused two-layer AFNO weight gradient (0: shape not covered -> two generic GEMM launches)"""
+    return _lib.load().dpot_afno_wgrad2_splitk(Mm, nb, bs) if _gemm_precision in (GEMM_F32, GEMM_AUTO) else 0
+
+
+def afno_wgrad2(S: Tensor, dO1pre: Tensor, O1: Tensor, dO2: Tensor, nb: int, bs: int, dw1: Tensor, db1: Tensor,
+                dw2: Tensor, db2: Tensor, splitk: int) -> None:
+    """dw1 / db1 (from S, dO1pre) and dw2 / db2 (from O1, dO2) of an AFNO block's complex MLP: one launch + one reduce"""
+    lib = _lib.load()
+    Mm, ld = S.shape
+    ws = torch.empty(lib.dpot_afno_wgrad2_ws_elems(nb, bs, splitk), dtype=torch.float32, device=S.device)
+    check(lib.dpot_afno_wgrad2(S.data_ptr(), dO1pre.data_ptr(), O1.data_ptr(), dO2.data_ptr(), ld, Mm, nb, bs,
+                               dw1.data_ptr(), db1.data_ptr(), dw2.data_ptr(), db2.data_ptr(), ws.data_ptr(), splitk,
+                               _stream()), "afno_wgrad2")
+
+
 def afno_mlp2_supported(nb: int, bs: int) -> bool:
     return bool(_lib.load().dpot_afno_mlp2_supported(nb, bs)) and os.environ.get("DPOT_AFNO_FUSED", "1") != "0"
 

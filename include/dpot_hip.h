@@ -143,6 +143,16 @@ int64_t dpot_gemm_workspace_bytes(const dpot_gemm_desc* d);
  * dpot_gemm_auto_splitk2).  Any splitk > 1 is accepted, the result does not depend on which kernel ran beyond fp32
  * summation order. */
 int dpot_gemm_tn_splitk(int M, int N, int K, int batch);
+/* Both weight gradients of an AFNO block's complex MLP (models/dpot.py:72-94) in one launch + one fixed-order reduce
+ * (csrc/gemm_tn.hip): per channel block k  dWbig1[k] = S[:,k]^T dO1pre[:,k], dWbig2[k] = O1[:,k]^T dO2[:,k], un-packed
+ * into the parameters' own layout dw [2, nb, bs, bs] / db [2, nb, bs] (db = column sums of the dO operand).
+ * S / dO1pre / O1 / dO2: [Mm, ld] planar-per-block spectra.  Needs 2*bs % 128 == 0 and Mm % 32 == 0
+ * (dpot_afno_wgrad2_splitk returns 0 otherwise); workspace: dpot_afno_wgrad2_ws_elems(nb, bs, splitk) floats. */
+int dpot_afno_wgrad2_splitk(int Mm, int nb, int bs);
+int64_t dpot_afno_wgrad2_ws_elems(int nb, int bs, int splitk);
+int dpot_afno_wgrad2(const float* S, const float* dO1pre, const float* O1, const float* dO2, int ld, int Mm, int nb,
+                     int bs, float* dw1, float* db1, float* dw2, float* db2, float* workspace, int splitk,
+                     dpot_stream_t stream);
 /* the split-K factor the library would pick for this shape (>= 1) */
 int dpot_gemm_auto_splitk(int M, int N, int K, int batch);
 /* the same for a given dpot_gemm_desc.precision (the bf16x6 kernel prefers fewer, larger workgroups) */

@@ -915,3 +915,28 @@ def test_afno_mlp3_three_product_form(ops, nb, bs, M, act):
                                 aux=pre_ref.float().contiguous().cuda(), want_mid=True, layout=1)
     assert_close(dmid, dmid_ref.reshape(M, -1), "dO1pre")
     assert_close(dS, dS_ref.reshape(M, -1), "dS")
+
+
+@pytest.mark.parametrize("nb,bs,Mm", [(4, 128, 4608), (2, 64, 32 * 13), (8, 128, 32 * 9)])
+def test_afno_wgrad2_both_layers_one_launch(ops, nb, bs, Mm):
+    """dpot_afno_wgrad2: the weight + bias gradients of both AFNO MLP layers from one launch of the weight-gradient kernel
+    (2*nb independent N x N problems) + one un-packing reduce, against float64 complex arithmetic"""
+    N = 2 * bs
+    sk = ops.afno_wgrad2_splitk(Mm, nb, bs)
+    assert sk >= 1
+    S, dO1, O1, dO2 = (rnd(Mm, nb * N, seed=k) for k in (1, 2, 3, 4))
+    dw1, dw2 = (torch.full((2, nb, bs, bs), float("nan"), device="cuda") for _ in range(2))
+    db1, db2 = (torch.full((2, nb, bs), float("nan"), device="cuda") for _ in range(2))
+    ops.afno_wgrad2(S.cuda(), dO1.cuda(), O1.cuda(), dO2.cuda(), nb, bs, dw1, db1, dw2, db2, sk)
+
+    def ref(A, Bm):
+        Ac = A.double().view(Mm, nb, 2, bs)
+        Bc = Bm.double().view(Mm, nb, 2, bs)
+        Ar, Ai, Br, Bi = Ac[:, :, 0], Ac[:, :, 1], Bc[:, :, 0], Bc[:, :, 1]
+        e = lambda x, y: torch.einsum("mki,mko->kio", x, y)
+        return torch.stack([e(Ar, Br) + e(Ai, Bi), e(Ar, Bi) - e(Ai, Br)]), torch.stack([Br.sum(0), Bi.sum(0)])
+
+    for (dw, db, A, Bm, nm) in ((dw1, db1, S, dO1, "layer 1"), (dw2, db2, O1, dO2, "layer 2")):
+        rw, rb = ref(A, Bm)
+        assert_close(dw, rw, f"dw {nm}", rtol=2e-5, atol_scale=2e-6)
+        assert_close(db, rb, f"db {nm}", rtol=2e-5, atol_scale=2e-6)
