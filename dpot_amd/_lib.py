@@ -120,6 +120,9 @@ SIGNATURES = {
     "dpot_gemm_bf16p": (c_i, [c_fp, c_fp, c_fp, c_fp, c_i, c_fp, c_i, c_fp, c_i, c_fp, c_i] + [c_i] * 7 + [c_fp] * 5),
     "dpot_gemm_bf16p_splitk": (c_i, [c_i, c_i, c_i]),
     "dpot_gemm_tn_splitk": (c_i, [c_i] * 4),
+    "dpot_mlp_wgrad2_splitk": (c_i, [c_i] * 3),
+    "dpot_mlp_wgrad2_ws_elems": (c_i64, [c_i] * 3),
+    "dpot_mlp_wgrad2": (c_i, [c_fp] * 4 + [c_i] * 3 + [c_fp] * 5 + [c_i, c_fp]),
     "dpot_afno_wgrad2_splitk": (c_i, [c_i] * 3),
     "dpot_afno_wgrad2_ws_elems": (c_i64, [c_i] * 3),
     "dpot_afno_wgrad2": (c_i, [c_fp] * 4 + [c_i] * 4 + [c_fp] * 5 + [c_i, c_fp]),

@@ -33,6 +33,8 @@ struct TnArgs {
   const float* A2;       // problems zb >= batch1 take their operands from (A2, B2) (same strides): the two weight
   const float* B2;       //   gradients of an AFNO block in one launch (dpot_afno_wgrad2)
   int batch1;
+  int cs_of2;            // column-sum operand of the second problem set (cs_of serves the first)
+  int csL;               // length of a column-sum partial slot (0: N1 or N2 by cs_of)
   int lda, ldb;
   long long sA, sB;      // batch strides (elements)
   int N1, N2, T, batch;
@@ -131,8 +133,9 @@ __global__ __launch_bounds__(384) void gemm_tn_kernel(const TnArgs p) {
 #pragma unroll
     for (int eb = 0; eb < 4; ++eb) acc[ea][eb] = tn_f32x4{0.f, 0.f, 0.f, 0.f};
   tn_f32x4 cs = {0.f, 0.f, 0.f, 0.f};
-  const bool cs_a = p.cs_of == 1 && t2 == 0 && wn == 0;
-  const bool cs_b = p.cs_of == 2 && t1 == 0 && wm == 0;
+  const int cs_sel = zb >= p.batch1 ? p.cs_of2 : p.cs_of;
+  const bool cs_a = cs_sel == 1 && t2 == 0 && wn == 0;
+  const bool cs_b = cs_sel == 2 && t1 == 0 && wm == 0;
 
   // this lane's fragment addresses inside a slab: A [tok = 4q + kq][wm*64 + 4*i16], B likewise with wn
   const int offA = kq * TN_W + wm * 64 + 4 * i16;
@@ -192,7 +195,7 @@ __global__ __launch_bounds__(384) void gemm_tn_kernel(const TnArgs p) {
       cs[e] = v;
     }
     if (kq == 0) {
-      const int L = cs_a ? p.N1 : p.N2;
+      const int L = p.csL ? p.csL : (cs_a ? p.N1 : p.N2);
       const int g0 = cs_a ? t1 * TN_W + wm * 64 : t2 * TN_W + wn * 64;
       float* wc = p.ws + (long long)p.splits * p.batch * p.N1 * p.N2 + ((long long)zs * p.batch + zb) * L + g0 + 4 * i16;
       *reinterpret_cast<float4*>(wc) = make_float4(cs[0], cs[1], cs[2], cs[3]);
@@ -233,7 +236,7 @@ int dpot_gemm_tn_try(const dpot_gemm_desc* d, hipStream_t s) {
   if (d->splitk > nslab || (long long)d->batch * d->splitk > 65535) return -1;
   TnArgs p;
   p.A = d->A; p.B = d->B; p.lda = d->lda; p.ldb = d->ldb; p.sA = d->strideA; p.sB = d->strideB;
-  p.A2 = nullptr; p.B2 = nullptr; p.batch1 = d->batch;
+  p.A2 = nullptr; p.B2 = nullptr; p.batch1 = d->batch; p.cs_of2 = d->colsum_of; p.csL = 0;
   p.N1 = d->M; p.N2 = d->N; p.T = d->K; p.batch = d->batch;
   p.tiles1 = d->M / TN_W; p.tiles2 = d->N / TN_W;
   p.splits = d->splitk;
@@ -324,7 +327,7 @@ extern "C" int dpot_afno_wgrad2(const float* S, const float* dO1pre, const float
   const int nslab = Mm / TN_TOK;
   DPOT_REQUIRE(splitk >= 1 && splitk <= nslab && (long long)2 * nb * splitk <= 65535, "afno_wgrad2: bad split factor");
   TnArgs p;
-  p.A = S; p.B = dO1pre; p.A2 = O1; p.B2 = dO2; p.batch1 = nb;
+  p.A = S; p.B = dO1pre; p.A2 = O1; p.B2 = dO2; p.batch1 = nb; p.cs_of2 = 2; p.csL = 0;
   p.lda = ld; p.ldb = ld; p.sA = N; p.sB = N;
   p.N1 = N; p.N2 = N; p.T = Mm; p.batch = 2 * nb;
   p.tiles1 = N / TN_W; p.tiles2 = N / TN_W;
@@ -343,4 +346,102 @@ extern "C" int dpot_afno_wgrad2(const float* S, const float* dO1pre, const float
   hipLaunchKernelGGL(afno_wgrad2_reduce_kernel, dim3((unsigned)blocks), dim3(256), 0, s, (const float*)workspace, splitk, nb,
                      bs, dw1, db1, dw2, db2);
   return check_launch("afno_wgrad2_reduce_kernel");
+}
+
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Both weight gradients of a channel MLP (y = fc2(act(fc1(x)))) in one launch:
+//     dW2 [E, mh]   = do2^T Hh        + db2 = colsum(do2)      (problem 0: column sums of the A operand)
+//     dW1^T [E, mh] = xn2^T dHpre     + db1 = colsum(dHpre)    (problem 1: of the B operand; stored transposed -> dW1 [mh, E])
+// Two same-shaped problems -> half the split factor of two separate launches (less partial traffic, longer token ranges).
+// ---------------------------------------------------------------------------------------------------------------------
+namespace dpot {
+__global__ __launch_bounds__(256) void mlp_wgrad2_reduce_kernel(const float* __restrict__ ws, int splits, int E, int mh,
+                                                                float* __restrict__ dW2, float* __restrict__ dW1,
+                                                                float* __restrict__ db2, float* __restrict__ db1) {
+  __shared__ float tile[32][33];
+  const long long MN = (long long)E * mh, total = 2 * MN;
+  const int L = E > mh ? E : mh;
+  // 32 x 32 tiles of the [E, mh] outputs: problem 0 is copied, problem 1 goes out transposed (coalesced both ways)
+  const int tn = mh / 32, tcount = (E / 32) * tn;
+  for (int tix = blockIdx.x; tix < 2 * tcount; tix += gridDim.x) {
+    const int prob = tix >= tcount, tt = tix - prob * tcount;
+    const int r0 = (tt / tn) * 32, c0 = (tt % tn) * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int r = r0 + ty + 8 * q;
+      const float* w = ws + (long long)prob * MN + (long long)r * mh + c0 + tx;
+      float v = 0.f;
+      for (int s = 0; s < splits; ++s) v += w[(long long)s * total];     // fixed order
+      if (prob == 0) dW2[(long long)r * mh + c0 + tx] = v;
+      else tile[ty + 8 * q][tx] = v;
+    }
+    if (prob) {
+      __syncthreads();
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int c = c0 + ty + 8 * q;                                   // row of dW1 [mh, E]
+        dW1[(long long)c * E + r0 + tx] = tile[tx][ty + 8 * q];
+      }
+      __syncthreads();
+    }
+  }
+  const float* wc = ws + (long long)splits * total;
+  for (int idx = blockIdx.x * 256 + threadIdx.x; idx < E + mh; idx += gridDim.x * 256) {
+    const int prob = idx >= E, g = idx - prob * E;
+    float v = 0.f;
+    for (int s = 0; s < splits; ++s) v += wc[((long long)s * 2 + prob) * L + g];
+    (prob ? db1 : db2)[g] = v;
+  }
+}
+}  // namespace dpot
+
+extern "C" int dpot_mlp_wgrad2_splitk(int T, int E, int mh) {
+  static const int enabled = [] { const char* e = getenv("DPOT_MLP_WGRAD2"); return e ? atoi(e) : 1; }();
+  if (!enabled || T <= 0 || E <= 0 || mh <= 0 || E % TN_W || mh % TN_W || T % TN_TOK) return 0;
+  const long long tiles = 2ll * (E / TN_W) * (mh / TN_W);
+  if (tiles > 256) return 0;                           // big layers fill the chip per launch: nothing to merge for
+  const int nslab = T / TN_TOK;
+  long long s = (256 + tiles / 2) / tiles;
+  const long long smax = nslab / 4;
+  if (s > smax) s = smax;
+  if (s < 1) s = 1;
+  while (s > 1 && ((nslab + s - 1) / s) * (s - 1) >= nslab) --s;
+  return (int)s;
+}
+
+extern "C" int64_t dpot_mlp_wgrad2_ws_elems(int E, int mh, int splitk) {
+  const int64_t L = E > mh ? E : mh;
+  return (int64_t)splitk * 2 * ((int64_t)E * mh + L);
+}
+
+extern "C" int dpot_mlp_wgrad2(const float* do2, const float* Hh, const float* xn2, const float* dHpre, int T, int E,
+                               int mh, float* dW2, float* db2, float* dW1, float* db1, float* workspace, int splitk,
+                               dpot_stream_t stream) {
+  DPOT_REQUIRE(do2 && Hh && xn2 && dHpre && dW2 && db2 && dW1 && db1 && workspace, "mlp_wgrad2: null pointer");
+  DPOT_REQUIRE(T > 0 && E % TN_W == 0 && mh % TN_W == 0 && T % TN_TOK == 0, "mlp_wgrad2: needs E, mh %% 128 == 0, T %% 32 == 0");
+  DPOT_REQUIRE(aligned16(do2) && aligned16(Hh) && aligned16(xn2) && aligned16(dHpre) && aligned16(workspace),
+               "mlp_wgrad2: operands must be 16-byte aligned");
+  const int nslab = T / TN_TOK;
+  DPOT_REQUIRE(splitk >= 1 && splitk <= nslab && 2ll * splitk <= 65535, "mlp_wgrad2: bad split factor");
+  TnArgs p;
+  p.A = do2; p.B = Hh; p.A2 = xn2; p.B2 = dHpre; p.batch1 = 1;
+  p.lda = E; p.ldb = mh; p.sA = 0; p.sB = 0;
+  p.N1 = E; p.N2 = mh; p.T = T; p.batch = 2;
+  p.tiles1 = E / TN_W; p.tiles2 = mh / TN_W;
+  p.splits = splitk;
+  p.slabs_per_split = (nslab + splitk - 1) / splitk;
+  DPOT_REQUIRE((long long)p.slabs_per_split * (splitk - 1) < nslab, "mlp_wgrad2: split factor leaves an empty split");
+  p.ws = workspace;
+  p.cs_of = 1; p.cs_of2 = 2; p.csL = E > mh ? E : mh;
+  hipStream_t s = as_stream(stream);
+  hipLaunchKernelGGL(gemm_tn_kernel, dim3((unsigned)(p.tiles1 * p.tiles2), 1, (unsigned)(2 * splitk)), dim3(384), 0, s, p);
+  int rc = check_launch("gemm_tn_kernel");
+  if (rc) return rc;
+  int blocks = 2 * (E / 32) * (mh / 32);
+  if (blocks > 2048) blocks = 2048;
+  hipLaunchKernelGGL(mlp_wgrad2_reduce_kernel, dim3(blocks), dim3(256), 0, s, (const float*)workspace, splitk, E, mh, dW2,
+                     dW1, db2, db1);
+  return check_launch("mlp_wgrad2_reduce_kernel");
 }

@@ -424,8 +424,13 @@ class BlockFn(torch.autograd.Function):
             dxn2, _ = ops.gemm_bf16p(dhp, mlp_pk[1], M, E, mh)
             del dhp, dhpT
         else:
-            with streams.side(dev):
-                df2w, df2b = wgrad(do2, Hh, s_f2w, s_f2b, (E, mh, 1, 1))
+            # native fp32: both weight gradients in ONE launch once dHpre exists (csrc/gemm_tn.hip, dpot_mlp_wgrad2)
+            skm = 0 if bf16p else ops.mlp_wgrad2_splitk(M, E, mh, mp)
+            if skm and not (do2.is_contiguous() and Hh.is_contiguous() and xn2.is_contiguous()):
+                skm = 0
+            if not skm:
+                with streams.side(dev):
+                    df2w, df2b = wgrad(do2, Hh, s_f2w, s_f2b, (E, mh, 1, 1))
             if bf16p:
                 dHpre, _ = ops.gemm_bf16p(ops.bf16_pack_rows(do2, planes=npl), mlp_pk[3], M, mh, E, act=act, mode=EPI_DACT,
                                           aux=Hpre, planes=npl)
@@ -433,8 +438,15 @@ class BlockFn(torch.autograd.Function):
                 dHpre, _ = ops.gemm_panel(do2, mlp_pk[3], mh, act=act, mode=EPI_DACT, aux=Hpre)       # do2 W2, * act'(Hpre)
             else:
                 dHpre = ops.linear_bwd_data(do2, f2w, act=act, aux=Hpre, precision=mp)  # [M, mh]
-            with streams.side(dev):
-                df1w, df1b = wgrad(dHpre, xn2.view(M, E), s_f1w, s_f1b, (mh, E, 1, 1))
+            if skm:
+                df2w, df2b = ops._out(s_f2w.out(), (E, mh), dev), ops._out(s_f2b.out(), (E,), dev)
+                df1w, df1b = ops._out(s_f1w.out(), (mh, E), dev), ops._out(s_f1b.out(), (mh,), dev)
+                ops.mlp_wgrad2(do2, Hh, xn2.view(M, E), dHpre, df2w, df2b, df1w, df1b, skm)
+                df2w, df2b = s_f2w.done(df2w.view(E, mh, 1, 1)), s_f2b.done(df2b)
+                df1w, df1b = s_f1w.done(df1w.view(mh, E, 1, 1)), s_f1b.done(df1b)
+            else:
+                with streams.side(dev):
+                    df1w, df1b = wgrad(dHpre, xn2.view(M, E), s_f1w, s_f1b, (mh, E, 1, 1))
             if bf16p:
                 dxn2, _ = ops.gemm_bf16p(ops.bf16_pack_rows(dHpre, planes=npl), mlp_pk[1], M, E, mh, planes=npl)
             elif mlp_pk is not None:

@@ -438,6 +438,23 @@ def afno_block_weights(wbig: Tensor) -> Tuple[Tensor, Tensor]:
     return fwd, bwd
 
 
+def mlp_wgrad2_splitk(T: int, E: int, mh: int, precision: Optional[int] = None) -> int:
+    """split factor of the fused fc1 + fc2 weight gradient (0: not covered / not worthwhile -> two separate GEMMs)"""
+    prec = _gemm_precision if precision is None else precision
+    return _lib.load().dpot_mlp_wgrad2_splitk(T, E, mh) if prec == GEMM_F32 else 0
+
+
+def mlp_wgrad2(do2: Tensor, Hh: Tensor, xn2: Tensor, dHpre: Tensor, dW2: Tensor, db2: Tensor, dW1: Tensor, db1: Tensor,
+               splitk: int) -> None:
+    lib = _lib.load()
+    T, E = do2.shape
+    mh = Hh.shape[1]
+    ws = torch.empty(lib.dpot_mlp_wgrad2_ws_elems(E, mh, splitk), dtype=torch.float32, device=do2.device)
+    check(lib.dpot_mlp_wgrad2(do2.data_ptr(), Hh.data_ptr(), xn2.data_ptr(), dHpre.data_ptr(), T, E, mh, dW2.data_ptr(),
+                              db2.data_ptr(), dW1.data_ptr(), db1.data_ptr(), ws.data_ptr(), splitk, _stream()),
+          "mlp_wgrad2")
+
+
 def afno_wgrad2_splitk(Mm: int, nb: int, bs: int) -> int:
     """split factor of the fused two-layer AFNO weight gradient (0: shape not covered -> two generic GEMM launches)"""
     return _lib.load().dpot_afno_wgrad2_splitk(Mm, nb, bs) if _gemm_precision in (GEMM_F32, GEMM_AUTO) else 0

@@ -148,6 +148,14 @@ int dpot_gemm_tn_splitk(int M, int N, int K, int batch);
  * into the parameters' own layout dw [2, nb, bs, bs] / db [2, nb, bs] (db = column sums of the dO operand).
  * S / dO1pre / O1 / dO2: [Mm, ld] planar-per-block spectra.  Needs 2*bs % 128 == 0 and Mm % 32 == 0
  * (dpot_afno_wgrad2_splitk returns 0 otherwise); workspace: dpot_afno_wgrad2_ws_elems(nb, bs, splitk) floats. */
+/* Both weight gradients of a channel MLP y = fc2(act(fc1(x))) (models/dpot.py:157-161) in one launch + one reduce:
+ * dW2 [E, mh] = do2^T Hh, db2 = colsum(do2), dW1 [mh, E] = dHpre^T xn2, db1 = colsum(dHpre); do2 / xn2 [T, E],
+ * Hh / dHpre [T, mh], all contiguous.  E, mh % 128 == 0, T % 32 == 0 (dpot_mlp_wgrad2_splitk returns 0 otherwise, and
+ * for layers whose single weight gradient already fills the chip). */
+int dpot_mlp_wgrad2_splitk(int T, int E, int mh);
+int64_t dpot_mlp_wgrad2_ws_elems(int E, int mh, int splitk);
+int dpot_mlp_wgrad2(const float* do2, const float* Hh, const float* xn2, const float* dHpre, int T, int E, int mh,
+                    float* dW2, float* db2, float* dW1, float* db1, float* workspace, int splitk, dpot_stream_t stream);
 int dpot_afno_wgrad2_splitk(int Mm, int nb, int bs);
 int64_t dpot_afno_wgrad2_ws_elems(int nb, int bs, int splitk);
 int dpot_afno_wgrad2(const float* S, const float* dO1pre, const float* O1, const float* dO2, int ld, int Mm, int nb,

@@ -940,3 +940,20 @@ def test_afno_wgrad2_both_layers_one_launch(ops, nb, bs, Mm):
         rw, rb = ref(A, Bm)
         assert_close(dw, rw, f"dw {nm}", rtol=2e-5, atol_scale=2e-6)
         assert_close(db, rb, f"db {nm}", rtol=2e-5, atol_scale=2e-6)
+
+
+@pytest.mark.parametrize("T,E,mh", [(8192, 512, 512), (32 * 11, 128, 384), (1024, 256, 128)])
+def test_mlp_wgrad2_both_layers_one_launch(ops, T, E, mh):
+    """dpot_mlp_wgrad2: dW2 = do2^T Hh, db2, dW1 = dHpre^T xn2 (stored un-transposed), db1 from one launch + one reduce"""
+    sk = ops.mlp_wgrad2_splitk(T, E, mh)
+    assert sk >= 1
+    do2, Hh, xn2, dH = rnd(T, E, seed=1), rnd(T, mh, seed=2), rnd(T, E, seed=3), rnd(T, mh, seed=4)
+    dW2 = torch.full((E, mh), float("nan"), device="cuda")
+    dW1 = torch.full((mh, E), float("nan"), device="cuda")
+    db2 = torch.full((E,), float("nan"), device="cuda")
+    db1 = torch.full((mh,), float("nan"), device="cuda")
+    ops.mlp_wgrad2(do2.cuda(), Hh.cuda(), xn2.cuda(), dH.cuda(), dW2, db2, dW1, db1, sk)
+    assert_close(dW2, do2.double().t() @ Hh.double(), "dW2", rtol=2e-5, atol_scale=2e-6)
+    assert_close(dW1, dH.double().t() @ xn2.double(), "dW1", rtol=2e-5, atol_scale=2e-6)
+    assert_close(db2, do2.double().sum(0), "db2", rtol=2e-5, atol_scale=2e-6)
+    assert_close(db1, dH.double().sum(0), "db1", rtol=2e-5, atol_scale=2e-6)
