@@ -211,8 +211,9 @@ def other_rooflines(model, B: int, timeit):
                         "frac": round(fl / t / 1e12 / FP32_MFMA_PEAK_TFLOPS, 4),
                         "frac_of_sustained": round(fl / t / 1e12 / SUSTAINED_FP32_MFMA_TFLOPS, 4)})
         t = timeit(lambda: ops.linear_bwd_wb(dy, A))
-        out.append({"kernel": "dpot::gemm_f32_kernel<64,64,TN> + splitk_reduce (channel-MLP weight gradient dY^T X, bias "
-                              "gradient fused)", "shape": [mh, E, M], "bound": "mfma",
+        out.append({"kernel": "dpot::gemm_tn_kernel + splitk_reduce (ONE channel-MLP weight gradient dY^T X with its bias "
+                              "gradient; the train step runs fc1's and fc2's as one launch)", "shape": [mh, E, M],
+                    "bound": "mfma",
                     "us_per_launch": round(t * 1e6, 2), "achieved": round(fl / t / 1e12, 2),
                     "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                     "frac": round(fl / t / 1e12 / FP32_MFMA_PEAK_TFLOPS, 4),
