@@ -259,6 +259,27 @@ int dpot_gemm_tn_try(const dpot_gemm_desc* d, hipStream_t s) {
 // dWi = D[0:bs,bs:] - D[bs:,0:bs]  and the bias gradients (column sums of dO) for both layers, fixed order.
 // ---------------------------------------------------------------------------------------------------------------------
 namespace dpot {
+// sum_s w[s * stride], s < splits: always the same association ((0+1)+(2+3))+((4+5)+(6+7)) per group of eight, groups in
+// order - deterministic - with eight independent loads in flight (a dependent chain of `splits` L2 round trips made the
+// reduce kernels latency bound: 16 MB in 12 us)
+__device__ __forceinline__ float tn_sum_splits(const float* __restrict__ w, long long stride, int splits) {
+  float v = 0.f;
+  int s = 0;
+  for (; s + 8 <= splits; s += 8) {
+    const float a0 = w[(long long)(s + 0) * stride], a1 = w[(long long)(s + 1) * stride];
+    const float a2 = w[(long long)(s + 2) * stride], a3 = w[(long long)(s + 3) * stride];
+    const float a4 = w[(long long)(s + 4) * stride], a5 = w[(long long)(s + 5) * stride];
+    const float a6 = w[(long long)(s + 6) * stride], a7 = w[(long long)(s + 7) * stride];
+    v += ((a0 + a1) + (a2 + a3)) + ((a4 + a5) + (a6 + a7));
+  }
+  for (; s + 2 <= splits; s += 2) {
+    const float a0 = w[(long long)s * stride], a1 = w[(long long)(s + 1) * stride];
+    v += a0 + a1;
+  }
+  if (s < splits) v += w[(long long)s * stride];
+  return v;
+}
+
 __global__ __launch_bounds__(256) void afno_wgrad2_reduce_kernel(const float* __restrict__ ws, int splits, int nb, int bs,
                                                                  float* __restrict__ dw1, float* __restrict__ db1,
                                                                  float* __restrict__ dw2, float* __restrict__ db2) {
@@ -270,14 +291,10 @@ __global__ __launch_bounds__(256) void afno_wgrad2_reduce_kernel(const float* __
     const long long q = idx - layer * nw;
     const int o = (int)(q % bs), i = (int)((q / bs) % bs), k = (int)(q / ((long long)bs * bs));
     const float* base = ws + (long long)(layer * nb + k) * MN;
-    float rr = 0.f, ii = 0.f, ri = 0.f, ir = 0.f;
-    for (int s = 0; s < splits; ++s) {           // fixed order
-      const float* W = base + (long long)s * total;
-      rr += W[(long long)i * n2 + o];
-      ii += W[(long long)(bs + i) * n2 + bs + o];
-      ri += W[(long long)i * n2 + bs + o];
-      ir += W[(long long)(bs + i) * n2 + o];
-    }
+    const float rr = tn_sum_splits(base + (long long)i * n2 + o, total, splits);
+    const float ii = tn_sum_splits(base + (long long)(bs + i) * n2 + bs + o, total, splits);
+    const float ri = tn_sum_splits(base + (long long)i * n2 + bs + o, total, splits);
+    const float ir = tn_sum_splits(base + (long long)(bs + i) * n2 + o, total, splits);
     float* dw = layer ? dw2 : dw1;
     dw[q] = rr + ii;
     dw[nw + q] = ri - ir;
@@ -285,8 +302,7 @@ __global__ __launch_bounds__(256) void afno_wgrad2_reduce_kernel(const float* __
   const float* wc = ws + (long long)splits * total;
   const long long nc = (long long)2 * nb * n2;
   for (long long idx = blockIdx.x * 256ll + threadIdx.x; idx < nc; idx += (long long)gridDim.x * 256) {
-    float v = 0.f;
-    for (int s = 0; s < splits; ++s) v += wc[(long long)s * nc + idx];
+    const float v = tn_sum_splits(wc + idx, nc, splits);
     const int layer = idx >= (long long)nb * n2;
     const long long q = idx - (long long)layer * nb * n2;
     const int c = (int)(q % bs), part = (int)((q / bs) & 1), k = (int)(q / n2);
@@ -371,9 +387,7 @@ __global__ __launch_bounds__(256) void mlp_wgrad2_reduce_kernel(const float* __r
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       const int r = r0 + ty + 8 * q;
-      const float* w = ws + (long long)prob * MN + (long long)r * mh + c0 + tx;
-      float v = 0.f;
-      for (int s = 0; s < splits; ++s) v += w[(long long)s * total];     // fixed order
+      const float v = tn_sum_splits(ws + (long long)prob * MN + (long long)r * mh + c0 + tx, total, splits);
       if (prob == 0) dW2[(long long)r * mh + c0 + tx] = v;
       else tile[ty + 8 * q][tx] = v;
     }
@@ -390,9 +404,7 @@ __global__ __launch_bounds__(256) void mlp_wgrad2_reduce_kernel(const float* __r
   const float* wc = ws + (long long)splits * total;
   for (int idx = blockIdx.x * 256 + threadIdx.x; idx < E + mh; idx += gridDim.x * 256) {
     const int prob = idx >= E, g = idx - prob * E;
-    float v = 0.f;
-    for (int s = 0; s < splits; ++s) v += wc[((long long)s * 2 + prob) * L + g];
-    (prob ? db1 : db2)[g] = v;
+    (prob ? db1 : db2)[g] = tn_sum_splits(wc + (long long)prob * L + g, 2ll * L, splits);
   }
 }
 }  // namespace dpot
