@@ -33,7 +33,32 @@ __global__ __launch_bounds__(1024) void rel_l2_stats_kernel(const float* __restr
   const ChanLayout L = chan_layout(C, 1024);
   const int tc = threadIdx.x % L.CP, ts = threadIdx.x / L.CP;
   double d2 = 0.0, y2 = 0.0, ms = 0.0;
-  if (tc < C) {
+  if (C == 4 && ((((uintptr_t)x | (uintptr_t)y | (uintptr_t)mask) & 15u) == 0)) {
+    // the DPOT case: one float4 = the 4 channels of a grid point.  Thread (tc = lane & 3, ts) still owns channel tc
+    // in the reduction below, but LOADS whole points: lanes 4q..4q+3 read the same float4 and keep their component
+    // (one coalesced 16-byte access per point instead of four 4-byte ones; two points in flight per trip)
+    const float4* xb = reinterpret_cast<const float4*>(x) + (long long)b * S;
+    const float4* yb = reinterpret_cast<const float4*>(y) + (long long)b * S;
+    const float4* mb = mask ? reinterpret_cast<const float4*>(mask) + (long long)b * (S / Tt) : nullptr;
+    auto comp = [&](const float4& v) __attribute__((always_inline)) {
+      return tc == 0 ? v.x : tc == 1 ? v.y : tc == 2 ? v.z : v.w;
+    };
+    auto one = [&](int s2, const float4& xv, const float4& yv4) __attribute__((always_inline)) {
+      const float m = mb ? comp(mb[s2 / Tt]) : 1.f;
+      const float yv = comp(yv4) * m;
+      const float d = comp(xv) * m - yv;
+      d2 += (double)d * d;
+      y2 += (double)yv * yv;
+      if ((s2 % Tt) == 0) ms += m;
+    };
+    int s2 = s_beg + ts;
+    for (; s2 + L.TS < s_end; s2 += 2 * L.TS) {
+      const float4 x0 = xb[s2], y0 = yb[s2], x1 = xb[s2 + L.TS], y1 = yb[s2 + L.TS];
+      one(s2, x0, y0);
+      one(s2 + L.TS, x1, y1);
+    }
+    if (s2 < s_end) one(s2, xb[s2], yb[s2]);
+  } else if (tc < C) {
     const float* xb = x + (long long)b * S * C;
     const float* yb = y + (long long)b * S * C;
     const float* mb = mask ? mask + (long long)b * (S / Tt) * C : nullptr;
@@ -50,13 +75,18 @@ __global__ __launch_bounds__(1024) void rel_l2_stats_kernel(const float* __restr
   red[1][threadIdx.x] = y2;
   red[2][threadIdx.x] = ms;
   __syncthreads();
-  if (ts == 0 && tc < C) {
-    double a = 0.0, bq = 0.0, cq = 0.0;
-    for (int r = 0; r < L.TS; ++r) {
-      a += red[0][r * L.CP + tc];
-      bq += red[1][r * L.CP + tc];
-      cq += red[2][r * L.CP + tc];
+  // fixed-shape tree over the row lanes (a serial 256-long loop of double LDS reads by C threads cost 15 of 20 us)
+  for (int half = L.TS >> 1; half >= 1; half >>= 1) {
+    if (ts < half) {
+      const int o = half * L.CP;
+      red[0][threadIdx.x] += red[0][threadIdx.x + o];
+      red[1][threadIdx.x] += red[1][threadIdx.x + o];
+      red[2][threadIdx.x] += red[2][threadIdx.x + o];
     }
+    __syncthreads();
+  }
+  if (ts == 0 && tc < C) {
+    const double a = red[0][tc], bq = red[1][tc], cq = red[2][tc];
     float* st = part + (((long long)b * nch + chunk) * C + tc) * 4;
     st[0] = (float)a;
     st[1] = (float)bq;
@@ -68,25 +98,32 @@ __global__ __launch_bounds__(1024) void rel_l2_stats_kernel(const float* __restr
 __global__ void rel_l2_final_kernel(float* __restrict__ stats, const float* __restrict__ part, int nchunk,
                                     float* __restrict__ loss, int B, int C, int has_mask) {
   __shared__ double shd[16];
+  // phase 1: one thread per (sample, channel) combines the chunk partials (16-byte loads, fixed order) and leaves the
+  // channel's loss term in the 4th slot of its stats entry; phase 2: one thread per sample adds its channels in order.
+  // (One thread per SAMPLE walking C * nchunk * 3 dependent 4-byte loads took 5-11 us.)
+  for (int idx = threadIdx.x; idx < B * C; idx += blockDim.x) {
+    const int b = idx / C, c = idx - b * C;
+    double a0 = 0.0, a1 = 0.0, a2 = 0.0;
+    const float4* pp = reinterpret_cast<const float4*>(part) + ((long long)b * nchunk) * C + c;
+#pragma unroll 4
+    for (int k = 0; k < nchunk; ++k) {
+      const float4 v = pp[(long long)k * C];
+      a0 += (double)v.x;
+      a1 += (double)v.y;
+      a2 += (double)v.z;
+    }
+    const float s0 = (float)a0, s1 = (float)a1;
+    reinterpret_cast<float4*>(stats)[idx] = make_float4(s0, s1, (float)a2, sqrtf(s0) / (sqrtf(s1) + 1e-8f));
+  }
+  __syncthreads();
   double acc = 0.0;
   for (int b = threadIdx.x; b < B; b += blockDim.x) {
     double s = 0.0;
     int nch = 0;
     for (int c = 0; c < C; ++c) {
-      float* st = stats + ((long long)b * C + c) * 4;
-      double a0 = 0.0, a1 = 0.0, a2 = 0.0;
-      for (int k = 0; k < nchunk; ++k) {
-        const float* pp = part + (((long long)b * nchunk + k) * C + c) * 4;
-        a0 += (double)pp[0];
-        a1 += (double)pp[1];
-        a2 += (double)pp[2];
-      }
-      st[0] = (float)a0;
-      st[1] = (float)a1;
-      st[2] = (float)a2;
-      st[3] = 0.f;
-      s += (double)(sqrtf(st[0]) / (sqrtf(st[1]) + 1e-8f));
-      if (st[2] != 0.f) ++nch;
+      const float4 st = reinterpret_cast<const float4*>(stats)[(long long)b * C + c];
+      s += (double)st.w;
+      if (st.z != 0.f) ++nch;
     }
     if (!has_mask) nch = C;
     acc += s / (double)nch;
@@ -100,6 +137,28 @@ __global__ void rel_l2_bwd_kernel(const float* __restrict__ x, const float* __re
                                   const float* __restrict__ gloss, float* __restrict__ dx, int S, int C, int Tt,
                                   long long total) {
   const float g = gloss[0];
+  if (C == 4 && total < (1ll << 31) && ((((uintptr_t)x | (uintptr_t)y | (uintptr_t)dx | (uintptr_t)mask) & 15u) == 0)) {
+    // the DPOT case: one float4 per grid point, 32-bit index arithmetic (the generic loop below divides 64-bit
+    // integers three times per element: ~300 VALU instructions, 25 MB in 14 us)
+    const unsigned n4 = (unsigned)(total >> 2), S_u = (unsigned)S;
+    for (unsigned q = blockIdx.x * 256u + threadIdx.x; q < n4; q += gridDim.x * 256u) {
+      const unsigned b = q / S_u, s = q - b * S_u;
+      const float* st = stats + (long long)b * 16;          // [c][4] = {d2, y2, msum, -}
+      int nch = 4;
+      if (mask) nch = (st[2] != 0.f) + (st[6] != 0.f) + (st[10] != 0.f) + (st[14] != 0.f);
+      const float4 m = mask ? reinterpret_cast<const float4*>(mask)[(long long)b * (S / Tt) + s / Tt]
+                            : make_float4(1.f, 1.f, 1.f, 1.f);
+      const float4 xv = reinterpret_cast<const float4*>(x)[q], yv = reinterpret_cast<const float4*>(y)[q];
+      auto one = [&](float xe, float ye, float me, int c) __attribute__((always_inline)) {
+        const float dn = sqrtf(st[4 * c]);
+        const float yn = sqrtf(st[4 * c + 1]) + 1e-8f;
+        return dn > 0.f ? g * ((xe - ye) * me * me) / (dn * yn * (float)nch) : 0.f;
+      };
+      reinterpret_cast<float4*>(dx)[q] = make_float4(one(xv.x, yv.x, m.x, 0), one(xv.y, yv.y, m.y, 1),
+                                                     one(xv.z, yv.z, m.z, 2), one(xv.w, yv.w, m.w, 3));
+    }
+    return;
+  }
   for (long long idx = blockIdx.x * 256ll + threadIdx.x; idx < total; idx += (long long)gridDim.x * 256) {
     const int c = (int)(idx % C);
     const long long r = idx / C;
@@ -451,7 +510,7 @@ static inline unsigned grid_for(long long n, int cap = 4096) {
 using namespace dpot;
 
 extern "C" int dpot_rel_l2_chunks(int S, int C) {
-  long long n = ((long long)S * C + 16383) / 16384;
+  long long n = ((long long)S * C + 4095) / 4096;       // 1024 points of 4 channels per 1024-thread block and trip pair
   if (n > 32) n = 32;
   if (n < 1) n = 1;
   return (int)n;

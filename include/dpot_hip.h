@@ -298,7 +298,7 @@ int dpot_out_tail_bwd(const float* upre, const float* dout, const float* w2, con
 /* masked relative L2 summed over the batch (SimpleLpLoss(size_average=False), utils/criterion.py:38-59).
  * x,y: [B, S, C] (S = X*Y*T), mask: [B, Sm, C] with S % Sm == 0 broadcast over the time axis (or NULL).
  * stats: (1 + dpot_rel_l2_chunks(S, C)) * B * C * 4 floats; the first [B, C, 4] block holds the final
- * {sum d^2, sum y^2, sum mask, unused}, the rest is per-chunk scratch.  loss: 1 float.  bwd: dx = gloss[0] * dloss/dx. */
+ * {sum d^2, sum y^2, sum mask, the channel's loss term}, the rest is per-chunk scratch.  loss: 1 float.  bwd: dx = gloss[0] * dloss/dx. */
 int dpot_rel_l2_chunks(int S, int C);
 int dpot_rel_l2_fwd(const float* x, const float* y, const float* mask, float* stats, float* loss, int B,
                     int S, int C, int Tt, dpot_stream_t stream);
