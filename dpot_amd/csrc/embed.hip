@@ -102,9 +102,6 @@ __global__ __launch_bounds__(256) void embed_fwd_kernel(const EmbedArgs a) {
   const int abase = (p * EM_P * T + t) * EM_C + kq;
 
   auto issue = [&](int g, int buf) __attribute__((always_inline)) {
-#ifdef EMB_NODMA
-    if (a.act == 77)
-#endif
     em_issue_x(a, g, lds + buf * EM_GFL, run, tid, nthr);
     const int pyq = g % a.wq, px = (g / a.wq) % a.h;
     em_issue_lin(a.bt + (long long)(px * a.w + pyq * EM_NP) * T * hidp, btl + buf * BTF, btn >> 2, tid, nthr);
@@ -123,7 +120,6 @@ __global__ __launch_bounds__(256) void embed_fwd_kernel(const EmbedArgs a) {
     f32x4 acc[EM_CT];
 #pragma unroll
     for (int ct = 0; ct < EM_CT; ++ct) acc[ct] = f32x4{0.f, 0.f, 0.f, 0.f};
-#ifndef EMB_NOMFMA
 #pragma unroll 2
     for (int i = 0; i < EM_P; ++i) {
       float av[8];
@@ -142,7 +138,6 @@ __global__ __launch_bounds__(256) void embed_fwd_kernel(const EmbedArgs a) {
             acc[ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[4 * jq + jj], bf[ct][jj], acc[ct], 0, 0, 0);
       }
     }
-#endif
     // epilogue in place: the bias-table tile of the group becomes its Hpre tile (each element is touched by exactly one
     // lane; the 16 rows of a wave are one contiguous piece of the tile), then every wave streams its rows out with
     // 16-byte stores - Hpre as is, Hh through the activation
@@ -169,9 +164,6 @@ __global__ __launch_bounds__(256) void embed_fwd_kernel(const EmbedArgs a) {
       const float4* src = reinterpret_cast<const float4*>(tile + r0 * hidp);
       float4* o1 = reinterpret_cast<float4*>(a.hpre + (m0 + r0) * hidp);
       float4* o2 = reinterpret_cast<float4*>(a.hh + (m0 + r0) * hidp);
-#ifdef EMB_NOEPI
-      if (a.act == 77)
-#endif
       for (int q = lane; q < nq; q += 64) {
         const float4 v = src[q];
         o1[q] = v;

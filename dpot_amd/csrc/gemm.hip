@@ -390,8 +390,6 @@ extern "C" int dpot_gemm_auto_splitk(int M, int N, int K, int batch) {
 // DPOT_GEMM_AUTO: both kernels are fp32-accurate, so the choice is pure speed.  The bf16x6 kernel has the higher
 // roof but a longer pipeline (two slabs of prologue, 120 KB of LDS per workgroup): it pays on the large products
 // (measured in the DPOT-Tiny step: 3 GFLOP and up: channel-MLP, embed and de-embed GEMMs), not on the 2.4 GFLOP batched AFNO mixer.
-int dpot_gemm_tn_try(const dpot_gemm_desc* d, hipStream_t s);   // gemm_tn.hip
-
 static int resolve_precision(int precision, int M, int N, int K, int batch) {
   if (precision != DPOT_GEMM_AUTO) return precision;
   static const double min_gflop = [] {

@@ -149,3 +149,6 @@ __device__ __forceinline__ void epi_fragment(const EpiArgs& e, int evec, int b, 
 
 
 }  // namespace dpot
+
+// gemm_tn.hip: the weight-gradient kernel behind dpot_gemm_f32 (transA, !transB, split-K); -1 = descriptor not eligible
+int dpot_gemm_tn_try(const dpot_gemm_desc* d, hipStream_t s);

@@ -281,8 +281,8 @@ def _block_parts(x, n1w, n1b, n2w, n2b, f1w, f1b, packed, dims, mp, need_out, f2
     if wb1T is not None:
         # both layers of the block-diagonal complex MLP in ONE launch; the activated spectrum never leaves the CU
         # except as the copy saved for the backward (csrc/afno_mlp.hip)
-        # (layout 1: the (Wr, Wi) fragment packs of the three-product kernel, tagged on the tensors by ops.AfnoPacks)
-        lay = afno_layout if afno_layout is not None else getattr(wb1T, "afno_layout", 0)
+        # (layout 1: the (Wr, Wi) fragment packs of the three-product kernel; ops.AfnoItem carries the tag)
+        lay = afno_layout if afno_layout is not None else getattr(packed[0], "layout", 0)
         O2, O1pre, O1 = ops.afno_mlp2(S, wb1T, bb1, wb2T, bb2, nb, bs, act, mode=0, want_pre=True, want_mid=True,
                                       layout=lay)
     else:
@@ -308,8 +308,8 @@ def _block_parts(x, n1w, n1b, n2w, n2b, f1w, f1b, packed, dims, mp, need_out, f2
         xp, xpT, _ = ops.bf16_pack_both(xn2.view(M, E))
         del xn2
         # fc1: the epilogue emits the activated hidden layer directly in its two packed forms (no fp32 copy of it exists)
-        _, Hpre, hp, hpT, _ = ops.gemm_bf16p(xp, mlp_pk[0], M, mh, E, bias=f1b, act=act, mode=EPI_ACT, save_pre=True,
-                                             pack_rows=need_out, pack_trans=True, store=False)
+        _, Hpre, hp, hpT, _ = ops.gemm_bf16p_packed(xp, mlp_pk[0], M, mh, E, bias=f1b, act=act, mode=EPI_ACT,
+                                                    save_pre=True, pack_rows=need_out, pack_trans=True, store=False)
         out = None
         if need_out:
             out, _ = ops.gemm_bf16p(hp, mlp_pk[2], M, E, mh, bias=f2b, res=x.view(M, E))
@@ -364,7 +364,7 @@ class BlockFn(torch.autograd.Function):
             ctx.save_for_backward(x, *parts, wb1, wb2, n1w, n2w, f1w, f2w)
         ctx.recompute = recompute
         ctx.dims = dims
-        ctx.afno_layout = getattr(packed[0][2], "afno_layout", 0) if ctx.fused_mixer else 0
+        ctx.afno_layout = getattr(packed[0], "layout", 0) if ctx.fused_mixer else 0
         ctx.mlp_precision = mp
         ctx.sinks = _sinks(ctx, (n1w, n1b, w1, b1, w2, b2, n2w, n2b, f1w, f1b, f2w, f2b), 1)
         return out.view(B, tok, E)
@@ -415,9 +415,9 @@ class BlockFn(torch.autograd.Function):
             df2w, _ = ops.gemm_bf16p(dopT, Hh, E, mh, M, out=s_f2w.out())
             df2w, df2b = s_f2w.done(df2w.view(E, mh, 1, 1)), s_f2b.done(df2b)
             # dHpre = (do2 W2) * act'(Hpre) leaves the GEMM as its two packs + bias column sums only
-            _, _, dhp, dhpT, df1b = ops.gemm_bf16p(dop, mlp_pk[3], M, mh, E, act=act, mode=EPI_DACT, aux=Hpre,
-                                                   pack_rows=True, pack_trans=True, colsum=True,
-                                                   colsum_out=s_f1b.out(), store=False)
+            _, _, dhp, dhpT, df1b = ops.gemm_bf16p_packed(dop, mlp_pk[3], M, mh, E, act=act, mode=EPI_DACT, aux=Hpre,
+                                                          pack_rows=True, pack_trans=True, colsum=True,
+                                                          colsum_out=s_f1b.out(), store=False)
             del dop, dopT
             df1w, _ = ops.gemm_bf16p(dhpT, xn2, mh, E, M, out=s_f1w.out())
             df1w, df1b = s_f1w.done(df1w.view(mh, E, 1, 1)), s_f1b.done(df1b)

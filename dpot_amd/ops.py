@@ -250,13 +250,23 @@ def bf16_pack_both(x: Tensor, want_rows: bool = True, want_trans: bool = True, c
 def gemm_bf16p(Ap: Tensor, Wp: Tensor, M: int, N: int, K: int, *, bias: Optional[Tensor] = None, act: int = 0,
                mode: int = EPI_LINEAR, aux: Optional[Tensor] = None, res: Optional[Tensor] = None,
                save_pre: bool = False, out: Optional[Tensor] = None, splitk: Optional[int] = None,
-               planes: int = 1, pack_rows: bool = False, pack_trans: bool = False, colsum: bool = False,
-               colsum_out: Optional[Tensor] = None, store: bool = True):
+               planes: int = 1) -> Tuple[Tensor, Optional[Tensor]]:
     """C[M,N] fp32 = epilogue(A @ Wt^T) on the bf16 matrix cores; Ap / Wp: packed bf16 operands (bf16_pack_rows, or a
     bf16 PanelPacks buffer) with the same number of planes (1: plain bf16, 3: bf16x6 = fp32-accurate).
-    splitk=None: the library's choice (weight gradients use split-K).  Returns (C, pre).
-    pack_rows / pack_trans / colsum (planes == 1, M % 32 == 0): the epilogue also emits the packed forms of the output
-    and its column sums; store=False skips the fp32 output.  Returns (C | None, pre, row pack, transposed pack, colsum)."""
+    splitk=None: the library's choice (weight gradients use split-K).  Returns (C, pre | None)."""
+    C_, pre, _, _, _ = gemm_bf16p_packed(Ap, Wp, M, N, K, bias=bias, act=act, mode=mode, aux=aux, res=res,
+                                         save_pre=save_pre, out=out, splitk=splitk, planes=planes)
+    return C_, pre
+
+
+def gemm_bf16p_packed(Ap: Tensor, Wp: Tensor, M: int, N: int, K: int, *, bias: Optional[Tensor] = None, act: int = 0,
+                      mode: int = EPI_LINEAR, aux: Optional[Tensor] = None, res: Optional[Tensor] = None,
+                      save_pre: bool = False, out: Optional[Tensor] = None, splitk: Optional[int] = None,
+                      planes: int = 1, pack_rows: bool = False, pack_trans: bool = False, colsum: bool = False,
+                      colsum_out: Optional[Tensor] = None, store: bool = True):
+    """gemm_bf16p whose epilogue can ALSO emit the packed forms of the output and its column sums
+    (pack_rows / pack_trans / colsum: planes == 1, M % 32 == 0, no split-K); store=False skips the fp32 output.
+    Always returns (C | None, pre | None, row pack | None, transposed pack | None, column sums | None)."""
     lib = _lib.load()
     packs = pack_rows or pack_trans or colsum
     C_ = _out(out, (M, N), Ap.device) if (store or not packs) else None
@@ -271,8 +281,6 @@ def gemm_bf16p(Ap: Tensor, Wp: Tensor, M: int, N: int, K: int, *, bias: Optional
                               aux.stride(0) if aux is not None else 0, _p(res),
                               res.stride(0) if res is not None else 0, _p(pre), N, _p(C_), N, M, N, K,
                               act, mode, planes, splitk, _p(ws), _p(pr), _p(pt), _p(part), _stream()), "gemm_bf16p")
-    if not packs:
-        return C_, pre
     cs = globals()["colsum"](part, M // 32, N, out=colsum_out) if colsum else None
     return C_, pre, pr, pt, cs
 
@@ -390,6 +398,16 @@ def afno_pack_multi(pairs) -> list:
     return [(wbig[i], bbig[i], None, None) for i in range(n)]
 
 
+class AfnoItem(tuple):
+    """(Wbig, bbig, fwd pack | None, bwd pack | None) of one AFNO layer + the layout of the packs (0: fragment-block-major
+    Wbig for afno_mlp2's four-product kernel, 1: (Wr, Wi) fragments for the three-product kernel)"""
+
+    def __new__(cls, items, layout: int = 0):
+        self = super().__new__(cls, items)
+        self.layout = layout
+        return self
+
+
 class AfnoPacks:
     """Packed forms of ALL AFNO layers of a model, refreshed by ONE launch (dpot_afno_pack_all) from a device-resident
     job table: persistent output buffers, so the table is built once per parameter placement.
@@ -417,11 +435,8 @@ class AfnoPacks:
             tab[i].fwd = fwd[i].data_ptr() if fused else None
             tab[i].bwd = bwd[i].data_ptr() if fused else None
         self.table = torch.from_numpy(host).to(dev)
-        self.items = [(wbig[i], bbig[i], fwd[i] if fused else None, bwd[i] if fused else None) for i in range(n)]
-        for it in self.items:           # the fused-kernel packs remember their layout (functional._block_parts reads it)
-            for t in it[2:]:
-                if t is not None:
-                    t.afno_layout = self.layout
+        self.items = [AfnoItem((wbig[i], bbig[i], fwd[i] if fused else None, bwd[i] if fused else None), self.layout)
+                      for i in range(n)]
 
     def refresh(self):
         check(_lib.load().dpot_afno_pack_all(self.table.data_ptr(), self.n, self.nb, self.bs, self.layout, _stream()),

@@ -857,13 +857,13 @@ def test_gemm_bf16_panel_packed_epilogue_outputs(ops):
     pk.refresh()
     Ap = ops.bf16_pack_rows(A.cuda())
     y, pre = ops.gemm_bf16p(Ap, pk.bufs[0], M, N, K, bias=b.cuda(), act=1, mode=ops.EPI_ACT, save_pre=True)
-    y2, pre2, pr, pt, cs = ops.gemm_bf16p(Ap, pk.bufs[0], M, N, K, bias=b.cuda(), act=1, mode=ops.EPI_ACT, save_pre=True,
-                                          pack_rows=True, pack_trans=True, colsum=True)
+    y2, pre2, pr, pt, cs = ops.gemm_bf16p_packed(Ap, pk.bufs[0], M, N, K, bias=b.cuda(), act=1, mode=ops.EPI_ACT,
+                                                 save_pre=True, pack_rows=True, pack_trans=True, colsum=True)
     assert torch.equal(y, y2) and torch.equal(pre, pre2)
     assert torch.equal(pr, ops.bf16_pack_rows(y)) and torch.equal(pt, ops.bf16_pack_rows(y, trans=True))
     assert_close(cs, y.double().sum(0), "colsum", rtol=2e-5, atol_scale=2e-6)
-    y3, _, pr3, pt3, cs3 = ops.gemm_bf16p(Ap, pk.bufs[0], M, N, K, bias=b.cuda(), act=1, mode=ops.EPI_ACT,
-                                          pack_trans=True, store=False)
+    y3, _, pr3, pt3, cs3 = ops.gemm_bf16p_packed(Ap, pk.bufs[0], M, N, K, bias=b.cuda(), act=1, mode=ops.EPI_ACT,
+                                                 pack_trans=True, store=False)
     assert y3 is None and pr3 is None and cs3 is None and torch.equal(pt3, pt)
 
 
