@@ -957,3 +957,25 @@ def test_mlp_wgrad2_both_layers_one_launch(ops, T, E, mh):
     assert_close(dW1, dH.double().t() @ xn2.double(), "dW1", rtol=2e-5, atol_scale=2e-6)
     assert_close(db2, do2.double().sum(0), "db2", rtol=2e-5, atol_scale=2e-6)
     assert_close(db1, dH.double().sum(0), "db1", rtol=2e-5, atol_scale=2e-6)
+
+
+def test_bf16_panel_packed_epilogue_dact_with_colsum_and_strided_pack(ops):
+    """the backward form the bf16 channel MLP uses: (dy W) * gelu'(aux) leaves the GEMM only as its two packs + the bias
+    column sums (no fp32 store); and dpot_bf16_pack_both on a row window of a wider matrix (ld > K)"""
+    M, N, K = 128, 256, 512
+    dY, W, aux = rnd(M, K, seed=1), rnd(N, K, seed=2, scale=1.0 / math.sqrt(K)), rnd(M, N, seed=3)
+    Wd = W.cuda()
+    pk = ops.PanelPacks([(Wd, N, K, K, False)], bf16=True)
+    pk.refresh()
+    Ap = ops.bf16_pack_rows(dY.cuda())
+    ref, _ = ops.gemm_bf16p(Ap, pk.bufs[0], M, N, K, act=1, mode=ops.EPI_DACT, aux=aux.cuda())
+    c, pre, pr, pt, cs = ops.gemm_bf16p_packed(Ap, pk.bufs[0], M, N, K, act=1, mode=ops.EPI_DACT, aux=aux.cuda(),
+                                               pack_rows=True, pack_trans=True, colsum=True, store=False)
+    assert c is None and pre is None
+    assert torch.equal(pr, ops.bf16_pack_rows(ref)) and torch.equal(pt, ops.bf16_pack_rows(ref, trans=True))
+    assert_close(cs, ref.double().sum(0), "colsum", rtol=2e-5, atol_scale=2e-6)
+    wide = rnd(192, 1024, seed=5).cuda()
+    win = wide[64:, 256:768]                                   # [128, 512] window, ld = 1024
+    r1, t1, c1 = ops.bf16_pack_both(win, want_colsum=True)
+    r2, t2, c2 = ops.bf16_pack_both(win.contiguous(), want_colsum=True)
+    assert torch.equal(r1, r2) and torch.equal(t1, t2) and torch.equal(c1, c2)
