@@ -36,13 +36,16 @@ static inline int64_t cdiv64(int64_t a, int64_t b) { return (a + b - 1) / b; }
 // two orders below the 1e-4 parity tolerance.  exp(-z^2) = exp(-x^2/2) is also the Gaussian of the derivative.
 __device__ __forceinline__ void gelu_parts(float x, float& cdf, float& gauss) {
   const float z = fabsf(x) * 0.70710678118654752440f;
-  const float t = __frcp_rn(fmaf(0.3275911f, z, 1.0f));
+  // v_rcp_f32 / v_exp_f32 directly (1 ulp each): __frcp_rn expands to the correctly-rounded division sequence
+  // (v_div_scale x2, v_div_fmas, v_div_fixup + Newton steps: ~10 of the ~24 instructions of a GELU) and __expf to a
+  // range-checked form; their last-bit differences are two orders below the 3e-7 error of the 7.1.26 polynomial itself
+  const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, z, 1.0f));
   float poly = fmaf(t, 1.061405429f, -1.453152027f);
   poly = fmaf(t, poly, 1.421413741f);
   poly = fmaf(t, poly, -0.284496736f);
   poly = fmaf(t, poly, 0.254829592f);
   poly *= t;
-  gauss = __expf(-z * z);
+  gauss = __builtin_amdgcn_exp2f(-1.4426950408889634f * z * z);        // exp(-z^2)
   const float half = 0.5f * poly * gauss;
   cdf = x >= 0.f ? 1.0f - half : half;
 }
