@@ -29,35 +29,54 @@ static inline int64_t cdiv64(int64_t a, int64_t b) { return (a + b - 1) / b; }
 // ---- activations (models/dpot.py:19) ---------------------------------------------------------------
 // Exact-erf GELU is the DPOT default and sits in every GEMM epilogue and in the fused tail; libm's erff costs ~150
 // VALU instructions per element (two divergent branches), which made GELU ~8% of the whole training step.
-// Phi(x) = 0.5 (1 + erf(x/sqrt2)) is evaluated branch-free from Abramowitz-Stegun 7.1.26,
-//   1 - erf(z) = t (a1 + t (a2 + t (a3 + t (a4 + t a5)))) exp(-z^2),  t = 1/(1 + p z),  |err| <= 1.5e-7,
-// on |x| with the reflection Phi(-x) = 1 - Phi(x) (no cancellation in the left tail); measured in fp32 against
-// float64 erf over [-12, 12]: |Phi err| <= 3.0e-7, |gelu err| <= 6.5e-7 (1.6e-7 relative), |gelu' err| <= 3.3e-7 -
-// two orders below the 1e-4 parity tolerance.  exp(-z^2) = exp(-x^2/2) is also the Gaussian of the derivative.
-__device__ __forceinline__ void gelu_parts(float x, float& cdf, float& gauss) {
-  const float z = fabsf(x) * 0.70710678118654752440f;
-  // v_rcp_f32 / v_exp_f32 directly (1 ulp each): __frcp_rn expands to the correctly-rounded division sequence
-  // (v_div_scale x2, v_div_fmas, v_div_fixup + Newton steps: ~10 of the ~24 instructions of a GELU) and __expf to a
-  // range-checked form; their last-bit differences are two orders below the 3e-7 error of the 7.1.26 polynomial itself
-  const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, z, 1.0f));
-  float poly = fmaf(t, 1.061405429f, -1.453152027f);
-  poly = fmaf(t, poly, 1.421413741f);
-  poly = fmaf(t, poly, -0.284496736f);
-  poly = fmaf(t, poly, 0.254829592f);
-  poly *= t;
-  gauss = __builtin_amdgcn_exp2f(-1.4426950408889634f * z * z);        // exp(-z^2)
-  const float half = 0.5f * poly * gauss;
-  cdf = x >= 0.f ? 1.0f - half : half;
+// The normal tail is evaluated branch-free, without a division, as  Phi(-a) = 2^-R(a),  a = min(|x|, 6.5):
+// R(a) = -log2 Phi(-a) is smooth (1 at a = 0, ~0.72 a^2 for large a) and a degree-8 polynomial (weighted minimax fit,
+// scripts/fit_gelu_tail.py) reproduces Phi(-a) to 1.4e-8; in fp32 against float64 over [-12, 12]:
+// |Phi err| <= 8.3e-8, |gelu err| <= 2.5e-7 (half an ulp at |x| = 12), |gelu' err| <= 1.5e-7 - three orders below the
+// 1e-4 parity tolerance.  With the tail in hand
+//     gelu(x) = x Phi(x) = max(x, 0) - |x| Phi(-|x|),      Phi(x) = x >= 0 ? 1 - Phi(-|x|) : Phi(-|x|)
+// (no cancellation in the left tail; beyond |x| = 6.5 the clamped tail, 4e-11, is below fp32 resolution of the result).
+// Cost: 11 VALU instructions + one v_exp_f32 (quarter rate) = 15 issue slots - the previous Abramowitz-Stegun 7.1.26
+// form needed a reciprocal AND an exponential plus a compare / select and was 3x less accurate.  This matters: the
+// per-pixel tail kernels (csrc/tail.hip) are bound by VALU ISSUE, 33.5 M GELUs per launch at DPOT-Tiny B=32.
+// The clamp and the max use gfx950's v_minimum3_f32 / v_maximum3_f32 (IEEE-754-2019 minimum / maximum): unlike
+// v_min / v_max they PROPAGATE NaN, so a diverged run still surfaces as NaN loss (and they take the |x| modifier).
+// (Packed v_pk_fma_f32 would halve the polynomial's slots, but packed fp32 is an anti-lever beside MFMAs -
+// MI355X_MICROARCH "price of one filler" - and the compiler scalarises most of it there anyway; measured: no gain.)
+__device__ __forceinline__ float normal_tail(float ax) {   // Phi(-ax), 0 <= ax <= 6.5
+  float r = fmaf(ax, 2.275872930e-06f, -3.296802970e-05f);
+  r = fmaf(r, ax, 1.572788460e-04f);
+  r = fmaf(r, ax, 2.024787827e-04f);
+  r = fmaf(r, ax, -7.142781746e-03f);
+  r = fmaf(r, ax, 5.254643410e-02f);
+  r = fmaf(r, ax, 4.591930509e-01f);
+  r = fmaf(r, ax, 1.151106954e+00f);
+  r = fmaf(r, ax, 9.999999404e-01f);
+  return __builtin_amdgcn_exp2f(-r);
 }
+__device__ __forceinline__ float gelu_clamp_abs(float x) { return __builtin_elementwise_minimum(__builtin_fabsf(x), 6.5f); }
 __device__ __forceinline__ float gelu_fwd(float x) {
-  float cdf, g;
-  gelu_parts(x, cdf, g);
-  return x * cdf;
+  const float ax = gelu_clamp_abs(x);
+  return fmaf(-ax, normal_tail(ax), __builtin_elementwise_maximum(x, 0.0f));
+}
+// cdf = Phi(x), gauss = exp(-x^2 / 2) (the Gaussian of the derivative)
+__device__ __forceinline__ void gelu_parts(float x, float& cdf, float& gauss) {
+  const float e = normal_tail(gelu_clamp_abs(x));
+  gauss = __builtin_amdgcn_exp2f(-0.72134752044448170368f * x * x);
+  cdf = x >= 0.f ? 1.0f - e : e;
 }
 __device__ __forceinline__ float gelu_bwd(float x) {
   float cdf, g;
   gelu_parts(x, cdf, g);
   return fmaf(x * 0.39894228040143267794f, g, cdf);
+}
+// value and derivative together (one tail evaluation)
+__device__ __forceinline__ void gelu_val_der(float x, float& val, float& der) {
+  const float ax = gelu_clamp_abs(x);
+  const float e = normal_tail(ax);
+  const float phi = __builtin_amdgcn_exp2f(fmaf(x * x, -0.72134752044448170368f, -1.32574806473615975284f));
+  val = fmaf(-ax, e, __builtin_elementwise_maximum(x, 0.0f));
+  der = fmaf(x, phi, x >= 0.f ? 1.0f - e : e);
 }
 
 __device__ __forceinline__ float act_fwd(int act, float x) {
