@@ -88,6 +88,8 @@ SIGNATURES = {
     "dpot_colsum_scatter": (c_i, [c_fp, c_i, c_i, c_i, c_fp, c_i, C.POINTER(C.c_int), C.POINTER(C.c_int),
                                   C.POINTER(C.c_void_p), c_fp]),
     "dpot_group_rowsum": (c_i, [c_fp, c_fp] + [c_i] * 4 + [c_fp]),
+    "dpot_small_linear_supported": (c_i, [c_i] * 3),
+    "dpot_small_linear": (c_i, [c_fp, c_i, c_fp, c_i, c_fp, c_fp, c_fp] + [c_i] * 5 + [c_fp]),
     "dpot_token_mean": (c_i, [c_fp, c_fp] + [c_i] * 3 + [c_fp]),
     "dpot_token_mean_bwd": (c_i, [c_fp] * 3 + [c_i] * 3 + [c_fp]),
     "dpot_bias_add": (c_i, [c_fp] * 3 + [c_i, c_i, c_fp]),

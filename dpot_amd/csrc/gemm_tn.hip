@@ -220,6 +220,9 @@ extern "C" int dpot_gemm_tn_splitk(int M, int N, int K, int batch) {
   if (s > smax) s = smax;
   if (s < 2) s = 2;                                   // the kernel always goes through the workspace + reduce
   if (s > nslab) return 0;
+  const long long sps = (nslab + s - 1) / s;          // slabs per split; drop the splits that would come out empty
+  s = (nslab + sps - 1) / sps;                        // (e.g. 256 slabs / 21 splits -> 13 per split -> 20 splits)
+  if (s < 2) return 0;
   return (int)s;
 }
 

@@ -583,8 +583,12 @@ static int noise_launch(const float* xx, const float* eps, float* out, float* no
   hipLaunchKernelGGL(chan_sumsq_part_kernel, dim3(nch, B), dim3(256), 0, as_stream(stream), xx, part, S, C, nch, rng);
   int rc = check_launch("chan_sumsq_part_kernel");
   if (rc) return rc;
-  long long g = ((long long)S * C / 4 + 511) / 512;       // 2 float4 per thread (every thread's loads issue up front)
-  if (g > 2048) g = 2048;
+  // 2 float4 per thread and trip (every thread's loads issue up front); ~2048 workgroups in all (8 per CU, one
+  // resident round): every workgroup first re-reduces the norm partials (nch dependent-latency loads), which a grid
+  // of one trip per workgroup (10240 of them at DPOT-Tiny B=32) paid five rounds deep
+  long long g = ((long long)S * C / 4 + 511) / 512;
+  const long long cap = B >= 2048 ? 1 : (2048 + B - 1) / B;
+  if (g > cap) g = cap;
   if (g < 1) g = 1;
   hipLaunchKernelGGL(noise_axpy_kernel, dim3((unsigned)g, B), dim3(256), C * sizeof(float), as_stream(stream), xx, eps,
                      (const float*)part, norms, out, noise_scale, S, C, nch, (const unsigned long long*)rng);

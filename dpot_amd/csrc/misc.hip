@@ -430,6 +430,76 @@ extern "C" int dpot_group_rowsum(const float* X, float* out, int B, int R, int T
   return check_launch("group_rowsum_kernel");
 }
 
+// ---- few-row Linear: y[M, N] = act(x[M, K] W[N, K]^T + b), M <= a few dozen rows (models/dpot.py:333-336, the cls_head
+// on the token mean: M = batch).  A GEMM tile grid has 8 output tiles here and the split-K + reduce pair that spreads
+// it costs 12 us per layer, all latency; as a mat-vec family the layer is one 1-MiB pass over W.  A workgroup stages
+// 32 rows x 512 k of x in LDS (64 KiB, one round of 16 float4 loads per thread); each of its 8 waves owns one output
+// column: its W row chunk sits in registers (2 float4 per lane), the 32 row products are FMA chains over conflict-free
+// ds_read_b128, reduced across the lanes by a halving butterfly (32 shuffles for 32 values; lane l ends with row
+// l >> 1).  fp32 throughout, fixed order.
+constexpr int SL_ROWS = 32, SL_KCH = 512, SL_WAVES = 8;
+// one butterfly stage (compile-time HALF: a run-time loop bound would turn the register array into select chains)
+template <int HALF>
+__device__ __forceinline__ void sl_stage(float (&part)[SL_ROWS], int lane) {
+  const bool hi = (lane & (2 * HALF)) != 0;
+#pragma unroll
+  for (int i = 0; i < HALF; ++i) {
+    const float send = hi ? part[i] : part[HALF + i];
+    const float keep = hi ? part[HALF + i] : part[i];
+    part[i] = keep + __shfl_xor(send, 2 * HALF, 64);
+  }
+}
+__global__ __launch_bounds__(64 * SL_WAVES) void small_linear_kernel(const float* __restrict__ x, int ldx,
+                                                                     const float* __restrict__ W, int ldw,
+                                                                     const float* __restrict__ bias,
+                                                                     float* __restrict__ y, float* __restrict__ pre,
+                                                                     int ldy, int M, int N, int K, int act) {
+  extern __shared__ __attribute__((aligned(16))) float xs[];      // [32][512]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int n_raw = blockIdx.x * SL_WAVES + wave;
+  const int n = n_raw < N ? n_raw : N - 1;                          // clamped (barriers below); masked at the store
+  const float bn = bias ? bias[n] : 0.f;
+  for (int m0 = 0; m0 < M; m0 += SL_ROWS) {
+    float part[SL_ROWS];
+#pragma unroll
+    for (int i = 0; i < SL_ROWS; ++i) part[i] = 0.f;
+    for (int k0 = 0; k0 < K; k0 += SL_KCH) {
+      const float4 w0 = *reinterpret_cast<const float4*>(W + (long long)n * ldw + k0 + 4 * lane);
+      const float4 w1 = *reinterpret_cast<const float4*>(W + (long long)n * ldw + k0 + 256 + 4 * lane);
+      __syncthreads();                                              // the previous chunk has been consumed
+      float4 st[SL_ROWS * SL_KCH / 4 / (64 * SL_WAVES)];
+#pragma unroll
+      for (int j = 0; j < SL_ROWS * SL_KCH / 4 / (64 * SL_WAVES); ++j) {
+        const int q = tid + j * 64 * SL_WAVES;                      // float4 index: row = q / 128, quad = q % 128
+        const int m = m0 + (q >> 7) < M ? m0 + (q >> 7) : M - 1;
+        st[j] = *reinterpret_cast<const float4*>(x + (long long)m * ldx + k0 + 4 * (q & 127));
+      }
+#pragma unroll
+      for (int j = 0; j < SL_ROWS * SL_KCH / 4 / (64 * SL_WAVES); ++j)
+        *reinterpret_cast<float4*>(xs + 4 * (tid + j * 64 * SL_WAVES)) = st[j];
+      __syncthreads();
+#pragma unroll
+      for (int i = 0; i < SL_ROWS; ++i) {
+        const float4 a = *reinterpret_cast<const float4*>(xs + i * SL_KCH + 4 * lane);
+        const float4 b = *reinterpret_cast<const float4*>(xs + i * SL_KCH + 256 + 4 * lane);
+        float t = part[i];
+        t = fmaf(a.x, w0.x, t); t = fmaf(a.y, w0.y, t); t = fmaf(a.z, w0.z, t); t = fmaf(a.w, w0.w, t);
+        t = fmaf(b.x, w1.x, t); t = fmaf(b.y, w1.y, t); t = fmaf(b.z, w1.z, t); t = fmaf(b.w, w1.w, t);
+        part[i] = t;
+      }
+    }
+    // halving butterfly: after the stage with stride s a lane keeps the half of its values selected by (lane & s)
+    sl_stage<16>(part, lane); sl_stage<8>(part, lane); sl_stage<4>(part, lane); sl_stage<2>(part, lane);
+    sl_stage<1>(part, lane);
+    const float v = part[0] + __shfl_xor(part[0], 1, 64) + bn;
+    const int m = m0 + (lane >> 1);
+    if ((lane & 1) == 0 && m < M && n_raw < N) {
+      if (pre) pre[(long long)m * ldy + n] = v;
+      y[(long long)m * ldy + n] = act_fwd(act, v);
+    }
+  }
+}
+
 extern "C" int dpot_token_mean(const float* x, float* y, int B, int T, int E, dpot_stream_t stream) {
   DPOT_REQUIRE(x && y && B > 0 && T > 0 && E > 0 && B <= 65535, "token_mean: bad argument");
   hipLaunchKernelGGL(token_mean_kernel, dim3(cdiv(E, 64), B), dim3(256), 0, as_stream(stream), x, y, T, E);
@@ -483,4 +553,23 @@ extern "C" int dpot_timeagg_scale_w_bwd(const float* dws, const float* w, const 
   hipLaunchKernelGGL(timeagg_scale_w_bwd_kernel, dim3(E), dim3(256), 0, as_stream(stream), dws, w, gamma, tt, dw,
                      dgamma, T, E);
   return check_launch("timeagg_scale_w_bwd_kernel");
+}
+
+extern "C" int dpot_small_linear_supported(int M, int N, int K) {
+  return M > 0 && M <= 128 && N > 0 && K >= SL_KCH && K % SL_KCH == 0 ? 1 : 0;
+}
+
+extern "C" int dpot_small_linear(const float* x, int ldx, const float* W, int ldw, const float* bias, float* y, float* pre,
+                                 int ldy, int M, int N, int K, int act, dpot_stream_t stream) {
+  DPOT_REQUIRE(x && W && y, "small_linear: null operand");
+  DPOT_REQUIRE(dpot_small_linear_supported(M, N, K), "small_linear: unsupported shape M=%d N=%d K=%d", M, N, K);
+  DPOT_REQUIRE(ldx >= K && ldw >= K && ldy >= N && ldx % 4 == 0 && ldw % 4 == 0 && aligned16(x) && aligned16(W),
+               "small_linear: bad leading dimension / alignment");
+  const size_t lds = sizeof(float) * SL_ROWS * SL_KCH;
+  static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(small_linear_kernel),
+                                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  DPOT_REQUIRE(attr == hipSuccess, "small_linear: cannot reserve %zu bytes of LDS", lds);
+  hipLaunchKernelGGL(small_linear_kernel, dim3((unsigned)cdiv(N, SL_WAVES)), dim3(64 * SL_WAVES), lds, as_stream(stream),
+                     x, ldx, W, ldw, bias, y, pre, ldy, M, N, K, act);
+  return check_launch("small_linear_kernel");
 }

@@ -285,6 +285,10 @@ def gemm_bf16p_packed(Ap: Tensor, Wp: Tensor, M: int, N: int, K: int, *, bias: O
     return C_, pre, pr, pt, cs
 
 
+def small_linear_supported(M: int, N: int, K: int) -> bool:
+    return bool(_lib.load().dpot_small_linear_supported(M, N, K))
+
+
 def linear_fwd(x: Tensor, W: Tensor, bias: Optional[Tensor], act: int = 0, save_pre: bool = False,
                res: Optional[Tensor] = None, res_div: int = 0, res_mod: int = 0,
                ldw: Optional[int] = None, precision: Optional[int] = None) -> Tuple[Tensor, Optional[Tensor]]:
@@ -293,6 +297,15 @@ def linear_fwd(x: Tensor, W: Tensor, bias: Optional[Tensor], act: int = 0, save_
     N = W.shape[0]
     y = torch.empty(M, N, dtype=torch.float32, device=x.device)
     pre = torch.empty_like(y) if save_pre else None
+    lib = _lib.load()
+    prec = _gemm_precision if precision is None else precision
+    if (res is None and M <= 128 and prec != GEMM_BF16 and lib.dpot_small_linear_supported(M, N, K)
+            and os.environ.get("DPOT_SMALL_LINEAR", "1") != "0"):
+        # a handful of rows (the cls_head on the token mean): one pass over W, no split-K / reduce pair; exact fp32
+        # (not under the opt-in bf16 operand rounding: that mode keeps its rounding at every batch size)
+        check(lib.dpot_small_linear(x.data_ptr(), x.stride(0), W.data_ptr(), ldw or W.stride(0), _p(bias), y.data_ptr(),
+                                    _p(pre), N, M, N, K, act, _stream()), "small_linear")
+        return y, pre
     gemm(x, W, y, M, N, K, transB=True, lda=x.stride(0), ldb=ldw or W.stride(0), ldc=N, bias=bias, act=act,
          mode=EPI_ACT if act else EPI_LINEAR, preact=pre, ldpre=N, res=res, ldres=N, res_div=res_div,
          res_mod=res_mod, precision=precision)

@@ -258,6 +258,12 @@ int dpot_group_rowsum(const float* X, float* out, int B, int R, int T, int N, dp
 int dpot_token_mean(const float* x, float* y, int B, int T, int E, dpot_stream_t stream);
 int dpot_token_mean_bwd(const float* dy, const float* add, float* dx, int B, int T, int E,
                         dpot_stream_t stream);
+/* few-row Linear (reference: models/dpot.py:333-336, cls_head on the token mean; M = batch rows):
+ * y[M, N] = act(x[M, K] W[N, K]^T + bias), pre (optional) receives the pre-activation.  One wave per output column,
+ * fp32 FMA chains in a fixed order.  Supported: M <= 128, K a multiple of 512. */
+int dpot_small_linear_supported(int M, int N, int K);
+int dpot_small_linear(const float* x, int ldx, const float* W, int ldw, const float* bias, float* y, float* pre, int ldy,
+                      int M, int N, int K, int act, dpot_stream_t stream);
 /* y[r, n] = x[r, n] + v[n]   (row-broadcast add; pos_embed + conv bias folded ahead of the TimeAggregator);
  * x == NULL: y = v tiled R times (the ConvTranspose bias repeated per output pixel of a patch) */
 int dpot_bias_add(const float* x, const float* v, float* y, int R, int N, dpot_stream_t stream);

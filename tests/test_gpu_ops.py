@@ -1,6 +1,7 @@
 """GPU parity tests, kernel level: every C-ABI entry point against the CPU oracle / fp64 torch on the same
 seeded inputs.  Tolerance: rtol 1e-4 (north_star, fp32) with an absolute term of 1e-4 * max|ref|."""
 import math
+import os
 
 import numpy as np
 import pytest
@@ -979,3 +980,23 @@ def test_bf16_panel_packed_epilogue_dact_with_colsum_and_strided_pack(ops):
     r1, t1, c1 = ops.bf16_pack_both(win, want_colsum=True)
     r2, t2, c2 = ops.bf16_pack_both(win.contiguous(), want_colsum=True)
     assert torch.equal(r1, r2) and torch.equal(t1, t2) and torch.equal(c1, c2)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("M,N,K,act", [(32, 512, 512, 1), (5, 12, 512, 0), (33, 1024, 1024, 1), (64, 100, 1536, 0), (1, 7, 2048, 1)])
+def test_small_linear_vs_fp64(ops, M, N, K, act):
+    """few-row Linear (cls_head on the token mean): one wave per output column, against float64"""
+    torch.manual_seed(M + N)
+    x = torch.randn(M, K, device="cuda"); W = torch.randn(N, K, device="cuda") * 0.05; b = torch.randn(N, device="cuda")
+    assert ops.small_linear_supported(M, N, K)
+    y, pre = ops.linear_fwd(x, W, b, act=act, save_pre=True)
+    ref = x.double() @ W.double().t() + b.double()
+    assert_close(pre, ref, "small_linear pre")
+    assert_close(y, torch.nn.functional.gelu(ref) if act else ref, "small_linear act")
+    # the GEMM path on the same operands (what larger batches use) agrees
+    os.environ["DPOT_SMALL_LINEAR"] = "0"
+    try:
+        y2, _ = ops.linear_fwd(x, W, b, act=act, save_pre=True)
+    finally:
+        del os.environ["DPOT_SMALL_LINEAR"]
+    assert_close(y2, y.double(), "small_linear vs GEMM")
