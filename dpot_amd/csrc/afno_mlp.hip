@@ -722,22 +722,28 @@ __global__ __launch_bounds__(256) void afno_pack_all_kernel(const dpot_afno_pack
     const int nsl = bs / 16;                              // slabs = column tiles per part
     const long long nP = (long long)nb * 2 * bs * bs;
     const long long plane1 = (long long)nb * bs * bs;
-    for (long long idx = blockIdx.x * 256ll + threadIdx.x; idx < nP; idx += (long long)gridDim.x * 256) {
-      const int e = (int)(idx & 3), l = (int)((idx >> 2) & 63);
-      long long blk = idx >> 8;
-      const int c = (int)(blk % nsl);
-      blk /= nsl;
-      const int part = (int)(blk & 1);
-      blk >>= 1;
-      const int t = (int)(blk % nsl);
-      const int k = (int)(blk / nsl);
-      const int kk = 16 * t + 4 * (l >> 4) + e, n = 16 * c + (l & 15);
+    // one destination quad (4 consecutive k) per thread and trip, 32-bit index arithmetic
+    const unsigned nq = (unsigned)(nP >> 2), unsl = (unsigned)nsl;
+    for (unsigned q = blockIdx.x * 256u + threadIdx.x; q < nq; q += gridDim.x * 256u) {
+      const unsigned l = q & 63u;
+      unsigned blk = q >> 6;
+      const unsigned b1 = blk / unsl, c = blk - b1 * unsl;
+      const unsigned part = b1 & 1u;
+      blk = b1 >> 1;
+      const unsigned k = blk / unsl, t = blk - k * unsl;
+      const unsigned kk = 16u * t + 4u * (l >> 4), n = 16u * c + (l & 15u);
       const float* wp = job.w + part * plane1 + (long long)k * bs * bs;
-      if (job.fwd) job.fwd[idx] = wp[(long long)kk * bs + n];
-      if (job.bwd) job.bwd[idx] = part ? -wp[(long long)n * bs + kk] : wp[(long long)n * bs + kk];
+      if (job.fwd) {
+        const float* sp = wp + (long long)kk * bs + n;
+        reinterpret_cast<float4*>(job.fwd)[q] = make_float4(sp[0], sp[bs], sp[2 * bs], sp[3 * bs]);
+      }
+      if (job.bwd) {
+        const float4 v = *reinterpret_cast<const float4*>(wp + (long long)n * bs + kk);   // bs % 16 == 0, 16-B aligned
+        reinterpret_cast<float4*>(job.bwd)[q] = part ? make_float4(-v.x, -v.y, -v.z, -v.w) : v;
+      }
     }
   }
-  const long long nW = (long long)nb * N * N;
+  const long long nW = (job.wbig || layout == 0) ? (long long)nb * N * N : 0;   // layout 1 without the dense copy: nothing to do
   const long long plane = (long long)nb * bs * bs;
   for (long long idx = blockIdx.x * 256ll + threadIdx.x; idx < nW; idx += (long long)gridDim.x * 256) {
     const int c = (int)(idx % N);
@@ -847,7 +853,7 @@ extern "C" int dpot_afno_pack_all(const dpot_afno_pack_job* jobs_dev, int njobs,
   DPOT_REQUIRE(layout == 0 || (layout == 1 && dpot_afno_mlp3_supported(nb, bs)), "afno_pack_all: layout 1 needs bs in {64, 96, 128}");
   DPOT_REQUIRE((2 * bs) % 16 == 0, "afno_pack_all: 2*bs must be a multiple of 16 for the blocked copies");
   long long g = ((long long)nb * 4 * bs * bs + 255) / 256;
-  if (g > 1024) g = 1024;
+  if (g > 512) g = 512;
   hipLaunchKernelGGL(afno_pack_all_kernel, dim3((unsigned)g, njobs), dim3(256), 0, as_stream(stream), jobs_dev, nb, bs,
                      layout);
   return check_launch("afno_pack_all_kernel");

@@ -247,17 +247,28 @@ __global__ __launch_bounds__(64 * (NW + 2)) void gemm_panel_kernel(const PanelAr
 
 // pack jobs (DEVICE table): W given as rows x K (row r, k) = trans ? src[k*ld + r] : src[r*ld + k]
 // -> dst[(ct*NSLAB + t)*256 + 4*l + e] = element (row 16ct + (l&15), k 16t + 4(l>>4) + e)
+// one destination quad (4 consecutive k of one row) per thread and trip, 32-bit index arithmetic (the element-wise
+// version spent its time in two 64-bit divisions per element)
 __global__ __launch_bounds__(256) void panel_pack_kernel(const dpot_pack_job* __restrict__ jobs) {
   const dpot_pack_job job = jobs[blockIdx.y];
-  const int nslab = job.K >> 4;
-  const long long total = (long long)job.rows * job.K;
-  for (long long idx = blockIdx.x * 256ll + threadIdx.x; idx < total; idx += (long long)gridDim.x * 256) {
-    const int e = (int)(idx & 3), l = (int)((idx >> 2) & 63);
-    const long long blk = idx >> 8;
-    const int t = (int)(blk % nslab);
-    const int ct = (int)(blk / nslab);
-    const int r = 16 * ct + (l & 15), k = 16 * t + 4 * (l >> 4) + e;
-    job.dst[idx] = job.trans ? job.src[(long long)k * job.ld + r] : job.src[(long long)r * job.ld + k];
+  const unsigned nslab = (unsigned)job.K >> 4;
+  const unsigned quads = (unsigned)(((long long)job.rows * job.K) >> 2);
+  const bool vec = !job.trans && (job.ld & 3) == 0 && (reinterpret_cast<uintptr_t>(job.src) & 15u) == 0;
+  for (unsigned q = blockIdx.x * 256u + threadIdx.x; q < quads; q += gridDim.x * 256u) {
+    const unsigned l = q & 63u, blk = q >> 6;
+    const unsigned ct = blk / nslab, t = blk - ct * nslab;
+    const unsigned r = 16u * ct + (l & 15u), k = 16u * t + 4u * (l >> 4);
+    float4 v;
+    if (vec) {
+      v = *reinterpret_cast<const float4*>(job.src + (long long)r * job.ld + k);
+    } else if (job.trans) {
+      const float* sp = job.src + (long long)k * job.ld + r;
+      v = make_float4(sp[0], sp[job.ld], sp[2ll * job.ld], sp[3ll * job.ld]);
+    } else {
+      const float* sp = job.src + (long long)r * job.ld + k;
+      v = make_float4(sp[0], sp[1], sp[2], sp[3]);
+    }
+    reinterpret_cast<float4*>(job.dst)[q] = v;
   }
 }
 
@@ -322,8 +333,9 @@ extern "C" int dpot_gemm_panel_supported(int M, int N, int K) {
 
 extern "C" int dpot_panel_pack_weights(const dpot_pack_job* jobs_dev, int njobs, int max_elems, dpot_stream_t stream) {
   DPOT_REQUIRE(jobs_dev && njobs > 0 && njobs <= 65535 && max_elems > 0, "panel_pack_weights: bad argument");
-  long long g = ((long long)max_elems + 255) / 256;
-  if (g > 2048) g = 2048;
+  long long g = ((long long)max_elems / 4 + 255) / 256;
+  if (g > 512) g = 512;
+  if (g < 1) g = 1;
   hipLaunchKernelGGL(panel_pack_kernel, dim3((unsigned)g, njobs), dim3(256), 0, as_stream(stream), jobs_dev);
   return check_launch("panel_pack_kernel");
 }
