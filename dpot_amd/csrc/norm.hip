@@ -196,10 +196,18 @@ __global__ __launch_bounds__(GN_THREADS) void groupnorm_bwd_kernel(const float* 
 }
 
 // dgamma/dbeta = sum over samples of the per-sample partials; block = 64 channels x 4 sample lanes, fixed order
-__global__ __launch_bounds__(256) void groupnorm_param_grad_kernel(const float* __restrict__ part,
-                                                                   float* __restrict__ dgamma,
-                                                                   float* __restrict__ dbeta, int B, int E) {
+struct GnParamJobs {
+  const float* part[4];
+  float* dgamma[4];
+  float* dbeta[4];
+};
+// blockIdx.y = job: several GroupNorm layers (the two of a DPOT block) share one launch - each of these reductions is
+// a handful of workgroups and pure launch / dependent-load latency
+__global__ __launch_bounds__(256) void groupnorm_param_grad_kernel(const GnParamJobs jobs, int B, int E) {
   __shared__ float red[2][4][64];
+  const float* __restrict__ part = jobs.part[blockIdx.y];
+  float* __restrict__ dgamma = jobs.dgamma[blockIdx.y];
+  float* __restrict__ dbeta = jobs.dbeta[blockIdx.y];
   const int tc = threadIdx.x & 63, tr = threadIdx.x >> 6;
   const int c = blockIdx.x * 64 + tc;
   float sg0 = 0.f, sg1 = 0.f, sb0 = 0.f, sb1 = 0.f;
@@ -386,7 +394,8 @@ extern "C" int dpot_groupnorm_fwd(const float* x, const float* gamma, const floa
 extern "C" int dpot_groupnorm_bwd(const float* dy, const float* x, const float* mean, const float* rstd,
                                   const float* gamma, const float* add, float* dx, float* dgamma, float* dbeta,
                                   float* part, int B, int T, int E, int G, dpot_stream_t stream) {
-  DPOT_REQUIRE(dy && x && mean && rstd && gamma && dx && dgamma && dbeta && part, "groupnorm_bwd: null pointer");
+  DPOT_REQUIRE(dy && x && mean && rstd && gamma && dx && part && ((dgamma == nullptr) == (dbeta == nullptr)),
+               "groupnorm_bwd: null pointer");
   DPOT_REQUIRE(B > 0 && T > 0 && E > 0 && G > 0 && E % G == 0 && B <= 65535, "groupnorm_bwd: bad shape");
   const bool vec = ((E / G) % 4 == 0) && aligned16(x) && aligned16(dy) && aligned16(dx) && aligned16(gamma) &&
                    (add == nullptr || aligned16(add));
@@ -404,8 +413,21 @@ extern "C" int dpot_groupnorm_bwd(const float* dy, const float* x, const float* 
     hipLaunchKernelGGL(groupnorm_bwd_kernel<1>, dim3(G, B), dim3(GN_THREADS), 0, as_stream(stream), dy, x, mean, rstd,
                        gamma, add, dx, part, B, T, E, G);
   int rc = check_launch("groupnorm_bwd_kernel");
-  if (rc) return rc;
-  hipLaunchKernelGGL(groupnorm_param_grad_kernel, dim3(cdiv(E, 64)), dim3(256), 0, as_stream(stream),
-                     (const float*)part, dgamma, dbeta, B, E);
+  if (rc || !dgamma) return rc;          // dgamma == dbeta == NULL: the caller reduces `part` later (dpot_groupnorm_param_grads)
+  GnParamJobs jobs{};
+  jobs.part[0] = part; jobs.dgamma[0] = dgamma; jobs.dbeta[0] = dbeta;
+  hipLaunchKernelGGL(groupnorm_param_grad_kernel, dim3(cdiv(E, 64), 1), dim3(256), 0, as_stream(stream), jobs, B, E);
+  return check_launch("groupnorm_param_grad_kernel");
+}
+
+extern "C" int dpot_groupnorm_param_grads(const float* const* parts, float* const* dgammas, float* const* dbetas,
+                                          int njobs, int B, int E, dpot_stream_t stream) {
+  DPOT_REQUIRE(parts && dgammas && dbetas && njobs > 0 && njobs <= 4 && B > 0 && E > 0, "groupnorm_param_grads: bad argument");
+  GnParamJobs jobs{};
+  for (int i = 0; i < njobs; ++i) {
+    DPOT_REQUIRE(parts[i] && dgammas[i] && dbetas[i], "groupnorm_param_grads: null pointer in job %d", i);
+    jobs.part[i] = parts[i]; jobs.dgamma[i] = dgammas[i]; jobs.dbeta[i] = dbetas[i];
+  }
+  hipLaunchKernelGGL(groupnorm_param_grad_kernel, dim3(cdiv(E, 64), njobs), dim3(256), 0, as_stream(stream), jobs, B, E);
   return check_launch("groupnorm_param_grad_kernel");
 }

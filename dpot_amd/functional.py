@@ -453,9 +453,8 @@ class BlockFn(torch.autograd.Function):
                 dxn2, _ = ops.gemm_panel(dHpre, mlp_pk[1], E)                      # dHpre W1
             else:
                 dxn2 = ops.linear_bwd_data(dHpre, f1w, precision=mp)               # [M, E]
-        dy1, dn2w, dn2b = ops.groupnorm_bwd(dxn2.view(B, tok, E), y1, mean2, rstd2, n2w, out_dgamma=s_n2w.out(),
-                                            out_dbeta=s_n2b.out())
-        dn2w, dn2b = s_n2w.done(dn2w), s_n2b.done(dn2b)
+        # parameter-gradient partials of norm2 are reduced together with norm1's at the end of the block (one launch)
+        dy1, gn2_part = ops.groupnorm_bwd(dxn2.view(B, tok, E), y1, mean2, rstd2, n2w, defer=True)
         # AFNO mixer
         dO2 = ops.rfft2(dy1, h, w, nb, mx, my, 1)                              # adjoint of irfft2
         kw = dict(lda=2 * E, ldb=2 * bs, ldc=2 * E, batch=nb, strideA=2 * bs, strideB=4 * bs * bs, strideC=2 * bs)
@@ -493,9 +492,11 @@ class BlockFn(torch.autograd.Function):
             dS = torch.empty(Mm, 2 * E, dtype=torch.float32, device=dev)
             ops.gemm(dO1pre, wb1, dS, Mm, 2 * bs, 2 * bs, transB=True, **kw)
         dxn1 = ops.irfft2(dS, B, h, w, E, nb, mx, my, 0, res=dy1)              # adjoint of rfft2, + skip path
-        dx, dn1w, dn1b = ops.groupnorm_bwd(dxn1, x, mean1, rstd1, n1w, add=dout, out_dgamma=s_n1w.out(),
-                                           out_dbeta=s_n1b.out())
+        dx, gn1_part = ops.groupnorm_bwd(dxn1, x, mean1, rstd1, n1w, add=dout, defer=True)
+        (dn1w, dn1b), (dn2w, dn2b) = ops.groupnorm_param_grads([(gn1_part, s_n1w.out(), s_n1b.out()),
+                                                                (gn2_part, s_n2w.out(), s_n2b.out())])
         dn1w, dn1b = s_n1w.done(dn1w), s_n1b.done(dn1b)
+        dn2w, dn2b = s_n2w.done(dn2w), s_n2b.done(dn2b)
         streams.join(dev)      # the side stream's readers of this frame's tensors are done before they can be freed
         return (dx, dn1w, dn1b, dw1, db1, dw2, db2, dn2w, dn2b, df1w, df1b, df2w, df2b, None, None, None, None, None,
                 None, None, None)

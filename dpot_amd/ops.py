@@ -549,16 +549,30 @@ def groupnorm_fwd(x: Tensor, gamma: Tensor, beta: Tensor, G: int = 8, eps: float
 
 def groupnorm_bwd(dy: Tensor, x: Tensor, mean: Tensor, rstd: Tensor, gamma: Tensor, G: int = 8,
                   add: Optional[Tensor] = None, out_dgamma: Optional[Tensor] = None,
-                  out_dbeta: Optional[Tensor] = None):
+                  out_dbeta: Optional[Tensor] = None, defer: bool = False):
+    """defer=False: returns (dx, dgamma, dbeta).  defer=True: returns (dx, part) - the per-sample partials [2,B,E] of the
+    parameter gradients, to be reduced later by groupnorm_param_grads (several layers in one launch)"""
     B, T, E = x.shape
     dx = torch.empty_like(x)
-    dgamma = _out(out_dgamma, (E,), x.device)
-    dbeta = _out(out_dbeta, (E,), x.device)
     part = torch.empty(2, B, E, dtype=torch.float32, device=x.device)
+    dgamma = None if defer else _out(out_dgamma, (E,), x.device)
+    dbeta = None if defer else _out(out_dbeta, (E,), x.device)
     check(_lib.load().dpot_groupnorm_bwd(dy.data_ptr(), x.data_ptr(), mean.data_ptr(), rstd.data_ptr(),
-                                         gamma.data_ptr(), _p(add), dx.data_ptr(), dgamma.data_ptr(),
-                                         dbeta.data_ptr(), part.data_ptr(), B, T, E, G, _stream()), "groupnorm_bwd")
-    return dx, dgamma, dbeta
+                                         gamma.data_ptr(), _p(add), dx.data_ptr(), _p(dgamma), _p(dbeta),
+                                         part.data_ptr(), B, T, E, G, _stream()), "groupnorm_bwd")
+    return (dx, part) if defer else (dx, dgamma, dbeta)
+
+
+def groupnorm_param_grads(jobs):
+    """jobs = [(part [2,B,E], out_dgamma | None, out_dbeta | None)] (<= 4) -> [(dgamma, dbeta)], one launch"""
+    n = len(jobs)
+    _, B, E = jobs[0][0].shape
+    outs = [(_out(og, (E,), p.device), _out(ob, (E,), p.device)) for p, og, ob in jobs]
+    parts = (C.c_void_p * n)(*[p.data_ptr() for p, _, _ in jobs])
+    dgs = (C.c_void_p * n)(*[g.data_ptr() for g, _ in outs])
+    dbs = (C.c_void_p * n)(*[b.data_ptr() for _, b in outs])
+    check(_lib.load().dpot_groupnorm_param_grads(parts, dgs, dbs, n, B, E, _stream()), "groupnorm_param_grads")
+    return outs
 
 
 # ------------------------------------------------------------------------------------------------------

@@ -209,6 +209,10 @@ int dpot_groupnorm_fwd(const float* x, const float* gamma, const float* beta, fl
 int dpot_groupnorm_bwd(const float* dy, const float* x, const float* mean, const float* rstd,
                        const float* gamma, const float* add, float* dx, float* dgamma, float* dbeta,
                        float* part /* [2,B,E] */, int B, int T, int E, int G, dpot_stream_t stream);
+/* dgamma == dbeta == NULL above leaves the per-sample partials in `part`; this reduces up to 4 such partial sets
+ * (HOST arrays of njobs pointers; e.g. the two GroupNorm layers of a block) in ONE launch. */
+int dpot_groupnorm_param_grads(const float* const* parts, float* const* dgammas, float* const* dbetas, int njobs,
+                               int B, int E, dpot_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
  * data movement / small ops

@@ -1000,3 +1000,23 @@ def test_small_linear_vs_fp64(ops, M, N, K, act):
     finally:
         del os.environ["DPOT_SMALL_LINEAR"]
     assert_close(y2, y.double(), "small_linear vs GEMM")
+
+
+@pytest.mark.gpu
+def test_groupnorm_deferred_param_grads_match(ops):
+    """deferred parameter-gradient partials of two GroupNorm layers, reduced by one launch == the immediate reduction"""
+    torch.manual_seed(3)
+    B, T, E, G = 6, 64, 256, 8
+    outs = []
+    for add in (None, torch.randn(B, T, E, device="cuda")):
+        x = torch.randn(B, T, E, device="cuda"); dy = torch.randn(B, T, E, device="cuda"); gw = torch.randn(E, device="cuda")
+        _, mean, rstd = ops.groupnorm_fwd(x, gw, torch.zeros(E, device="cuda"), G)
+        dx0, dg0, db0 = ops.groupnorm_bwd(dy, x, mean, rstd, gw, G, add=add)
+        dx1, part = ops.groupnorm_bwd(dy, x, mean, rstd, gw, G, add=add, defer=True)
+        assert torch.equal(dx0, dx1)
+        outs.append((part, dg0, db0))
+    slot = torch.zeros(E, device="cuda")
+    res = ops.groupnorm_param_grads([(outs[0][0], slot, None), (outs[1][0], None, None)])
+    assert res[0][0].data_ptr() == slot.data_ptr()
+    for (dg, db), (_, dg0, db0) in zip(res, outs):
+        assert torch.equal(dg, dg0) and torch.equal(db, db0)
