@@ -14,7 +14,8 @@
 // contribution is folded into the bias table bt[(tok,t), n] once per optimiser step by a 2560 x 192 x 36 GEMM on the
 // host side (functional.embed_derived), and their weight gradient is that GEMM's transpose on the batch-summed dHpre.
 //
-//   * forward: persistent workgroups, one group of 4 patches (4*T rows -> ceil(4T/16) row tiles = waves) per iteration,
+//   * forward: persistent workgroups, one group of 4 patches (4*T rows -> ceil(4T/16) row tiles = compute waves, plus
+//     two loader waves that issue all LDS-DMA and are the only ones to wait on vmcnt) per iteration,
 //     double-buffered groups (the DMA of group g+1 runs under the MFMAs of group g, one barrier per group); the weights
 //     sit in LDS in fragment order ([i][j/4][col tile][lane][j%4]: one ds_read_b128 serves 4 k-quads);
 //     v_mfma_f32_16x16x4_f32, fused bias-table add + activation, both outputs stored.
@@ -32,6 +33,7 @@ constexpr int EM_P = 8;          // patch size
 constexpr int EM_C = 4;          // data channels (one float4 per pixel and frame)
 constexpr int EM_NP = 4;         // patches per group
 constexpr int EM_CT = 3;         // 16-column tiles of the hidden width (hid <= 48)
+constexpr int EM_LW = 2;         // loader waves of the forward kernel
 constexpr int EM_TMAX = 10;      // frames: group = 8 * NP*8*T*4 floats <= 40 KiB (DPOT: T_in = 10)
 constexpr int EM_KD = EM_C * EM_P * EM_P;                    // 256 data columns of the conv weight
 constexpr int EM_WFL = EM_P * 2 * EM_CT * 256;               // floats of the fragment-ordered weights (48 KiB)
@@ -61,11 +63,13 @@ __device__ __forceinline__ void em_issue_x(const EmbedArgs& a, int g, float* buf
   const long long rowf = (long long)a.Y * a.T * EM_C;
   const float* src = a.x + ((long long)b * a.X + px * EM_P) * rowf + (long long)pyq * run;
   const int per = run >> 2;                            // 16-byte chunks per run
+  int i = tid / per, o = tid - i * per;                // (run index, chunk within the run), advanced incrementally
   for (int c = tid; c < EM_P * per; c += nthr) {      // wave-uniform trip count up to the ragged last wave-instruction
-    const int i = c / per, o = c - i * per;
     // destination: the wave-uniform base of this instruction (the hardware adds lane * 16 bytes); chunk c lands at
     // float 4*c = i*run + 4*o, so a wave-instruction may straddle two runs
     em_glds16(src + i * rowf + 4 * o, buf + 4 * (c - (tid & 63)));
+    o += nthr;
+    while (o >= per) { o -= per; ++i; }
   }
 }
 
@@ -81,7 +85,7 @@ __device__ __forceinline__ void em_wave_sync() {
 }
 
 template <bool GELU>
-__global__ __launch_bounds__(256) void embed_fwd_kernel(const EmbedArgs a) {
+__global__ __launch_bounds__(64 * (3 + EM_LW)) void embed_fwd_kernel(const EmbedArgs a) {
   constexpr int BTF = EM_NP * EM_TMAX * 48;            // floats of one bias-table tile buffer
   __shared__ __attribute__((aligned(16))) float lds[2 * EM_GFL + 2 * BTF + EM_WFL];
   float* const btl = lds + 2 * EM_GFL;
@@ -107,6 +111,20 @@ __global__ __launch_bounds__(256) void embed_fwd_kernel(const EmbedArgs a) {
     em_issue_lin(a.bt + (long long)(px * a.w + pyq * EM_NP) * T * hidp, btl + buf * BTF, btn >> 2, tid, nthr);
   };
 
+  // the LAST EM_LW waves only load: vmcnt counts stores as well as loads, so a wave that both streams its output rows
+  // out and waits for the next group's DMA sits through the write latency of its own stores once per group (measured:
+  // 7.6 us per group against 2.6 us of MFMA work).  The loaders' counters see nothing but the DMA; the compute waves
+  // never wait on vmcnt at all and their stores drain under the next group.  (Also tried: the loaders streaming the
+  // finished tile out while the compute waves go straight on - slower, 52-54 us against 49.)
+  const int ncw = (nthr >> 6) - EM_LW;
+  const bool loader = wave >= ncw;
+  const int ltid = tid - 64 * ncw;                     // thread index among the loaders
+  auto issue_l = [&](int g, int buf) __attribute__((always_inline)) {
+    em_issue_x(a, g, lds + buf * EM_GFL, run, ltid, 64 * EM_LW);
+    const int pyq = g % a.wq, px = (g / a.wq) % a.h;
+    em_issue_lin(a.bt + (long long)(px * a.w + pyq * EM_NP) * T * hidp, btl + buf * BTF, btn >> 2, ltid, 64 * EM_LW);
+  };
+
   int g = blockIdx.x;
   if (g < a.ngroups) issue(g, 0);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -115,12 +133,18 @@ __global__ __launch_bounds__(256) void embed_fwd_kernel(const EmbedArgs a) {
   for (; g < a.ngroups; g += gridDim.x) {
     // the other buffers are free: every wave passed the barrier below after its reads of group g - 1
     const int gn = g + gridDim.x;
-    if (gn < a.ngroups) issue(gn, cur ^ 1);
+    if (loader) {
+      if (gn < a.ngroups) issue_l(gn, cur ^ 1);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();                                 // group g + 1 landed; the compute waves are done with group g
+      cur ^= 1;
+      continue;
+    }
     const float* xs = lds + cur * EM_GFL + abase;
     f32x4 acc[EM_CT];
 #pragma unroll
     for (int ct = 0; ct < EM_CT; ++ct) acc[ct] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll 2
+#pragma unroll
     for (int i = 0; i < EM_P; ++i) {
       float av[8];
 #pragma unroll
@@ -176,10 +200,7 @@ __global__ __launch_bounds__(256) void embed_fwd_kernel(const EmbedArgs a) {
         o2[q] = u;
       }
     }
-    // the DMA of group g + 1 must have landed before the barrier releases its readers.  (The stores above are counted
-    // by vmcnt too; they are younger than the DMA, so this also drains them - a few hundred ns per group.)
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();                                   // group g + 1 landed everywhere; reads of group g are done
+    __syncthreads();                                   // group g + 1 landed (loader waves); reads of group g are done
     cur ^= 1;
   }
 }
@@ -351,7 +372,7 @@ extern "C" int dpot_embed_fwd(const float* x, const float* wfrag, const float* b
   if (rc) return rc;
   DPOT_REQUIRE(wfrag && btab && hpre && hh && aligned16(wfrag), "embed_fwd: null / misaligned pointer");
   a.wf = wfrag; a.bt = btab; a.hpre = hpre; a.hh = hh; a.act = act;
-  const int waves = (EM_NP * T + 15) / 16;
+  const int waves = (EM_NP * T + 15) / 16 + EM_LW;     // row tiles + the loader waves
   if (act == DPOT_ACT_GELU)
     hipLaunchKernelGGL(embed_fwd_kernel<true>, dim3(embed_grid(a.ngroups)), dim3(64 * waves), 0, as_stream(stream), a);
   else
