@@ -430,6 +430,7 @@ extern "C" int dpot_group_rowsum(const float* X, float* out, int B, int R, int T
   return check_launch("group_rowsum_kernel");
 }
 
+namespace dpot {
 // ---- few-row Linear: y[M, N] = act(x[M, K] W[N, K]^T + b), M <= a few dozen rows (models/dpot.py:333-336, the cls_head
 // on the token mean: M = batch).  A GEMM tile grid has 8 output tiles here and the split-K + reduce pair that spreads
 // it costs 12 us per layer, all latency; as a mat-vec family the layer is one 1-MiB pass over W.  A workgroup stages
@@ -499,6 +500,8 @@ __global__ __launch_bounds__(64 * SL_WAVES) void small_linear_kernel(const float
     }
   }
 }
+
+}  // namespace dpot
 
 extern "C" int dpot_token_mean(const float* x, float* y, int B, int T, int E, dpot_stream_t stream) {
   DPOT_REQUIRE(x && y && B > 0 && T > 0 && E > 0 && B <= 65535, "token_mean: bad argument");
