@@ -19,7 +19,8 @@
 //     dUpre leaves the same way in reverse;
 //   * weight gradients (dW2 = dvpre u^T, dW4 = dz v^T, sums over pixels) are MFMA products with the PIXEL index as the
 //     contraction: the operands are transposed through LDS slabs; each wave accumulates over all its tiles
-//     and writes one partial row, reduced afterwards by dpot_colsum (fixed order -> deterministic).
+//     the four waves of a workgroup sum their rows through LDS and write one partial row, reduced afterwards by
+//     dpot_colsum (fixed order -> deterministic).
 //
 // Fast path for out_layer_dim == 32 (DPOT-Ti/S/M); other widths use the generic GEMM chain (functional.HeadFn).
 #include "common.h"
@@ -413,8 +414,9 @@ __global__ __launch_bounds__(256, CO4 ? 2 : 1) void out_tail_bwd_kernel(
     __builtin_amdgcn_wave_barrier();
   }
 
-  // ---- one partial row per wave
-  float* prow = partials + ((long long)blockIdx.x * 4 + wave) * TAIL_PCOLS;
+  // ---- one partial row per WORKGROUP: the waves park their rows in LDS (their own slab region, dead by now), four
+  //      rows are summed in a fixed order (a row per wave made the reduction pass read 17.6 MB at DPOT-Tiny B=32)
+  float* prow = sm + wave * WSL;
   if constexpr (CO4) {
     float w4s[4];
 #pragma unroll
@@ -466,6 +468,10 @@ __global__ __launch_bounds__(256, CO4 ? 2 : 1) void out_tail_bwd_kernel(
       }
     }
   }
+  __syncthreads();
+  float* grow = partials + (long long)blockIdx.x * TAIL_PCOLS;
+  for (int c = threadIdx.x; c < TAIL_PCOLS; c += 256)
+    grow[c] = (sm[c] + sm[WSL + c]) + (sm[2 * WSL + c] + sm[3 * WSL + c]);
 }
 
 static unsigned tail_magic(unsigned d) { return d <= 1 ? 0u : (unsigned)((1ull << 32) / d) + 1u; }
@@ -502,7 +508,7 @@ static int tail_check(const char* who, int B, int h, int w, int P, int co) {
 
 // rows of the partial buffer: sized for the larger (co <= 4) grid, so that the count does not depend on co
 extern "C" int dpot_out_tail_partial_rows(int B, int h, int w, int P) {
-  return tail_grid_bwd((long long)B * h * w * P * P / 32, true) * 4;
+  return tail_grid_bwd((long long)B * h * w * P * P / 32, true);
 }
 extern "C" int dpot_out_tail_partial_cols(void) { return TAIL_PCOLS; }
 
@@ -554,7 +560,7 @@ extern "C" int dpot_out_tail_bwd(const float* upre, const float* dout, const flo
   const TailGeom g = tail_geom(h, w, P, co);
   hipStream_t s = as_stream(stream);
   const bool gelu = act == DPOT_ACT_GELU, co4 = co <= 4;
-  const int rows_all = tail_grid_bwd(ntiles, true) * 4, rows = tail_grid_bwd(ntiles, co4) * 4;
+  const int rows_all = tail_grid_bwd(ntiles, true), rows = tail_grid_bwd(ntiles, co4);
   if (rows < rows_all) {
     const hipError_t e = hipMemsetAsync(partials + (size_t)rows * TAIL_PCOLS, 0,
                                         sizeof(float) * (size_t)(rows_all - rows) * TAIL_PCOLS, s);
