@@ -572,30 +572,42 @@ __global__ __launch_bounds__(256) void bf16_pack_both_kernel(const float* __rest
 }
 
 // weights (job table in device memory): logical Wt [rows, K] (row n, k) = trans ? src[k*ld + n] : src[n*ld + k]
+// A wave fills ONE destination fragment block per trip (64 chunks of 16 B = 1 KiB, contiguous): lane l packs row
+// 32*rb + (l & 31), k-chunk 2*kb + (l >> 5).  (Mapping threads to consecutive source chunks instead scattered the
+// 16-byte stores over 64 blocks per wave and paid two 64-bit divisions per chunk: 325 us for DPOT-M's weights.)
 template <int NPL>
 __global__ __launch_bounds__(256) void bf16_pack_jobs_kernel(const dpot_pack_job* __restrict__ jobs) {
   const dpot_pack_job job = jobs[blockIdx.y];
-  const int kc_per_row = job.K >> 3;
-  const long long nchunks = (long long)job.rows * kc_per_row;
+  const unsigned kb_per_row = (unsigned)job.K >> 4;                   // 16-k blocks per row block
+  const unsigned rbs = ((unsigned)job.rows + 31u) >> 5;
+  const unsigned nblk = rbs * kb_per_row;
+  const unsigned lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
+  const bool vec = !job.trans && (job.ld & 3) == 0 && (reinterpret_cast<uintptr_t>(job.src) & 15u) == 0;
   uint4* dst = reinterpret_cast<uint4*>(job.dst);
-  for (long long c = blockIdx.x * 256ll + threadIdx.x; c < nchunks; c += (long long)gridDim.x * 256) {
-    int row, kc;
-    if (job.trans) {               // adjacent threads: adjacent rows (contiguous in the [K][rows] source)
-      row = (int)(c % job.rows);
-      kc = (int)(c / job.rows);
-    } else {
-      kc = (int)(c % kc_per_row);
-      row = (int)(c / kc_per_row);
-    }
+  for (unsigned blk = blockIdx.x * 4u + wv; blk < nblk; blk += gridDim.x * 4u) {
+    const unsigned rb = blk / kb_per_row, kb = blk - rb * kb_per_row;
+    const unsigned row_raw = 32u * rb + (lane & 31u), kc = 2u * kb + (lane >> 5);
+    const bool live = row_raw < (unsigned)job.rows;
+    const unsigned row = live ? row_raw : (unsigned)job.rows - 1u;    // clamped address, zero value (padding rows)
     float v[8];
+    if (vec) {
+      const float4* sp = reinterpret_cast<const float4*>(job.src + (long long)row * job.ld + 8u * kc);
+      const float4 a = sp[0], b = sp[1];
+      v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+    } else {
 #pragma unroll
-    for (int e = 0; e < 8; ++e) {
-      const int k = 8 * kc + e;
-      v[e] = job.trans ? job.src[(long long)k * job.ld + row] : job.src[(long long)row * job.ld + k];
+      for (int e = 0; e < 8; ++e) {
+        const unsigned k = 8u * kc + e;
+        v[e] = job.trans ? job.src[(long long)k * job.ld + row] : job.src[(long long)row * job.ld + k];
+      }
+    }
+    if (!live) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] = 0.f;
     }
     uint4 o[NPL];
     pack8<NPL>(v, o);
-    uint4* d = dst + (((long long)(row >> 5) * (job.K >> 4) + (kc >> 1)) * NPL) * 64 + (row & 31) + 32 * (kc & 1);
+    uint4* d = dst + (long long)blk * NPL * 64 + lane;
 #pragma unroll
     for (int pl = 0; pl < NPL; ++pl) d[pl * 64] = o[pl];
   }
@@ -650,7 +662,7 @@ extern "C" int dpot_bf16_pack_jobs(const dpot_pack_job* jobs_dev, int njobs, int
   DPOT_REQUIRE(jobs_dev && njobs > 0 && njobs <= 65535 && max_elems > 0, "bf16_pack_jobs: bad argument");
   DPOT_REQUIRE(planes == 1 || planes == 3, "bf16_pack_jobs: planes must be 1 or 3");
   long long g = ((long long)max_elems / 8 + 255) / 256;
-  if (g > 2048) g = 2048;
+  if (g > 1024) g = 1024;
   if (planes == 3)
     hipLaunchKernelGGL(bf16_pack_jobs_kernel<3>, dim3((unsigned)g, njobs), dim3(256), 0, as_stream(stream), jobs_dev);
   else
