@@ -138,14 +138,14 @@ constexpr int PB_COLT = 8;      // 32-column tiles per workgroup (256 columns)
 constexpr int PB_NLOAD = 4;     // loader waves
 constexpr int PB_SLABB = (PB_ROWT + PB_COLT) * 2 * 1024;        // bytes of one 32-k slab: 24 KiB
 
-__global__ __launch_bounds__(64 * (8 + PB_NLOAD)) void gemm_bf16p_kernel(const Bf16pArgs p) {
+// body of the kernel: problem p, workgroup index bid0 within the problem, split-K index zs
+__device__ __forceinline__ void gemm_bf16p_body(const Bf16pArgs& p, const int bid0, const int zs) {
   // ring of 3 slabs; the epilogue stages through it afterwards (8 waves x 32 x EPI_LD floats = 36 KiB)
   __shared__ __attribute__((aligned(16))) unsigned char lds[3 * PB_SLABB];
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int ks16 = p.K >> 4;                        // 16-k blocks per row tile
-  const int zs = blockIdx.y;                        // split-K index
   const int slab0 = zs * p.slabs_per_split;         // first 32-k slab of this split (K % 32 == 0)
   int nslab = (p.K >> 5) - slab0;
   nslab = nslab < p.slabs_per_split ? nslab : p.slabs_per_split;
@@ -154,7 +154,7 @@ __global__ __launch_bounds__(64 * (8 + PB_NLOAD)) void gemm_bf16p_kernel(const B
   const int ntiles = p.tilesM * p.tilesN;
   int tile;
   {
-    const int bid = blockIdx.x, xcd = bid & 7, slot = bid >> 3;
+    const int bid = bid0, xcd = bid & 7, slot = bid >> 3;
     const int q = ntiles >> 3, r = ntiles & 7;
     tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + slot;
   }
@@ -302,6 +302,21 @@ __global__ __launch_bounds__(64 * (8 + PB_NLOAD)) void gemm_bf16p_kernel(const B
   epi_fragment(p.e, 1, 0, m0, n0 + 32, acc[0][1], stage, lane);
   epi_fragment(p.e, 1, 0, m0 + 32, n0, acc[1][0], stage, lane);
   epi_fragment(p.e, 1, 0, m0 + 32, n0 + 32, acc[1][1], stage, lane);
+}
+
+__global__ __launch_bounds__(64 * (8 + PB_NLOAD)) void gemm_bf16p_kernel(const Bf16pArgs p) {
+  gemm_bf16p_body(p, blockIdx.x, blockIdx.y);
+}
+
+// two independent problems in ONE launch (the fc1 and fc2 weight gradients of a block: 128 tiles each at DPOT-M - alone
+// each needs split-K 2, i.e. 2 x 16 MB of partial sums and a reduce launch, to fill 256 CUs; together they fill them)
+struct Bf16pPair {
+  Bf16pArgs a[2];
+  int n0;          // workgroups of problem 0
+};
+__global__ __launch_bounds__(64 * (8 + PB_NLOAD)) void gemm_bf16p_pair_kernel(const Bf16pPair pp) {
+  const int which = (int)blockIdx.x >= pp.n0 ? 1 : 0;
+  gemm_bf16p_body(pp.a[which], (int)blockIdx.x - which * pp.n0, 0);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -745,3 +760,52 @@ extern "C" int dpot_gemm_bf16p(const void* Apacked, const void* Wpacked, const f
                      1, e, (float*)nullptr, 0ll, 0);
   return check_launch("splitk_reduce_kernel");
 }
+
+// C0[M0, N0] = A0 W0^T and C1[M1, N1] = A1 W1^T (plain bf16 operands, common K, linear epilogue, no split-K) in one launch
+extern "C" int dpot_gemm_bf16p_pair_wanted(int M0, int N0, int M1, int N1, int K) {
+  static const int enabled = [] { const char* e = getenv("DPOT_BF16P_PAIR"); return e ? atoi(e) : 1; }();
+  if (!enabled || !dpot_gemm_bf16p_supported(M0, N0, K) || !dpot_gemm_bf16p_supported(M1, N1, K)) return 0;
+  const long long t0 = (long long)((M0 + 127) / 128) * (N0 / 256), t1 = (long long)((M1 + 127) / 128) * (N1 / 256);
+  // worth it when each alone would be split (fewer than 192 tiles) and together they fill the chip
+  return t0 < 192 && t1 < 192 && t0 + t1 >= 192 ? 1 : 0;
+}
+
+extern "C" int dpot_gemm_bf16p_pair(const void* A0, const void* W0, float* C0, int ldc0, int M0, int N0, const void* A1,
+                                    const void* W1, float* C1, int ldc1, int M1, int N1, int K, dpot_stream_t stream) {
+  DPOT_REQUIRE(A0 && W0 && C0 && A1 && W1 && C1, "gemm_bf16p_pair: null operand");
+  DPOT_REQUIRE(dpot_gemm_bf16p_supported(M0, N0, K) && dpot_gemm_bf16p_supported(M1, N1, K),
+               "gemm_bf16p_pair: unsupported shape (N %% 256, K %% 32)");
+  DPOT_REQUIRE(ldc0 >= N0 && ldc1 >= N1 && ldc0 % 4 == 0 && ldc1 % 4 == 0 && aligned16(A0) && aligned16(W0) && aligned16(C0) &&
+                   aligned16(A1) && aligned16(W1) && aligned16(C1),
+               "gemm_bf16p_pair: bad leading dimension / alignment");
+  Bf16pPair pp;
+  const void* As[2] = {A0, A1};
+  const void* Ws[2] = {W0, W1};
+  float* Cs[2] = {C0, C1};
+  const int Ms[2] = {M0, M1}, Ns[2] = {N0, N1}, lds_[2] = {ldc0, ldc1};
+  for (int i = 0; i < 2; ++i) {
+    Bf16pArgs& p = pp.a[i];
+    p.A = reinterpret_cast<const unsigned short*>(As[i]);
+    p.W = reinterpret_cast<const unsigned short*>(Ws[i]);
+    p.M = Ms[i]; p.N = Ns[i]; p.K = K;
+    p.tilesM = (Ms[i] + 32 * PB_ROWT - 1) / (32 * PB_ROWT);
+    p.tilesN = Ns[i] / (32 * PB_COLT);
+    EpiArgs& e = p.e;
+    e.C = Cs[i]; e.ldc = lds_[i]; e.sC = 0;
+    e.bias = nullptr; e.sBias = 0;
+    e.aux = nullptr; e.ldaux = 0; e.sAux = 0;
+    e.pre = nullptr; e.ldpre = 0; e.sPre = 0;
+    e.res = nullptr; e.ldres = 0; e.res_div = 0; e.res_mod = 0; e.sRes = 0;
+    e.act = 0; e.mode = DPOT_EPI_LINEAR; e.accumulate = 0;
+    e.M = Ms[i]; e.N = Ns[i];
+    p.splits = 1;
+    p.slabs_per_split = K >> 5;
+    p.ws = nullptr;
+    p.out_rows = nullptr; p.out_trans = nullptr; p.cs_part = nullptr;
+  }
+  pp.n0 = pp.a[0].tilesM * pp.a[0].tilesN;
+  const unsigned grid = (unsigned)(pp.n0 + pp.a[1].tilesM * pp.a[1].tilesN);
+  hipLaunchKernelGGL(gemm_bf16p_pair_kernel, dim3(grid), dim3(64 * (8 + PB_NLOAD)), 0, as_stream(stream), pp);
+  return check_launch("gemm_bf16p_pair_kernel");
+}
+

@@ -412,14 +412,20 @@ class BlockFn(torch.autograd.Function):
             # pack-both path (see _block_parts): xn2 / Hh ARE the transposed bf16 packs; each gradient is packed once, in
             # both forms, and its bias column sums come out of the same pass
             dop, dopT, df2b = ops.bf16_pack_both(do2, want_colsum=True, colsum_out=s_f2b.out())
-            df2w, _ = ops.gemm_bf16p(dopT, Hh, E, mh, M, out=s_f2w.out())
-            df2w, df2b = s_f2w.done(df2w.view(E, mh, 1, 1)), s_f2b.done(df2b)
+            # both weight gradients in ONE launch once dHpre's pack exists, when each alone would need split-K
+            pair = ops.gemm_bf16p_pair_wanted(E, mh, mh, E, M)
+            if not pair:
+                df2w, _ = ops.gemm_bf16p(dopT, Hh, E, mh, M, out=s_f2w.out())
             # dHpre = (do2 W2) * act'(Hpre) leaves the GEMM as its two packs + bias column sums only
             _, _, dhp, dhpT, df1b = ops.gemm_bf16p_packed(dop, mlp_pk[3], M, mh, E, act=act, mode=EPI_DACT, aux=Hpre,
                                                           pack_rows=True, pack_trans=True, colsum=True,
                                                           colsum_out=s_f1b.out(), store=False)
+            if pair:
+                df2w, df1w = ops.gemm_bf16p_pair(dopT, Hh, E, mh, dhpT, xn2, mh, E, M, out0=s_f2w.out(), out1=s_f1w.out())
+            else:
+                df1w, _ = ops.gemm_bf16p(dhpT, xn2, mh, E, M, out=s_f1w.out())
             del dop, dopT
-            df1w, _ = ops.gemm_bf16p(dhpT, xn2, mh, E, M, out=s_f1w.out())
+            df2w, df2b = s_f2w.done(df2w.view(E, mh, 1, 1)), s_f2b.done(df2b)
             df1w, df1b = s_f1w.done(df1w.view(mh, E, 1, 1)), s_f1b.done(df1b)
             dxn2, _ = ops.gemm_bf16p(dhp, mlp_pk[1], M, E, mh)
             del dhp, dhpT

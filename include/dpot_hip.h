@@ -441,6 +441,12 @@ int dpot_gemm_bf16p(const void* Apacked, const void* Wpacked, const float* bias,
                     const float* res, int ldres, float* pre, int ldpre, float* C, int ldc, int M, int N, int K, int act,
                     int epi_mode, int planes, int splitk, float* workspace, void* out_rows, void* out_trans,
                     float* colsum_part, dpot_stream_t stream);
+/* two independent products of that kind (plain bf16 operands, common K, linear epilogue, no split-K) in ONE launch:
+ * the fc1 / fc2 weight gradients of a block, which alone have too few tiles for 256 CUs and would each go through
+ * split-K partials + a reduce launch.  _wanted: 1 when each alone would be split and together they fill the chip. */
+int dpot_gemm_bf16p_pair_wanted(int M0, int N0, int M1, int N1, int K);
+int dpot_gemm_bf16p_pair(const void* A0, const void* W0, float* C0, int ldc0, int M0, int N0, const void* A1,
+                         const void* W1, float* C1, int ldc1, int M1, int N1, int K, dpot_stream_t stream);
 /* out_rows / out_trans / colsum_part (all optional, planes == 1, splitk <= 1, M % 32 == 0): the epilogue also emits the
  * 1-plane packs of the FINAL output (row form [M, N]; transposed form = rows N, k M) and partial column sums
  * [M/32, N] - the next GEMMs of a chain then need no pack pass over this output; C may be NULL in that case. */

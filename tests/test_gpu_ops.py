@@ -1020,3 +1020,22 @@ def test_groupnorm_deferred_param_grads_match(ops):
     assert res[0][0].data_ptr() == slot.data_ptr()
     for (dg, db), (_, dg0, db0) in zip(res, outs):
         assert torch.equal(dg, dg0) and torch.equal(db, db0)
+
+
+@pytest.mark.gpu
+def test_bf16_panel_pair_launch_matches_single(ops):
+    """two weight-gradient products in one launch (csrc/gemm_bf16p.hip pair kernel) == the two single launches, bit for bit
+    up to the split-K summation order of the singles (compared against the products of the bf16-rounded operands)"""
+    torch.manual_seed(11)
+    T, n0, k0, n1, k1 = 1024, 256, 512, 512, 256
+    dy0 = torch.randn(T, n0, device="cuda"); x0 = torch.randn(T, k0, device="cuda")
+    dy1 = torch.randn(T, n1, device="cuda"); x1 = torch.randn(T, k1, device="cuda")
+    packs = [ops.bf16_pack_rows(t, trans=True) for t in (dy0, x0, dy1, x1)]
+    C0, C1 = ops.gemm_bf16p_pair(packs[0], packs[1], n0, k0, packs[2], packs[3], n1, k1, T)
+    r = lambda t: t.bfloat16().double()
+    assert_close(C0, r(dy0).t() @ r(x0), "pair product 0")
+    assert_close(C1, r(dy1).t() @ r(x1), "pair product 1")
+    S0, _ = ops.gemm_bf16p(packs[0], packs[1], n0, k0, T, splitk=1)
+    S1, _ = ops.gemm_bf16p(packs[2], packs[3], n1, k1, T, splitk=1)
+    assert torch.equal(C0, S0) and torch.equal(C1, S1)
+    assert ops.gemm_bf16p_pair_wanted(1024, 4096, 4096, 1024, 8192) and not ops.gemm_bf16p_pair_wanted(256, 512, 512, 256, 1024)
