@@ -76,8 +76,9 @@ SIGNATURES = {
     "dpot_afno_mlp3_supported": (c_i, [c_i, c_i]),
     "dpot_afno_block_weights": (c_i, [c_fp] * 3 + [c_i, c_i, c_fp]),
     "dpot_afno_pack_all": (c_i, [c_fp, c_i, c_i, c_i, c_i, c_fp]),
-    "dpot_groupnorm_fwd": (c_i, [c_fp] * 6 + [c_i] * 4 + [c_f, c_fp]),
-    "dpot_groupnorm_bwd": (c_i, [c_fp] * 10 + [c_i] * 4 + [c_fp]),
+    "dpot_groupnorm_ws_elems": (c_i64, [c_i] * 4),
+    "dpot_groupnorm_fwd": (c_i, [c_fp] * 7 + [c_i] * 4 + [c_f, c_fp]),
+    "dpot_groupnorm_bwd": (c_i, [c_fp] * 11 + [c_i] * 4 + [c_fp]),
     "dpot_groupnorm_param_grads": (c_i, [C.c_void_p] * 3 + [c_i] * 3 + [c_fp]),
     "dpot_patchify": (c_i, [c_fp] * 5 + [c_i] * 6 + [c_fp]),
     "dpot_unpatchify": (c_i, [c_fp] * 2 + [c_i] * 6 + [c_fp]),

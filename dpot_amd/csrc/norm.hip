@@ -366,16 +366,236 @@ static int gn_cached_items(int T, int E, int G) {
   return 0;
 }
 
+
+// ---- chunked variants: large slabs on few (sample, group) pairs -------------------------------------------------------
+// DPOT-L at 256^2, B = 4: a (b, group) slab is 1024 tokens x 192 channels = 768 KiB and there are only B*G = 32 of them:
+// one workgroup per slab keeps 32 of 256 CUs busy (measured 69 us forward / 92 us backward for 25 MB tensors).  Here a
+// slab is cut into token chunks, grid (chunks, G, B) >= 512 workgroups, and the group statistics go through a tiny
+// workspace: pass A writes per-chunk partials, pass B merges them in its prologue (every workgroup of the slab redoes the
+// merge - `chunks` values, fixed order) and applies.  x is read twice (the second read mostly from L2 / MALL).
+struct GnChunks {
+  int TC, chunks;      // tokens per chunk, chunks per slab
+};
+
+// forward, pass A: per-chunk (mean, M2 = sum (x - mean)^2); two sweeps over the chunk (the second hits L2)
+__global__ __launch_bounds__(GN_THREADS) void gn_chunk_stats_kernel(const float* __restrict__ x, float* __restrict__ ws,
+                                                                    int T, int E, int G, GnChunks c) {
+  __shared__ double shd[16];
+  const int ch = blockIdx.x, g = blockIdx.y, b = blockIdx.z;
+  const int cg = E / G, q4 = cg >> 2;
+  const int t0 = ch * c.TC;
+  const int nt = T - t0 < c.TC ? T - t0 : c.TC;
+  const unsigned nq = (unsigned)nt * (unsigned)q4;
+  const float* xs = x + ((long long)b * T + t0) * E + g * cg;
+  float s = 0.f;
+  for (unsigned i = threadIdx.x; i < nq; i += GN_THREADS) {
+    const unsigned t = i / (unsigned)q4, j = i - t * (unsigned)q4;
+    const float4 v = *reinterpret_cast<const float4*>(xs + (long long)t * E + 4 * j);
+    s += (v.x + v.y) + (v.z + v.w);
+  }
+  const double n = (double)nt * cg;
+  const float mu = (float)(block_sum_d((double)s, shd) / n);
+  float q = 0.f;
+  for (unsigned i = threadIdx.x; i < nq; i += GN_THREADS) {
+    const unsigned t = i / (unsigned)q4, j = i - t * (unsigned)q4;
+    const float4 v = *reinterpret_cast<const float4*>(xs + (long long)t * E + 4 * j);
+    const float d0 = v.x - mu, d1 = v.y - mu, d2 = v.z - mu, d3 = v.w - mu;
+    q = fmaf(d0, d0, q); q = fmaf(d1, d1, q); q = fmaf(d2, d2, q); q = fmaf(d3, d3, q);
+  }
+  const double m2 = block_sum_d((double)q, shd);
+  if (threadIdx.x == 0) {
+    float* w = ws + (((long long)b * G + g) * c.chunks + ch) * 2;
+    w[0] = mu;
+    w[1] = (float)m2;
+  }
+}
+
+// merge of the chunk partials of slab (b, g) (Chan et al.), identical in every workgroup of the slab
+__device__ __forceinline__ void gn_chunk_merge(const float* __restrict__ ws, int b, int g, int G, int T, int cg, GnChunks c,
+                                               float eps, float& mu, float& rs) {
+  const float* w = ws + ((long long)b * G + g) * c.chunks * 2;
+  double sm = 0.0;
+  for (int k = 0; k < c.chunks; ++k) {
+    const int nt = T - k * c.TC < c.TC ? T - k * c.TC : c.TC;
+    sm += (double)w[2 * k] * ((double)nt * cg);
+  }
+  const double N = (double)T * cg, mean = sm / N;
+  double m2 = 0.0;
+  for (int k = 0; k < c.chunks; ++k) {
+    const int nt = T - k * c.TC < c.TC ? T - k * c.TC : c.TC;
+    const double d = (double)w[2 * k] - mean;
+    m2 += (double)w[2 * k + 1] + d * d * ((double)nt * cg);
+  }
+  mu = (float)mean;
+  rs = 1.0f / sqrtf((float)(m2 / N) + eps);
+}
+
+// forward, pass B
+__global__ __launch_bounds__(GN_THREADS) void gn_chunk_apply_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
+                                                                    const float* __restrict__ beta, float* __restrict__ y,
+                                                                    float* __restrict__ mean, float* __restrict__ rstd,
+                                                                    const float* __restrict__ ws, int T, int E, int G,
+                                                                    GnChunks c, float eps) {
+  const int ch = blockIdx.x, g = blockIdx.y, b = blockIdx.z;
+  const int cg = E / G, q4 = cg >> 2;
+  float mu, rs;
+  gn_chunk_merge(ws, b, g, G, T, cg, c, eps, mu, rs);
+  if (ch == 0 && threadIdx.x == 0) {
+    mean[b * G + g] = mu;
+    rstd[b * G + g] = rs;
+  }
+  const int t0 = ch * c.TC;
+  const int nt = T - t0 < c.TC ? T - t0 : c.TC;
+  const unsigned nq = (unsigned)nt * (unsigned)q4;
+  const long long off = ((long long)b * T + t0) * E + g * cg;
+  for (unsigned i = threadIdx.x; i < nq; i += GN_THREADS) {
+    const unsigned t = i / (unsigned)q4, j = i - t * (unsigned)q4;
+    const long long o = off + (long long)t * E + 4 * j;
+    const float4 v = *reinterpret_cast<const float4*>(x + o);
+    float4 ga = *reinterpret_cast<const float4*>(gamma + g * cg + 4 * j);
+    const float4 be = *reinterpret_cast<const float4*>(beta + g * cg + 4 * j);
+    ga.x *= rs; ga.y *= rs; ga.z *= rs; ga.w *= rs;
+    *reinterpret_cast<float4*>(y + o) = make_float4(fmaf(v.x - mu, ga.x, be.x), fmaf(v.y - mu, ga.y, be.y),
+                                                    fmaf(v.z - mu, ga.z, be.z), fmaf(v.w - mu, ga.w, be.w));
+  }
+}
+
+// backward, pass A: per-chunk per-channel sums  ws[((b*chunks + ch)*2 + k)*E + c]:  k = 0: sum_t dy*xhat, k = 1: sum_t dy
+__global__ __launch_bounds__(GN_THREADS) void gn_chunk_bwd_part_kernel(const float* __restrict__ dy, const float* __restrict__ x,
+                                                                       const float* __restrict__ mean,
+                                                                       const float* __restrict__ rstd, float* __restrict__ ws,
+                                                                       int T, int E, int G, GnChunks c) {
+  __shared__ float red[GN_THREADS][8];
+  const int ch = blockIdx.x, g = blockIdx.y, b = blockIdx.z;
+  const int cg = E / G, q4 = cg >> 2;
+  const int TT = GN_THREADS / q4;                         // token lanes; threads >= TT * q4 idle
+  const int tj = threadIdx.x % q4, tt = threadIdx.x / q4;
+  const int t0 = ch * c.TC;
+  const int nt = T - t0 < c.TC ? T - t0 : c.TC;
+  const float mu = mean[b * G + g], rs = rstd[b * G + g];
+  const long long off = ((long long)b * T + t0) * E + g * cg + 4 * tj;
+  float a[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  if (tt < TT) {
+    for (int t = tt; t < nt; t += TT) {
+      const float4 d = *reinterpret_cast<const float4*>(dy + off + (long long)t * E);
+      const float4 v = *reinterpret_cast<const float4*>(x + off + (long long)t * E);
+      a[0] = fmaf(d.x, (v.x - mu) * rs, a[0]); a[1] = fmaf(d.y, (v.y - mu) * rs, a[1]);
+      a[2] = fmaf(d.z, (v.z - mu) * rs, a[2]); a[3] = fmaf(d.w, (v.w - mu) * rs, a[3]);
+      a[4] += d.x; a[5] += d.y; a[6] += d.z; a[7] += d.w;
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < 8; ++k) red[threadIdx.x][k] = a[k];
+  __syncthreads();
+  if (tt == 0) {                                          // fixed order over the token lanes
+    float r[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    for (int l = 0; l < TT; ++l)
+#pragma unroll
+      for (int k = 0; k < 8; ++k) r[k] += red[l * q4 + tj][k];
+    float* w = ws + ((long long)b * c.chunks + ch) * 2 * E + g * cg + 4 * tj;
+    *reinterpret_cast<float4*>(w) = make_float4(r[0], r[1], r[2], r[3]);
+    *reinterpret_cast<float4*>(w + E) = make_float4(r[4], r[5], r[6], r[7]);
+  }
+}
+
+// backward, pass B: per-channel totals over the chunks (-> the per-sample parameter-gradient partials, written by chunk 0),
+// group means m1 = mean_g(gamma dy), m2 = mean_g(gamma dy xhat), then dx for this chunk
+__global__ __launch_bounds__(GN_THREADS) void gn_chunk_bwd_apply_kernel(
+    const float* __restrict__ dy, const float* __restrict__ x, const float* __restrict__ mean,
+    const float* __restrict__ rstd, const float* __restrict__ gamma, const float* __restrict__ add,
+    float* __restrict__ dx, float* __restrict__ part, const float* __restrict__ ws, int B, int T, int E, int G,
+    GnChunks c) {
+  __shared__ double shd[16];
+  const int ch = blockIdx.x, g = blockIdx.y, b = blockIdx.z;
+  const int cg = E / G, q4 = cg >> 2;
+  const float mu = mean[b * G + g], rs = rstd[b * G + g];
+  double s1 = 0.0, s2 = 0.0;
+  if ((int)threadIdx.x < cg) {
+    const int col = g * cg + threadIdx.x;
+    float tdx = 0.f, td = 0.f;
+    for (int k = 0; k < c.chunks; ++k) {
+      const float* w = ws + ((long long)b * c.chunks + k) * 2 * E + col;
+      tdx += w[0];
+      td += w[E];
+    }
+    if (ch == 0) {
+      part[((long long)0 * B + b) * E + col] = tdx;
+      part[((long long)1 * B + b) * E + col] = td;
+    }
+    const float gm = gamma[col];
+    s1 = (double)(gm * td);
+    s2 = (double)(gm * tdx);
+  }
+  const double n = (double)T * cg;
+  const float m1 = (float)(block_sum_d(s1, shd) / n);
+  const float m2 = (float)(block_sum_d(s2, shd) / n);
+  const int t0 = ch * c.TC;
+  const int nt = T - t0 < c.TC ? T - t0 : c.TC;
+  const unsigned nq = (unsigned)nt * (unsigned)q4;
+  const long long off = ((long long)b * T + t0) * E + g * cg;
+  for (unsigned i = threadIdx.x; i < nq; i += GN_THREADS) {
+    const unsigned t = i / (unsigned)q4, j = i - t * (unsigned)q4;
+    const long long o = off + (long long)t * E + 4 * j;
+    const float4 d = *reinterpret_cast<const float4*>(dy + o);
+    const float4 v = *reinterpret_cast<const float4*>(x + o);
+    const float4 ga = *reinterpret_cast<const float4*>(gamma + g * cg + 4 * j);
+    float4 r;
+    r.x = rs * (ga.x * d.x - m1 - (v.x - mu) * rs * m2);
+    r.y = rs * (ga.y * d.y - m1 - (v.y - mu) * rs * m2);
+    r.z = rs * (ga.z * d.z - m1 - (v.z - mu) * rs * m2);
+    r.w = rs * (ga.w * d.w - m1 - (v.w - mu) * rs * m2);
+    if (add) {
+      const float4 a4 = *reinterpret_cast<const float4*>(add + o);
+      r.x += a4.x; r.y += a4.y; r.z += a4.z; r.w += a4.w;
+    }
+    *reinterpret_cast<float4*>(dx + o) = r;
+  }
+}
+
+// chunking of a slab, or {0, 0} when the one-workgroup-per-slab kernels are the right ones
+static GnChunks gn_chunking(int B, int T, int E, int G) {
+  static const int enabled = [] { const char* e = getenv("DPOT_GN_CHUNKED"); return e ? atoi(e) : 1; }();
+  GnChunks c{0, 0};
+  const int cg = E / G;
+  if (!enabled || cg % 4 || cg > GN_THREADS || gn_cached_items(T, E, G) != 0) return c;
+  const long long slabs = (long long)B * G;
+  if (slabs >= 192 || T < 64) return c;                   // enough slabs to fill the chip as they are
+  long long chunks = (512 + slabs - 1) / slabs;
+  if (chunks > T / 16) chunks = T / 16;
+  if (chunks > 64) chunks = 64;
+  if (chunks < 2) return c;
+  c.TC = (int)((T + chunks - 1) / chunks);
+  c.chunks = (T + c.TC - 1) / c.TC;
+  return c;
+}
+
 }  // namespace dpot
 
 using namespace dpot;
 
+extern "C" int64_t dpot_groupnorm_ws_elems(int B, int T, int E, int G) {
+  if (B <= 0 || T <= 0 || E <= 0 || G <= 0 || E % G) return 0;
+  const GnChunks c = gn_chunking(B, T, E, G);
+  return c.chunks ? (int64_t)B * c.chunks * 2 * E : 0;    // backward partials (the forward needs B*G*chunks*2 <= this)
+}
+
 extern "C" int dpot_groupnorm_fwd(const float* x, const float* gamma, const float* beta, float* y, float* mean,
-                                  float* rstd, int B, int T, int E, int G, float eps, dpot_stream_t stream) {
+                                  float* rstd, float* workspace, int B, int T, int E, int G, float eps,
+                                  dpot_stream_t stream) {
   DPOT_REQUIRE(x && gamma && beta && y && mean && rstd, "groupnorm_fwd: null pointer");
   DPOT_REQUIRE(B > 0 && T > 0 && E > 0 && G > 0 && E % G == 0 && B <= 65535, "groupnorm_fwd: bad shape");
   const bool vec = ((E / G) % 4 == 0) && aligned16(x) && aligned16(y) && aligned16(gamma) && aligned16(beta);
   const int items = vec ? gn_cached_items(T, E, G) : 0;
+  const GnChunks ck = vec && workspace && aligned16(workspace) ? gn_chunking(B, T, E, G) : GnChunks{0, 0};
+  if (ck.chunks) {
+    const dim3 grid(ck.chunks, G, B);
+    hipLaunchKernelGGL(gn_chunk_stats_kernel, grid, dim3(GN_THREADS), 0, as_stream(stream), x, workspace, T, E, G, ck);
+    int rc = check_launch("gn_chunk_stats_kernel");
+    if (rc) return rc;
+    hipLaunchKernelGGL(gn_chunk_apply_kernel, grid, dim3(GN_THREADS), 0, as_stream(stream), x, gamma, beta, y, mean, rstd,
+                       (const float*)workspace, T, E, G, ck, eps);
+    return check_launch("gn_chunk_apply_kernel");
+  }
   if (items == 4)
     hipLaunchKernelGGL(groupnorm_fwd_cached_kernel<4>, dim3(G, B), dim3(GN_THREADS), 0, as_stream(stream), x, gamma, beta,
                        y, mean, rstd, T, E, G, eps);
@@ -393,14 +613,23 @@ extern "C" int dpot_groupnorm_fwd(const float* x, const float* gamma, const floa
 
 extern "C" int dpot_groupnorm_bwd(const float* dy, const float* x, const float* mean, const float* rstd,
                                   const float* gamma, const float* add, float* dx, float* dgamma, float* dbeta,
-                                  float* part, int B, int T, int E, int G, dpot_stream_t stream) {
+                                  float* part, float* workspace, int B, int T, int E, int G, dpot_stream_t stream) {
   DPOT_REQUIRE(dy && x && mean && rstd && gamma && dx && part && ((dgamma == nullptr) == (dbeta == nullptr)),
                "groupnorm_bwd: null pointer");
   DPOT_REQUIRE(B > 0 && T > 0 && E > 0 && G > 0 && E % G == 0 && B <= 65535, "groupnorm_bwd: bad shape");
   const bool vec = ((E / G) % 4 == 0) && aligned16(x) && aligned16(dy) && aligned16(dx) && aligned16(gamma) &&
                    (add == nullptr || aligned16(add));
   const int items = vec ? gn_cached_items(T, E, G) : 0;
-  if (items == 4)
+  const GnChunks ck = vec && workspace && aligned16(workspace) ? gn_chunking(B, T, E, G) : GnChunks{0, 0};
+  if (ck.chunks) {
+    const dim3 grid(ck.chunks, G, B);
+    hipLaunchKernelGGL(gn_chunk_bwd_part_kernel, grid, dim3(GN_THREADS), 0, as_stream(stream), dy, x, mean, rstd, workspace,
+                       T, E, G, ck);
+    int rc0 = check_launch("gn_chunk_bwd_part_kernel");
+    if (rc0) return rc0;
+    hipLaunchKernelGGL(gn_chunk_bwd_apply_kernel, grid, dim3(GN_THREADS), 0, as_stream(stream), dy, x, mean, rstd, gamma, add,
+                       dx, part, (const float*)workspace, B, T, E, G, ck);
+  } else if (items == 4)
     hipLaunchKernelGGL(groupnorm_bwd_cached_kernel<4>, dim3(G, B), dim3(GN_THREADS), 0, as_stream(stream), dy, x, mean,
                        rstd, gamma, add, dx, part, B, T, E, G);
   else if (items == 8)

@@ -551,13 +551,26 @@ def afno_unpack_grad(dwbig: Tensor, dbbig: Tensor, nb: int, bs: int, out_dw: Opt
 # ------------------------------------------------------------------------------------------------------
 # GroupNorm
 # ------------------------------------------------------------------------------------------------------
-def groupnorm_fwd(x: Tensor, gamma: Tensor, beta: Tensor, G: int = 8, eps: float = 1e-5):
+def _gn_workspace(B: int, T: int, E: int, G: int, device) -> Optional[Tensor]:
+    """scratch for the chunked GroupNorm kernels (few, large (sample, group) slabs: DPOT-L at 256^2), or None"""
+    n = _lib.load().dpot_groupnorm_ws_elems(B, T, E, G)
+    return torch.empty(n, dtype=torch.float32, device=device) if n > 0 else None
+
+
+def groupnorm_ws_elems(B: int, T: int, E: int, G: int) -> int:
+    return int(_lib.load().dpot_groupnorm_ws_elems(B, T, E, G))
+
+
+def groupnorm_fwd(x: Tensor, gamma: Tensor, beta: Tensor, G: int = 8, eps: float = 1e-5, chunked: bool = True):
+    """chunked=False: never the chunked kernels (no workspace is passed)"""
     B, T, E = x.shape
     y = torch.empty_like(x)
     mean = torch.empty(B, G, dtype=torch.float32, device=x.device)
     rstd = torch.empty(B, G, dtype=torch.float32, device=x.device)
+    ws = _gn_workspace(B, T, E, G, x.device) if chunked else None
     check(_lib.load().dpot_groupnorm_fwd(x.data_ptr(), gamma.data_ptr(), beta.data_ptr(), y.data_ptr(),
-                                         mean.data_ptr(), rstd.data_ptr(), B, T, E, G, eps, _stream()), "groupnorm_fwd")
+                                         mean.data_ptr(), rstd.data_ptr(), _p(ws), B, T, E, G, eps, _stream()),
+          "groupnorm_fwd")
     return y, mean, rstd
 
 
@@ -571,9 +584,10 @@ def groupnorm_bwd(dy: Tensor, x: Tensor, mean: Tensor, rstd: Tensor, gamma: Tens
     part = torch.empty(2, B, E, dtype=torch.float32, device=x.device)
     dgamma = None if defer else _out(out_dgamma, (E,), x.device)
     dbeta = None if defer else _out(out_dbeta, (E,), x.device)
+    ws = _gn_workspace(B, T, E, G, x.device)
     check(_lib.load().dpot_groupnorm_bwd(dy.data_ptr(), x.data_ptr(), mean.data_ptr(), rstd.data_ptr(),
                                          gamma.data_ptr(), _p(add), dx.data_ptr(), _p(dgamma), _p(dbeta),
-                                         part.data_ptr(), B, T, E, G, _stream()), "groupnorm_bwd")
+                                         part.data_ptr(), _p(ws), B, T, E, G, _stream()), "groupnorm_bwd")
     return (dx, part) if defer else (dx, dgamma, dbeta)
 
 

@@ -204,11 +204,16 @@ int dpot_afno_unpack_grad(const float* dwbig, const float* dbbig, float* dw, flo
  * bwd: dx = rstd * (gamma*dy - mean_g(gamma*dy) - xhat * mean_g(gamma*dy*xhat)) (+ add), and
  *      dgamma/dbeta via per-sample partials part[2,B,E] that are then reduced over B in a fixed order.
  * ------------------------------------------------------------------------------------------------ */
+/* workspace: dpot_groupnorm_ws_elems(B,T,E,G) floats (0: none needed, NULL is fine).  It is used when there are few,
+ * large (sample, group) slabs (DPOT-L at 256^2, B = 4: 32 slabs of 768 KiB): the slabs are cut into token chunks so
+ * that >= 512 workgroups run, and the group statistics are merged through the workspace (two launches per call).
+ * Passing NULL always selects the one-workgroup-per-slab kernels. */
+int64_t dpot_groupnorm_ws_elems(int B, int T, int E, int G);
 int dpot_groupnorm_fwd(const float* x, const float* gamma, const float* beta, float* y, float* mean,
-                       float* rstd, int B, int T, int E, int G, float eps, dpot_stream_t stream);
+                       float* rstd, float* workspace, int B, int T, int E, int G, float eps, dpot_stream_t stream);
 int dpot_groupnorm_bwd(const float* dy, const float* x, const float* mean, const float* rstd,
                        const float* gamma, const float* add, float* dx, float* dgamma, float* dbeta,
-                       float* part /* [2,B,E] */, int B, int T, int E, int G, dpot_stream_t stream);
+                       float* part /* [2,B,E] */, float* workspace, int B, int T, int E, int G, dpot_stream_t stream);
 /* dgamma == dbeta == NULL above leaves the per-sample partials in `part`; this reduces up to 4 such partial sets
  * (HOST arrays of njobs pointers; e.g. the two GroupNorm layers of a block) in ONE launch. */
 int dpot_groupnorm_param_grads(const float* const* parts, float* const* dgammas, float* const* dbetas, int njobs,

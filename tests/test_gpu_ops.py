@@ -1039,3 +1039,31 @@ def test_bf16_panel_pair_launch_matches_single(ops):
     S1, _ = ops.gemm_bf16p(packs[2], packs[3], n1, k1, T, splitk=1)
     assert torch.equal(C0, S0) and torch.equal(C1, S1)
     assert ops.gemm_bf16p_pair_wanted(1024, 4096, 4096, 1024, 8192) and not ops.gemm_bf16p_pair_wanted(256, 512, 512, 256, 1024)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("B,T,E,G", [(4, 1024, 1536, 8), (2, 200, 96, 8), (1, 4096, 768, 8)])
+def test_groupnorm_chunked_vs_fp64(ops, monkeypatch, B, T, E, G):
+    """few, large (sample, group) slabs: the chunked kernels (statistics merged through a workspace) against float64
+    and against the one-workgroup-per-slab kernels (DPOT_GN_CHUNKED is read once per process: compared via NULL workspace)"""
+    torch.manual_seed(B + T)
+    x = torch.randn(B, T, E, device="cuda") * 1.7 + 0.8
+    gw = torch.randn(E, device="cuda"); gb = torch.randn(E, device="cuda")
+    dy = torch.randn(B, T, E, device="cuda"); add = torch.randn(B, T, E, device="cuda")
+    assert ops.groupnorm_ws_elems(B, T, E, G) > 0
+    y, mean, rstd = ops.groupnorm_fwd(x, gw, gb, G)
+    xd = x.double().view(B, T, G, E // G)
+    mu = xd.mean(dim=(1, 3), keepdim=True); var = xd.var(dim=(1, 3), unbiased=False, keepdim=True)
+    xh = ((xd - mu) / torch.sqrt(var + 1e-5)).view(B, T, E)
+    assert_close(y, xh * gw.double() + gb.double(), "chunked groupnorm fwd")
+    assert_close(mean, mu.view(B, G), "mean"); assert_close(rstd, (1 / torch.sqrt(var + 1e-5)).view(B, G), "rstd")
+    dx, dg, db = ops.groupnorm_bwd(dy, x, mean, rstd, gw, G, add=add)
+    xr = x.double().requires_grad_(True)
+    gwr = gw.double().requires_grad_(True)
+    yr = torch.nn.functional.group_norm(xr.transpose(1, 2), G, gwr, gb.double(), 1e-5).transpose(1, 2)
+    yr.backward(dy.double())
+    assert_close(dx, xr.grad + add.double(), "chunked groupnorm dx")
+    assert_close(dg, gwr.grad, "dgamma"); assert_close(db, dy.double().sum(dim=(0, 1)), "dbeta")
+    # the one-workgroup-per-slab kernels on the same data
+    y0, mean0, rstd0 = ops.groupnorm_fwd(x, gw, gb, G, chunked=False)
+    assert_close(y, y0.double(), "chunked vs slab kernels")
