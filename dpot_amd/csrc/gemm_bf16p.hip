@@ -766,8 +766,11 @@ extern "C" int dpot_gemm_bf16p_pair_wanted(int M0, int N0, int M1, int N1, int K
   static const int enabled = [] { const char* e = getenv("DPOT_BF16P_PAIR"); return e ? atoi(e) : 1; }();
   if (!enabled || !dpot_gemm_bf16p_supported(M0, N0, K) || !dpot_gemm_bf16p_supported(M1, N1, K)) return 0;
   const long long t0 = (long long)((M0 + 127) / 128) * (N0 / 256), t1 = (long long)((M1 + 127) / 128) * (N1 / 256);
-  // worth it when each alone would be split (fewer than 192 tiles) and together they fill the chip
-  return t0 < 192 && t1 < 192 && t0 + t1 >= 192 ? 1 : 0;
+  // worth it when each alone would be split (fewer than 192 tiles) and together they fill the chip, or when the joint
+  // grid needs fewer 256-workgroup rounds (DPOT-L: 288 + 288 tiles = 2 + 2 rounds apart, 3 together)
+  if (t0 < 192 && t1 < 192 && t0 + t1 >= 192) return 1;
+  const long long r0 = (t0 + 255) / 256, r1 = (t1 + 255) / 256, r01 = (t0 + t1 + 255) / 256;
+  return t0 >= 192 && t1 >= 192 && r0 + r1 > r01 ? 1 : 0;
 }
 
 extern "C" int dpot_gemm_bf16p_pair(const void* A0, const void* W0, float* C0, int ldc0, int M0, int N0, const void* A1,
