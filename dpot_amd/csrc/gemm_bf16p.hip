@@ -316,7 +316,7 @@ struct Bf16pPair {
 };
 __global__ __launch_bounds__(64 * (8 + PB_NLOAD)) void gemm_bf16p_pair_kernel(const Bf16pPair pp) {
   const int which = (int)blockIdx.x >= pp.n0 ? 1 : 0;
-  gemm_bf16p_body(pp.a[which], (int)blockIdx.x - which * pp.n0, 0);
+  gemm_bf16p_body(pp.a[which], (int)blockIdx.x - which * pp.n0, blockIdx.y);   // blockIdx.y: common split-K index
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -762,30 +762,54 @@ extern "C" int dpot_gemm_bf16p(const void* Apacked, const void* Wpacked, const f
 }
 
 // C0[M0, N0] = A0 W0^T and C1[M1, N1] = A1 W1^T (plain bf16 operands, common K, linear epilogue, no split-K) in one launch
-extern "C" int dpot_gemm_bf16p_pair_wanted(int M0, int N0, int M1, int N1, int K) {
+// split-K factor of the pair launch (common to both problems): 0 = do not pair, 1 = pair without split, s > 1 = pair
+// with s splits (workspace: s * (M0*N0 + M1*N1) floats; two fixed-order reduce launches follow)
+extern "C" int dpot_gemm_bf16p_pair_splitk(int M0, int N0, int M1, int N1, int K) {
   static const int enabled = [] { const char* e = getenv("DPOT_BF16P_PAIR"); return e ? atoi(e) : 1; }();
   if (!enabled || !dpot_gemm_bf16p_supported(M0, N0, K) || !dpot_gemm_bf16p_supported(M1, N1, K)) return 0;
   const long long t0 = (long long)((M0 + 127) / 128) * (N0 / 256), t1 = (long long)((M1 + 127) / 128) * (N1 / 256);
-  // worth it when each alone would be split (fewer than 192 tiles) and together they fill the chip, or when the joint
-  // grid needs fewer 256-workgroup rounds (DPOT-L: 288 + 288 tiles = 2 + 2 rounds apart, 3 together)
-  if (t0 < 192 && t1 < 192 && t0 + t1 >= 192) return 1;
+  if (t0 < 192 && t1 < 192) {
+    // each alone would be split: together they need half the split factor (half the partial-sum traffic), or none
+    if (t0 + t1 >= 192) return 1;
+    const int nslab = K >> 5;
+    long long s = (256 + t0 + t1 - 1) / (t0 + t1);
+    const long long smax = nslab / 16;                 // >= 16 slabs (512 k) per split
+    if (s > smax) s = smax;
+    if (s > 16) s = 16;
+    if (s < 2) return 0;
+    const long long sps = (nslab + s - 1) / s;
+    s = (nslab + sps - 1) / sps;                       // no empty split
+    return s < 2 ? 0 : (int)s;
+  }
+  // the joint grid needs fewer 256-workgroup rounds (DPOT-L: 288 + 288 tiles = 2 + 2 rounds apart, 3 together)
   const long long r0 = (t0 + 255) / 256, r1 = (t1 + 255) / 256, r01 = (t0 + t1 + 255) / 256;
   return t0 >= 192 && t1 >= 192 && r0 + r1 > r01 ? 1 : 0;
 }
+extern "C" int dpot_gemm_bf16p_pair_wanted(int M0, int N0, int M1, int N1, int K) {
+  return dpot_gemm_bf16p_pair_splitk(M0, N0, M1, N1, K) > 0 ? 1 : 0;
+}
 
 extern "C" int dpot_gemm_bf16p_pair(const void* A0, const void* W0, float* C0, int ldc0, int M0, int N0, const void* A1,
-                                    const void* W1, float* C1, int ldc1, int M1, int N1, int K, dpot_stream_t stream) {
+                                    const void* W1, float* C1, int ldc1, int M1, int N1, int K, int splitk,
+                                    float* workspace, dpot_stream_t stream) {
   DPOT_REQUIRE(A0 && W0 && C0 && A1 && W1 && C1, "gemm_bf16p_pair: null operand");
   DPOT_REQUIRE(dpot_gemm_bf16p_supported(M0, N0, K) && dpot_gemm_bf16p_supported(M1, N1, K),
                "gemm_bf16p_pair: unsupported shape (N %% 256, K %% 32)");
   DPOT_REQUIRE(ldc0 >= N0 && ldc1 >= N1 && ldc0 % 4 == 0 && ldc1 % 4 == 0 && aligned16(A0) && aligned16(W0) && aligned16(C0) &&
-                   aligned16(A1) && aligned16(W1) && aligned16(C1),
+                   aligned16(A1) && aligned16(W1) && aligned16(C1) && aligned16(workspace),
                "gemm_bf16p_pair: bad leading dimension / alignment");
+  const int nslab = K >> 5;
+  int splits = splitk > 1 ? splitk : 1;
+  DPOT_REQUIRE(splits == 1 || workspace != nullptr, "gemm_bf16p_pair: split-K needs a workspace of splitk*(M0*N0+M1*N1) floats");
+  DPOT_REQUIRE(splits <= nslab && splits <= 65535, "gemm_bf16p_pair: too many splits");
+  const int sps = (nslab + splits - 1) / splits;
+  DPOT_REQUIRE((nslab + sps - 1) / sps == splits, "gemm_bf16p_pair: splitk would leave an empty split (use dpot_gemm_bf16p_pair_splitk)");
   Bf16pPair pp;
   const void* As[2] = {A0, A1};
   const void* Ws[2] = {W0, W1};
   float* Cs[2] = {C0, C1};
   const int Ms[2] = {M0, M1}, Ns[2] = {N0, N1}, lds_[2] = {ldc0, ldc1};
+  float* wss[2] = {workspace, workspace ? workspace + (size_t)splits * M0 * N0 : nullptr};
   for (int i = 0; i < 2; ++i) {
     Bf16pArgs& p = pp.a[i];
     p.A = reinterpret_cast<const unsigned short*>(As[i]);
@@ -801,14 +825,24 @@ extern "C" int dpot_gemm_bf16p_pair(const void* A0, const void* W0, float* C0, i
     e.res = nullptr; e.ldres = 0; e.res_div = 0; e.res_mod = 0; e.sRes = 0;
     e.act = 0; e.mode = DPOT_EPI_LINEAR; e.accumulate = 0;
     e.M = Ms[i]; e.N = Ns[i];
-    p.splits = 1;
-    p.slabs_per_split = K >> 5;
-    p.ws = nullptr;
+    p.splits = splits;
+    p.slabs_per_split = sps;
+    p.ws = wss[i];
     p.out_rows = nullptr; p.out_trans = nullptr; p.cs_part = nullptr;
   }
   pp.n0 = pp.a[0].tilesM * pp.a[0].tilesN;
   const unsigned grid = (unsigned)(pp.n0 + pp.a[1].tilesM * pp.a[1].tilesN);
-  hipLaunchKernelGGL(gemm_bf16p_pair_kernel, dim3(grid), dim3(64 * (8 + PB_NLOAD)), 0, as_stream(stream), pp);
-  return check_launch("gemm_bf16p_pair_kernel");
+  hipLaunchKernelGGL(gemm_bf16p_pair_kernel, dim3(grid, splits), dim3(64 * (8 + PB_NLOAD)), 0, as_stream(stream), pp);
+  int rc = check_launch("gemm_bf16p_pair_kernel");
+  if (rc != DPOT_OK || splits == 1) return rc;
+  for (int i = 0; i < 2; ++i) {
+    const long long total = (long long)Ms[i] * Ns[i];
+    int blocks = (int)((total + 255) / 256);
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, as_stream(stream), (const float*)wss[i], splits, 1,
+                       pp.a[i].e, (float*)nullptr, 0ll, 0);
+    rc = check_launch("splitk_reduce_kernel");
+    if (rc) return rc;
+  }
+  return DPOT_OK;
 }
-

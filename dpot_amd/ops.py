@@ -264,12 +264,16 @@ def gemm_bf16p_pair_wanted(M0: int, N0: int, M1: int, N1: int, K: int) -> bool:
 
 
 def gemm_bf16p_pair(A0: Tensor, W0: Tensor, M0: int, N0: int, A1: Tensor, W1: Tensor, M1: int, N1: int, K: int,
-                    out0: Optional[Tensor] = None, out1: Optional[Tensor] = None) -> Tuple[Tensor, Tensor]:
+                    out0: Optional[Tensor] = None, out1: Optional[Tensor] = None,
+                    splitk: Optional[int] = None) -> Tuple[Tensor, Tensor]:
     """(A0 W0^T [M0,N0], A1 W1^T [M1,N1]) on the bf16 matrix cores in ONE launch (packed plain-bf16 operands, common K,
-    no split-K): the two channel-MLP weight gradients of a block"""
+    one common split-K factor - None: the library's choice): the two channel-MLP weight gradients of a block"""
+    lib = _lib.load()
     C0, C1 = _out(out0, (M0, N0), A0.device), _out(out1, (M1, N1), A1.device)
-    check(_lib.load().dpot_gemm_bf16p_pair(A0.data_ptr(), W0.data_ptr(), C0.data_ptr(), N0, M0, N0, A1.data_ptr(),
-                                           W1.data_ptr(), C1.data_ptr(), N1, M1, N1, K, _stream()), "gemm_bf16p_pair")
+    sk = max(1, lib.dpot_gemm_bf16p_pair_splitk(M0, N0, M1, N1, K)) if splitk is None else splitk
+    ws = torch.empty(sk * (M0 * N0 + M1 * N1), dtype=torch.float32, device=A0.device) if sk > 1 else None
+    check(lib.dpot_gemm_bf16p_pair(A0.data_ptr(), W0.data_ptr(), C0.data_ptr(), N0, M0, N0, A1.data_ptr(),
+                                   W1.data_ptr(), C1.data_ptr(), N1, M1, N1, K, sk, _p(ws), _stream()), "gemm_bf16p_pair")
     return C0, C1
 
 

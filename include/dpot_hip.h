@@ -450,8 +450,12 @@ int dpot_gemm_bf16p(const void* Apacked, const void* Wpacked, const float* bias,
  * the fc1 / fc2 weight gradients of a block, which alone have too few tiles for 256 CUs and would each go through
  * split-K partials + a reduce launch.  _wanted: 1 when each alone would be split and together they fill the chip. */
 int dpot_gemm_bf16p_pair_wanted(int M0, int N0, int M1, int N1, int K);
+/* common split-K factor of the pair launch: 0 = do not pair, 1 = no split, s > 1 = s splits (workspace of
+ * s * (M0*N0 + M1*N1) floats; the partial sums are reduced in a fixed order by two further launches) */
+int dpot_gemm_bf16p_pair_splitk(int M0, int N0, int M1, int N1, int K);
 int dpot_gemm_bf16p_pair(const void* A0, const void* W0, float* C0, int ldc0, int M0, int N0, const void* A1,
-                         const void* W1, float* C1, int ldc1, int M1, int N1, int K, dpot_stream_t stream);
+                         const void* W1, float* C1, int ldc1, int M1, int N1, int K, int splitk, float* workspace,
+                         dpot_stream_t stream);
 /* out_rows / out_trans / colsum_part (all optional, planes == 1, splitk <= 1, M % 32 == 0): the epilogue also emits the
  * 1-plane packs of the FINAL output (row form [M, N]; transposed form = rows N, k M) and partial column sums
  * [M/32, N] - the next GEMMs of a chain then need no pack pass over this output; C may be NULL in that case. */

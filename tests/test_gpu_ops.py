@@ -1031,14 +1031,18 @@ def test_bf16_panel_pair_launch_matches_single(ops):
     dy0 = torch.randn(T, n0, device="cuda"); x0 = torch.randn(T, k0, device="cuda")
     dy1 = torch.randn(T, n1, device="cuda"); x1 = torch.randn(T, k1, device="cuda")
     packs = [ops.bf16_pack_rows(t, trans=True) for t in (dy0, x0, dy1, x1)]
-    C0, C1 = ops.gemm_bf16p_pair(packs[0], packs[1], n0, k0, packs[2], packs[3], n1, k1, T)
+    C0, C1 = ops.gemm_bf16p_pair(packs[0], packs[1], n0, k0, packs[2], packs[3], n1, k1, T, splitk=1)
     r = lambda t: t.bfloat16().double()
     assert_close(C0, r(dy0).t() @ r(x0), "pair product 0")
     assert_close(C1, r(dy1).t() @ r(x1), "pair product 1")
     S0, _ = ops.gemm_bf16p(packs[0], packs[1], n0, k0, T, splitk=1)
     S1, _ = ops.gemm_bf16p(packs[2], packs[3], n1, k1, T, splitk=1)
     assert torch.equal(C0, S0) and torch.equal(C1, S1)
-    assert ops.gemm_bf16p_pair_wanted(1024, 4096, 4096, 1024, 8192) and not ops.gemm_bf16p_pair_wanted(256, 512, 512, 256, 1024)
+    assert ops.gemm_bf16p_pair_wanted(1024, 4096, 4096, 1024, 8192)
+    # with a common split-K factor (few tiles, long K: DPOT-S): partial sums + fixed-order reduction
+    Z0, Z1 = ops.gemm_bf16p_pair(packs[0], packs[1], n0, k0, packs[2], packs[3], n1, k1, T, splitk=2)
+    assert_close(Z0, r(dy0).t() @ r(x0), "split pair product 0")
+    assert_close(Z1, r(dy1).t() @ r(x1), "split pair product 1")
 
 
 @pytest.mark.gpu
