@@ -107,6 +107,13 @@ __device__ __forceinline__ float colw_f(int colw, int ky, int w) {
   return 2.f;
 }
 
+// Channel chunk of workgroup x: consecutive workgroups go to different XCDs (8 L2 slices); with CC = 16 channels a
+// workgroup touches 64-byte halves of the 128-byte lines of a token, so the chunk sharing a line must sit on the SAME
+// XCD or every L2 fetches the line for half its bytes.  XCD k gets the contiguous chunks [k*n/8, (k+1)*n/8).
+__device__ __forceinline__ int xcd_chunk(int x, int n) {
+  return (n & 7) == 0 ? (x & 7) * (n >> 3) + (x >> 3) : x;
+}
+
 // x[B,H*W,E] -> spec[B,mx,my,nb,2,bs]
 template <int H, int W, int CC>
 __global__ __launch_bounds__(256) void rfft2_fast_kernel(const float* __restrict__ x, float* __restrict__ spec, int E,
@@ -114,7 +121,7 @@ __global__ __launch_bounds__(256) void rfft2_fast_kernel(const float* __restrict
   constexpr int WF = W / 2 + 1;
   extern __shared__ __attribute__((aligned(16))) float sm[];
   float* Z = sm;                                            // [WF][H][2][CC]
-  const int b = blockIdx.y, c0 = blockIdx.x * CC;
+  const int b = blockIdx.y, c0 = xcd_chunk(blockIdx.x, gridDim.x) * CC;
   const int tid = threadIdx.x;
   const int bs = E / nb;
   const float* xb = x + (long long)b * H * W * E + c0;
@@ -170,7 +177,7 @@ __global__ __launch_bounds__(256) void irfft2_fast_kernel(const float* __restric
   constexpr int WF = W / 2 + 1;
   extern __shared__ __attribute__((aligned(16))) float sm[];
   float* U = sm;                                            // [H][WF][2][CC]
-  const int b = blockIdx.y, c0 = blockIdx.x * CC;
+  const int b = blockIdx.y, c0 = xcd_chunk(blockIdx.x, gridDim.x) * CC;
   const int tid = threadIdx.x;
   const int bs = E / nb;
 
