@@ -151,4 +151,24 @@ __device__ __forceinline__ double block_sum_d(double v, double* sh) {
   return r;
 }
 
+// two block-wide sums in one pass (one pair of barriers); `sh` needs >= 32 doubles
+__device__ __forceinline__ void block_sum2_d(double& a, double& b, double* sh) {
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+  a = wave_sum_d(a);
+  b = wave_sum_d(b);
+  __syncthreads();
+  if (lane == 0) {
+    sh[wid] = a;
+    sh[16 + wid] = b;
+  }
+  __syncthreads();
+  double ra = 0.0, rb = 0.0;
+  for (int i = 0; i < nw; ++i) {
+    ra += sh[i];
+    rb += sh[16 + i];
+  }
+  a = ra;
+  b = rb;
+}
+
 }  // namespace dpot

@@ -56,7 +56,7 @@ __global__ __launch_bounds__(GN_THREADS) void groupnorm_fwd_kernel(const float* 
                                                                    const float* __restrict__ beta, float* __restrict__ y,
                                                                    float* __restrict__ mean, float* __restrict__ rstd,
                                                                    int T, int E, int G, float eps) {
-  __shared__ double shd[16];
+  __shared__ double shd[32];
   const int g = blockIdx.x, b = blockIdx.y;
   const int cg = E / G, cgv = cg / VW;
   const GnLayout L = gn_layout(cgv);
@@ -117,7 +117,7 @@ __global__ __launch_bounds__(GN_THREADS) void groupnorm_bwd_kernel(const float* 
                                                                    const float* __restrict__ add, float* __restrict__ dx,
                                                                    float* __restrict__ part, int B, int T, int E, int G) {
   __shared__ float red[2][GN_THREADS][VW];
-  __shared__ double shd[16];
+  __shared__ double shd[32];
   const int g = blockIdx.x, b = blockIdx.y;
   const int cg = E / G, cgv = cg / VW;
   const GnLayout L = gn_layout(cgv);
@@ -170,8 +170,9 @@ __global__ __launch_bounds__(GN_THREADS) void groupnorm_bwd_kernel(const float* 
       s2 += (double)ga * sg;
     }
   }
-  const float m1 = (float)(block_sum_d(s1, shd) / n);
-  const float m2 = (float)(block_sum_d(s2, shd) / n);
+  block_sum2_d(s1, s2, shd);
+  const float m1 = (float)(s1 / n);
+  const float m2 = (float)(s2 / n);
   float* dxs = dx + off;
   const float* adds = add ? add + off : nullptr;
   for (int j = tj; j < cgv; j += L.TJ) {
@@ -243,7 +244,7 @@ __global__ __launch_bounds__(GN_THREADS) void groupnorm_fwd_cached_kernel(const 
                                                                           float* __restrict__ y, float* __restrict__ mean,
                                                                           float* __restrict__ rstd, int T, int E, int G,
                                                                           float eps) {
-  __shared__ double shd[16];
+  __shared__ double shd[32];
   const int g = blockIdx.x, b = blockIdx.y;
   const int cg = E / G, TJ = cg / 4, TT = GN_THREADS / TJ;
   const int tj = threadIdx.x % TJ, tt = threadIdx.x / TJ;
@@ -292,7 +293,7 @@ __global__ __launch_bounds__(GN_THREADS) void groupnorm_bwd_cached_kernel(
     const float* __restrict__ rstd, const float* __restrict__ gamma, const float* __restrict__ add,
     float* __restrict__ dx, float* __restrict__ part, int B, int T, int E, int G) {
   __shared__ float red[2][GN_THREADS][4];
-  __shared__ double shd[16];
+  __shared__ double shd[32];
   const int g = blockIdx.x, b = blockIdx.y;
   const int cg = E / G, TJ = cg / 4, TT = GN_THREADS / TJ;
   const int tj = threadIdx.x % TJ, tt = threadIdx.x / TJ;
@@ -335,8 +336,9 @@ __global__ __launch_bounds__(GN_THREADS) void groupnorm_bwd_cached_kernel(
     s1 = (double)ga * sb;
     s2 = (double)ga * sg;
   }
-  const float m1 = (float)(block_sum_d(s1, shd) / n);
-  const float m2 = (float)(block_sum_d(s2, shd) / n);
+  block_sum2_d(s1, s2, shd);
+  const float m1 = (float)(s1 / n);
+  const float m2 = (float)(s2 / n);
   const float4 ga = *reinterpret_cast<const float4*>(gamma + g * cg + tj * 4);
 #pragma unroll
   for (int i = 0; i < ITEMS; ++i) {
@@ -380,7 +382,7 @@ struct GnChunks {
 // forward, pass A: per-chunk (mean, M2 = sum (x - mean)^2); two sweeps over the chunk (the second hits L2)
 __global__ __launch_bounds__(GN_THREADS) void gn_chunk_stats_kernel(const float* __restrict__ x, float* __restrict__ ws,
                                                                     int T, int E, int G, GnChunks c) {
-  __shared__ double shd[16];
+  __shared__ double shd[32];
   const int ch = blockIdx.x, g = blockIdx.y, b = blockIdx.z;
   const int cg = E / G, q4 = cg >> 2;
   const int t0 = ch * c.TC;
@@ -505,7 +507,7 @@ __global__ __launch_bounds__(GN_THREADS) void gn_chunk_bwd_apply_kernel(
     const float* __restrict__ rstd, const float* __restrict__ gamma, const float* __restrict__ add,
     float* __restrict__ dx, float* __restrict__ part, const float* __restrict__ ws, int B, int T, int E, int G,
     GnChunks c) {
-  __shared__ double shd[16];
+  __shared__ double shd[32];
   const int ch = blockIdx.x, g = blockIdx.y, b = blockIdx.z;
   const int cg = E / G, q4 = cg >> 2;
   const float mu = mean[b * G + g], rs = rstd[b * G + g];
@@ -527,8 +529,9 @@ __global__ __launch_bounds__(GN_THREADS) void gn_chunk_bwd_apply_kernel(
     s2 = (double)(gm * tdx);
   }
   const double n = (double)T * cg;
-  const float m1 = (float)(block_sum_d(s1, shd) / n);
-  const float m2 = (float)(block_sum_d(s2, shd) / n);
+  block_sum2_d(s1, s2, shd);
+  const float m1 = (float)(s1 / n);
+  const float m2 = (float)(s2 / n);
   const int t0 = ch * c.TC;
   const int nt = T - t0 < c.TC ? T - t0 : c.TC;
   const unsigned nq = (unsigned)nt * (unsigned)q4;
