@@ -269,6 +269,9 @@ static inline int try_rfft2_fast(const float* x, float* spec, int B, int h, int 
     if (forced != 32 && E % 64 == 0 && ((long long)B * (E / 64) >= 512 || forced == 64)) { *rc = launch_rfft2_fast<16, 16, 64>(x, spec, B, E, nb, mx, my, colw, scale, s); return 1; }
     if (E % 32 == 0) { *rc = launch_rfft2_fast<16, 16, 32>(x, spec, B, E, nb, mx, my, colw, scale, s); return 1; }
   } else if (h == 32 && w == 32) {
+    // 32-channel chunks (full 128-byte lines per token, 139 KiB of LDS: one workgroup per CU) when that still gives
+    // >= 128 workgroups: 18.0 against 22.7 us at DPOT-L B = 4 (the inverse is FASTER with 16: 29.8 against 42.5 us)
+    if (forced != 16 && E % 32 == 0 && (long long)B * (E / 32) >= 128) { *rc = launch_rfft2_fast<32, 32, 32>(x, spec, B, E, nb, mx, my, colw, scale, s); return 1; }
     if (E % 16 == 0) { *rc = launch_rfft2_fast<32, 32, 16>(x, spec, B, E, nb, mx, my, colw, scale, s); return 1; }
   }
   return 0;
