@@ -137,7 +137,7 @@ def test_linear_bwd_weight_auto_splitk_large_k(ops):
 # ------------------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("B,h,w,E,nb,modes", [(2, 16, 16, 64, 4, 32), (3, 16, 16, 512, 4, 32), (2, 16, 16, 64, 4, 5),
                                               (2, 32, 32, 96, 2, 64), (2, 4, 4, 32, 4, 32), (1, 14, 14, 24, 3, 6),
-                                              (2, 5, 7, 8, 1, 32)])
+                                              (2, 5, 7, 8, 1, 32), (4, 32, 32, 1536, 16, 64), (8, 32, 32, 512, 4, 64)])
 def test_rfft2_irfft2_vs_torch(ops, B, h, w, E, nb, modes):
     bs = E // nb
     mx, my = min(modes, h), min(modes, w // 2 + 1)
