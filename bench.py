@@ -9,6 +9,12 @@ A step = forward + masked relative-L2 loss + backward (+ RCCL gradient all-reduc
 T_ar = 1, on BASELINE.json configs[1]: DPOT-Tiny (embed 512, depth 4, 4 blocks, modes 32, patch 8), per-GPU batch 32,
 fp32, synthetic N(0,1) fields already resident in HBM.  Weak scaling: every rank processes its own batch of 32.
 Rank 0 prints ONE JSON line (metric/value/unit + `roofline` for the AFNO mixer kernel + `cpu_baseline`).
+
+`--gpus N` without a launcher (WORLD_SIZE unset) re-executes itself under torch.distributed.run on 127.0.0.1.
+`--config {T,S,M,L,L20}` selects the other BASELINE.json configs (default T = configs[1], the headline):
+S = configs[2] (DPOT-Small, bf16 channel-MLP), M = configs[3] (DPOT-Medium, 32 per GPU = 256 global on 8 GPUs, bf16
+channel-MLP), L = DPOT-Large at 256^2 (T_ar = 1), L20 = configs[4] (DPOT-Large, 20-step auto-regressive rollout with
+activation recomputation; value = sample-steps/s).
 """
 from __future__ import annotations
 
@@ -27,6 +33,17 @@ import torch.distributed as dist
 
 TINY = dict(img_size=128, patch_size=8, in_channels=4, out_channels=4, in_timesteps=10, out_timesteps=1, n_blocks=4,
             embed_dim=512, out_layer_dim=32, depth=4, modes=32, mlp_ratio=1, n_cls=12)
+SMALL = dict(TINY, embed_dim=1024, depth=6, n_blocks=8)
+MEDIUM = dict(TINY, embed_dim=1024, depth=12, n_blocks=8, mlp_ratio=4)
+LARGE = dict(TINY, img_size=256, embed_dim=1536, depth=24, n_blocks=16, mlp_ratio=4, out_layer_dim=128, modes=64)
+# name, model kwargs, per-GPU batch, T_ar, channel-MLP precision, activation recomputation, BASELINE.json entry
+CONFIGS = {
+    "T": ("DPOT-Tiny", TINY, 32, 1, None, False, "configs[1]"),
+    "S": ("DPOT-Small", SMALL, 32, 1, "bf16", False, "configs[2]"),
+    "M": ("DPOT-Medium", MEDIUM, 32, 1, "bf16", False, "configs[3]"),
+    "L": ("DPOT-Large", LARGE, 16, 1, "bf16", False, "configs[4] model, one rollout step"),
+    "L20": ("DPOT-Large", LARGE, 4, 20, "bf16", True, "configs[4]"),
+}
 FP32_MFMA_PEAK_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
 SUSTAINED_FP32_MFMA_TFLOPS = 132.8   # register-only MFMA loop, random operands (profiles/r02_mfma_f32_peak.txt)
 HBM_PEAK_GBS = 8000.0              # MI355X_MICROARCH.md: HBM3E spec
@@ -41,7 +58,11 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--batch", type=int, default=32, help="per-GPU batch (BASELINE configs[1]: 32)")
+    ap.add_argument("--config", default="T", choices=tuple(CONFIGS),
+                    help="T (default, the headline: BASELINE configs[1]) | S | M | L | L20 - see the module docstring")
+    ap.add_argument("--batch", type=int, default=None, help="per-GPU batch (default: the config's; T/S/M 32, L 16, L20 4)")
+    ap.add_argument("--mlp-precision", default=None, choices=("f32", "bf16x6", "auto", "bf16"),
+                    help="channel-MLP GEMM precision (default: the config's - f32 for T, bf16 for S/M/L/L20)")
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of hipGraph replay")
     ap.add_argument("--overlap", action="store_true",
                     help="N>1: EAGER step with the bucketed all-reduce driven by the backward's gradient-ready "
@@ -64,6 +85,42 @@ def parse():
 
 
 # ------------------------------------------------------------------------------------------------------
+def step_flops_per_sample(kw: dict, B: int, three_product: bool = True):
+    """(algorithmic, executed) FLOP of ONE train step (fwd + bwd) per sample.  Algorithmic = 3 x the forward of the model
+    as the reference computes it (SURVEY 8d accounting: 3.79 GFLOP forward at DPOT-Tiny).  Executed = what the kernels of
+    this build run: the 1x1 conv of the patch embed folded into the time aggregation (K = T*hid_p instead of T*E), the
+    three unit-grid channels folded into a bias table, Gauss's three-product complex multiply in the mixer data path
+    (forward and data gradient; the weight gradients run four products), no input gradient for the patch conv, and the
+    weight-only products (embed fold) once per step, i.e. divided by the batch."""
+    E, depth, nb, P = kw["embed_dim"], kw["depth"], kw["n_blocks"], kw["patch_size"]
+    T, C, Co = kw["in_timesteps"], kw["in_channels"], kw["out_channels"] * kw["out_timesteps"]
+    h = kw["img_size"] // P
+    tok, wf = h * h, h // 2 + 1
+    mx, my = min(kw["modes"], h), min(kw["modes"], wf)
+    bs, mh, old = E // nb, int(E * kw["mlp_ratio"]), kw["out_layer_dim"]
+    hid = kw["out_channels"] * P + 3
+    hidp = (hid + 3) // 4 * 4
+    npx = tok * P * P
+    # --- algorithmic forward (reference formulation)
+    a_patch = 2.0 * tok * T * ((C + 3) * P * P * hid + hid * E)
+    a_tagg = 2.0 * tok * T * E * E
+    a_mix = depth * mx * my * nb * 2 * 4 * 2.0 * bs * bs
+    a_fft = depth * 2 * 5.0 * tok * E * max(1.0, __import__("math").log2(tok)) / 2
+    a_mlp = depth * 2 * 2.0 * tok * E * mh
+    a_head = 2.0 * tok * E * P * P * old + 2.0 * npx * (old * old + old * Co)
+    alg = 3.0 * (a_patch + a_tagg + a_mix + a_fft + a_mlp + a_head)
+    # --- executed (this build), forward / backward listed separately
+    e_patch_f = 2.0 * tok * T * (C * P * P) * hidp                      # implicit GEMM over the data channels only
+    e_fold_f = 2.0 * tok * (T * hidp) * E
+    e_mix_f = depth * mx * my * nb * 2 * (3 if three_product else 4) * 2.0 * bs * bs
+    e_fwd = e_patch_f + e_fold_f + e_mix_f + a_fft + a_mlp + a_head
+    e_bwd = (e_patch_f                                                # patch conv: weight gradient only
+             + 2 * e_fold_f + e_mix_f + a_mix                         # mixer: 3-product data path + 4-product wgrad
+             + a_fft + 2 * a_mlp + 2 * a_head)
+    w_only = 3.0 * 2.0 * T * hidp * E * E + 3.0 * 2.0 * tok * E * E  # V = w2^T ws_t (T products) and c = posb wsum, + bwd
+    return alg, e_fwd + e_bwd + w_only / B
+
+
 def mixer_roofline(model, B: int):
     """Time the AFNO mixer kernel - both layers of the block-diagonal complex MLP, one launch of
     dpot::afno_mlp2_kernel (csrc/afno_mlp.hip) - with HIP events on the launch stream, in the form the train step runs
@@ -299,14 +356,34 @@ def cpu_baseline(seconds: float):
 
 
 # ------------------------------------------------------------------------------------------------------
+def _self_launch(n: int) -> int:
+    """`python bench.py --gpus N` with no launcher around it: re-execute under torch.distributed.run, one rank per GPU,
+    rendezvous on 127.0.0.1 (the container hostname may not resolve)"""
+    import socket
+    import subprocess
+    sk = socket.socket()
+    sk.bind(("127.0.0.1", 0))
+    port = sk.getsockname()[1]
+    sk.close()
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr",
+           "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    log("[bench] no launcher detected (WORLD_SIZE unset): " + " ".join(cmd))
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(_self_launch(args.gpus))
     rank = int(os.environ.get("RANK", 0))
     local_rank = int(os.environ.get("LOCAL_RANK", 0))
     world = int(os.environ.get("WORLD_SIZE", 1))
     if args.gpus != world:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run with --nproc-per-node {args.gpus}")
+        log(f"[bench] --gpus {args.gpus} but WORLD_SIZE={world}: running with the launcher's world size")
+    cname, ckw, cB, T_ar, cmlp, recompute, cbase = CONFIGS[args.config]
+    headline = args.config == "T"
     # DPOT_BENCH_DEBUG_GLOO=1: functional dry-run of the N>1 code path on a 1-GPU box (all ranks share cuda:0, gloo
     # collectives) - for testing only, never a performance number
     debug_gloo = os.environ.get("DPOT_BENCH_DEBUG_GLOO") == "1"
@@ -328,8 +405,13 @@ def main():
     _lib.load()
     ops.set_gemm_precision(args.gemm_precision)
 
+    mlp_prec = args.mlp_precision if args.mlp_precision is not None else cmlp
+    if mlp_prec is not None:
+        ops.set_mlp_precision(mlp_prec)
+
     torch.manual_seed(0)                                       # identical random-init weights on every rank
-    model = DPOTNet(**TINY).cuda()
+    model = DPOTNet(**ckw).cuda()
+    model.recompute_blocks = recompute
     fp = FlatParams(model)
     # DDP semantics for N>1: cls_head takes part (zero gradients -> weight decay only), grads averaged over ranks
     opt = FusedAdam(fp, lr=1e-3, betas=(0.9, 0.9), weight_decay=1e-6, max_norm=10000.0, update_tail=world > 1)
@@ -338,11 +420,12 @@ def main():
         reducer.broadcast_parameters(0)
     grad_scale = 1.0 / world
 
-    B = args.batch
+    B = args.batch if args.batch is not None else cB
+    res = ckw["img_size"]
     g = torch.Generator().manual_seed(1234 + rank)
-    xx = torch.randn(B, 128, 128, 10, 4, generator=g).cuda()
-    yy = torch.randn(B, 128, 128, 1, 4, generator=g).cuda()
-    msk = torch.ones(B, 128, 128, 1, 4, device="cuda")
+    xx = torch.randn(B, res, res, 10, 4, generator=g).cuda()
+    yy = torch.randn(B, res, res, T_ar, 4, generator=g).cuda()
+    msk = torch.ones(B, res, res, 1, 4, device="cuda")
     total_steps = args.warmup + args.steps + 8
     # N>1: accelerate steps the scheduler `world` times per optimiser step over a schedule sized by the unsharded
     # loader (train_temporal_parallel.py:150,185) - dp.dp_one_cycle_lr reproduces that rule
@@ -359,9 +442,11 @@ def main():
             elif world > 1:
                 # default N>1 path: hipGraph segments cut at the gradient-bucket boundaries; bucket k is all-reduced
                 # on the side stream while the compute stream replays the backward of the earlier stages
-                graphed = SegmentedTrainStep(model, opt, reducer, xx, yy, msk, noise_scale=args.noise_scale, warmup=2)
+                graphed = SegmentedTrainStep(model, opt, reducer, xx, yy, msk, noise_scale=args.noise_scale,
+                                             warmup=1 if T_ar > 1 else 2)
             else:
-                graphed = GraphedTrainStep(model, opt, xx, yy, msk, noise_scale=args.noise_scale, warmup=2)
+                graphed = GraphedTrainStep(model, opt, xx, yy, msk, noise_scale=args.noise_scale,
+                                           warmup=1 if T_ar > 1 else 2)
             mode = "hipgraph"
         except Exception as e:                                 # pragma: no cover - depends on the box
             log(f"[bench] hipGraph capture failed ({type(e).__name__}: {e}); falling back to eager launches")
@@ -404,19 +489,29 @@ def main():
 
     if rank == 0:
         ms = elapsed / args.steps * 1e3
-        value = world * B * args.steps / elapsed
+        value = world * B * T_ar * args.steps / elapsed          # T_ar > 1: sample-steps/s
         out = {
-            "metric": "PDE samples/sec (128^2 x10 -> 1 rollout step), DPOT-Tiny train step",
-            "value": round(value, 2), "unit": "samples/s", "n_gpus": world, "steps": args.steps,
+            "metric": f"PDE samples/sec ({res}^2 x10 -> 1 rollout step), {cname} train step",
+            "value": round(value, 2), "unit": "samples/s" if T_ar == 1 else "sample-steps/s", "n_gpus": world,
+            "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(ms, 4), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "DPOT-Tiny (embed 512, depth 4, n_blocks 4, modes 32, patch 8) on synthetic "
-                                   "ns2d-shaped 128x128x10x4 fields, T_ar=1: fwd + rel-L2 loss + bwd + clip + Adam",
+            "vs_baseline": None, "dtype": "f32" if mlp_prec in (None, "f32") else f"f32 (channel-MLP GEMM operands {mlp_prec})",
+            "data": "synthetic",
+            "config": {"workload": f"{cname} (embed {ckw['embed_dim']}, depth {ckw['depth']}, n_blocks {ckw['n_blocks']}, "
+                                   f"modes {ckw['modes']}, patch 8, mlp_ratio {ckw['mlp_ratio']}) on synthetic ns2d-shaped "
+                                   f"{res}x{res}x10x4 fields, T_ar={T_ar}: fwd + rel-L2 loss + bwd + clip + Adam",
+                       "baseline_config": cbase,
                        "per_gpu_batch": B, "global_batch": B * world, "parallelism": f"dp{world}",
                        "launch": mode, "noise_scale": args.noise_scale, "final_loss": round(final_loss, 5),
-                       "gemm_precision": args.gemm_precision},
+                       "gemm_precision": args.gemm_precision, "mlp_precision": mlp_prec or args.gemm_precision,
+                       "activation_recomputation": recompute,
+                       "peak_mem_GB": round(torch.cuda.max_memory_allocated() / 2 ** 30, 2)},
         }
         if world > 1:
+            out["config"]["collectives"] = {
+                "backend": dist.get_backend(), "world_size": dist.get_world_size(),
+                "library": ("gloo (DPOT_BENCH_DEBUG_GLOO=1: functional dry run, all ranks on cuda:0 - NOT a performance "
+                            "number)") if debug_gloo else f"RCCL {'.'.join(map(str, torch.cuda.nccl.version()))} over xGMI"}
             out["config"]["dp"] = ("eager, hook-driven bucket all-reduce" if graphed is None else
                                    "one graph + all-reduce after backward" if args.no_overlap else
                                    f"segmented hipGraph chain ({len(graphed.graphs)} segments), bucket all-reduce on a "
@@ -432,14 +527,24 @@ def main():
             es = time.perf_counter() - ts
             out["sustained"] = {"steps": n_sus, "seconds": round(es, 3), "ms_per_step": round(es / n_sus * 1e3, 4),
                                 "value": round(B * n_sus / es, 2)}
-        # fraction of the fp32 MFMA roof for the whole step: 3 x 3.79 GFLOP per sample
-        out["model_flops_frac"] = round(3 * 3.79e9 * value / world / (FP32_MFMA_PEAK_TFLOPS * 1e12), 4)
+        # whole-step FLOP rates per GPU: ALGORITHMIC = 3 x the forward FLOPs of the model as the reference computes it
+        # (3 x 3.79 GFLOP per sample at DPOT-Tiny); EXECUTED = what this build's kernels actually run after
+        # the embed fold (K 5120 -> 360), the grid-channel bias table and the three-product mixer (step_flops_per_sample)
+        alg, exe = step_flops_per_sample(ckw, B)
+        per_gpu = value / world
+        out["model_flops_frac"] = round(alg * per_gpu / (FP32_MFMA_PEAK_TFLOPS * 1e12), 4)
+        out["executed_flops_frac"] = round(exe * per_gpu / (FP32_MFMA_PEAK_TFLOPS * 1e12), 4)
+        out["flops_note"] = (f"per sample-step: algorithmic {alg / 1e9:.2f} GFLOP (model_flops_frac, SURVEY 8d accounting), "
+                             f"executed {exe / 1e9:.2f} GFLOP (executed_flops_frac: what the chip's matrix pipes really do); both "
+                             f"priced against the {FP32_MFMA_PEAK_TFLOPS} TFLOP/s fp32 MFMA peak"
+                             + ("" if mlp_prec in (None, "f32") else " although the channel-MLP GEMMs of this config run on "
+                                "the bf16 matrix cores (2.5 PF) - fractions above 1 are possible"))
         try:
             out["roofline"] = mixer_roofline(model, B)
         except Exception as e:                                 # pragma: no cover
             log(f"[bench] roofline probe failed: {e}")
             out["roofline"] = None
-        if world == 1 and graphed is not None and args.gemm_precision == "f32" and not args.no_alt:
+        if headline and world == 1 and graphed is not None and args.gemm_precision == "f32" and not args.no_alt:
             # not the headline: the same step with the large GEMMs on the bf16x6 kernel (fp32 emulated by operand
             # splitting on the bf16 matrix cores, same accuracy class - DESIGN.md "bf16x6"); a fresh graph is captured
             # because the kernel choice is baked in at capture time
@@ -462,7 +567,7 @@ def main():
                 log(f"[bench] gemm_auto timing failed: {e}")
             finally:
                 ops.set_gemm_precision(args.gemm_precision)
-        if world == 1:
+        if world == 1 and T_ar == 1:
             # forward-only (inference) rate of the same batch, SURVEY 8(d): no_grad forward, hipGraph replay
             try:
                 with torch.no_grad():
@@ -485,7 +590,7 @@ def main():
                                     "what": "DPOTNet forward only (no_grad), batch %d, hipGraph replay" % B}
             except Exception as e:                             # pragma: no cover
                 log(f"[bench] inference timing failed: {e}")
-        if world == 1 and graphed is not None and not args.no_pipeline:
+        if headline and world == 1 and graphed is not None and not args.no_pipeline:
             # input-pipeline-inclusive rate (never `value`): raw 64x64 single-channel trajectories in host memory (the
             # ns2d_fno_1e-5 shape) -> pinned staging -> ONE H2D copy per batch on a copy stream -> device-side bilinear
             # resize to 128^2 + channel pad with ones + temporal window (csrc/data.hip) -> double-buffered batch slots;
@@ -522,7 +627,7 @@ def main():
                             "batching inclusive, single host thread"}
             except Exception as e:                             # pragma: no cover
                 log(f"[bench] pipeline-inclusive timing failed: {type(e).__name__}: {e}")
-        if world == 1 and not args.skip_cpu_baseline:
+        if headline and world == 1 and not args.skip_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.cpu_seconds)
             out["speedup_vs_cpu_baseline"] = round(value / out["cpu_baseline"]["value"], 1)
         print(json.dumps(out), flush=True)

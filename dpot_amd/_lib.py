@@ -15,6 +15,7 @@ c_fp = C.c_void_p       # device pointer (float*)
 c_i = C.c_int
 c_i64 = C.c_int64
 c_f = C.c_float
+c_d = C.c_double
 
 
 class GemmDesc(C.Structure):
@@ -108,7 +109,7 @@ SIGNATURES = {
     "dpot_rel_l2_bwd": (c_i, [c_fp] * 6 + [c_i] * 4 + [c_fp]),
     "dpot_sumsq": (c_i, [c_fp, c_i64, c_fp, c_fp, c_i, c_fp]),
     "dpot_adam_step": (c_i, [c_fp] * 4 + [c_i64, c_fp, c_fp, c_f, c_fp]),
-    "dpot_adam_stage": (c_i, [c_fp, c_fp] + [c_f] * 6 + [c_i, c_fp]),
+    "dpot_adam_stage": (c_i, [c_fp, c_fp, c_f, c_d, c_d, c_f, c_f, c_f, c_i, c_fp]),
     "dpot_noise_chunks": (c_i, [c_i, c_i]),
     "dpot_noise_inject": (c_i, [c_fp] * 4 + [c_f] + [c_i] * 3 + [c_fp]),
     "dpot_noise_inject_rng": (c_i, [c_fp] * 4 + [c_f] + [c_i] * 3 + [c_fp]),

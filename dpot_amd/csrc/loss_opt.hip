@@ -236,14 +236,16 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
 // host side of a step without a host buffer: all hyper-parameters travel BY VALUE in the kernarg segment of this
 // one-thread launch (copied at enqueue time), and the step counter / bias corrections live on the device - so a host
 // that runs several graph replays ahead of the GPU can never overwrite the values a queued step still has to read
-__global__ void adam_stage_kernel(float* __restrict__ hyper, long long* __restrict__ step, float lr, float b1,
-                                  float b2, float eps, float wd, float max_norm, int advance) {
+// (the betas arrive as DOUBLES: utils/optimizer.py:140-141 forms 1 - beta^step in Python floats; with beta2 rounded to
+// fp32 first, the correction at step 1 is off by 1.3e-5 relative)
+__global__ void adam_stage_kernel(float* __restrict__ hyper, long long* __restrict__ step, float lr, double b1,
+                                  double b2, float eps, float wd, float max_norm, int advance) {
   if (threadIdx.x != 0 || blockIdx.x != 0) return;
   const long long t = step[0] + advance;
   step[0] = t;
-  hyper[0] = lr; hyper[1] = b1; hyper[2] = b2; hyper[3] = eps; hyper[4] = wd;
-  hyper[5] = (float)(1.0 - pow((double)b1, (double)t));
-  hyper[6] = (float)(1.0 - pow((double)b2, (double)t));
+  hyper[0] = lr; hyper[1] = (float)b1; hyper[2] = (float)b2; hyper[3] = eps; hyper[4] = wd;
+  hyper[5] = (float)(1.0 - pow(b1, (double)t));
+  hyper[6] = (float)(1.0 - pow(b2, (double)t));
   hyper[7] = max_norm;
 }
 
@@ -560,7 +562,7 @@ extern "C" int dpot_adam_step(float* p, const float* g, float* m, float* v, int6
   return check_launch("adam_kernel");
 }
 
-extern "C" int dpot_adam_stage(float* hyper, int64_t* step, float lr, float beta1, float beta2, float eps,
+extern "C" int dpot_adam_stage(float* hyper, int64_t* step, float lr, double beta1, double beta2, float eps,
                                float weight_decay, float max_norm, int advance, dpot_stream_t stream) {
   DPOT_REQUIRE(hyper && step, "adam_stage: null pointer");
   DPOT_REQUIRE(advance >= 0, "adam_stage: advance must be >= 0");

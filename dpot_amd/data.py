@@ -117,28 +117,50 @@ class DeviceBatcher:
         self.consumed = [None] * n_buffers                                # slot's last reader (recorded on compute)
         self.k = 0
         self.pending: List[int] = []
+        self.used = [False] * n_buffers                                   # slot has been filled at least once
+        self._out = set()                                                 # slots handed out by get(), not yet released
+        self._last: Optional[int] = None
         self.h2d_bytes = 0
 
     def submit(self, samples: Sequence, starts: Sequence[int]) -> None:
         """enqueue one batch: samples = numpy arrays / CPU tensors [H,W,T,C] (or [H,W,T]); returns immediately"""
         assert len(samples) == self.B and len(starts) == self.B
         slot = self.k % self.n
-        self.k += 1
-        if self.consumed[slot] is not None:
-            self.consumed[slot].synchronize()          # host buffer / device slot are free again (normally long since)
-        host, off, offs, shapes = self.host[slot], self.head, [], []
-        hnp = host.numpy()
-        for s in samples:
+        # validate BEFORE anything is overwritten (a bad batch must leave the slot and the counters untouched)
+        arrs, offs, shapes, off = [], [], [], self.head
+        for i, (s, t0) in enumerate(zip(samples, starts)):
             a = np.asarray(s, dtype=np.float32) if not torch.is_tensor(s) else s.detach().float().numpy()
             if a.ndim == 3:
                 a = a[..., None]                       # griddataset.py:145 "augment channel dim"
-            n = a.size
-            if off + n > hnp.size:
+            H, W, T, Cc = a.shape
+            if Cc > self.C or t0 < 0 or t0 + self.t_in + self.t_ar > T:
+                raise ValueError(f"sample {i}: shape {(H, W, T, Cc)}, window [{t0}, {t0 + self.t_in + self.t_ar}) - needs "
+                                 f"C <= {self.C} and the window inside its {T} frames")
+            if off + a.size > self.host[slot].numel():
                 raise ValueError("DeviceBatcher: raw samples exceed max_raw_floats_per_sample")
-            hnp[off:off + n] = a.reshape(-1)
+            arrs.append(a)
             offs.append(off)
             shapes.append(a.shape)
-            off += n
+            off += a.size
+        # the slot is reused: its pinned staging buffer, raw buffer and xx / yy must be free.  The previous H2D copy +
+        # transform of this slot (copy stream) and the step that read it (recorded by release()) are waited for; a slot
+        # that was handed out by get() but never release()d has an unknown reader - wait for the whole device then
+        if slot in self.pending or slot in self._out:
+            if slot in self.pending:
+                raise RuntimeError(f"DeviceBatcher: all {self.n} slots hold batches that were never fetched with get()")
+            torch.cuda.synchronize(self.dev)           # unreleased consumer: conservative, correct
+            self._out.discard(slot)
+        if self.used[slot]:
+            self.ready[slot].synchronize()
+        if self.consumed[slot] is not None:
+            self.consumed[slot].synchronize()          # host buffer / device slot are free again (normally long since)
+            self.consumed[slot] = None
+        self.k += 1
+        self.used[slot] = True
+        host = self.host[slot]
+        hnp = host.numpy()
+        for a, o in zip(arrs, offs):
+            hnp[o:o + a.size] = a.reshape(-1)
         base = self.raw[slot].data_ptr()
         _fill_table(hnp[:self.head].view(np.uint8), [base + 4 * o for o in offs], shapes, starts, self.t_in, self.t_ar,
                     self.C)
@@ -153,13 +175,25 @@ class DeviceBatcher:
 
     def get(self) -> Tuple[Tensor, Tensor, Tensor]:
         """the oldest submitted batch; the CURRENT stream waits for it (no host synchronisation).  The tensors stay
-        valid until `n_buffers` further submits; call `release()` after the step that reads them was enqueued."""
+        valid until `n_buffers` further submits; call `release()` (or `release(slot)` with `last_slot`) after the step that
+        reads them was enqueued - a slot that is re-used without having been released costs a device synchronise."""
         slot = self.pending.pop(0)
         torch.cuda.current_stream().wait_event(self.ready[slot])
         self._last = slot
+        self._out.add(slot)
         return self.xx[slot], self.yy[slot], self.msk
 
-    def release(self) -> None:
+    @property
+    def last_slot(self) -> Optional[int]:
+        """token of the batch the latest get() returned (pass it to release() when several batches are in flight)"""
+        return self._last
+
+    def release(self, slot: Optional[int] = None) -> None:
+        """the step reading batch `slot` (default: the latest get()) has been enqueued on the current stream"""
+        slot = self._last if slot is None else slot
+        if slot is None or slot not in self._out:
+            raise RuntimeError("DeviceBatcher.release: no batch outstanding for this slot")
         ev = torch.cuda.Event()
         ev.record(torch.cuda.current_stream())
-        self.consumed[self._last] = ev
+        self.consumed[slot] = ev
+        self._out.discard(slot)

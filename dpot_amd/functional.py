@@ -19,7 +19,7 @@ from typing import Optional
 
 import torch
 
-from . import ops, streams
+from . import ops
 from .ops import EPI_ACT, EPI_DACT
 
 Tensor = torch.Tensor
@@ -72,6 +72,25 @@ class _Sink:
         fp.pending[i] -= 1
         if fp.pending[i] == 0 and fp.filled[i]:
             fp.fire(i)
+
+
+def _epoch_of(sinks):
+    """(FlatParams, its weights epoch) of the first flat-bound parameter, or None.  DPOTNet keeps its derived weights
+    (AFNO packs, panel packs, the de-embed matrix) in PERSISTENT buffers that every forward outside a weights_scope
+    rewrites in place, and the stage backwards read them again without autograd version tracking; train.FusedAdam bumps
+    the epoch when it changes the parameters.  (Parameters changed by other means are the caller's responsibility:
+    run backward before modifying them.)"""
+    for sk in sinks:
+        if sk.fp is not None:
+            return sk.fp, sk.fp.epoch
+    return None
+
+
+def _check_epoch(ctx, what: str) -> None:
+    rec = ctx.weights_epoch
+    if rec is not None and rec[0].epoch != rec[1]:
+        raise RuntimeError(f"{what}.backward: the parameters were updated (optimiser step) after this forward ran; its "
+                           "packed weights have been overwritten.  Run backward before the step, or re-run the forward.")
 
 
 def _sinks(ctx, params, first_index: int):
@@ -135,7 +154,6 @@ class EmbedFn(torch.autograd.Function):
 
         implicit = derived is not None and derived[8] is not None
         A0 = None if implicit else ops.patchify(x, gx, gy, gt, P)               # [M0, K0], rows (b,px,py,t)
-        streams.prep_join(dev)        # derived weights of this step (DPOTNet.weights_scope) are ready past this point
         if derived is None:
             derived = embed_derived(pos, w0, b0, w2, b2, taw, tagamma, tt, T)
         w0p, b0p, w2p, posb, ws, V, wsum, cc, wfrag, bt, grid = derived
@@ -157,10 +175,12 @@ class EmbedFn(torch.autograd.Function):
                               grid if implicit else x.new_empty(0))
         ctx.dims = (B, X, Y, T, Cc, P, h, w, hid, hidp, E, K0, act)
         ctx.sinks = _sinks(ctx, (pos, w0, b0, w2, b2, taw, tagamma), 1)
+        ctx.weights_epoch = _epoch_of(ctx.sinks)
         return Yl.view(B, tok, E)
 
     @staticmethod
     def backward(ctx, dY):
+        _check_epoch(ctx, "EmbedFn")
         A0, Hpre, Hh, w0p, w2p, ws, V, wsum, posb, taw, tagamma, tt, grid = ctx.saved_tensors
         B, X, Y, T, Cc, P, h, w, hid, hidp, E, K0, act = ctx.dims
         s_pos, s_w0, s_b0, s_w2, s_b2, s_taw, s_gamma = ctx.sinks
@@ -268,15 +288,13 @@ def _mlp_panel_mode(mlp_pk, M, E, mh, mp) -> int:
     return 2 if ok else 0
 
 
-def _block_parts(x, n1w, n1b, n2w, n2b, f1w, f1b, packed, dims, mp, need_out, f2w=None, f2b=None, mlp_pk=None,
-                 afno_layout=None):
-    """forward of one Block up to (and optionally including) the second channel-MLP GEMM; returns every intermediate
-    the backward needs.  Called by BlockFn.forward, and again by BlockFn.backward when activations are recomputed."""
+def _mixer_fwd(xn1, packed, dims, afno_layout=None):
+    """AFNO2D.forward on a [B, tok, E] field (models/dpot.py:51-110): rfft2 -> block-diagonal complex 2-layer MLP on the
+    kept modes -> irfft2 + x_orig.  Returns (y1, S, O1pre, O1); shared by BlockFn and AFNO2DFn."""
     B, tok, E, h, w, nb, bs, mx, my, mh, act = dims
-    Mm, M = B * mx * my, B * tok
-    dev = x.device
+    Mm = B * mx * my
+    dev = xn1.device
     (wb1, bb1, wb1T, _), (wb2, bb2, wb2T, _) = packed          # w*T: fragment-block-major W for the fused kernel
-    xn1, mean1, rstd1 = ops.groupnorm_fwd(x, n1w, n1b)
     S = ops.rfft2(xn1, h, w, nb, mx, my, 0)                                # [Mm, 2E]
     if wb1T is not None:
         # both layers of the block-diagonal complex MLP in ONE launch; the activated spectrum never leaves the CU
@@ -295,7 +313,96 @@ def _block_parts(x, n1w, n1b, n2w, n2b, f1w, f1b, packed, dims, mp, need_out, f2
         O2 = torch.empty_like(O1)
         ops.gemm(O1, wb2, O2, Mm, 2 * bs, 2 * bs, bias=bb2, **kw)
     y1 = ops.irfft2(O2, B, h, w, E, nb, mx, my, 1, res=xn1)                # + x_orig (the normalised input)
-    del O2, xn1
+    return y1, S, O1pre, O1
+
+
+def _mixer_bwd(dy1, S, O1pre, O1, wb1, wb2, dims, fused, afno_layout, sinks):
+    """backward of _mixer_fwd: returns (dxn1 = adjoint-rfft2(dS) + dy1, dw1, db1, dw2, db2); wb1 / wb2: the
+    fragment-block-major W^T (fused kernel) or the plain Wbig (generic GEMM); sinks = (s_w1, s_b1, s_w2, s_b2)"""
+    B, tok, E, h, w, nb, bs, mx, my, mh, act = dims
+    s_w1, s_b1, s_w2, s_b2 = sinks
+    Mm = B * mx * my
+    dev = dy1.device
+    dO2 = ops.rfft2(dy1, h, w, nb, mx, my, 1)                              # adjoint of irfft2
+    kw = dict(lda=2 * E, ldb=2 * bs, ldc=2 * E, batch=nb, strideA=2 * bs, strideB=4 * bs * bs, strideC=2 * bs)
+    sk = max(2, ops.auto_splitk(2 * bs, 2 * bs, Mm, nb, tn=True))
+    wkw = dict(transA=True, lda=2 * E, ldb=2 * E, ldc=2 * bs, batch=nb, strideA=2 * bs, strideB=2 * bs,
+               strideC=4 * bs * bs, splitk=sk, mode=ops.EPI_AFNO_WGRAD)
+    # both weight gradients of the mixer in ONE launch (csrc/gemm_tn.hip, dpot_afno_wgrad2) once dO1pre exists
+    sk2 = ops.afno_wgrad2_splitk(Mm, nb, bs) if fused and S.stride(0) == 2 * E else 0
+    if not sk2:
+        # wgrad of Wbig; its split-K reduction writes dw / db in the parameters' own [2, nb, bs, ...] layout
+        dw2, db2 = ops._out(s_w2.out(), (2, nb, bs, bs), dev), ops._out(s_b2.out(), (2, nb, bs), dev)
+        ops.gemm(O1, dO2, dw2, 2 * bs, 2 * bs, Mm, colsum_out=db2, colsum_of=2, **wkw)
+        dw2, db2 = s_w2.done(dw2), s_b2.done(db2)
+    if fused:
+        # data path of both layers in one launch: dO1pre = (dO2 W2^T) * act'(O1pre), dS = dO1pre W1^T
+        # (wb1 / wb2 hold the fragment-block-major W^T here)
+        dS, _, dO1pre = ops.afno_mlp2(dO2, wb2, None, wb1, None, nb, bs, act, mode=1, aux=O1pre, want_mid=True,
+                                      layout=afno_layout)
+    else:
+        dO1pre = torch.empty(Mm, 2 * E, dtype=torch.float32, device=dev)
+        ops.gemm(dO2, wb2, dO1pre, Mm, 2 * bs, 2 * bs, transB=True, act=act, mode=EPI_DACT, aux=O1pre,
+                 ldaux=2 * E, strideAux=2 * bs, **kw)
+    if sk2:
+        dw1, db1 = ops._out(s_w1.out(), (2, nb, bs, bs), dev), ops._out(s_b1.out(), (2, nb, bs), dev)
+        dw2, db2 = ops._out(s_w2.out(), (2, nb, bs, bs), dev), ops._out(s_b2.out(), (2, nb, bs), dev)
+        ops.afno_wgrad2(S, dO1pre, O1, dO2, nb, bs, dw1, db1, dw2, db2, sk2)
+        dw1, db1, dw2, db2 = s_w1.done(dw1), s_b1.done(db1), s_w2.done(dw2), s_b2.done(db2)
+    else:
+        dw1, db1 = ops._out(s_w1.out(), (2, nb, bs, bs), dev), ops._out(s_b1.out(), (2, nb, bs), dev)
+        ops.gemm(S, dO1pre, dw1, 2 * bs, 2 * bs, Mm, colsum_out=db1, colsum_of=2, **wkw)
+        dw1, db1 = s_w1.done(dw1), s_b1.done(db1)
+    if not fused:
+        dS = torch.empty(Mm, 2 * E, dtype=torch.float32, device=dev)
+        ops.gemm(dO1pre, wb1, dS, Mm, 2 * bs, 2 * bs, transB=True, **kw)
+    dxn1 = ops.irfft2(dS, B, h, w, E, nb, mx, my, 0, res=dy1)              # adjoint of rfft2, + skip path
+    return dxn1, dw1, db1, dw2, db2
+
+
+class AFNO2DFn(torch.autograd.Function):
+    """The AFNO mixer alone, as the reference's ``AFNO2D`` module computes it (models/dpot.py:51-110) on a channels-last
+    field: x[B, h*w, E] -> irfft2(MLP(rfft2(x))) + x.  The very kernel sequence BlockFn runs (same helpers): the per-op
+    golden vectors g1_afno_* drive the product mixer through this entry."""
+
+    @staticmethod
+    def forward(ctx, x, w1, b1, w2, b2, h: int, w: int, nb: int, modes: int, act: int, packed=None):
+        x = x.contiguous()
+        B, tok, E = x.shape
+        bs = E // nb
+        mx, my = min(modes, h), min(modes, w // 2 + 1)
+        if packed is None:
+            packed = tuple(ops.AfnoPacks([(w1, b1), (w2, b2)]).refresh())
+        dims = (B, tok, E, h, w, nb, bs, mx, my, 0, act)
+        y1, S, O1pre, O1 = _mixer_fwd(x, packed, dims)
+        ctx.fused = packed[0][2] is not None
+        wb1, wb2 = (packed[0][3], packed[1][3]) if ctx.fused else (packed[0][0], packed[1][0])
+        ctx.afno_layout = getattr(packed[0], "layout", 0) if ctx.fused else 0
+        ctx.save_for_backward(S, O1pre, O1, wb1, wb2)
+        ctx.dims = dims
+        ctx.sinks = _sinks(ctx, (w1, b1, w2, b2), 1)
+        ctx.weights_epoch = _epoch_of(ctx.sinks)
+        return y1
+
+    @staticmethod
+    def backward(ctx, dy):
+        _check_epoch(ctx, "AFNO2DFn")
+        S, O1pre, O1, wb1, wb2 = ctx.saved_tensors
+        dx, dw1, db1, dw2, db2 = _mixer_bwd(dy.contiguous(), S, O1pre, O1, wb1, wb2, ctx.dims, ctx.fused,
+                                            ctx.afno_layout, ctx.sinks)
+        return dx, dw1, db1, dw2, db2, None, None, None, None, None, None
+
+
+def _block_parts(x, n1w, n1b, n2w, n2b, f1w, f1b, packed, dims, mp, need_out, f2w=None, f2b=None, mlp_pk=None,
+                 afno_layout=None):
+    """forward of one Block up to (and optionally including) the second channel-MLP GEMM; returns every intermediate
+    the backward needs.  Called by BlockFn.forward, and again by BlockFn.backward when activations are recomputed."""
+    B, tok, E, h, w, nb, bs, mx, my, mh, act = dims
+    Mm, M = B * mx * my, B * tok
+    dev = x.device
+    xn1, mean1, rstd1 = ops.groupnorm_fwd(x, n1w, n1b)
+    y1, S, O1pre, O1 = _mixer_fwd(xn1, packed, dims, afno_layout)
+    del xn1
     xn2, mean2, rstd2 = ops.groupnorm_fwd(y1, n2w, n2b)
     panel = _mlp_panel_mode(mlp_pk, M, E, mh, mp)
     npl = mlp_pk.planes if panel == 2 else 0
@@ -367,10 +474,12 @@ class BlockFn(torch.autograd.Function):
         ctx.afno_layout = getattr(packed[0], "layout", 0) if ctx.fused_mixer else 0
         ctx.mlp_precision = mp
         ctx.sinks = _sinks(ctx, (n1w, n1b, w1, b1, w2, b2, n2w, n2b, f1w, f1b, f2w, f2b), 1)
+        ctx.weights_epoch = _epoch_of(ctx.sinks)
         return out.view(B, tok, E)
 
     @staticmethod
     def backward(ctx, dout):
+        _check_epoch(ctx, "BlockFn")
         mp = ctx.mlp_precision
         if ctx.recompute:
             x, wb1, bb1, wb2, bb2, n1w, n1b, n2w, n2b, f1w, f1b, f2w, *wts = ctx.saved_tensors
@@ -389,8 +498,6 @@ class BlockFn(torch.autograd.Function):
         dev = dout.device
         dout = dout.contiguous()
         do2 = dout.view(M, E)
-        # Critical path on the current stream: dgrad GEMMs, GroupNorm, DFTs.  Everything that only produces parameter
-        # gradients (wgrad GEMMs + split-K reductions, bias column sums, un-packing) runs on the side stream.
         # channel MLP
         mlp_pk = ctx.mlp_pk
         bf16p = mlp_pk is not None and mlp_pk.kind != "f32"
@@ -435,8 +542,7 @@ class BlockFn(torch.autograd.Function):
             if skm and not (do2.is_contiguous() and Hh.is_contiguous() and xn2.is_contiguous()):
                 skm = 0
             if not skm:
-                with streams.side(dev):
-                    df2w, df2b = wgrad(do2, Hh, s_f2w, s_f2b, (E, mh, 1, 1))
+                df2w, df2b = wgrad(do2, Hh, s_f2w, s_f2b, (E, mh, 1, 1))
             if bf16p:
                 dHpre, _ = ops.gemm_bf16p(ops.bf16_pack_rows(do2, planes=npl), mlp_pk[3], M, mh, E, act=act, mode=EPI_DACT,
                                           aux=Hpre, planes=npl)
@@ -451,8 +557,7 @@ class BlockFn(torch.autograd.Function):
                 df2w, df2b = s_f2w.done(df2w.view(E, mh, 1, 1)), s_f2b.done(df2b)
                 df1w, df1b = s_f1w.done(df1w.view(mh, E, 1, 1)), s_f1b.done(df1b)
             else:
-                with streams.side(dev):
-                    df1w, df1b = wgrad(dHpre, xn2.view(M, E), s_f1w, s_f1b, (mh, E, 1, 1))
+                df1w, df1b = wgrad(dHpre, xn2.view(M, E), s_f1w, s_f1b, (mh, E, 1, 1))
             if bf16p:
                 dxn2, _ = ops.gemm_bf16p(ops.bf16_pack_rows(dHpre, planes=npl), mlp_pk[1], M, E, mh, planes=npl)
             elif mlp_pk is not None:
@@ -462,48 +567,13 @@ class BlockFn(torch.autograd.Function):
         # parameter-gradient partials of norm2 are reduced together with norm1's at the end of the block (one launch)
         dy1, gn2_part = ops.groupnorm_bwd(dxn2.view(B, tok, E), y1, mean2, rstd2, n2w, defer=True)
         # AFNO mixer
-        dO2 = ops.rfft2(dy1, h, w, nb, mx, my, 1)                              # adjoint of irfft2
-        kw = dict(lda=2 * E, ldb=2 * bs, ldc=2 * E, batch=nb, strideA=2 * bs, strideB=4 * bs * bs, strideC=2 * bs)
-        sk = max(2, ops.auto_splitk(2 * bs, 2 * bs, Mm, nb, tn=True))
-        wkw = dict(transA=True, lda=2 * E, ldb=2 * E, ldc=2 * bs, batch=nb, strideA=2 * bs, strideB=2 * bs,
-                   strideC=4 * bs * bs, splitk=sk, mode=ops.EPI_AFNO_WGRAD)
-        # both weight gradients of the mixer in ONE launch (csrc/gemm_tn.hip, dpot_afno_wgrad2) once dO1pre exists
-        sk2 = ops.afno_wgrad2_splitk(Mm, nb, bs) if ctx.fused_mixer and S.stride(0) == 2 * E else 0
-        if not sk2:
-            with streams.side(dev):
-                # wgrad of Wbig; its split-K reduction writes dw / db in the parameters' own [2, nb, bs, ...] layout
-                dw2, db2 = ops._out(s_w2.out(), (2, nb, bs, bs), dev), ops._out(s_b2.out(), (2, nb, bs), dev)
-                ops.gemm(O1, dO2, dw2, 2 * bs, 2 * bs, Mm, colsum_out=db2, colsum_of=2, **wkw)
-                dw2, db2 = s_w2.done(dw2), s_b2.done(db2)
-        if ctx.fused_mixer:
-            # data path of both layers in one launch: dO1pre = (dO2 W2^T) * act'(O1pre), dS = dO1pre W1^T
-            # (wb1 / wb2 hold the fragment-block-major W^T here)
-            dS, _, dO1pre = ops.afno_mlp2(dO2, wb2, None, wb1, None, nb, bs, act, mode=1, aux=O1pre, want_mid=True,
-                                          layout=ctx.afno_layout)
-        else:
-            dO1pre = torch.empty(Mm, 2 * E, dtype=torch.float32, device=dev)
-            ops.gemm(dO2, wb2, dO1pre, Mm, 2 * bs, 2 * bs, transB=True, act=act, mode=EPI_DACT, aux=O1pre,
-                     ldaux=2 * E, strideAux=2 * bs, **kw)
-        if sk2:
-            dw1, db1 = ops._out(s_w1.out(), (2, nb, bs, bs), dev), ops._out(s_b1.out(), (2, nb, bs), dev)
-            dw2, db2 = ops._out(s_w2.out(), (2, nb, bs, bs), dev), ops._out(s_b2.out(), (2, nb, bs), dev)
-            ops.afno_wgrad2(S, dO1pre, O1, dO2, nb, bs, dw1, db1, dw2, db2, sk2)
-            dw1, db1, dw2, db2 = s_w1.done(dw1), s_b1.done(db1), s_w2.done(dw2), s_b2.done(db2)
-        else:
-            with streams.side(dev):
-                dw1, db1 = ops._out(s_w1.out(), (2, nb, bs, bs), dev), ops._out(s_b1.out(), (2, nb, bs), dev)
-                ops.gemm(S, dO1pre, dw1, 2 * bs, 2 * bs, Mm, colsum_out=db1, colsum_of=2, **wkw)
-                dw1, db1 = s_w1.done(dw1), s_b1.done(db1)
-        if not ctx.fused_mixer:
-            dS = torch.empty(Mm, 2 * E, dtype=torch.float32, device=dev)
-            ops.gemm(dO1pre, wb1, dS, Mm, 2 * bs, 2 * bs, transB=True, **kw)
-        dxn1 = ops.irfft2(dS, B, h, w, E, nb, mx, my, 0, res=dy1)              # adjoint of rfft2, + skip path
+        dxn1, dw1, db1, dw2, db2 = _mixer_bwd(dy1, S, O1pre, O1, wb1, wb2, ctx.dims, ctx.fused_mixer, ctx.afno_layout,
+                                              (s_w1, s_b1, s_w2, s_b2))
         dx, gn1_part = ops.groupnorm_bwd(dxn1, x, mean1, rstd1, n1w, add=dout, defer=True)
         (dn1w, dn1b), (dn2w, dn2b) = ops.groupnorm_param_grads([(gn1_part, s_n1w.out(), s_n1b.out()),
                                                                 (gn2_part, s_n2w.out(), s_n2b.out())])
         dn1w, dn1b = s_n1w.done(dn1w), s_n1b.done(dn1b)
         dn2w, dn2b = s_n2w.done(dn2w), s_n2b.done(dn2b)
-        streams.join(dev)      # the side stream's readers of this frame's tensors are done before they can be freed
         return (dx, dn1w, dn1b, dw1, db1, dw2, db2, dn2w, dn2b, df1w, df1b, df2w, df2b, None, None, None, None, None,
                 None, None, None)
 
@@ -581,10 +651,12 @@ class HeadFn(torch.autograd.Function):
         ctx.sinks = _sinks(ctx, (o0w, o0b, o2w, o2b, o4w, o4b), 1)
         ctx.cls_params = (c0w, c0b, c2w, c2b, c4w, c4b)
         ctx.cls_needed = tuple(ctx.needs_input_grad[7:13])
+        ctx.weights_epoch = _epoch_of(ctx.sinks)
         return pred, cls
 
     @staticmethod
     def backward(ctx, dpred, dcls):
+        _check_epoch(ctx, "HeadFn")
         x, wt, U, Upre, V, Vpre, o2w, o2b, o4w, cm, c1, c1pre, c2, c2pre, c0w, c2w, c4w = ctx.saved_tensors
         B, tok, E, h, w, P, old, co, act = ctx.dims
         s_o0w, s_o0b, s_o2w, s_o2b, s_o4w, s_o4b = ctx.sinks

@@ -20,7 +20,7 @@ import os
 import torch
 import torch.nn as nn
 
-from . import _lib, ops, streams
+from . import _lib, ops
 import contextlib
 
 from .functional import (AdaINFn, BlockFn, EmbedFn, HeadFn, embed_derived, embed_grid_matrix, head_derived,
@@ -139,18 +139,13 @@ class DPOTNet(nn.Module):
         if self._scope_depth == 1:
             self._scope_cache = None
             if dev.type == "cuda":
-                # weight-only work starts NOW on the prep stream, under the batch-only head of the step (noise, patch
-                # gathering); EmbedFn joins before the first kernel that reads a derived weight
-                with streams.prep(dev):
-                    self._derived_weights()
+                self._derived_weights()
         try:
             yield self
         finally:
             self._scope_depth -= 1
             if self._scope_depth == 0:
                 self._scope_cache = None
-                if dev.type == "cuda":
-                    streams.prep_join(dev)
 
     def _derived_weights(self):
         if self._scope_depth > 0 and self._scope_cache is not None:

@@ -901,6 +901,11 @@ def window_slide(xx: Tensor, im: Tensor) -> Tensor:
     """cat(xx[..., Tb:, :], im) along the time axis of [B,X,Y,T,C] (train_temporal.py:219)"""
     T, Cc = xx.shape[-2], xx.shape[-1]
     Tb = im.shape[-2]
+    # the reference's torch.cat raises when the prediction does not continue the window (out_channels != in_channels,
+    # other leading dims); the kernel would read `im` with the wrong stride instead
+    if im.shape[:-2] != xx.shape[:-2] or im.shape[-1] != Cc or Tb > T:
+        raise _lib.DpotHipError(f"window_slide: prediction {tuple(im.shape)} does not continue the window {tuple(xx.shape)} "
+                                f"(needs equal leading dims and channel count, T_bundle <= T_in)")
     rows = xx.numel() // (T * Cc)
     out = torch.empty_like(xx)
     check(_lib.load().dpot_window_slide(xx.data_ptr(), im.data_ptr(), out.data_ptr(), rows, T, Tb, Cc, _stream()),
@@ -910,6 +915,8 @@ def window_slide(xx: Tensor, im: Tensor) -> Tensor:
 
 def window_slide_bwd(dout: Tensor, Tb: int, need_xx: bool, need_im: bool):
     T, Cc = dout.shape[-2], dout.shape[-1]
+    if not 0 < Tb <= T:
+        raise _lib.DpotHipError(f"window_slide_bwd: T_bundle {Tb} outside (0, {T}]")
     rows = dout.numel() // (T * Cc)
     dxx = torch.empty_like(dout) if need_xx else None
     dim = torch.empty(dout.shape[:-2] + (Tb, Cc), dtype=torch.float32, device=dout.device) if need_im else None

@@ -65,6 +65,7 @@ class FlatParams:
         self.filled: List[bool] = [False] * n_p      # slot already holds a gradient contribution this step
         self.pending: List[int] = [0] * n_p          # forward uses whose backward has not delivered yet
         self.callbacks: List[Callable[[int], None]] = []   # fired with the parameter index when its grad is final
+        self.epoch = 0                               # bumped by the optimiser whenever it changes the parameters
         with torch.no_grad():
             for i, (p, o) in enumerate(zip(self.params, self.offsets)):
                 n = p.numel()
@@ -145,6 +146,7 @@ class FusedAdam:
             ops.sumsq(g, self.sumsq, self._part)
         ops.adam_step(self.fp.flat[:n], g, self.exp_avg[:n], self.exp_avg_sq[:n], self.hyper,
                       self.sumsq if use_clip else None, grad_scale)
+        self.fp.epoch += 1            # parameters changed: a backward of an EARLIER forward must not run any more
 
     def step(self, lr: Optional[float] = None, grad_scale: float = 1.0) -> None:
         self.stage_hyper(lr)
@@ -388,8 +390,8 @@ class GraphedTrainStep:
 
 
 class SegmentedTrainStep:
-    """The data-parallel train step (T_ar = 1 rollout step) as a CHAIN of hipGraphs, cut where a gradient bucket
-    becomes final, so that the RCCL all-reduce of bucket k runs on the reducer's side stream while the compute stream
+    """The data-parallel train step (any T_ar, as train_temporal_parallel.py:214-244 runs it under DDP) as a CHAIN of
+    hipGraphs, cut where a gradient bucket becomes final, so that the RCCL all-reduce of bucket k runs on the reducer's side stream while the compute stream
     replays the backward of the earlier stages - the overlap torch-DDP gets from autograd hooks
     (train_temporal_parallel.py:244), without a collective inside a capture and without eager launch overhead.
 
@@ -399,11 +401,16 @@ class SegmentedTrainStep:
 
     The autograd graph is cut at the bucket boundaries (``DPOTNet._boundary_hook``): each cut replaces the latent by a
     detached leaf; the next segment continues with ``out.backward(leaf.grad)``.  All segments share one memory pool
-    and are always replayed in capture order."""
+    and are always replayed in capture order.
+
+    Auto-regressive rollouts (T_ar > T_bundle): every AR step adds to every parameter gradient, and the backward visits
+    the AR steps last to first - a bucket is final only once the backward of the FIRST AR step has passed it.  The cuts
+    are therefore made in the first forward call only; segment 0 holds the whole rollout forward, the loss, the complete
+    backward of AR steps T-1 .. 1 and the backward of AR step 0 down to its last cut."""
 
     def __init__(self, model: nn.Module, opt: FusedAdam, reducer, xx: Tensor, yy: Tensor, msk: Optional[Tensor],
-                 noise_scale: float = 0.0, warmup: int = 2):
-        assert yy.shape[-2] == getattr(model, "out_timesteps", yy.shape[-2]), "SegmentedTrainStep: T_ar = T_bundle only"
+                 noise_scale: float = 0.0, warmup: int = 2, T_bundle: int = 1):
+        self.T_bundle = T_bundle
         self.model, self.opt, self.reducer = model, opt, reducer
         self.xx, self.yy = xx.clone(), yy.clone()
         self.msk = msk.clone() if msk is not None else None
@@ -449,9 +456,12 @@ class SegmentedTrainStep:
         """generator of the segment bodies; segment j+1 may only be built after segment j has run"""
         cuts = []
         cut_at = set(self.cut_at)
+        calls = [0]                                  # forward calls of this rollout seen so far (hook(1, .) opens one)
 
         def hook(b, lat):
-            if b in cut_at and lat.requires_grad:
+            if b == 1:
+                calls[0] += 1
+            if calls[0] == 1 and b in cut_at and lat.requires_grad:
                 leaf = lat.detach().requires_grad_(True)
                 cuts.append((lat, leaf))
                 return leaf
@@ -460,10 +470,12 @@ class SegmentedTrainStep:
         def first():
             self.opt.zero_grad()
             self.model._boundary_hook = hook
+            calls[0] = 0
             try:
-                loss, pred = rollout(self.model, self.xx, self.yy, self.msk, 1, self.noise_scale)
+                loss, pred = rollout(self.model, self.xx, self.yy, self.msk, self.T_bundle, self.noise_scale)
             finally:
                 self.model._boundary_hook = None
+            assert len(cuts) == len(self.cut_at), f"expected {len(self.cut_at)} graph cuts, the forward made {len(cuts)}"
             loss.backward()
             self.loss, self.pred = loss.detach(), pred.detach()
 
@@ -492,7 +504,7 @@ class SegmentedTrainStep:
             red.reduce_bucket(k)              # side stream waits for the compute stream, then all-reduces bucket k
         if self.tail_has_grad:
             red.reduce_bucket(red.tail_bucket)
-        else:
+        elif red.tail_bucket >= 0:
             red._launched[red.tail_bucket] = True
         red.finish()                          # compute stream joins the side stream
         self.opt_graph.replay()

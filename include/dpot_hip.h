@@ -332,9 +332,10 @@ int dpot_adam_step(float* p, const float* g, float* m, float* v, int64_t n, cons
 
 /* Host side of an optimiser step (utils/optimizer.py:139-141: state['step'] += 1, bias corrections) as ONE one-thread
  * launch whose arguments travel by value: step[0] += advance (DEVICE int64), hyper = {lr, beta1, beta2, eps,
- * weight_decay, 1-beta1^step, 1-beta2^step, max_norm (0 = no clip)}.  No host buffer is read when the kernel runs,
+ * weight_decay, 1-beta1^step, 1-beta2^step, max_norm (0 = no clip)}; the betas are doubles so that the bias
+ * corrections are formed from the un-rounded values, as Python does.  No host buffer is read when the kernel runs,
  * so the host may enqueue any number of steps ahead (hipGraph replays included). */
-int dpot_adam_stage(float* hyper, int64_t* step, float lr, float beta1, float beta2, float eps,
+int dpot_adam_stage(float* hyper, int64_t* step, float lr, double beta1, double beta2, float eps,
                     float weight_decay, float max_norm, int advance, dpot_stream_t stream);
 
 /* xx_out = xx + noise_scale * ||xx||_2(over X,Y,T per (b,c)) * eps   (train_temporal.py:205)

@@ -37,8 +37,12 @@ def _block_fn(m, x, h):
 
 @pytest.mark.parametrize("name", ["g1_afno_trunc", "g1_afno_tiny"])
 def test_afno_mixer_golden(name):
-    """AFNO2D alone (golden g1): drive the BlockFn pieces = rfft2 -> 2 GEMMs -> irfft2 + residual, fwd and bwd"""
+    """AFNO2D alone (golden g1, written by the imported reference's AFNO2D module): the PRODUCT mixer -
+    functional.AFNO2DFn = the helpers BlockFn runs: rfft2 -> afno_mlp3_kernel (both layers, three-product form; the two
+    generic GEMMs at block sizes the fused kernel does not cover) -> irfft2 + residual, and backward through
+    afno_mlp2(mode 1) + dpot_afno_wgrad2 - forward, dx and the four parameter gradients"""
     from dpot_amd import ops
+    from dpot_amd.functional import AFNO2DFn
     fx = load(name)
     B, h, E, nb, modes = (int(fx[k]) for k in ("B", "h", "E", "nb", "modes"))
     cfg = R.DPOTConfig(img_size=h * 8, patch_size=8, embed_dim=E, n_blocks=nb, modes=modes, depth=1)
@@ -47,50 +51,12 @@ def test_afno_mixer_golden(name):
           if k.startswith(pre)}
     x = R.recipe_input((B, h, h, E), salt=11)
     up = (R.recipe_input((B, h, h, E), salt=12) * 0.3)
-
-    class MixFn(torch.autograd.Function):                      # the mixer slice of BlockFn, same kernel sequence
-        @staticmethod
-        def forward(ctx, xx, w1, b1, w2, b2):
-            bs = E // nb
-            mx, my = min(modes, h), min(modes, h // 2 + 1)
-            Mm = B * mx * my
-            S = ops.rfft2(xx, h, h, nb, mx, my, 0)
-            wb1, bb1 = ops.afno_pack(w1, b1)
-            wb2, bb2 = ops.afno_pack(w2, b2)
-            kw = dict(lda=2 * E, ldb=2 * bs, ldc=2 * E, batch=nb, strideA=2 * bs, strideB=4 * bs * bs,
-                      strideC=2 * bs)
-            O1, O1pre = torch.empty(Mm, 2 * E, device="cuda"), torch.empty(Mm, 2 * E, device="cuda")
-            ops.gemm(S, wb1, O1, Mm, 2 * bs, 2 * bs, bias=bb1, strideBias=2 * bs, act=1, mode=ops.EPI_ACT,
-                     preact=O1pre, ldpre=2 * E, stridePre=2 * bs, **kw)
-            O2 = torch.empty_like(O1)
-            ops.gemm(O1, wb2, O2, Mm, 2 * bs, 2 * bs, bias=bb2, strideBias=2 * bs, **kw)
-            ctx.save_for_backward(S, O1pre, O1, wb1, wb2)
-            ctx.c = (bs, mx, my, Mm, kw)
-            return ops.irfft2(O2, B, h, h, E, nb, mx, my, 1, res=xx)
-
-        @staticmethod
-        def backward(ctx, dy):
-            S, O1pre, O1, wb1, wb2 = ctx.saved_tensors
-            bs, mx, my, Mm, kw = ctx.c
-            dy = dy.contiguous()
-            dO2 = ops.rfft2(dy, h, h, nb, mx, my, 1)
-            dO1pre = torch.empty(Mm, 2 * E, device="cuda")
-            ops.gemm(dO2, wb2, dO1pre, Mm, 2 * bs, 2 * bs, transB=True, act=1, mode=ops.EPI_DACT, aux=O1pre,
-                     ldaux=2 * E, strideAux=2 * bs, **kw)
-            wkw = dict(transA=True, lda=2 * E, ldb=2 * E, ldc=2 * bs, batch=nb, strideA=2 * bs, strideB=2 * bs,
-                       strideC=4 * bs * bs, splitk=ops.auto_splitk(2 * bs, 2 * bs, Mm, nb))
-            dwb2 = torch.empty(nb, 2 * bs, 2 * bs, device="cuda")
-            ops.gemm(O1, dO2, dwb2, 2 * bs, 2 * bs, Mm, **wkw)
-            dS = torch.empty(Mm, 2 * E, device="cuda")
-            ops.gemm(dO1pre, wb1, dS, Mm, 2 * bs, 2 * bs, transB=True, **kw)
-            dwb1 = torch.empty(nb, 2 * bs, 2 * bs, device="cuda")
-            ops.gemm(S, dO1pre, dwb1, 2 * bs, 2 * bs, Mm, **wkw)
-            dw1, db1 = ops.afno_unpack_grad(dwb1, ops.colsum(dO1pre, Mm, 2 * E), nb, bs)
-            dw2, db2 = ops.afno_unpack_grad(dwb2, ops.colsum(dO2, Mm, 2 * E), nb, bs)
-            return ops.irfft2(dS, B, h, h, E, nb, mx, my, 0, res=dy), dw1, db1, dw2, db2
-
+    bs = E // nb
+    if name == "g1_afno_tiny":        # the DPOT-Tiny layer must run on the fused three-product kernel
+        assert ops.afno_mlp2_supported(nb, bs) and ops.afno_mlp3_supported(nb, bs)
+        assert ops.afno_wgrad2_splitk(B * min(modes, h) * min(modes, h // 2 + 1), nb, bs) > 0
     xg = x.cuda().view(B, h * h, E).requires_grad_(True)
-    y = MixFn.apply(xg, sd["w1"], sd["b1"], sd["w2"], sd["b2"])
+    y = AFNO2DFn.apply(xg, sd["w1"], sd["b1"], sd["w2"], sd["b2"], h, h, nb, modes, 1)
     (y * up.cuda().view(B, h * h, E)).sum().backward()
     full = name == "g1_afno_trunc"
     cmp = (lambda t, k: assert_close(t.reshape(fx[k].shape), fx[k], k)) if full else \

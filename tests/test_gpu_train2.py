@@ -173,14 +173,16 @@ def test_rollout_with_noise_gradient_vs_oracle():
 
 
 # ------------------------------------------------------------------------------------------------------
-def test_segmented_graph_step_equals_eager_step():
+@pytest.mark.parametrize("T_ar", [1, 3])
+def test_segmented_graph_step_equals_eager_step(T_ar):
     """the bucket-segmented hipGraph chain (train.SegmentedTrainStep) reproduces the eager step bit for bit (world 1:
-    the collectives are no-ops, the graph cuts / leaf hand-over / shared pool are what is tested)"""
+    the collectives are no-ops, the graph cuts / leaf hand-over / shared pool are what is tested); T_ar = 3: the cuts sit
+    in the FIRST auto-regressive step's backward only (train_temporal_parallel.py:214-244 under DDP)"""
     from dpot_amd.dp import BucketedGradReducer
     from dpot_amd.train import SegmentedTrainStep, train_step
     kw = dict(R.MINI, depth=4)
     m1, cfg = build(kw, salt=3)
-    xx, yy, msk = _batch(cfg, 2)
+    xx, yy, msk = _batch(cfg, 2, T_ar=T_ar)
     opt1 = _opt(m1, update_tail=True)
     for lr in (1e-3, 2e-3, 5e-4):
         l_e, _ = train_step(m1, opt1, xx, yy, msk, lr=lr)
@@ -204,7 +206,7 @@ def _free_port():
     return p
 
 
-def _dp_worker(rank, world, port, out_dir, segmented):
+def _dp_worker(rank, world, port, out_dir, segmented, T_ar=1):
     import torch.distributed as dist
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -226,7 +228,7 @@ def _dp_worker(rank, world, port, out_dir, segmented):
     red.broadcast_parameters(0)
     B = 4
     xx = R.recipe_input((B, cfg.img_size, cfg.img_size, cfg.in_timesteps, cfg.in_channels), salt=81)
-    yy = R.recipe_input((B, cfg.img_size, cfg.img_size, 1, cfg.out_channels), salt=82)
+    yy = R.recipe_input((B, cfg.img_size, cfg.img_size, T_ar, cfg.out_channels), salt=82)
     msk = torch.ones(B, cfg.img_size, cfg.img_size, 1, cfg.out_channels)
     sl = slice(2 * rank, 2 * rank + 2)
     xs, ys, ms = xx[sl].cuda(), yy[sl].cuda(), msk[sl].cuda()
@@ -245,7 +247,7 @@ def _dp_worker(rank, world, port, out_dir, segmented):
     torch.cuda.synchronize()
     g = (fp.grad * red.grad_scale).cpu()
     if rank == 0:
-        np.savez(os.path.join(out_dir, f"dp_{int(segmented)}.npz"),
+        np.savez(os.path.join(out_dir, f"dp_{int(segmented)}.npz"), flat=g.numpy(),
                  gnorm=np.float64(torch.sqrt((g.double() ** 2).sum()).item()), names=np.array(fp.names),
                  norms=np.array([g[o:o + p.numel()].norm().item() for p, o in zip(fp.params, fp.offsets)]),
                  launched=launched, n_buckets=red.n_buckets)
@@ -273,3 +275,60 @@ def test_two_process_dp_hip_backward_vs_golden(tmp_path, segmented):
         assert abs(v - want[str(n)]) <= RTOL * want[str(n)] + 1e-7, n
     if not segmented:
         assert int(got["launched"]) >= int(got["n_buckets"]) - 1     # buckets went out DURING the backward
+
+
+@pytest.mark.timeout(600)
+def test_two_process_dp_segmented_rollout_vs_oracle(tmp_path):
+    """T_ar = 3 under data parallelism (train_temporal_parallel.py:214-244): two processes on the one GPU, gloo
+    collectives; the segmented graph chain (cuts in the first AR step's backward) and the eager hook-driven path must give
+    the SAME averaged flat gradient bit for bit, and that gradient must match the oracle's rollout gradient of the full
+    batch divided by the world size (sum-loss + DDP mean)"""
+    import torch.multiprocessing as mp
+    T_ar = 3
+    res = {}
+    for segmented in (False, True):
+        mp.spawn(_dp_worker, args=(2, _free_port(), str(tmp_path), segmented, T_ar), nprocs=2, join=True)
+        res[segmented] = np.load(os.path.join(str(tmp_path), f"dp_{int(segmented)}.npz"))
+    assert np.array_equal(res[True]["flat"], res[False]["flat"])
+    assert int(res[True]["launched"]) >= 2                       # the chain really is several graphs
+    cfg = R.DPOTConfig(**R.MINI)
+    sd = OrderedDict((k, v.clone().requires_grad_(True)) for k, v in R.recipe_state_dict(cfg, salt=17).items())
+    B = 4
+    xx = R.recipe_input((B, cfg.img_size, cfg.img_size, cfg.in_timesteps, cfg.in_channels), salt=81)
+    yy = R.recipe_input((B, cfg.img_size, cfg.img_size, T_ar, cfg.out_channels), salt=82)
+    msk = torch.ones(B, cfg.img_size, cfg.img_size, 1, cfg.out_channels)
+    loss, _ = R.rollout_loss(sd, xx, yy, msk, cfg)
+    loss.backward()
+    got = dict(zip([str(n) for n in res[True]["names"]], res[True]["norms"]))
+    for k, v in sd.items():
+        if v.grad is None:
+            continue
+        want = v.grad.double().norm().item() / 2
+        assert abs(got[k] - want) <= RTOL * want + 1e-7, k
+
+
+def test_backward_after_optimiser_step_raises():
+    """the derived weight packs are persistent buffers; a backward that runs AFTER the optimiser changed the
+    parameters would silently use overwritten packs - it must raise instead"""
+    from dpot_amd.train import rollout
+    m, cfg = build(R.MINI, salt=3)
+    xx, yy, msk = _batch(cfg, 2)
+    opt = _opt(m)
+    opt.zero_grad()
+    loss_a, _ = rollout(m, xx, yy, msk)
+    opt.step(1e-3)                                            # parameters change between forward(A) and backward(A)
+    with pytest.raises(RuntimeError, match="parameters were updated"):
+        loss_a.backward()
+    opt.zero_grad()                                           # a fresh forward / backward pair is fine again
+    loss_b, _ = rollout(m, xx, yy, msk)
+    loss_b.backward()
+    assert torch.isfinite(opt.grad_norm()).item()
+
+
+def test_window_slide_rejects_mismatched_prediction():
+    from dpot_amd import _lib, ops
+    xx = torch.zeros(2, 8, 8, 4, 3, device="cuda")
+    with pytest.raises(_lib.DpotHipError):
+        ops.window_slide(xx, torch.zeros(2, 8, 8, 1, 4, device="cuda"))      # out_channels != in_channels
+    with pytest.raises(_lib.DpotHipError):
+        ops.window_slide(xx, torch.zeros(2, 8, 4, 1, 3, device="cuda"))      # other spatial extent
