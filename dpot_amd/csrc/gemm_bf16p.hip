@@ -36,6 +36,12 @@ struct Bf16pArgs {
   uint4* out_rows;
   uint4* out_trans;
   float* cs_part;
+  // the activation DERIVATIVE as bf16 in the row-form pack layout of the output ([M/32][N/16][64 chunks][8]): written
+  // by an EPI_ACT launch (dact_out: act'(pre) - what the backward multiplies by; replaces the fp32 pre-activation save,
+  // half the bytes and no second activation evaluation), read by an EPI_DACT launch (dact_in instead of e.aux)
+  uint4* dact_out;
+  const unsigned short* dact_in;
+  int super_r, super_c;          // tile rasterisation: the 32 concurrent tiles of an XCD form super_r x super_c blocks
   EpiArgs e;
 };
 
@@ -58,8 +64,10 @@ __device__ __forceinline__ unsigned pack2(float lo, float hi) {
 // residual, optional fp32 store) but the final values go back into the LDS slab, from which the wave emits the bf16
 // row-form chunks (row, 8 consecutive columns), the transposed chunks (column, 8 consecutive rows) and the 32-row partial
 // column sums.  Vector path only (N % 4 == 0, aligned), M % 32 == 0.
+__device__ __forceinline__ unsigned long long ld8(const void* p) { return *reinterpret_cast<const unsigned long long*>(p); }
+
 __device__ __forceinline__ void epi_fragment_pack(const Bf16pArgs& p, int m0f, int n0f, const f32x16& acc, float* stage,
-                                                  int lane) {
+                                                  float* stage2, int lane) {
   const EpiArgs& e = p.e;
   const int li = lane & 31, kh = lane >> 5;
 #pragma unroll
@@ -82,12 +90,35 @@ __device__ __forceinline__ void epi_fragment_pack(const Bf16pArgs& p, int m0f, i
     }
     if (e.pre) *reinterpret_cast<float4*>(e.pre + (long long)m * e.ldpre + n) = make_float4(v[0], v[1], v[2], v[3]);
     if (e.mode == DPOT_EPI_ACT) {
+      if (p.dact_out) {
+        float d[4];
+        if (e.act == DPOT_ACT_GELU) {
 #pragma unroll
-      for (int k = 0; k < 4; ++k) v[k] = act_fwd(e.act, v[k]);
+          for (int k = 0; k < 4; ++k) gelu_val_der(v[k], v[k], d[k]);
+        } else {
+#pragma unroll
+          for (int k = 0; k < 4; ++k) { d[k] = act_bwd(e.act, v[k]); v[k] = act_fwd(e.act, v[k]); }
+        }
+        *reinterpret_cast<float4*>(&stage2[row * EPI_LD + c4]) = make_float4(d[0], d[1], d[2], d[3]);
+      } else {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) v[k] = act_fwd(e.act, v[k]);
+      }
     } else if (e.mode == DPOT_EPI_DACT) {
-      const Vec4 q = ld4(e.aux + (long long)m * e.ldaux + n, true);
+      if (p.dact_in) {
+        // the fragment's derivatives are 2 KiB contiguous: block pair (m0f/32, n0f/16 + {0,1}), chunk (row, octet)
+        const unsigned short* dp = p.dact_in + (((long long)(m0f >> 5) * (p.N >> 4) + (n0f >> 4) + (c4 >> 4)) * 64 +
+                                                row + 32 * ((c4 >> 3) & 1)) * 8 + (c4 & 4);
+        const unsigned long long q = ld8(dp);
+        v[0] *= __uint_as_float((unsigned)(q & 0xffffull) << 16);
+        v[1] *= __uint_as_float((unsigned)(q >> 16) << 16);
+        v[2] *= __uint_as_float((unsigned)(q >> 32) << 16);
+        v[3] *= __uint_as_float((unsigned)(q >> 48) << 16);
+      } else {
+        const Vec4 q = ld4(e.aux + (long long)m * e.ldaux + n, true);
 #pragma unroll
-      for (int k = 0; k < 4; ++k) v[k] *= act_bwd(e.act, q.v[k]);
+        for (int k = 0; k < 4; ++k) v[k] *= act_bwd(e.act, q.v[k]);
+      }
     }
     if (e.res) {
       const Vec4 q = ld4(e.res + (long long)m * e.ldres + n, true);
@@ -108,6 +139,17 @@ __device__ __forceinline__ void epi_fragment_pack(const Bf16pArgs& p, int m0f, i
       const float4 x1 = *reinterpret_cast<const float4*>(&stage[row * EPI_LD + 8 * oc + 4]);
       const int m = m0f + row, nn = n0f + 8 * oc;
       p.out_rows[((long long)(m >> 5) * (p.N >> 4) + (nn >> 4)) * 64 + (m & 31) + 32 * ((nn >> 3) & 1)] =
+          make_uint4(pack2(x0.x, x0.y), pack2(x0.z, x0.w), pack2(x1.x, x1.y), pack2(x1.z, x1.w));
+    }
+  }
+  if (p.dact_out) {     // the derivative, same chunking as out_rows, from the second staging slab
+#pragma unroll
+    for (int s2 = 0; s2 < 2; ++s2) {
+      const int id = lane + 64 * s2, row = id >> 2, oc = id & 3;
+      const float4 x0 = *reinterpret_cast<const float4*>(&stage2[row * EPI_LD + 8 * oc]);
+      const float4 x1 = *reinterpret_cast<const float4*>(&stage2[row * EPI_LD + 8 * oc + 4]);
+      const int m = m0f + row, nn = n0f + 8 * oc;
+      p.dact_out[((long long)(m >> 5) * (p.N >> 4) + (nn >> 4)) * 64 + (m & 31) + 32 * ((nn >> 3) & 1)] =
           make_uint4(pack2(x0.x, x0.y), pack2(x0.z, x0.w), pack2(x1.x, x1.y), pack2(x1.z, x1.w));
     }
   }
@@ -150,15 +192,30 @@ __device__ __forceinline__ void gemm_bf16p_body(const Bf16pArgs& p, const int bi
   int nslab = (p.K >> 5) - slab0;
   nslab = nslab < p.slabs_per_split ? nslab : p.slabs_per_split;
 
-  // XCD-contiguous tile order, column-tile major: workgroups sharing a weight chunk sit on one chiplet's L2
-  const int ntiles = p.tilesM * p.tilesN;
-  int tile;
-  {
+  int tm, tn;
+  if (p.super_r > 0) {
+    // L2-aware rasterisation.  Workgroup b runs on XCD b % 8, and an XCD's 32 CUs hold 32 consecutive slots b >> 3 at a
+    // time: those 32 concurrent tiles are made ONE super_r x super_c block of the tile grid (8 x 4: 8 A row tiles + 4 W
+    // column chunks feed 32 tiles through that chiplet's L2, against 32 + 1 for a column of tiles), and an XCD walks the
+    // super-blocks of ONE super-row before the next (its A slice stays L2-resident while the W chunks stream)
+    const int xcd = bid0 & 7, slot = bid0 >> 3;
+    const int sb = slot >> 5, in = slot & 31;                 // super-block number of this XCD, position inside
+    const int srows = p.tilesM / p.super_r, scols = p.tilesN / p.super_c;
+    const int g = sb * 8 + xcd;                               // global super-block index, super-row fastest ...
+    if (g >= srows * scols) return;                           // (grid padded to whole rounds of 8 super-blocks)
+    const int srow = g % srows, scol = g / srows;             // ... so XCD x keeps super-row (x mod srows)
+    tm = srow * p.super_r + in % p.super_r;
+    tn = scol * p.super_c + in / p.super_r;
+  } else {
+    // XCD-contiguous tile order, column-tile major: workgroups sharing a weight chunk sit on one chiplet's L2
+    const int ntiles = p.tilesM * p.tilesN;
+    int tile;
     const int bid = bid0, xcd = bid & 7, slot = bid >> 3;
     const int q = ntiles >> 3, r = ntiles & 7;
     tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + slot;
+    tn = tile / p.tilesM;
+    tm = tile - tn * p.tilesM;
   }
-  const int tn = tile / p.tilesM, tm = tile - tn * p.tilesM;
   const int rt0 = tm * PB_ROWT, ct0 = tn * PB_COLT;  // first 32-row tile / 32-column tile
   const int mtiles = (p.M + 31) >> 5;
 
@@ -287,14 +344,17 @@ __device__ __forceinline__ void gemm_bf16p_body(const Bf16pArgs& p, const int bi
       }
     return;
   }
-  if (p.out_rows || p.out_trans || p.cs_part) {        // host-checked: M % 32 == 0 -> every fragment is full or empty
+  if (p.out_rows || p.out_trans || p.cs_part || p.dact_out || p.dact_in) {   // host-checked: M % 32 == 0
+    // two staging slabs per wave (values, derivatives): 8 x 2 x 32 x EPI_LD floats = the 72 KiB of the ring exactly
+    float* st1 = reinterpret_cast<float*>(lds) + wave * (2 * 32 * EPI_LD);
+    float* st2 = st1 + 32 * EPI_LD;
     if (m0 < p.M) {
-      epi_fragment_pack(p, m0, n0, acc[0][0], stage, lane);
-      epi_fragment_pack(p, m0, n0 + 32, acc[0][1], stage, lane);
+      epi_fragment_pack(p, m0, n0, acc[0][0], st1, st2, lane);
+      epi_fragment_pack(p, m0, n0 + 32, acc[0][1], st1, st2, lane);
     }
     if (m0 + 32 < p.M) {
-      epi_fragment_pack(p, m0 + 32, n0, acc[1][0], stage, lane);
-      epi_fragment_pack(p, m0 + 32, n0 + 32, acc[1][1], stage, lane);
+      epi_fragment_pack(p, m0 + 32, n0, acc[1][0], st1, st2, lane);
+      epi_fragment_pack(p, m0 + 32, n0 + 32, acc[1][1], st1, st2, lane);
     }
     return;
   }
@@ -704,17 +764,32 @@ extern "C" int dpot_gemm_bf16p_splitk(int M, int N, int K) {
   return s < 1 ? 1 : (int)s;
 }
 
+// super-block shape (rows x columns of tiles, product 32) for the L2-aware rasterisation, or 0 x 0: the most square
+// shape that divides the tile grid; needs more than one round of workgroups to matter.  DPOT_BF16P_RASTER=0 disables it.
+static void bf16p_pick_super(int tilesM, int tilesN, int splits, int* sr, int* sc) {
+  static const int enabled = [] { const char* e = getenv("DPOT_BF16P_RASTER"); return e ? atoi(e) : 1; }();
+  *sr = 0; *sc = 0;
+  if (!enabled || splits > 1 || (long long)tilesM * tilesN < 512) return;
+  static const int cand[6][2] = {{8, 4}, {4, 8}, {16, 2}, {2, 16}, {32, 1}, {1, 32}};
+  for (int i = 0; i < 6; ++i)
+    if (tilesM % cand[i][0] == 0 && tilesN % cand[i][1] == 0) { *sr = cand[i][0]; *sc = cand[i][1]; return; }
+}
+
 extern "C" int dpot_gemm_bf16p(const void* Apacked, const void* Wpacked, const float* bias, const float* aux, int ldaux,
                                const float* res, int ldres, float* pre, int ldpre, float* C, int ldc, int M, int N, int K,
                                int act, int epi_mode, int planes, int splitk, float* workspace, void* out_rows,
-                               void* out_trans, float* colsum_part, dpot_stream_t stream) {
-  const bool packs = out_rows || out_trans || colsum_part;
+                               void* out_trans, float* colsum_part, void* dact_out, const void* dact_in,
+                               dpot_stream_t stream) {
+  const bool packs = out_rows || out_trans || colsum_part || dact_out || dact_in;
+  DPOT_REQUIRE(!dact_out || epi_mode == DPOT_EPI_ACT, "gemm_bf16p: dact_out needs the activation epilogue");
+  DPOT_REQUIRE(!dact_in || epi_mode == DPOT_EPI_DACT, "gemm_bf16p: dact_in needs the act' epilogue");
+  DPOT_REQUIRE(aligned16(dact_out) && aligned16(dact_in), "gemm_bf16p: derivative packs must be 16-byte aligned");
   DPOT_REQUIRE(Apacked && Wpacked && (C || packs), "gemm_bf16p: null operand");
   DPOT_REQUIRE(!packs || (planes == 1 && splitk <= 1 && M % 32 == 0 && aligned16(out_rows) && aligned16(out_trans)),
                "gemm_bf16p: packed outputs need planes == 1, no split-K and M %% 32 == 0");
   DPOT_REQUIRE(planes == 1 || planes == 3, "gemm_bf16p: planes must be 1 (plain bf16) or 3 (bf16x6, fp32-accurate)");
   DPOT_REQUIRE(dpot_gemm_bf16p_supported(M, N, K), "gemm_bf16p: unsupported shape M=%d N=%d K=%d (N %% 256, K %% 32)", M, N, K);
-  DPOT_REQUIRE(epi_mode == DPOT_EPI_LINEAR || epi_mode == DPOT_EPI_ACT || (epi_mode == DPOT_EPI_DACT && aux),
+  DPOT_REQUIRE(epi_mode == DPOT_EPI_LINEAR || epi_mode == DPOT_EPI_ACT || (epi_mode == DPOT_EPI_DACT && (aux || dact_in)),
                "gemm_bf16p: bad epilogue mode");
   DPOT_REQUIRE(ldc >= N && ldc % 4 == 0 && (!aux || ldaux % 4 == 0) && (!res || ldres % 4 == 0) && (!pre || ldpre % 4 == 0),
                "gemm_bf16p: leading dimensions must be multiples of 4");
@@ -745,12 +820,16 @@ extern "C" int dpot_gemm_bf16p(const void* Apacked, const void* Wpacked, const f
   p.out_rows = reinterpret_cast<uint4*>(out_rows);
   p.out_trans = reinterpret_cast<uint4*>(out_trans);
   p.cs_part = colsum_part;
+  p.dact_out = reinterpret_cast<uint4*>(dact_out);
+  p.dact_in = reinterpret_cast<const unsigned short*>(dact_in);
+  unsigned grid = (unsigned)(p.tilesM * p.tilesN);
+  bf16p_pick_super(p.tilesM, p.tilesN, p.splits, &p.super_r, &p.super_c);
+  if (p.super_r > 0) grid = 256u * (unsigned)((p.tilesM * p.tilesN / 32 + 7) / 8);
   if (planes == 3)
     hipLaunchKernelGGL(gemm_bf16x6p_kernel, dim3((unsigned)(p.tilesM * p.tilesN), p.splits), dim3(512), 0,
                        as_stream(stream), p);
   else
-    hipLaunchKernelGGL(gemm_bf16p_kernel, dim3((unsigned)(p.tilesM * p.tilesN), p.splits), dim3(64 * (8 + PB_NLOAD)), 0,
-                       as_stream(stream), p);
+    hipLaunchKernelGGL(gemm_bf16p_kernel, dim3(grid, p.splits), dim3(64 * (8 + PB_NLOAD)), 0, as_stream(stream), p);
   int rc = check_launch("gemm_bf16p_kernel");
   if (rc != DPOT_OK || p.splits == 1) return rc;
   const long long total = (long long)M * N;
@@ -829,6 +908,7 @@ extern "C" int dpot_gemm_bf16p_pair(const void* A0, const void* W0, float* C0, i
     p.slabs_per_split = sps;
     p.ws = wss[i];
     p.out_rows = nullptr; p.out_trans = nullptr; p.cs_part = nullptr;
+    p.dact_out = nullptr; p.dact_in = nullptr; p.super_r = 0; p.super_c = 0;
   }
   pp.n0 = pp.a[0].tilesM * pp.a[0].tilesN;
   const unsigned grid = (unsigned)(pp.n0 + pp.a[1].tilesM * pp.a[1].tilesN);

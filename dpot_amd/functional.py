@@ -415,8 +415,10 @@ def _block_parts(x, n1w, n1b, n2w, n2b, f1w, f1b, packed, dims, mp, need_out, f2
         xp, xpT, _ = ops.bf16_pack_both(xn2.view(M, E))
         del xn2
         # fc1: the epilogue emits the activated hidden layer directly in its two packed forms (no fp32 copy of it exists)
+        # (Hpre here = act'(pre-activation) as a bf16 pack: all the backward needs of it, at half the bytes of the fp32
+        # pre-activation and without a second activation evaluation)
         _, Hpre, hp, hpT, _ = ops.gemm_bf16p_packed(xp, mlp_pk[0], M, mh, E, bias=f1b, act=act, mode=EPI_ACT,
-                                                    save_pre=True, pack_rows=need_out, pack_trans=True, store=False)
+                                                    save_dact=True, pack_rows=need_out, pack_trans=True, store=False)
         out = None
         if need_out:
             out, _ = ops.gemm_bf16p(hp, mlp_pk[2], M, E, mh, bias=f2b, res=x.view(M, E))
@@ -524,7 +526,7 @@ class BlockFn(torch.autograd.Function):
             if not pair:
                 df2w, _ = ops.gemm_bf16p(dopT, Hh, E, mh, M, out=s_f2w.out())
             # dHpre = (do2 W2) * act'(Hpre) leaves the GEMM as its two packs + bias column sums only
-            _, _, dhp, dhpT, df1b = ops.gemm_bf16p_packed(dop, mlp_pk[3], M, mh, E, act=act, mode=EPI_DACT, aux=Hpre,
+            _, _, dhp, dhpT, df1b = ops.gemm_bf16p_packed(dop, mlp_pk[3], M, mh, E, act=act, mode=EPI_DACT, dact=Hpre,
                                                           pack_rows=True, pack_trans=True, colsum=True,
                                                           colsum_out=s_f1b.out(), store=False)
             if pair:

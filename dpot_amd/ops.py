@@ -281,12 +281,15 @@ def gemm_bf16p_packed(Ap: Tensor, Wp: Tensor, M: int, N: int, K: int, *, bias: O
                       mode: int = EPI_LINEAR, aux: Optional[Tensor] = None, res: Optional[Tensor] = None,
                       save_pre: bool = False, out: Optional[Tensor] = None, splitk: Optional[int] = None,
                       planes: int = 1, pack_rows: bool = False, pack_trans: bool = False, colsum: bool = False,
-                      colsum_out: Optional[Tensor] = None, store: bool = True):
+                      colsum_out: Optional[Tensor] = None, store: bool = True, save_dact: bool = False,
+                      dact: Optional[Tensor] = None):
     """gemm_bf16p whose epilogue can ALSO emit the packed forms of the output and its column sums
     (pack_rows / pack_trans / colsum: planes == 1, M % 32 == 0, no split-K); store=False skips the fp32 output.
-    Always returns (C | None, pre | None, row pack | None, transposed pack | None, column sums | None)."""
+    save_dact (EPI_ACT): instead of the fp32 pre-activation, the second return value is act'(pre) as a packed bf16
+    tensor - pass it as `dact` to the EPI_DACT launch of the backward (replaces aux).
+    Always returns (C | None, pre or act' pack | None, row pack | None, transposed pack | None, column sums | None)."""
     lib = _lib.load()
-    packs = pack_rows or pack_trans or colsum
+    packs = pack_rows or pack_trans or colsum or save_dact or dact is not None
     C_ = _out(out, (M, N), Ap.device) if (store or not packs) else None
     pre = torch.empty(M, N, dtype=torch.float32, device=Ap.device) if save_pre else None
     if splitk is None:
@@ -295,12 +298,14 @@ def gemm_bf16p_packed(Ap: Tensor, Wp: Tensor, M: int, N: int, K: int, *, bias: O
     pr = torch.empty(lib.dpot_bf16_packed_elems(M, N, 1), dtype=torch.bfloat16, device=Ap.device) if pack_rows else None
     pt = torch.empty(lib.dpot_bf16_packed_elems(N, M, 1), dtype=torch.bfloat16, device=Ap.device) if pack_trans else None
     part = torch.empty(M // 32, N, dtype=torch.float32, device=Ap.device) if colsum else None
+    dout = torch.empty(lib.dpot_bf16_packed_elems(M, N, 1), dtype=torch.bfloat16, device=Ap.device) if save_dact else None
     check(lib.dpot_gemm_bf16p(Ap.data_ptr(), Wp.data_ptr(), _p(bias), _p(aux),
                               aux.stride(0) if aux is not None else 0, _p(res),
                               res.stride(0) if res is not None else 0, _p(pre), N, _p(C_), N, M, N, K,
-                              act, mode, planes, splitk, _p(ws), _p(pr), _p(pt), _p(part), _stream()), "gemm_bf16p")
+                              act, mode, planes, splitk, _p(ws), _p(pr), _p(pt), _p(part), _p(dout), _p(dact),
+                              _stream()), "gemm_bf16p")
     cs = globals()["colsum"](part, M // 32, N, out=colsum_out) if colsum else None
-    return C_, pre, pr, pt, cs
+    return C_, (dout if save_dact else pre), pr, pt, cs
 
 
 def small_linear_supported(M: int, N: int, K: int) -> bool:

@@ -446,7 +446,7 @@ int dpot_gemm_bf16p_supported(int M, int N, int K);
 int dpot_gemm_bf16p(const void* Apacked, const void* Wpacked, const float* bias, const float* aux, int ldaux,
                     const float* res, int ldres, float* pre, int ldpre, float* C, int ldc, int M, int N, int K, int act,
                     int epi_mode, int planes, int splitk, float* workspace, void* out_rows, void* out_trans,
-                    float* colsum_part, dpot_stream_t stream);
+                    float* colsum_part, void* dact_out, const void* dact_in, dpot_stream_t stream);
 /* two independent products of that kind (plain bf16 operands, common K, linear epilogue, no split-K) in ONE launch:
  * the fc1 / fc2 weight gradients of a block, which alone have too few tiles for 256 CUs and would each go through
  * split-K partials + a reduce launch.  _wanted: 1 when each alone would be split and together they fill the chip. */
@@ -459,7 +459,10 @@ int dpot_gemm_bf16p_pair(const void* A0, const void* W0, float* C0, int ldc0, in
                          dpot_stream_t stream);
 /* out_rows / out_trans / colsum_part (all optional, planes == 1, splitk <= 1, M % 32 == 0): the epilogue also emits the
  * 1-plane packs of the FINAL output (row form [M, N]; transposed form = rows N, k M) and partial column sums
- * [M/32, N] - the next GEMMs of a chain then need no pack pass over this output; C may be NULL in that case. */
+ * [M/32, N] - the next GEMMs of a chain then need no pack pass over this output; C may be NULL in that case.
+ * dact_out (EPI_ACT launches): act'(pre-activation) as bf16 in the row-form pack layout of [M, N] - what the backward
+ * of Block.mlp (models/dpot.py:157-161) multiplies by; it replaces the fp32 `pre` save at half the bytes.
+ * dact_in (EPI_DACT launches): that buffer, used instead of act'(aux).  Same restrictions as the packed outputs. */
 /* split-K factor the library recommends for a shape (weight gradients: few output tiles, K = tokens); splitk > 1 needs
  * a workspace of splitk*M*N floats, summed in a fixed order by a second launch (deterministic) */
 int dpot_gemm_bf16p_splitk(int M, int N, int K);

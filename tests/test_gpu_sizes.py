@@ -87,15 +87,17 @@ def test_full_model_gradients_vs_oracle(name, B):
 
 # Tolerance of the OPT-IN reduced-precision channel MLP (`set_mlp_precision("bf16")`, BASELINE configs[2] "bf16
 # channel-MLP on MFMA" and the DPOT-M/L headline mode).  Both operands of fc1 / fc2 (forward, data gradient, weight
-# gradient) are rounded to bf16 (8-bit significand, unit round-off u = 2^-9 = 1.95e-3), products exact, fp32
-# accumulation.  A K-term dot product of rounded operands carries a relative error of about u*sqrt(2/3) = 1.6e-3 of
-# sqrt(sum of squared terms); a block adds its MLP branch to the residual stream, so over `depth` blocks the error of
-# the latent grows like sqrt(depth) (random signs): 1.6e-3 * sqrt(24) = 8e-3 at DPOT-L, and a gradient passes through
-# the chain twice (forward activations + backward products).  Bound used: NORM-WISE  ||hip - oracle|| / ||oracle||
-# <= 2e-2 for outputs and dx, <= 3e-2 per parameter gradient (element-wise bounds are meaningless at this precision).
-# Everything outside the channel MLP stays fp32 - the fp32 test above is the parity gate; this one bounds the mode.
-BF16_OUT_TOL = 2e-2
-BF16_GRAD_TOL = 3e-2
+# gradient) are rounded to bf16 (8-bit significand, unit round-off u = 2^-9 = 1.95e-3), as is the saved activation
+# derivative; products exact, fp32 accumulation.  A K-term dot product of rounded operands carries a relative error of
+# about u*sqrt(2/3) = 1.6e-3 of sqrt(sum of squared terms); each block adds its MLP branch to the residual stream, so the
+# error of the latent - and of every gradient, which passes the chain forward AND backward - grows like sqrt(depth)
+# (independent roundings).  Measured on MI355X (norm-wise ||hip - oracle|| / ||oracle||, worst parameter gradient):
+# Tiny 1.0e-2, Small 1.1e-2, Medium 1.5e-2, Large 2.7e-2 = (4.3 .. 5.6)e-3 * sqrt(depth); dx (3.1 .. 4.0)e-3 * sqrt(depth);
+# prediction 5e-3 .. 6.5e-3.  Bounds = those laws with 1.5x headroom; element-wise bounds are meaningless at this
+# precision.  Everything outside the channel MLP stays fp32 - the fp32 test above is the parity gate, this bounds the mode.
+BF16_OUT_TOL = 2e-2                          # prediction, cls
+BF16_DX_PER_SQRT_DEPTH = 6e-3
+BF16_GRAD_PER_SQRT_DEPTH = 8e-3
 
 
 def _nrel(a, b):
@@ -131,8 +133,9 @@ def test_bf16_channel_mlp_mode_vs_oracle(name, B, bf16_mlp):
             worst, worst_k = e, k
     print(f"[{name} B={B} bf16-MLP] norm-wise error: pred {e_y:.2e} cls {e_c:.2e} dx {e_dx:.2e}; worst parameter "
           f"gradient {worst:.2e} ({worst_k})")
-    assert e_y <= BF16_OUT_TOL and e_c <= BF16_OUT_TOL and e_dx <= BF16_OUT_TOL
-    assert worst <= BF16_GRAD_TOL, worst_k
+    sd = cfg.depth ** 0.5
+    assert e_y <= BF16_OUT_TOL and e_c <= BF16_OUT_TOL and e_dx <= BF16_DX_PER_SQRT_DEPTH * sd
+    assert worst <= BF16_GRAD_PER_SQRT_DEPTH * sd, worst_k
     # and it IS a reduced-precision mode: not bit-identical to fp32 parity
     assert e_y > 1e-6
 
