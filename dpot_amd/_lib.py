@@ -81,6 +81,11 @@ SIGNATURES = {
     "dpot_groupnorm_fwd": (c_i, [c_fp] * 7 + [c_i] * 4 + [c_f, c_fp]),
     "dpot_groupnorm_bwd": (c_i, [c_fp] * 11 + [c_i] * 4 + [c_fp]),
     "dpot_groupnorm_param_grads": (c_i, [C.c_void_p] * 3 + [c_i] * 3 + [c_fp]),
+    "dpot_gn_dft_supported": (c_i, [c_i] * 4),
+    "dpot_gn_rfft2": (c_i, [c_fp] * 6 + [c_i] * 8 + [c_f, c_fp]),
+    "dpot_irfft2_gn": (c_i, [c_fp] * 12 + [c_i] * 9 + [c_f, c_fp]),
+    "dpot_gn_bwd_rfft2": (c_i, [c_fp] * 8 + [c_i] * 9 + [c_fp]),
+    "dpot_irfft2_gn_bwd": (c_i, [c_fp] * 9 + [c_i] * 9 + [c_fp]),
     "dpot_patchify": (c_i, [c_fp] * 5 + [c_i] * 6 + [c_fp]),
     "dpot_unpatchify": (c_i, [c_fp] * 2 + [c_i] * 6 + [c_fp]),
     "dpot_pixel_shuffle": (c_i, [c_fp] * 2 + [c_i] * 6 + [c_fp]),
@@ -122,6 +127,7 @@ SIGNATURES = {
     "dpot_bf16_pack_rows": (c_i, [c_fp, c_i, c_i, c_i, c_i, c_i, c_fp, c_fp]),
     "dpot_bf16_pack_jobs": (c_i, [c_fp, c_i, c_i, c_i, c_fp]),
     "dpot_gemm_bf16p_supported": (c_i, [c_i, c_i, c_i]),
+    "dpot_gemm_bf16p_tile_rows": (c_i, [c_i] * 5),
     "dpot_gemm_bf16p": (c_i, [c_fp, c_fp, c_fp, c_fp, c_i, c_fp, c_i, c_fp, c_i, c_fp, c_i] + [c_i] * 7 + [c_fp] * 7),
     "dpot_gemm_bf16p_splitk": (c_i, [c_i, c_i, c_i]),
     "dpot_gemm_bf16p_pair_wanted": (c_i, [c_i] * 5),

@@ -238,6 +238,7 @@ __global__ __launch_bounds__(256) void irfft2_fast_kernel(const float* __restric
   }
 }
 
+#ifndef DPOT_DFT_NO_KERNELS   // (csrc/gn_dft.hip uses the register FFTs above only)
 template <int H, int W, int CC>
 static int launch_rfft2_fast(const float* x, float* spec, int B, int E, int nb, int mx, int my, int colw, float scale,
                              hipStream_t s) {
@@ -293,5 +294,6 @@ static inline int try_irfft2_fast(const float* spec, const float* res, float* y,
   }
   return 0;
 }
+#endif  // DPOT_DFT_NO_KERNELS
 
 }  // namespace dpot

@@ -288,14 +288,13 @@ def _mlp_panel_mode(mlp_pk, M, E, mh, mp) -> int:
     return 2 if ok else 0
 
 
-def _mixer_fwd(xn1, packed, dims, afno_layout=None):
-    """AFNO2D.forward on a [B, tok, E] field (models/dpot.py:51-110): rfft2 -> block-diagonal complex 2-layer MLP on the
-    kept modes -> irfft2 + x_orig.  Returns (y1, S, O1pre, O1); shared by BlockFn and AFNO2DFn."""
+def _mixer_core(S, packed, dims, afno_layout=None):
+    """the block-diagonal complex 2-layer MLP on the kept modes (models/dpot.py:72-94): spectrum S [Mm, 2E] ->
+    (O2, O1pre, O1)"""
     B, tok, E, h, w, nb, bs, mx, my, mh, act = dims
     Mm = B * mx * my
-    dev = xn1.device
+    dev = S.device
     (wb1, bb1, wb1T, _), (wb2, bb2, wb2T, _) = packed          # w*T: fragment-block-major W for the fused kernel
-    S = ops.rfft2(xn1, h, w, nb, mx, my, 0)                                # [Mm, 2E]
     if wb1T is not None:
         # both layers of the block-diagonal complex MLP in ONE launch; the activated spectrum never leaves the CU
         # except as the copy saved for the backward (csrc/afno_mlp.hip)
@@ -312,18 +311,26 @@ def _mixer_fwd(xn1, packed, dims, afno_layout=None):
                  stridePre=2 * bs, **kw)
         O2 = torch.empty_like(O1)
         ops.gemm(O1, wb2, O2, Mm, 2 * bs, 2 * bs, bias=bb2, **kw)
+    return O2, O1pre, O1
+
+
+def _mixer_fwd(xn1, packed, dims, afno_layout=None):
+    """AFNO2D.forward on a [B, tok, E] field (models/dpot.py:51-110): rfft2 -> block-diagonal complex 2-layer MLP on the
+    kept modes -> irfft2 + x_orig.  Returns (y1, S, O1pre, O1); shared by BlockFn and AFNO2DFn."""
+    B, tok, E, h, w, nb, bs, mx, my, mh, act = dims
+    S = ops.rfft2(xn1, h, w, nb, mx, my, 0)                                # [Mm, 2E]
+    O2, O1pre, O1 = _mixer_core(S, packed, dims, afno_layout)
     y1 = ops.irfft2(O2, B, h, w, E, nb, mx, my, 1, res=xn1)                # + x_orig (the normalised input)
     return y1, S, O1pre, O1
 
 
-def _mixer_bwd(dy1, S, O1pre, O1, wb1, wb2, dims, fused, afno_layout, sinks):
-    """backward of _mixer_fwd: returns (dxn1 = adjoint-rfft2(dS) + dy1, dw1, db1, dw2, db2); wb1 / wb2: the
-    fragment-block-major W^T (fused kernel) or the plain Wbig (generic GEMM); sinks = (s_w1, s_b1, s_w2, s_b2)"""
+def _mixer_core_bwd(dO2, S, O1pre, O1, wb1, wb2, dims, fused, afno_layout, sinks):
+    """backward of _mixer_core: dO2 [Mm, 2E] -> (dS, dw1, db1, dw2, db2); wb1 / wb2: the fragment-block-major W^T (fused
+    kernel) or the plain Wbig (generic GEMM); sinks = (s_w1, s_b1, s_w2, s_b2)"""
     B, tok, E, h, w, nb, bs, mx, my, mh, act = dims
     s_w1, s_b1, s_w2, s_b2 = sinks
     Mm = B * mx * my
-    dev = dy1.device
-    dO2 = ops.rfft2(dy1, h, w, nb, mx, my, 1)                              # adjoint of irfft2
+    dev = dO2.device
     kw = dict(lda=2 * E, ldb=2 * bs, ldc=2 * E, batch=nb, strideA=2 * bs, strideB=4 * bs * bs, strideC=2 * bs)
     sk = max(2, ops.auto_splitk(2 * bs, 2 * bs, Mm, nb, tn=True))
     wkw = dict(transA=True, lda=2 * E, ldb=2 * E, ldc=2 * bs, batch=nb, strideA=2 * bs, strideB=2 * bs,
@@ -356,6 +363,14 @@ def _mixer_bwd(dy1, S, O1pre, O1, wb1, wb2, dims, fused, afno_layout, sinks):
     if not fused:
         dS = torch.empty(Mm, 2 * E, dtype=torch.float32, device=dev)
         ops.gemm(dO1pre, wb1, dS, Mm, 2 * bs, 2 * bs, transB=True, **kw)
+    return dS, dw1, db1, dw2, db2
+
+
+def _mixer_bwd(dy1, S, O1pre, O1, wb1, wb2, dims, fused, afno_layout, sinks):
+    """backward of _mixer_fwd: returns (dxn1 = adjoint-rfft2(dS) + dy1, dw1, db1, dw2, db2)"""
+    B, tok, E, h, w, nb, bs, mx, my, mh, act = dims
+    dO2 = ops.rfft2(dy1, h, w, nb, mx, my, 1)                              # adjoint of irfft2
+    dS, dw1, db1, dw2, db2 = _mixer_core_bwd(dO2, S, O1pre, O1, wb1, wb2, dims, fused, afno_layout, sinks)
     dxn1 = ops.irfft2(dS, B, h, w, E, nb, mx, my, 0, res=dy1)              # adjoint of rfft2, + skip path
     return dxn1, dw1, db1, dw2, db2
 
@@ -400,10 +415,18 @@ def _block_parts(x, n1w, n1b, n2w, n2b, f1w, f1b, packed, dims, mp, need_out, f2
     B, tok, E, h, w, nb, bs, mx, my, mh, act = dims
     Mm, M = B * mx * my, B * tok
     dev = x.device
-    xn1, mean1, rstd1 = ops.groupnorm_fwd(x, n1w, n1b)
-    y1, S, O1pre, O1 = _mixer_fwd(xn1, packed, dims, afno_layout)
-    del xn1
-    xn2, mean2, rstd2 = ops.groupnorm_fwd(y1, n2w, n2b)
+    if ops.gn_dft_supported(h, w, E):
+        # GroupNorm fused with the neighbouring DFT (csrc/gn_dft.hip): norm1 + rfft2, and irfft2 + x_orig + norm2 -
+        # two launches around the mixer instead of four, GroupNorm1(x) never written
+        S, mean1, rstd1 = ops.gn_rfft2(x, n1w, n1b, h, w, nb, mx, my)
+        O2, O1pre, O1 = _mixer_core(S, packed, dims, afno_layout)
+        y1, xn2, mean2, rstd2 = ops.irfft2_gn(O2, x, mean1, rstd1, n1w, n1b, n2w, n2b, h, w, nb, mx, my)
+        del O2
+    else:
+        xn1, mean1, rstd1 = ops.groupnorm_fwd(x, n1w, n1b)
+        y1, S, O1pre, O1 = _mixer_fwd(xn1, packed, dims, afno_layout)
+        del xn1
+        xn2, mean2, rstd2 = ops.groupnorm_fwd(y1, n2w, n2b)
     panel = _mlp_panel_mode(mlp_pk, M, E, mh, mp)
     npl = mlp_pk.planes if panel == 2 else 0
     both = (panel == 2 and npl == 1 and os.environ.get("DPOT_PACK_BOTH", "1") != "0"
@@ -567,11 +590,20 @@ class BlockFn(torch.autograd.Function):
             else:
                 dxn2 = ops.linear_bwd_data(dHpre, f1w, precision=mp)               # [M, E]
         # parameter-gradient partials of norm2 are reduced together with norm1's at the end of the block (one launch)
-        dy1, gn2_part = ops.groupnorm_bwd(dxn2.view(B, tok, E), y1, mean2, rstd2, n2w, defer=True)
-        # AFNO mixer
-        dxn1, dw1, db1, dw2, db2 = _mixer_bwd(dy1, S, O1pre, O1, wb1, wb2, ctx.dims, ctx.fused_mixer, ctx.afno_layout,
-                                              (s_w1, s_b1, s_w2, s_b2))
-        dx, gn1_part = ops.groupnorm_bwd(dxn1, x, mean1, rstd1, n1w, add=dout, defer=True)
+        if ops.gn_dft_supported(h, w, E):
+            # norm2 backward + rfft2 (adjoint of the forward irfft2), then irfft2 (adjoint) + skip + norm1 backward + outer
+            # skip: two launches around the mixer's backward (csrc/gn_dft.hip)
+            dy1, gn2_part, dO2 = ops.gn_bwd_rfft2(dxn2.view(B, tok, E), y1, mean2, rstd2, n2w, h, w, nb, mx, my,
+                                                  col_weights=1)
+            dS, dw1, db1, dw2, db2 = _mixer_core_bwd(dO2, S, O1pre, O1, wb1, wb2, ctx.dims, ctx.fused_mixer,
+                                                     ctx.afno_layout, (s_w1, s_b1, s_w2, s_b2))
+            dx, gn1_part = ops.irfft2_gn_bwd(dS, dy1, x, mean1, rstd1, n1w, h, w, nb, mx, my, add=dout, col_weights=0)
+        else:
+            dy1, gn2_part = ops.groupnorm_bwd(dxn2.view(B, tok, E), y1, mean2, rstd2, n2w, defer=True)
+            # AFNO mixer
+            dxn1, dw1, db1, dw2, db2 = _mixer_bwd(dy1, S, O1pre, O1, wb1, wb2, ctx.dims, ctx.fused_mixer,
+                                                  ctx.afno_layout, (s_w1, s_b1, s_w2, s_b2))
+            dx, gn1_part = ops.groupnorm_bwd(dxn1, x, mean1, rstd1, n1w, add=dout, defer=True)
         (dn1w, dn1b), (dn2w, dn2b) = ops.groupnorm_param_grads([(gn1_part, s_n1w.out(), s_n1b.out()),
                                                                 (gn2_part, s_n2w.out(), s_n2b.out())])
         dn1w, dn1b = s_n1w.done(dn1w), s_n1b.done(dn1b)

@@ -613,6 +613,65 @@ def groupnorm_param_grads(jobs):
 
 
 # ------------------------------------------------------------------------------------------------------
+# GroupNorm fused with the mixer's DFTs (csrc/gn_dft.hip)
+# ------------------------------------------------------------------------------------------------------
+def gn_dft_supported(h: int, w: int, E: int, G: int = 8) -> bool:
+    """16x16 latent grid and 64 / 128 channels per group (DPOT-Tiny / -Small / -Medium at 128^2); DPOT_GN_DFT=0 disables"""
+    return bool(_lib.load().dpot_gn_dft_supported(h, w, E, G))
+
+
+def gn_rfft2(x: Tensor, gamma: Tensor, beta: Tensor, h: int, w: int, nb: int, mx: int, my: int, G: int = 8,
+             eps: float = 1e-5):
+    """(spec [B*mx*my, 2E] = rfft2(GroupNorm(x)), mean [B,G], rstd [B,G]) in one launch; GroupNorm(x) is not written"""
+    B, _, E = x.shape
+    spec = torch.empty(B * mx * my, 2 * E, dtype=torch.float32, device=x.device)
+    mean = torch.empty(B, G, dtype=torch.float32, device=x.device)
+    rstd = torch.empty(B, G, dtype=torch.float32, device=x.device)
+    check(_lib.load().dpot_gn_rfft2(x.data_ptr(), gamma.data_ptr(), beta.data_ptr(), spec.data_ptr(), mean.data_ptr(),
+                                    rstd.data_ptr(), B, h, w, E, G, nb, mx, my, eps, _stream()), "gn_rfft2")
+    return spec, mean, rstd
+
+
+def irfft2_gn(spec: Tensor, x: Tensor, mean1: Tensor, rstd1: Tensor, g1: Tensor, b1: Tensor, g2: Tensor, b2: Tensor,
+              h: int, w: int, nb: int, mx: int, my: int, G: int = 8, eps: float = 1e-5, col_weights: int = 1):
+    """(y1 = irfft2(spec) + GroupNorm1(x), xn2 = GroupNorm2(y1), mean2, rstd2) in one launch"""
+    B, _, E = x.shape
+    y1, xn2 = torch.empty_like(x), torch.empty_like(x)
+    mean2 = torch.empty(B, G, dtype=torch.float32, device=x.device)
+    rstd2 = torch.empty(B, G, dtype=torch.float32, device=x.device)
+    check(_lib.load().dpot_irfft2_gn(spec.data_ptr(), x.data_ptr(), mean1.data_ptr(), rstd1.data_ptr(), g1.data_ptr(),
+                                     b1.data_ptr(), g2.data_ptr(), b2.data_ptr(), y1.data_ptr(), xn2.data_ptr(),
+                                     mean2.data_ptr(), rstd2.data_ptr(), B, h, w, E, G, nb, mx, my, col_weights, eps,
+                                     _stream()), "irfft2_gn")
+    return y1, xn2, mean2, rstd2
+
+
+def gn_bwd_rfft2(dy: Tensor, xin: Tensor, mean: Tensor, rstd: Tensor, gamma: Tensor, h: int, w: int, nb: int, mx: int,
+                 my: int, G: int = 8, col_weights: int = 1):
+    """(dx = GroupNorm backward of dy, part [2,B,E], spec = rfft2(dx; col_weights)) in one launch"""
+    B, _, E = xin.shape
+    dx = torch.empty_like(xin)
+    part = torch.empty(2, B, E, dtype=torch.float32, device=xin.device)
+    spec = torch.empty(B * mx * my, 2 * E, dtype=torch.float32, device=xin.device)
+    check(_lib.load().dpot_gn_bwd_rfft2(dy.data_ptr(), xin.data_ptr(), mean.data_ptr(), rstd.data_ptr(), gamma.data_ptr(),
+                                        dx.data_ptr(), part.data_ptr(), spec.data_ptr(), B, h, w, E, G, nb, mx, my,
+                                        col_weights, _stream()), "gn_bwd_rfft2")
+    return dx, part, spec
+
+
+def irfft2_gn_bwd(spec: Tensor, res: Tensor, xin: Tensor, mean: Tensor, rstd: Tensor, gamma: Tensor, h: int, w: int,
+                  nb: int, mx: int, my: int, add: Optional[Tensor] = None, G: int = 8, col_weights: int = 0):
+    """(dx = GroupNorm backward of (irfft2(spec; col_weights) + res) (+ add), part [2,B,E]) in one launch"""
+    B, _, E = xin.shape
+    dx = torch.empty_like(xin)
+    part = torch.empty(2, B, E, dtype=torch.float32, device=xin.device)
+    check(_lib.load().dpot_irfft2_gn_bwd(spec.data_ptr(), res.data_ptr(), xin.data_ptr(), mean.data_ptr(), rstd.data_ptr(),
+                                         gamma.data_ptr(), _p(add), dx.data_ptr(), part.data_ptr(), B, h, w, E, G, nb, mx,
+                                         my, col_weights, _stream()), "irfft2_gn_bwd")
+    return dx, part
+
+
+# ------------------------------------------------------------------------------------------------------
 # data movement / small ops
 # ------------------------------------------------------------------------------------------------------
 def patchify(x: Tensor, gx: Tensor, gy: Tensor, gt: Tensor, P: int) -> Tensor:

@@ -220,6 +220,32 @@ int dpot_groupnorm_param_grads(const float* const* parts, float* const* dgammas,
                                int B, int E, dpot_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * GroupNorm fused with the neighbouring DFT of the AFNO mixer (csrc/gn_dft.hip; models/dpot.py:165-175 runs
+ * norm1 -> AFNO2D(rfft2 .. irfft2 + x_orig) -> norm2 as separate modules).  16 x 16 latent grid, E/G in {64, 128}
+ * (dpot_gn_dft_supported); layouts as dpot_groupnorm_* / dpot_rfft2 / dpot_irfft2.
+ *   gn_rfft2       spec = rfft2_ortho(GroupNorm(x; gamma, beta)), kept modes; mean / rstd [B,G] out.  GroupNorm(x)
+ *                  itself is not written: consumers re-derive it from x and the statistics.
+ *   irfft2_gn      y1 = irfft2_ortho(spec; col_weights) + GroupNorm1(x) (from x, mean1, rstd1, gamma1, beta1);
+ *                  xn2 = GroupNorm2(y1); mean2 / rstd2 out.
+ *   gn_bwd_rfft2   dx = GroupNorm backward of dy at input xin (statistics given), part [2,B,E] = per-sample partials
+ *                  of (dgamma, dbeta) as dpot_groupnorm_bwd leaves them; spec = rfft2_ortho(dx; col_weights).
+ *   irfft2_gn_bwd  d = irfft2_ortho(spec; col_weights) + res, dx = GroupNorm backward of d at input xin (+ add), part.
+ * ------------------------------------------------------------------------------------------------ */
+int dpot_gn_dft_supported(int h, int w, int E, int G);
+int dpot_gn_rfft2(const float* x, const float* gamma, const float* beta, float* spec, float* mean, float* rstd, int B,
+                  int h, int w, int E, int G, int nb, int mx, int my, float eps, dpot_stream_t stream);
+int dpot_irfft2_gn(const float* spec, const float* x, const float* mean1, const float* rstd1, const float* gamma1,
+                   const float* beta1, const float* gamma2, const float* beta2, float* y1, float* xn2, float* mean2,
+                   float* rstd2, int B, int h, int w, int E, int G, int nb, int mx, int my, int col_weights, float eps,
+                   dpot_stream_t stream);
+int dpot_gn_bwd_rfft2(const float* dy, const float* xin, const float* mean, const float* rstd, const float* gamma,
+                      float* dx, float* part, float* spec, int B, int h, int w, int E, int G, int nb, int mx, int my,
+                      int col_weights, dpot_stream_t stream);
+int dpot_irfft2_gn_bwd(const float* spec, const float* res, const float* xin, const float* mean, const float* rstd,
+                       const float* gamma, const float* add, float* dx, float* part, int B, int h, int w, int E, int G,
+                       int nb, int mx, int my, int col_weights, dpot_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
  * data movement / small ops
  * ------------------------------------------------------------------------------------------------ */
 /* x[B,X,Y,T,C] -> A[(b,px,py,t), (c,i,j)], c in [0,C+3): channels C..C+2 are the (x,y,t) unit grid
@@ -443,6 +469,9 @@ int dpot_bf16_pack_jobs(const dpot_pack_job* jobs_dev, int njobs, int max_elems,
 /* C[M,N] (fp32) = epilogue(A @ Wt^T), A = packed [M, K], Wt = packed [N, K] (same `planes`); epilogue as
  * dpot_gemm_panel.  Needs N % 256 == 0 and K % 32 == 0 (dpot_gemm_bf16p_supported). */
 int dpot_gemm_bf16p_supported(int M, int N, int K);
+/* rows of the workgroup tile dpot_gemm_bf16p runs a shape on: 256 (the 256 x 256 "q" kernel: many tiles, short K - the
+ * channel-MLP fc1 forward / fc2 data gradient) or 128 (128 x 256) */
+int dpot_gemm_bf16p_tile_rows(int M, int N, int K, int planes, int splitk);
 int dpot_gemm_bf16p(const void* Apacked, const void* Wpacked, const float* bias, const float* aux, int ldaux,
                     const float* res, int ldres, float* pre, int ldpre, float* C, int ldc, int M, int N, int K, int act,
                     int epi_mode, int planes, int splitk, float* workspace, void* out_rows, void* out_trans,
