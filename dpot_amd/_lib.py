@@ -127,7 +127,6 @@ SIGNATURES = {
     "dpot_bf16_pack_rows": (c_i, [c_fp, c_i, c_i, c_i, c_i, c_i, c_fp, c_fp]),
     "dpot_bf16_pack_jobs": (c_i, [c_fp, c_i, c_i, c_i, c_fp]),
     "dpot_gemm_bf16p_supported": (c_i, [c_i, c_i, c_i]),
-    "dpot_gemm_bf16p_tile_rows": (c_i, [c_i] * 5),
     "dpot_gemm_bf16p": (c_i, [c_fp, c_fp, c_fp, c_fp, c_i, c_fp, c_i, c_fp, c_i, c_fp, c_i] + [c_i] * 7 + [c_fp] * 7),
     "dpot_gemm_bf16p_splitk": (c_i, [c_i, c_i, c_i]),
     "dpot_gemm_bf16p_pair_wanted": (c_i, [c_i] * 5),

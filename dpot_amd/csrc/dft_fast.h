@@ -1,5 +1,6 @@
-// dft_fast.h - register-blocked rfft2 / irfft2 for the latent grids DPOT actually uses (16x16: 128^2/patch 8;
-// 32x32: 256^2/patch 8).  Same contract as the generic kernels in dft.hip:
+// dft_fast.h - register-blocked rfft2 / irfft2 for the power-of-two latent grids: 16x16 (128^2 / patch 8) and 32x32
+// (256^2 / patch 8) - what the DPOT configs use - plus 8x8 and 64x64 (64^2 and 512^2 fields at patch 8: the other
+// resolutions utils/griddataset.py:35 lists; 128^2 / 256^2 at patch 16 / 4).  Same contract as the generic kernels in dft.hip:
 //   * both passes keep one line of a channel (16 / 32 points) in VGPRs and transform it with a fully unrolled
 //     radix-2 FFT whose twiddles are compile-time constants (round 1 evaluated the direct O(N^2) sums there, which left
 //     the kernels VALU-bound at 2.7 / 3.5 TB/s; the real-input / one-sided zeros and the unused outputs fold away)
@@ -36,6 +37,28 @@ template <> struct Twid<32> {
   }
 };
 
+
+template <> struct Twid<8> {   // (every 8-point twiddle is one of the special-cased angles; the table only has to exist)
+  static __host__ __device__ constexpr float c(int i) {
+    constexpr float t[8] = {1.0f, 0.7071067690849304f, 0.0f, -0.7071067690849304f, -1.0f, -0.7071067690849304f, 0.0f, 0.7071067690849304f};
+    return t[i];
+  }
+  static __host__ __device__ constexpr float s(int i) {
+    constexpr float t[8] = {0.0f, 0.7071067690849304f, 1.0f, 0.7071067690849304f, 0.0f, -0.7071067690849304f, -1.0f, -0.7071067690849304f};
+    return t[i];
+  }
+};
+
+template <> struct Twid<64> {
+  static __host__ __device__ constexpr float c(int i) {
+    constexpr float t[64] = {1.0f, 0.9951847195625305f, 0.9807852506637573f, 0.9569403529167175f, 0.9238795042037964f, 0.8819212913513184f, 0.8314695954322815f, 0.7730104327201843f, 0.7071067690849304f, 0.6343932747840881f, 0.5555702447891235f, 0.4713967442512512f, 0.3826834261417389f, 0.290284663438797f, 0.19509032368659973f, 0.0980171412229538f, 0.0f, -0.0980171412229538f, -0.19509032368659973f, -0.290284663438797f, -0.3826834261417389f, -0.4713967442512512f, -0.5555702447891235f, -0.6343932747840881f, -0.7071067690849304f, -0.7730104327201843f, -0.8314695954322815f, -0.8819212913513184f, -0.9238795042037964f, -0.9569403529167175f, -0.9807852506637573f, -0.9951847195625305f, -1.0f, -0.9951847195625305f, -0.9807852506637573f, -0.9569403529167175f, -0.9238795042037964f, -0.8819212913513184f, -0.8314695954322815f, -0.7730104327201843f, -0.7071067690849304f, -0.6343932747840881f, -0.5555702447891235f, -0.4713967442512512f, -0.3826834261417389f, -0.290284663438797f, -0.19509032368659973f, -0.0980171412229538f, 0.0f, 0.0980171412229538f, 0.19509032368659973f, 0.290284663438797f, 0.3826834261417389f, 0.4713967442512512f, 0.5555702447891235f, 0.6343932747840881f, 0.7071067690849304f, 0.7730104327201843f, 0.8314695954322815f, 0.8819212913513184f, 0.9238795042037964f, 0.9569403529167175f, 0.9807852506637573f, 0.9951847195625305f};
+    return t[i];
+  }
+  static __host__ __device__ constexpr float s(int i) {
+    constexpr float t[64] = {0.0f, 0.0980171412229538f, 0.19509032368659973f, 0.290284663438797f, 0.3826834261417389f, 0.4713967442512512f, 0.5555702447891235f, 0.6343932747840881f, 0.7071067690849304f, 0.7730104327201843f, 0.8314695954322815f, 0.8819212913513184f, 0.9238795042037964f, 0.9569403529167175f, 0.9807852506637573f, 0.9951847195625305f, 1.0f, 0.9951847195625305f, 0.9807852506637573f, 0.9569403529167175f, 0.9238795042037964f, 0.8819212913513184f, 0.8314695954322815f, 0.7730104327201843f, 0.7071067690849304f, 0.6343932747840881f, 0.5555702447891235f, 0.4713967442512512f, 0.3826834261417389f, 0.290284663438797f, 0.19509032368659973f, 0.0980171412229538f, 0.0f, -0.0980171412229538f, -0.19509032368659973f, -0.290284663438797f, -0.3826834261417389f, -0.4713967442512512f, -0.5555702447891235f, -0.6343932747840881f, -0.7071067690849304f, -0.7730104327201843f, -0.8314695954322815f, -0.8819212913513184f, -0.9238795042037964f, -0.9569403529167175f, -0.9807852506637573f, -0.9951847195625305f, -1.0f, -0.9951847195625305f, -0.9807852506637573f, -0.9569403529167175f, -0.9238795042037964f, -0.8819212913513184f, -0.8314695954322815f, -0.7730104327201843f, -0.7071067690849304f, -0.6343932747840881f, -0.5555702447891235f, -0.4713967442512512f, -0.3826834261417389f, -0.290284663438797f, -0.19509032368659973f, -0.0980171412229538f};
+    return t[i];
+  }
+};
 
 // ---------------------------------------------------------------------------------------------------------------------
 // N-point complex FFT in registers (N = 16 / 32), fully unrolled decimation-in-frequency with compile-time twiddles:
@@ -269,6 +292,12 @@ static inline int try_rfft2_fast(const float* x, float* spec, int B, int h, int 
     // 64-channel slabs only when that still gives every CU >= 2 workgroups (latency hiding); else 32-channel slabs
     if (forced != 32 && E % 64 == 0 && ((long long)B * (E / 64) >= 512 || forced == 64)) { *rc = launch_rfft2_fast<16, 16, 64>(x, spec, B, E, nb, mx, my, colw, scale, s); return 1; }
     if (E % 32 == 0) { *rc = launch_rfft2_fast<16, 16, 32>(x, spec, B, E, nb, mx, my, colw, scale, s); return 1; }
+  } else if (h == 8 && w == 8) {
+    if (E % 64 == 0 && (long long)B * (E / 64) >= 512) { *rc = launch_rfft2_fast<8, 8, 64>(x, spec, B, E, nb, mx, my, colw, scale, s); return 1; }
+    if (E % 32 == 0) { *rc = launch_rfft2_fast<8, 8, 32>(x, spec, B, E, nb, mx, my, colw, scale, s); return 1; }
+  } else if (h == 64 && w == 64) {
+    // 64-point lines in registers (128 values per line item): 8-channel chunks, 132 KiB of LDS for the half-complex plane
+    if (E % 8 == 0) { *rc = launch_rfft2_fast<64, 64, 8>(x, spec, B, E, nb, mx, my, colw, scale, s); return 1; }
   } else if (h == 32 && w == 32) {
     // 32-channel chunks (full 128-byte lines per token, 139 KiB of LDS: one workgroup per CU) when that still gives
     // >= 128 workgroups: 18.0 against 22.7 us at DPOT-L B = 4 (the inverse is FASTER with 16: 29.8 against 42.5 us)
@@ -286,6 +315,11 @@ static inline int try_irfft2_fast(const float* spec, const float* res, float* y,
     if (forced == 16 && E % 16 == 0) { *rc = launch_irfft2_fast<16, 16, 16>(spec, res, y, B, E, nb, mx, my, colw, scale, s); return 1; }
     if (forced != 32 && E % 64 == 0 && ((long long)B * (E / 64) >= 512 || forced == 64)) { *rc = launch_irfft2_fast<16, 16, 64>(spec, res, y, B, E, nb, mx, my, colw, scale, s); return 1; }
     if (E % 32 == 0) { *rc = launch_irfft2_fast<16, 16, 32>(spec, res, y, B, E, nb, mx, my, colw, scale, s); return 1; }
+  } else if (h == 8 && w == 8) {
+    if (E % 64 == 0 && (long long)B * (E / 64) >= 512) { *rc = launch_irfft2_fast<8, 8, 64>(spec, res, y, B, E, nb, mx, my, colw, scale, s); return 1; }
+    if (E % 32 == 0) { *rc = launch_irfft2_fast<8, 8, 32>(spec, res, y, B, E, nb, mx, my, colw, scale, s); return 1; }
+  } else if (h == 64 && w == 64) {
+    if (E % 8 == 0) { *rc = launch_irfft2_fast<64, 64, 8>(spec, res, y, B, E, nb, mx, my, colw, scale, s); return 1; }
   } else if (h == 32 && w == 32) {
     // 12-channel chunks when the blocks allow it: 512 workgroups = 2 per CU at DPOT-L B = 4 (E = 1536) instead of the
     // 384 of 16-channel chunks (1.5 per CU: half the CUs run two in a row) - 20.4 against 29.8 us

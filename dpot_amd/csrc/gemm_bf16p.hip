@@ -368,162 +368,10 @@ __global__ __launch_bounds__(64 * (8 + PB_NLOAD)) void gemm_bf16p_kernel(const B
   gemm_bf16p_body(p, blockIdx.x, blockIdx.y);
 }
 
-// ---------------------------------------------------------------------------------------------------------------------
-// 256 x 256 workgroup tile ("q" kernel) for the many-tile / short-K products (channel-MLP fc1 forward and fc2 data
-// gradient: K = E = 1024 .. 1536, N = 4 E).  Measured on the 128 x 256 tile above (profiles/r03_bf16p_train_bench.txt): its
-// main loop needs 24 KiB of operands per 512 MFMA cycles per CU and runs at ~950 TFLOP/s - 2.6x the matrix-pipe time per
-// slab - because at most 2-3 slabs (48-72 KiB) are in flight per CU against a loaded L2/MALL latency of several
-// thousand cycles; and every tile pays ~10 us of prologue + epilogue.  This kernel halves both per FLOP:
-//   * 8 waves in a 4 x 2 grid, wave tile 64 x 128 (2 x 4 accumulators of 32x32 = 128 registers), 16 MFMAs per wave and
-//     32-k slab = 1024 matrix-pipe cycles per SIMD and slab for 32 KiB of operands (128 FLOP/B against 85);
-//   * ring of FOUR 32 KiB slabs (128 KiB), three slabs ahead: ~3 x 1024 cycles of latency tolerance instead of ~2 x 512;
-//   * no loader waves (12 waves would cap the registers at 168; the 2 x 48 fragment registers + 128 accumulators need
-//     the 256 of an 8-wave workgroup): every wave issues 4 of the 32 one-KiB DMA pieces of a slab, counted vmcnt;
-//   * a quarter of the workgroups, i.e. of the per-tile fixed costs.
-// Same packed-operand layout, same epilogues (epi_fragment / epi_fragment_pack), no split-K.
-// ---------------------------------------------------------------------------------------------------------------------
-constexpr int QB_ROWT = 8, QB_COLT = 8;                           // 32-row / 32-column tiles per workgroup
-constexpr int QB_SLABB = (QB_ROWT + QB_COLT) * 2 * 1024;          // bytes of one 32-k slab: 32 KiB
-constexpr int QB_RING = 4;
-constexpr int QB_NI = 4;                                          // DMA instructions per wave and slab
-
-__global__ __launch_bounds__(512) void gemm_bf16q_kernel(const Bf16pArgs p) {
-  __shared__ __attribute__((aligned(16))) unsigned char lds[QB_RING * QB_SLABB];
-  const int tid = threadIdx.x;
-  const int lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int ks16 = p.K >> 4;
-  const int nslab = p.K >> 5;
-
-  int tm, tn;
-  {
-    const int bid0 = blockIdx.x;
-    if (p.super_r > 0) {
-      const int xcd = bid0 & 7, slot = bid0 >> 3;
-      const int sb = slot >> 5, in = slot & 31;
-      const int srows = p.tilesM / p.super_r, scols = p.tilesN / p.super_c;
-      const int g = sb * 8 + xcd;
-      if (g >= srows * scols) return;
-      const int srow = g % srows, scol = g / srows;
-      tm = srow * p.super_r + in % p.super_r;
-      tn = scol * p.super_c + in / p.super_r;
-    } else {
-      const int ntiles = p.tilesM * p.tilesN;
-      const int xcd = bid0 & 7, slot = bid0 >> 3;
-      const int q = ntiles >> 3, r = ntiles & 7;
-      const int tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + slot;
-      tn = tile / p.tilesM;
-      tm = tile - tn * p.tilesM;
-    }
-  }
-  const int rt0 = tm * QB_ROWT, ct0 = tn * QB_COLT;
-  const int mtiles = (p.M + 31) >> 5;
-
-  auto bar = [&]() __attribute__((always_inline)) {
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    asm volatile("" ::: "memory");
-  };
-
-  // this wave's DMA pieces of a slab: block b = wave + 8 n; b < 16: A (row tile b >> 1, k-half b & 1), else W
-  const unsigned short* src[QB_NI];
-  int dst[QB_NI];
-#pragma unroll
-  for (int n = 0; n < QB_NI; ++n) {
-    const int b = wave + 8 * n;
-    if (b < 2 * QB_ROWT) {
-      int rt = rt0 + (b >> 1);
-      rt = rt < mtiles ? rt : mtiles - 1;            // clamped: rows past M only feed outputs that are never stored
-      src[n] = p.A + ((long long)rt * ks16 + (b & 1)) * 512 + lane * 8;
-    } else {
-      const int c = b - 2 * QB_ROWT;
-      src[n] = p.W + ((long long)(ct0 + (c >> 1)) * ks16 + (c & 1)) * 512 + lane * 8;
-    }
-    dst[n] = b * 1024;
-  }
-  auto issue = [&](int t, int ring) __attribute__((always_inline)) {
-#pragma unroll
-    for (int n = 0; n < QB_NI; ++n) bglds16(src[n] + (long long)t * 1024, lds + ring * QB_SLABB + dst[n]);
-  };
-
-  const int wm = wave >> 1, wn = wave & 1;
-  f32x16 acc[2][4];
-#pragma unroll
-  for (int i = 0; i < 2; ++i)
-#pragma unroll
-    for (int j = 0; j < 4; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-
-  auto read_frags = [&](bf16x8_t (&a)[2][2], bf16x8_t (&b)[4][2], int ring) __attribute__((always_inline)) {
-    const unsigned char* base = lds + ring * QB_SLABB + lane * 16;
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-      for (int ks = 0; ks < 2; ++ks)
-        a[i][ks] = *reinterpret_cast<const bf16x8_t*>(base + ((2 * wm + i) * 2 + ks) * 1024);
-#pragma unroll
-    for (int j = 0; j < 4; ++j)
-#pragma unroll
-      for (int ks = 0; ks < 2; ++ks)
-        b[j][ks] = *reinterpret_cast<const bf16x8_t*>(base + (2 * QB_ROWT + (4 * wn + j) * 2 + ks) * 1024);
-  };
-  auto mma = [&](const bf16x8_t (&a)[2][2], const bf16x8_t (&b)[4][2]) __attribute__((always_inline)) {
-#pragma unroll
-    for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-      for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][ks], b[j][ks], acc[i][j], 0, 0, 0);
-  };
-
-  bf16x8_t aA[2][2], bA[4][2], aB[2][2], bB[4][2];
-  issue(0, 0);
-  if (nslab > 1) issue(1, 1);
-  if (nslab > 2) issue(2, 2);
-  if (nslab > 2) bwait_vm<2 * QB_NI>(); else if (nslab > 1) bwait_vm<QB_NI>(); else bwait_vm<0>();
-  bar();                                               // P: slab 0 landed everywhere
-  read_frags(aA, bA, 0);
-  {
-    int ring = 0;                                      // ring slot of slab t
-    auto step = [&](int t, bf16x8_t (&ca)[2][2], bf16x8_t (&cb)[4][2], bf16x8_t (&na)[2][2], bf16x8_t (&nb)[4][2])
-        __attribute__((always_inline)) {
-      // own DMA still in flight here: slabs t+1 and t+2 (if they exist); slab t+1 must have landed before B_t
-      if (t + 2 < nslab) bwait_vm<QB_NI>(); else bwait_vm<0>();
-      bar();                                           // B_t: slab t+1 landed; every wave holds slab t in registers
-      if (t + 3 < nslab) issue(t + 3, (ring + 3) & 3); // the slot of slab t-1
-      const int rn = (ring + 1) & 3;
-      if (t + 1 < nslab) read_frags(na, nb, rn);
-      mma(ca, cb);
-      ring = rn;
-    };
-#pragma unroll 1
-    for (int t = 0; t < nslab; t += 2) {
-      step(t, aA, bA, aB, bB);
-      if (t + 1 < nslab) step(t + 1, aB, bB, aA, bA);
-    }
-  }
-  bar();                                               // S: the ring becomes epilogue staging
-
-  const int m0 = (rt0 + 2 * wm) * 32, n0 = (ct0 + 4 * wn) * 32;
-  float* st1 = reinterpret_cast<float*>(lds) + wave * (2 * 32 * EPI_LD);
-  float* st2 = st1 + 32 * EPI_LD;
-  if (p.out_rows || p.out_trans || p.cs_part || p.dact_out || p.dact_in) {   // host-checked: M % 32 == 0
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      if (m0 + 32 * i < p.M) {
-#pragma unroll
-        for (int j = 0; j < 4; ++j) epi_fragment_pack(p, m0 + 32 * i, n0 + 32 * j, acc[i][j], st1, st2, lane);
-      }
-    }
-    return;
-  }
-#pragma unroll
-  for (int i = 0; i < 2; ++i)
-#pragma unroll
-    for (int j = 0; j < 4; ++j) epi_fragment(p.e, 1, 0, m0 + 32 * i, n0 + 32 * j, acc[i][j], st1, lane);
-}
+// (A 256 x 256-tile variant - 8 self-loading waves of 64 x 128, ring of four 32 KiB slabs, a quarter of the workgroups -
+// was built and measured in round 3 on the theory that the main loop is bound by operand latency: it is SLOWER on every
+// DPOT-M / -L shape (fc1 forward at DPOT-M 167.6 against 145.6 us, fc2 forward 134.6 against 92.3 us;
+// profiles/r03_bf16p_train_bench_tile256_rejected.txt) and was removed.)
 
 // two independent problems in ONE launch (the fc1 and fc2 weight gradients of a block: 128 tiles each at DPOT-M - alone
 // each needs split-K 2, i.e. 2 x 16 MB of partial sums and a reduce launch, to fill 256 CUs; together they fill them)
@@ -932,23 +780,6 @@ static void bf16p_pick_super(int tilesM, int tilesN, int splits, int* sr, int* s
     if (tilesM % cand[i][0] == 0 && tilesN % cand[i][1] == 0) { *sr = cand[i][0]; *sc = cand[i][1]; return; }
 }
 
-// 256 x 256 tile kernel or the 128 x 256 one?  DPOT_BF16Q = 0: never, 1: whenever the shape allows, unset: when the
-// 256-tiles fill whole rounds of 256 CUs at least as well as the 128-row tiles and K is short (the per-tile fixed costs
-// and the operand latency dominate there; long-K products with few tiles keep the small tile: more workgroups)
-static bool bf16q_wanted(int M, int N, int K) {
-  static const int mode = [] { const char* e = getenv("DPOT_BF16Q"); return e ? atoi(e) : -1; }();
-  if (mode == 0 || N % 256 || M % 32 || K % 32 || K < 64) return false;
-  if (mode == 1) return true;
-  const long long t256 = (long long)((M + 255) / 256) * (N / 256), t128 = (long long)((M + 127) / 128) * (N / 256);
-  if (t256 < 256) return false;
-  const double e256 = (double)t256 / (double)(((t256 + 255) / 256) * 256), e128 = (double)t128 / (double)(((t128 + 255) / 256) * 256);
-  return e256 >= 0.9 * e128 && K <= 2048;
-}
-
-extern "C" int dpot_gemm_bf16p_tile_rows(int M, int N, int K, int planes, int splitk) {
-  return planes == 1 && splitk <= 1 && bf16q_wanted(M, N, K) ? 256 : 128;
-}
-
 extern "C" int dpot_gemm_bf16p(const void* Apacked, const void* Wpacked, const float* bias, const float* aux, int ldaux,
                                const float* res, int ldres, float* pre, int ldpre, float* C, int ldc, int M, int N, int K,
                                int act, int epi_mode, int planes, int splitk, float* workspace, void* out_rows,
@@ -996,15 +827,6 @@ extern "C" int dpot_gemm_bf16p(const void* Apacked, const void* Wpacked, const f
   p.cs_part = colsum_part;
   p.dact_out = reinterpret_cast<uint4*>(dact_out);
   p.dact_in = reinterpret_cast<const unsigned short*>(dact_in);
-  if (planes == 1 && p.splits == 1 && bf16q_wanted(M, N, K)) {
-    p.tilesM = (M + 32 * QB_ROWT - 1) / (32 * QB_ROWT);
-    p.tilesN = N / (32 * QB_COLT);
-    unsigned gq = (unsigned)(p.tilesM * p.tilesN);
-    bf16p_pick_super(p.tilesM, p.tilesN, 1, &p.super_r, &p.super_c);
-    if (p.super_r > 0) gq = 256u * (unsigned)((p.tilesM * p.tilesN / 32 + 7) / 8);
-    hipLaunchKernelGGL(gemm_bf16q_kernel, dim3(gq), dim3(512), 0, as_stream(stream), p);
-    return check_launch("gemm_bf16q_kernel");
-  }
   unsigned grid = (unsigned)(p.tilesM * p.tilesN);
   bf16p_pick_super(p.tilesM, p.tilesN, p.splits, &p.super_r, &p.super_c);
   if (p.super_r > 0) grid = 256u * (unsigned)((p.tilesM * p.tilesN / 32 + 7) / 8);

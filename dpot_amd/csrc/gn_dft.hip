@@ -235,10 +235,10 @@ __global__ __launch_bounds__(GD_T) void irfft2_gn_kernel(const float* __restrict
 #pragma unroll
   for (int i = 0; i < IT; ++i) {
     const int xr = xr0 + i * XS;
-    float q[GD_W];
+    row_ifft_load<CG>(U, xr, c, my, yv[i]);
+    float q[GD_W];                                          // (loaded AFTER the FFT: 16 fewer live registers inside it)
 #pragma unroll
     for (int yy = 0; yy < GD_W; ++yy) q[yy] = xs[(xr * GD_W + yy) * E + c];
-    row_ifft_load<CG>(U, xr, c, my, yv[i]);
 #pragma unroll
     for (int yy = 0; yy < GD_W; ++yy) yv[i][yy] = fmaf(yv[i][yy], scale, fmaf(q[yy], a1, b1));
     float lm, qq;
@@ -257,12 +257,14 @@ __global__ __launch_bounds__(GD_T) void irfft2_gn_kernel(const float* __restrict
     rstd2[b * G + g] = rs;
   }
   const float a2 = rs * gamma2[chn], b2 = beta2[chn];
+  int co = c;                                               // opaque copy: no 64-bit addresses kept alive across the
+  asm volatile("" : "+v"(co));                              // reduction (see irfft2_gn_bwd_kernel)
 #pragma unroll
   for (int i = 0; i < IT; ++i) {
     const int xr = xr0 + i * XS;
 #pragma unroll
     for (int yy = 0; yy < GD_W; ++yy) {
-      const int o = (xr * GD_W + yy) * E + c;
+      const int o = (xr * GD_W + yy) * E + co;
       y1s[o] = yv[i][yy];
       xn2s[o] = fmaf(yv[i][yy] - mu, a2, b2);
     }
@@ -346,6 +348,8 @@ __global__ __launch_bounds__(GD_T) void gn_bwd_rfft2_kernel(const float* __restr
   float m1, m2;
   gn_bwd_means<CG, IT>(Z, a_dyx, a_dy, xr0, c, chn, gamma, part, B, b, E, shd, m1, m2);
   const float ga = gamma[chn];
+  int co = c;                                               // opaque copy (see irfft2_gn_bwd_kernel)
+  asm volatile("" : "+v"(co));
 #pragma unroll
   for (int i = 0; i < IT; ++i) {
     const int xr = xr0 + i * XS;
@@ -353,7 +357,7 @@ __global__ __launch_bounds__(GD_T) void gn_bwd_rfft2_kernel(const float* __restr
     for (int y = 0; y < GD_W; ++y) {
       const float r = rs * (ga * d[i][y] - m1 - xh[i][y] * m2);
       d[i][y] = r;
-      dxs[(xr * GD_W + y) * E + c] = r;
+      dxs[(xr * GD_W + y) * E + co] = r;
     }
     row_fft_store<CG>(d[i], Z, xr, c);
   }
@@ -395,44 +399,44 @@ __global__ __launch_bounds__(GD_T) void irfft2_gn_bwd_kernel(const float* __rest
   const float* __restrict__ adds = add ? add + base : nullptr;
   float* __restrict__ dxs = dx + base;
   const float mu = mean[b * G + g], rs = rstd[b * G + g];
-  // two row items per thread (128 channels per group): x-hat is re-derived from x in the apply loop instead of being
-  // held across the reductions (48 spilled registers otherwise; the re-read hits L2)
-  constexpr bool KEEP = IT == 1;
-  float d[IT][GD_W], xh[KEEP ? IT : 1][GD_W], a_dyx[IT], a_dy[IT];
+  // d stays in registers across the reductions; x-hat too with one row item per thread (64 channels per group) - with
+  // two items (128 channels) it is re-derived from x in the apply loop (L2-hot) to stay inside 128 registers
+  constexpr bool KEEPX = IT == 1;
+  float dk[IT][GD_W], xhk[GD_W], a_dyx[IT], a_dy[IT];
 #pragma unroll
   for (int i = 0; i < IT; ++i) {
     const int xr = xr0 + i * XS;
-    float q[GD_W], xr_[GD_W];
-#pragma unroll
-    for (int y = 0; y < GD_W; ++y) {
-      const int o = (xr * GD_W + y) * E + c;
-      q[y] = ress[o];
-      xr_[y] = (xis[o] - mu) * rs;
-      if (KEEP) xh[KEEP ? i : 0][y] = xr_[y];
-    }
-    row_ifft_load<CG>(U, xr, c, my, d[i]);
+    row_ifft_load<CG>(U, xr, c, my, dk[i]);
     float sd = 0.f, sx = 0.f;
 #pragma unroll
-    for (int y = 0; y < GD_W; ++y) {
-      d[i][y] = fmaf(d[i][y], scale, q[y]);
-      sd += d[i][y];
-      sx = fmaf(d[i][y], xr_[y], sx);
+    for (int y = 0; y < GD_W; ++y) {                        // (operands loaded AFTER the FFT: fewer live registers in it)
+      const int o = (xr * GD_W + y) * E + c;
+      const float xh = (xis[o] - mu) * rs;
+      dk[i][y] = fmaf(dk[i][y], scale, ress[o]);
+      sd += dk[i][y];
+      sx = fmaf(dk[i][y], xh, sx);
+      if (KEEPX) xhk[y] = xh;
     }
     a_dy[i] = sd;
     a_dyx[i] = sx;
+    __builtin_amdgcn_sched_barrier(0);
   }
   __syncthreads();                                          // every thread is done reading U: its head becomes `red`
   float m1, m2;
   gn_bwd_means<CG, IT>(U, a_dyx, a_dy, xr0, c, chn, gamma, part, B, b, E, shd, m1, m2);
   const float ga = gamma[chn];
+  // the apply loop's addresses hang off an OPAQUE copy of the channel index: shared with the loop above, the compiler
+  // keeps 3 x 16 x IT 64-bit addresses alive across the reductions and spills them
+  int co = c;
+  asm volatile("" : "+v"(co));
 #pragma unroll
   for (int i = 0; i < IT; ++i) {
     const int xr = xr0 + i * XS;
 #pragma unroll
     for (int y = 0; y < GD_W; ++y) {
-      const int o = (xr * GD_W + y) * E + c;
-      const float xhv = KEEP ? xh[KEEP ? i : 0][y] : (xis[o] - mu) * rs;
-      float r = rs * (ga * d[i][y] - m1 - xhv * m2);
+      const int o = (xr * GD_W + y) * E + co;
+      const float xhv = KEEPX ? xhk[y] : (xis[o] - mu) * rs;
+      float r = rs * (ga * dk[i][y] - m1 - xhv * m2);
       if (adds) r += adds[o];
       dxs[o] = r;
     }

