@@ -121,7 +121,7 @@ SIGNATURES = {
     "dpot_noise_inject_bwd": (c_i, [c_fp] * 7 + [c_f] + [c_i] * 3 + [c_fp]),
     "dpot_window_slide": (c_i, [c_fp] * 3 + [c_i64] + [c_i] * 3 + [c_fp]),
     "dpot_window_slide_bwd": (c_i, [c_fp] * 3 + [c_i64] + [c_i] * 3 + [c_fp]),
-    "dpot_resize_pad_window": (c_i, [c_fp, c_i, c_fp, c_fp] + [c_i] * 4 + [c_fp]),
+    "dpot_resize_pad_window": (c_i, [c_fp, c_i, c_fp, c_fp] + [c_i] * 6 + [c_fp]),
     "dpot_panel_pack_weights": (c_i, [c_fp, c_i, c_i, c_fp]),
     "dpot_bf16_packed_elems": (c_i64, [c_i, c_i, c_i]),
     "dpot_bf16_pack_rows": (c_i, [c_fp, c_i, c_i, c_i, c_i, c_i, c_fp, c_fp]),

@@ -27,14 +27,17 @@ __device__ __forceinline__ void src_index(int dst, float scale, int in_size, int
 // frames of the same four source pixels
 __global__ __launch_bounds__(256) void resize_pad_window_kernel(const dpot_sample_desc* __restrict__ jobs,
                                                                 float* __restrict__ xx, float* __restrict__ yy, int res,
-                                                                int t_in, int t_ar, int Cmax) {
+                                                                int t_in, int t_ar, int Cmax, int dh, int dw) {
   // (the job table lives in device memory: a by-value table indexed by blockIdx.y is copied to scratch by every thread)
   const int j = blockIdx.y;
   const dpot_sample_desc job = jobs[j];
   const int H = job.H, W = job.W, T = job.T, C = job.C, t0 = job.t0;
   const float* __restrict__ src = job.data;
   if (H <= 0 || W <= 0 || C <= 0 || C > Cmax || t0 < 0 || t0 + t_in + t_ar > T) return;   // malformed entry: skip
-  const long long npix = (long long)res * res;
+  // dh, dw: the strided sub-sampling x[::dh, ::dw] the reference applies AFTER the resize (griddataset.py:170-172):
+  // output pixel (oy, ox) is pixel (oy * dh, ox * dw) of the res x res image
+  const int ro_h = (res + dh - 1) / dh, ro_w = (res + dw - 1) / dw;
+  const long long npix = (long long)ro_h * ro_w;
   const long long nx = npix * t_in, total = npix * (t_in + t_ar);
   const float sh = (float)H / (float)res, sw = (float)W / (float)res;
   const long long TC = (long long)T * C;
@@ -53,11 +56,11 @@ __global__ __launch_bounds__(256) void resize_pad_window_kernel(const dpot_sampl
       t = t_in + ty;
       o = yy + ((b * npix + pix) * t_ar + ty) * Cmax;
     }
-    const int oy = pix / res, ox = pix - oy * res;       // oy indexes the FIRST spatial axis (H), ox the second (W)
+    const int oy = pix / ro_w, ox = pix - oy * ro_w;     // oy indexes the FIRST spatial axis (H), ox the second (W)
     int h0, h1, w0, w1;
     float hl0, hl1, wl0, wl1;
-    src_index(oy, sh, H, h0, h1, hl0, hl1);
-    src_index(ox, sw, W, w0, w1, wl0, wl1);
+    src_index(oy * dh, sh, H, h0, h1, hl0, hl1);
+    src_index(ox * dw, sw, W, w0, w1, wl0, wl1);
     const long long so = (long long)(t0 + t) * C;
     const float* p00 = src + ((long long)h0 * W + w0) * TC + so;
     const float* p01 = src + ((long long)h0 * W + w1) * TC + so;
@@ -87,15 +90,17 @@ __global__ __launch_bounds__(256) void resize_pad_window_kernel(const dpot_sampl
 using namespace dpot;
 
 extern "C" int dpot_resize_pad_window(const dpot_sample_desc* samples_dev, int nsamples, float* xx, float* yy, int res,
-                                      int t_in, int t_ar, int n_channels, dpot_stream_t stream) {
+                                      int t_in, int t_ar, int n_channels, int down_h, int down_w,
+                                      dpot_stream_t stream) {
+  DPOT_REQUIRE(down_h >= 1 && down_w >= 1 && down_h <= res && down_w <= res, "resize_pad_window: bad down-sampling factors");
   DPOT_REQUIRE(samples_dev && nsamples > 0 && nsamples <= 65535 && xx && res > 0 && t_in > 0 && t_ar >= 0 &&
                    n_channels > 0,
                "resize_pad_window: bad argument");
   DPOT_REQUIRE(t_ar == 0 || yy != nullptr, "resize_pad_window: t_ar > 0 needs yy");
   DPOT_REQUIRE(n_channels != 4 || (aligned16(xx) && aligned16(yy)), "resize_pad_window: outputs must be 16-byte aligned");
-  long long blocks = ((long long)res * res * (t_in + t_ar) + 255) / 256;
+  long long blocks = ((long long)((res + down_h - 1) / down_h) * ((res + down_w - 1) / down_w) * (t_in + t_ar) + 255) / 256;
   if (blocks > 1024) blocks = 1024;
   hipLaunchKernelGGL(resize_pad_window_kernel, dim3((unsigned)blocks, nsamples), dim3(256), 0, as_stream(stream),
-                     samples_dev, xx, yy, res, t_in, t_ar, n_channels);
+                     samples_dev, xx, yy, res, t_in, t_ar, n_channels, down_h, down_w);
   return check_launch("resize_pad_window_kernel");
 }

@@ -13,6 +13,10 @@ for ns2d_fno: 16x fewer bytes than the padded 128x128x4 batch):
 
 HDF5 reading (h5py is not available in this image) stays with the caller: `DeviceBatcher.submit` takes numpy arrays /
 CPU tensors.  Dataset mixing and index sharding are host logic (`MixedIndex`, dp.shard_indices).
+
+Also covered (griddataset.py:159-174): test-mode windows (`train=False`: x = the first t_in frames, y = the following
+t_test frames, the resolution / channel mask of `get_target_mask`), the per-dataset strided `downsample` of the resized
+fields, and `idx_cls` (the dataset index of every sample, int64 [B, 1]).
 """
 from __future__ import annotations
 
@@ -31,6 +35,12 @@ Tensor = torch.Tensor
 def random_window_start(T: int, t_in: int, t_ar: int, rng: np.random.Generator) -> int:
     """griddataset.py:151  start_idx = np.random.randint(max(T - (t_in + t_ar) + 1, 1))"""
     return int(rng.integers(max(T - (t_in + t_ar) + 1, 1)))
+
+
+def eval_window(T: int, t_in: int, t_test: int) -> Tuple[int, int]:
+    """griddataset.py:159-161 (test datasets return the whole trajectory): (t0, t_ar) = (0, number of frames of
+    sample[..., t_in : t_in + t_test, :] that exist)"""
+    return 0, max(0, min(t_test, T - t_in))
 
 
 def target_mask(res: int, size_orig: Sequence[int], n_channels: int) -> Tensor:
@@ -76,15 +86,25 @@ def _fill_table(table: np.ndarray, ptrs: Sequence[int], shapes: Sequence[Sequenc
         descs[i].data, descs[i].H, descs[i].W, descs[i].T, descs[i].C, descs[i].t0 = ptr, H, W, T, Cc, int(t0)
 
 
+def _down_shape(res: int, downsample: Tuple[int, int]) -> Tuple[int, int]:
+    dh, dw = int(downsample[0]), int(downsample[1])
+    if dh < 1 or dw < 1:
+        raise ValueError(f"downsample {downsample}: factors must be >= 1")
+    return (res + dh - 1) // dh, (res + dw - 1) // dw
+
+
 def resize_pad_window(samples: Sequence[Tensor], starts: Sequence[int], res: int, t_in: int, t_ar: int,
-                      n_channels: int, out_xx: Optional[Tensor] = None, out_yy: Optional[Tensor] = None):
+                      n_channels: int, out_xx: Optional[Tensor] = None, out_yy: Optional[Tensor] = None,
+                      downsample: Tuple[int, int] = (1, 1)):
     """samples: CUDA tensors [H,W,T,C] (fp32, contiguous), one per batch entry -> (xx [B,res,res,t_in,Cmax],
-    yy [B,res,res,t_ar,Cmax]) through ONE launch of csrc/data.hip"""
+    yy [B,res,res,t_ar,Cmax]) through ONE launch of csrc/data.hip.  downsample = (dh, dw): the reference's
+    x[::dh, ::dw] on the resized fields (griddataset.py:170-172) - the outputs then have ceil(res/d) points per axis"""
     B = len(samples)
     dev = samples[0].device
-    xx = out_xx if out_xx is not None else torch.empty(B, res, res, t_in, n_channels, dtype=torch.float32, device=dev)
+    rh, rw = _down_shape(res, downsample)
+    xx = out_xx if out_xx is not None else torch.empty(B, rh, rw, t_in, n_channels, dtype=torch.float32, device=dev)
     yy = out_yy if out_yy is not None else (
-        torch.empty(B, res, res, t_ar, n_channels, dtype=torch.float32, device=dev) if t_ar > 0 else None)
+        torch.empty(B, rh, rw, t_ar, n_channels, dtype=torch.float32, device=dev) if t_ar > 0 else None)
     for s in samples:
         if not (s.is_cuda and s.dtype == torch.float32 and s.is_contiguous() and s.dim() == 4):
             raise _lib.DpotHipError("resize_pad_window: samples must be contiguous float32 CUDA tensors [H,W,T,C]")
@@ -92,7 +112,8 @@ def resize_pad_window(samples: Sequence[Tensor], starts: Sequence[int], res: int
     _fill_table(host, [s.data_ptr() for s in samples], [tuple(s.shape) for s in samples], starts, t_in, t_ar, n_channels)
     table = torch.from_numpy(host).to(dev)
     check(_lib.load().dpot_resize_pad_window(table.data_ptr(), B, xx.data_ptr(), yy.data_ptr() if yy is not None else None,
-                                             res, t_in, t_ar, n_channels, torch.cuda.current_stream().cuda_stream),
+                                             res, t_in, t_ar, n_channels, int(downsample[0]), int(downsample[1]),
+                                             torch.cuda.current_stream().cuda_stream),
           "resize_pad_window")
     return xx, yy
 
@@ -101,8 +122,12 @@ class DeviceBatcher:
     """Double-buffered batch producer: raw samples in, device-resident (xx, yy, msk) out, overlapped with the step."""
 
     def __init__(self, batch: int, res: int, t_in: int, t_ar: int, n_channels: int, max_raw_floats_per_sample: int,
-                 device="cuda", n_buffers: int = 2):
+                 device="cuda", n_buffers: int = 2, downsample: Tuple[int, int] = (1, 1)):
+        """t_ar: frames of y per sample (training: the rollout length; test mode: t_test of the dataset, with
+        starts = 0 - see `eval_window`).  downsample: one factor pair per batcher (a batch is one tensor)."""
         self.B, self.res, self.t_in, self.t_ar, self.C = batch, res, t_in, t_ar, n_channels
+        self.down = (int(downsample[0]), int(downsample[1]))
+        rh, rw = _down_shape(res, self.down)
         self.dev = torch.device(device)
         self.n = n_buffers
         self.head = batch * DESC_FLOATS                # the descriptor table rides at the head of the staging buffer
@@ -110,9 +135,13 @@ class DeviceBatcher:
         self.stream = torch.cuda.Stream(device=self.dev)
         self.host = [torch.empty(cap, dtype=torch.float32).pin_memory() for _ in range(n_buffers)]
         self.raw = [torch.empty(cap, dtype=torch.float32, device=self.dev) for _ in range(n_buffers)]
-        self.xx = [torch.empty(batch, res, res, t_in, n_channels, device=self.dev) for _ in range(n_buffers)]
-        self.yy = [torch.empty(batch, res, res, t_ar, n_channels, device=self.dev) for _ in range(n_buffers)]
-        self.msk = torch.ones(batch, res, res, 1, n_channels, device=self.dev)      # training mask (griddataset.py:157)
+        self.xx = [torch.empty(batch, rh, rw, t_in, n_channels, device=self.dev) for _ in range(n_buffers)]
+        self.yy = [torch.empty(batch, rh, rw, t_ar, n_channels, device=self.dev) for _ in range(n_buffers)]
+        # training mask (griddataset.py:157: ones at the window's resolution, i.e. BEFORE the down-sampling - the reference
+        # does not sub-sample msk; test-mode masks: `target_mask` per dataset)
+        self.msk = torch.ones(batch, res, res, 1, n_channels, device=self.dev)
+        self.cls = [torch.zeros(batch, 1, dtype=torch.int64, device=self.dev) for _ in range(n_buffers)]
+        self.cls_host = [torch.zeros(batch, 1, dtype=torch.int64).pin_memory() for _ in range(n_buffers)]
         self.ready = [torch.cuda.Event() for _ in range(n_buffers)]       # slot filled (recorded on the copy stream)
         self.consumed = [None] * n_buffers                                # slot's last reader (recorded on compute)
         self.k = 0
@@ -122,9 +151,11 @@ class DeviceBatcher:
         self._last: Optional[int] = None
         self.h2d_bytes = 0
 
-    def submit(self, samples: Sequence, starts: Sequence[int]) -> None:
-        """enqueue one batch: samples = numpy arrays / CPU tensors [H,W,T,C] (or [H,W,T]); returns immediately"""
+    def submit(self, samples: Sequence, starts: Sequence[int], dataset_ids: Optional[Sequence[int]] = None) -> None:
+        """enqueue one batch: samples = numpy arrays / CPU tensors [H,W,T,C] (or [H,W,T]); returns immediately.
+        dataset_ids: the dataset index of every sample (griddataset.py:174 idx_cls; default zeros)"""
         assert len(samples) == self.B and len(starts) == self.B
+        assert dataset_ids is None or len(dataset_ids) == self.B
         slot = self.k % self.n
         # validate BEFORE anything is overwritten (a bad batch must leave the slot and the counters untouched)
         arrs, offs, shapes, off = [], [], [], self.head
@@ -164,10 +195,15 @@ class DeviceBatcher:
         base = self.raw[slot].data_ptr()
         _fill_table(hnp[:self.head].view(np.uint8), [base + 4 * o for o in offs], shapes, starts, self.t_in, self.t_ar,
                     self.C)
+        self.cls_host[slot].zero_()
+        if dataset_ids is not None:
+            self.cls_host[slot][:, 0] = torch.as_tensor(list(dataset_ids), dtype=torch.int64)
         with torch.cuda.stream(self.stream):
             self.raw[slot][:off].copy_(host[:off], non_blocking=True)            # ONE H2D copy: table + raw samples
+            self.cls[slot].copy_(self.cls_host[slot], non_blocking=True)
             check(_lib.load().dpot_resize_pad_window(base, self.B, self.xx[slot].data_ptr(), self.yy[slot].data_ptr(),
-                                                     self.res, self.t_in, self.t_ar, self.C, self.stream.cuda_stream),
+                                                     self.res, self.t_in, self.t_ar, self.C, self.down[0], self.down[1],
+                                                     self.stream.cuda_stream),
                   "resize_pad_window")
             self.ready[slot].record(self.stream)
         self.h2d_bytes += (off - self.head) * 4
@@ -182,6 +218,11 @@ class DeviceBatcher:
         self._last = slot
         self._out.add(slot)
         return self.xx[slot], self.yy[slot], self.msk
+
+    @property
+    def last_cls(self) -> Optional[Tensor]:
+        """idx_cls [B, 1] int64 of the batch the latest get() returned (griddataset.py:174; train_temporal.py:199)"""
+        return None if self._last is None else self.cls[self._last]
 
     @property
     def last_slot(self) -> Optional[int]:

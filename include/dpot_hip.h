@@ -507,9 +507,12 @@ typedef struct dpot_sample_desc {
  * align_corners=False semantics), channels C..n_channels-1 filled with ones, written as
  * xx[b] = [res, res, t_in, n_channels] and yy[b] = [res, res, t_ar, n_channels] (yy may be NULL when t_ar == 0).
  * `samples_dev` is a DEVICE array of nsamples descriptors (upload it with the raw samples, one H2D copy per batch);
- * the caller validates it (C <= n_channels, t0 + t_in + t_ar <= T) - a malformed entry is skipped by the kernel. */
+ * the caller validates it (C <= n_channels, t0 + t_in + t_ar <= T) - a malformed entry is skipped by the kernel.
+ * down_h, down_w >= 1: the strided sub-sampling x[::down_h, ::down_w] the reference applies to the resized fields of
+ * some datasets (utils/griddataset.py:170-172): xx[b] / yy[b] then have ceil(res / down) points per axis.
+ * Test-mode windows (griddataset.py:159-163) are the same call with t0 = 0 and t_ar = min(t_test, T - t_in). */
 int dpot_resize_pad_window(const dpot_sample_desc* samples_dev, int nsamples, float* xx, float* yy, int res, int t_in,
-                           int t_ar, int n_channels, dpot_stream_t stream);
+                           int t_ar, int n_channels, int down_h, int down_w, dpot_stream_t stream);
 
 #ifdef __cplusplus
 }

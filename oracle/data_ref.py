@@ -29,6 +29,25 @@ def window(sample: Tensor, t0: int, t_in: int, t_ar: int):
     return sample[..., t0:t0 + t_in, :], sample[..., t0 + t_in:min(t0 + t_in + t_ar, sample.shape[-2]), :]
 
 
+def test_window(sample: Tensor, t_in: int, t_test: int):
+    """griddataset.py:159-161 (test datasets): x = the first t_in frames, y = sample[..., t_in : t_in + t_test, :]"""
+    return sample[..., 0:t_in, :], sample[..., t_in:t_in + t_test, :]
+
+
+def target_mask(sample: Tensor, size_orig) -> Tensor:
+    """griddataset.py:103-117 get_target_mask: ones on the grid points / channels the dataset itself has"""
+    msk = torch.zeros(*sample.shape[:2], 1, sample.shape[-1])
+    kx, ky = sample.shape[0] // size_orig[0], sample.shape[1] // size_orig[1]
+    kx, ky = (1 if kx == 0 else kx), (1 if ky == 0 else ky)
+    msk[::kx, ::ky, :, :size_orig[-1]] = 1
+    return msk
+
+
+def downsample(x: Tensor, y: Tensor, d):
+    """griddataset.py:170-172"""
+    return x[::d[0], ::d[1]], y[::d[0], ::d[1]]
+
+
 def recipe_sample(shape, salt: int) -> Tensor:
     """closed-form raw trajectory (smooth field + a hash texture), identical wherever it is evaluated"""
     from oracle.dpot_ref import recipe_tensor

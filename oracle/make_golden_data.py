@@ -37,8 +37,51 @@ def reference_pad_data(x, res, n_channels):
     return x_new
 
 
+# test-mode / down-sampling cases (griddataset.py:159-174): (H, W, T, C), res, n_channels, t_in, t_test, downsample,
+# pred_channels (None: all the dataset's channels)
+TEST_CASES = [
+    ((16, 16, 12, 1), 32, 4, 4, 6, (1, 1), None),     # test trajectory, mask on every 2nd grid point, 1 of 4 channels
+    ((32, 32, 7, 3), 32, 3, 4, 10, (1, 1), 2),        # t_test runs past the trajectory (slice clips), pred_channels 2
+    ((48, 40, 9, 2), 24, 4, 3, 4, (2, 3), None),      # target resolution below the data's (k = 0 -> 1), downsample (2, 3)
+    ((16, 16, 8, 2), 32, 2, 4, 3, (4, 4), None),      # downsample 4
+]
+
+
+def reference_test_item(sample_raw, res, n_channels, t_in, t_test, down, pred_channels):
+    # ---- griddataset.py:143-174 with train = False, verbatim where the lines do not touch files / self.*
+    sample = sample_raw
+    orig_size = list(sample.shape)
+    orig_size[-1] = pred_channels if pred_channels is not None else orig_size[-1]
+    sample = reference_pad_data(sample, res, n_channels)
+    start_idx = 0
+    x, y = sample[..., start_idx:start_idx + t_in, :], sample[..., t_in:t_in + t_test, :]
+    # get_target_mask (griddataset.py:103-117)
+    msk = torch.zeros(*sample.shape[:2], 1, sample.shape[-1])    ## target mask shape H,W,1,C
+    kx, ky = sample.shape[0] // orig_size[0], sample.shape[1] // orig_size[1]
+    if kx == 0 or ky == 0:
+        kx = 1 if kx == 0 else kx
+        ky = 1 if ky == 0 else ky
+    msk[::kx, ::ky, :, :orig_size[-1]] = 1
+    ### downsample
+    if down != (1, 1):
+        x, y = x[::down[0], ::down[1]], y[::down[0], ::down[1]]
+    return x, y, msk
+
+
 def main():
     out = {}
+    for k, (shape, res, nc, t_in, t_test, down, pc) in enumerate(TEST_CASES):
+        raw = D.recipe_sample(shape, salt=200 + k).contiguous()
+        x, y, msk = reference_test_item(raw, res, nc, t_in, t_test, down, pc)
+        padded = D.pad_data(raw, res, nc)
+        xo, yo = D.test_window(padded, t_in, t_test)
+        xo, yo = D.downsample(xo, yo, down)
+        mo = D.target_mask(padded, list(shape[:3]) + [pc if pc is not None else shape[3]])
+        assert torch.equal(x, xo) and torch.equal(y, yo) and torch.equal(msk, mo), f"oracle disagrees on test case {k}"
+        out[f"t{k}.x"], out[f"t{k}.y"], out[f"t{k}.msk"] = x.numpy(), y.numpy(), msk.numpy()
+        out[f"t{k}.meta"] = np.array(list(shape) + [res, nc, t_in, t_test, down[0], down[1], -1 if pc is None else pc],
+                                     dtype=np.int64)
+        print(f"test case {k}: raw {shape} -> x {tuple(x.shape)}, y {tuple(y.shape)}, msk {tuple(msk.shape)}")
     for k, (shape, res, nc, t_in, t_ar, t0) in enumerate(CASES):
         raw = D.recipe_sample(shape, salt=100 + k).contiguous()
         sample = reference_pad_data(raw, res, nc)

@@ -42,3 +42,25 @@ def test_mixed_index_and_window_rules():
     msk[::kx, ::ky, :, :size_orig[-1]] = 1
     assert torch.equal(target_mask(res, size_orig, nc), msk)
     assert target_mask(8, [16, 16, 5, 1], 2)[..., 0].sum() == 64          # target coarser than the data: k -> 1
+
+
+def test_data_oracle_test_mode_and_downsample_match_golden():
+    """g12 t0..t3: griddataset.py:143-174 with train=False (test window, get_target_mask, downsample) transcribed in
+    oracle/make_golden_data.py; the oracle's restatement and the product's host helpers (eval_window, target_mask)"""
+    from dpot_amd.data import eval_window, target_mask
+    fx = load("g12_data")
+    k = 0
+    while f"t{k}.meta" in fx.files:
+        H, W, T, Cc, res, nc, t_in, t_test, dh, dw, pc = (int(v) for v in fx[f"t{k}.meta"])
+        raw = D.recipe_sample((H, W, T, Cc), salt=200 + k)
+        padded = D.pad_data(raw, res, nc)
+        x, y = D.downsample(*D.test_window(padded, t_in, t_test), (dh, dw))
+        size_orig = [H, W, T, Cc if pc < 0 else pc]
+        msk = D.target_mask(padded, size_orig)
+        assert np.array_equal(x.numpy(), fx[f"t{k}.x"]) and np.array_equal(y.numpy(), fx[f"t{k}.y"])
+        assert np.array_equal(msk.numpy(), fx[f"t{k}.msk"])
+        t0, t_ar = eval_window(T, t_in, t_test)
+        assert t0 == 0 and t_ar == fx[f"t{k}.y"].shape[2]
+        assert np.array_equal(target_mask(res, size_orig, nc).numpy(), fx[f"t{k}.msk"])
+        k += 1
+    assert k == 4

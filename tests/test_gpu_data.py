@@ -59,3 +59,29 @@ def test_device_batcher_double_buffer_overlaps_and_is_exact():
             assert_close(got_y[i], yr, f"batch {it} sample {i} y", rtol=1e-6, atol_scale=1e-6)
         assert tuple(msk.shape) == (B, res, res, 1, nc) and bool((msk == 1).all())
     assert db.h2d_bytes == sum(int(np.prod(r.shape)) * 4 for raws, _ in batches for r in raws)
+
+
+def test_test_mode_windows_downsample_and_idx_cls_golden():
+    """SURVEY f2 remainder (griddataset.py:159-174): test-mode window (x = first t_in frames, y = the following t_test
+    frames, clipped at the trajectory's end), strided down-sampling of the resized fields, idx_cls - the device kernel
+    against the golden vectors written from the transcribed reference lines (g12 t0..t3), and through DeviceBatcher"""
+    from dpot_amd.data import DeviceBatcher, eval_window, resize_pad_window
+    fx = load("g12_data")
+    for k in range(4):
+        H, W, T, Cc, res, nc, t_in, t_test, dh, dw, pc = (int(v) for v in fx[f"t{k}.meta"])
+        raw = D.recipe_sample((H, W, T, Cc), salt=200 + k).contiguous()
+        t0, t_ar = eval_window(T, t_in, t_test)
+        xx, yy = resize_pad_window([raw.cuda()], [t0], res, t_in, t_ar, nc, downsample=(dh, dw))
+        assert_close(xx[0], fx[f"t{k}.x"], f"test case {k} x", rtol=1e-6, atol_scale=1e-6)
+        assert_close(yy[0], fx[f"t{k}.y"], f"test case {k} y", rtol=1e-6, atol_scale=1e-6)
+        # the same through the double-buffered batcher (batch of 2 identical samples, dataset ids 3 and 5)
+        db = DeviceBatcher(2, res, t_in, t_ar, nc, max_raw_floats_per_sample=raw.numel(), downsample=(dh, dw))
+        db.submit([raw.numpy(), raw.numpy()], [t0, t0], dataset_ids=[3, 5])
+        bx, by, _ = db.get()
+        cls = db.last_cls.clone()
+        gx, gy = bx.clone(), by.clone()
+        db.release()
+        torch.cuda.synchronize()
+        assert cls.dtype == torch.int64 and cls.cpu().tolist() == [[3], [5]]
+        assert_close(gx[1], fx[f"t{k}.x"], f"batcher test case {k} x", rtol=1e-6, atol_scale=1e-6)
+        assert_close(gy[0], fx[f"t{k}.y"], f"batcher test case {k} y", rtol=1e-6, atol_scale=1e-6)
