@@ -597,7 +597,14 @@ class BlockFn(torch.autograd.Function):
                                                   col_weights=1)
             dS, dw1, db1, dw2, db2 = _mixer_core_bwd(dO2, S, O1pre, O1, wb1, wb2, ctx.dims, ctx.fused_mixer,
                                                      ctx.afno_layout, (s_w1, s_b1, s_w2, s_b2))
-            dx, gn1_part = ops.irfft2_gn_bwd(dS, dy1, x, mean1, rstd1, n1w, h, w, nb, mx, my, add=dout, col_weights=0)
+            if E // 8 <= 64:
+                dx, gn1_part = ops.irfft2_gn_bwd(dS, dy1, x, mean1, rstd1, n1w, h, w, nb, mx, my, add=dout,
+                                                 col_weights=0)
+            else:
+                # 128 channels per group (DPOT-S / -M): this pair reads four fields with 4-byte accesses and runs at 64.7 us
+                # against 20.0 + 24.6 us for the separate kernels (profiles/r03_step_census_M_bf16_v1.txt) - not fused
+                dxn1 = ops.irfft2(dS, B, h, w, E, nb, mx, my, 0, res=dy1)
+                dx, gn1_part = ops.groupnorm_bwd(dxn1, x, mean1, rstd1, n1w, add=dout, defer=True)
         else:
             dy1, gn2_part = ops.groupnorm_bwd(dxn2.view(B, tok, E), y1, mean2, rstd2, n2w, defer=True)
             # AFNO mixer
