@@ -537,6 +537,11 @@ __global__ __launch_bounds__(64 * (BS / 16 + 2)) void afno_mlp3_kernel(const Afn
     // where every register is taken, and spilled across it (17 MB of scratch traffic per launch in the L2 counters)
     // the epilogue's index arithmetic hangs off an OPAQUE copy of the lane id: everything derived from it is computed
     // here, after the slab loops (hoisted above them - where every register is taken - it was spilled across them)
+    const long long gbase = (long long)row0 * p.ldo + (long long)kblk * N;       // uniform
+    float* const pre_b = p.pre ? p.pre + gbase : nullptr;
+    float* const mid_b = p.mid ? p.mid + gbase : nullptr;
+    const float* const aux_b = p.aux ? p.aux + gbase : nullptr;
+    float* const Y_b = p.Y + gbase;
     int ln = lane;
     asm volatile("" : "+v"(ln)::"memory");
     const int efr = ln & 15, efq = ln >> 4;
@@ -572,24 +577,25 @@ __global__ __launch_bounds__(64 * (BS / 16 + 2)) void afno_mlp3_kernel(const Afn
         const int col = bcol[it];
         const bool ok = row < p.M;
         const int rowc = ok ? row : p.M - 1;
-        const long long go = (long long)rowc * p.ldo + (long long)kblk * N + col;
+        // 32-bit offset from a workgroup-uniform base (row0, kblk come from blockIdx): no 64-bit per-lane address math
+        const int go = (rowc - row0) * p.ldo + col;
         if (first) {
           if (p.mode == 0) {
-            if (p.pre && ok) *reinterpret_cast<float4*>(p.pre + go) = make_float4(v[0], v[1], v[2], v[3]);
+            if (pre_b && ok) *reinterpret_cast<float4*>(pre_b + go) = make_float4(v[0], v[1], v[2], v[3]);
 #pragma unroll
             for (int e = 0; e < 4; ++e) v[e] = ACTK == DPOT_ACT_GELU ? gelu_fwd(v[e]) : act_fwd(p.act, v[e]);
           } else {
-            const float4 x4 = *reinterpret_cast<const float4*>(p.aux + go);
+            const float4 x4 = *reinterpret_cast<const float4*>(aux_b + go);
             const float xs[4] = {x4.x, x4.y, x4.z, x4.w};
 #pragma unroll
             for (int e = 0; e < 4; ++e) v[e] *= ACTK == DPOT_ACT_GELU ? gelu_bwd(xs[e]) : act_bwd(p.act, xs[e]);
           }
-          if (p.mid && ok) *reinterpret_cast<float4*>(p.mid + go) = make_float4(v[0], v[1], v[2], v[3]);
+          if (mid_b && ok) *reinterpret_cast<float4*>(mid_b + go) = make_float4(v[0], v[1], v[2], v[3]);
           const int s = col >> 4, kq = (col >> 2) & 3;
           *reinterpret_cast<f32x4*>(Y1 + ((i * NCT + s) * 64 + kq * 16 + ((r + s + 8 * (kq >> 1)) & 15)) * 4) =
               (f32x4){v[0], v[1], v[2], v[3]};
         } else {
-          if (ok) *reinterpret_cast<float4*>(p.Y + go) = make_float4(v[0], v[1], v[2], v[3]);
+          if (ok) *reinterpret_cast<float4*>(Y_b + go) = make_float4(v[0], v[1], v[2], v[3]);
         }
       }
       __builtin_amdgcn_wave_barrier();
@@ -636,7 +642,7 @@ __global__ __launch_bounds__(64 * (BS / 16 + 2)) void afno_mlp3_kernel(const Afn
   read_w(B0, 0);
   {
     int r1 = 1, r2 = 2;                                // ring buffers of slabs t+1, t+2
-#pragma unroll 1
+#pragma unroll
     for (int t = 0; t < NSLAB; t += 2) {
       f32x4 bs;
       bar();                                           // B_t: slab t+1 has landed
@@ -663,7 +669,7 @@ __global__ __launch_bounds__(64 * (BS / 16 + 2)) void afno_mlp3_kernel(const Afn
   {
     int r1 = (NSLAB + 1) % 3, r2 = (NSLAB + 2) % 3;
     read_y(AR, AI, 0);                                 // (B0: fetched during the last slab of layer 1)
-#pragma unroll 1
+#pragma unroll
     for (int u = 0; u < NSLAB; u += 2) {
       f32x4 bs;
       if (u > 0) bar();                                // B_(NSLAB+u)

@@ -770,9 +770,14 @@ extern "C" int dpot_gemm_bf16p_splitk(int M, int N, int K) {
 }
 
 // super-block shape (rows x columns of tiles, product 32) for the L2-aware rasterisation, or 0 x 0: the most square
-// shape that divides the tile grid; needs more than one round of workgroups to matter.  DPOT_BF16P_RASTER=0 disables it.
+// shape that divides the tile grid; needs more than one round of workgroups to matter.  OPT-IN (DPOT_BF16P_RASTER=1):
+// on back-to-back launches of one GEMM it gains 3-6 % (fc1 forward at DPOT-M 148.9 -> 139.4 us,
+// profiles/r03_bf16p_train_bench_raster{0,1}.txt), but inside the DPOT-M train step - operands cold, written by the
+// previous kernel - the 48 launches average 123.7 us with it against 121.1 us without
+// (profiles/r03_step_census_M_bf16_seq_raster{1,0}.txt): the column-major order it replaces streams each weight chunk
+// through one XCD's L2 exactly once, which matters more when nothing is cache-resident.
 static void bf16p_pick_super(int tilesM, int tilesN, int splits, int* sr, int* sc) {
-  static const int enabled = [] { const char* e = getenv("DPOT_BF16P_RASTER"); return e ? atoi(e) : 1; }();
+  static const int enabled = [] { const char* e = getenv("DPOT_BF16P_RASTER"); return e ? atoi(e) : 0; }();
   *sr = 0; *sc = 0;
   if (!enabled || splits > 1 || (long long)tilesM * tilesN < 512) return;
   static const int cand[6][2] = {{8, 4}, {4, 8}, {16, 2}, {2, 16}, {32, 1}, {1, 32}};

@@ -1116,12 +1116,12 @@ def test_groupnorm_chunked_vs_fp64(ops, monkeypatch, B, T, E, G):
     assert_close(y, y0.double(), "chunked vs slab kernels")
 
 
-def test_gemm_bf16_panel_large_shape_rasterised(ops):
-    """round 3: at >= 512 tiles the bf16 panel kernel walks the tile grid in L2-aware super-blocks (8 x 4 tiles per XCD
-    round).  bf16 x bf16 products are exact and the accumulation is fp32, so against an fp64 product of the bf16-ROUNDED
-    operands the result must agree to fp32 accumulation accuracy - a mis-mapped tile shows as an O(1) error; the packed
-    outputs must be the bf16 rounding of the activated output"""
-    M, N, K = 8192, 2048, 256                      # 64 x 8 tiles = 512: the rasterised path
+def test_gemm_bf16_panel_large_shape(ops):
+    """the bf16 panel kernel on a many-tile shape (512 tiles: two rounds of workgroups; with DPOT_BF16P_RASTER=1 also the
+    L2-aware super-block tile order).  bf16 x bf16 products are exact and the accumulation is fp32, so against an fp64
+    product of the bf16-ROUNDED operands the result must agree to fp32 accumulation accuracy - a mis-mapped tile shows as
+    an O(1) error; the packed outputs must be the bf16 rounding of the activated output"""
+    M, N, K = 8192, 2048, 256                      # 64 x 8 tiles = 512
     A, W, b = rnd(M, K, seed=1), rnd(N, K, seed=2, scale=1.0 / math.sqrt(K)), rnd(N, seed=3, scale=0.3)
     pk = ops.PanelPacks([(W.cuda(), N, K, K, False)], bf16=True)
     pk.refresh()
