@@ -154,7 +154,8 @@ def mixer_roofline(model, B: int):
 
         def run(train: bool):
             if fused:
-                return ops.afno_mlp2(S, W1f, b1, W2f, b2, nb, bs, 1, mode=0, want_pre=train, want_mid=train,
+                # training form (round 3): only the pre-activation is saved; the backward launch re-derives act(pre)
+                return ops.afno_mlp2(S, W1f, b1, W2f, b2, nb, bs, 1, mode=0, want_pre=train, want_mid=False,
                                      layout=1 if three else 0)
             O1, O1pre, O2 = torch.empty_like(S), torch.empty_like(S), torch.empty_like(S)
             kw = dict(lda=2 * E, ldb=N, ldc=2 * E, batch=nb, strideA=N, strideB=N * N, strideC=N, strideBias=N, tag=1)
@@ -191,7 +192,7 @@ def mixer_roofline(model, B: int):
     # gfx950 correction follow MI355X_MICROARCH.md section HBM: bytes = (2 * FETCH_SIZE + WRITE_SIZE) * 1024
     traffic = None
     try:
-        pmc = json.load(open(os.path.join(ROOT, "profiles", "r02_pmc_mixer.json")))
+        pmc = json.load(open(os.path.join(ROOT, "profiles", "r03_pmc_mixer.json")))
         traffic = (2.0 * pmc["FETCH_SIZE"]["mean"] + pmc["WRITE_SIZE"]["mean"]) * 1024.0
     except Exception:
         pass
@@ -208,14 +209,15 @@ def mixer_roofline(model, B: int):
                        "complex multiplication), i.e. its matrix pipes run at 0.75 x achieved") if three else None,
         "bound": "mfma", "achieved": round(achieved, 2), "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
         "frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": traffic,
-        "traffic_note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), (2*FETCH+WRITE)*1024 B; the training "
-                        "form of the launch also stores the pre-activation and the activated spectrum (saved for the "
-                        "backward): 3 spectrum-sized writes instead of the 1 that algorithmic_bytes counts",
+        "traffic_note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, profiles/r03_pmc_mixer.json), "
+                        "(2*FETCH+WRITE)*1024 B; the training form of the launch also stores the pre-activation (saved for "
+                        "the backward): 2 spectrum-sized writes instead of the 1 that algorithmic_bytes counts (round 2 also "
+                        "stored the activated spectrum: 3 writes, 80.7 MB)",
         "us_per_launch": round(t * 1e6, 2), "flops_per_launch": flops, "algorithmic_bytes_per_launch": bytes_alg,
         "hbm_frac": round(bytes_alg / t / 1e9 / HBM_PEAK_GBS, 4),
         "inference_form": {"us_per_launch": round(t_inf * 1e6, 2), "achieved": round(flops / t_inf / 1e12, 2),
                            "frac": round(flops / t_inf / 1e12 / FP32_MFMA_PEAK_TFLOPS, 4),
-                           "what": "same launch without the two saved-for-backward stores (no_grad forward)"},
+                           "what": "same launch without the saved-for-backward store (no_grad forward)"},
         "sustained_mfma_tflops": SUSTAINED_FP32_MFMA_TFLOPS,
         "frac_of_sustained": round(achieved / SUSTAINED_FP32_MFMA_TFLOPS, 4),
         "note": "FLOP-bound (128 FLOP/B >> 20 FLOP/B ridge): hbm_frac is reported because north_star asks for it; "
@@ -224,6 +226,35 @@ def mixer_roofline(model, B: int):
                 "part (power-limited clocks; profiles/r02_mfma_f32_peak.txt) - frac_of_sustained prices against that",
         "other_kernels": other_rooflines(model, B, timeit_graph),
     }
+
+
+def bf16_mlp_roofline(model, B: int):
+    """DPOT-S / -M / -L with the bf16 channel MLP: the dominant kernel is dpot::gemm_bf16p_kernel (csrc/gemm_bf16p.hip).
+    Timed here in the form the forward launches it for fc1 (x W1^T + b -> GELU; row pack, transposed pack and act' pack of
+    the hidden layer written, no fp32 output), HIP events around a hipGraph of 20 launches, random operands."""
+    from dpot_amd import ops
+    E, h = model.embed_dim, model.latent_size[0]
+    M = B * h * h
+    mh = model.blocks[0].mlp[0].weight.shape[0]
+    x = torch.randn(M, E, device="cuda")
+    W1 = torch.randn(mh, E, device="cuda") * 0.03
+    b1 = torch.randn(mh, device="cuda") * 0.1
+    pk = ops.PanelPacks([(W1, mh, E, E, False)], bf16=True)
+    pk.refresh()
+    xp = ops.bf16_pack_rows(x)
+    t = timeit_graph(lambda: ops.gemm_bf16p_packed(xp, pk.bufs[0], M, mh, E, bias=b1, act=1, mode=ops.EPI_ACT, save_dact=True,
+                                                    pack_rows=True, pack_trans=True, store=False), reps=20)
+    fl = 2.0 * M * mh * E
+    by = 2.0 * M * E + 2.0 * mh * E + 3 * 2.0 * M * mh            # packed A + packed W read once, three bf16 packs written
+    return {"kernel": "dpot::gemm_bf16p_kernel (channel-MLP fc1 forward: bf16 operands pre-packed fragment-block-major, "
+                      "v_mfma_f32_32x32x16_bf16, epilogue writes the activated hidden layer as row + transposed bf16 packs "
+                      "and act' as a bf16 pack)",
+            "shape": [M, mh, E], "bound": "mfma", "achieved": round(fl / t / 1e12, 1), "peak": 2500.0, "unit": "TFLOP/s",
+            "frac": round(fl / t / 1e12 / 2500.0, 4), "us_per_launch": round(t * 1e6, 2), "flops_per_launch": fl,
+            "algorithmic_bytes_per_launch": by, "hbm_frac": round(by / t / 1e9 / HBM_PEAK_GBS, 4), "traffic": None,
+            "note": "2.5 PFLOP/s = dense bf16 MFMA peak (MI355X_MICROARCH.md); a register-only MFMA loop sustains 1.4-1.8 "
+                    "PFLOP/s on random operands on this part (profiles/r02_mfma_bf16_peak.txt).  Per tile the kernel pays "
+                    "~20 us of prologue + epilogue + store drain beside an 18 us main loop at K = 1024 (DESIGN.md section 3)"}
 
 
 def timeit_graph(fn, reps: int = 30):
@@ -278,17 +309,36 @@ def other_rooflines(model, B: int, timeit):
         x = torch.randn(B, h * h, E, device="cuda")
         nb = model.n_blocks
         mx, my = min(model.modes, h), min(model.modes, h // 2 + 1)
-        t = timeit(lambda: ops.rfft2(x, h, h, nb, mx, my, 0))
-        by = x.numel() * 4 + B * mx * my * 2 * E * 4
-        out.append({"kernel": "dpot::rfft2_fast_kernel (field -> kept modes, register FFTs)", "bound": "hbm",
-                    "us_per_launch": round(t * 1e6, 2), "achieved": round(by / t / 1e9, 1), "peak": HBM_PEAK_GBS,
-                    "unit": "GB/s", "frac": round(by / t / 1e9 / HBM_PEAK_GBS, 4)})
         gw, gb_ = torch.randn(E, device="cuda"), torch.randn(E, device="cuda")
-        t = timeit(lambda: ops.groupnorm_fwd(x, gw, gb_))
-        by = 2 * x.numel() * 4
-        out.append({"kernel": "dpot::groupnorm_fwd_cached_kernel", "bound": "hbm", "us_per_launch": round(t * 1e6, 2),
-                    "achieved": round(by / t / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": round(by / t / 1e9 / HBM_PEAK_GBS, 4)})
+        fld, spc = x.numel() * 4, B * mx * my * 2 * E * 4
+        if ops.gn_dft_supported(h, h, E):
+            # GroupNorm fused with the mixer's DFTs (csrc/gn_dft.hip): the four launches around the mixer kernel
+            S_, m1_, r1_ = ops.gn_rfft2(x, gw, gb_, h, h, nb, mx, my)
+            y1_, xn2_, m2_, r2_ = ops.irfft2_gn(S_, x, m1_, r1_, gw, gb_, gw, gb_, h, h, nb, mx, my)
+            dy_ = torch.randn_like(x)
+            fused = [("gn_rfft2_kernel (GroupNorm1 statistics + rfft2; GroupNorm1(x) never written)",
+                      lambda: ops.gn_rfft2(x, gw, gb_, h, h, nb, mx, my), fld + spc),
+                     ("irfft2_gn_kernel (irfft2 + x_orig + GroupNorm2: y1 and xn2 written)",
+                      lambda: ops.irfft2_gn(S_, x, m1_, r1_, gw, gb_, gw, gb_, h, h, nb, mx, my), spc + 3 * fld),
+                     ("gn_bwd_rfft2_kernel (GroupNorm2 backward + adjoint rfft2)",
+                      lambda: ops.gn_bwd_rfft2(dy_, y1_, m2_, r2_, gw, h, h, nb, mx, my), 3 * fld + spc)]
+            if E // 8 <= 64:
+                fused.append(("irfft2_gn_bwd_kernel (adjoint irfft2 + skip + GroupNorm1 backward + outer skip)",
+                              lambda: ops.irfft2_gn_bwd(S_, dy_, x, m1_, r1_, gw, h, h, nb, mx, my, add=dy_), spc + 4 * fld))
+            for name, fn, by in fused:
+                t = timeit(fn)
+                out.append({"kernel": "dpot::" + name, "bound": "hbm", "us_per_launch": round(t * 1e6, 2),
+                            "achieved": round(by / t / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                            "frac": round(by / t / 1e9 / HBM_PEAK_GBS, 4)})
+        else:
+            t = timeit(lambda: ops.rfft2(x, h, h, nb, mx, my, 0))
+            out.append({"kernel": "dpot::rfft2_fast_kernel (field -> kept modes, register FFTs)", "bound": "hbm",
+                        "us_per_launch": round(t * 1e6, 2), "achieved": round((fld + spc) / t / 1e9, 1), "peak": HBM_PEAK_GBS,
+                        "unit": "GB/s", "frac": round((fld + spc) / t / 1e9 / HBM_PEAK_GBS, 4)})
+            t = timeit(lambda: ops.groupnorm_fwd(x, gw, gb_))
+            out.append({"kernel": "dpot::groupnorm_fwd_cached_kernel", "bound": "hbm", "us_per_launch": round(t * 1e6, 2),
+                        "achieved": round(2 * fld / t / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                        "frac": round(2 * fld / t / 1e9 / HBM_PEAK_GBS, 4)})
         # fused per-pixel tail of the de-embed (csrc/tail.hip): NOT HBM-bound - fp32 MFMA and fp32 VALU share the FMA
         # lanes on gfx950 (profiles/r02_pmc_tail.json: VALU-active + MFMA-busy = kernel time); hbm frac reported because
         # VERDICT r1 prices these kernels against the HBM roof
@@ -540,7 +590,14 @@ def main():
                              + ("" if mlp_prec in (None, "f32") else " although the channel-MLP GEMMs of this config run on "
                                 "the bf16 matrix cores (2.5 PF) - fractions above 1 are possible"))
         try:
-            out["roofline"] = mixer_roofline(model, B)
+            mix = mixer_roofline(model, B)
+            if mlp_prec == "bf16" and not headline:
+                # the dominant kernel of these configs is the bf16 panel GEMM; the mixer goes to other_kernels
+                out["roofline"] = bf16_mlp_roofline(model, B)
+                others = mix.pop("other_kernels", [])
+                out["roofline"]["other_kernels"] = [mix] + others
+            else:
+                out["roofline"] = mix
         except Exception as e:                                 # pragma: no cover
             log(f"[bench] roofline probe failed: {e}")
             out["roofline"] = None

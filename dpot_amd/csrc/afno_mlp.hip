@@ -288,8 +288,26 @@ __global__ __launch_bounds__(64 * (NW + 2)) void afno_mlp2_kernel(const AfnoMlpA
           } else {
             const float4 x4 = *reinterpret_cast<const float4*>(p.aux + go);
             const float xs[4] = {x4.x, x4.y, x4.z, x4.w};
+            if (p.pre) {
+              // the backward also re-derives the ACTIVATED layer-1 output act(aux) (operand of the layer-2 weight gradient):
+              // the forward then need not store it (value and derivative share the Gaussian tail evaluation)
+              float a[4];
 #pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] *= ACTK == DPOT_ACT_GELU ? gelu_bwd(xs[e]) : act_bwd(p.act, xs[e]);
+              for (int e = 0; e < 4; ++e) {
+                if (ACTK == DPOT_ACT_GELU) {
+                  float d;
+                  gelu_val_der(xs[e], a[e], d);
+                  v[e] *= d;
+                } else {
+                  a[e] = act_fwd(p.act, xs[e]);
+                  v[e] *= act_bwd(p.act, xs[e]);
+                }
+              }
+              if (ok) *reinterpret_cast<float4*>(p.pre + go) = make_float4(a[0], a[1], a[2], a[3]);
+            } else {
+#pragma unroll
+              for (int e = 0; e < 4; ++e) v[e] *= ACTK == DPOT_ACT_GELU ? gelu_bwd(xs[e]) : act_bwd(p.act, xs[e]);
+            }
           }
           if (p.mid && ok) *reinterpret_cast<float4*>(p.mid + go) = make_float4(v[0], v[1], v[2], v[3]);
           // A operand of layer 2: K-slab s = col/16, chunk (k-quad, row) at a row position rotated by s + 8*(kq/2):
@@ -587,8 +605,26 @@ __global__ __launch_bounds__(64 * (BS / 16 + 2)) void afno_mlp3_kernel(const Afn
           } else {
             const float4 x4 = *reinterpret_cast<const float4*>(aux_b + go);
             const float xs[4] = {x4.x, x4.y, x4.z, x4.w};
+            if (pre_b) {
+              // the backward also re-derives the ACTIVATED layer-1 output act(aux) (operand of the layer-2 weight gradient):
+              // the forward then need not store it (value and derivative share the Gaussian tail evaluation)
+              float a[4];
 #pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] *= ACTK == DPOT_ACT_GELU ? gelu_bwd(xs[e]) : act_bwd(p.act, xs[e]);
+              for (int e = 0; e < 4; ++e) {
+                if (ACTK == DPOT_ACT_GELU) {
+                  float d;
+                  gelu_val_der(xs[e], a[e], d);
+                  v[e] *= d;
+                } else {
+                  a[e] = act_fwd(p.act, xs[e]);
+                  v[e] *= act_bwd(p.act, xs[e]);
+                }
+              }
+              if (ok) *reinterpret_cast<float4*>(pre_b + go) = make_float4(a[0], a[1], a[2], a[3]);
+            } else {
+#pragma unroll
+              for (int e = 0; e < 4; ++e) v[e] *= ACTK == DPOT_ACT_GELU ? gelu_bwd(xs[e]) : act_bwd(p.act, xs[e]);
+            }
           }
           if (mid_b && ok) *reinterpret_cast<float4*>(mid_b + go) = make_float4(v[0], v[1], v[2], v[3]);
           const int s = col >> 4, kq = (col >> 2) & 3;

@@ -535,7 +535,8 @@ def afno_mlp2(X: Tensor, WaT: Tensor, ba: Optional[Tensor], WbT: Tensor, bb: Opt
               act: int, mode: int = 0, aux: Optional[Tensor] = None, want_pre: bool = False, want_mid: bool = False,
               layout: int = 0):
     """both layers of the AFNO block-diagonal complex MLP in one launch (csrc/afno_mlp.hip).
-    mode 0: pre = X Wa + ba, mid = act(pre), Y = mid Wb + bb;  mode 1: mid = (X Wa) * act'(aux), Y = mid Wb.
+    mode 0: pre = X Wa + ba, mid = act(pre), Y = mid Wb + bb;  mode 1: mid = (X Wa) * act'(aux), Y = mid Wb, and with
+    want_pre the `pre` output is act(aux) (the forward's activated layer-1 output, re-derived for the weight gradient).
     X / outputs: [M, nb*2*bs]; WaT / WbT: [nb, 2bs, 2bs] fragment-block-major weights from afno_block_weights (`fwd`
     to multiply by W, `bwd` to multiply by W^T).  Returns (Y, pre | None, mid | None)."""
     M, ld = X.shape

@@ -378,6 +378,8 @@ int dpot_noise_inject_rng(const float* xx, float* out, float* norms, uint64_t* r
 /* The AFNO mixer's 2-layer block-diagonal complex MLP (models/dpot.py:72-94) as ONE launch (csrc/afno_mlp.hip):
  *   mode 0 (forward):        pre = X Wa + ba;  mid = act(pre);          Y = mid Wb + bb
  *   mode 1 (backward data):  mid = (X Wa) * act'(aux);                  Y = mid Wb         (ba = bb = NULL)
+ *                            pre (optional) = act(aux): the activated layer-1 output of the FORWARD, re-derived here
+ *                            for the layer-2 weight gradient, so that the forward need not store it
  * X [M, ldx], outputs / aux [M, ldo]: block k owns columns k*N..(k+1)*N, N = 2*bs = [re | im].  Wa / Wb: the real
  * N x N matrices of the packed complex weights in FRAGMENT-BLOCK-MAJOR order, as written by dpot_afno_block_weights
  * from dpot_afno_pack's Wbig: its `fwd` output for mode 0 (multiply by Wbig), its `bwd` output for mode 1 (multiply

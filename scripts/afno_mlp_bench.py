@@ -24,9 +24,11 @@ def bench(nb, bs, M, reps=50):
         c1 = torch.randn(2, nb, bs, device="cuda") * 0.1; c2 = torch.randn(2, nb, bs, device="cuda") * 0.1
         pk = ops.AfnoPacks([(w1, c1), (w2, c2)])
         (_, bb1, f1, k1), (_, bb2, f2, k2) = pk.refresh()
-        forms.update({"3mult fwd-train": lambda: ops.afno_mlp2(S, f1, bb1, f2, bb2, nb, bs, 1, mode=0, want_pre=True, want_mid=True, layout=1),
+        forms.update({"3mult fwd-train": lambda: ops.afno_mlp2(S, f1, bb1, f2, bb2, nb, bs, 1, mode=0, want_pre=True, want_mid=False, layout=1),
+                      "3mult fwd-train(r2: +mid)": lambda: ops.afno_mlp2(S, f1, bb1, f2, bb2, nb, bs, 1, mode=0, want_pre=True, want_mid=True, layout=1),
                       "3mult fwd-infer": lambda: ops.afno_mlp2(S, f1, bb1, f2, bb2, nb, bs, 1, mode=0, layout=1),
-                      "3mult bwd-data": lambda: ops.afno_mlp2(S, k2, None, k1, None, nb, bs, 1, mode=1, aux=pre, want_mid=True, layout=1)})
+                      "3mult bwd-data": lambda: ops.afno_mlp2(S, k2, None, k1, None, nb, bs, 1, mode=1, aux=pre, want_mid=True, want_pre=True, layout=1),
+                      "3mult bwd-data(r2: no act out)": lambda: ops.afno_mlp2(S, k2, None, k1, None, nb, bs, 1, mode=1, aux=pre, want_mid=True, layout=1)})
     flops = 2 * 2.0 * M * N * N * nb
     out = []
     for name, fn in forms.items():
@@ -58,7 +60,7 @@ def tiny_train(n=30):
                             (torch.randn(2, nb, bs, bs, device="cuda") * 0.05, torch.randn(2, nb, bs, device="cuda") * 0.1)])
         (_, c1, f1, _), (_, c2, f2, _) = pk.refresh()
         for _ in range(n):
-            ops.afno_mlp2(S, f1, c1, f2, c2, nb, bs, 1, mode=0, want_pre=True, want_mid=True, layout=1)
+            ops.afno_mlp2(S, f1, c1, f2, c2, nb, bs, 1, mode=0, want_pre=True, want_mid=False, layout=1)
         torch.cuda.synchronize()
         return
     for _ in range(n):

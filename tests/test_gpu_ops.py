@@ -518,6 +518,12 @@ def test_afno_mlp2_fused_two_layers(ops, nb, bs, M, act):
                                 aux=pre_ref.float().reshape(M, -1).contiguous().cuda(), want_mid=True)
     assert_close(dmid, dmid_ref.reshape(M, -1), "dO1pre")
     assert_close(dS, dS_ref.reshape(M, -1), "dS")
+    # round 3: the backward launch can also re-derive the forward's activated layer-1 output act(aux)
+    dS2, o1, dmid2 = ops.afno_mlp2(dO2.cuda(), W2B, None, W1B, None, nb, bs, ops.ACT_IDS[act], mode=1,
+                                   aux=pre_ref.float().reshape(M, -1).contiguous().cuda(), want_mid=True, want_pre=True)
+    assert_close(o1, f(pre_ref.float().double()).reshape(M, -1), "act(aux) re-derived by the backward launch")
+    assert_close(dS2, dS_ref.reshape(M, -1), "dS (with act(aux) output)")
+    assert_close(dmid2, dmid_ref.reshape(M, -1), "dO1pre (with act(aux) output)")
 
 
 def test_plain_bf16_mlp_mode_is_reduced_precision_but_sane(ops):
@@ -955,10 +961,11 @@ def test_afno_mlp3_three_product_form(ops, nb, bs, M, act):
     Wbig1, Wbig2 = wb1.cpu().double(), wb2.cpu().double()                       # [nb, N, N], W[k][n]
     dmid_ref = torch.einsum("mko,kno->mkn", dO2.double().view(M, nb, N), Wbig2) * dact.view(M, nb, N)
     dS_ref = torch.einsum("mko,kno->mkn", dmid_ref, Wbig1)
-    dS, _, dmid = ops.afno_mlp2(dO2.cuda(), bw2, None, bw1, None, nb, bs, ops.ACT_IDS[act], mode=1,
-                                aux=pre_ref.float().contiguous().cuda(), want_mid=True, layout=1)
+    dS, o1, dmid = ops.afno_mlp2(dO2.cuda(), bw2, None, bw1, None, nb, bs, ops.ACT_IDS[act], mode=1,
+                                 aux=pre_ref.float().contiguous().cuda(), want_mid=True, want_pre=True, layout=1)
     assert_close(dmid, dmid_ref.reshape(M, -1), "dO1pre")
     assert_close(dS, dS_ref.reshape(M, -1), "dS")
+    assert_close(o1, f(pre_ref.float().double()), "act(aux) re-derived by the backward launch")     # == the forward's mid
 
 
 @pytest.mark.parametrize("nb,bs,Mm", [(4, 128, 4608), (2, 64, 32 * 13), (8, 128, 32 * 9)])
