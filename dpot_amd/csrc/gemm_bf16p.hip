@@ -49,6 +49,16 @@ template <int N>
 __device__ __forceinline__ void bwait_vm() {
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
+// s_waitcnt vmcnt(n) for a wave-uniform n in {0, 6, 12, 18, 24} (the immediate must be a constant)
+__device__ __forceinline__ void bwait_vm_dyn(int n) {
+  switch (n) {
+    case 0: bwait_vm<0>(); break;
+    case 6: bwait_vm<6>(); break;
+    case 12: bwait_vm<12>(); break;
+    case 18: bwait_vm<18>(); break;
+    default: bwait_vm<24>(); break;
+  }
+}
 __device__ __forceinline__ void bglds16(const void* g, void* l) {
   __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
                                    (__attribute__((address_space(3))) void*)l, 16, 0, 0);
@@ -179,11 +189,20 @@ constexpr int PB_ROWT = 4;      // 32-row tiles per workgroup (128 rows)
 constexpr int PB_COLT = 8;      // 32-column tiles per workgroup (256 columns)
 constexpr int PB_NLOAD = 4;     // loader waves
 constexpr int PB_SLABB = (PB_ROWT + PB_COLT) * 2 * 1024;        // bytes of one 32-k slab: 24 KiB
+// Depth of the slab ring.  Slab g + R goes into the slot of slab g, which is free at barrier B_g, and has to have landed by
+// B_(g+R-1): the loop tolerates R - 1 slab periods (512 matrix-pipe cycles each) of LDS-DMA latency.  Under load that
+// latency is well above a thousand cycles (L2 misses served by the MALL / HBM while every CU streams), so the ring of
+// three of round 2 (2 periods) left the loop latency bound at ~1350 cycles per slab.
+#ifndef PB_RING_N
+#define PB_RING_N 5
+#endif
+constexpr int PB_RING = PB_RING_N;
 
 // body of the kernel: problem p, workgroup index bid0 within the problem, split-K index zs
 __device__ __forceinline__ void gemm_bf16p_body(const Bf16pArgs& p, const int bid0, const int zs) {
-  // ring of 3 slabs; the epilogue stages through it afterwards (8 waves x 32 x EPI_LD floats = 36 KiB)
-  __shared__ __attribute__((aligned(16))) unsigned char lds[3 * PB_SLABB];
+  // ring of PB_RING slabs; the epilogue stages through it afterwards (8 waves x 2 x 32 x EPI_LD floats = 72 KiB)
+  static_assert(PB_RING >= 3 && PB_RING * PB_SLABB <= 160 * 1024, "slab ring must fit the 160 KiB LDS");
+  __shared__ __attribute__((aligned(16))) unsigned char lds[PB_RING * PB_SLABB];
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -248,22 +267,25 @@ __device__ __forceinline__ void gemm_bf16p_body(const Bf16pArgs& p, const int bi
 #pragma unroll
       for (int n = 0; n < 6; ++n) bglds16(src[n] + (long long)t * 1024, lds + ring * PB_SLABB + dst[n]);
     };
-    issue(0, 0);
-    if (nslab > 1) issue(1, 1);
-    if (nslab > 2) issue(2, 2);
-    if (nslab > 2) bwait_vm<6>(); else bwait_vm<0>();
+    // prologue: slabs 0 .. R-1 in flight; slabs 0 and 1 (the oldest 12 pieces) must have landed at barrier P: the
+    // compute waves fetch slab 0 right after P and slab 1 after B_0, and nothing is waited for in between
+    int issued = 0;
+#pragma unroll
+    for (int r = 0; r < PB_RING; ++r)
+      if (r < nslab) { issue(r, r); ++issued; }
+    bwait_vm_dyn(issued > 2 ? 6 * (issued - 2) : 0);
     bar();                                              // P
     int ring = 0;
 #pragma unroll 1
     for (int g = 0; g < nslab; ++g) {
-      bar();                                            // B_g
-      if (g + 3 < nslab) {
-        issue(g + 3, ring);
-        bwait_vm<6>();
-      } else {
-        bwait_vm<0>();
-      }
-      ring = ring == 2 ? 0 : ring + 1;
+      bar();                                            // B_g: every wave holds slab g in registers -> its slot is free
+      if (g + PB_RING < nslab) issue(g + PB_RING, ring);
+      ring = ring == PB_RING - 1 ? 0 : ring + 1;
+      // slab g + 2 must have landed before B_(g+1) (the compute waves fetch its fragments there): everything younger
+      // may stay in flight
+      int younger = nslab - (g + 3);                    // slabs g+3 .. that have been issued
+      younger = younger < 0 ? 0 : (younger > PB_RING - 2 ? PB_RING - 2 : younger);
+      bwait_vm_dyn(6 * younger);
     }
     bar();                                              // S
     return;
@@ -307,7 +329,7 @@ __device__ __forceinline__ void gemm_bf16p_body(const Bf16pArgs& p, const int bi
   bar();                                               // P
   read_frags(aA, bA, 0);
   {
-    int r1 = 1, r2 = 2;
+    int r1 = 1 % PB_RING, r2 = 2 % PB_RING;            // ring slots of slabs t+1, t+2
 #pragma unroll 1
     for (int t = 0; t < nslab; t += 2) {
       bar();                                           // B_t
@@ -318,8 +340,8 @@ __device__ __forceinline__ void gemm_bf16p_body(const Bf16pArgs& p, const int bi
         if (t + 2 < nslab) read_frags(aA, bA, r2);
         mma(aB, bB);
       }
-      r1 = r1 == 0 ? 2 : r1 - 1;
-      r2 = r2 == 0 ? 2 : r2 - 1;
+      r1 = r1 + 2 >= PB_RING ? r1 + 2 - PB_RING : r1 + 2;
+      r2 = r2 + 2 >= PB_RING ? r2 + 2 - PB_RING : r2 + 2;
     }
   }
   bar();                                               // S: all DMA landed and read; the ring becomes epilogue staging

@@ -50,22 +50,6 @@ __device__ __forceinline__ void block_sum3_d(double& a, double& b, double& c, do
   c = rc;
 }
 
-// Pull a (sample, group) slab of a field towards this CU / its L2 without registers and without waiting: LDS-DMA into a
-// 1 KiB sink nobody reads (the trick of csrc/afno_mlp.hip).  The fused kernels are ONE workgroup per CU running a chain of
-// dependent phases; operands that are only needed in a LATER phase (the residual / x-hat / outer-skip fields of the
-// inverse kernels) would otherwise pay a full HBM latency when that phase starts.
-template <int CG>
-__device__ __forceinline__ void prefetch_slab(const float* __restrict__ slab, int E, float* sink) {
-  constexpr int CH = CG / 4;                                // 16-byte chunks per token
-#pragma unroll
-  for (int q0 = 0; q0 < GD_H * GD_W * CH; q0 += GD_T) {
-    const int q = q0 + threadIdx.x;
-    const int tok = q / CH, c4 = q - tok * CH;
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(slab + tok * E + 4 * c4),
-                                     (__attribute__((address_space(3))) void*)sink, 16, 0, 0);
-  }
-}
-
 // mean and centred sum of squares of one 16-token row
 __device__ __forceinline__ void row_stats(const float (&v)[GD_W], float& lm, float& q) {
   float s = 0.f;
@@ -231,11 +215,9 @@ __global__ __launch_bounds__(GD_T) void irfft2_gn_kernel(const float* __restrict
   extern __shared__ __attribute__((aligned(16))) float sm[];
   float* U = sm;                                            // [H][WF][2][CG]
   __shared__ double shd[48];
-  __shared__ __attribute__((aligned(16))) float sink[256];
   const int g = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
   const int bs = E / nb;
   const long long base = (long long)b * GD_H * GD_W * E + g * CG;
-  prefetch_slab<CG>(x + base, E, sink);                     // needed by the row pass, after the column pass + barrier
   for (int it = tid; it < my * CG; it += GD_T) {
     const int c2 = it % CG, ky = it / CG;
     col_ifft_store<CG>(spec, U, b, g * CG + c2, c2, ky, nb, bs, mx, my, colw_f(colw, ky, GD_W));
@@ -402,13 +384,9 @@ __global__ __launch_bounds__(GD_T) void irfft2_gn_bwd_kernel(const float* __rest
   extern __shared__ __attribute__((aligned(16))) float sm[];
   float* U = sm;
   __shared__ double shd[32];
-  __shared__ __attribute__((aligned(16))) float sink[256];
   const int g = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
   const int bs = E / nb;
   const long long base = (long long)b * GD_H * GD_W * E + g * CG;
-  prefetch_slab<CG>(res + base, E, sink);                   // the row pass and the apply loop read three more fields:
-  prefetch_slab<CG>(xin + base, E, sink);                   // pull them in under the column pass
-  if (add) prefetch_slab<CG>(add + base, E, sink);
   for (int it = tid; it < my * CG; it += GD_T) {
     const int c2 = it % CG, ky = it / CG;
     col_ifft_store<CG>(spec, U, b, g * CG + c2, c2, ky, nb, bs, mx, my, colw_f(colw, ky, GD_W));
