@@ -189,12 +189,12 @@ constexpr int PB_ROWT = 4;      // 32-row tiles per workgroup (128 rows)
 constexpr int PB_COLT = 8;      // 32-column tiles per workgroup (256 columns)
 constexpr int PB_NLOAD = 4;     // loader waves
 constexpr int PB_SLABB = (PB_ROWT + PB_COLT) * 2 * 1024;        // bytes of one 32-k slab: 24 KiB
-// Depth of the slab ring.  Slab g + R goes into the slot of slab g, which is free at barrier B_g, and has to have landed by
-// B_(g+R-1): the loop tolerates R - 1 slab periods (512 matrix-pipe cycles each) of LDS-DMA latency.  Under load that
-// latency is well above a thousand cycles (L2 misses served by the MALL / HBM while every CU streams), so the ring of
-// three of round 2 (2 periods) left the loop latency bound at ~1350 cycles per slab.
+// Depth of the slab ring (-DPB_RING_N=3..6).  Slab g + R goes into the slot of slab g, which is free at barrier B_g, and has
+// to have landed by B_(g+R-1): the loop tolerates R - 1 slab periods of LDS-DMA latency.  Round 3 swept R = 3 .. 6 on the
+// theory that the main loop (1350 cycles per slab against 512 of matrix-pipe time) is bound by that latency: no effect
+// (fc1 forward at DPOT-M 150.0 / 150.0 / 150.9 / 149.9 us, profiles/r03_bf16p_ring_sweep.txt) - it is not; R stays 3.
 #ifndef PB_RING_N
-#define PB_RING_N 5
+#define PB_RING_N 3
 #endif
 constexpr int PB_RING = PB_RING_N;
 
