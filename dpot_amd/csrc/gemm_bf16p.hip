@@ -49,11 +49,13 @@ template <int N>
 __device__ __forceinline__ void bwait_vm() {
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
-// s_waitcnt vmcnt(n) for a wave-uniform n in {0, 6, 12, 18, 24} (the immediate must be a constant)
+// s_waitcnt vmcnt(n) for a wave-uniform multiple of 3 up to 24 (the immediate must be a constant)
 __device__ __forceinline__ void bwait_vm_dyn(int n) {
   switch (n) {
     case 0: bwait_vm<0>(); break;
+    case 3: bwait_vm<3>(); break;
     case 6: bwait_vm<6>(); break;
+    case 9: bwait_vm<9>(); break;
     case 12: bwait_vm<12>(); break;
     case 18: bwait_vm<18>(); break;
     default: bwait_vm<24>(); break;
@@ -187,7 +189,11 @@ __device__ __forceinline__ void epi_fragment_pack(const Bf16pArgs& p, int m0f, i
 
 constexpr int PB_ROWT = 4;      // 32-row tiles per workgroup (128 rows)
 constexpr int PB_COLT = 8;      // 32-column tiles per workgroup (256 columns)
-constexpr int PB_NLOAD = 4;     // loader waves
+#ifndef PB_NLOAD_N
+#define PB_NLOAD_N 4
+#endif
+constexpr int PB_NLOAD = PB_NLOAD_N;                           // loader waves (4 or 8)
+constexpr int PB_NPC = 2 * (PB_ROWT + PB_COLT) / PB_NLOAD;      // 1 KiB DMA pieces per loader wave and slab (6 or 3)
 constexpr int PB_SLABB = (PB_ROWT + PB_COLT) * 2 * 1024;        // bytes of one 32-k slab: 24 KiB
 // Depth of the slab ring (-DPB_RING_N=3..6).  Slab g + R goes into the slot of slab g, which is free at barrier B_g, and has
 // to have landed by B_(g+R-1): the loop tolerates R - 1 slab periods of LDS-DMA latency.  Round 3 swept R = 3 .. 6 on the
@@ -238,20 +244,37 @@ __device__ __forceinline__ void gemm_bf16p_body(const Bf16pArgs& p, const int bi
   const int rt0 = tm * PB_ROWT, ct0 = tn * PB_COLT;  // first 32-row tile / 32-column tile
   const int mtiles = (p.M + 31) >> 5;
 
+  // s_waitcnt lgkmcnt(0) as the BUILTIN (simm16 0xC07F: vmcnt 63, expcnt 7, lgkmcnt 0), not inline asm: the compiler's
+  // own wait-count pass cannot see through inline asm.  With the asm form it did not know that the fragments of the
+  // current slab had landed, and put a second `s_waitcnt lgkmcnt(0)` in front of the first MFMA of every slab - AFTER the
+  // ds_reads of the next slab had been issued: the MFMAs waited for the full LDS round trip of loads they do not use, and
+  // matrix-pipe time and LDS time ADDED up instead of overlapping (ablation profiles/r03_bf16p_ablation.txt: 563 ns per
+  // slab = 375 ns without the MFMAs + ~190 ns of MFMAs).
   auto bar = [&]() __attribute__((always_inline)) {
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    asm volatile("" ::: "memory");                      // (compiler fence: LDS accesses stay on their side)
+    __builtin_amdgcn_s_waitcnt(0xC07F);
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
   };
+  // ablation builds (scripts/variant.sh gemm_bf16p NAME -DPB_ABL_...): timing experiments, the results are garbage
+#ifdef PB_ABL_NOBAR
+  auto lbar = [&]() __attribute__((always_inline)) {
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_s_waitcnt(0xC07F);
+    asm volatile("" ::: "memory");
+  };
+#else
+  auto lbar = bar;                                    // the per-slab barrier of the main loop
+#endif
 
   if (wave >= 8) {
     // ================================ loader waves: 24 blocks per slab, 6 per wave ================================
     const int L = wave - 8;
     // block b of a slab: b < 8: A (row tile b>>1, k-half b&1); else W (column tile (b-8)>>1, k-half (b-8)&1)
-    const unsigned short* src[6];
-    int dst[6];
+    const unsigned short* src[PB_NPC];
+    int dst[PB_NPC];
 #pragma unroll
-    for (int n = 0; n < 6; ++n) {
+    for (int n = 0; n < PB_NPC; ++n) {
       const int b = L + PB_NLOAD * n;
       if (b < 2 * PB_ROWT) {
         int rt = rt0 + (b >> 1);
@@ -265,7 +288,7 @@ __device__ __forceinline__ void gemm_bf16p_body(const Bf16pArgs& p, const int bi
     }
     auto issue = [&](int t, int ring) __attribute__((always_inline)) {
 #pragma unroll
-      for (int n = 0; n < 6; ++n) bglds16(src[n] + (long long)t * 1024, lds + ring * PB_SLABB + dst[n]);
+      for (int n = 0; n < PB_NPC; ++n) bglds16(src[n] + (long long)t * 1024, lds + ring * PB_SLABB + dst[n]);
     };
     // prologue: slabs 0 .. R-1 in flight; slabs 0 and 1 (the oldest 12 pieces) must have landed at barrier P: the
     // compute waves fetch slab 0 right after P and slab 1 after B_0, and nothing is waited for in between
@@ -273,19 +296,19 @@ __device__ __forceinline__ void gemm_bf16p_body(const Bf16pArgs& p, const int bi
 #pragma unroll
     for (int r = 0; r < PB_RING; ++r)
       if (r < nslab) { issue(r, r); ++issued; }
-    bwait_vm_dyn(issued > 2 ? 6 * (issued - 2) : 0);
+    bwait_vm_dyn(issued > 2 ? PB_NPC * (issued - 2) : 0);
     bar();                                              // P
     int ring = 0;
 #pragma unroll 1
     for (int g = 0; g < nslab; ++g) {
-      bar();                                            // B_g: every wave holds slab g in registers -> its slot is free
+      lbar();                                           // B_g: every wave holds slab g in registers -> its slot is free
       if (g + PB_RING < nslab) issue(g + PB_RING, ring);
       ring = ring == PB_RING - 1 ? 0 : ring + 1;
       // slab g + 2 must have landed before B_(g+1) (the compute waves fetch its fragments there): everything younger
       // may stay in flight
       int younger = nslab - (g + 3);                    // slabs g+3 .. that have been issued
       younger = younger < 0 ? 0 : (younger > PB_RING - 2 ? PB_RING - 2 : younger);
-      bwait_vm_dyn(6 * younger);
+      bwait_vm_dyn(PB_NPC * younger);
     }
     bar();                                              // S
     return;
@@ -322,29 +345,49 @@ __device__ __forceinline__ void gemm_bf16p_body(const Bf16pArgs& p, const int bi
       for (int i = 0; i < 2; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j)
+#ifdef PB_ABL_NOMMA
+          acc[i][j][0] += (float)a[i][ks][0] + (float)b[j][ks][0];   // keeps the fragment reads alive
+#else
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][ks], b[j][ks], acc[i][j], 0, 0, 0);
+#endif
   };
 
   bf16x8_t aA[2][2], bA[2][2], aB[2][2], bB[2][2];
   bar();                                               // P
   read_frags(aA, bA, 0);
   {
+    // branch-free slab pairs: the fragment reads are unconditional (past the last slab they fetch stale bytes of a valid
+    // ring slot that nobody uses) - a conditional read puts a control-flow join in front of the MFMAs, where the compiler
+    // no longer knows how many LDS operations are outstanding and waits for all of them
     int r1 = 1 % PB_RING, r2 = 2 % PB_RING;            // ring slots of slabs t+1, t+2
+    int t = 0;
 #pragma unroll 1
-    for (int t = 0; t < nslab; t += 2) {
-      bar();                                           // B_t
-      if (t + 1 < nslab) read_frags(aB, bB, r1);
+    for (; t + 1 < nslab; t += 2) {
+      // (sched_barrier: the fragment reads of the NEXT slab are issued first, then the MFMAs of the current one run under
+      // them; left alone, the scheduler sinks the reads towards their uses and the prefetch distance is gone)
+      lbar();                                          // B_t
+      read_frags(aB, bB, r1);
+      __builtin_amdgcn_sched_barrier(0);
       mma(aA, bA);
-      if (t + 1 < nslab) {
-        bar();                                         // B_(t+1)
-        if (t + 2 < nslab) read_frags(aA, bA, r2);
-        mma(aB, bB);
-      }
+      __builtin_amdgcn_sched_barrier(0);
+      lbar();                                          // B_(t+1)
+      read_frags(aA, bA, r2);
+      __builtin_amdgcn_sched_barrier(0);
+      mma(aB, bB);
+      __builtin_amdgcn_sched_barrier(0);
       r1 = r1 + 2 >= PB_RING ? r1 + 2 - PB_RING : r1 + 2;
       r2 = r2 + 2 >= PB_RING ? r2 + 2 - PB_RING : r2 + 2;
     }
+    if (t < nslab) {                                   // odd slab count (split-K ranges)
+      lbar();                                          // B_t
+      mma(aA, bA);
+    }
   }
   bar();                                               // S: all DMA landed and read; the ring becomes epilogue staging
+#ifdef PB_ABL_NOEPI
+  if (acc[0][0][0] == 12345.678f) reinterpret_cast<float*>(lds)[lane] = acc[1][1][3] + acc[0][1][2] + acc[1][0][1];
+  return;
+#endif
 
   float* stage = reinterpret_cast<float*>(lds) + wave * (32 * EPI_LD);
   const int m0 = (rt0 + 2 * wm) * 32, n0 = (ct0 + 2 * wn) * 32;
