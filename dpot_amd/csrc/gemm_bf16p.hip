@@ -336,7 +336,11 @@ __device__ __forceinline__ void gemm_bf16p_body(const Bf16pArgs& p, const int bi
     for (int j = 0; j < 2; ++j)
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks)
+#ifdef PB_ABL_NOBREAD
+        b[j][ks] = a[j][ks];
+#else
         b[j][ks] = *reinterpret_cast<const bf16x8_t*>(base + (2 * PB_ROWT + (2 * wn + j) * 2 + ks) * 1024);
+#endif
   };
   auto mma = [&](const bf16x8_t (&a)[2][2], const bf16x8_t (&b)[2][2]) __attribute__((always_inline)) {
 #pragma unroll
