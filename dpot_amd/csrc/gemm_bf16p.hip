@@ -290,6 +290,9 @@ __device__ __forceinline__ void gemm_bf16p_body(const Bf16pArgs& p, const int bi
 #pragma unroll
       for (int n = 0; n < PB_NPC; ++n) bglds16(src[n] + (long long)t * 1024, lds + ring * PB_SLABB + dst[n]);
     };
+    // (Round 3 also tried REGISTER-STAGED loaders - global_load_dwordx4 -> VGPRs -> ds_write_b128, every loader wave a whole
+    // slab, three slab periods of latency tolerance - on the reading of the ablation that the LDS-DMA path itself is the
+    // limit: 3.5x SLOWER, 256 us against 72 us for the K = 4096 main loop, profiles/r03_bf16p_regstage_rejected.txt.)
     // prologue: slabs 0 .. R-1 in flight; slabs 0 and 1 (the oldest 12 pieces) must have landed at barrier P: the
     // compute waves fetch slab 0 right after P and slab 1 after B_0, and nothing is waited for in between
     int issued = 0;
