@@ -8,6 +8,7 @@ namespace dpot {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
+
 struct EpiArgs {
   float* C;
   int ldc;
@@ -90,13 +91,21 @@ __device__ __forceinline__ Vec4 ld4(const float* p, bool vec) {
 __device__ __forceinline__ void epi_fragment(const EpiArgs& e, int evec, int b, int m0f, int n0f, const f32x16& acc,
                                              float* stage, int lane) {
   const int li = lane & 31, kh = lane >> 5;
+  const int c4 = (lane & 7) * 4;
+  const int n = n0f + c4;
+  // vector path: the bias of this lane's four columns is the same for all four row groups - ONE load per fragment,
+  // issued before the staging round trip (inside the loop it was a dependent L2 access per trip)
+  Vec4 bq;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) bq.v[k] = 0.f;
+  if (evec && e.bias) bq = ld4(e.bias + b * e.sBias + (n < e.N ? n : e.N - 4), true);
 #pragma unroll
   for (int r = 0; r < 16; ++r) stage[((r & 3) + 8 * (r >> 2) + 4 * kh) * EPI_LD + li] = acc[r];
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
   __builtin_amdgcn_wave_barrier();
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-  const int c4 = (lane & 7) * 4;
-  const int n = n0f + c4;
+  // (the loop stays rolled: unrolled - so that the four trips' aux / residual loads are in flight together - the bf16
+  // panel GEMM's epilogues got SLOWER, fc1 forward 139 -> 177 us, and gemm.hip takes 4.5 minutes to compile)
 #pragma unroll 1
   for (int it = 0; it < 4; ++it) {
     const int row = it * 8 + (lane >> 3);
@@ -108,11 +117,8 @@ __device__ __forceinline__ void epi_fragment(const EpiArgs& e, int evec, int b, 
       const bool ok = (m < e.M) && (n < e.N);
       const int mc = m < e.M ? m : e.M - 1;
       const int nc = n < e.N ? n : e.N - 4;
-      if (e.bias) {
-        const Vec4 q = ld4(e.bias + b * e.sBias + nc, true);
 #pragma unroll
-        for (int k = 0; k < 4; ++k) v[k] += q.v[k];
-      }
+      for (int k = 0; k < 4; ++k) v[k] += bq.v[k];
       if (e.pre && ok)
         *reinterpret_cast<float4*>(e.pre + b * e.sPre + (long long)mc * e.ldpre + nc) =
             make_float4(v[0], v[1], v[2], v[3]);

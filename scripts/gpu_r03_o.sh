@@ -1,0 +1,8 @@
+#!/bin/bash
+cd "$GRAFT_REPO_ROOT" || exit 1
+mkdir -p gpurun_out
+timeout 1200 python -m pytest tests/test_gpu_ops.py -m gpu -x -q -k "gemm or linear or bf16 or large_shape or panel" 2>&1 | tail -3 > gpurun_out/r03o_tests.log
+timeout 600 python scripts/bf16p_train_bench.py M L 2>&1 | grep -v "amdgpu\|RASTER\|round 2" > gpurun_out/r03o_bf16p.txt
+timeout 600 python bench.py --no-alt --no-pipeline --skip-cpu-baseline > gpurun_out/r03o_bench.json 2> gpurun_out/r03o_bench.err
+timeout 600 python bench.py --config M --steps 10 --warmup 3 > gpurun_out/r03o_bench_M.json 2> gpurun_out/r03o_bench_M.err
+tail -3 gpurun_out/r03o_tests.log; cat gpurun_out/r03o_bf16p.txt; head -c 250 gpurun_out/r03o_bench.json; echo; head -c 250 gpurun_out/r03o_bench_M.json
