@@ -422,20 +422,21 @@ __device__ __forceinline__ void gemm_bf16p_body(const Bf16pArgs& p, const int bi
     // two staging slabs per wave (values, derivatives): 8 x 2 x 32 x EPI_LD floats = the 72 KiB of the ring exactly
     float* st1 = reinterpret_cast<float*>(lds) + wave * (2 * 32 * EPI_LD);
     float* st2 = st1 + 32 * EPI_LD;
-    if (m0 < p.M) {
-      epi_fragment_pack(p, m0, n0, acc[0][0], st1, st2, lane);
-      epi_fragment_pack(p, m0, n0 + 32, acc[0][1], st1, st2, lane);
-    }
-    if (m0 + 32 < p.M) {
-      epi_fragment_pack(p, m0 + 32, n0, acc[1][0], st1, st2, lane);
-      epi_fragment_pack(p, m0 + 32, n0 + 32, acc[1][1], st1, st2, lane);
+    // ONE copy of the fragment epilogue, looped over the wave's four accumulators (moved into a common register set):
+    // inlined four times the epilogue is ~25 k instructions of straight-line code that every wave runs exactly once
+#pragma unroll 1
+    for (int f = 0; f < 4; ++f) {
+      if (m0 + 32 * (f >> 1) >= p.M) break;
+      const f32x16 a = f == 0 ? acc[0][0] : f == 1 ? acc[0][1] : f == 2 ? acc[1][0] : acc[1][1];
+      epi_fragment_pack(p, m0 + 32 * (f >> 1), n0 + 32 * (f & 1), a, st1, st2, lane);
     }
     return;
   }
-  epi_fragment(p.e, 1, 0, m0, n0, acc[0][0], stage, lane);
-  epi_fragment(p.e, 1, 0, m0, n0 + 32, acc[0][1], stage, lane);
-  epi_fragment(p.e, 1, 0, m0 + 32, n0, acc[1][0], stage, lane);
-  epi_fragment(p.e, 1, 0, m0 + 32, n0 + 32, acc[1][1], stage, lane);
+#pragma unroll 1
+  for (int f = 0; f < 4; ++f) {
+    const f32x16 a = f == 0 ? acc[0][0] : f == 1 ? acc[0][1] : f == 2 ? acc[1][0] : acc[1][1];
+    epi_fragment(p.e, 1, 0, m0 + 32 * (f >> 1), n0 + 32 * (f & 1), a, stage, lane);
+  }
 }
 
 __global__ __launch_bounds__(64 * (8 + PB_NLOAD)) void gemm_bf16p_kernel(const Bf16pArgs p) {
