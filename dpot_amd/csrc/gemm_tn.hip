@@ -203,6 +203,151 @@ __global__ __launch_bounds__(384) void gemm_tn_kernel(const TnArgs p) {
   }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------
+// 192 x 192 variant (round 3): the AFNO weight gradients of DPOT-Large (bs = 96 -> N = 2*bs = 192, not a multiple of the
+// 128-wide tile above; they ran on the generic kernel of gemm.hip at 68 TFLOP/s, 5 % of the DPOT-L step).  One workgroup
+// owns the WHOLE 192 x 192 output of a (channel block, layer) problem x a token range: 3 x 3 compute waves of 64 x 64
+// (same row-interleaved fragments, same 16-byte stores) + 2 loader waves; slabs of 32 tokens = [32][192] per operand
+// (48 KiB), ring of three; a DMA piece is 1 KiB of the slab's linear image - 192 floats per token is a multiple of the
+// 16-byte lane chunk, so a piece never splits a chunk across rows.  Nine waves on four SIMDs leave one SIMD with three:
+// the matrix pipes can reach 75 % at best - against 43 % on the generic kernel.
+// ---------------------------------------------------------------------------------------------------------------------
+constexpr int TW = 192;                      // tile width (both operands)
+constexpr int TW_SLABF = 2 * TN_TOK * TW;    // floats per slab: A [32][192] | B [32][192]
+constexpr int TW_RING = 3;
+constexpr int TW_NI = 24;                    // DMA instructions per slab and loader wave (12 of A + 12 of B)
+
+__global__ __launch_bounds__(704) void gemm_tn192_kernel(const TnArgs p) {
+  __shared__ __attribute__((aligned(16))) float lds[TW_RING * TW_SLABF];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int zb = blockIdx.z / p.splits, zs = blockIdx.z - zb * p.splits;
+  const int nslab_all = p.T / TN_TOK;
+  const int slab0 = zs * p.slabs_per_split;
+  int nslab = nslab_all - slab0;
+  nslab = nslab < p.slabs_per_split ? nslab : p.slabs_per_split;
+  if (nslab < 0) nslab = 0;
+
+  auto bar = [&]() __attribute__((always_inline)) {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+  };
+
+  if (wave >= 9) {
+    // ---------------------------------- loader waves ----------------------------------
+    const int L = wave - 9;
+    const bool second = zb >= p.batch1;
+    const int zq = second ? zb - p.batch1 : zb;
+    const float* abase = (second ? p.A2 : p.A) + zq * p.sA + (long long)slab0 * TN_TOK * p.lda;
+    const float* bbase = (second ? p.B2 : p.B) + zq * p.sB + (long long)slab0 * TN_TOK * p.ldb;
+    auto issue = [&](int t, int ring) __attribute__((always_inline)) {
+      float* dst = lds + ring * TW_SLABF;
+      const float* a = abase + (long long)t * TN_TOK * p.lda;
+      const float* b = bbase + (long long)t * TN_TOK * p.ldb;
+#pragma unroll
+      for (int j = 0; j < 12; ++j) {
+        const int f = 256 * (L + 2 * j) + 4 * lane;     // float index inside the operand's [32][192] image
+        const int tok = f / TW, col = f - tok * TW;
+        tn_glds16(a + (long long)tok * p.lda + col, dst + 256 * (L + 2 * j));
+      }
+#pragma unroll
+      for (int j = 0; j < 12; ++j) {
+        const int f = 256 * (L + 2 * j) + 4 * lane;
+        const int tok = f / TW, col = f - tok * TW;
+        tn_glds16(b + (long long)tok * p.ldb + col, dst + TN_TOK * TW + 256 * (L + 2 * j));
+      }
+    };
+    if (nslab > 0) issue(0, 0);
+    if (nslab > 1) issue(1, 1);
+    if (nslab > 1) tn_wait_vm<TW_NI>(); else tn_wait_vm<0>();
+    bar();                                              // P: slab 0 landed
+    int ring = 2;                                       // slot of slab g + 2
+#pragma unroll 1
+    for (int g = 0; g < nslab; ++g) {
+      tn_wait_vm<0>();                                  // slab g + 1 landed (the compute waves prefetch its first fragments)
+      bar();                                            // B_g: everyone is done with slab g - 1 -> its slot is free
+      if (g + 2 < nslab) issue(g + 2, ring);
+      ring = ring == TW_RING - 1 ? 0 : ring + 1;
+    }
+    return;
+  }
+
+  // ---------------------------------- compute waves ----------------------------------
+  const int wm = wave / 3, wn = wave - 3 * wm;
+  const int i16 = lane & 15, kq = lane >> 4;
+  tn_f32x4 acc[4][4];
+#pragma unroll
+  for (int ea = 0; ea < 4; ++ea)
+#pragma unroll
+    for (int eb = 0; eb < 4; ++eb) acc[ea][eb] = tn_f32x4{0.f, 0.f, 0.f, 0.f};
+  tn_f32x4 cs = {0.f, 0.f, 0.f, 0.f};
+  const int cs_sel = zb >= p.batch1 ? p.cs_of2 : p.cs_of;
+  const bool cs_a = cs_sel == 1 && wn == 0;
+  const bool cs_b = cs_sel == 2 && wm == 0;
+  const int offA = kq * TW + wm * 64 + 4 * i16;
+  const int offB = TN_TOK * TW + kq * TW + wn * 64 + 4 * i16;
+  constexpr int NQ = TN_TOK / 4;
+
+  bar();                                                // P
+  tn_f32x4 fa = {0.f, 0.f, 0.f, 0.f}, fb = fa;
+  if (nslab > 0) {
+    fa = *reinterpret_cast<const tn_f32x4*>(lds + offA);
+    fb = *reinterpret_cast<const tn_f32x4*>(lds + offB);
+  }
+  int ring = 0;
+#pragma unroll 1
+  for (int g = 0; g < nslab; ++g) {
+    bar();                                              // B_g
+    const float* cur = lds + ring * TW_SLABF;
+    const int rn = ring == TW_RING - 1 ? 0 : ring + 1;
+    const float* nxt = g + 1 < nslab ? lds + rn * TW_SLABF : cur;
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+      const tn_f32x4 a = fa, b = fb;
+      const float* src = q + 1 < NQ ? cur + (q + 1) * 4 * TW : nxt;
+      fa = *reinterpret_cast<const tn_f32x4*>(src + offA);
+      fb = *reinterpret_cast<const tn_f32x4*>(src + offB);
+      if (cs_a) cs += a;
+      if (cs_b) cs += b;
+#pragma unroll
+      for (int ea = 0; ea < 4; ++ea)
+#pragma unroll
+        for (int eb = 0; eb < 4; ++eb)
+          acc[ea][eb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[ea], b[eb], acc[ea][eb], 0, 0, 0);
+    }
+    ring = rn;
+  }
+
+  float* ws = p.ws + ((long long)zs * p.batch + zb) * p.N1 * p.N2;
+  const int n1b = wm * 64, n2b = wn * 64 + 4 * i16;
+#pragma unroll
+  for (int ea = 0; ea < 4; ++ea)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int n1 = n1b + 4 * (4 * kq + r) + ea;
+      *reinterpret_cast<float4*>(ws + (long long)n1 * p.N2 + n2b) =
+          make_float4(acc[ea][0][r], acc[ea][1][r], acc[ea][2][r], acc[ea][3][r]);
+    }
+  if (cs_a || cs_b) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      float v = cs[e];
+      v += __shfl_xor(v, 16);
+      v += __shfl_xor(v, 32);
+      cs[e] = v;
+    }
+    if (kq == 0) {
+      const int Lc = p.csL ? p.csL : (cs_a ? p.N1 : p.N2);
+      const int g0 = cs_a ? wm * 64 : wn * 64;
+      float* wc = p.ws + (long long)p.splits * p.batch * p.N1 * p.N2 + ((long long)zs * p.batch + zb) * Lc + g0 + 4 * i16;
+      *reinterpret_cast<float4*>(wc) = make_float4(cs[0], cs[1], cs[2], cs[3]);
+    }
+  }
+}
+
 }  // namespace dpot
 
 using namespace dpot;
@@ -317,8 +462,8 @@ __global__ __launch_bounds__(256) void afno_wgrad2_reduce_kernel(const float* __
 extern "C" int dpot_afno_wgrad2_splitk(int Mm, int nb, int bs) {
   static const int enabled = [] { const char* e = getenv("DPOT_AFNO_WGRAD2"); return e ? atoi(e) : 1; }();
   const int N = 2 * bs;
-  if (!enabled || nb <= 0 || bs <= 0 || N % TN_W || Mm <= 0 || Mm % TN_TOK) return 0;
-  const long long tiles = (long long)2 * nb * (N / TN_W) * (N / TN_W);
+  if (!enabled || nb <= 0 || bs <= 0 || (N % TN_W && N != TW) || Mm <= 0 || Mm % TN_TOK) return 0;
+  const long long tiles = N == TW ? (long long)2 * nb : (long long)2 * nb * (N / TN_W) * (N / TN_W);
   const int nslab = Mm / TN_TOK;
   long long s = (256 + tiles / 2) / tiles;
   const long long smax = nslab / 4;
@@ -339,8 +484,8 @@ extern "C" int dpot_afno_wgrad2(const float* S, const float* dO1pre, const float
                                 int splitk, dpot_stream_t stream) {
   DPOT_REQUIRE(S && dO1pre && O1 && dO2 && dw1 && db1 && dw2 && db2 && workspace, "afno_wgrad2: null pointer");
   const int N = 2 * bs;
-  DPOT_REQUIRE(nb > 0 && bs > 0 && N % TN_W == 0 && Mm > 0 && Mm % TN_TOK == 0 && ld >= nb * N && ld % 4 == 0,
-               "afno_wgrad2: needs 2*bs %% 128 == 0, Mm %% 32 == 0");
+  DPOT_REQUIRE(nb > 0 && bs > 0 && (N % TN_W == 0 || N == TW) && Mm > 0 && Mm % TN_TOK == 0 && ld >= nb * N && ld % 4 == 0,
+               "afno_wgrad2: needs 2*bs %% 128 == 0 or 2*bs == 192, Mm %% 32 == 0");
   DPOT_REQUIRE(aligned16(S) && aligned16(dO1pre) && aligned16(O1) && aligned16(dO2) && aligned16(workspace),
                "afno_wgrad2: operands must be 16-byte aligned");
   const int nslab = Mm / TN_TOK;
@@ -356,8 +501,13 @@ extern "C" int dpot_afno_wgrad2(const float* S, const float* dO1pre, const float
   p.ws = workspace;
   p.cs_of = 2;
   hipStream_t s = as_stream(stream);
-  hipLaunchKernelGGL(gemm_tn_kernel, dim3((unsigned)(p.tiles1 * p.tiles2), 1, (unsigned)(2 * nb * splitk)), dim3(384), 0, s,
-                     p);
+  if (N == TW) {
+    p.tiles1 = p.tiles2 = 1;
+    hipLaunchKernelGGL(gemm_tn192_kernel, dim3(1, 1, (unsigned)(2 * nb * splitk)), dim3(704), 0, s, p);
+  } else {
+    hipLaunchKernelGGL(gemm_tn_kernel, dim3((unsigned)(p.tiles1 * p.tiles2), 1, (unsigned)(2 * nb * splitk)), dim3(384), 0, s,
+                       p);
+  }
   int rc = check_launch("gemm_tn_kernel");
   if (rc) return rc;
   long long blocks = (2ll * nb * bs * bs + 255) / 256;

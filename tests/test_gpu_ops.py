@@ -968,7 +968,9 @@ def test_afno_mlp3_three_product_form(ops, nb, bs, M, act):
     assert_close(o1, f(pre_ref.float().double()), "act(aux) re-derived by the backward launch")     # == the forward's mid
 
 
-@pytest.mark.parametrize("nb,bs,Mm", [(4, 128, 4608), (2, 64, 32 * 13), (8, 128, 32 * 9)])
+@pytest.mark.parametrize("nb,bs,Mm", [(4, 128, 4608), (2, 64, 32 * 13), (8, 128, 32 * 9),
+                                      # round 3: bs = 96 (DPOT-Large, N = 192) on the 192 x 192-tile kernel
+                                      (16, 96, 2176), (3, 96, 32 * 5), (16, 96, 32)])
 def test_afno_wgrad2_both_layers_one_launch(ops, nb, bs, Mm):
     """dpot_afno_wgrad2: the weight + bias gradients of both AFNO MLP layers from one launch of the weight-gradient kernel
     (2*nb independent N x N problems) + one un-packing reduce, against float64 complex arithmetic"""
