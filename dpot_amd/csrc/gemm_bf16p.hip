@@ -106,6 +106,12 @@ __device__ __forceinline__ void epi_fragment_pack(const Bf16pArgs& p, int m0f, i
     if (e.mode == DPOT_EPI_ACT) {
       if (p.dact_out) {
         float d[4];
+#ifdef PB_ABL_NOACT
+        if (true) {
+#pragma unroll
+          for (int k = 0; k < 4; ++k) d[k] = v[k] * 0.5f;
+        } else
+#endif
         if (e.act == DPOT_ACT_GELU) {
 #pragma unroll
           for (int k = 0; k < 4; ++k) gelu_val_der(v[k], v[k], d[k]);
@@ -145,6 +151,7 @@ __device__ __forceinline__ void epi_fragment_pack(const Bf16pArgs& p, int m0f, i
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
   __builtin_amdgcn_wave_barrier();
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#ifndef PB_ABL_NOSTORE
   if (p.out_rows) {     // 128 chunks (row, column octet): chunk id = lane + 64 s -> row = id >> 2, octet = id & 3
 #pragma unroll
     for (int s2 = 0; s2 < 2; ++s2) {
@@ -167,6 +174,7 @@ __device__ __forceinline__ void epi_fragment_pack(const Bf16pArgs& p, int m0f, i
           make_uint4(pack2(x0.x, x0.y), pack2(x0.z, x0.w), pack2(x1.x, x1.y), pack2(x1.z, x1.w));
     }
   }
+#ifndef PB_ABL_NOTRANS
   if (p.out_trans) {    // 128 chunks (column, row octet): id = lane + 64 s -> column = id & 31, octet = id >> 5
 #pragma unroll
     for (int s2 = 0; s2 < 2; ++s2) {
@@ -179,6 +187,8 @@ __device__ __forceinline__ void epi_fragment_pack(const Bf16pArgs& p, int m0f, i
           make_uint4(pack2(x[0], x[1]), pack2(x[2], x[3]), pack2(x[4], x[5]), pack2(x[6], x[7]));
     }
   }
+#endif
+#endif
   if (p.cs_part) {      // column sums of the 32 rows, fixed order: 16 rows per half-wave, then the two halves
     float a = 0.f;
 #pragma unroll
