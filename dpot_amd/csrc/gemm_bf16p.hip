@@ -686,53 +686,57 @@ __global__ __launch_bounds__(256) void bf16_pack_rows_kernel(const float* __rest
 
 // One pass over an activation matrix src [R, K] (tokens x features) that produces BOTH packed forms the channel MLP
 // needs - the row form (GEMM A operand: rows = tokens, k = features) and the transposed form (weight-gradient operand:
-// rows = features, k = tokens) - and, optionally, per-block partial column sums (the bias gradient).  A thread owns an
-// 8 x 8 patch: 8 row-form chunks (one per token) and 8 transposed chunks (one per feature).  Block = 32 feature groups x
-// 8 token groups = 256 features x 64 tokens.  R % 64 == 0, K % 256 == 0.
+// rows = features, k = tokens) - and, optionally, per-block partial column sums (the bias gradient).
+// Block = 64 tokens x 256 features, staged through LDS (pitch 260 floats: the 16-byte fragment reads of 32 consecutive
+// rows fall on all 64 banks), so that every wave-instruction stores ONE whole 1 KiB fragment block - 64 consecutive
+// 16-byte chunks.  (Round 2 kept an 8 x 8 patch per thread and stored its chunks straight from registers: a store
+// instruction scattered its 64 chunks over 64 different blocks, 20 us for 67 MB at DPOT-M = 3.3 TB/s.)
+// R % 64 == 0, K % 256 == 0.
+constexpr int PKB_PITCH = 260;
 __global__ __launch_bounds__(256) void bf16_pack_both_kernel(const float* __restrict__ src, int ld, int R, int K,
                                                              uint4* __restrict__ drow, uint4* __restrict__ dtr,
                                                              float* __restrict__ cpart) {
-  __shared__ float red[8][256];
-  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
-  const int c0 = blockIdx.x * 256 + tx * 8, r0 = blockIdx.y * 64 + ty * 8;
-  float v[8][8];
+  __shared__ __attribute__((aligned(16))) float tile[64 * PKB_PITCH];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int c0 = blockIdx.x * 256, r0 = blockIdx.y * 64;
+  // phase 1: 64 rows x 1 KiB, a wave per row (16 rows per wave), straight into the LDS tile; column sums on the way
+  float4 cs = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
-  for (int i = 0; i < 8; ++i) {
-    const float4 x0 = *reinterpret_cast<const float4*>(src + (long long)(r0 + i) * ld + c0);
-    const float4 x1 = *reinterpret_cast<const float4*>(src + (long long)(r0 + i) * ld + c0 + 4);
-    v[i][0] = x0.x; v[i][1] = x0.y; v[i][2] = x0.z; v[i][3] = x0.w;
-    v[i][4] = x1.x; v[i][5] = x1.y; v[i][6] = x1.z; v[i][7] = x1.w;
+  for (int i = 0; i < 16; ++i) {
+    const int row = wave + 4 * i;
+    const float4 v = *reinterpret_cast<const float4*>(src + (long long)(r0 + row) * ld + c0 + 4 * lane);
+    *reinterpret_cast<float4*>(&tile[row * PKB_PITCH + 4 * lane]) = v;
+    cs.x += v.x; cs.y += v.y; cs.z += v.z; cs.w += v.w;
   }
-  if (drow) {   // chunk (token r, features c0..c0+7): block (r >> 5, c0 >> 4), slot (r & 31) + 32 * ((c0 >> 3) & 1)
+  __syncthreads();
+  if (drow) {   // block (row tile rt, 16-k block kb): chunk l = (row l & 31, features 8 * (l >> 5) .. + 7)
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      const int r = r0 + i;
-      drow[((long long)(r >> 5) * (K >> 4) + (c0 >> 4)) * 64 + (r & 31) + 32 * ((c0 >> 3) & 1)] =
-          make_uint4(pack2(v[i][0], v[i][1]), pack2(v[i][2], v[i][3]), pack2(v[i][4], v[i][5]), pack2(v[i][6], v[i][7]));
+    for (int q = 0; q < 8; ++q) {
+      const int b = wave + 4 * q, rt = b >> 4, kb = b & 15;
+      const float* t = &tile[(32 * rt + (lane & 31)) * PKB_PITCH + 16 * kb + 8 * (lane >> 5)];
+      const float4 x0 = *reinterpret_cast<const float4*>(t), x1 = *reinterpret_cast<const float4*>(t + 4);
+      drow[((long long)((r0 >> 5) + rt) * (K >> 4) + (c0 >> 4) + kb) * 64 + lane] =
+          make_uint4(pack2(x0.x, x0.y), pack2(x0.z, x0.w), pack2(x1.x, x1.y), pack2(x1.z, x1.w));
     }
   }
-  if (dtr) {    // chunk (feature f, tokens r0..r0+7): block (f >> 5, r0 >> 4), slot (f & 31) + 32 * ((r0 >> 3) & 1)
+  if (dtr) {    // block (feature tile ft, 16-token block tb): chunk l = (feature l & 31, tokens 8 * (l >> 5) .. + 7)
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      const int f = c0 + j;
-      dtr[((long long)(f >> 5) * (R >> 4) + (r0 >> 4)) * 64 + (f & 31) + 32 * ((r0 >> 3) & 1)] =
-          make_uint4(pack2(v[0][j], v[1][j]), pack2(v[2][j], v[3][j]), pack2(v[4][j], v[5][j]), pack2(v[6][j], v[7][j]));
+    for (int q = 0; q < 8; ++q) {
+      const int b = wave + 4 * q, ft = b >> 2, tb = b & 3;
+      const float* t = &tile[(16 * tb + 8 * (lane >> 5)) * PKB_PITCH + 32 * ft + (lane & 31)];
+      float x[8];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) x[i] = t[i * PKB_PITCH];
+      dtr[((long long)((c0 >> 5) + ft) * (R >> 4) + (r0 >> 4) + tb) * 64 + lane] =
+          make_uint4(pack2(x[0], x[1]), pack2(x[2], x[3]), pack2(x[4], x[5]), pack2(x[6], x[7]));
     }
   }
-  if (cpart) {  // column sums of this block's 64 tokens, fixed order: 8 rows in the thread, then the 8 token groups
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      float a = 0.f;
-#pragma unroll
-      for (int i = 0; i < 8; ++i) a += v[i][j];
-      red[ty][tx * 8 + j] = a;
-    }
+  if (cpart) {  // column sums of this block's 64 tokens, fixed order: 16 rows in the thread, then the 4 waves
+    __syncthreads();                                       // the tile is dead: its head becomes the reduction scratch
+    *reinterpret_cast<float4*>(&tile[wave * 256 + 4 * lane]) = cs;
     __syncthreads();
-    const int c = threadIdx.x;
-    float a = 0.f;
-#pragma unroll
-    for (int g = 0; g < 8; ++g) a += red[g][c];
-    cpart[(long long)blockIdx.y * K + blockIdx.x * 256 + c] = a;
+    const float a = (tile[tid] + tile[256 + tid]) + (tile[512 + tid] + tile[768 + tid]);
+    cpart[(long long)blockIdx.y * K + c0 + tid] = a;
   }
 }
 

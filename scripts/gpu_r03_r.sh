@@ -1,0 +1,8 @@
+#!/bin/bash
+cd "$GRAFT_REPO_ROOT" || exit 1
+mkdir -p gpurun_out
+timeout 1200 python -m pytest tests/test_gpu_ops.py -m gpu -x -q -k "bf16 or pack" 2>&1 | tail -3 > gpurun_out/r03r_tests.log
+timeout 600 python scripts/bf16p_train_bench.py M L 2>&1 | grep "pack_both\|tokens" > gpurun_out/r03r_pack.txt
+timeout 600 python bench.py --config M --steps 10 --warmup 3 > gpurun_out/r03r_bench_M.json 2> gpurun_out/r03r_bench_M.err
+timeout 600 python bench.py --config S --steps 10 --warmup 3 > gpurun_out/r03r_bench_S.json 2> gpurun_out/r03r_bench_S.err
+cat gpurun_out/r03r_tests.log gpurun_out/r03r_pack.txt; head -c 250 gpurun_out/r03r_bench_M.json; echo; head -c 250 gpurun_out/r03r_bench_S.json
