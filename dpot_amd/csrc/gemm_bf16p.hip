@@ -152,10 +152,10 @@ __device__ __forceinline__ void epi_fragment_pack(const Bf16pArgs& p, int m0f, i
   __builtin_amdgcn_wave_barrier();
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 #ifndef PB_ABL_NOSTORE
-  if (p.out_rows) {     // 128 chunks (row, column octet): chunk id = lane + 64 s -> row = id >> 2, octet = id & 3
-#pragma unroll
+  if (p.out_rows) {     // 128 chunks (row, column octet) = two 1 KiB blocks (16 columns each): instruction s2 writes block s2
+#pragma unroll          // whole - lane l = chunk l of the block = (row l & 31, octet l >> 5): 64 consecutive 16-byte chunks
     for (int s2 = 0; s2 < 2; ++s2) {
-      const int id = lane + 64 * s2, row = id >> 2, oc = id & 3;
+      const int row = lane & 31, oc = 2 * s2 + (lane >> 5);
       const float4 x0 = *reinterpret_cast<const float4*>(&stage[row * EPI_LD + 8 * oc]);
       const float4 x1 = *reinterpret_cast<const float4*>(&stage[row * EPI_LD + 8 * oc + 4]);
       const int m = m0f + row, nn = n0f + 8 * oc;
@@ -166,7 +166,7 @@ __device__ __forceinline__ void epi_fragment_pack(const Bf16pArgs& p, int m0f, i
   if (p.dact_out) {     // the derivative, same chunking as out_rows, from the second staging slab
 #pragma unroll
     for (int s2 = 0; s2 < 2; ++s2) {
-      const int id = lane + 64 * s2, row = id >> 2, oc = id & 3;
+      const int row = lane & 31, oc = 2 * s2 + (lane >> 5);
       const float4 x0 = *reinterpret_cast<const float4*>(&stage2[row * EPI_LD + 8 * oc]);
       const float4 x1 = *reinterpret_cast<const float4*>(&stage2[row * EPI_LD + 8 * oc + 4]);
       const int m = m0f + row, nn = n0f + 8 * oc;
