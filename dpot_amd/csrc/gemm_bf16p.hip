@@ -79,7 +79,7 @@ __device__ __forceinline__ unsigned pack2(float lo, float hi) {
 __device__ __forceinline__ unsigned long long ld8(const void* p) { return *reinterpret_cast<const unsigned long long*>(p); }
 
 __device__ __forceinline__ void epi_fragment_pack(const Bf16pArgs& p, int m0f, int n0f, const f32x16& acc, float* stage,
-                                                  float* stage2, int lane) {
+                                                  int lane) {
   const EpiArgs& e = p.e;
   const int li = lane & 31, kh = lane >> 5;
   const int c4 = (lane & 7) * 4;
@@ -104,41 +104,12 @@ __device__ __forceinline__ void epi_fragment_pack(const Bf16pArgs& p, int m0f, i
     float v[4] = {t.x + bq.v[0], t.y + bq.v[1], t.z + bq.v[2], t.w + bq.v[3]};
     if (e.pre) *reinterpret_cast<float4*>(e.pre + (long long)m * e.ldpre + n) = make_float4(v[0], v[1], v[2], v[3]);
     if (e.mode == DPOT_EPI_ACT) {
-      if (p.dact_out) {
-        float d[4];
-#ifdef PB_ABL_NOACT
-        if (true) {
 #pragma unroll
-          for (int k = 0; k < 4; ++k) d[k] = v[k] * 0.5f;
-        } else
-#endif
-        if (e.act == DPOT_ACT_GELU) {
-#pragma unroll
-          for (int k = 0; k < 4; ++k) gelu_val_der(v[k], v[k], d[k]);
-        } else {
-#pragma unroll
-          for (int k = 0; k < 4; ++k) { d[k] = act_bwd(e.act, v[k]); v[k] = act_fwd(e.act, v[k]); }
-        }
-        *reinterpret_cast<float4*>(&stage2[row * EPI_LD + c4]) = make_float4(d[0], d[1], d[2], d[3]);
-      } else {
-#pragma unroll
-        for (int k = 0; k < 4; ++k) v[k] = act_fwd(e.act, v[k]);
-      }
+      for (int k = 0; k < 4; ++k) v[k] = act_fwd(e.act, v[k]);
     } else if (e.mode == DPOT_EPI_DACT) {
-      if (p.dact_in) {
-        // the fragment's derivatives are 2 KiB contiguous: block pair (m0f/32, n0f/16 + {0,1}), chunk (row, octet)
-        const unsigned short* dp = p.dact_in + (((long long)(m0f >> 5) * (p.N >> 4) + (n0f >> 4) + (c4 >> 4)) * 64 +
-                                                row + 32 * ((c4 >> 3) & 1)) * 8 + (c4 & 4);
-        const unsigned long long q = ld8(dp);
-        v[0] *= __uint_as_float((unsigned)(q & 0xffffull) << 16);
-        v[1] *= __uint_as_float((unsigned)(q >> 16) << 16);
-        v[2] *= __uint_as_float((unsigned)(q >> 32) << 16);
-        v[3] *= __uint_as_float((unsigned)(q >> 48) << 16);
-      } else {
-        const Vec4 q = ld4(e.aux + (long long)m * e.ldaux + n, true);
+      const Vec4 q = ld4(e.aux + (long long)m * e.ldaux + n, true);
 #pragma unroll
-        for (int k = 0; k < 4; ++k) v[k] *= act_bwd(e.act, q.v[k]);
-      }
+      for (int k = 0; k < 4; ++k) v[k] *= act_bwd(e.act, q.v[k]);
     }
     if (e.res) {
       const Vec4 q = ld4(e.res + (long long)m * e.ldres + n, true);
@@ -160,17 +131,6 @@ __device__ __forceinline__ void epi_fragment_pack(const Bf16pArgs& p, int m0f, i
       const float4 x1 = *reinterpret_cast<const float4*>(&stage[row * EPI_LD + 8 * oc + 4]);
       const int m = m0f + row, nn = n0f + 8 * oc;
       p.out_rows[((long long)(m >> 5) * (p.N >> 4) + (nn >> 4)) * 64 + (m & 31) + 32 * ((nn >> 3) & 1)] =
-          make_uint4(pack2(x0.x, x0.y), pack2(x0.z, x0.w), pack2(x1.x, x1.y), pack2(x1.z, x1.w));
-    }
-  }
-  if (p.dact_out) {     // the derivative, same chunking as out_rows, from the second staging slab
-#pragma unroll
-    for (int s2 = 0; s2 < 2; ++s2) {
-      const int row = lane & 31, oc = 2 * s2 + (lane >> 5);
-      const float4 x0 = *reinterpret_cast<const float4*>(&stage2[row * EPI_LD + 8 * oc]);
-      const float4 x1 = *reinterpret_cast<const float4*>(&stage2[row * EPI_LD + 8 * oc + 4]);
-      const int m = m0f + row, nn = n0f + 8 * oc;
-      p.dact_out[((long long)(m >> 5) * (p.N >> 4) + (nn >> 4)) * 64 + (m & 31) + 32 * ((nn >> 3) & 1)] =
           make_uint4(pack2(x0.x, x0.y), pack2(x0.z, x0.w), pack2(x1.x, x1.y), pack2(x1.z, x1.w));
     }
   }
@@ -197,6 +157,151 @@ __device__ __forceinline__ void epi_fragment_pack(const Bf16pArgs& p, int m0f, i
     if (kh == 0) p.cs_part[(long long)(m0f >> 5) * p.N + n0f + li] = a;
   }
   __builtin_amdgcn_wave_barrier();
+}
+
+// The same packed-output epilogue computed IN THE ACCUMULATOR LAYOUT (round 3; the launches of the bf16 channel MLP:
+// no fp32 pre-activation, no residual).  A lane of a 32x32 fragment holds ONE column (lane & 31) and 16 rows
+// (row(r) = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)), so
+//   * bias is one scalar per lane, and the activation + derivative run on 16 independent register values (the staged
+//     form above evaluates 4 per trip of a rolled loop behind an LDS round trip: the epilogue was bound by that latency
+//     chain - 54 of 142 us at fc1 forward of DPOT-M - not by its stores);
+//   * the derivative pack is written / read in FRAGMENT ORDER - [M/32][N/32][2][64 lanes][8 bf16], lane's r = 8 s .. 8 s + 7
+//     in half s - straight from / into registers: producer (fc1 forward) and consumer (fc2 data gradient) have the same
+//     fragment grid, nobody else reads it;
+//   * the transposed pack's chunks are (column, 8 consecutive rows): a lane has rows 8 j + 4 kh .. + 3, its partner in the
+//     other half-wave the other four - one v_permlane32_swap per packed pair completes them, no LDS;
+//   * the column sums are in-lane sums + one cross-half add;
+//   * only the row-form pack (and the optional fp32 store) needs the transpose through LDS: one round trip.
+typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+// 16-byte store of a pack chunk, non-temporal: the packs are read by the NEXT kernel (67 MB each at DPOT-M) and only push
+// the operand panels out of L2 (fc2 data gradient at DPOT-M 120.4 -> 112.4 us; -DPB_NO_NT_STORES: plain stores)
+__device__ __forceinline__ void st_chunk(uint4* p, unsigned a, unsigned b, unsigned c, unsigned d) {
+#ifndef PB_NO_NT_STORES
+  const u32x4_t v = {a, b, c, d};
+  __builtin_nontemporal_store(v, reinterpret_cast<u32x4_t*>(p));
+#else
+  *p = make_uint4(a, b, c, d);
+#endif
+}
+__device__ __forceinline__ float bf_lo(unsigned q) { return __uint_as_float(q << 16); }
+__device__ __forceinline__ float bf_hi(unsigned q) { return __uint_as_float(q & 0xffff0000u); }
+
+__device__ __forceinline__ void epi_fragment_direct(const Bf16pArgs& p, int m0f, int n0f, const f32x16& acc, float* stage,
+                                                    int lane) {
+  const EpiArgs& e = p.e;
+  const int li = lane & 31, kh = lane >> 5;
+  const long long frag = (long long)(m0f >> 5) * (p.N >> 5) + (n0f >> 5);
+  const float bq = e.bias ? e.bias[n0f + li] : 0.f;
+  const bool to_lds = p.out_rows || e.C;
+  const bool want_d = e.mode == DPOT_EPI_ACT && p.dact_out;
+  unsigned q[8];                                       // act' pack of this lane (EPI_DACT)
+  if (e.mode == DPOT_EPI_DACT) {                       // host-checked: dact_in
+    const uint4* dp = reinterpret_cast<const uint4*>(p.dact_in) + frag * 128 + lane;
+    const uint4 q0 = dp[0], q1 = dp[64];
+    q[0] = q0.x; q[1] = q0.y; q[2] = q0.z; q[3] = q0.w; q[4] = q1.x; q[5] = q1.y; q[6] = q1.z; q[7] = q1.w;
+  }
+  // four values at a time (register budget: the wave still holds its other three accumulators - 8 at a time spilled 400
+  // registers in the two-workgroup kernel); what stays live across the groups is packed: w = the values, dq = act'
+  unsigned w[8], dq[8];
+  float cs = 0.f;
+#pragma unroll
+  for (int g = 0; g < 4; ++g) {
+    float v[4], d[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) v[k] = acc[4 * g + k] + bq;
+    if (e.mode == DPOT_EPI_ACT) {
+      if (want_d) {
+#ifdef PB_ABL_NOACT
+        if (true) {
+#pragma unroll
+          for (int k = 0; k < 4; ++k) d[k] = v[k] * 0.5f;
+        } else
+#endif
+        if (e.act == DPOT_ACT_GELU) {
+#pragma unroll
+          for (int k = 0; k < 4; ++k) gelu_val_der(v[k], v[k], d[k]);
+        } else {
+#pragma unroll
+          for (int k = 0; k < 4; ++k) { d[k] = act_bwd(e.act, v[k]); v[k] = act_fwd(e.act, v[k]); }
+        }
+        dq[2 * g] = pack2(d[0], d[1]);
+        dq[2 * g + 1] = pack2(d[2], d[3]);
+      } else if (e.act == DPOT_ACT_GELU) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) v[k] = gelu_fwd(v[k]);
+      } else {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) v[k] = act_fwd(e.act, v[k]);
+      }
+    } else if (e.mode == DPOT_EPI_DACT) {
+      v[0] *= bf_lo(q[2 * g]); v[1] *= bf_hi(q[2 * g]); v[2] *= bf_lo(q[2 * g + 1]); v[3] *= bf_hi(q[2 * g + 1]);
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) cs += v[k];            // fixed order: r ascending
+    if (to_lds) {                                      // rows (r & 3) + 8 (r >> 2) + 4 kh, r = 4 g + k
+#pragma unroll
+      for (int k = 0; k < 4; ++k) stage[(k + 8 * g + 4 * kh) * EPI_LD + li] = v[k];
+    }
+    w[2 * g] = pack2(v[0], v[1]);
+    w[2 * g + 1] = pack2(v[2], v[3]);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+#ifndef PB_ABL_NOSTORE
+  if (want_d) {
+    uint4* dp = p.dact_out + frag * 128 + lane;
+    st_chunk(dp, dq[0], dq[1], dq[2], dq[3]);
+    st_chunk(dp + 64, dq[4], dq[5], dq[6], dq[7]);
+  }
+  if (p.out_trans) {
+    // packed pairs w[k] = rows (2k, 2k+1 of this lane's 16).  Lane kh = 0 completes row octets 0 and 2, kh = 1 octets 1
+    // and 3: swap the upper half-wave of X = w[a] with the lower half-wave of Y = w[a + 2], a in {0, 1, 4, 5} - then
+    // (X, Y) = (own, partner's) in the lower half, (partner's, own) in the upper, i.e. rows ascending in both
+    unsigned X[4] = {w[0], w[1], w[4], w[5]};
+    unsigned Y[4] = {w[2], w[3], w[6], w[7]};
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const auto sw = __builtin_amdgcn_permlane32_swap(X[k], Y[k], false, false);
+      X[k] = sw[0];
+      Y[k] = sw[1];
+    }
+    // octet kh -> block (n0f / 32, m0f / 16), chunk li + 32 kh = lane; octet 2 + kh -> the next block: each instruction
+    // writes one whole 1 KiB block
+    uint4* tp = p.out_trans + ((long long)(n0f >> 5) * (p.M >> 4) + (m0f >> 4)) * 64 + lane;
+    st_chunk(tp, X[0], X[1], Y[0], Y[1]);
+    st_chunk(tp + 64, X[2], X[3], Y[2], Y[3]);
+  }
+#endif
+  if (p.cs_part) {      // column sums of the fragment's 32 rows: 16 in the lane (fixed order), then the two half-waves
+    cs += __shfl_xor(cs, 32);
+    if (kh == 0) p.cs_part[(long long)(m0f >> 5) * p.N + n0f + li] = cs;
+  }
+  if (to_lds) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#ifndef PB_ABL_NOSTORE
+    if (p.out_rows) {   // instruction s2 writes block s2 whole: lane l = chunk (row l & 31, column octet 2 s2 + (l >> 5))
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2) {
+        const int oc = 2 * s2 + kh;
+        const float4 x0 = *reinterpret_cast<const float4*>(&stage[li * EPI_LD + 8 * oc]);
+        const float4 x1 = *reinterpret_cast<const float4*>(&stage[li * EPI_LD + 8 * oc + 4]);
+        st_chunk(p.out_rows + ((long long)(m0f >> 5) * (p.N >> 4) + (n0f >> 4) + s2) * 64 + lane, pack2(x0.x, x0.y),
+                 pack2(x0.z, x0.w), pack2(x1.x, x1.y), pack2(x1.z, x1.w));
+      }
+    }
+#endif
+    if (e.C) {
+      const int c4 = (lane & 7) * 4;
+#pragma unroll
+      for (int it = 0; it < 4; ++it) {
+        const int row = it * 8 + (lane >> 3);
+        *reinterpret_cast<float4*>(e.C + (long long)(m0f + row) * e.ldc + n0f + c4) =
+            *reinterpret_cast<const float4*>(&stage[row * EPI_LD + c4]);
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
+  }
 }
 
 constexpr int PB_ROWT = 4;      // 32-row tiles per workgroup (128 rows)
@@ -429,16 +534,17 @@ __device__ __forceinline__ void gemm_bf16p_body(const Bf16pArgs& p, const int bi
     return;
   }
   if (p.out_rows || p.out_trans || p.cs_part || p.dact_out || p.dact_in) {   // host-checked: M % 32 == 0
-    // two staging slabs per wave (values, derivatives): 8 x 2 x 32 x EPI_LD floats = the 72 KiB of the ring exactly
-    float* st1 = reinterpret_cast<float*>(lds) + wave * (2 * 32 * EPI_LD);
-    float* st2 = st1 + 32 * EPI_LD;
+    float* st1 = reinterpret_cast<float*>(lds) + wave * (32 * EPI_LD);
     // ONE copy of the fragment epilogue, looped over the wave's four accumulators (moved into a common register set):
     // inlined four times the epilogue is ~25 k instructions of straight-line code that every wave runs exactly once
+    // (host-checked: act' packs only in the direct form)
+    const bool direct = !p.e.pre && !p.e.res && !(p.e.mode == DPOT_EPI_DACT && !p.dact_in);
 #pragma unroll 1
     for (int f = 0; f < 4; ++f) {
       if (m0 + 32 * (f >> 1) >= p.M) break;
       const f32x16 a = f == 0 ? acc[0][0] : f == 1 ? acc[0][1] : f == 2 ? acc[1][0] : acc[1][1];
-      epi_fragment_pack(p, m0 + 32 * (f >> 1), n0 + 32 * (f & 1), a, st1, st2, lane);
+      if (direct) epi_fragment_direct(p, m0 + 32 * (f >> 1), n0 + 32 * (f & 1), a, st1, lane);
+      else epi_fragment_pack(p, m0 + 32 * (f >> 1), n0 + 32 * (f & 1), a, st1, lane);
     }
     return;
   }
@@ -457,6 +563,130 @@ __global__ __launch_bounds__(64 * (8 + PB_NLOAD)) void gemm_bf16p_kernel(const B
 // was built and measured in round 3 on the theory that the main loop is bound by operand latency: it is SLOWER on every
 // DPOT-M / -L shape (fc1 forward at DPOT-M 167.6 against 145.6 us, fc2 forward 134.6 against 92.3 us;
 // profiles/r03_bf16p_train_bench_tile256_rejected.txt) and was removed.)
+
+// ---------------------------------------------------------------------------------------------------------------------
+// "duo" form of the same GEMM for the launches with a FAT epilogue and several rounds of tiles (fc1 forward: GELU + its
+// derivative + three bf16 packs = 201 MB at DPOT-M; fc2 data gradient).  In the 12-wave kernel above a CU holds ONE
+// workgroup (133 VGPRs x 12 waves), all 256 CUs run the same phase, and the epilogue (13.7 us per round of tiles at fc1
+// forward, 54 of 142 us) runs with the matrix pipes idle.  Here a workgroup is 8 SELF-LOADING waves with one fragment
+// register set (<= 128 VGPRs, 72 KiB of LDS): TWO workgroups share a CU, and the one in its epilogue leaves the matrix
+// pipes and the operand path to the other.  Same tile, wave grid, slab ring and epilogue code; the fragment reads of a
+// wave are no longer prefetched under its own MFMAs - the other three waves of the SIMD cover them.
+//   * per slab and wave: 3 of the 24 one-KiB DMA pieces; slab g + 2 is issued after barrier B_g (the slot of slab g - 1,
+//     which every wave has consumed: its MFMAs were issued before B_g), waited for (counted vmcnt) before B_(g+2);
+//   * nothing forces the two workgroups of a CU out of phase; a raised wave priority for the first 256 workgroups and a
+//     delayed start of the second 256 (0.3 - 0.7 of a main loop) were measured and change nothing
+//     (profiles/r03_bf16p_duo.txt): the gain is not an alternation of epilogue and main loop but 16 waves per CU in
+//     both - the main loop alone takes 65-72 us instead of 84-89 at fc1 forward of DPOT-M.
+// No split-K (the weight gradients have 3.4 MB epilogues and stay on the 12-wave kernel).
+__global__ __launch_bounds__(512, 4) void gemm_bf16p_duo_kernel(const Bf16pArgs p) {
+  __shared__ __attribute__((aligned(16))) unsigned char lds[3 * PB_SLABB];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int ks16 = p.K >> 4;
+  const int nslab = p.K >> 5;
+  const int bid0 = blockIdx.x;
+  int tm, tn;
+  {
+    const int ntiles = p.tilesM * p.tilesN;
+    const int xcd = bid0 & 7, slot = bid0 >> 3;
+    const int q = ntiles >> 3, r = ntiles & 7;
+    const int tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + slot;
+    tn = tile / p.tilesM;
+    tm = tile - tn * p.tilesM;
+  }
+  const int rt0 = tm * PB_ROWT, ct0 = tn * PB_COLT;
+  const int mtiles = (p.M + 31) >> 5;
+  // this wave's 3 pieces of a slab: piece b = wave + 8 n; b < 8: A (row tile b >> 1, k-half b & 1), else W
+  const unsigned short* src[3];
+  int dst[3];
+#pragma unroll
+  for (int n = 0; n < 3; ++n) {
+    const int b = wave + 8 * n;
+    if (b < 2 * PB_ROWT) {
+      int rt = rt0 + (b >> 1);
+      rt = rt < mtiles ? rt : mtiles - 1;
+      src[n] = p.A + ((long long)rt * ks16 + (b & 1)) * 512 + lane * 8;
+    } else {
+      const int c = b - 2 * PB_ROWT;
+      src[n] = p.W + ((long long)(ct0 + (c >> 1)) * ks16 + (c & 1)) * 512 + lane * 8;
+    }
+    dst[n] = b * 1024;
+  }
+  auto issue = [&](int t, int ring) __attribute__((always_inline)) {
+#pragma unroll
+    for (int n = 0; n < 3; ++n) bglds16(src[n] + (long long)t * 1024, lds + ring * PB_SLABB + dst[n]);
+  };
+
+  const int wm = wave >> 2, wn = wave & 3;
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  issue(0, 0);
+  if (nslab > 1) issue(1, 1);
+  int ring = 0, ring2 = 2;                            // slots of slab g and of slab g + 2
+#pragma unroll 1
+  for (int g = 0; g < nslab; ++g) {
+    if (g + 1 < nslab) bwait_vm<3>(); else bwait_vm<0>();   // own pieces of slab g have landed (slab g + 1 may fly)
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_s_barrier();                     // B_g: slab g complete; slab g - 1 consumed by every wave
+    asm volatile("" ::: "memory");
+    if (g + 2 < nslab) issue(g + 2, ring2);
+    const unsigned char* base = lds + ring * PB_SLABB + lane * 16;
+    bf16x8_t a[2][2], b[2][2];
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+#pragma unroll
+      for (int i = 0; i < 2; ++i) a[i][ks] = *reinterpret_cast<const bf16x8_t*>(base + ((2 * wm + i) * 2 + ks) * 1024);
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+        b[j][ks] = *reinterpret_cast<const bf16x8_t*>(base + (2 * PB_ROWT + (2 * wn + j) * 2 + ks) * 1024);
+    }
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][ks], b[j][ks], acc[i][j], 0, 0, 0);
+    ring = ring == 2 ? 0 : ring + 1;
+    ring2 = ring2 == 2 ? 0 : ring2 + 1;
+  }
+  asm volatile("" ::: "memory");
+  __builtin_amdgcn_s_waitcnt(0xC07F);
+  __builtin_amdgcn_s_barrier();                       // S: every wave has read the last slab; the ring becomes staging
+  asm volatile("" ::: "memory");
+
+#ifdef PB_ABL_NOEPI
+  if (acc[0][0][0] == 12345.678f) reinterpret_cast<float*>(lds)[lane] = acc[1][1][3] + acc[0][1][2] + acc[1][0][1];
+  return;
+#endif
+  const int m0 = (rt0 + 2 * wm) * 32, n0 = (ct0 + 2 * wn) * 32;
+  if (p.out_rows || p.out_trans || p.cs_part || p.dact_out || p.dact_in) {
+    float* st1 = reinterpret_cast<float*>(lds) + wave * (32 * EPI_LD);
+    const bool direct = !p.e.pre && !p.e.res && !(p.e.mode == DPOT_EPI_DACT && !p.dact_in);
+#pragma unroll 1
+    for (int f = 0; f < 4; ++f) {
+      if (m0 + 32 * (f >> 1) >= p.M) break;
+      const f32x16 af = f == 0 ? acc[0][0] : f == 1 ? acc[0][1] : f == 2 ? acc[1][0] : acc[1][1];
+      if (direct) epi_fragment_direct(p, m0 + 32 * (f >> 1), n0 + 32 * (f & 1), af, st1, lane);
+      else epi_fragment_pack(p, m0 + 32 * (f >> 1), n0 + 32 * (f & 1), af, st1, lane);
+    }
+    return;
+  }
+  float* stage = reinterpret_cast<float*>(lds) + wave * (32 * EPI_LD);
+#pragma unroll 1
+  for (int f = 0; f < 4; ++f) {
+    const f32x16 af = f == 0 ? acc[0][0] : f == 1 ? acc[0][1] : f == 2 ? acc[1][0] : acc[1][1];
+    epi_fragment(p.e, 1, 0, m0 + 32 * (f >> 1), n0 + 32 * (f & 1), af, stage, lane);
+  }
+}
 
 // two independent problems in ONE launch (the fc1 and fc2 weight gradients of a block: 128 tiles each at DPOT-M - alone
 // each needs split-K 2, i.e. 2 x 16 MB of partial sums and a reduce launch, to fill 256 CUs; together they fill them)
@@ -883,6 +1113,9 @@ extern "C" int dpot_gemm_bf16p(const void* Apacked, const void* Wpacked, const f
   DPOT_REQUIRE(!dact_out || epi_mode == DPOT_EPI_ACT, "gemm_bf16p: dact_out needs the activation epilogue");
   DPOT_REQUIRE(!dact_in || epi_mode == DPOT_EPI_DACT, "gemm_bf16p: dact_in needs the act' epilogue");
   DPOT_REQUIRE(aligned16(dact_out) && aligned16(dact_in), "gemm_bf16p: derivative packs must be 16-byte aligned");
+  DPOT_REQUIRE(!(dact_out || dact_in) || (!pre && !res && N % 32 == 0),
+               "gemm_bf16p: the act' pack (fragment order) cannot be combined with a pre-activation save or a residual");
+  DPOT_REQUIRE(epi_mode != DPOT_EPI_DACT || dact_in || aux, "gemm_bf16p: the act' epilogue needs dact_in or aux");
   DPOT_REQUIRE(Apacked && Wpacked && (C || packs), "gemm_bf16p: null operand");
   DPOT_REQUIRE(!packs || (planes == 1 && splitk <= 1 && M % 32 == 0 && aligned16(out_rows) && aligned16(out_trans)),
                "gemm_bf16p: packed outputs need planes == 1, no split-K and M %% 32 == 0");
@@ -924,9 +1157,16 @@ extern "C" int dpot_gemm_bf16p(const void* Apacked, const void* Wpacked, const f
   unsigned grid = (unsigned)(p.tilesM * p.tilesN);
   bf16p_pick_super(p.tilesM, p.tilesN, p.splits, &p.super_r, &p.super_c);
   if (p.super_r > 0) grid = 256u * (unsigned)((p.tilesM * p.tilesN / 32 + 7) / 8);
+  // duo form (two workgroups per CU): 1 (default) = launches with packed outputs and >= 2 tiles per CU, 2 = every
+  // unsplit launch with >= 512 tiles, 0 = never
+  static const int duo = [] { const char* ev = getenv("DPOT_BF16P_DUO"); return ev ? atoi(ev) : 1; }();
+  const bool use_duo = planes == 1 && p.splits == 1 && p.super_r == 0 && (long long)p.tilesM * p.tilesN >= 512 &&
+                       (duo == 2 || (duo == 1 && packs));
   if (planes == 3)
     hipLaunchKernelGGL(gemm_bf16x6p_kernel, dim3((unsigned)(p.tilesM * p.tilesN), p.splits), dim3(512), 0,
                        as_stream(stream), p);
+  else if (use_duo)
+    hipLaunchKernelGGL(gemm_bf16p_duo_kernel, dim3(grid), dim3(512), 0, as_stream(stream), p);
   else
     hipLaunchKernelGGL(gemm_bf16p_kernel, dim3(grid, p.splits), dim3(64 * (8 + PB_NLOAD)), 0, as_stream(stream), p);
   int rc = check_launch("gemm_bf16p_kernel");

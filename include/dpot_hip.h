@@ -488,9 +488,11 @@ int dpot_gemm_bf16p_pair(const void* A0, const void* W0, float* C0, int ldc0, in
 /* out_rows / out_trans / colsum_part (all optional, planes == 1, splitk <= 1, M % 32 == 0): the epilogue also emits the
  * 1-plane packs of the FINAL output (row form [M, N]; transposed form = rows N, k M) and partial column sums
  * [M/32, N] - the next GEMMs of a chain then need no pack pass over this output; C may be NULL in that case.
- * dact_out (EPI_ACT launches): act'(pre-activation) as bf16 in the row-form pack layout of [M, N] - what the backward
+ * dact_out (EPI_ACT launches): act'(pre-activation) as bf16, M * N elements in the kernel's FRAGMENT order
+ * ([M/32][N/32][2][64 lanes][8]: the accumulator layout of a 32x32 tile, opaque to the caller) - what the backward
  * of Block.mlp (models/dpot.py:157-161) multiplies by; it replaces the fp32 `pre` save at half the bytes.
- * dact_in (EPI_DACT launches): that buffer, used instead of act'(aux).  Same restrictions as the packed outputs. */
+ * dact_in (EPI_DACT launches): that buffer (same M, N), used instead of act'(aux).  Same restrictions as the packed
+ * outputs; not together with `pre` or `res`. */
 /* split-K factor the library recommends for a shape (weight gradients: few output tiles, K = tokens); splitk > 1 needs
  * a workspace of splitk*M*N floats, summed in a fixed order by a second launch (deterministic) */
 int dpot_gemm_bf16p_splitk(int M, int N, int K);

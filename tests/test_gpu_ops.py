@@ -867,6 +867,14 @@ def _unpack_rows(pk, M, N):
     return t.permute(0, 3, 1, 2, 4).reshape(M, N)
 
 
+def _unpack_frag(pk, M, N):
+    """act' pack in FRAGMENT order [M/32][N/32][2 halves][64 lanes][8 bf16] (csrc/gemm_bf16p.hip epi_fragment_direct):
+    lane l = (column l & 31, kh = l >> 5), element j of half s is accumulator register r = 8 s + j, i.e. row
+    (r & 3) + 8 (r >> 2) + 4 kh = (j & 3) + 4 kh + 8 (j >> 2) + 16 s of the 32x32 fragment  ->  [M, N] fp32"""
+    t = pk.view(M // 32, N // 32, 2, 2, 32, 2, 4).float()                 # [mt, nt, s, kh, col, j >> 2, j & 3]
+    return t.permute(0, 2, 5, 3, 6, 1, 4).reshape(M, N)                   # row bits [s][j >> 2][kh][j & 3]
+
+
 def test_gemm_bf16_panel_saved_activation_derivative(ops):
     """round 3: the EPI_ACT launch of the bf16 channel MLP saves act'(pre-activation) as a bf16 pack instead of the fp32
     pre-activation, and the EPI_DACT launch multiplies by that pack: (a) the pack holds bf16(act'(pre)) - checked against
@@ -884,7 +892,7 @@ def test_gemm_bf16_panel_saved_activation_derivative(ops):
     p64 = pre.double().cpu().requires_grad_(True)
     torch.nn.functional.gelu(p64).sum().backward()
     want = p64.grad
-    got = _unpack_rows(D, M, N).double().cpu()
+    got = _unpack_frag(D, M, N).double().cpu()
     assert ((got - want).abs() <= 2.0 ** -8 * want.abs() + 1e-6).all()      # one bf16 ulp (8-bit significand)
     # (b) an act'-product epilogue on the same shapes: out = (dY W^T) * act'(pre)
     dY = rnd(M, K, seed=5)
@@ -892,7 +900,7 @@ def test_gemm_bf16_panel_saved_activation_derivative(ops):
     ref, _ = ops.gemm_bf16p(dYp, pk.bufs[0], M, N, K, act=1, mode=ops.EPI_DACT, aux=pre)
     out, _, _, _, _ = ops.gemm_bf16p_packed(dYp, pk.bufs[0], M, N, K, act=1, mode=ops.EPI_DACT, dact=D)
     lin, _ = ops.gemm_bf16p(dYp, pk.bufs[0], M, N, K)                      # dY W^T without the derivative
-    assert torch.equal(out, lin * _unpack_rows(D, M, N))                   # exactly the product with the stored bf16
+    assert torch.equal(out, lin * _unpack_frag(D, M, N))                   # exactly the product with the stored bf16
     err = ((out.double() - ref.double()).norm() / ref.double().norm()).item()
     assert err <= 3e-3, err
 
