@@ -1,25 +1,57 @@
-"""weight-gradient GEMM micro-benchmark: csrc/gemm_tn.hip vs the generic kernel (DPOT_GEMM_TN=0), graph-timed"""
+"""micro-benchmark: the fused weight-gradient launches of csrc/gemm_tn.hip at the DPOT-Tiny B=32 shapes, by split factor;
+'warm' = the same operands every launch (they stay in the 256 MB Infinity Cache), 'cold' = rotating through operand sets
+that total more than it (what the train step sees)."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from dpot_amd import ops
 
-def timeit(fn, reps=20):
-    for _ in range(3): fn()
+
+def timeit(fns, reps=24):
+    for f in fns: f()
     torch.cuda.synchronize()
     g = torch.cuda.CUDAGraph()
     with torch.cuda.graph(g):
-        for _ in range(reps): fn()
+        for i in range(reps): fns[i % len(fns)]()
     g.replay(); torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record(); g.replay(); e1.record(); e1.synchronize()
-    return e0.elapsed_time(e1) * 1e3 / reps
+    return e0.elapsed_time(e1) * 1e-3 / reps
 
-for (M, N, K, batch, sks) in ((512, 512, 8192, 1, (4, 8, 16, 32)), (256, 256, 4608, 4, (4, 8, 16)), (512, 2048, 8192, 1, (2, 4, 8))):
-    A = torch.randn(K, M * batch, device="cuda"); B = torch.randn(K, N * batch, device="cuda")
-    C = torch.empty(batch, M, N, device="cuda"); cs = torch.empty(batch, M, device="cuda")
-    fl = 2.0 * M * N * K * batch
-    for sk in sks:
-        t = timeit(lambda: ops.gemm(A, B, C, M, N, K, transA=True, lda=M * batch, ldb=N * batch, ldc=N, batch=batch, strideA=M,
-                                    strideB=N, strideC=M * N, splitk=sk, colsum_out=cs, colsum_of=1, strideColsum=M))
-        print(f"M={M} N={N} K={K} batch={batch} splitk={sk}: {t:7.1f} us  {fl/t/1e6:6.1f} TF (incl. reduce)", flush=True)
+
+def afno(Mm, nb, bs, E, nsets):
+    sets = []
+    for _ in range(nsets):
+        sets.append([torch.randn(Mm, 2 * E, device="cuda") for _ in range(4)])
+    N = 2 * bs
+    dw1, dw2 = torch.empty(2, nb, bs, bs, device="cuda"), torch.empty(2, nb, bs, bs, device="cuda")
+    db1, db2 = torch.empty(2, nb, bs, device="cuda"), torch.empty(2, nb, bs, device="cuda")
+    fl = 2.0 * 2 * nb * N * N * Mm
+    auto = ops.afno_wgrad2_splitk(Mm, nb, bs)
+    for sk in (2, 4, 6, 8, 12, 16, 18, 24, 36):
+        nslab = Mm // 32
+        sps = (nslab + sk - 1) // sk
+        if sps * (sk - 1) >= nslab: continue
+        fns = [(lambda s=s, sk=sk: ops.afno_wgrad2(s[0], s[1], s[2], s[3], nb, bs, dw1, db1, dw2, db2, sk)) for s in sets]
+        t = timeit(fns)
+        print(f"  afno_wgrad2 Mm={Mm} nb={nb} bs={bs} sets={nsets} splitk={sk:2d}{'*' if sk == auto else ' '} {t*1e6:7.1f} us  {fl/t/1e12:6.1f} TF", flush=True)
+
+
+def mlp(T, E, mh, nsets):
+    sets = [[torch.randn(T, E, device="cuda"), torch.randn(T, mh, device="cuda"), torch.randn(T, E, device="cuda"),
+             torch.randn(T, mh, device="cuda")] for _ in range(nsets)]
+    dW2, dW1 = torch.empty(E, mh, device="cuda"), torch.empty(mh, E, device="cuda")
+    db2, db1 = torch.empty(E, device="cuda"), torch.empty(mh, device="cuda")
+    fl = 2.0 * 2 * T * E * mh
+    auto = ops.mlp_wgrad2_splitk(T, E, mh)
+    for sk in (2, 4, 8, 16):
+        fns = [(lambda s=s, sk=sk: ops.mlp_wgrad2(s[0], s[1], s[2], s[3], dW2, db2, dW1, db1, sk)) for s in sets]
+        t = timeit(fns)
+        print(f"  mlp_wgrad2 T={T} E={E} mh={mh} sets={nsets} splitk={sk:2d}{'*' if sk == auto else ' '} {t*1e6:7.1f} us  {fl/t/1e12:6.1f} TF", flush=True)
+
+
+print("DPOT-Tiny B=32 (kernel + reduce launch per call)")
+for nsets in (1, 5):
+    afno(4608, 4, 128, 512, nsets)
+for nsets in (1, 5):
+    mlp(8192, 512, 512, nsets)
