@@ -246,15 +246,19 @@ def bf16_mlp_roofline(model, B: int):
                                                     pack_rows=True, pack_trans=True, store=False), reps=20)
     fl = 2.0 * M * mh * E
     by = 2.0 * M * E + 2.0 * mh * E + 3 * 2.0 * M * mh            # packed A + packed W read once, three bf16 packs written
-    return {"kernel": "dpot::gemm_bf16p_kernel (channel-MLP fc1 forward: bf16 operands pre-packed fragment-block-major, "
-                      "v_mfma_f32_32x32x16_bf16, epilogue writes the activated hidden layer as row + transposed bf16 packs "
-                      "and act' as a bf16 pack)",
+    tiles = ((M + 127) // 128) * (mh // 256)
+    duo = tiles >= 512 and os.environ.get("DPOT_BF16P_DUO", "1") != "0"
+    kname = "dpot::gemm_bf16p_duo_kernel (two 8-wave workgroups per CU)" if duo else "dpot::gemm_bf16p_kernel (8 compute + 4 loader waves)"
+    return {"kernel": kname + " - channel-MLP fc1 forward: bf16 operands pre-packed fragment-block-major, "
+                      "v_mfma_f32_32x32x16_bf16, epilogue in the accumulator layout writes the activated hidden layer as row + "
+                      "transposed bf16 packs and act' as a bf16 pack",
             "shape": [M, mh, E], "bound": "mfma", "achieved": round(fl / t / 1e12, 1), "peak": 2500.0, "unit": "TFLOP/s",
             "frac": round(fl / t / 1e12 / 2500.0, 4), "us_per_launch": round(t * 1e6, 2), "flops_per_launch": fl,
             "algorithmic_bytes_per_launch": by, "hbm_frac": round(by / t / 1e9 / HBM_PEAK_GBS, 4), "traffic": None,
             "note": "2.5 PFLOP/s = dense bf16 MFMA peak (MI355X_MICROARCH.md); a register-only MFMA loop sustains 1.4-1.8 "
-                    "PFLOP/s on random operands on this part (profiles/r02_mfma_bf16_peak.txt).  Per tile the kernel pays "
-                    "~20 us of prologue + epilogue + store drain beside an 18 us main loop at K = 1024 (DESIGN.md section 3)"}
+                    "PFLOP/s on random operands on this part (profiles/r02_mfma_bf16_peak.txt).  At DPOT-M the main loop of this "
+                    "launch takes 65-72 us (operand path: ~845 cycles per 24 KiB slab and CU), the epilogue ~50 (201 MB of pack "
+                    "stores 31, GELU + derivative 14): DESIGN.md section 3, profiles/r03_bf16p_duo.txt"}
 
 
 def timeit_graph(fn, reps: int = 30):

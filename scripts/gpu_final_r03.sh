@@ -11,6 +11,7 @@ bash scripts/gpu_census_M.sh L bf16 > /dev/null 2>&1; cp gpurun_out/censusL.txt 
 for c in S M L L20; do timeout 900 python bench.py --config $c --steps 10 --warmup 3 > gpurun_out/r03_final_bench_$c.json 2> gpurun_out/r03_final_bench_$c.err; done
 timeout 900 python bench.py --config L --batch 24 --steps 6 --warmup 2 > gpurun_out/r03_final_bench_L_B24.json 2> gpurun_out/r03_final_bench_L_B24.err
 timeout 300 python scripts/gn_dft_bench.py 2>&1 | grep -v amdgpu > gpurun_out/r03_final_gn_dft_bench.txt
+timeout 600 python scripts/bf16p_train_bench.py M L 2>&1 | grep -v "amdgpu\|RASTER\|round 2" > gpurun_out/r03_final_bf16p_train_bench.txt
 tail -4 gpurun_out/r03_final_tests.log
 for f in r03_final_bench r03_final_bench_S r03_final_bench_M r03_final_bench_L r03_final_bench_L20 r03_final_bench_L_B24; do head -c 230 gpurun_out/$f.json | cut -c1-230; echo; done
 head -12 gpurun_out/r03_final_prof.stats.txt

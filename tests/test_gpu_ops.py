@@ -1133,12 +1133,15 @@ def test_groupnorm_chunked_vs_fp64(ops, monkeypatch, B, T, E, G):
     assert_close(y, y0.double(), "chunked vs slab kernels")
 
 
-def test_gemm_bf16_panel_large_shape(ops):
+@pytest.mark.parametrize("M", [8192, 8160])
+def test_gemm_bf16_panel_large_shape(ops, M):
     """the bf16 panel kernel on a many-tile shape (512 tiles: two rounds of workgroups; with DPOT_BF16P_RASTER=1 also the
-    L2-aware super-block tile order).  bf16 x bf16 products are exact and the accumulation is fp32, so against an fp64
-    product of the bf16-ROUNDED operands the result must agree to fp32 accumulation accuracy - a mis-mapped tile shows as
-    an O(1) error; the packed outputs must be the bf16 rounding of the activated output"""
-    M, N, K = 8192, 2048, 256                      # 64 x 8 tiles = 512
+    L2-aware super-block tile order; launches with packed outputs run the two-workgroups-per-CU kernel from 512 tiles on -
+    M = 8160 leaves its last row of tiles 96 rows tall).  bf16 x bf16 products are exact and the accumulation is fp32, so
+    against an fp64 product of the bf16-ROUNDED operands the result must agree to fp32 accumulation accuracy - a
+    mis-mapped tile shows as an O(1) error; the packed outputs must be the bf16 rounding of the activated output, the
+    act' pack the derivative of the activation at the kernel's own pre-activation"""
+    N, K = 2048, 256                               # 64 x 8 tiles = 512
     A, W, b = rnd(M, K, seed=1), rnd(N, K, seed=2, scale=1.0 / math.sqrt(K)), rnd(N, seed=3, scale=0.3)
     pk = ops.PanelPacks([(W.cuda(), N, K, K, False)], bf16=True)
     pk.refresh()
@@ -1154,6 +1157,19 @@ def test_gemm_bf16_panel_large_shape(ops):
     assert torch.equal(_unpack_rows(pr, M, N), y.bfloat16().float())
     assert torch.equal(_unpack_rows(pt, N, M), y.t().contiguous().bfloat16().float())
     assert_close(cs, y.double().sum(0), "column sums", rtol=1e-5, atol_scale=1e-5)
+    p64 = pre.double().cpu().requires_grad_(True)
+    torch.nn.functional.gelu(p64).sum().backward()
+    assert ((_unpack_frag(D, M, N).double().cpu() - p64.grad).abs() <= 2.0 ** -8 * p64.grad.abs() + 1e-6).all()
+    # the act'-product launch (fc2 data gradient form) on the same many-tile grid, without an fp32 output
+    dY = rnd(M, K, seed=5)
+    dYp = ops.bf16_pack_rows(dY.cuda())
+    lin, _ = ops.gemm_bf16p(dYp, pk.bufs[0], M, N, K)
+    want = lin * _unpack_frag(D, M, N)
+    _, _, pr2, pt2, cs2 = ops.gemm_bf16p_packed(dYp, pk.bufs[0], M, N, K, act=1, mode=ops.EPI_DACT, dact=D, pack_rows=True,
+                                                pack_trans=True, colsum=True, store=False)
+    assert torch.equal(_unpack_rows(pr2, M, N), want.bfloat16().float())
+    assert torch.equal(_unpack_rows(pt2, N, M), want.t().contiguous().bfloat16().float())
+    assert_close(cs2, want.double().sum(0), "column sums of the act' product", rtol=1e-5, atol_scale=1e-5)
     res = rnd(M, N, seed=7).cuda()
     z, _ = ops.gemm_bf16p(Ap, pk.bufs[0], M, N, K, bias=b.cuda(), res=res)
     assert_close(z, ref + res.double().cpu(), "residual epilogue", rtol=2e-6, atol_scale=2e-6)
