@@ -565,8 +565,8 @@ __global__ __launch_bounds__(64 * (8 + PB_NLOAD)) void gemm_bf16p_kernel(const B
 // profiles/r03_bf16p_train_bench_tile256_rejected.txt) and was removed.)
 
 // ---------------------------------------------------------------------------------------------------------------------
-// "duo" form of the same GEMM for the launches with a FAT epilogue and several rounds of tiles (fc1 forward: GELU + its
-// derivative + three bf16 packs = 201 MB at DPOT-M; fc2 data gradient).  In the 12-wave kernel above a CU holds ONE
+// "duo" form of the same GEMM for the launches with several rounds of tiles, built for the ones with a FAT epilogue (fc1
+// forward: GELU + its derivative + three bf16 packs = 201 MB at DPOT-M; fc2 data gradient).  In the 12-wave kernel above a CU holds ONE
 // workgroup (133 VGPRs x 12 waves), all 256 CUs run the same phase, and the epilogue (13.7 us per round of tiles at fc1
 // forward, 54 of 142 us) runs with the matrix pipes idle.  Here a workgroup is 8 SELF-LOADING waves with one fragment
 // register set (<= 128 VGPRs, 72 KiB of LDS): TWO workgroups share a CU, and the one in its epilogue leaves the matrix
@@ -1157,11 +1157,12 @@ extern "C" int dpot_gemm_bf16p(const void* Apacked, const void* Wpacked, const f
   unsigned grid = (unsigned)(p.tilesM * p.tilesN);
   bf16p_pick_super(p.tilesM, p.tilesN, p.splits, &p.super_r, &p.super_c);
   if (p.super_r > 0) grid = 256u * (unsigned)((p.tilesM * p.tilesN / 32 + 7) / 8);
-  // duo form (two workgroups per CU): 1 (default) = launches with packed outputs and >= 2 tiles per CU, 2 = every
-  // unsplit launch with >= 512 tiles, 0 = never
+  // duo form (two workgroups per CU): every unsplit launch with >= 2 tiles per CU (DPOT_BF16P_DUO=0: never; 3: only the
+  // launches with packed outputs).  Measured inside the DPOT-L step at batch 16, where the fp32-output launches have 768
+  // tiles as well: 106.2 -> 104.0 ms with them on this kernel too (profiles/r03_bf16p_duo.txt)
   static const int duo = [] { const char* ev = getenv("DPOT_BF16P_DUO"); return ev ? atoi(ev) : 1; }();
   const bool use_duo = planes == 1 && p.splits == 1 && p.super_r == 0 && (long long)p.tilesM * p.tilesN >= 512 &&
-                       (duo == 2 || (duo == 1 && packs));
+                       (duo == 1 || duo == 2 || (duo == 3 && packs));
   if (planes == 3)
     hipLaunchKernelGGL(gemm_bf16x6p_kernel, dim3((unsigned)(p.tilesM * p.tilesN), p.splits), dim3(512), 0,
                        as_stream(stream), p);
