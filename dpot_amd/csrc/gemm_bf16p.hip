@@ -49,16 +49,20 @@ template <int N>
 __device__ __forceinline__ void bwait_vm() {
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
-// s_waitcnt vmcnt(n) for a wave-uniform multiple of 3 up to 24 (the immediate must be a constant)
+// s_waitcnt vmcnt(n) for the wave-uniform counts the loaders use (multiples of 3, 5 or 6; the immediate must be a constant)
 __device__ __forceinline__ void bwait_vm_dyn(int n) {
   switch (n) {
     case 0: bwait_vm<0>(); break;
     case 3: bwait_vm<3>(); break;
+    case 5: bwait_vm<5>(); break;
     case 6: bwait_vm<6>(); break;
+    case 10: bwait_vm<10>(); break;
+    case 15: bwait_vm<15>(); break;
     case 9: bwait_vm<9>(); break;
     case 12: bwait_vm<12>(); break;
     case 18: bwait_vm<18>(); break;
-    default: bwait_vm<24>(); break;
+    case 24: bwait_vm<24>(); break;
+    default: bwait_vm<0>(); break;          // (not a count this kernel produces: wait for everything)
   }
 }
 __device__ __forceinline__ void bglds16(const void* g, void* l) {
@@ -321,11 +325,18 @@ constexpr int PB_SLABB = (PB_ROWT + PB_COLT) * 2 * 1024;        // bytes of one 
 #endif
 constexpr int PB_RING = PB_RING_N;
 
-// body of the kernel: problem p, workgroup index bid0 within the problem, split-K index zs
+// body of the kernel: problem p, workgroup index bid0 within the problem, split-K index zs.
+// COLT = 32-column tiles of the workgroup tile: 8 (128 x 256, 2 x 4 compute waves) or 6 (128 x 192, 2 x 3 compute waves + the
+// same 4 loader waves: 20 KiB slabs) - the narrower tile exists for tile COUNTS, not for speed (see the pair launch)
+template <int COLT>
 __device__ __forceinline__ void gemm_bf16p_body(const Bf16pArgs& p, const int bid0, const int zs) {
+  constexpr int NCW = COLT;                                       // compute waves: 2 x (COLT / 2), 64 x 64 each
+  constexpr int NPC = 2 * (PB_ROWT + COLT) / PB_NLOAD;            // 1 KiB DMA pieces per loader wave and slab
+  constexpr int SLABB = (PB_ROWT + COLT) * 2 * 1024;              // bytes of one 32-k slab
+  static_assert(2 * (PB_ROWT + COLT) % PB_NLOAD == 0, "pieces must divide among the loader waves");
   // ring of PB_RING slabs; the epilogue stages through it afterwards (8 waves x 2 x 32 x EPI_LD floats = 72 KiB)
-  static_assert(PB_RING >= 3 && PB_RING * PB_SLABB <= 160 * 1024, "slab ring must fit the 160 KiB LDS");
-  __shared__ __attribute__((aligned(16))) unsigned char lds[PB_RING * PB_SLABB];
+  static_assert(PB_RING >= 3 && PB_RING * SLABB <= 160 * 1024, "slab ring must fit the 160 KiB LDS");
+  __shared__ __attribute__((aligned(16))) unsigned char lds[PB_RING * SLABB];
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -358,7 +369,7 @@ __device__ __forceinline__ void gemm_bf16p_body(const Bf16pArgs& p, const int bi
     tn = tile / p.tilesM;
     tm = tile - tn * p.tilesM;
   }
-  const int rt0 = tm * PB_ROWT, ct0 = tn * PB_COLT;  // first 32-row tile / 32-column tile
+  const int rt0 = tm * PB_ROWT, ct0 = tn * COLT;  // first 32-row tile / 32-column tile
   const int mtiles = (p.M + 31) >> 5;
 
   // s_waitcnt lgkmcnt(0) as the BUILTIN (simm16 0xC07F: vmcnt 63, expcnt 7, lgkmcnt 0), not inline asm: the compiler's
@@ -384,14 +395,14 @@ __device__ __forceinline__ void gemm_bf16p_body(const Bf16pArgs& p, const int bi
   auto lbar = bar;                                    // the per-slab barrier of the main loop
 #endif
 
-  if (wave >= 8) {
+  if (wave >= NCW) {
     // ================================ loader waves: 24 blocks per slab, 6 per wave ================================
-    const int L = wave - 8;
+    const int L = wave - NCW;
     // block b of a slab: b < 8: A (row tile b>>1, k-half b&1); else W (column tile (b-8)>>1, k-half (b-8)&1)
-    const unsigned short* src[PB_NPC];
-    int dst[PB_NPC];
+    const unsigned short* src[NPC];
+    int dst[NPC];
 #pragma unroll
-    for (int n = 0; n < PB_NPC; ++n) {
+    for (int n = 0; n < NPC; ++n) {
       const int b = L + PB_NLOAD * n;
       if (b < 2 * PB_ROWT) {
         int rt = rt0 + (b >> 1);
@@ -405,7 +416,7 @@ __device__ __forceinline__ void gemm_bf16p_body(const Bf16pArgs& p, const int bi
     }
     auto issue = [&](int t, int ring) __attribute__((always_inline)) {
 #pragma unroll
-      for (int n = 0; n < PB_NPC; ++n) bglds16(src[n] + (long long)t * 1024, lds + ring * PB_SLABB + dst[n]);
+      for (int n = 0; n < NPC; ++n) bglds16(src[n] + (long long)t * 1024, lds + ring * SLABB + dst[n]);
     };
     // (Round 3 also tried REGISTER-STAGED loaders - global_load_dwordx4 -> VGPRs -> ds_write_b128, every loader wave a whole
     // slab, three slab periods of latency tolerance - on the reading of the ablation that the LDS-DMA path itself is the
@@ -416,7 +427,7 @@ __device__ __forceinline__ void gemm_bf16p_body(const Bf16pArgs& p, const int bi
 #pragma unroll
     for (int r = 0; r < PB_RING; ++r)
       if (r < nslab) { issue(r, r); ++issued; }
-    bwait_vm_dyn(issued > 2 ? PB_NPC * (issued - 2) : 0);
+    bwait_vm_dyn(issued > 2 ? NPC * (issued - 2) : 0);
     bar();                                              // P
     int ring = 0;
 #pragma unroll 1
@@ -428,14 +439,14 @@ __device__ __forceinline__ void gemm_bf16p_body(const Bf16pArgs& p, const int bi
       // may stay in flight
       int younger = nslab - (g + 3);                    // slabs g+3 .. that have been issued
       younger = younger < 0 ? 0 : (younger > PB_RING - 2 ? PB_RING - 2 : younger);
-      bwait_vm_dyn(PB_NPC * younger);
+      bwait_vm_dyn(NPC * younger);
     }
     bar();                                              // S
     return;
   }
 
   // ================================ compute waves ================================
-  const int wm = wave >> 2, wn = wave & 3;
+  const int wm = wave / (COLT / 2), wn = wave - wm * (COLT / 2);
   f32x16 acc[2][2];
 #pragma unroll
   for (int i = 0; i < 2; ++i)
@@ -446,7 +457,7 @@ __device__ __forceinline__ void gemm_bf16p_body(const Bf16pArgs& p, const int bi
 
   // fragments of one slab: a[i][ks], b[j][ks]  (ks = 16-k half of the 32-k slab)
   auto read_frags = [&](bf16x8_t (&a)[2][2], bf16x8_t (&b)[2][2], int ring) __attribute__((always_inline)) {
-    const unsigned char* base = lds + ring * PB_SLABB + lane * 16;
+    const unsigned char* base = lds + ring * SLABB + lane * 16;
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -555,8 +566,9 @@ __device__ __forceinline__ void gemm_bf16p_body(const Bf16pArgs& p, const int bi
   }
 }
 
-__global__ __launch_bounds__(64 * (8 + PB_NLOAD)) void gemm_bf16p_kernel(const Bf16pArgs p) {
-  gemm_bf16p_body(p, blockIdx.x, blockIdx.y);
+template <int COLT>
+__global__ __launch_bounds__(64 * (COLT + PB_NLOAD)) void gemm_bf16p_kernel(const Bf16pArgs p) {
+  gemm_bf16p_body<COLT>(p, blockIdx.x, blockIdx.y);
 }
 
 // (A 256 x 256-tile variant - 8 self-loading waves of 64 x 128, ring of four 32 KiB slabs, a quarter of the workgroups -
@@ -694,9 +706,10 @@ struct Bf16pPair {
   Bf16pArgs a[2];
   int n0;          // workgroups of problem 0
 };
-__global__ __launch_bounds__(64 * (8 + PB_NLOAD)) void gemm_bf16p_pair_kernel(const Bf16pPair pp) {
+template <int COLT>
+__global__ __launch_bounds__(64 * (COLT + PB_NLOAD)) void gemm_bf16p_pair_kernel(const Bf16pPair pp) {
   const int which = (int)blockIdx.x >= pp.n0 ? 1 : 0;
-  gemm_bf16p_body(pp.a[which], (int)blockIdx.x - which * pp.n0, blockIdx.y);   // blockIdx.y: common split-K index
+  gemm_bf16p_body<COLT>(pp.a[which], (int)blockIdx.x - which * pp.n0, blockIdx.y);   // blockIdx.y: common split-K index
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -1154,22 +1167,34 @@ extern "C" int dpot_gemm_bf16p(const void* Apacked, const void* Wpacked, const f
   p.cs_part = colsum_part;
   p.dact_out = reinterpret_cast<uint4*>(dact_out);
   p.dact_in = reinterpret_cast<const unsigned short*>(dact_in);
-  unsigned grid = (unsigned)(p.tilesM * p.tilesN);
   bf16p_pick_super(p.tilesM, p.tilesN, p.splits, &p.super_r, &p.super_c);
+  // 128 x 192 tiles where they fill the rounds of 256 CUs better (as for the pair launch below; a 192-wide tile costs ~0.83
+  // of a 256-wide one): DPOT-L at batch 4 has 32 x 6 = 192 tiles of 128 x 256 in fc2 forward / fc1 data gradient - a
+  // quarter of the chip idle - and 32 x 8 = 256 of 128 x 192
+  static const int allow192 = [] { const char* ev = getenv("DPOT_BF16P_TILE192"); return ev ? atoi(ev) : 1; }();
+  int colt = PB_COLT;
+  if (allow192 && planes == 1 && N % 192 == 0 && p.super_r == 0) {
+    const long long t8 = (long long)p.tilesM * p.tilesN * p.splits, t6 = (long long)p.tilesM * (N / 192) * p.splits;
+    if (t8 < 512 && 0.83 * (double)((t6 + 255) / 256) < 0.97 * (double)((t8 + 255) / 256)) colt = 6;
+  }
+  if (colt == 6) p.tilesN = N / 192;
+  unsigned grid = (unsigned)(p.tilesM * p.tilesN);
   if (p.super_r > 0) grid = 256u * (unsigned)((p.tilesM * p.tilesN / 32 + 7) / 8);
   // duo form (two workgroups per CU): every unsplit launch with >= 2 tiles per CU (DPOT_BF16P_DUO=0: never; 3: only the
   // launches with packed outputs).  Measured inside the DPOT-L step at batch 16, where the fp32-output launches have 768
   // tiles as well: 106.2 -> 104.0 ms with them on this kernel too (profiles/r03_bf16p_duo.txt)
   static const int duo = [] { const char* ev = getenv("DPOT_BF16P_DUO"); return ev ? atoi(ev) : 1; }();
-  const bool use_duo = planes == 1 && p.splits == 1 && p.super_r == 0 && (long long)p.tilesM * p.tilesN >= 512 &&
+  const bool use_duo = planes == 1 && colt == PB_COLT && p.splits == 1 && p.super_r == 0 && (long long)p.tilesM * p.tilesN >= 512 &&
                        (duo == 1 || duo == 2 || (duo == 3 && packs));
   if (planes == 3)
     hipLaunchKernelGGL(gemm_bf16x6p_kernel, dim3((unsigned)(p.tilesM * p.tilesN), p.splits), dim3(512), 0,
                        as_stream(stream), p);
   else if (use_duo)
     hipLaunchKernelGGL(gemm_bf16p_duo_kernel, dim3(grid), dim3(512), 0, as_stream(stream), p);
+  else if (colt == 6)
+    hipLaunchKernelGGL(gemm_bf16p_kernel<6>, dim3(grid, p.splits), dim3(64 * (6 + PB_NLOAD)), 0, as_stream(stream), p);
   else
-    hipLaunchKernelGGL(gemm_bf16p_kernel, dim3(grid, p.splits), dim3(64 * (8 + PB_NLOAD)), 0, as_stream(stream), p);
+    hipLaunchKernelGGL(gemm_bf16p_kernel<PB_COLT>, dim3(grid, p.splits), dim3(64 * (8 + PB_NLOAD)), 0, as_stream(stream), p);
   int rc = check_launch("gemm_bf16p_kernel");
   if (rc != DPOT_OK || p.splits == 1) return rc;
   const long long total = (long long)M * N;
@@ -1250,9 +1275,28 @@ extern "C" int dpot_gemm_bf16p_pair(const void* A0, const void* W0, float* C0, i
     p.out_rows = nullptr; p.out_trans = nullptr; p.cs_part = nullptr;
     p.dact_out = nullptr; p.dact_in = nullptr; p.super_r = 0; p.super_c = 0;
   }
+  // 128 x 192 tiles when they need fewer workgroup-rounds' worth of time: DPOT-L's weight gradients are 1536 x 6144 and
+  // 6144 x 1536 - 288 + 288 tiles of 128 x 256 = 2.25 rounds of 256 CUs, i.e. THREE rounds; 384 + 384 tiles of 128 x 192 are
+  // exactly three rounds of tiles three quarters the size (a 192-wide tile costs ~0.83 of a 256-wide one: 20 instead of
+  // 24 KiB of operands per slab, and the loop is bound by those)
+  static const int allow192 = [] { const char* ev = getenv("DPOT_BF16P_TILE192"); return ev ? atoi(ev) : 1; }();
+  int colt = PB_COLT;
+  if (allow192 && splits == 1 && N0 % 192 == 0 && N1 % 192 == 0) {
+    const long long t8 = (long long)pp.a[0].tilesM * pp.a[0].tilesN + (long long)pp.a[1].tilesM * pp.a[1].tilesN;
+    const long long t6 = (long long)pp.a[0].tilesM * (N0 / 192) + (long long)pp.a[1].tilesM * (N1 / 192);
+    const double c8 = (double)((t8 + 255) / 256), c6 = 0.83 * (double)((t6 + 255) / 256);
+    if (c6 < 0.97 * c8) colt = 6;
+  }
+  if (colt == 6) {
+    pp.a[0].tilesN = N0 / 192;
+    pp.a[1].tilesN = N1 / 192;
+  }
   pp.n0 = pp.a[0].tilesM * pp.a[0].tilesN;
   const unsigned grid = (unsigned)(pp.n0 + pp.a[1].tilesM * pp.a[1].tilesN);
-  hipLaunchKernelGGL(gemm_bf16p_pair_kernel, dim3(grid, splits), dim3(64 * (8 + PB_NLOAD)), 0, as_stream(stream), pp);
+  if (colt == 6)
+    hipLaunchKernelGGL(gemm_bf16p_pair_kernel<6>, dim3(grid, splits), dim3(64 * (6 + PB_NLOAD)), 0, as_stream(stream), pp);
+  else
+    hipLaunchKernelGGL(gemm_bf16p_pair_kernel<PB_COLT>, dim3(grid, splits), dim3(64 * (8 + PB_NLOAD)), 0, as_stream(stream), pp);
   int rc = check_launch("gemm_bf16p_pair_kernel");
   if (rc != DPOT_OK || splits == 1) return rc;
   for (int i = 0; i < 2; ++i) {

@@ -1103,6 +1103,20 @@ def test_bf16_panel_pair_launch_matches_single(ops):
     Z0, Z1 = ops.gemm_bf16p_pair(packs[0], packs[1], n0, k0, packs[2], packs[3], n1, k1, T, splitk=2)
     assert_close(Z0, r(dy0).t() @ r(x0), "split pair product 0")
     assert_close(Z1, r(dy1).t() @ r(x1), "split pair product 1")
+    # DPOT-L's weight-gradient shapes (1536 x 6144 and 6144 x 1536): 576 tiles of 128 x 256 = three rounds of 256 CUs, so
+    # the pair launch runs them as 768 tiles of 128 x 192 (2 x 3 compute waves) - same products, same k order: bit-equal to
+    # the single launches on 256-wide tiles
+    T, n0, k0, n1, k1 = 512, 1536, 6144, 6144, 1536
+    dy0 = torch.randn(T, n0, device="cuda"); x0 = torch.randn(T, k0, device="cuda")
+    dy1 = torch.randn(T, n1, device="cuda"); x1 = torch.randn(T, k1, device="cuda")
+    packs = [ops.bf16_pack_rows(t, trans=True) for t in (dy0, x0, dy1, x1)]
+    assert ops.gemm_bf16p_pair_wanted(n0, k0, n1, k1, T)
+    C0, C1 = ops.gemm_bf16p_pair(packs[0], packs[1], n0, k0, packs[2], packs[3], n1, k1, T, splitk=1)
+    assert_close(C0, r(dy0).t() @ r(x0), "192-tile pair product 0")
+    assert_close(C1, r(dy1).t() @ r(x1), "192-tile pair product 1")
+    S0, _ = ops.gemm_bf16p(packs[0], packs[1], n0, k0, T, splitk=1)
+    S1, _ = ops.gemm_bf16p(packs[2], packs[3], n1, k1, T, splitk=1)
+    assert torch.equal(C0, S0) and torch.equal(C1, S1)
 
 
 @pytest.mark.gpu
@@ -1173,6 +1187,37 @@ def test_gemm_bf16_panel_large_shape(ops, M):
     res = rnd(M, N, seed=7).cuda()
     z, _ = ops.gemm_bf16p(Ap, pk.bufs[0], M, N, K, bias=b.cuda(), res=res)
     assert_close(z, ref + res.double().cpu(), "residual epilogue", rtol=2e-6, atol_scale=2e-6)
+
+
+def test_gemm_bf16_panel_192_wide_tiles(ops):
+    """DPOT-L at batch 4: tokens 4096, E = 1536 -> fc2 forward / fc1 data gradient have 32 x 6 = 192 tiles of 128 x 256, so
+    the library runs them as 32 x 8 = 256 tiles of 128 x 192 (2 x 3 compute waves, 20 KiB slabs).  Same checks as the
+    256-wide kernel: fp64 product of the bf16-rounded operands, residual epilogue, packed outputs, act' pack"""
+    M, N, K = 4096, 1536, 512
+    A, W, b = rnd(M, K, seed=1), rnd(N, K, seed=2, scale=1.0 / math.sqrt(K)), rnd(N, seed=3, scale=0.3)
+    pk = ops.PanelPacks([(W.cuda(), N, K, K, False)], bf16=True)
+    pk.refresh()
+    Ap = ops.bf16_pack_rows(A.cuda())
+    ref = A.bfloat16().double() @ W.bfloat16().double().t() + b.double()
+    res = rnd(M, N, seed=7).cuda()
+    z, _ = ops.gemm_bf16p(Ap, pk.bufs[0], M, N, K, bias=b.cuda(), res=res)
+    assert_close(z, ref + res.double().cpu(), "residual epilogue", rtol=2e-6, atol_scale=2e-6)
+    y, pre = ops.gemm_bf16p(Ap, pk.bufs[0], M, N, K, bias=b.cuda(), act=1, mode=ops.EPI_ACT, save_pre=True)
+    assert_close(pre, ref, "pre-activation", rtol=2e-6, atol_scale=2e-6)
+    y2, D, pr, pt, cs = ops.gemm_bf16p_packed(Ap, pk.bufs[0], M, N, K, bias=b.cuda(), act=1, mode=ops.EPI_ACT,
+                                              save_dact=True, pack_rows=True, pack_trans=True, colsum=True)
+    assert torch.equal(y, y2)
+    assert torch.equal(_unpack_rows(pr, M, N), y.bfloat16().float())
+    assert torch.equal(_unpack_rows(pt, N, M), y.t().contiguous().bfloat16().float())
+    assert_close(cs, y.double().sum(0), "column sums", rtol=1e-5, atol_scale=1e-5)
+    p64 = pre.double().cpu().requires_grad_(True)
+    torch.nn.functional.gelu(p64).sum().backward()
+    assert ((_unpack_frag(D, M, N).double().cpu() - p64.grad).abs() <= 2.0 ** -8 * p64.grad.abs() + 1e-6).all()
+    # weight-gradient form with split-K on the same column count (K = tokens)
+    dy, x = rnd(M, 256, seed=8), rnd(M, N, seed=9)
+    dyT, xT = ops.bf16_pack_rows(dy.cuda(), trans=True), ops.bf16_pack_rows(x.cuda(), trans=True)
+    g, _ = ops.gemm_bf16p(dyT, xT, 256, N, M)
+    assert_close(g, dy.bfloat16().double().t() @ x.bfloat16().double(), "weight-gradient form", rtol=4e-6, atol_scale=4e-6)
 
 
 @pytest.mark.parametrize("E,nb,modes", [(512, 4, 32), (1024, 8, 32), (512, 4, 5)])
