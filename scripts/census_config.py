@@ -8,6 +8,7 @@ from scripts.gpu_configs2 import CFGS
 
 key, mlp = sys.argv[1], (sys.argv[2] if len(sys.argv) > 2 else None)
 kw, B, T_ar = CFGS[key]
+B = int(os.environ.get("CENSUS_BATCH", B))          # CENSUS_BATCH=16: DPOT-L at the batch bench.py measures it
 ops.set_mlp_precision(mlp)
 model = DPOTNet(**kw).cuda()
 S = kw["img_size"]
