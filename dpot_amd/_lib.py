@@ -68,6 +68,9 @@ SIGNATURES = {
     "dpot_gemm_auto_splitk": (c_i, [c_i, c_i, c_i, c_i]),
     "dpot_gemm_auto_splitk2": (c_i, [c_i, c_i, c_i, c_i, c_i]),
     "dpot_rfft2": (c_i, [c_fp, c_fp] + [c_i] * 8 + [c_fp]),
+    "dpot_rfft2_norm_supported": (c_i, [c_i, c_i, c_i]),
+    "dpot_rfft2_norm": (c_i, [c_fp] * 5 + [c_i, c_fp] + [c_i] * 8 + [c_fp]),
+    "dpot_irfft2_norm": (c_i, [c_fp] * 6 + [c_i, c_fp] + [c_i] * 8 + [c_fp]),
     "dpot_irfft2": (c_i, [c_fp, c_fp, c_fp] + [c_i] * 8 + [c_fp]),
     "dpot_afno_pack": (c_i, [c_fp] * 4 + [c_i, c_i, c_fp]),
     "dpot_afno_pack_multi": (c_i, [C.POINTER(C.c_void_p)] * 4 + [c_i, c_i, c_i, c_fp]),
@@ -141,6 +144,7 @@ SIGNATURES = {
     "dpot_afno_wgrad2": (c_i, [c_fp] * 4 + [c_i] * 4 + [c_fp] * 5 + [c_i, c_fp]),
     "dpot_bf16_pack_both_supported": (c_i, [c_i, c_i]),
     "dpot_bf16_pack_both": (c_i, [c_fp, c_i, c_i, c_i, c_fp, c_fp, c_fp, c_fp]),
+    "dpot_bf16_pack_both_norm": (c_i, [c_fp, c_i, c_i, c_i, c_fp, c_fp, c_fp, c_fp, c_i, c_i, c_fp, c_fp, c_fp]),
     "dpot_embed_supported": (c_i, [c_i] * 5),
     "dpot_embed_wfrag_elems": (c_i, []),
     "dpot_embed_pack_w0": (c_i, [c_fp, c_i, c_fp, c_fp]),

@@ -274,6 +274,30 @@ extern "C" int dpot_rfft2(const float* x, float* spec, int B, int h, int w, int 
   return check_launch("rfft2_kernel");
 }
 
+// rfft2(GroupNorm(x)) with the statistics given: register-FFT grids only (dpot_rfft2_norm_supported)
+extern "C" int dpot_rfft2_norm_supported(int h, int w, int E) {
+  if (h != w) return 0;
+  if (h == 16 || h == 8) return E % 32 == 0;
+  if (h == 64) return E % 8 == 0;
+  if (h == 32) return E % 16 == 0;
+  return 0;
+}
+
+extern "C" int dpot_rfft2_norm(const float* x, const float* mean, const float* rstd, const float* gamma, const float* beta,
+                               int G, float* spec, int B, int h, int w, int E, int nb, int mx, int my, int col_weights,
+                               dpot_stream_t stream) {
+  int rc = check_dft_args("rfft2_norm", B, h, w, E, nb, mx, my);
+  if (rc) return rc;
+  DPOT_REQUIRE(x && spec && mean && rstd && gamma && beta && G > 0 && E % G == 0, "rfft2_norm: bad argument");
+  DPOT_REQUIRE(dpot_rfft2_norm_supported(h, w, E), "rfft2_norm: latent grid %dx%d has no register-FFT path", h, w);
+  int frc = 0;
+  if (try_rfft2_fast(x, spec, B, h, w, E, nb, mx, my, col_weights, (float)(1.0 / sqrt((double)h * (double)w)),
+                     as_stream(stream), &frc, DftNorm{mean, rstd, gamma, beta, G}))
+    return frc;
+  set_error("rfft2_norm: no register-FFT kernel for this shape");
+  return DPOT_EUNSUP;
+}
+
 extern "C" int dpot_irfft2(const float* spec, const float* res, float* y, int B, int h, int w, int E, int nb, int mx,
                            int my, int col_weights, dpot_stream_t stream) {
   int rc = check_dft_args("irfft2", B, h, w, E, nb, mx, my);
@@ -336,4 +360,20 @@ extern "C" int dpot_afno_unpack_grad(const float* dwbig, const float* dbbig, flo
   hipLaunchKernelGGL(afno_unpack_grad_kernel, dim3((unsigned)cdiv64(n, 256)), dim3(256), 0, as_stream(stream), dwbig,
                      dbbig, dw, db, nb, bs);
   return check_launch("afno_unpack_grad_kernel");
+}
+
+// irfft2(spec) + GroupNorm(res) with the statistics given (the "+ x_orig" of models/dpot.py:106 where x_orig = norm1(x))
+extern "C" int dpot_irfft2_norm(const float* spec, const float* res, const float* mean, const float* rstd,
+                                const float* gamma, const float* beta, int G, float* y, int B, int h, int w, int E, int nb,
+                                int mx, int my, int col_weights, dpot_stream_t stream) {
+  int rc = check_dft_args("irfft2_norm", B, h, w, E, nb, mx, my);
+  if (rc) return rc;
+  DPOT_REQUIRE(spec && res && y && mean && rstd && gamma && beta && G > 0 && E % G == 0, "irfft2_norm: bad argument");
+  DPOT_REQUIRE(dpot_rfft2_norm_supported(h, w, E), "irfft2_norm: latent grid %dx%d has no register-FFT path", h, w);
+  int frc = 0;
+  if (try_irfft2_fast(spec, res, y, B, h, w, E, nb, mx, my, col_weights, (float)(1.0 / sqrt((double)h * (double)w)),
+                      as_stream(stream), &frc, DftNorm{mean, rstd, gamma, beta, G}))
+    return frc;
+  set_error("irfft2_norm: no register-FFT kernel for this shape");
+  return DPOT_EUNSUP;
 }

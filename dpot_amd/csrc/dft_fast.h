@@ -138,9 +138,20 @@ __device__ __forceinline__ int xcd_chunk(int x, int n) {
 }
 
 // x[B,H*W,E] -> spec[B,mx,my,nb,2,bs]
+// optional GroupNorm on the way in (dpot_rfft2_norm): the transform of GN(x) = (x - mean) * rstd * gamma + beta with the
+// statistics of (sample, group = channel / (E / G)) - the normalised tensor is never written (same expression as the
+// GroupNorm apply kernels of norm.hip: the spectrum is bit-identical to the two-launch form)
+struct DftNorm {
+  const float* mean;     // [B, G]; NULL: plain transform
+  const float* rstd;
+  const float* gamma;    // [E]
+  const float* beta;
+  int G;
+};
 template <int H, int W, int CC>
 __global__ __launch_bounds__(256) void rfft2_fast_kernel(const float* __restrict__ x, float* __restrict__ spec, int E,
-                                                         int nb, int mx, int my, int colw, float scale) {
+                                                         int nb, int mx, int my, int colw, float scale,
+                                                         const DftNorm nrm) {
   constexpr int WF = W / 2 + 1;
   extern __shared__ __attribute__((aligned(16))) float sm[];
   float* Z = sm;                                            // [WF][H][2][CC]
@@ -155,6 +166,12 @@ __global__ __launch_bounds__(256) void rfft2_fast_kernel(const float* __restrict
     float v[W];
 #pragma unroll
     for (int y = 0; y < W; ++y) v[y] = xb[(long long)(xr * W + y) * E + c];
+    if (nrm.mean) {
+      const int sg = b * nrm.G + (c0 + c) / (E / nrm.G);
+      const float mu = nrm.mean[sg], ga = nrm.gamma[c0 + c] * nrm.rstd[sg], be = nrm.beta[c0 + c];
+#pragma unroll
+      for (int y = 0; y < W; ++y) v[y] = fmaf(v[y] - mu, ga, be);
+    }
     float vi[W];
 #pragma unroll
     for (int y = 0; y < W; ++y) vi[y] = 0.f;               // real input: the zero half folds away
@@ -196,7 +213,7 @@ __global__ __launch_bounds__(256) void rfft2_fast_kernel(const float* __restrict
 template <int H, int W, int CC>
 __global__ __launch_bounds__(256) void irfft2_fast_kernel(const float* __restrict__ spec, const float* __restrict__ res,
                                                           float* __restrict__ y, int E, int nb, int mx, int my,
-                                                          int colw, float scale) {
+                                                          int colw, float scale, const DftNorm nrm) {
   constexpr int WF = W / 2 + 1;
   extern __shared__ __attribute__((aligned(16))) float sm[];
   float* U = sm;                                            // [H][WF][2][CC]
@@ -251,6 +268,12 @@ __global__ __launch_bounds__(256) void irfft2_fast_kernel(const float* __restric
     if (res) {
 #pragma unroll
       for (int yy = 0; yy < W; ++yy) q[yy] = res[base + (long long)(xr * W + yy) * E + c];
+      if (nrm.mean) {                                      // the residual is GroupNorm(res) (dpot_irfft2_norm)
+        const int sg = b * nrm.G + (c0 + c) / (E / nrm.G);
+        const float mu = nrm.mean[sg], ga = nrm.gamma[c0 + c] * nrm.rstd[sg], be = nrm.beta[c0 + c];
+#pragma unroll
+        for (int yy = 0; yy < W; ++yy) q[yy] = fmaf(q[yy] - mu, ga, be);
+      }
     }
     fft_sfor<0, W>([&](auto YY) __attribute__((always_inline)) {
       constexpr int yy = decltype(YY)::value;
@@ -264,67 +287,69 @@ __global__ __launch_bounds__(256) void irfft2_fast_kernel(const float* __restric
 #ifndef DPOT_DFT_NO_KERNELS   // (csrc/gn_dft.hip uses the register FFTs above only)
 template <int H, int W, int CC>
 static int launch_rfft2_fast(const float* x, float* spec, int B, int E, int nb, int mx, int my, int colw, float scale,
-                             hipStream_t s) {
+                             hipStream_t s, const DftNorm nrm) {
   constexpr size_t lds = sizeof(float) * ((size_t)(W / 2 + 1) * H * 2 * CC);
   hipFuncSetAttribute(reinterpret_cast<const void*>(rfft2_fast_kernel<H, W, CC>),
                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   hipLaunchKernelGGL((rfft2_fast_kernel<H, W, CC>), dim3(E / CC, B), dim3(256), lds, s, x, spec, E, nb, mx, my, colw,
-                     scale);
+                     scale, nrm);
   return check_launch("rfft2_fast_kernel");
 }
 template <int H, int W, int CC>
 static int launch_irfft2_fast(const float* spec, const float* res, float* y, int B, int E, int nb, int mx, int my,
-                              int colw, float scale, hipStream_t s) {
+                              int colw, float scale, hipStream_t s, const DftNorm nrm) {
   constexpr size_t lds = sizeof(float) * ((size_t)(W / 2 + 1) * H * 2 * CC);
   hipFuncSetAttribute(reinterpret_cast<const void*>(irfft2_fast_kernel<H, W, CC>),
                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   hipLaunchKernelGGL((irfft2_fast_kernel<H, W, CC>), dim3(E / CC, B), dim3(256), lds, s, spec, res, y, E, nb, mx, my,
-                     colw, scale);
+                     colw, scale, nrm);
   return check_launch("irfft2_fast_kernel");
 }
 
 // returns 1 if a fast kernel was launched (rc in *rc), 0 if the shape has no fast path
 static inline int try_rfft2_fast(const float* x, float* spec, int B, int h, int w, int E, int nb, int mx, int my,
-                                 int colw, float scale, hipStream_t s, int* rc) {
+                                 int colw, float scale, hipStream_t s, int* rc,
+                                 const DftNorm nrm = DftNorm{nullptr, nullptr, nullptr, nullptr, 0}) {
   static const int forced = [] { const char* e = getenv("DPOT_DFT_CC"); return e ? atoi(e) : 0; }();
   if (h == 16 && w == 16) {
-    if (forced == 16 && E % 16 == 0) { *rc = launch_rfft2_fast<16, 16, 16>(x, spec, B, E, nb, mx, my, colw, scale, s); return 1; }
+    if (forced == 16 && E % 16 == 0) { *rc = launch_rfft2_fast<16, 16, 16>(x, spec, B, E, nb, mx, my, colw, scale, s, nrm); return 1; }
     // 64-channel slabs only when that still gives every CU >= 2 workgroups (latency hiding); else 32-channel slabs
-    if (forced != 32 && E % 64 == 0 && ((long long)B * (E / 64) >= 512 || forced == 64)) { *rc = launch_rfft2_fast<16, 16, 64>(x, spec, B, E, nb, mx, my, colw, scale, s); return 1; }
-    if (E % 32 == 0) { *rc = launch_rfft2_fast<16, 16, 32>(x, spec, B, E, nb, mx, my, colw, scale, s); return 1; }
+    if (forced != 32 && E % 64 == 0 && ((long long)B * (E / 64) >= 512 || forced == 64)) { *rc = launch_rfft2_fast<16, 16, 64>(x, spec, B, E, nb, mx, my, colw, scale, s, nrm); return 1; }
+    if (E % 32 == 0) { *rc = launch_rfft2_fast<16, 16, 32>(x, spec, B, E, nb, mx, my, colw, scale, s, nrm); return 1; }
   } else if (h == 8 && w == 8) {
-    if (E % 64 == 0 && (long long)B * (E / 64) >= 512) { *rc = launch_rfft2_fast<8, 8, 64>(x, spec, B, E, nb, mx, my, colw, scale, s); return 1; }
-    if (E % 32 == 0) { *rc = launch_rfft2_fast<8, 8, 32>(x, spec, B, E, nb, mx, my, colw, scale, s); return 1; }
+    if (E % 64 == 0 && (long long)B * (E / 64) >= 512) { *rc = launch_rfft2_fast<8, 8, 64>(x, spec, B, E, nb, mx, my, colw, scale, s, nrm); return 1; }
+    if (E % 32 == 0) { *rc = launch_rfft2_fast<8, 8, 32>(x, spec, B, E, nb, mx, my, colw, scale, s, nrm); return 1; }
   } else if (h == 64 && w == 64) {
     // 64-point lines in registers (128 values per line item): 8-channel chunks, 132 KiB of LDS for the half-complex plane
-    if (E % 8 == 0) { *rc = launch_rfft2_fast<64, 64, 8>(x, spec, B, E, nb, mx, my, colw, scale, s); return 1; }
+    if (E % 8 == 0) { *rc = launch_rfft2_fast<64, 64, 8>(x, spec, B, E, nb, mx, my, colw, scale, s, nrm); return 1; }
   } else if (h == 32 && w == 32) {
     // 32-channel chunks (full 128-byte lines per token, 139 KiB of LDS: one workgroup per CU) when that still gives
     // >= 128 workgroups: 18.0 against 22.7 us at DPOT-L B = 4 (the inverse is FASTER with 16: 29.8 against 42.5 us)
     // 12-channel chunks: 512 balanced workgroups at DPOT-L B = 4 (see the inverse below) - 15.7 us (32: 18.1, 16: 22.7)
-    if (forced != 16 && forced != 32 && E % 12 == 0 && (E / nb) % 12 == 0 && (long long)B * (E / 12) >= 256) { *rc = launch_rfft2_fast<32, 32, 12>(x, spec, B, E, nb, mx, my, colw, scale, s); return 1; }
-    if (forced != 16 && E % 32 == 0 && (long long)B * (E / 32) >= 128) { *rc = launch_rfft2_fast<32, 32, 32>(x, spec, B, E, nb, mx, my, colw, scale, s); return 1; }
-    if (E % 16 == 0) { *rc = launch_rfft2_fast<32, 32, 16>(x, spec, B, E, nb, mx, my, colw, scale, s); return 1; }
+    if (forced != 16 && forced != 32 && E % 12 == 0 && (E / nb) % 12 == 0 && (long long)B * (E / 12) >= 256) { *rc = launch_rfft2_fast<32, 32, 12>(x, spec, B, E, nb, mx, my, colw, scale, s, nrm); return 1; }
+    if (forced != 16 && E % 32 == 0 && (long long)B * (E / 32) >= 128) { *rc = launch_rfft2_fast<32, 32, 32>(x, spec, B, E, nb, mx, my, colw, scale, s, nrm); return 1; }
+    if (E % 16 == 0) { *rc = launch_rfft2_fast<32, 32, 16>(x, spec, B, E, nb, mx, my, colw, scale, s, nrm); return 1; }
   }
   return 0;
 }
 static inline int try_irfft2_fast(const float* spec, const float* res, float* y, int B, int h, int w, int E, int nb,
-                                  int mx, int my, int colw, float scale, hipStream_t s, int* rc) {
+                                  int mx, int my, int colw, float scale, hipStream_t s, int* rc,
+                                  const DftNorm nrm = DftNorm{nullptr, nullptr, nullptr, nullptr, 0}) {
   static const int forced = [] { const char* e = getenv("DPOT_DFT_CC"); return e ? atoi(e) : 0; }();
   if (h == 16 && w == 16) {
-    if (forced == 16 && E % 16 == 0) { *rc = launch_irfft2_fast<16, 16, 16>(spec, res, y, B, E, nb, mx, my, colw, scale, s); return 1; }
-    if (forced != 32 && E % 64 == 0 && ((long long)B * (E / 64) >= 512 || forced == 64)) { *rc = launch_irfft2_fast<16, 16, 64>(spec, res, y, B, E, nb, mx, my, colw, scale, s); return 1; }
-    if (E % 32 == 0) { *rc = launch_irfft2_fast<16, 16, 32>(spec, res, y, B, E, nb, mx, my, colw, scale, s); return 1; }
+    if (forced == 16 && E % 16 == 0) { *rc = launch_irfft2_fast<16, 16, 16>(spec, res, y, B, E, nb, mx, my, colw, scale, s, nrm); return 1; }
+    if (forced != 32 && E % 64 == 0 && ((long long)B * (E / 64) >= 512 || forced == 64)) { *rc = launch_irfft2_fast<16, 16, 64>(spec, res, y, B, E, nb, mx, my, colw, scale, s, nrm); return 1; }
+    if (E % 32 == 0) { *rc = launch_irfft2_fast<16, 16, 32>(spec, res, y, B, E, nb, mx, my, colw, scale, s, nrm); return 1; }
   } else if (h == 8 && w == 8) {
-    if (E % 64 == 0 && (long long)B * (E / 64) >= 512) { *rc = launch_irfft2_fast<8, 8, 64>(spec, res, y, B, E, nb, mx, my, colw, scale, s); return 1; }
-    if (E % 32 == 0) { *rc = launch_irfft2_fast<8, 8, 32>(spec, res, y, B, E, nb, mx, my, colw, scale, s); return 1; }
+    if (E % 64 == 0 && (long long)B * (E / 64) >= 512) { *rc = launch_irfft2_fast<8, 8, 64>(spec, res, y, B, E, nb, mx, my, colw, scale, s, nrm); return 1; }
+    if (E % 32 == 0) { *rc = launch_irfft2_fast<8, 8, 32>(spec, res, y, B, E, nb, mx, my, colw, scale, s, nrm); return 1; }
   } else if (h == 64 && w == 64) {
-    if (E % 8 == 0) { *rc = launch_irfft2_fast<64, 64, 8>(spec, res, y, B, E, nb, mx, my, colw, scale, s); return 1; }
+    if (E % 8 == 0) { *rc = launch_irfft2_fast<64, 64, 8>(spec, res, y, B, E, nb, mx, my, colw, scale, s, nrm); return 1; }
   } else if (h == 32 && w == 32) {
     // 12-channel chunks when the blocks allow it: 512 workgroups = 2 per CU at DPOT-L B = 4 (E = 1536) instead of the
     // 384 of 16-channel chunks (1.5 per CU: half the CUs run two in a row) - 20.4 against 29.8 us
-    if (forced != 16 && E % 12 == 0 && (E / nb) % 12 == 0 && (long long)B * (E / 12) >= 256) { *rc = launch_irfft2_fast<32, 32, 12>(spec, res, y, B, E, nb, mx, my, colw, scale, s); return 1; }
-    if (E % 16 == 0) { *rc = launch_irfft2_fast<32, 32, 16>(spec, res, y, B, E, nb, mx, my, colw, scale, s); return 1; }
+    if (forced != 16 && E % 12 == 0 && (E / nb) % 12 == 0 && (long long)B * (E / 12) >= 256) { *rc = launch_irfft2_fast<32, 32, 12>(spec, res, y, B, E, nb, mx, my, colw, scale, s, nrm); return 1; }
+    if (E % 16 == 0) { *rc = launch_irfft2_fast<32, 32, 16>(spec, res, y, B, E, nb, mx, my, colw, scale, s, nrm); return 1; }
   }
   return 0;
 }

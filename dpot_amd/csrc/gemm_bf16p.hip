@@ -936,18 +936,40 @@ __global__ __launch_bounds__(256) void bf16_pack_rows_kernel(const float* __rest
 // instruction scattered its 64 chunks over 64 different blocks, 20 us for 67 MB at DPOT-M = 3.3 TB/s.)
 // R % 64 == 0, K % 256 == 0.
 constexpr int PKB_PITCH = 260;
+// optional GroupNorm on the way in (dpot_bf16_pack_both_norm): the packs hold GN(src) = (src - mean) * rstd * gamma + beta with
+// the statistics of (sample = row / rows_per_sample, group = column / (K / G)) - the channel MLP's input GroupNorm2(y1) is then
+// never written in fp32 (the expression is the one of the GroupNorm apply kernels: bit-identical packs)
+struct PackNorm {
+  const float* mean;     // [samples, G]; NULL: plain pack
+  const float* rstd;
+  const float* gamma;    // [K]
+  const float* beta;
+  int rows_per_sample, G;
+};
 __global__ __launch_bounds__(256) void bf16_pack_both_kernel(const float* __restrict__ src, int ld, int R, int K,
                                                              uint4* __restrict__ drow, uint4* __restrict__ dtr,
-                                                             float* __restrict__ cpart) {
+                                                             float* __restrict__ cpart, const PackNorm nrm) {
   __shared__ __attribute__((aligned(16))) float tile[64 * PKB_PITCH];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int c0 = blockIdx.x * 256, r0 = blockIdx.y * 64;
+  float mu = 0.f;
+  float4 ga = make_float4(1.f, 1.f, 1.f, 1.f), be = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (nrm.mean) {      // the 64 rows of a block lie in ONE sample (host-checked), a lane's 4 columns in one group
+    const int sg = (r0 / nrm.rows_per_sample) * nrm.G + (c0 + 4 * lane) / (K / nrm.G);
+    mu = nrm.mean[sg];
+    const float rs = nrm.rstd[sg];
+    ga = *reinterpret_cast<const float4*>(nrm.gamma + c0 + 4 * lane);
+    be = *reinterpret_cast<const float4*>(nrm.beta + c0 + 4 * lane);
+    ga.x *= rs; ga.y *= rs; ga.z *= rs; ga.w *= rs;
+  }
   // phase 1: 64 rows x 1 KiB, a wave per row (16 rows per wave), straight into the LDS tile; column sums on the way
   float4 cs = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
   for (int i = 0; i < 16; ++i) {
     const int row = wave + 4 * i;
-    const float4 v = *reinterpret_cast<const float4*>(src + (long long)(r0 + row) * ld + c0 + 4 * lane);
+    float4 v = *reinterpret_cast<const float4*>(src + (long long)(r0 + row) * ld + c0 + 4 * lane);
+    if (nrm.mean) v = make_float4(fmaf(v.x - mu, ga.x, be.x), fmaf(v.y - mu, ga.y, be.y), fmaf(v.z - mu, ga.z, be.z),
+                                  fmaf(v.w - mu, ga.w, be.w));
     *reinterpret_cast<float4*>(&tile[row * PKB_PITCH + 4 * lane]) = v;
     cs.x += v.x; cs.y += v.y; cs.z += v.z; cs.w += v.w;
   }
@@ -1065,7 +1087,24 @@ extern "C" int dpot_bf16_pack_both(const float* src, int ld, int rows, int K, vo
                "bf16_pack_both: needs rows %% 64 == 0, K %% 256 == 0, 16-byte aligned rows");
   DPOT_REQUIRE(rows / 64 <= 65535, "bf16_pack_both: too many rows");
   hipLaunchKernelGGL(bf16_pack_both_kernel, dim3(K / 256, rows / 64), dim3(256), 0, as_stream(stream), src, ld, rows, K,
-                     reinterpret_cast<uint4*>(dst_rows), reinterpret_cast<uint4*>(dst_trans), colsum_part);
+                     reinterpret_cast<uint4*>(dst_rows), reinterpret_cast<uint4*>(dst_trans), colsum_part,
+                     PackNorm{nullptr, nullptr, nullptr, nullptr, 0, 0});
+  return check_launch("bf16_pack_both_kernel");
+}
+
+extern "C" int dpot_bf16_pack_both_norm(const float* src, int ld, int rows, int K, const float* mean, const float* rstd,
+                                        const float* gamma, const float* beta, int rows_per_sample, int G, void* dst_rows,
+                                        void* dst_trans, dpot_stream_t stream) {
+  DPOT_REQUIRE(src && mean && rstd && gamma && beta && (dst_rows || dst_trans), "bf16_pack_both_norm: null pointer");
+  DPOT_REQUIRE(dpot_bf16_pack_both_supported(rows, K) && ld >= K && ld % 4 == 0 && aligned16(src) && aligned16(gamma) &&
+                   aligned16(beta) && aligned16(dst_rows) && aligned16(dst_trans),
+               "bf16_pack_both_norm: needs rows %% 64 == 0, K %% 256 == 0, 16-byte aligned rows");
+  DPOT_REQUIRE(G > 0 && K % G == 0 && (K / G) % 4 == 0 && rows_per_sample > 0 && rows_per_sample % 64 == 0 &&
+                   rows % rows_per_sample == 0 && rows / 64 <= 65535,
+               "bf16_pack_both_norm: rows_per_sample must be a multiple of 64 dividing rows, K / G a multiple of 4");
+  hipLaunchKernelGGL(bf16_pack_both_kernel, dim3(K / 256, rows / 64), dim3(256), 0, as_stream(stream), src, ld, rows, K,
+                     reinterpret_cast<uint4*>(dst_rows), reinterpret_cast<uint4*>(dst_trans), (float*)nullptr,
+                     PackNorm{mean, rstd, gamma, beta, rows_per_sample, G});
   return check_launch("bf16_pack_both_kernel");
 }
 

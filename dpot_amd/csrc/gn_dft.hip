@@ -266,7 +266,7 @@ __global__ __launch_bounds__(GD_T) void irfft2_gn_kernel(const float* __restrict
     for (int yy = 0; yy < GD_W; ++yy) {
       const int o = (xr * GD_W + yy) * E + co;
       y1s[o] = yv[i][yy];
-      xn2s[o] = fmaf(yv[i][yy] - mu, a2, b2);
+      if (xn2) xn2s[o] = fmaf(yv[i][yy] - mu, a2, b2);       // (NULL: the bf16 channel MLP packs GN2(y1) itself, below)
     }
   }
 }
@@ -494,8 +494,8 @@ extern "C" int dpot_irfft2_gn(const float* spec, const float* x, const float* me
                               int my, int col_weights, float eps, dpot_stream_t stream) {
   int rc = gd_check("irfft2_gn", B, h, w, E, G, nb, mx, my);
   if (rc) return rc;
-  DPOT_REQUIRE(spec && x && mean1 && rstd1 && gamma1 && beta1 && gamma2 && beta2 && y1 && xn2 && mean2 && rstd2,
-               "irfft2_gn: null pointer");
+  DPOT_REQUIRE(spec && x && mean1 && rstd1 && gamma1 && beta1 && gamma2 && beta2 && y1 && mean2 && rstd2,
+               "irfft2_gn: null pointer");                  // xn2 may be NULL: statistics only (dpot_bf16_pack_both_norm)
   const float scale = 1.0f / 16.0f;
   if (E / G == 64) {
     gd_attr(irfft2_gn_kernel<64>, gd_lds<64>());

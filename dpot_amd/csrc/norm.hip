@@ -446,6 +446,7 @@ __global__ __launch_bounds__(GN_THREADS) void gn_chunk_apply_kernel(const float*
     mean[b * G + g] = mu;
     rstd[b * G + g] = rs;
   }
+  if (!y) return;                                          // statistics only (grid (1, G, B))
   const int t0 = ch * c.TC;
   const int nt = T - t0 < c.TC ? T - t0 : c.TC;
   const unsigned nq = (unsigned)nt * (unsigned)q4;
@@ -585,7 +586,7 @@ extern "C" int64_t dpot_groupnorm_ws_elems(int B, int T, int E, int G) {
 extern "C" int dpot_groupnorm_fwd(const float* x, const float* gamma, const float* beta, float* y, float* mean,
                                   float* rstd, float* workspace, int B, int T, int E, int G, float eps,
                                   dpot_stream_t stream) {
-  DPOT_REQUIRE(x && gamma && beta && y && mean && rstd, "groupnorm_fwd: null pointer");
+  DPOT_REQUIRE(x && gamma && beta && mean && rstd, "groupnorm_fwd: null pointer");
   DPOT_REQUIRE(B > 0 && T > 0 && E > 0 && G > 0 && E % G == 0 && B <= 65535, "groupnorm_fwd: bad shape");
   const bool vec = ((E / G) % 4 == 0) && aligned16(x) && aligned16(y) && aligned16(gamma) && aligned16(beta);
   const int items = vec ? gn_cached_items(T, E, G) : 0;
@@ -595,10 +596,13 @@ extern "C" int dpot_groupnorm_fwd(const float* x, const float* gamma, const floa
     hipLaunchKernelGGL(gn_chunk_stats_kernel, grid, dim3(GN_THREADS), 0, as_stream(stream), x, workspace, T, E, G, ck);
     int rc = check_launch("gn_chunk_stats_kernel");
     if (rc) return rc;
-    hipLaunchKernelGGL(gn_chunk_apply_kernel, grid, dim3(GN_THREADS), 0, as_stream(stream), x, gamma, beta, y, mean, rstd,
-                       (const float*)workspace, T, E, G, ck, eps);
+    // y == NULL: statistics only - the consumer applies the affine map itself (rfft2 with `norm` operands, the bf16 pack of
+    // the channel MLP's input): the merge of the chunk partials runs once per (sample, group)
+    hipLaunchKernelGGL(gn_chunk_apply_kernel, y ? grid : dim3(1, G, B), dim3(GN_THREADS), 0, as_stream(stream), x, gamma,
+                       beta, y, mean, rstd, (const float*)workspace, T, E, G, ck, eps);
     return check_launch("gn_chunk_apply_kernel");
   }
+  DPOT_REQUIRE(y, "groupnorm_fwd: statistics-only calls (y == NULL) need the chunked path (dpot_groupnorm_ws_elems > 0)");
   if (items == 4)
     hipLaunchKernelGGL(groupnorm_fwd_cached_kernel<4>, dim3(G, B), dim3(GN_THREADS), 0, as_stream(stream), x, gamma, beta,
                        y, mean, rstd, T, E, G, eps);

@@ -316,13 +316,15 @@ def _mixer_core(S, packed, dims, afno_layout=None):
     return O2, O1pre, O1
 
 
-def _mixer_fwd(xn1, packed, dims, afno_layout=None):
+def _mixer_fwd(xn1, packed, dims, afno_layout=None, norm=None):
     """AFNO2D.forward on a [B, tok, E] field (models/dpot.py:51-110): rfft2 -> block-diagonal complex 2-layer MLP on the
-    kept modes -> irfft2 + x_orig.  Returns (y1, S, O1pre, O1); shared by BlockFn and AFNO2DFn."""
+    kept modes -> irfft2 + x_orig.  Returns (y1, S, O1pre, O1); shared by BlockFn and AFNO2DFn.
+    norm = (mean, rstd, gamma, beta): xn1 is the UN-normalised block input and both DFT kernels apply GroupNorm1 on their
+    loads (the transform's input and the residual) - the normalised field is never written"""
     B, tok, E, h, w, nb, bs, mx, my, mh, act = dims
-    S = ops.rfft2(xn1, h, w, nb, mx, my, 0)                                # [Mm, 2E]
+    S = ops.rfft2(xn1, h, w, nb, mx, my, 0, norm=norm)                     # [Mm, 2E]
     O2, O1pre, O1 = _mixer_core(S, packed, dims, afno_layout)
-    y1 = ops.irfft2(O2, B, h, w, E, nb, mx, my, 1, res=xn1)                # + x_orig (the normalised input)
+    y1 = ops.irfft2(O2, B, h, w, E, nb, mx, my, 1, res=xn1, res_norm=norm)  # + x_orig (the normalised input)
     return y1, S, O1pre, O1
 
 
@@ -420,27 +422,46 @@ def _block_parts(x, n1w, n1b, n2w, n2b, f1w, f1b, packed, dims, mp, need_out, f2
     B, tok, E, h, w, nb, bs, mx, my, mh, act = dims
     Mm, M = B * mx * my, B * tok
     dev = x.device
+    panel = _mlp_panel_mode(mlp_pk, M, E, mh, mp)
+    npl = mlp_pk.planes if panel == 2 else 0
+    both = (panel == 2 and npl == 1 and os.environ.get("DPOT_PACK_BOTH", "1") != "0"
+            and ops.bf16_pack_both_supported(M, E) and ops.bf16_pack_both_supported(M, mh))
+    # GroupNorm applied ON THE LOAD of its consumer (DPOT_GN_ONLOAD=0 disables): norm2 inside the pack pass of the bf16
+    # channel MLP (the fp32 GroupNorm2(y1) is never written); norm1 inside both DFT kernels where they are not fused with
+    # the statistics anyway (32x32 latent grid: statistics-only GroupNorm launches, no normalised tensor)
+    onload = os.environ.get("DPOT_GN_ONLOAD", "1") != "0"
+    pack_norm = both and onload and tok % 64 == 0 and (E // 8) % 4 == 0
     if ops.gn_dft_supported(h, w, E):
         # GroupNorm fused with the neighbouring DFT (csrc/gn_dft.hip): norm1 + rfft2, and irfft2 + x_orig + norm2 -
         # two launches around the mixer instead of four, GroupNorm1(x) never written
         S, mean1, rstd1 = ops.gn_rfft2(x, n1w, n1b, h, w, nb, mx, my)
         O2, O1pre, O1 = _mixer_core(S, packed, dims, afno_layout)
-        y1, xn2, mean2, rstd2 = ops.irfft2_gn(O2, x, mean1, rstd1, n1w, n1b, n2w, n2b, h, w, nb, mx, my)
+        y1, xn2, mean2, rstd2 = ops.irfft2_gn(O2, x, mean1, rstd1, n1w, n1b, n2w, n2b, h, w, nb, mx, my,
+                                              want_xn2=not pack_norm)
         del O2
     else:
-        xn1, mean1, rstd1 = ops.groupnorm_fwd(x, n1w, n1b)
-        y1, S, O1pre, O1 = _mixer_fwd(xn1, packed, dims, afno_layout)
-        del xn1
-        xn2, mean2, rstd2 = ops.groupnorm_fwd(y1, n2w, n2b)
-    panel = _mlp_panel_mode(mlp_pk, M, E, mh, mp)
-    npl = mlp_pk.planes if panel == 2 else 0
-    both = (panel == 2 and npl == 1 and os.environ.get("DPOT_PACK_BOTH", "1") != "0"
-            and ops.bf16_pack_both_supported(M, E) and ops.bf16_pack_both_supported(M, mh))
+        stats = onload and ops.groupnorm_stats_supported(B, tok, E)
+        if stats and ops.rfft2_norm_supported(h, w, E):
+            mean1, rstd1 = ops.groupnorm_stats(x, n1w, n1b)
+            y1, S, O1pre, O1 = _mixer_fwd(x, packed, dims, afno_layout, norm=(mean1, rstd1, n1w, n1b))
+        else:
+            xn1, mean1, rstd1 = ops.groupnorm_fwd(x, n1w, n1b)
+            y1, S, O1pre, O1 = _mixer_fwd(xn1, packed, dims, afno_layout)
+            del xn1
+        pack_norm = pack_norm and stats
+        if pack_norm:
+            xn2 = None
+            mean2, rstd2 = ops.groupnorm_stats(y1, n2w, n2b)
+        else:
+            xn2, mean2, rstd2 = ops.groupnorm_fwd(y1, n2w, n2b)
     if both:
         # plain-bf16 channel MLP, one pack pass per activation: the pass that packs xn2 / Hh as the A operand of the
         # next GEMM also writes the TRANSPOSED pack the weight gradient will need - that (bf16, half the bytes) is what
         # the backward keeps; the fp32 xn2 / Hh are dropped right here
-        xp, xpT, _ = ops.bf16_pack_both(xn2.view(M, E))
+        if pack_norm:
+            xp, xpT, _ = ops.bf16_pack_both(y1.view(M, E), norm=(mean2, rstd2, n2w, n2b, tok))
+        else:
+            xp, xpT, _ = ops.bf16_pack_both(xn2.view(M, E))
         del xn2
         # fc1: the epilogue emits the activated hidden layer directly in its two packed forms (no fp32 copy of it exists)
         # (Hpre here = act'(pre-activation) as a bf16 pack: all the backward needs of it, at half the bytes of the fp32

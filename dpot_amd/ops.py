@@ -234,13 +234,22 @@ def bf16_pack_both_supported(rows: int, K: int) -> bool:
 
 
 def bf16_pack_both(x: Tensor, want_rows: bool = True, want_trans: bool = True, colsum_out: Optional[Tensor] = None,
-                   want_colsum: bool = False):
+                   want_colsum: bool = False, norm=None):
     """one pass over x [M, K] fp32 -> (row-form pack | None, transposed pack | None, column sums | None): the two operand
-    forms the bf16 channel MLP needs of an activation (data GEMM and weight gradient) and its bias gradient"""
+    forms the bf16 channel MLP needs of an activation (data GEMM and weight gradient) and its bias gradient.
+    norm = (mean [B,G], rstd [B,G], gamma [K], beta [K], rows_per_sample): the packs of GroupNorm(x) with those statistics
+    (rows_per_sample % 64 == 0), applied on the load - no column sums in that form"""
     lib = _lib.load()
     M, K = x.shape
     pr = torch.empty(lib.dpot_bf16_packed_elems(M, K, 1), dtype=torch.bfloat16, device=x.device) if want_rows else None
     pt = torch.empty(lib.dpot_bf16_packed_elems(K, M, 1), dtype=torch.bfloat16, device=x.device) if want_trans else None
+    if norm is not None:
+        mean, rstd, gamma, beta, rps = norm
+        assert not want_colsum
+        check(lib.dpot_bf16_pack_both_norm(x.data_ptr(), x.stride(0), M, K, mean.data_ptr(), rstd.data_ptr(),
+                                           gamma.data_ptr(), beta.data_ptr(), rps, mean.shape[1], _p(pr), _p(pt), _stream()),
+              "bf16_pack_both_norm")
+        return pr, pt, None
     part = torch.empty(M // 64, K, dtype=torch.float32, device=x.device) if want_colsum else None
     check(lib.dpot_bf16_pack_both(x.data_ptr(), x.stride(0), M, K, _p(pr), _p(pt), _p(part), _stream()), "bf16_pack_both")
     cs = colsum(part, M // 64, K, out=colsum_out) if want_colsum else None
@@ -377,18 +386,37 @@ def linear_bwd_wb(dy: Tensor, x: Tensor, out_w: Optional[Tensor] = None, out_b: 
 # ------------------------------------------------------------------------------------------------------
 # spectral ops
 # ------------------------------------------------------------------------------------------------------
-def rfft2(x: Tensor, h: int, w: int, nb: int, mx: int, my: int, col_weights: int = 0) -> Tensor:
-    """x[B,h*w,E] -> spec[B*mx*my, 2E] (planar per channel block)."""
+def rfft2_norm_supported(h: int, w: int, E: int) -> bool:
+    return bool(_lib.load().dpot_rfft2_norm_supported(h, w, E))
+
+
+def rfft2(x: Tensor, h: int, w: int, nb: int, mx: int, my: int, col_weights: int = 0, norm=None) -> Tensor:
+    """x[B,h*w,E] -> spec[B*mx*my, 2E] (planar per channel block).
+    norm = (mean [B,G], rstd [B,G], gamma [E], beta [E]): the transform of GroupNorm(x) with those statistics, applied on
+    the load (rfft2_norm_supported grids)"""
     B, E = x.shape[0], x.shape[-1]
     spec = torch.empty(B * mx * my, 2 * E, dtype=torch.float32, device=x.device)
+    if norm is not None:
+        mean, rstd, gamma, beta = norm
+        check(_lib.load().dpot_rfft2_norm(x.data_ptr(), mean.data_ptr(), rstd.data_ptr(), gamma.data_ptr(), beta.data_ptr(),
+                                          mean.shape[1], spec.data_ptr(), B, h, w, E, nb, mx, my, col_weights, _stream()),
+              "rfft2_norm")
+        return spec
     check(_lib.load().dpot_rfft2(x.data_ptr(), spec.data_ptr(), B, h, w, E, nb, mx, my, col_weights, _stream()),
           "rfft2")
     return spec
 
 
 def irfft2(spec: Tensor, B: int, h: int, w: int, E: int, nb: int, mx: int, my: int, col_weights: int = 1,
-           res: Optional[Tensor] = None) -> Tensor:
+           res: Optional[Tensor] = None, res_norm=None) -> Tensor:
+    """res_norm = (mean, rstd, gamma, beta): the residual added is GroupNorm(res) with those statistics"""
     y = torch.empty(B, h * w, E, dtype=torch.float32, device=spec.device)
+    if res_norm is not None:
+        mean, rstd, gamma, beta = res_norm
+        check(_lib.load().dpot_irfft2_norm(spec.data_ptr(), res.data_ptr(), mean.data_ptr(), rstd.data_ptr(),
+                                           gamma.data_ptr(), beta.data_ptr(), mean.shape[1], y.data_ptr(), B, h, w, E, nb,
+                                           mx, my, col_weights, _stream()), "irfft2_norm")
+        return y
     check(_lib.load().dpot_irfft2(spec.data_ptr(), _p(res), y.data_ptr(), B, h, w, E, nb, mx, my, col_weights,
                                   _stream()), "irfft2")
     return y
@@ -584,6 +612,23 @@ def groupnorm_fwd(x: Tensor, gamma: Tensor, beta: Tensor, G: int = 8, eps: float
     return y, mean, rstd
 
 
+def groupnorm_stats_supported(B: int, T: int, E: int, G: int = 8) -> bool:
+    """statistics-only GroupNorm (groupnorm_stats): the chunked kernels (few, large (sample, group) slabs - DPOT-L)"""
+    return _lib.load().dpot_groupnorm_ws_elems(B, T, E, G) > 0
+
+
+def groupnorm_stats(x: Tensor, gamma: Tensor, beta: Tensor, G: int = 8, eps: float = 1e-5):
+    """(mean, rstd) [B, G] of GroupNorm(G, E) over x [B, T, E] without writing the normalised tensor - the consumer applies
+    the affine map on its load (rfft2(norm=...), bf16_pack_both(norm=...)); needs groupnorm_stats_supported"""
+    B, T, E = x.shape
+    mean = torch.empty(B, G, dtype=torch.float32, device=x.device)
+    rstd = torch.empty(B, G, dtype=torch.float32, device=x.device)
+    ws = _gn_workspace(B, T, E, G, x.device)
+    check(_lib.load().dpot_groupnorm_fwd(x.data_ptr(), gamma.data_ptr(), beta.data_ptr(), None, mean.data_ptr(),
+                                         rstd.data_ptr(), _p(ws), B, T, E, G, eps, _stream()), "groupnorm_fwd (statistics)")
+    return mean, rstd
+
+
 def groupnorm_bwd(dy: Tensor, x: Tensor, mean: Tensor, rstd: Tensor, gamma: Tensor, G: int = 8,
                   add: Optional[Tensor] = None, out_dgamma: Optional[Tensor] = None,
                   out_dbeta: Optional[Tensor] = None, defer: bool = False):
@@ -634,14 +679,16 @@ def gn_rfft2(x: Tensor, gamma: Tensor, beta: Tensor, h: int, w: int, nb: int, mx
 
 
 def irfft2_gn(spec: Tensor, x: Tensor, mean1: Tensor, rstd1: Tensor, g1: Tensor, b1: Tensor, g2: Tensor, b2: Tensor,
-              h: int, w: int, nb: int, mx: int, my: int, G: int = 8, eps: float = 1e-5, col_weights: int = 1):
-    """(y1 = irfft2(spec) + GroupNorm1(x), xn2 = GroupNorm2(y1), mean2, rstd2) in one launch"""
+              h: int, w: int, nb: int, mx: int, my: int, G: int = 8, eps: float = 1e-5, col_weights: int = 1,
+              want_xn2: bool = True):
+    """(y1 = irfft2(spec) + GroupNorm1(x), xn2 = GroupNorm2(y1), mean2, rstd2) in one launch; want_xn2=False: statistics
+    only (xn2 = None: the bf16 channel MLP packs GroupNorm2(y1) itself, bf16_pack_both(norm=...))"""
     B, _, E = x.shape
-    y1, xn2 = torch.empty_like(x), torch.empty_like(x)
+    y1, xn2 = torch.empty_like(x), (torch.empty_like(x) if want_xn2 else None)
     mean2 = torch.empty(B, G, dtype=torch.float32, device=x.device)
     rstd2 = torch.empty(B, G, dtype=torch.float32, device=x.device)
     check(_lib.load().dpot_irfft2_gn(spec.data_ptr(), x.data_ptr(), mean1.data_ptr(), rstd1.data_ptr(), g1.data_ptr(),
-                                     b1.data_ptr(), g2.data_ptr(), b2.data_ptr(), y1.data_ptr(), xn2.data_ptr(),
+                                     b1.data_ptr(), g2.data_ptr(), b2.data_ptr(), y1.data_ptr(), _p(xn2),
                                      mean2.data_ptr(), rstd2.data_ptr(), B, h, w, E, G, nb, mx, my, col_weights, eps,
                                      _stream()), "irfft2_gn")
     return y1, xn2, mean2, rstd2

@@ -187,6 +187,17 @@ int dpot_rfft2(const float* x, float* spec, int B, int h, int w, int E, int nb, 
                int col_weights, dpot_stream_t stream);
 int dpot_irfft2(const float* spec, const float* res, float* y, int B, int h, int w, int E, int nb, int mx,
                 int my, int col_weights, dpot_stream_t stream);
+/* rfft2(GroupNorm(x)) with the statistics given (mean / rstd [B, G] from dpot_groupnorm_fwd with y == NULL): norm1 of
+ * Block.forward (models/dpot.py:167-168) folded into the load of the transform, GroupNorm1(x) is never written.  Register-FFT
+ * grids only (8, 16, 32, 64 square): dpot_rfft2_norm_supported. */
+int dpot_rfft2_norm_supported(int h, int w, int E);
+int dpot_rfft2_norm(const float* x, const float* mean, const float* rstd, const float* gamma, const float* beta, int G,
+                    float* spec, int B, int h, int w, int E, int nb, int mx, int my, int col_weights,
+                    dpot_stream_t stream);
+/* irfft2(spec) + GroupNorm(res): the AFNO residual x_orig = norm1(x) (models/dpot.py:55,106) re-derived on the load */
+int dpot_irfft2_norm(const float* spec, const float* res, const float* mean, const float* rstd, const float* gamma,
+                     const float* beta, int G, float* y, int B, int h, int w, int E, int nb, int mx, int my,
+                     int col_weights, dpot_stream_t stream);
 
 /* AFNO weight packing: w[2,nb,bs,bs], b[2,nb,bs] -> Wbig[nb,2bs,2bs] = [[Wr,Wi],[-Wi,Wr]], bbig[nb,2,bs]
  * and the adjoint (gradients back to the reference layout).  models/dpot.py:45-48,72-94 */
@@ -466,6 +477,12 @@ int dpot_bf16_pack_rows(const float* src, int ld, int rows, int K, int trans, in
 int dpot_bf16_pack_both_supported(int rows, int K);
 int dpot_bf16_pack_both(const float* src, int ld, int rows, int K, void* dst_rows, void* dst_trans, float* colsum_part,
                         dpot_stream_t stream);
+/* the same pass over GroupNorm(src): the packs of (src - mean) * rstd * gamma + beta, statistics [rows / rows_per_sample, G]
+ * given (norm2 of Block.forward, models/dpot.py:173, folded into the pack of the channel MLP's input: the normalised tensor
+ * is never written in fp32).  rows_per_sample % 64 == 0, (K / G) % 4 == 0. */
+int dpot_bf16_pack_both_norm(const float* src, int ld, int rows, int K, const float* mean, const float* rstd,
+                             const float* gamma, const float* beta, int rows_per_sample, int G, void* dst_rows,
+                             void* dst_trans, dpot_stream_t stream);
 /* static weights: a DEVICE table of dpot_pack_job entries whose dst is the packed bf16 buffer, all weights in one launch */
 int dpot_bf16_pack_jobs(const dpot_pack_job* jobs_dev, int njobs, int max_elems, int planes, dpot_stream_t stream);
 /* C[M,N] (fp32) = epilogue(A @ Wt^T), A = packed [M, K], Wt = packed [N, K] (same `planes`); epilogue as

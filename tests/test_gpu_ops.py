@@ -1189,6 +1189,42 @@ def test_gemm_bf16_panel_large_shape(ops, M):
     assert_close(z, ref + res.double().cpu(), "residual epilogue", rtol=2e-6, atol_scale=2e-6)
 
 
+@pytest.mark.parametrize("B,h,E,nb", [(2, 32, 384, 4), (4, 32, 1536, 16), (3, 16, 512, 4)])
+def test_groupnorm_applied_on_the_load_of_its_consumer(ops, B, h, E, nb):
+    """GroupNorm folded into the kernels that read its output (round 3): rfft2 / irfft2 with `norm` operands (the transform's
+    input and the AFNO residual are GroupNorm1(x), never written) and the bf16 pack pass of the channel MLP's input
+    (GroupNorm2(y1) never written in fp32) use the expression of the GroupNorm apply kernels - results are BIT-identical
+    to the two-launch forms; statistics-only GroupNorm == the statistics of the full kernel"""
+    tok = h * h
+    mx, my = h, h // 2 + 1
+    x = (rnd(B, tok, E, seed=1) * 1.3 + 0.2).cuda()
+    g, b = (1 + 0.3 * rnd(E, seed=2)).cuda(), (0.2 * rnd(E, seed=3)).cuda()
+    xn, mean, rstd = ops.groupnorm_fwd(x, g, b)
+    if ops.groupnorm_stats_supported(B, tok, E):
+        m2, r2 = ops.groupnorm_stats(x, g, b)
+        assert torch.equal(m2, mean) and torch.equal(r2, rstd)
+    assert ops.rfft2_norm_supported(h, h, E)
+    S_ref = ops.rfft2(xn, h, h, nb, mx, my, 0)
+    S = ops.rfft2(x, h, h, nb, mx, my, 0, norm=(mean, rstd, g, b))
+    assert torch.equal(S, S_ref)
+    y_ref = ops.irfft2(S_ref, B, h, h, E, nb, mx, my, 1, res=xn)
+    y = ops.irfft2(S_ref, B, h, h, E, nb, mx, my, 1, res=x, res_norm=(mean, rstd, g, b))
+    assert torch.equal(y, y_ref)
+    M = B * tok
+    if ops.bf16_pack_both_supported(M, E) and tok % 64 == 0:
+        pr0, pt0, _ = ops.bf16_pack_both(xn.view(M, E))
+        pr1, pt1, _ = ops.bf16_pack_both(x.view(M, E), norm=(mean, rstd, g, b, tok))
+        assert torch.equal(pr0, pr1) and torch.equal(pt0, pt1)
+    if ops.gn_dft_supported(h, h, E):
+        g2, b2 = (1 + 0.3 * rnd(E, seed=4)).cuda(), (0.2 * rnd(E, seed=5)).cuda()
+        y1, xn2, mm, rr = ops.irfft2_gn(S_ref, x, mean, rstd, g, b, g2, b2, h, h, nb, mx, my)
+        y1b, none, mmb, rrb = ops.irfft2_gn(S_ref, x, mean, rstd, g, b, g2, b2, h, h, nb, mx, my, want_xn2=False)
+        assert none is None and torch.equal(y1, y1b) and torch.equal(mm, mmb) and torch.equal(rr, rrb)
+        pr0, pt0, _ = ops.bf16_pack_both(xn2.view(M, E))
+        pr1, pt1, _ = ops.bf16_pack_both(y1.view(M, E), norm=(mm, rr, g2, b2, tok))
+        assert torch.equal(pr0, pr1) and torch.equal(pt0, pt1)
+
+
 def test_gemm_bf16_panel_192_wide_tiles(ops):
     """DPOT-L at batch 4: tokens 4096, E = 1536 -> fc2 forward / fc1 data gradient have 32 x 6 = 192 tiles of 128 x 256, so
     the library runs them as 32 x 8 = 256 tiles of 128 x 192 (2 x 3 compute waves, 20 KiB slabs).  Same checks as the
