@@ -246,6 +246,16 @@ def bf16_mlp_roofline(model, B: int):
                                                     pack_rows=True, pack_trans=True, store=False), reps=20)
     fl = 2.0 * M * mh * E
     by = 2.0 * M * E + 2.0 * mh * E + 3 * 2.0 * M * mh            # packed A + packed W read once, three bf16 packs written
+    traffic, tnote = None, "no PMC profile for this shape (profiles/r03_pmc_bf16p_M.json holds DPOT-M, batch 32)"
+    try:
+        pmc = json.load(open(os.path.join(ROOT, "profiles", "r03_pmc_bf16p_M.json")))["forms"]["fc1_fwd"]
+        if (M, E, mh) == (8192, 1024, 4096):
+            traffic = float(pmc["bytes_guide"])
+            tnote = ("rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes (profiles/r03_pmc_bf16p_M.json): (2*FETCH + "
+                     "WRITE)*1024 B; un-doubled %.0f MB. Reads: every XCD's L2 pulls the whole A pack once (8 x 16.8 MB, from "
+                     "the Infinity Cache) + its weight chunks; writes 234 MB for 201 MB of packs" % (pmc["bytes_raw"] / 1e6))
+    except Exception:
+        pass
     tiles = ((M + 127) // 128) * (mh // 256)
     duo = tiles >= 512 and os.environ.get("DPOT_BF16P_DUO", "1") != "0"
     kname = "dpot::gemm_bf16p_duo_kernel (two 8-wave workgroups per CU)" if duo else "dpot::gemm_bf16p_kernel (8 compute + 4 loader waves)"
@@ -254,7 +264,8 @@ def bf16_mlp_roofline(model, B: int):
                       "transposed bf16 packs and act' as a bf16 pack",
             "shape": [M, mh, E], "bound": "mfma", "achieved": round(fl / t / 1e12, 1), "peak": 2500.0, "unit": "TFLOP/s",
             "frac": round(fl / t / 1e12 / 2500.0, 4), "us_per_launch": round(t * 1e6, 2), "flops_per_launch": fl,
-            "algorithmic_bytes_per_launch": by, "hbm_frac": round(by / t / 1e9 / HBM_PEAK_GBS, 4), "traffic": None,
+            "algorithmic_bytes_per_launch": by, "hbm_frac": round(by / t / 1e9 / HBM_PEAK_GBS, 4), "traffic": traffic,
+            "traffic_note": tnote,
             "note": "2.5 PFLOP/s = dense bf16 MFMA peak (MI355X_MICROARCH.md); a register-only MFMA loop sustains 1.4-1.8 "
                     "PFLOP/s on random operands on this part (profiles/r02_mfma_bf16_peak.txt).  At DPOT-M the main loop of this "
                     "launch takes 65-72 us (operand path: ~845 cycles per 24 KiB slab and CU), the epilogue ~50 (201 MB of pack "
