@@ -599,7 +599,15 @@ __global__ __launch_bounds__(64 * (BS / 16 + 2)) void afno_mlp3_kernel(const Afn
         const int go = (rowc - row0) * p.ldo + col;
         if (first) {
           if (p.mode == 0) {
+#ifndef AFNO_NO_NT_PRE   // saved for the backward only: non-temporal, it would only push live tensors out of L2 / Infinity Cache
+            if (pre_b && ok) {
+              typedef float nt_f4 __attribute__((ext_vector_type(4)));
+              const nt_f4 q = {v[0], v[1], v[2], v[3]};
+              __builtin_nontemporal_store(q, reinterpret_cast<nt_f4*>(pre_b + go));
+            }
+#else
             if (pre_b && ok) *reinterpret_cast<float4*>(pre_b + go) = make_float4(v[0], v[1], v[2], v[3]);
+#endif
 #pragma unroll
             for (int e = 0; e < 4; ++e) v[e] = ACTK == DPOT_ACT_GELU ? gelu_fwd(v[e]) : act_fwd(p.act, v[e]);
           } else {

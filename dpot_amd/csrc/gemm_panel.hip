@@ -220,7 +220,15 @@ __global__ __launch_bounds__(64 * (NW + 2)) void gemm_panel_kernel(const PanelAr
       const int col = colw + 4 * c4;
       const bool ok = row < p.M;
       const long long rowc = ok ? row : p.M - 1;
+#ifndef PANEL_NO_NT_PRE   // saved for the backward only: non-temporal, it would only push live tensors out of L2 / Infinity Cache
+      if (p.pre && ok) {
+        typedef float nt_f4 __attribute__((ext_vector_type(4)));
+        const nt_f4 q = {v[0], v[1], v[2], v[3]};
+        __builtin_nontemporal_store(q, reinterpret_cast<nt_f4*>(p.pre + rowc * p.ldpre + col));
+      }
+#else
       if (p.pre && ok) *reinterpret_cast<float4*>(p.pre + rowc * p.ldpre + col) = make_float4(v[0], v[1], v[2], v[3]);
+#endif
       if (p.mode == DPOT_EPI_ACT) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) v[e] = ACTK == DPOT_ACT_GELU ? gelu_fwd(v[e]) : act_fwd(p.act, v[e]);
