@@ -105,6 +105,49 @@ def _nrel(a, b):
     return ((a - b).norm() / (b.norm() + 1e-300)).item()
 
 
+@pytest.mark.parametrize("img,B,mlp", [(64, 3, None), (256, 2, None), (256, 2, "bf16")])
+def test_tiny_at_other_resolutions_vs_oracle(img, B, mlp):
+    """the DPOT-Tiny architecture on the other latent grids of utils/griddataset.py:35 (64^2 -> 8x8 tokens, 256^2 -> 32x32):
+    every gradient vs the CPU oracle.  8x8: the register FFTs for 8-point lines, 64 tokens per sample; 32x32 at 64 channels per
+    group: chunked statistics-only GroupNorm with norm1 applied on the load of rfft2 / irfft2 - here in the fp32 mode too -
+    and (bf16 channel MLP) norm2 inside the pack pass, at a second shape besides DPOT-L"""
+    from dpot_amd import DPOTNet, ops
+    kw = dict(R.TINY, img_size=img)
+    cfg = R.DPOTConfig(**kw)
+    sd0 = R.recipe_state_dict(cfg, salt=5)
+    x = R.recipe_input((B, img, img, cfg.in_timesteps, cfg.in_channels), salt=81)
+    up_y = R.recipe_input((B, img, img, cfg.out_timesteps, cfg.out_channels), salt=82) * 0.3
+    sd = OrderedDict((k, v.clone().requires_grad_(True)) for k, v in sd0.items())
+    xo = x.clone().requires_grad_(True)
+    yo, co = R.dpot_forward(sd, xo, cfg)
+    (yo * up_y).sum().backward()
+    ops.set_mlp_precision(mlp)
+    try:
+        m = DPOTNet(**kw)
+        m.load_state_dict(sd0)
+        m.cuda()
+        xg = x.cuda().requires_grad_(True)
+        y, c = m(xg)
+        (y * up_y.cuda()).sum().backward()
+    finally:
+        ops.set_mlp_precision(None)
+    if mlp is None:
+        assert_close(y, yo.detach(), f"Tiny@{img} pred")
+        assert_close(xg.grad, xo.grad, f"Tiny@{img} dx")
+        for k, p in m.named_parameters():
+            if k.startswith("cls_head."):
+                continue
+            assert_close(p.grad, sd[k].grad, f"Tiny@{img} d{k}")
+    else:
+        depth = cfg.depth
+        assert _nrel(y, yo) <= BF16_OUT_TOL
+        assert _nrel(xg.grad, xo.grad) <= BF16_DX_PER_SQRT_DEPTH * depth ** 0.5
+        for k, p in m.named_parameters():
+            if k.startswith("cls_head."):
+                continue
+            assert _nrel(p.grad, sd[k].grad) <= BF16_GRAD_PER_SQRT_DEPTH * depth ** 0.5, k
+
+
 @pytest.fixture
 def bf16_mlp():
     from dpot_amd import ops
