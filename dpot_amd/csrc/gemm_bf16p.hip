@@ -1150,7 +1150,11 @@ extern "C" int dpot_gemm_bf16p_splitk(int M, int N, int K) {
 static void bf16p_pick_super(int tilesM, int tilesN, int splits, int* sr, int* sc) {
   static const int enabled = [] { const char* e = getenv("DPOT_BF16P_RASTER"); return e ? atoi(e) : 0; }();
   *sr = 0; *sc = 0;
-  if (!enabled || splits > 1 || (long long)tilesM * tilesN < 512) return;
+  const long long nt = (long long)tilesM * tilesN;
+  // 1: the launches with >= 512 tiles (instead of the two-workgroup kernel); 2: only those with one round of 256..511 tiles
+  // (the K = 4096 launches of DPOT-M: 64 x 4 tiles - every A row panel is otherwise pulled into four XCDs' L2s; measured:
+  // 87.2 against 87.3 us back to back, DPOT-M step 14.64 against 14.68 ms - the L2 fill path is not what bounds them)
+  if (!enabled || splits > 1 || (enabled == 2 ? (nt < 256 || nt >= 512) : nt < 512)) return;
   static const int cand[6][2] = {{8, 4}, {4, 8}, {16, 2}, {2, 16}, {32, 1}, {1, 32}};
   for (int i = 0; i < 6; ++i)
     if (tilesM % cand[i][0] == 0 && tilesN % cand[i][1] == 0) { *sr = cand[i][0]; *sc = cand[i][1]; return; }
