@@ -584,7 +584,8 @@ def test_gemm_panel_static_weight(ops, M, N, K):
         assert_close(dx, dx_ref, "dgrad * gelu'")
 
 
-@pytest.mark.parametrize("M,N,K", [(8192, 1024, 1024), (300, 256, 64), (4096, 512, 2048), (129, 768, 96), (1, 256, 32)])
+@pytest.mark.parametrize("M,N,K", [(8192, 1024, 1024), (300, 256, 64), (4096, 512, 2048), (129, 768, 96), (1, 256, 32),
+                                   (65500, 256, 64), (16400, 1024, 96)])   # >= 512 tiles: the two-workgroup kernel, ragged M
 def test_gemm_bf16_panel(ops, M, N, K):
     """bf16 panel GEMM (csrc/gemm_bf16p.hip): packed bf16 operands, fp32 accumulation.  Checked against an fp64 product of
     the bf16-ROUNDED operands (exactly what the kernel multiplies: error there is fp32 accumulation only) and, loosely,
