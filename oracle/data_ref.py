@@ -2,8 +2,8 @@
 
 Restates utils/griddataset.py:88-101 (`pad_data`: bilinear resize of every (t, c) image with
 F.interpolate(mode='bilinear'), channel pad with ones) and :150-153 (training window) for one raw sample.
-Pinned by tests/golden/g12_data.npz, generated from a literal transcription of the reference lines
-(oracle/make_golden_data.py; the reference module itself cannot be imported here: it needs h5py).
+Pinned by tests/golden/g12_data.npz, written by the reference's own `MixedTemporalDataset.__getitem__` imported from
+/root/reference (oracle/make_golden_data.py: in-memory stand-in for the absent h5py, temporary CWD).
 """
 from __future__ import annotations
 

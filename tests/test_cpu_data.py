@@ -1,5 +1,6 @@
-"""CPU tests of the input pipeline's host logic and of its oracle against the golden vectors (g12: generated from a
-literal transcription of utils/griddataset.py:94-101,152)."""
+"""CPU tests of the input pipeline's host logic and of its oracle against the golden vectors (g12: written by the
+reference's own `MixedTemporalDataset.__getitem__`, utils/griddataset.py:125-175, run in the build container with an
+in-memory stand-in for h5py - oracle/make_golden_data.py)."""
 import numpy as np
 import torch
 
@@ -45,8 +46,8 @@ def test_mixed_index_and_window_rules():
 
 
 def test_data_oracle_test_mode_and_downsample_match_golden():
-    """g12 t0..t3: griddataset.py:143-174 with train=False (test window, get_target_mask, downsample) transcribed in
-    oracle/make_golden_data.py; the oracle's restatement and the product's host helpers (eval_window, target_mask)"""
+    """g12 t0..t3: the reference's `__getitem__` with train=False (test window, get_target_mask, downsample;
+    griddataset.py:143-174) against the oracle's restatement and the product's host helpers (eval_window, target_mask)"""
     from dpot_amd.data import eval_window, target_mask
     fx = load("g12_data")
     k = 0
@@ -64,3 +65,13 @@ def test_data_oracle_test_mode_and_downsample_match_golden():
         assert np.array_equal(target_mask(res, size_orig, nc).numpy(), fx[f"t{k}.msk"])
         k += 1
     assert k == 4
+
+
+def test_mixed_index_matches_reference_dataset_mixing():
+    """g12 mix.*: `idx_cls` of every global index of a two-dataset mix with data_weights (1, 2), as the reference's
+    `__getitem__` returned it (griddataset.py:133-141,174)"""
+    from dpot_amd.data import MixedIndex
+    fx = load("g12_data")
+    mi = MixedIndex([3, 3], [1, 2])
+    assert len(mi) == int(fx["mix.len"][0])
+    assert [mi.locate(i)[0] for i in range(len(mi))] == fx["mix.cls"].tolist()

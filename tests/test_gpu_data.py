@@ -64,7 +64,7 @@ def test_device_batcher_double_buffer_overlaps_and_is_exact():
 def test_test_mode_windows_downsample_and_idx_cls_golden():
     """SURVEY f2 remainder (griddataset.py:159-174): test-mode window (x = first t_in frames, y = the following t_test
     frames, clipped at the trajectory's end), strided down-sampling of the resized fields, idx_cls - the device kernel
-    against the golden vectors written from the transcribed reference lines (g12 t0..t3), and through DeviceBatcher"""
+    against the golden vectors written by the reference dataset class itself (g12 t0..t3), and through DeviceBatcher"""
     from dpot_amd.data import DeviceBatcher, eval_window, resize_pad_window
     fx = load("g12_data")
     for k in range(4):
