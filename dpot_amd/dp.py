@@ -8,7 +8,8 @@ Semantics kept from the reference:
     buffer and a 1/world_size ``grad_scale`` folded into the fused clip+Adam kernel (no extra pass over memory);
   * clip + Adam run redundantly on every rank after the reduction (replicated optimiser, no ZeRO);
   * per-rank batch = configured batch size (Accelerator(split_batches=False)): ``shard_indices`` hands rank r the
-    batches r, r+W, ... of the shuffled batch list.
+    batches r, r+W, ... of the shuffled batch list; the last round wraps around to the start of the epoch
+    (accelerate's even_batches=True with drop_last=False), nothing is dropped.
 
 MI355X-specific choices: xGMI is point-to-point (7 links x ~153 GB/s per GPU), ring collectives are per-link
 bound and latency matters for the 30 MB Tiny gradient, so the buffer is cut into FEW LARGE contiguous buckets
@@ -17,7 +18,7 @@ produced its last gradient, and the compute stream only waits for the side strea
 """
 from __future__ import annotations
 
-from typing import List, Optional, Sequence
+from typing import List, Optional, Sequence, Tuple
 
 import torch
 import torch.distributed as dist
@@ -197,17 +198,44 @@ def gather_eval_metric(value: torch.Tensor, process_group=None) -> torch.Tensor:
     return value.clone()
 
 
+def shard_batches(order: Sequence[int], batch_size: int, rank: int, world: int) -> List[List[int]]:
+    """The batches of rank `rank` for one epoch over the common sample order `order`, with the semantics the reference
+    gets from `accelerator.prepare(train_loader)` (train_temporal_parallel.py:120,185: `DataLoader(batch_size,
+    shuffle=True)`, i.e. drop_last=False, under `Accelerator(split_batches=False)` (:102) whose default is
+    even_batches=True -> accelerate's `BatchSamplerShard`): batch i of the unsharded loader goes to rank i % W, and the
+    LAST round is completed by WRAPPING AROUND to the samples at the start of the epoch - first the ragged final batch
+    is filled up to `batch_size`, then whole batches are appended until every rank has the same number of full
+    batches.  Nothing is dropped; a few early samples are seen twice.  Every rank runs ceil(ceil(n / bs) / W) steps.
+    (tests/test_cpu_host.py compares with accelerate's class itself.)"""
+    n = len(order)
+    if n == 0:
+        return []
+    per_round = batch_size * world
+    n_batches = -(-n // batch_size)
+    rounds = -(-n_batches // world)
+    head = list(order[:per_round])                    # what the wrap-around draws from: the first W batches
+    while len(head) < per_round:                      # fewer than one round of samples: cycle them
+        head += head
+    ext = list(order) + head[:rounds * per_round - n]
+    return [ext[(k * world + rank) * batch_size:(k * world + rank + 1) * batch_size] for k in range(rounds)]
+
+
 def shard_indices(n_samples: int, batch_size: int, rank: int, world: int, epoch: int, seed: int = 0,
                   shuffle: bool = True) -> List[List[int]]:
-    """accelerate's BatchSamplerShard(split_batches=False) contract: all ranks build the same shuffled batch list
-    (common seed) and rank r takes batches r, r+W, ...; the ragged tail is dropped so every rank runs the same
-    number of steps."""
+    """all ranks draw the same shuffled order (common seed + epoch, like accelerate's synchronised
+    SeedableRandomSampler) and take their `shard_batches` of it."""
     g = torch.Generator()
     g.manual_seed(seed + epoch)
     order = torch.randperm(n_samples, generator=g).tolist() if shuffle else list(range(n_samples))
-    batches = [order[i:i + batch_size] for i in range(0, n_samples - batch_size + 1, batch_size)]
-    usable = len(batches) // world * world
-    return [batches[i] for i in range(rank, usable, world)]
+    return shard_batches(order, batch_size, rank, world)
+
+
+def dp_steps_per_epoch(n_samples: int, batch_size: int, world: int) -> Tuple[int, int]:
+    """-> (optimiser steps per epoch on every rank, length of the UNSHARDED loader).  The second number is what the
+    reference sizes OneCycleLR with (train_temporal_parallel.py:150: `epochs * len(train_loader)` before
+    `accelerator.prepare`), the first is how many steps really run (see `dp_lr_step_index`)."""
+    unsharded = -(-n_samples // batch_size)
+    return -(-unsharded // world), unsharded
 
 
 def all_reduce_scalar(value: torch.Tensor, process_group=None) -> torch.Tensor:

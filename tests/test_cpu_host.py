@@ -119,15 +119,37 @@ def test_one_cycle_lr_matches_torch():
 
 
 def test_shard_indices_partition():
-    from dpot_amd.dp import shard_indices
+    from dpot_amd.dp import dp_steps_per_epoch, shard_indices
     W, n, bs = 4, 103, 5
     per_rank = [shard_indices(n, bs, r, W, epoch=3, seed=7) for r in range(W)]
     assert len({len(p) for p in per_rank}) == 1
     flat = [i for p in per_rank for b in p for i in b]
-    assert len(flat) == len(set(flat))
+    assert set(flat) == set(range(n))                         # nothing is dropped ...
+    assert len(flat) == 6 * W * bs                            # ... the last round wraps around (21 batches -> 24)
     assert all(len(b) == bs for p in per_rank for b in p)
+    assert dp_steps_per_epoch(n, bs, W) == (6, 21) and len(per_rank[0]) == 6
     assert per_rank[0] == shard_indices(n, bs, 0, W, epoch=3, seed=7)
     assert per_rank[0] != shard_indices(n, bs, 0, W, epoch=4, seed=7)
+
+
+def test_shard_batches_equal_accelerate_batch_sampler_shard():
+    """the reference's sharding IS accelerate's `BatchSamplerShard(split_batches=False, even_batches=True)` over a
+    `BatchSampler(drop_last=False)` (train_temporal_parallel.py:102,120,185); accelerate is installed in this image, so
+    compare with the class itself on ragged, exact and degenerate sizes"""
+    accelerate = pytest.importorskip("accelerate")
+    from accelerate.data_loader import BatchSamplerShard
+    from torch.utils.data import BatchSampler
+    from dpot_amd.dp import dp_steps_per_epoch, shard_batches
+    rng = np.random.default_rng(5)
+    for n, bs, W in [(103, 5, 4), (100, 5, 4), (101, 5, 4), (97, 8, 8), (64, 8, 8), (65, 8, 8), (7, 4, 4), (3, 2, 8),
+                     (1, 4, 2), (40, 4, 1), (41, 4, 1), (1000, 32, 8), (1023, 32, 8), (29, 3, 2)]:
+        order = rng.permutation(n).tolist()
+        for r in range(W):
+            want = list(BatchSamplerShard(BatchSampler(order, bs, drop_last=False), num_processes=W, process_index=r,
+                                          split_batches=False, even_batches=True))
+            got = shard_batches(order, bs, r, W)
+            assert got == want, (n, bs, W, r)
+            assert len(got) == dp_steps_per_epoch(n, bs, W)[0]
 
 
 def test_flat_params_views():
