@@ -81,6 +81,11 @@ def parse():
                     help="how the GEMMs form their fp32 products for the headline number (f32 = native fp32 MFMA)")
     ap.add_argument("--no-alt", action="store_true", help="skip the extra timing with --gemm-precision auto")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
+    ap.add_argument("--no-other-configs", action="store_true",
+                    help="default run (config T, N=1): do NOT append BASELINE configs[2..4] (S, M, L at batch 16, L20) as "
+                         "`other_configs` (each is one short child run of this script)")
+    ap.add_argument("--brief", action="store_true",
+                    help="only the step timing and the dominant-kernel roofline (what the `other_configs` children run)")
     return ap.parse_args()
 
 
@@ -420,6 +425,42 @@ def cpu_baseline(seconds: float):
                       f"199 ms/step - VERDICT r1), so a 'reference' baseline would read ~1.1x this value"}
 
 
+def other_configs(args):
+    """BASELINE configs[2..4] (DPOT-S / -M / -L at batch 16 / the 20-step DPOT-L rollout), each as ONE short child run of
+    this script (`--config X --brief`): fresh process = fresh kernel-selection state, the same timing code as the headline.
+    Kept short (the default run must finish within minutes): steps / warm-up scaled to the step time."""
+    import subprocess
+    res = []
+    for key, steps, warm in (("S", 20, 5), ("M", 20, 5), ("L", 8, 3), ("L20", 3, 1)):
+        cmd = [sys.executable, os.path.abspath(__file__), "--gpus", "1", "--config", key, "--brief", "--steps", str(steps),
+               "--warmup", str(warm), "--noise-scale", str(args.noise_scale)]
+        t0 = time.perf_counter()
+        try:
+            r = subprocess.run(cmd, capture_output=True, text=True, timeout=240)
+            line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+            if r.returncode != 0 or not line:
+                raise RuntimeError(f"rc {r.returncode}: {r.stderr[-400:]}")
+            d = json.loads(line[-1])
+            rl = d.get("roofline") or {}
+            res.append({"config": key, "baseline_config": d["config"]["baseline_config"], "metric": d["metric"],
+                        "value": d["value"], "unit": d["unit"], "ms_per_step": d["ms_per_step"], "steps": d["steps"],
+                        "warmup": d["warmup"], "dtype": d["dtype"], "per_gpu_batch": d["config"]["per_gpu_batch"],
+                        "workload": d["config"]["workload"], "launch": d["config"]["launch"],
+                        "activation_recomputation": d["config"]["activation_recomputation"],
+                        "peak_mem_GB": d["config"]["peak_mem_GB"], "final_loss": d["config"]["final_loss"],
+                        "model_flops_frac": d.get("model_flops_frac"),
+                        "roofline": {k: rl.get(k) for k in ("kernel", "bound", "achieved", "peak", "unit", "frac", "traffic",
+                                                            "us_per_launch", "flops_per_launch",
+                                                            "algorithmic_bytes_per_launch", "traffic_note")},
+                        "mixer": next(({k: o.get(k) for k in ("kernel", "achieved", "peak", "unit", "frac", "us_per_launch")}
+                                       for o in rl.get("other_kernels", []) if "afno" in str(o.get("kernel"))), None),
+                        "wall_s": round(time.perf_counter() - t0, 1)})
+        except Exception as e:                                  # pragma: no cover - must never take the headline down
+            log(f"[bench] other config {key} failed: {type(e).__name__}: {e}")
+            res.append({"config": key, "error": f"{type(e).__name__}: {e}"[:300]})
+    return res
+
+
 # ------------------------------------------------------------------------------------------------------
 def _self_launch(n: int) -> int:
     """`python bench.py --gpus N` with no launcher around it: re-execute under torch.distributed.run, one rank per GPU,
@@ -556,7 +597,9 @@ def main():
         ms = elapsed / args.steps * 1e3
         value = world * B * T_ar * args.steps / elapsed          # T_ar > 1: sample-steps/s
         out = {
-            "metric": f"PDE samples/sec ({res}^2 x10 -> 1 rollout step), {cname} train step",
+            "metric": (f"PDE samples/sec ({res}^2 x10 -> 1 rollout step), {cname} train step" if T_ar == 1 else
+                       f"PDE sample-steps/sec ({res}^2 x10 -> 1 per step, {T_ar}-step auto-regressive rollout), {cname} "
+                       f"train step"),
             "value": round(value, 2), "unit": "samples/s" if T_ar == 1 else "sample-steps/s", "n_gpus": world,
             "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(ms, 4), "higher_is_better": True, "scaling": "weak",
@@ -581,7 +624,7 @@ def main():
                                    "one graph + all-reduce after backward" if args.no_overlap else
                                    f"segmented hipGraph chain ({len(graphed.graphs)} segments), bucket all-reduce on a "
                                    f"side stream overlapped with the remaining backward; {reducer.n_buckets} buckets")
-        if world == 1 and graphed is not None and args.sustain_seconds > 0:
+        if world == 1 and graphed is not None and args.sustain_seconds > 0 and not args.brief:
             # the K-step figure above covers < 0.1 s of GPU time; a sustained run shows what the clocks settle at
             n_sus = max(args.steps, int(args.sustain_seconds / (elapsed / args.steps)))
             torch.cuda.synchronize()
@@ -591,7 +634,7 @@ def main():
             torch.cuda.synchronize()
             es = time.perf_counter() - ts
             out["sustained"] = {"steps": n_sus, "seconds": round(es, 3), "ms_per_step": round(es / n_sus * 1e3, 4),
-                                "value": round(B * n_sus / es, 2)}
+                                "value": round(B * T_ar * n_sus / es, 2), "unit": out["unit"]}
         # whole-step FLOP rates per GPU: ALGORITHMIC = 3 x the forward FLOPs of the model as the reference computes it
         # (3 x 3.79 GFLOP per sample at DPOT-Tiny); EXECUTED = what this build's kernels actually run after
         # the embed fold (K 5120 -> 360), the grid-channel bias table and the three-product mixer (step_flops_per_sample)
@@ -616,7 +659,8 @@ def main():
         except Exception as e:                                 # pragma: no cover
             log(f"[bench] roofline probe failed: {e}")
             out["roofline"] = None
-        if headline and world == 1 and graphed is not None and args.gemm_precision == "f32" and not args.no_alt:
+        if headline and world == 1 and graphed is not None and args.gemm_precision == "f32" and not args.no_alt \
+                and not args.brief:
             # not the headline: the same step with the large GEMMs on the bf16x6 kernel (fp32 emulated by operand
             # splitting on the bf16 matrix cores, same accuracy class - DESIGN.md "bf16x6"); a fresh graph is captured
             # because the kernel choice is baked in at capture time
@@ -639,7 +683,7 @@ def main():
                 log(f"[bench] gemm_auto timing failed: {e}")
             finally:
                 ops.set_gemm_precision(args.gemm_precision)
-        if world == 1 and T_ar == 1:
+        if world == 1 and T_ar == 1 and not args.brief:
             # forward-only (inference) rate of the same batch, SURVEY 8(d): no_grad forward, hipGraph replay
             try:
                 with torch.no_grad():
@@ -662,7 +706,7 @@ def main():
                                     "what": "DPOTNet forward only (no_grad), batch %d, hipGraph replay" % B}
             except Exception as e:                             # pragma: no cover
                 log(f"[bench] inference timing failed: {e}")
-        if headline and world == 1 and graphed is not None and not args.no_pipeline:
+        if headline and world == 1 and graphed is not None and not args.no_pipeline and not args.brief:
             # input-pipeline-inclusive rate (never `value`): raw 64x64 single-channel trajectories in host memory (the
             # ns2d_fno_1e-5 shape) -> pinned staging -> ONE H2D copy per batch on a copy stream -> device-side bilinear
             # resize to 128^2 + channel pad with ones + temporal window (csrc/data.hip) -> double-buffered batch slots;
@@ -699,9 +743,15 @@ def main():
                             "batching inclusive, single host thread"}
             except Exception as e:                             # pragma: no cover
                 log(f"[bench] pipeline-inclusive timing failed: {type(e).__name__}: {e}")
-        if headline and world == 1 and not args.skip_cpu_baseline:
+        if headline and world == 1 and not args.skip_cpu_baseline and not args.brief:
             out["cpu_baseline"] = cpu_baseline(args.cpu_seconds)
             out["speedup_vs_cpu_baseline"] = round(value / out["cpu_baseline"]["value"], 1)
+        if headline and world == 1 and not args.brief and not args.no_other_configs and args.batch is None:
+            # BASELINE configs[2..4] through this same script, so that the driver's record carries them:
+            # the model of this process is released first - DPOT-L at batch 16 wants the HBM to itself
+            del graphed, model, opt, fp
+            torch.cuda.empty_cache()
+            out["other_configs"] = other_configs(args)
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()

@@ -166,6 +166,7 @@ __global__ __launch_bounds__(GD_T) void gn_rfft2_kernel(const float* __restrict_
   const int c = tid % CG, xr0 = tid / CG;
   const float* __restrict__ xb = x + (long long)b * GD_H * GD_W * E + g * CG;   // uniform base, 32-bit offsets below
   double s_m = 0.0, s_mm = 0.0, s_q = 0.0;
+  const float piv = xb[c];
 #pragma unroll
   for (int i = 0; i < IT; ++i) {
     const int xr = xr0 + i * XS;
@@ -177,6 +178,11 @@ __global__ __launch_bounds__(GD_T) void gn_rfft2_kernel(const float* __restrict_
     s_m += (double)lm;
     s_mm += (double)lm * (double)lm;
     s_q += (double)q;
+    // transform x - p_c (p_c = the channel's first token): the FFT's round-off then scales with the spread of the
+    // channel, not with |mean| - a group whose |mean| >> std would otherwise lose log10(|mean| / std) digits in every bin
+    // against GroupNorm-then-rfft2.  p_c comes back through the DC term below.
+#pragma unroll
+    for (int y = 0; y < GD_W; ++y) v[y] -= piv;
     row_fft_store<CG>(v, Z, xr, c);
   }
   block_sum3_d(s_m, s_mm, s_q, shd);                        // (its barriers also publish Z)
@@ -194,7 +200,9 @@ __global__ __launch_bounds__(GD_T) void gn_rfft2_kernel(const float* __restrict_
     const int c2 = it % CG, ky = it / CG;
     const int ch2 = g * CG + c2;
     const float a = rs * gamma[ch2];
-    const float dc = ky == 0 ? (beta[ch2] - mu * a) * (float)(GD_H * GD_W) * scale : 0.f;
+    // GN(x) = a (x - p) + (beta + a (p - mu)): the constant's spectrum is its DC bin; p - mu is formed in double
+    const float pm = (float)((double)xb[c2] - mu_d);
+    const float dc = ky == 0 ? fmaf(pm, a, beta[ch2]) * (float)(GD_H * GD_W) * scale : 0.f;
     col_fft_out<CG>(Z, spec, b, ch2, c2, ky, nb, bs, mx, my, a * scale, dc);
   }
 }

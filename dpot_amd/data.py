@@ -105,6 +105,14 @@ def resize_pad_window(samples: Sequence[Tensor], starts: Sequence[int], res: int
     xx = out_xx if out_xx is not None else torch.empty(B, rh, rw, t_in, n_channels, dtype=torch.float32, device=dev)
     yy = out_yy if out_yy is not None else (
         torch.empty(B, rh, rw, t_ar, n_channels, dtype=torch.float32, device=dev) if t_ar > 0 else None)
+    for name, buf, t in (("out_xx", out_xx, t_in), ("out_yy", out_yy, t_ar)):
+        # the kernel writes a dense [B, ceil(res/dh), ceil(res/dw), t, C] block: any other caller-supplied buffer would
+        # be garbled or overrun
+        if buf is not None and not (tuple(buf.shape) == (B, rh, rw, t, n_channels) and buf.is_contiguous()
+                                    and buf.dtype == torch.float32 and buf.device == dev):
+            raise _lib.DpotHipError(f"resize_pad_window: {name} must be a contiguous float32 tensor of shape "
+                                    f"{(B, rh, rw, t, n_channels)} on {dev}, got {tuple(buf.shape)} {buf.dtype} "
+                                    f"{buf.device}")
     for s in samples:
         if not (s.is_cuda and s.dtype == torch.float32 and s.is_contiguous() and s.dim() == 4):
             raise _lib.DpotHipError("resize_pad_window: samples must be contiguous float32 CUDA tensors [H,W,T,C]")

@@ -386,6 +386,7 @@ class GraphedTrainStep:
     def replay(self, lr: Optional[float] = None) -> Tensor:
         self.opt.stage_hyper(lr)
         self.graph.replay()
+        self.opt.fp.epoch += 1        # the captured Adam + pack launches rewrote the parameters and their packed copies
         return self.loss
 
 
@@ -508,4 +509,5 @@ class SegmentedTrainStep:
             red._launched[red.tail_bucket] = True
         red.finish()                          # compute stream joins the side stream
         self.opt_graph.replay()
+        self.opt.fp.epoch += 1                # as FusedAdam.launch: an eager backward of an earlier forward must fail
         return self.loss

@@ -85,3 +85,21 @@ def test_test_mode_windows_downsample_and_idx_cls_golden():
         assert cls.dtype == torch.int64 and cls.cpu().tolist() == [[3], [5]]
         assert_close(gx[1], fx[f"t{k}.x"], f"batcher test case {k} x", rtol=1e-6, atol_scale=1e-6)
         assert_close(gy[0], fx[f"t{k}.y"], f"batcher test case {k} y", rtol=1e-6, atol_scale=1e-6)
+
+
+def test_resize_pad_window_rejects_wrongly_shaped_output_buffers():
+    """caller-supplied out_xx / out_yy must have the down-sampled shape the kernel writes"""
+    from dpot_amd import _lib
+    from dpot_amd.data import resize_pad_window
+    raw = [torch.rand(16, 16, 8, 1, device="cuda")]
+    ok_x = torch.empty(1, 16, 16, 4, 4, device="cuda")
+    with pytest.raises(_lib.DpotHipError, match="out_xx"):
+        resize_pad_window(raw, [0], 32, 4, 2, 4, out_xx=torch.empty(1, 32, 32, 4, 4, device="cuda"), downsample=(2, 2))
+    with pytest.raises(_lib.DpotHipError, match="out_yy"):
+        resize_pad_window(raw, [0], 32, 4, 2, 4, out_xx=ok_x, out_yy=torch.empty(1, 16, 16, 1, 4, device="cuda"),
+                          downsample=(2, 2))
+    with pytest.raises(_lib.DpotHipError, match="out_xx"):
+        resize_pad_window(raw, [0], 32, 4, 2, 4, out_xx=torch.empty(1, 16, 16, 4, 8, device="cuda")[..., ::2],
+                          downsample=(2, 2))
+    xx, yy = resize_pad_window(raw, [0], 32, 4, 2, 4, out_xx=ok_x, downsample=(2, 2))
+    assert xx is ok_x and tuple(yy.shape) == (1, 16, 16, 2, 4)

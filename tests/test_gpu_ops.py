@@ -1264,7 +1264,8 @@ def test_groupnorm_dft_fused_kernels_vs_separate(ops, E, nb, modes):
     backward pair (norm2 backward + adjoint rfft2, adjoint irfft2 + skip + norm1 backward + outer skip); 64 and 128
     channels per group, full and truncated mode sets.  fp32 re-association only: rtol 2e-5 of the tensor scale."""
     B, h = 3, 16
-    assert ops.gn_dft_supported(h, h, E)
+    if not ops.gn_dft_supported(h, h, E):
+        pytest.skip("fused GroupNorm-DFT kernels switched off (DPOT_GN_DFT=0): the separate kernels run")
     mx, my = min(modes, h), min(modes, h // 2 + 1)
     x = (rnd(B, h * h, E, seed=1) * 1.7 + 0.4).cuda()
     g1, b1 = (1 + 0.3 * rnd(E, seed=2)).cuda(), (0.2 * rnd(E, seed=3)).cuda()
@@ -1304,3 +1305,30 @@ def test_groupnorm_dft_fused_kernels_vs_separate(ops, E, nb, modes):
     assert_close(part1, part1_ref, "irfft2_gn_bwd partials", **tol)
     dx0, _ = ops.irfft2_gn_bwd(dS, dy1_ref, x, m1, r1, g1, h, h, nb, mx, my, add=None, col_weights=0)
     assert_close(dx0, dx_ref - dout, "irfft2_gn_bwd without the outer skip", **tol)
+
+
+def test_groupnorm_rfft2_fused_with_a_large_group_mean(ops):
+    """gn_rfft2 transforms x itself and applies GroupNorm to the spectrum; with |mean| >> std the FFT's
+    round-off would scale with |mean| (log10(|mean|/std) digits lost in every bin).  The kernel transforms x - x[0]
+    per channel instead.  mean / std = 100 and 1000, against float64 GroupNorm -> rfft2: the fused kernel must be as
+    accurate as the separate GroupNorm-then-rfft2 kernels (whose input to the FFT is already normalised)"""
+    B, h, E, nb = 2, 16, 512, 4
+    if not ops.gn_dft_supported(h, h, E):
+        pytest.skip("fused GroupNorm-DFT kernels switched off")
+    g1, b1 = (1 + 0.3 * rnd(E, seed=2)).cuda(), (0.2 * rnd(E, seed=3)).cuda()
+    for ratio in (1e2, 1e3):
+        x = (rnd(B, h * h, E, seed=1) + ratio).cuda()
+        xd = x.double().view(B, h * h, 8, E // 8)
+        mu = xd.mean(dim=(1, 3), keepdim=True)
+        var = xd.var(dim=(1, 3), unbiased=False, keepdim=True)
+        xn = ((xd - mu) / torch.sqrt(var + 1e-5)).view(B, h, h, E) * g1.double() + b1.double()
+        F = torch.fft.rfft2(xn, dim=(1, 2), norm="ortho")                                     # [B, h, wf, E]
+        ref = torch.stack([F.real, F.imag], dim=-2).view(B, h, 9, 2, nb, E // nb).permute(0, 1, 2, 4, 3, 5)
+        ref = ref.reshape(B * h * 9, 2 * E)
+        xn1, _, _ = ops.groupnorm_fwd(x, g1, b1)
+        e_sep = ((ops.rfft2(xn1, h, h, nb, h, 9, 0).double() - ref).norm() / ref.norm()).item()
+        S, _, _ = ops.gn_rfft2(x, g1, b1, h, h, nb, h, 9)
+        e_fused = ((S.double() - ref).norm() / ref.norm()).item()
+        print(f"[gn_rfft2, mean/std = {ratio:g}] norm-wise error vs float64: fused {e_fused:.2e}, separate kernels {e_sep:.2e}")
+        # the input's own representation error is eps * ratio (a float32 x cannot carry more): both paths sit there
+        assert e_fused <= max(2.0 * e_sep, 3e-7 * ratio)

@@ -1,0 +1,51 @@
+"""The documented opt-out switches (DESIGN.md "Environment knobs") select the FALLBACK kernels of the product path.  They
+are read once per process (static initialisers in csrc/, module-level reads in dpot_amd/), so each switch gets its own
+child pytest process that re-runs a parity subset under it: the golden-vector model tests (test_gpu_model.py), the
+DPOT-Tiny / -Small / -Medium gradient cases against the oracle in fp32 and bf16 channel-MLP mode, and - for the switches
+that only act on DPOT-L's launch shapes - the DPOT-L batch-16 case against the reference's golden numbers.  Keeps the
+fallback kernels under the round-end GPU gate instead of a by-hand run."""
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+SMALL_SET = ("test_full_model_gradients_vs_oracle and (TINY-32 or SMALL-1) or "
+             "test_bf16_channel_mlp_mode_vs_oracle and (MEDIUM-1 or TINY-32) or test_tiny_at_other_resolutions_vs_oracle")
+LARGE_SET = "test_large_batch16_vs_reference_golden"
+
+# switch -> (-k expression over test_gpu_sizes.py, also run test_gpu_model.py?)
+SWITCHES = {
+    "DPOT_BF16P_DUO=0": (LARGE_SET + " or test_bf16_channel_mlp_mode_vs_oracle and MEDIUM-32", False),
+    "DPOT_BF16P_TILE192=0": (LARGE_SET, False),
+    "DPOT_BF16P_PAIR=0": (LARGE_SET + " or test_bf16_channel_mlp_mode_vs_oracle and MEDIUM-1", False),
+    "DPOT_AFNO_3MULT=0": (SMALL_SET, True),
+    "DPOT_AFNO_FUSED=0": (SMALL_SET, True),
+    "DPOT_GN_DFT=0": (SMALL_SET, True),
+    "DPOT_GN_ONLOAD=0": (SMALL_SET, False),
+    "DPOT_PANEL_GEMM=0": (SMALL_SET, True),
+    "DPOT_GEMM_TN=0": (SMALL_SET, True),
+    "DPOT_EMBED_IMPLICIT=0": (SMALL_SET, True),
+}
+
+
+@pytest.mark.parametrize("switch", list(SWITCHES))
+def test_parity_subset_under_opt_out_switch(switch):
+    expr, with_model = SWITCHES[switch]
+    env = dict(os.environ)
+    k, v = switch.split("=")
+    env[k] = v
+    files = ["tests/test_gpu_sizes.py"] + (["tests/test_gpu_model.py"] if with_model else [])
+    if with_model:
+        expr = f"({expr}) or test_gpu_model"
+    cmd = [sys.executable, "-m", "pytest", "-x", "-q", "-m", "gpu", "-p", "no:cacheprovider"] + files + ["-k", expr]
+    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=1500)
+    tail = (r.stdout + r.stderr)[-3000:]
+    assert r.returncode == 0, f"{switch}: parity subset failed\n{tail}"
+    last = [ln for ln in r.stdout.splitlines() if " passed" in ln]
+    assert last and " failed" not in last[-1], tail
+    print(f"[{switch}] {last[-1].strip()}")

@@ -286,6 +286,107 @@ def test_large_20_step_rollout_vs_reference_golden():
     assert res[True][2] < 0.6 * res[False][2], "recomputation should cut the activation memory"
 
 
+def test_large_batch16_vs_reference_golden():
+    """DPOT-L at the per-GPU batch `bench.py --config L` quotes (16: two-workgroup bf16 GEMM for every launch with >= 512
+    tiles, 128 x 192 tiles, pair-grid rules, panel heights and split-K factors all depend on the batch) against golden
+    numbers from the imported REFERENCE model (oracle/make_golden_large_b16.py; 50 TFLOP on the CPU, hence a committed
+    fixture): fp32 path at rtol 1e-4 - prediction / dx subsamples + checksums, cls, and for every parameter gradient a
+    strided subsample element-wise plus the float64 norm; then the bf16 channel-MLP mode (what the DPOT-L number runs)
+    against that verified fp32 result with the norm-wise sqrt(depth) bounds of `test_bf16_channel_mlp_mode_vs_oracle`"""
+    from helpers import assert_sub, load
+    from dpot_amd import DPOTNet, ops
+    fx = load("g13_large_b16")
+    B = int(fx["B"])
+    cfg = R.DPOTConfig(**R.LARGE)
+    S = cfg.img_size
+    x = R.recipe_input((B, S, S, cfg.in_timesteps, cfg.in_channels), salt=71)
+    up_y = (R.recipe_input((B, S, S, cfg.out_timesteps, cfg.out_channels), salt=72) * 0.3).cuda()
+    up_c = (R.recipe_input((B, cfg.n_cls), salt=73) * 0.3).cuda()
+
+    def run(mlp):
+        torch.cuda.empty_cache()
+        ops.set_mlp_precision(mlp)
+        try:
+            m = DPOTNet(**R.LARGE)
+            m.load_state_dict(_recipe_sd("LARGE", 4))
+            m.cuda()
+            xg = x.cuda().requires_grad_(True)
+            y, c = m(xg)
+            ((y * up_y).sum() + (c * up_c).sum()).backward()
+            torch.cuda.synchronize()
+        finally:
+            ops.set_mlp_precision(None)
+        return y.detach(), c.detach(), xg.grad, OrderedDict((k, p.grad) for k, p in m.named_parameters())
+
+    y, c, dx, grads = run(None)
+    assert_sub(y, fx, "y", "LARGE B=16 pred")
+    assert_close(c, fx["c"], "LARGE B=16 cls")
+    assert_sub(dx, fx, "dx", "LARGE B=16 dx")
+    want = dict(zip([str(n) for n in fx["names"]], fx["grad_norms"]))
+    assert set(want) == set(grads)
+    worst = 0.0
+    for k, g in grads.items():
+        assert_sub(g, fx, f"g/{k}", f"LARGE B=16 d{k}")
+        e = _rel(g.double().norm().item(), float(want[k]))
+        worst = max(worst, e)
+        assert e <= RTOL, f"LARGE B=16 |d{k}|: {e:.2e}"
+    print(f"[LARGE B={B} fp32 vs reference golden] worst gradient-norm error {worst:.2e}")
+
+    yb, cb, dxb, gb = run("bf16")
+    sd = cfg.depth ** 0.5
+    e_y, e_c, e_dx = _nrel(yb, y), _nrel(cb, c), _nrel(dxb, dx)
+    worst, worst_k = max((_nrel(gb[k], grads[k]), k) for k in grads)
+    print(f"[LARGE B={B} bf16-MLP vs the verified fp32 path] pred {e_y:.2e} cls {e_c:.2e} dx {e_dx:.2e}; worst parameter "
+          f"gradient {worst:.2e} ({worst_k})")
+    assert all(torch.isfinite(g).all() for g in gb.values())
+    assert e_y <= BF16_OUT_TOL and e_c <= BF16_OUT_TOL and e_dx <= BF16_DX_PER_SQRT_DEPTH * sd
+    assert worst <= BF16_GRAD_PER_SQRT_DEPTH * sd, worst_k
+    assert e_y > 1e-6
+
+
+# bf16 channel-MLP mode over a 20-step rollout (BASELINE configs[4] as bench.py --config L20 runs it: bf16 channel MLP +
+# activation recomputation).  Each AR step feeds its prediction back, so the per-step forward error (5-6.5e-3 norm-wise,
+# see above) compounds over the window: measured on MI355X against the reference's fp32 golden numbers (g11) - loss
+# %(L)s, global gradient norm %(G)s, worst per-tensor gradient NORM %(T)s (a norm comparison: rounding errors
+# that are orthogonal to the gradient do not show in it - the norm-wise gradient ERROR is bounded at one step by the tests above).
+BF16_L20_LOSS_TOL = 5e-3
+BF16_L20_GNORM_TOL = 3e-2
+BF16_L20_TENSOR_NORM_TOL = 8e-2
+
+
+def test_large_20_step_rollout_bf16_recompute_vs_reference_golden(bf16_mlp):
+    """`bench.py --config L20`'s mode - DPOT-L, 20-step rollout, bf16 channel MLP, activation recomputation - against
+    the reference's golden numbers (g11: loss, global / per-tensor gradient norms, 20-step prediction) with explicit
+    reduced-precision bounds; recomputation must stay bit-identical to the stored-activation run in this mode too"""
+    from helpers import load
+    fx = load("g11_large_rollout")
+    T_ar, B = int(fx["T_ar"]), int(fx["B"])
+    cfg = R.DPOTConfig(**R.LARGE)
+    S = cfg.img_size
+    xx = R.recipe_input((B, S, S, cfg.in_timesteps, cfg.in_channels), salt=81)
+    yy = R.recipe_input((B, S, S, T_ar, cfg.out_channels), salt=82)
+    msk = torch.ones(B, S, S, 1, cfg.out_channels)
+    res = {}
+    for recompute in (True, False):
+        loss, gn, norms, pred, flat, peak = _gpu_rollout_grads(R.LARGE, 6, xx, yy, msk, recompute)
+        e_l, e_g = _rel(loss, float(fx["loss"])), _rel(gn, float(fx["grad_norm"]))
+        stride = int(fx["pred.stride"])
+        ps = pred.cpu().reshape(-1)[::stride].double()
+        pr = torch.as_tensor(fx["pred.sub"]).double()
+        e_p = ((ps - pr).norm() / pr.norm()).item()
+        worst, worst_k = max((_rel(norms[str(n)], float(w)), str(n)) for n, w in zip(fx["names"], fx["grad_norms"]))
+        print(f"[LARGE T_ar={T_ar} B={B} bf16-MLP] recompute={recompute}: loss err {e_l:.2e}, |g| err {e_g:.2e}, "
+              f"20-step prediction (subsample, norm-wise) {e_p:.2e}, worst per-tensor gradient norm {worst:.2e} ({worst_k}), "
+              f"peak memory {peak:.2f} GiB")
+        assert e_l <= BF16_L20_LOSS_TOL and e_g <= BF16_L20_GNORM_TOL and worst <= BF16_L20_TENSOR_NORM_TOL
+        assert e_p <= 3 * BF16_OUT_TOL and e_p > 1e-6
+        res[recompute] = (loss, flat, peak)
+        del pred
+    assert res[True][0] == res[False][0]
+    assert torch.equal(res[True][1], res[False][1]), "recomputation must not change a single bit (bf16 mode)"
+    assert res[True][2] < 0.6 * res[False][2]
+
+
 def test_tiny_5_step_rollout_vs_oracle():
     """T_ar=5 DPOT-Tiny rollout (B=2) against the CPU oracle run live: loss, grad norms, prediction; +- recomputation"""
     kw, T_ar, B = R.TINY, 5, 2

@@ -325,6 +325,23 @@ def test_backward_after_optimiser_step_raises():
     assert torch.isfinite(opt.grad_norm()).item()
 
 
+def test_backward_after_graph_replay_raises():
+    """a hipGraph replay runs the captured Adam and rewrites the persistent weight packs just like the eager
+    optimiser: an eager forward -> replay -> eager backward sequence must raise, not use overwritten packs"""
+    from dpot_amd.train import GraphedTrainStep, rollout
+    m, cfg = build(R.MINI, salt=3)
+    xx, yy, msk = _batch(cfg, 2)
+    opt = _opt(m)
+    g = GraphedTrainStep(m, opt, xx, yy, msk, warmup=1)
+    loss_a, _ = rollout(m, xx, yy, msk)                       # eager forward A
+    g.replay(1e-3)                                            # parameters + packs change under it
+    with pytest.raises(RuntimeError, match="parameters were updated"):
+        loss_a.backward()
+    loss_b, _ = rollout(m, xx, yy, msk)
+    loss_b.backward()
+    assert torch.isfinite(opt.grad_norm()).item()
+
+
 def test_window_slide_rejects_mismatched_prediction():
     from dpot_amd import _lib, ops
     xx = torch.zeros(2, 8, 8, 4, 3, device="cuda")
