@@ -512,11 +512,10 @@ def main():
     ops.set_gemm_precision(args.gemm_precision)
 
     mlp_prec = args.mlp_precision if args.mlp_precision is not None else cmlp
-    if mlp_prec is not None:
-        ops.set_mlp_precision(mlp_prec)
 
     torch.manual_seed(0)                                       # identical random-init weights on every rank
     model = DPOTNet(**ckw).cuda()
+    model.mlp_precision = mlp_prec                             # per-model attribute (None: the process default = f32)
     model.recompute_blocks = recompute
     fp = FlatParams(model)
     # DDP semantics for N>1: cls_head takes part (zero gradients -> weight decay only), grads averaged over ranks
@@ -583,14 +582,24 @@ def main():
         one_step()
     fence()
     t0 = time.perf_counter()
+    host_s = 0.0                                               # host time spent INSIDE the step calls (no sync in there)
     for _ in range(args.steps):
+        th = time.perf_counter()
         loss = one_step()
+        host_s += time.perf_counter() - th
     fence()
     elapsed = time.perf_counter() - t0
+    rank_ms = [elapsed / args.steps * 1e3]
+    rank_host_us = [host_s / args.steps * 1e6]
     if world > 1:
-        t = torch.tensor([elapsed], device="cuda", dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = t.item()
+        # value uses the MAX over ranks; the per-rank spread (and the host cost of driving the segmented chain: 3-5 graph
+        # launches + the collectives of a step from one thread) is reported beside it
+        t = torch.tensor([elapsed, host_s], device="cuda", dtype=torch.float64)
+        allt = [torch.empty_like(t) for _ in range(world)]
+        dist.all_gather(allt, t)
+        rank_ms = [float(a[0]) / args.steps * 1e3 for a in allt]
+        rank_host_us = [float(a[1]) / args.steps * 1e6 for a in allt]
+        elapsed = max(float(a[0]) for a in allt)
     final_loss = float(loss.item())
 
     if rank == 0:
@@ -615,11 +624,19 @@ def main():
                        "activation_recomputation": recompute,
                        "peak_mem_GB": round(torch.cuda.max_memory_allocated() / 2 ** 30, 2)},
         }
+        out["config"]["host_us_per_step"] = round(max(rank_host_us), 1)
         if world > 1:
             out["config"]["collectives"] = {
                 "backend": dist.get_backend(), "world_size": dist.get_world_size(),
                 "library": ("gloo (DPOT_BENCH_DEBUG_GLOO=1: functional dry run, all ranks on cuda:0 - NOT a performance "
                             "number)") if debug_gloo else f"RCCL {'.'.join(map(str, torch.cuda.nccl.version()))} over xGMI"}
+            out["config"]["per_rank"] = {"ms_per_step_min": round(min(rank_ms), 4), "ms_per_step_max": round(max(rank_ms), 4),
+                                         "host_us_per_step_min": round(min(rank_host_us), 1),
+                                         "host_us_per_step_max": round(max(rank_host_us), 1),
+                                         "note": "host_us = wall time the rank's single host thread spends inside the step "
+                                                 "call (graph launches, stream waits, collective enqueues); it must stay "
+                                                 "below ms_per_step or the GPU starves"}
+            out["config"]["buckets_MB"] = [round((hi - lo) * 4 / 1e6, 2) for lo, hi in reducer.ranges]
             out["config"]["dp"] = ("eager, hook-driven bucket all-reduce" if graphed is None else
                                    "one graph + all-reduce after backward" if args.no_overlap else
                                    f"segmented hipGraph chain ({len(graphed.graphs)} segments), bucket all-reduce on a "

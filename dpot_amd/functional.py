@@ -530,6 +530,11 @@ class BlockFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dout):
+        with ops.mlp_precision_scope(ctx.mlp_precision):      # the mode the forward ran in (a per-model attribute)
+            return BlockFn._backward(ctx, dout)
+
+    @staticmethod
+    def _backward(ctx, dout):
         _check_epoch(ctx, "BlockFn")
         mp = ctx.mlp_precision
         if ctx.recompute:

@@ -120,6 +120,9 @@ class DPOTNet(nn.Module):
         # activation recomputation inside every Block (functional.BlockFn): keep only block inputs between forward
         # and backward - for long auto-regressive rollouts at 256^2 (BASELINE configs[4])
         self.recompute_blocks = False
+        # precision of the channel-MLP GEMMs of THIS model: None = the process default (ops.set_mlp_precision /
+        # DPOT_MLP_PRECISION), or 'f32' | 'bf16x6' | 'auto' | 'bf16' (BASELINE configs[2]: "bf16 channel-MLP on MFMA")
+        self.mlp_precision = None
         self._scope_depth = 0
         self._scope_cache = None
         # optional callable(b, lat) -> lat, called with the latent ENTERING stage b (1..depth = block b-1,
@@ -139,7 +142,8 @@ class DPOTNet(nn.Module):
         if self._scope_depth == 1:
             self._scope_cache = None
             if dev.type == "cuda":
-                self._derived_weights()
+                with ops.mlp_precision_scope(self.mlp_precision):
+                    self._derived_weights()
         try:
             yield self
         finally:
@@ -232,6 +236,10 @@ class DPOTNet(nn.Module):
         return mlp_pk, head_pk
 
     def forward(self, x):
+        with ops.mlp_precision_scope(self.mlp_precision):
+            return self._forward(x)
+
+    def _forward(self, x):
         if not x.is_cuda:
             raise _lib.DpotHipError("DPOTNet (dpot_amd) runs on MI355X only: move the model and the input to 'cuda'. "
                                     "There is no CPU fallback.")

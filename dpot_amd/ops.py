@@ -7,6 +7,7 @@ tensors.  There is deliberately no CPU or eager-PyTorch fallback.
 from __future__ import annotations
 
 import ctypes as C
+import contextlib
 import os
 from typing import Optional, Tuple
 
@@ -48,6 +49,25 @@ _mlp_precision = _PRECISIONS[os.environ["DPOT_MLP_PRECISION"]] if os.environ.get
 def set_mlp_precision(name: Optional[str]) -> None:
     global _mlp_precision
     _mlp_precision = None if name is None else _PRECISIONS[name]
+
+
+@contextlib.contextmanager
+def mlp_precision_scope(prec):
+    """the channel-MLP precision of ONE model while its kernels are being enqueued: `DPOTNet.mlp_precision` (a
+    per-model attribute: 'f32' | 'bf16x6' | 'auto' | 'bf16' | None = the process default above) is applied around the
+    model's forward, its weight derivation and - through the value captured in the autograd context - its backward, so two
+    models of one process can run different modes and nothing leaks to the next caller.  prec: a name, a precision code
+    or None (= leave the current setting)."""
+    global _mlp_precision
+    if prec is None:
+        yield
+        return
+    prev = _mlp_precision
+    _mlp_precision = _PRECISIONS[prec] if isinstance(prec, str) else int(prec)
+    try:
+        yield
+    finally:
+        _mlp_precision = prev
 
 
 def effective_mlp_precision() -> int:

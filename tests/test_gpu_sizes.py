@@ -148,6 +148,45 @@ def test_tiny_at_other_resolutions_vs_oracle(img, B, mlp):
             assert _nrel(p.grad, sd[k].grad) <= BF16_GRAD_PER_SQRT_DEPTH * depth ** 0.5, k
 
 
+def test_mlp_precision_is_a_per_model_attribute():
+    """the channel-MLP precision is an attribute of the MODEL (`DPOTNet.mlp_precision`), applied around
+    its forward / weight derivation / backward - two models of one process run different modes, interleaved, and the
+    process-global default is untouched afterwards"""
+    from dpot_amd import DPOTNet, ops
+    assert ops.mlp_precision() is None
+    cfg = R.DPOTConfig(**R.SMALL)
+    S = cfg.img_size
+    x = R.recipe_input((2, S, S, cfg.in_timesteps, cfg.in_channels), salt=71).cuda()
+    up = (R.recipe_input((2, S, S, cfg.out_timesteps, cfg.out_channels), salt=72) * 0.3).cuda()
+
+    def fresh(prec):
+        m = DPOTNet(**R.SMALL)
+        m.load_state_dict(_recipe_sd("SMALL", 4))
+        m.cuda()
+        m.mlp_precision = prec
+        return m
+
+    def run(m):
+        for p in m.parameters():
+            p.grad = None
+        y, _ = m(x)
+        (y * up).sum().backward()
+        return y.detach().clone(), m.blocks[0].mlp[0].weight.grad.clone()
+
+    y32, g32 = run(fresh(None))                                  # reference: a plain fp32 process
+    a, b = fresh("bf16"), fresh(None)
+    ya, _ = a(x)                                                 # forward A (bf16) ...
+    yb, _ = b(x)                                                 # ... forward B (fp32) ...
+    (ya * up).sum().backward()                                   # ... backward A after B's forward
+    (yb * up).sum().backward()
+    assert torch.equal(yb, y32) and torch.equal(b.blocks[0].mlp[0].weight.grad, g32), "fp32 model disturbed by its neighbour"
+    yA, gA = run(fresh("bf16"))
+    assert torch.equal(ya.detach(), yA) and torch.equal(a.blocks[0].mlp[0].weight.grad, gA), "bf16 model not reproducible"
+    e = _nrel(ya, y32)
+    assert 1e-6 < e <= BF16_OUT_TOL, e
+    assert ops.mlp_precision() is None
+
+
 @pytest.fixture
 def bf16_mlp():
     from dpot_amd import ops
