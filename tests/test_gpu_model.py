@@ -4,6 +4,8 @@ properties at the full BASELINE size (DPOT-Tiny, B=32)."""
 from collections import OrderedDict
 
 import numpy as np
+import os
+
 import pytest
 import torch
 
@@ -52,7 +54,8 @@ def test_afno_mixer_golden(name):
     x = R.recipe_input((B, h, h, E), salt=11)
     up = (R.recipe_input((B, h, h, E), salt=12) * 0.3)
     bs = E // nb
-    if name == "g1_afno_tiny":        # the DPOT-Tiny layer must run on the fused three-product kernel
+    opted_out = os.environ.get("DPOT_AFNO_3MULT", "1") == "0" or os.environ.get("DPOT_AFNO_FUSED", "1") == "0"
+    if name == "g1_afno_tiny" and not opted_out:      # the DPOT-Tiny layer must run on the fused three-product kernel
         assert ops.afno_mlp2_supported(nb, bs) and ops.afno_mlp3_supported(nb, bs)
         assert ops.afno_wgrad2_splitk(B * min(modes, h) * min(modes, h // 2 + 1), nb, bs) > 0
     xg = x.cuda().view(B, h * h, E).requires_grad_(True)

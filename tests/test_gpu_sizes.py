@@ -386,11 +386,12 @@ def test_large_batch16_vs_reference_golden():
 # bf16 channel-MLP mode over a 20-step rollout (BASELINE configs[4] as bench.py --config L20 runs it: bf16 channel MLP +
 # activation recomputation).  Each AR step feeds its prediction back, so the per-step forward error (5-6.5e-3 norm-wise,
 # see above) compounds over the window: measured on MI355X against the reference's fp32 golden numbers (g11) - loss
-# %(L)s, global gradient norm %(G)s, worst per-tensor gradient NORM %(T)s (a norm comparison: rounding errors
+# 7.8e-5, global gradient norm 2.9e-4, worst per-tensor gradient NORM 4.7e-3, 20-step prediction 8.2e-3 (a norm comparison: rounding errors
 # that are orthogonal to the gradient do not show in it - the norm-wise gradient ERROR is bounded at one step by the tests above).
-BF16_L20_LOSS_TOL = 5e-3
-BF16_L20_GNORM_TOL = 3e-2
-BF16_L20_TENSOR_NORM_TOL = 8e-2
+BF16_L20_LOSS_TOL = 5e-4
+BF16_L20_GNORM_TOL = 2e-3
+BF16_L20_TENSOR_NORM_TOL = 2e-2
+BF16_L20_PRED_TOL = 3e-2
 
 
 def test_large_20_step_rollout_bf16_recompute_vs_reference_golden(bf16_mlp):
@@ -418,7 +419,7 @@ def test_large_20_step_rollout_bf16_recompute_vs_reference_golden(bf16_mlp):
               f"20-step prediction (subsample, norm-wise) {e_p:.2e}, worst per-tensor gradient norm {worst:.2e} ({worst_k}), "
               f"peak memory {peak:.2f} GiB")
         assert e_l <= BF16_L20_LOSS_TOL and e_g <= BF16_L20_GNORM_TOL and worst <= BF16_L20_TENSOR_NORM_TOL
-        assert e_p <= 3 * BF16_OUT_TOL and e_p > 1e-6
+        assert e_p <= BF16_L20_PRED_TOL and e_p > 1e-6
         res[recompute] = (loss, flat, peak)
         del pred
     assert res[True][0] == res[False][0]
