@@ -1,6 +1,7 @@
 // dft_fast.h - register-blocked rfft2 / irfft2 for the power-of-two latent grids: 16x16 (128^2 / patch 8) and 32x32
-// (256^2 / patch 8) - what the DPOT configs use - plus 8x8 and 64x64 (64^2 and 512^2 fields at patch 8: the other
-// resolutions utils/griddataset.py:35 lists; 128^2 / 256^2 at patch 16 / 4).  Same contract as the generic kernels in dft.hip:
+// (256^2 / patch 8) - what the DPOT configs use - plus 8x8, 64x64 and 128x128 (64^2, 512^2 and 1024^2 fields at patch 8:
+// the other resolutions utils/griddataset.py:35 lists; 128^2 / 256^2 at patch 16 / 4).  Same contract as the generic
+// kernels in dft.hip (which keep every other size, odd ones included):
 //   * both passes keep one line of a channel (16 / 32 points) in VGPRs and transform it with a fully unrolled
 //     radix-2 FFT whose twiddles are compile-time constants (round 1 evaluated the direct O(N^2) sums there, which left
 //     the kernels VALU-bound at 2.7 / 3.5 TB/s; the real-input / one-sided zeros and the unused outputs fold away)
@@ -56,6 +57,17 @@ template <> struct Twid<64> {
   }
   static __host__ __device__ constexpr float s(int i) {
     constexpr float t[64] = {0.0f, 0.0980171412229538f, 0.19509032368659973f, 0.290284663438797f, 0.3826834261417389f, 0.4713967442512512f, 0.5555702447891235f, 0.6343932747840881f, 0.7071067690849304f, 0.7730104327201843f, 0.8314695954322815f, 0.8819212913513184f, 0.9238795042037964f, 0.9569403529167175f, 0.9807852506637573f, 0.9951847195625305f, 1.0f, 0.9951847195625305f, 0.9807852506637573f, 0.9569403529167175f, 0.9238795042037964f, 0.8819212913513184f, 0.8314695954322815f, 0.7730104327201843f, 0.7071067690849304f, 0.6343932747840881f, 0.5555702447891235f, 0.4713967442512512f, 0.3826834261417389f, 0.290284663438797f, 0.19509032368659973f, 0.0980171412229538f, 0.0f, -0.0980171412229538f, -0.19509032368659973f, -0.290284663438797f, -0.3826834261417389f, -0.4713967442512512f, -0.5555702447891235f, -0.6343932747840881f, -0.7071067690849304f, -0.7730104327201843f, -0.8314695954322815f, -0.8819212913513184f, -0.9238795042037964f, -0.9569403529167175f, -0.9807852506637573f, -0.9951847195625305f, -1.0f, -0.9951847195625305f, -0.9807852506637573f, -0.9569403529167175f, -0.9238795042037964f, -0.8819212913513184f, -0.8314695954322815f, -0.7730104327201843f, -0.7071067690849304f, -0.6343932747840881f, -0.5555702447891235f, -0.4713967442512512f, -0.3826834261417389f, -0.290284663438797f, -0.19509032368659973f, -0.0980171412229538f};
+    return t[i];
+  }
+};
+
+template <> struct Twid<128> {
+  static __host__ __device__ constexpr float c(int i) {
+    constexpr float t[128] = {1.0f, 0.9987954497337341f, 0.9951847195625305f, 0.9891765117645264f, 0.9807852506637573f, 0.9700312614440918f, 0.9569403529167175f, 0.9415440559387207f, 0.9238795042037964f, 0.903989315032959f, 0.8819212913513184f, 0.8577286005020142f, 0.8314695954322815f, 0.803207516670227f, 0.7730104327201843f, 0.7409511208534241f, 0.7071067690849304f, 0.6715589761734009f, 0.6343932747840881f, 0.5956993103027344f, 0.5555702447891235f, 0.5141027569770813f, 0.4713967442512512f, 0.4275550842285156f, 0.3826834261417389f, 0.3368898630142212f, 0.290284663438797f, 0.24298018217086792f, 0.19509032368659973f, 0.1467304676771164f, 0.0980171412229538f, 0.049067676067352295f, 0.0f, -0.049067676067352295f, -0.0980171412229538f, -0.1467304676771164f, -0.19509032368659973f, -0.24298018217086792f, -0.290284663438797f, -0.3368898630142212f, -0.3826834261417389f, -0.4275550842285156f, -0.4713967442512512f, -0.5141027569770813f, -0.5555702447891235f, -0.5956993103027344f, -0.6343932747840881f, -0.6715589761734009f, -0.7071067690849304f, -0.7409511208534241f, -0.7730104327201843f, -0.803207516670227f, -0.8314695954322815f, -0.8577286005020142f, -0.8819212913513184f, -0.903989315032959f, -0.9238795042037964f, -0.9415440559387207f, -0.9569403529167175f, -0.9700312614440918f, -0.9807852506637573f, -0.9891765117645264f, -0.9951847195625305f, -0.9987954497337341f, -1.0f, -0.9987954497337341f, -0.9951847195625305f, -0.9891765117645264f, -0.9807852506637573f, -0.9700312614440918f, -0.9569403529167175f, -0.9415440559387207f, -0.9238795042037964f, -0.903989315032959f, -0.8819212913513184f, -0.8577286005020142f, -0.8314695954322815f, -0.803207516670227f, -0.7730104327201843f, -0.7409511208534241f, -0.7071067690849304f, -0.6715589761734009f, -0.6343932747840881f, -0.5956993103027344f, -0.5555702447891235f, -0.5141027569770813f, -0.4713967442512512f, -0.4275550842285156f, -0.3826834261417389f, -0.3368898630142212f, -0.290284663438797f, -0.24298018217086792f, -0.19509032368659973f, -0.1467304676771164f, -0.0980171412229538f, -0.049067676067352295f, 0.0f, 0.049067676067352295f, 0.0980171412229538f, 0.1467304676771164f, 0.19509032368659973f, 0.24298018217086792f, 0.290284663438797f, 0.3368898630142212f, 0.3826834261417389f, 0.4275550842285156f, 0.4713967442512512f, 0.5141027569770813f, 0.5555702447891235f, 0.5956993103027344f, 0.6343932747840881f, 0.6715589761734009f, 0.7071067690849304f, 0.7409511208534241f, 0.7730104327201843f, 0.803207516670227f, 0.8314695954322815f, 0.8577286005020142f, 0.8819212913513184f, 0.903989315032959f, 0.9238795042037964f, 0.9415440559387207f, 0.9569403529167175f, 0.9700312614440918f, 0.9807852506637573f, 0.9891765117645264f, 0.9951847195625305f, 0.9987954497337341f};
+    return t[i];
+  }
+  static __host__ __device__ constexpr float s(int i) {
+    constexpr float t[128] = {0.0f, 0.049067676067352295f, 0.0980171412229538f, 0.1467304676771164f, 0.19509032368659973f, 0.24298018217086792f, 0.290284663438797f, 0.3368898630142212f, 0.3826834261417389f, 0.4275550842285156f, 0.4713967442512512f, 0.5141027569770813f, 0.5555702447891235f, 0.5956993103027344f, 0.6343932747840881f, 0.6715589761734009f, 0.7071067690849304f, 0.7409511208534241f, 0.7730104327201843f, 0.803207516670227f, 0.8314695954322815f, 0.8577286005020142f, 0.8819212913513184f, 0.903989315032959f, 0.9238795042037964f, 0.9415440559387207f, 0.9569403529167175f, 0.9700312614440918f, 0.9807852506637573f, 0.9891765117645264f, 0.9951847195625305f, 0.9987954497337341f, 1.0f, 0.9987954497337341f, 0.9951847195625305f, 0.9891765117645264f, 0.9807852506637573f, 0.9700312614440918f, 0.9569403529167175f, 0.9415440559387207f, 0.9238795042037964f, 0.903989315032959f, 0.8819212913513184f, 0.8577286005020142f, 0.8314695954322815f, 0.803207516670227f, 0.7730104327201843f, 0.7409511208534241f, 0.7071067690849304f, 0.6715589761734009f, 0.6343932747840881f, 0.5956993103027344f, 0.5555702447891235f, 0.5141027569770813f, 0.4713967442512512f, 0.4275550842285156f, 0.3826834261417389f, 0.3368898630142212f, 0.290284663438797f, 0.24298018217086792f, 0.19509032368659973f, 0.1467304676771164f, 0.0980171412229538f, 0.049067676067352295f, 0.0f, -0.049067676067352295f, -0.0980171412229538f, -0.1467304676771164f, -0.19509032368659973f, -0.24298018217086792f, -0.290284663438797f, -0.3368898630142212f, -0.3826834261417389f, -0.4275550842285156f, -0.4713967442512512f, -0.5141027569770813f, -0.5555702447891235f, -0.5956993103027344f, -0.6343932747840881f, -0.6715589761734009f, -0.7071067690849304f, -0.7409511208534241f, -0.7730104327201843f, -0.803207516670227f, -0.8314695954322815f, -0.8577286005020142f, -0.8819212913513184f, -0.903989315032959f, -0.9238795042037964f, -0.9415440559387207f, -0.9569403529167175f, -0.9700312614440918f, -0.9807852506637573f, -0.9891765117645264f, -0.9951847195625305f, -0.9987954497337341f, -1.0f, -0.9987954497337341f, -0.9951847195625305f, -0.9891765117645264f, -0.9807852506637573f, -0.9700312614440918f, -0.9569403529167175f, -0.9415440559387207f, -0.9238795042037964f, -0.903989315032959f, -0.8819212913513184f, -0.8577286005020142f, -0.8314695954322815f, -0.803207516670227f, -0.7730104327201843f, -0.7409511208534241f, -0.7071067690849304f, -0.6715589761734009f, -0.6343932747840881f, -0.5956993103027344f, -0.5555702447891235f, -0.5141027569770813f, -0.4713967442512512f, -0.4275550842285156f, -0.3826834261417389f, -0.3368898630142212f, -0.290284663438797f, -0.24298018217086792f, -0.19509032368659973f, -0.1467304676771164f, -0.0980171412229538f, -0.049067676067352295f};
     return t[i];
   }
 };
@@ -284,6 +296,174 @@ __global__ __launch_bounds__(256) void irfft2_fast_kernel(const float* __restric
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// 128 x 128 latent grids (1024^2 fields at patch 8 - the largest resolution utils/griddataset.py:35 lists; round 4).  A
+// 128-point complex line is 256 registers - too many to keep next to the butterflies - so every line is split by ONE
+// decimation-in-frequency stage applied while the inputs are loaded:
+//      X[2k]   = FFT64(x[n] + x[n+64])[k]            X[2k+1] = FFT64((x[n] - x[n+64]) w^n)[k],   w = e^{-+2 pi i / 128}
+// i.e. two independent 64-point register FFTs (fft_regs<64>, the 512^2 kernels' line) per 128-point line; a thread runs
+// them one after the other.  Same contract, passes and LDS plan as the kernels above; only the KEPT ky rows go through
+// LDS ([my][128][2][CC]: 4 channels per workgroup up to 36 kept columns, 2 up to all 65).
+// ---------------------------------------------------------------------------------------------------------------------
+template <int CC>
+__global__ __launch_bounds__(256) void rfft2_128_kernel(const float* __restrict__ x, float* __restrict__ spec, int E,
+                                                        int nb, int mx, int my, int colw, float scale) {
+  constexpr int H = 128, W = 128, HN = 64;
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  float* Z = sm;                                            // [my][H][2][CC]
+  const int b = blockIdx.y, c0 = xcd_chunk(blockIdx.x, gridDim.x) * CC;
+  const int tid = threadIdx.x;
+  const int bs = E / nb;
+  const float* xb = x + (long long)b * H * W * E + c0;
+
+  // pass 1: rows (real -> half complex).  Even ky from s[n] = x[n] + x[n+64], odd ky from (x[n] - x[n+64]) w^n
+  for (int it = tid; it < H * CC; it += 256) {
+    const int c = it % CC, xr = it / CC;
+    float d[HN], re[HN], im[HN];
+#pragma unroll
+    for (int n = 0; n < HN; ++n) {
+      const float a = xb[(long long)(xr * W + n) * E + c], q = xb[(long long)(xr * W + n + HN) * E + c];
+      re[n] = a + q;
+      d[n] = a - q;
+      im[n] = 0.f;                                           // real input: the zero half folds away
+    }
+    fft_regs<HN, -1>(re, im);
+    fft_sfor<0, HN>([&](auto K) __attribute__((always_inline)) {
+      constexpr int k = decltype(K)::value, ky = 2 * k;
+      if (ky < my) {
+        Z[((ky * H + xr) * 2 + 0) * CC + c] = re[brev<HN>(k)];
+        Z[((ky * H + xr) * 2 + 1) * CC + c] = im[brev<HN>(k)];
+      }
+    });
+    // (ky = 64, the Nyquist column, is k = 32 of the even half: written above when it is kept)
+    fft_sfor<0, HN>([&](auto Nn) __attribute__((always_inline)) {
+      constexpr int n = decltype(Nn)::value;
+      re[n] = d[n] * Twid<128>::c(n);
+      im[n] = -d[n] * Twid<128>::s(n);
+    });
+    fft_regs<HN, -1>(re, im);
+    fft_sfor<0, HN>([&](auto K) __attribute__((always_inline)) {
+      constexpr int k = decltype(K)::value, ky = 2 * k + 1;
+      if (ky < my) {
+        Z[((ky * H + xr) * 2 + 0) * CC + c] = re[brev<HN>(k)];
+        Z[((ky * H + xr) * 2 + 1) * CC + c] = im[brev<HN>(k)];
+      }
+    });
+  }
+  __syncthreads();
+
+  // pass 2: columns (complex -> complex), kept modes only; item = (ky, c, parity of kx)
+  for (int it = tid; it < my * CC * 2; it += 256) {
+    const int c = it % CC, par = (it / CC) & 1, ky = it / (2 * CC);
+    float zr[HN], zi[HN];
+    fft_sfor<0, HN>([&](auto Nn) __attribute__((always_inline)) {
+      constexpr int n = decltype(Nn)::value;
+      const float ar = Z[((ky * H + n) * 2 + 0) * CC + c], ai = Z[((ky * H + n) * 2 + 1) * CC + c];
+      const float br = Z[((ky * H + n + HN) * 2 + 0) * CC + c], bi = Z[((ky * H + n + HN) * 2 + 1) * CC + c];
+      const float dr = ar - br, di = ai - bi;
+      constexpr float cw = Twid<128>::c(n), sw = -Twid<128>::s(n);        // w^n = e^{-2 pi i n / 128}
+      zr[n] = par ? dr * cw - di * sw : ar + br;
+      zi[n] = par ? dr * sw + di * cw : ai + bi;
+    });
+    const int chn = c0 + c;
+    const int blk = chn / bs, ci = chn % bs;
+    const float wgt = scale * colw_f(colw, ky, W);
+    float* out = spec + (((long long)b * mx * my + ky) * nb + blk) * 2 * bs + ci;
+    const long long kxstride = (long long)my * nb * 2 * bs;
+    fft_regs<HN, -1>(zr, zi);
+    fft_sfor<0, HN>([&](auto K) __attribute__((always_inline)) {
+      constexpr int k = decltype(K)::value;
+      const int kx = 2 * k + par;
+      if (kx < mx) {
+        out[kx * kxstride] = zr[brev<HN>(k)] * wgt;
+        out[kx * kxstride + bs] = zi[brev<HN>(k)] * wgt;
+      }
+    });
+  }
+}
+
+// spec[B,mx,my,nb,2,bs] (+ res[B,H*W,E]) -> y[B,H*W,E], 128 x 128
+template <int CC>
+__global__ __launch_bounds__(256) void irfft2_128_kernel(const float* __restrict__ spec, const float* __restrict__ res,
+                                                         float* __restrict__ y, int E, int nb, int mx, int my, int colw,
+                                                         float scale) {
+  constexpr int H = 128, W = 128, HN = 64;
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  float* U = sm;                                            // [H][my][2][CC]
+  const int b = blockIdx.y, c0 = xcd_chunk(blockIdx.x, gridDim.x) * CC;
+  const int tid = threadIdx.x;
+  const int bs = E / nb;
+
+  // pass A: columns, U[x, ky] = sum_kx S[kx, ky] e^{+2 pi i kx x / H} times the column weight; item = (ky, c, parity of x)
+  for (int it = tid; it < my * CC * 2; it += 256) {
+    const int c = it % CC, par = (it / CC) & 1, ky = it / (2 * CC);
+    const int chn = c0 + c;
+    const int blk = chn / bs, ci = chn % bs;
+    const float* in = spec + (((long long)b * mx * my + ky) * nb + blk) * 2 * bs + ci;
+    const long long kxstride = (long long)my * nb * 2 * bs;
+    float sr[HN], si[HN];
+    fft_sfor<0, HN>([&](auto Kk) __attribute__((always_inline)) {
+      constexpr int k = decltype(Kk)::value;
+      const int k0 = k < mx ? k : mx - 1, k1 = k + HN < mx ? k + HN : mx - 1;   // clamped addresses, selected values
+      float ar = in[k0 * kxstride], ai = in[k0 * kxstride + bs];
+      float br = in[k1 * kxstride], bi = in[k1 * kxstride + bs];
+      ar = k < mx ? ar : 0.f;
+      ai = k < mx ? ai : 0.f;
+      br = k + HN < mx ? br : 0.f;
+      bi = k + HN < mx ? bi : 0.f;
+      const float dr = ar - br, di = ai - bi;
+      constexpr float cw = Twid<128>::c(k), sw = Twid<128>::s(k);         // w^k = e^{+2 pi i k / 128}
+      sr[k] = par ? dr * cw - di * sw : ar + br;
+      si[k] = par ? dr * sw + di * cw : ai + bi;
+    });
+    const float wgt = colw_f(colw, ky, W);
+    fft_regs<HN, 1>(sr, si);
+    fft_sfor<0, HN>([&](auto M) __attribute__((always_inline)) {
+      constexpr int m = decltype(M)::value;
+      const int xr = 2 * m + par;
+      U[((xr * my + ky) * 2 + 0) * CC + c] = sr[brev<HN>(m)] * wgt;
+      U[((xr * my + ky) * 2 + 1) * CC + c] = si[brev<HN>(m)] * wgt;
+    });
+  }
+  __syncthreads();
+
+  // pass B: rows (half complex -> real), + residual; item = (xr, c, parity of the output column)
+  const long long base = (long long)b * H * W * E + c0;
+  for (int it = tid; it < H * CC * 2; it += 256) {
+    const int c = it % CC, par = (it / CC) & 1, xr = it / (2 * CC);
+    float ur[HN], ui[HN];
+    // one-sided spectrum V[ky], ky < my <= 65 (zero above): a[k] = V[k] + V[k+64], b[k] = (V[k] - V[k+64]) w^k; V[k+64] is
+    // non-zero for k = 0 only (the Nyquist column, when it is kept)
+    fft_sfor<0, HN>([&](auto Kk) __attribute__((always_inline)) {
+      constexpr int k = decltype(Kk)::value;
+      const int kc = k < my ? k : my - 1;
+      float ar = U[((xr * my + kc) * 2 + 0) * CC + c], ai = U[((xr * my + kc) * 2 + 1) * CC + c];
+      ar = k < my ? ar : 0.f;
+      ai = k < my ? ai : 0.f;
+      float br = 0.f, bi = 0.f;
+      if constexpr (k == 0) {
+        const int kn = HN < my ? HN : my - 1;
+        br = U[((xr * my + kn) * 2 + 0) * CC + c];
+        bi = U[((xr * my + kn) * 2 + 1) * CC + c];
+        br = HN < my ? br : 0.f;
+        bi = HN < my ? bi : 0.f;
+      }
+      const float dr = ar - br, di = ai - bi;
+      constexpr float cw = Twid<128>::c(k), sw = Twid<128>::s(k);
+      ur[k] = par ? dr * cw - di * sw : ar + br;
+      ui[k] = par ? dr * sw + di * cw : ai + bi;
+    });
+    fft_regs<HN, 1>(ur, ui);                               // y[2m + par] = Re(IFFT64(.)[m])
+    fft_sfor<0, HN>([&](auto M) __attribute__((always_inline)) {
+      constexpr int m = decltype(M)::value;
+      const int yy = 2 * m + par;
+      float v = ur[brev<HN>(m)] * scale;
+      if (res) v += res[base + (long long)(xr * W + yy) * E + c];
+      y[base + (long long)(xr * W + yy) * E + c] = v;
+    });
+  }
+}
+
 #ifndef DPOT_DFT_NO_KERNELS   // (csrc/gn_dft.hip uses the register FFTs above only)
 template <int H, int W, int CC>
 static int launch_rfft2_fast(const float* x, float* spec, int B, int E, int nb, int mx, int my, int colw, float scale,
@@ -304,6 +484,26 @@ static int launch_irfft2_fast(const float* spec, const float* res, float* y, int
   hipLaunchKernelGGL((irfft2_fast_kernel<H, W, CC>), dim3(E / CC, B), dim3(256), lds, s, spec, res, y, E, nb, mx, my,
                      colw, scale, nrm);
   return check_launch("irfft2_fast_kernel");
+}
+
+template <int CC>
+static int launch_rfft2_128(const float* x, float* spec, int B, int E, int nb, int mx, int my, int colw, float scale,
+                            hipStream_t s) {
+  const size_t lds = sizeof(float) * ((size_t)my * 128 * 2 * CC);
+  hipFuncSetAttribute(reinterpret_cast<const void*>(rfft2_128_kernel<CC>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                      160 * 1024);
+  hipLaunchKernelGGL((rfft2_128_kernel<CC>), dim3(E / CC, B), dim3(256), lds, s, x, spec, E, nb, mx, my, colw, scale);
+  return check_launch("rfft2_128_kernel");
+}
+template <int CC>
+static int launch_irfft2_128(const float* spec, const float* res, float* y, int B, int E, int nb, int mx, int my, int colw,
+                             float scale, hipStream_t s) {
+  const size_t lds = sizeof(float) * ((size_t)my * 128 * 2 * CC);
+  hipFuncSetAttribute(reinterpret_cast<const void*>(irfft2_128_kernel<CC>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                      160 * 1024);
+  hipLaunchKernelGGL((irfft2_128_kernel<CC>), dim3(E / CC, B), dim3(256), lds, s, spec, res, y, E, nb, mx, my, colw,
+                     scale);
+  return check_launch("irfft2_128_kernel");
 }
 
 // returns 1 if a fast kernel was launched (rc in *rc), 0 if the shape has no fast path
@@ -329,6 +529,10 @@ static inline int try_rfft2_fast(const float* x, float* spec, int B, int h, int 
     if (forced != 16 && forced != 32 && E % 12 == 0 && (E / nb) % 12 == 0 && (long long)B * (E / 12) >= 256) { *rc = launch_rfft2_fast<32, 32, 12>(x, spec, B, E, nb, mx, my, colw, scale, s, nrm); return 1; }
     if (forced != 16 && E % 32 == 0 && (long long)B * (E / 32) >= 128) { *rc = launch_rfft2_fast<32, 32, 32>(x, spec, B, E, nb, mx, my, colw, scale, s, nrm); return 1; }
     if (E % 16 == 0) { *rc = launch_rfft2_fast<32, 32, 16>(x, spec, B, E, nb, mx, my, colw, scale, s, nrm); return 1; }
+  } else if (h == 128 && w == 128 && !nrm.mean) {
+    // 1024^2 fields at patch 8: two 64-point register FFTs per line; the kept ky rows in LDS ([my][128][2][CC])
+    if (E % 4 == 0 && my <= 36) { *rc = launch_rfft2_128<4>(x, spec, B, E, nb, mx, my, colw, scale, s); return 1; }
+    if (E % 2 == 0) { *rc = launch_rfft2_128<2>(x, spec, B, E, nb, mx, my, colw, scale, s); return 1; }
   }
   return 0;
 }
@@ -350,6 +554,9 @@ static inline int try_irfft2_fast(const float* spec, const float* res, float* y,
     // 384 of 16-channel chunks (1.5 per CU: half the CUs run two in a row) - 20.4 against 29.8 us
     if (forced != 16 && E % 12 == 0 && (E / nb) % 12 == 0 && (long long)B * (E / 12) >= 256) { *rc = launch_irfft2_fast<32, 32, 12>(spec, res, y, B, E, nb, mx, my, colw, scale, s, nrm); return 1; }
     if (E % 16 == 0) { *rc = launch_irfft2_fast<32, 32, 16>(spec, res, y, B, E, nb, mx, my, colw, scale, s, nrm); return 1; }
+  } else if (h == 128 && w == 128 && !nrm.mean) {
+    if (E % 4 == 0 && my <= 36) { *rc = launch_irfft2_128<4>(spec, res, y, B, E, nb, mx, my, colw, scale, s); return 1; }
+    if (E % 2 == 0) { *rc = launch_irfft2_128<2>(spec, res, y, B, E, nb, mx, my, colw, scale, s); return 1; }
   }
   return 0;
 }

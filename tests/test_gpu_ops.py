@@ -142,7 +142,12 @@ def test_linear_bwd_weight_auto_splitk_large_k(ops):
                                               # fields at patch 8, utils/griddataset.py:35), full and truncated mode sets;
                                               # 128x128 (1024^2) stays on the generic direct-sum kernel
                                               (16, 8, 8, 512, 4, 32), (2, 8, 8, 64, 4, 3), (2, 64, 64, 64, 4, 32),
-                                              (1, 64, 64, 512, 4, 64), (1, 128, 128, 8, 1, 32)])
+                                              (1, 64, 64, 512, 4, 64),
+                                              # round 4: 128 x 128 (1024^2 fields at patch 8) as two 64-point register FFTs
+                                              # per line - 4-channel chunks (<= 36 kept columns) and 2-channel chunks
+                                              # (all 65 columns incl. the Nyquist one), truncated and full mode sets
+                                              (1, 128, 128, 8, 1, 32), (2, 128, 128, 8, 2, 20), (1, 128, 128, 12, 2, 128),
+                                              (1, 128, 128, 6, 3, 64)])
 def test_rfft2_irfft2_vs_torch(ops, B, h, w, E, nb, modes):
     bs = E // nb
     mx, my = min(modes, h), min(modes, w // 2 + 1)

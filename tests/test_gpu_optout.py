@@ -18,18 +18,17 @@ SMALL_SET = ("test_full_model_gradients_vs_oracle and (TINY-32 or SMALL-1) or "
              "test_bf16_channel_mlp_mode_vs_oracle and (MEDIUM-1 or TINY-32) or test_tiny_at_other_resolutions_vs_oracle")
 LARGE_SET = "test_large_batch16_vs_reference_golden"
 
-# switch -> (-k expression over test_gpu_sizes.py, also run test_gpu_model.py?)
+# switch group (set together in one child: they act on different kernels) -> (-k expression over test_gpu_sizes.py, also
+# run the golden-vector model tests of test_gpu_model.py?)
 SWITCHES = {
-    "DPOT_BF16P_DUO=0": (LARGE_SET + " or test_bf16_channel_mlp_mode_vs_oracle and MEDIUM-32", False),
-    "DPOT_BF16P_TILE192=0": (LARGE_SET, False),
-    "DPOT_BF16P_PAIR=0": (LARGE_SET + " or test_bf16_channel_mlp_mode_vs_oracle and MEDIUM-1", False),
-    "DPOT_AFNO_3MULT=0": (SMALL_SET, True),
-    "DPOT_AFNO_FUSED=0": (SMALL_SET, True),
-    "DPOT_GN_DFT=0": (SMALL_SET, True),
-    "DPOT_GN_ONLOAD=0": (SMALL_SET, False),
-    "DPOT_PANEL_GEMM=0": (SMALL_SET, True),
-    "DPOT_GEMM_TN=0": (SMALL_SET, True),
-    "DPOT_EMBED_IMPLICIT=0": (SMALL_SET, True),
+    # bf16 channel-MLP launch shapes: 12-wave kernel for every launch, 128 x 256 tiles only, un-paired weight gradients
+    "DPOT_BF16P_DUO=0 DPOT_BF16P_TILE192=0 DPOT_BF16P_PAIR=0":
+        (LARGE_SET + " or test_bf16_channel_mlp_mode_vs_oracle and (MEDIUM-32 or MEDIUM-1)", False),
+    "DPOT_AFNO_3MULT=0": (SMALL_SET, True),               # four-product fused mixer
+    "DPOT_AFNO_FUSED=0": (SMALL_SET, True),               # two generic GEMM launches per mixer
+    # separate GroupNorm / DFT kernels, GroupNorm never applied on load, generic GEMM instead of the panel / weight-
+    # gradient kernels, explicit patch matrix instead of the implicit-GEMM embedding
+    "DPOT_GN_DFT=0 DPOT_GN_ONLOAD=0 DPOT_PANEL_GEMM=0 DPOT_GEMM_TN=0 DPOT_EMBED_IMPLICIT=0": (SMALL_SET, True),
 }
 
 
@@ -37,8 +36,9 @@ SWITCHES = {
 def test_parity_subset_under_opt_out_switch(switch):
     expr, with_model = SWITCHES[switch]
     env = dict(os.environ)
-    k, v = switch.split("=")
-    env[k] = v
+    for kv in switch.split():
+        k, v = kv.split("=")
+        env[k] = v
     files = ["tests/test_gpu_sizes.py"] + (["tests/test_gpu_model.py"] if with_model else [])
     if with_model:
         expr = f"({expr}) or test_gpu_model"

@@ -187,6 +187,35 @@ def test_mlp_precision_is_a_per_model_attribute():
     assert ops.mlp_precision() is None
 
 
+def test_small_model_at_1024_resolution_vs_oracle():
+    """the largest resolution utils/griddataset.py:35 lists (1024^2 -> a 128 x 128 latent grid at patch 8): a small DPOT
+    (embed 64, depth 2) end to end against the CPU oracle - forward, dx, every parameter gradient; the mixer's DFTs run on
+    the 128-point register-FFT kernels (csrc/dft_fast.h, round 4), GroupNorm on the chunked kernels"""
+    from dpot_amd import DPOTNet
+    kw = dict(R.MINI, img_size=1024, embed_dim=64, in_timesteps=3)
+    cfg = R.DPOTConfig(**kw)
+    B, S = 1, cfg.img_size
+    sd0 = R.recipe_state_dict(cfg, salt=5)
+    x = R.recipe_input((B, S, S, cfg.in_timesteps, cfg.in_channels), salt=81)
+    up_y = R.recipe_input((B, S, S, cfg.out_timesteps, cfg.out_channels), salt=82) * 0.3
+    sd = OrderedDict((k, v.clone().requires_grad_(True)) for k, v in sd0.items())
+    xo = x.clone().requires_grad_(True)
+    yo, _ = R.dpot_forward(sd, xo, cfg)
+    (yo * up_y).sum().backward()
+    m = DPOTNet(**kw)
+    m.load_state_dict(sd0)
+    m.cuda()
+    xg = x.cuda().requires_grad_(True)
+    y, _ = m(xg)
+    (y * up_y.cuda()).sum().backward()
+    assert_close(y, yo.detach(), "1024^2 pred")
+    assert_close(xg.grad, xo.grad, "1024^2 dx")
+    for k, p in m.named_parameters():
+        if k.startswith("cls_head."):
+            continue
+        assert_close(p.grad, sd[k].grad, f"1024^2 d{k}")
+
+
 @pytest.fixture
 def bf16_mlp():
     from dpot_amd import ops
