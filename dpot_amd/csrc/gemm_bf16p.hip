@@ -724,9 +724,15 @@ constexpr int BD_P = 3;                     // slabs of look-ahead
 constexpr int BD_RING = BD_P + 1;           // A ring slots / W register sets
 constexpr int BD_ASLAB = 2 * PB_ROWT * 1024;   // bytes of A per 32-k slab (4 row tiles x 2 k-halves x 1 KiB)
 
-template <int COLT>
+// CPW = 32-column tiles per wave: 1 -> COLT waves of 128 x 32 (one workgroup per CU, <= 256 VGPRs); 2 -> COLT / 2 waves of
+// 128 x 64 = 4 x 2 accumulators (128 accumulator registers; FOUR waves at COLT = 8, so two workgroups share a CU at two
+// waves per SIMD): each A fragment read from LDS then feeds two MFMAs - 32 instead of 64 KiB of fragment reads per slab, the
+// LDS side drops from ~576 to ~320 cycles per slab against 512 of matrix-pipe time - and the workgroup that is in its
+// epilogue leaves the matrix pipes to its neighbour.
+template <int COLT, int CPW>
 __device__ __forceinline__ void gemm_bf16p_bd_body(const Bf16pArgs& p, const int bid0, const int zs) {
-  constexpr int NW = COLT;                                        // waves = 32-column tiles of the workgroup tile
+  static_assert(COLT % CPW == 0, "column tiles must divide among the waves");
+  constexpr int NW = COLT / CPW;                                  // waves of the workgroup
   constexpr int STAGEB = NW * 32 * EPI_LD * 4;                    // epilogue staging, one 32 x EPI_LD slab per wave
   constexpr int LDSB = BD_RING * BD_ASLAB > STAGEB ? BD_RING * BD_ASLAB : STAGEB;
   __shared__ __attribute__((aligned(16))) unsigned char lds[LDSB];
@@ -749,6 +755,10 @@ __device__ __forceinline__ void gemm_bf16p_bd_body(const Bf16pArgs& p, const int
   }
   const int rt0 = tm * PB_ROWT, ct0 = tn * COLT;
   const int mtiles = (p.M + 31) >> 5;
+  // phase skew experiment (DPOT_BF16P_BD_SKEW = units of ~3.4 us, DPOT_BF16P_BD_SKEWBIT = which workgroups wait): if the
+  // two workgroups of a CU run in lock step their epilogues coincide and the matrix pipes idle through both
+  if (p.super_c > 0 && ((bid0 >> p.super_r) & 1))
+    for (int i = 0; i < p.super_c; ++i) __builtin_amdgcn_s_sleep(127);
 
   // this wave's DMA piece of an A slab: piece b = wave (b < 8: row tile b >> 1, k-half b & 1); waves 8.. (none at COLT <= 8)
   // and, at COLT = 6, pieces 6 and 7 are taken by waves 0 and 1 as a second piece
@@ -766,15 +776,18 @@ __device__ __forceinline__ void gemm_bf16p_bd_body(const Bf16pArgs& p, const int
     asrc[n] = p.A + ((long long)rt * ks16 + 2 * slab0 + (bb & 1)) * 512 + lane * 8;
     adst[n] = bb * 1024;
   }
-  // this wave's W stream: column tile ct0 + wave, blocks 2 (slab0 + t) + ks
-  const unsigned short* wsrc = p.W + ((long long)(ct0 + wave) * ks16 + 2 * slab0) * 512 + lane * 8;
+  // this wave's W streams: column tiles ct0 + CPW wave + j, blocks 2 (slab0 + t) + ks
+  const unsigned short* wsrc = p.W + ((long long)(ct0 + CPW * wave) * ks16 + 2 * slab0) * 512 + lane * 8;
+  const long long wcol = (long long)ks16 * 512;                   // elements between neighbouring column tiles
 
-  f32x16 acc[PB_ROWT];
+  f32x16 acc[PB_ROWT][CPW];
 #pragma unroll
   for (int i = 0; i < PB_ROWT; ++i)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
-  bf16x8_t wreg[BD_RING][2];
+    for (int j = 0; j < CPW; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  bf16x8_t wreg[BD_RING][CPW][2];
 
   // memory operations of slab t (ring slot / register set s): per wave NPA DMA pieces (issued by every wave, a piece the wave
   // does not own re-loads piece 0: uniform count) + 2 W loads = NPA + 2 vmcnt events
@@ -789,11 +802,14 @@ __device__ __forceinline__ void gemm_bf16p_bd_body(const Bf16pArgs& p, const int
     t = t < last ? t : last;
 #pragma unroll
     for (int n = 0; n < NPA; ++n) bglds16(asrc[n] + (long long)t * 1024, lds + s * BD_ASLAB + adst[n]);
-    const bf16x8_t* wp = reinterpret_cast<const bf16x8_t*>(wsrc + (long long)t * 1024);
-    wreg[s][0] = wp[0];                                     // default cache policy: the other row tiles' workgroups on this
-    wreg[s][1] = wp[64];                                    // XCD read the same W slice out of L2
+#pragma unroll
+    for (int j = 0; j < CPW; ++j) {
+      const bf16x8_t* wp = reinterpret_cast<const bf16x8_t*>(wsrc + j * wcol + (long long)t * 1024);
+      wreg[s][j][0] = wp[0];                                // default cache policy: the other row tiles' workgroups on
+      wreg[s][j][1] = wp[64];                               // this XCD read the same W slice out of L2
+    }
   };
-  constexpr int NOP = NPA + 2;                              // vmcnt events per slab and wave
+  constexpr int NOP = NPA + 2 * CPW;                        // vmcnt events per slab and wave
   constexpr int VMW = NOP * (BD_P - 1);                     // outstanding operations allowed when slab g is needed
   // s_waitcnt vmcnt(VMW) lgkmcnt(0) as the BUILTIN (the compiler's own wait-count pass sees it): simm16 = vmcnt[3:0] |
   // expcnt 7 << 4 | lgkmcnt 0 << 8 | vmcnt[5:4] << 14
@@ -815,7 +831,9 @@ __device__ __forceinline__ void gemm_bf16p_bd_body(const Bf16pArgs& p, const int
     for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
       for (int i = 0; i < PB_ROWT; ++i)
-        acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][ks], wreg[s][ks], acc[i], 0, 0, 0);
+#pragma unroll
+        for (int j = 0; j < CPW; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][ks], wreg[s][j][ks], acc[i][j], 0, 0, 0);
   };
   using I0 = std::integral_constant<int, 0>;
   using I1 = std::integral_constant<int, 1>;
@@ -842,35 +860,47 @@ __device__ __forceinline__ void gemm_bf16p_bd_body(const Bf16pArgs& p, const int
   asm volatile("" ::: "memory");
 
   float* stage = reinterpret_cast<float*>(lds) + wave * (32 * EPI_LD);
-  const int m0 = rt0 * 32, n0 = (ct0 + wave) * 32;
+  const int m0 = rt0 * 32, n0 = (ct0 + CPW * wave) * 32;
   if (p.splits > 1) {
     float* ws = p.ws + (long long)zs * p.M * p.N;
     const int li = lane & 31, kh = lane >> 5;
-    const int n = n0 + li;
 #pragma unroll
     for (int i = 0; i < PB_ROWT; ++i)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int m = m0 + 32 * i + 4 * kh + (r & 3) + 8 * (r >> 2);
-        if (m < p.M && n < p.N) ws[(long long)m * p.N + n] = acc[i][r];
+      for (int j = 0; j < CPW; ++j) {
+        const int n = n0 + 32 * j + li;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int m = m0 + 32 * i + 4 * kh + (r & 3) + 8 * (r >> 2);
+          if (m < p.M && n < p.N) ws[(long long)m * p.N + n] = acc[i][j][r];
+        }
       }
     return;
   }
   const bool packs = p.out_rows || p.out_trans || p.cs_part || p.dact_out || p.dact_in;
   const bool direct = packs && !p.e.pre && !p.e.res && !(p.e.mode == DPOT_EPI_DACT && !p.dact_in);
+  // ONE copy of the fragment epilogue, looped over the wave's accumulators (moved into a common register set)
 #pragma unroll 1
-  for (int f = 0; f < PB_ROWT; ++f) {
-    if (m0 + 32 * f >= p.M) break;
-    const f32x16 af = f == 0 ? acc[0] : f == 1 ? acc[1] : f == 2 ? acc[2] : acc[3];
-    if (!packs) epi_fragment(p.e, 1, 0, m0 + 32 * f, n0, af, stage, lane);
-    else if (direct) epi_fragment_direct(p, m0 + 32 * f, n0, af, stage, lane);
-    else epi_fragment_pack(p, m0 + 32 * f, n0, af, stage, lane);
+  for (int f = 0; f < PB_ROWT * CPW; ++f) {
+    const int fi = f / CPW, fj = f - fi * CPW;
+    if (m0 + 32 * fi >= p.M) break;
+    f32x16 af;
+    if constexpr (CPW == 1) {
+      af = f == 0 ? acc[0][0] : f == 1 ? acc[1][0] : f == 2 ? acc[2][0] : acc[3][0];
+    } else {
+      af = f == 0 ? acc[0][0] : f == 1 ? acc[0][1] : f == 2 ? acc[1][0] : f == 3 ? acc[1][1] : f == 4 ? acc[2][0]
+         : f == 5 ? acc[2][1] : f == 6 ? acc[3][0] : acc[3][1];
+    }
+    if (!packs) epi_fragment(p.e, 1, 0, m0 + 32 * fi, n0 + 32 * fj, af, stage, lane);
+    else if (direct) epi_fragment_direct(p, m0 + 32 * fi, n0 + 32 * fj, af, stage, lane);
+    else epi_fragment_pack(p, m0 + 32 * fi, n0 + 32 * fj, af, stage, lane);
   }
 }
 
-template <int COLT>
-__global__ __launch_bounds__(64 * COLT, 2) void gemm_bf16p_bd_kernel(const Bf16pArgs p) {
-  gemm_bf16p_bd_body<COLT>(p, blockIdx.x, blockIdx.y);
+template <int COLT, int CPW>
+__global__ __launch_bounds__(64 * COLT / CPW, 2) void gemm_bf16p_bd_kernel(const Bf16pArgs p) {
+  static_assert(CPW <= 2, "the epilogue's accumulator select covers 4 x 2 fragments");
+  gemm_bf16p_bd_body<COLT, CPW>(p, blockIdx.x, blockIdx.y);
 }
 
 // two independent problems in ONE launch (the fc1 and fc2 weight gradients of a block: 128 tiles each at DPOT-M - alone
@@ -885,10 +915,10 @@ __global__ __launch_bounds__(64 * (COLT + PB_NLOAD)) void gemm_bf16p_pair_kernel
   gemm_bf16p_body<COLT>(pp.a[which], (int)blockIdx.x - which * pp.n0, blockIdx.y);   // blockIdx.y: common split-K index
 }
 
-template <int COLT>
-__global__ __launch_bounds__(64 * COLT, 2) void gemm_bf16p_bd_pair_kernel(const Bf16pPair pp) {
+template <int COLT, int CPW>
+__global__ __launch_bounds__(64 * COLT / CPW, 2) void gemm_bf16p_bd_pair_kernel(const Bf16pPair pp) {
   const int which = (int)blockIdx.x >= pp.n0 ? 1 : 0;
-  gemm_bf16p_bd_body<COLT>(pp.a[which], (int)blockIdx.x - which * pp.n0, blockIdx.y);
+  gemm_bf16p_bd_body<COLT, CPW>(pp.a[which], (int)blockIdx.x - which * pp.n0, blockIdx.y);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -1307,6 +1337,13 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
                                                             long long sCs, int csL);
 }
 
+// B-direct kernels: 32-column tiles per wave (DPOT_BF16P_BD_CPW: 1 = eight 128 x 32 waves, one workgroup per CU; 2 = four
+// 128 x 64 waves, two workgroups per CU)
+static int bd_cpw() {
+  static const int v = [] { const char* ev = getenv("DPOT_BF16P_BD_CPW"); return ev ? atoi(ev) : 1; }();
+  return v == 2 ? 2 : 1;
+}
+
 extern "C" int dpot_gemm_bf16p_splitk(int M, int N, int K) {
   // weight-gradient shapes: few output tiles, long K.  Aim at >= 256 workgroups, keep >= 16 slabs (512 k) per split
   const long long tiles = (long long)((M + 127) / 128) * (N / 256);
@@ -1411,13 +1448,21 @@ extern "C" int dpot_gemm_bf16p(const void* Apacked, const void* Wpacked, const f
   // B-direct form (DPOT_BF16P_BD: 0 = off, 1 = every plain-bf16 launch, 2 = only the launches the duo kernel does not take)
   static const int bd = [] { const char* ev = getenv("DPOT_BF16P_BD"); return ev ? atoi(ev) : 0; }();
   const bool use_bd = planes == 1 && p.super_r == 0 && (bd == 1 || (bd == 2 && !use_duo));
+  if (use_bd) {                                  // (super_r / super_c are free in this form: the skew experiment's knobs)
+    static const int skew = [] { const char* ev = getenv("DPOT_BF16P_BD_SKEW"); return ev ? atoi(ev) : 0; }();
+    static const int sbit = [] { const char* ev = getenv("DPOT_BF16P_BD_SKEWBIT"); return ev ? atoi(ev) : 8; }();
+    p.super_c = (long long)p.tilesM * p.tilesN >= 512 ? skew : 0;
+    p.super_r = sbit;
+  }
   if (planes == 3)
     hipLaunchKernelGGL(gemm_bf16x6p_kernel, dim3((unsigned)(p.tilesM * p.tilesN), p.splits), dim3(512), 0,
                        as_stream(stream), p);
   else if (use_bd && colt == 6)
-    hipLaunchKernelGGL(gemm_bf16p_bd_kernel<6>, dim3(grid, p.splits), dim3(64 * 6), 0, as_stream(stream), p);
+    hipLaunchKernelGGL((gemm_bf16p_bd_kernel<6, 1>), dim3(grid, p.splits), dim3(64 * 6), 0, as_stream(stream), p);
+  else if (use_bd && bd_cpw() == 2)
+    hipLaunchKernelGGL((gemm_bf16p_bd_kernel<PB_COLT, 2>), dim3(grid, p.splits), dim3(64 * 4), 0, as_stream(stream), p);
   else if (use_bd)
-    hipLaunchKernelGGL(gemm_bf16p_bd_kernel<PB_COLT>, dim3(grid, p.splits), dim3(64 * 8), 0, as_stream(stream), p);
+    hipLaunchKernelGGL((gemm_bf16p_bd_kernel<PB_COLT, 1>), dim3(grid, p.splits), dim3(64 * 8), 0, as_stream(stream), p);
   else if (use_duo)
     hipLaunchKernelGGL(gemm_bf16p_duo_kernel, dim3(grid), dim3(512), 0, as_stream(stream), p);
   else if (colt == 6)
@@ -1524,9 +1569,11 @@ extern "C" int dpot_gemm_bf16p_pair(const void* A0, const void* W0, float* C0, i
   const unsigned grid = (unsigned)(pp.n0 + pp.a[1].tilesM * pp.a[1].tilesN);
   static const int bd = [] { const char* ev = getenv("DPOT_BF16P_BD"); return ev ? atoi(ev) : 0; }();
   if (bd && colt == 6)
-    hipLaunchKernelGGL(gemm_bf16p_bd_pair_kernel<6>, dim3(grid, splits), dim3(64 * 6), 0, as_stream(stream), pp);
+    hipLaunchKernelGGL((gemm_bf16p_bd_pair_kernel<6, 1>), dim3(grid, splits), dim3(64 * 6), 0, as_stream(stream), pp);
+  else if (bd && bd_cpw() == 2)
+    hipLaunchKernelGGL((gemm_bf16p_bd_pair_kernel<PB_COLT, 2>), dim3(grid, splits), dim3(64 * 4), 0, as_stream(stream), pp);
   else if (bd)
-    hipLaunchKernelGGL(gemm_bf16p_bd_pair_kernel<PB_COLT>, dim3(grid, splits), dim3(64 * 8), 0, as_stream(stream), pp);
+    hipLaunchKernelGGL((gemm_bf16p_bd_pair_kernel<PB_COLT, 1>), dim3(grid, splits), dim3(64 * 8), 0, as_stream(stream), pp);
   else if (colt == 6)
     hipLaunchKernelGGL(gemm_bf16p_pair_kernel<6>, dim3(grid, splits), dim3(64 * (6 + PB_NLOAD)), 0, as_stream(stream), pp);
   else
