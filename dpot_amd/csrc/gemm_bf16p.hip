@@ -1339,9 +1339,14 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
 
 // B-direct kernels: 32-column tiles per wave (DPOT_BF16P_BD_CPW: 1 = eight 128 x 32 waves, one workgroup per CU; 2 = four
 // 128 x 64 waves, two workgroups per CU)
-static int bd_cpw() {
-  static const int v = [] { const char* ev = getenv("DPOT_BF16P_BD_CPW"); return ev ? atoi(ev) : 1; }();
-  return v == 2 ? 2 : 1;
+static int bd_cpw(long long tiles) {
+  // auto (0): two workgroups of four fat waves per CU once there are >= 2 tiles per CU (the second workgroup then exists);
+  // a single round of <= 256..511 tiles keeps eight waves per workgroup (four would be ONE wave per SIMD).  Measured
+  // (profiles/r04_bf16p_bd_cpw.txt): DPOT-L at batch 16, fc1 forward 408 -> 371 us, fc2 data gradient 378 -> 352; DPOT-M's
+  // 256-tile launches 74.8 -> 84.2 us the other way round
+  static const int v = [] { const char* ev = getenv("DPOT_BF16P_BD_CPW"); return ev ? atoi(ev) : 0; }();
+  if (v == 1 || v == 2) return v;
+  return tiles >= 512 ? 2 : 1;
 }
 
 extern "C" int dpot_gemm_bf16p_splitk(int M, int N, int K) {
@@ -1445,8 +1450,9 @@ extern "C" int dpot_gemm_bf16p(const void* Apacked, const void* Wpacked, const f
   static const int duo = [] { const char* ev = getenv("DPOT_BF16P_DUO"); return ev ? atoi(ev) : 1; }();
   const bool use_duo = planes == 1 && colt == PB_COLT && p.splits == 1 && p.super_r == 0 && (long long)p.tilesM * p.tilesN >= 512 &&
                        (duo == 1 || duo == 2 || (duo == 3 && packs));
-  // B-direct form (DPOT_BF16P_BD: 0 = off, 1 = every plain-bf16 launch, 2 = only the launches the duo kernel does not take)
-  static const int bd = [] { const char* ev = getenv("DPOT_BF16P_BD"); return ev ? atoi(ev) : 0; }();
+  // B-direct form (DPOT_BF16P_BD: 1 (default) = every plain-bf16 launch, 0 = off: the LDS-DMA kernels of rounds 2-3, 2 = only
+  // the launches the duo kernel does not take)
+  static const int bd = [] { const char* ev = getenv("DPOT_BF16P_BD"); return ev ? atoi(ev) : 1; }();
   const bool use_bd = planes == 1 && p.super_r == 0 && (bd == 1 || (bd == 2 && !use_duo));
   if (use_bd) {                                  // (super_r / super_c are free in this form: the skew experiment's knobs)
     static const int skew = [] { const char* ev = getenv("DPOT_BF16P_BD_SKEW"); return ev ? atoi(ev) : 0; }();
@@ -1459,7 +1465,7 @@ extern "C" int dpot_gemm_bf16p(const void* Apacked, const void* Wpacked, const f
                        as_stream(stream), p);
   else if (use_bd && colt == 6)
     hipLaunchKernelGGL((gemm_bf16p_bd_kernel<6, 1>), dim3(grid, p.splits), dim3(64 * 6), 0, as_stream(stream), p);
-  else if (use_bd && bd_cpw() == 2)
+  else if (use_bd && bd_cpw((long long)p.tilesM * p.tilesN * p.splits) == 2)
     hipLaunchKernelGGL((gemm_bf16p_bd_kernel<PB_COLT, 2>), dim3(grid, p.splits), dim3(64 * 4), 0, as_stream(stream), p);
   else if (use_bd)
     hipLaunchKernelGGL((gemm_bf16p_bd_kernel<PB_COLT, 1>), dim3(grid, p.splits), dim3(64 * 8), 0, as_stream(stream), p);
@@ -1567,10 +1573,10 @@ extern "C" int dpot_gemm_bf16p_pair(const void* A0, const void* W0, float* C0, i
   }
   pp.n0 = pp.a[0].tilesM * pp.a[0].tilesN;
   const unsigned grid = (unsigned)(pp.n0 + pp.a[1].tilesM * pp.a[1].tilesN);
-  static const int bd = [] { const char* ev = getenv("DPOT_BF16P_BD"); return ev ? atoi(ev) : 0; }();
+  static const int bd = [] { const char* ev = getenv("DPOT_BF16P_BD"); return ev ? atoi(ev) : 1; }();
   if (bd && colt == 6)
     hipLaunchKernelGGL((gemm_bf16p_bd_pair_kernel<6, 1>), dim3(grid, splits), dim3(64 * 6), 0, as_stream(stream), pp);
-  else if (bd && bd_cpw() == 2)
+  else if (bd && bd_cpw((long long)grid * splits) == 2)
     hipLaunchKernelGGL((gemm_bf16p_bd_pair_kernel<PB_COLT, 2>), dim3(grid, splits), dim3(64 * 4), 0, as_stream(stream), pp);
   else if (bd)
     hipLaunchKernelGGL((gemm_bf16p_bd_pair_kernel<PB_COLT, 1>), dim3(grid, splits), dim3(64 * 8), 0, as_stream(stream), pp);

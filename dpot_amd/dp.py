@@ -72,6 +72,7 @@ class BucketedGradReducer:
         # two notification sources: (a) the HIP stage backwards write gradients straight into the flat buffer and
         # call FlatParams.fire(i); (b) ordinary autograd accumulation (foreign graphs) -> post-accumulate hooks
         self._attached = True
+        self.dry_run = False                 # world 1 only: go through the motions of the bucket all-reduces (see _launch)
         self.skip_zero_tail = True
         flat.callbacks.append(self._on_ready)
         for i, p in enumerate(flat.params):
@@ -129,8 +130,18 @@ class BucketedGradReducer:
         return hook
 
     def _launch(self, k: int) -> None:
-        if self._launched[k] or self.world == 1:
+        if self._launched[k] or (self.world == 1 and not self.dry_run):
             self._launched[k] = True
+            return
+        if self.world == 1:
+            # dry run on one process (scripts/r04/dp_host_time.py): the stream choreography of a bucket all-reduce - side
+            # stream waits for the compute stream, one device operation over the bucket on the side stream - without a
+            # collective, to time the HOST side of the segmented step where no second GPU exists
+            self._launched[k] = True
+            lo, hi = self.ranges[k]
+            self.stream.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(self.stream):
+                self.fp.grad[lo:hi].mul_(1.0)
             return
         self._launched[k] = True
         lo, hi = self.ranges[k]

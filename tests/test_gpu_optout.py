@@ -21,8 +21,14 @@ LARGE_SET = "test_large_batch16_vs_reference_golden"
 # switch group (set together in one child: they act on different kernels) -> (-k expression over test_gpu_sizes.py, also
 # run the golden-vector model tests of test_gpu_model.py?)
 SWITCHES = {
-    # bf16 channel-MLP launch shapes: 12-wave kernel for every launch, 128 x 256 tiles only, un-paired weight gradients
-    "DPOT_BF16P_DUO=0 DPOT_BF16P_TILE192=0 DPOT_BF16P_PAIR=0":
+    # bf16 channel-MLP kernels.  Default since round 4: the B-direct kernels (W fragments straight into registers).
+    # BD=0: the LDS-DMA kernels of rounds 2-3 in their own default selection (two-workgroup kernel, 128 x 192 tiles, pairs)
+    "DPOT_BF16P_BD=0": (LARGE_SET + " or test_bf16_channel_mlp_mode_vs_oracle and MEDIUM-32", False),
+    # ... and with the 12-wave kernel for every launch, 128 x 256 tiles only, un-paired weight gradients
+    "DPOT_BF16P_BD=0 DPOT_BF16P_DUO=0 DPOT_BF16P_TILE192=0 DPOT_BF16P_PAIR=0":
+        (LARGE_SET + " or test_bf16_channel_mlp_mode_vs_oracle and MEDIUM-1", False),
+    # B-direct with eight 128 x 32 waves everywhere (no two-workgroup form), 128 x 256 tiles only, un-paired weight gradients
+    "DPOT_BF16P_BD_CPW=1 DPOT_BF16P_TILE192=0 DPOT_BF16P_PAIR=0":
         (LARGE_SET + " or test_bf16_channel_mlp_mode_vs_oracle and (MEDIUM-32 or MEDIUM-1)", False),
     "DPOT_AFNO_3MULT=0": (SMALL_SET, True),               # four-product fused mixer
     "DPOT_AFNO_FUSED=0": (SMALL_SET, True),               # two generic GEMM launches per mixer
