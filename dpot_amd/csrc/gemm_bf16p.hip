@@ -720,17 +720,26 @@ __global__ __launch_bounds__(512, 4) void gemm_bf16p_duo_kernel(const Bf16pArgs 
 //     must be a compile-time constant).
 // Same tiles (128 x 256 / 128 x 192), tile order, split-K and epilogues as gemm_bf16p_body.
 // ---------------------------------------------------------------------------------------------------------------------
-constexpr int BD_P = 3;                     // slabs of look-ahead
-constexpr int BD_RING = BD_P + 1;           // A ring slots / W register sets
 constexpr int BD_ASLAB = 2 * PB_ROWT * 1024;   // bytes of A per 32-k slab (4 row tiles x 2 k-halves x 1 KiB)
+template <int B, int E, class F>
+__device__ __forceinline__ void bd_sfor(F&& f) {   // static for: f(integral_constant<int, i>) for i in [B, E)
+  if constexpr (B < E) {
+    f(std::integral_constant<int, B>{});
+    bd_sfor<B + 1, E>(f);
+  }
+}
 
 // CPW = 32-column tiles per wave: 1 -> COLT waves of 128 x 32 (one workgroup per CU, <= 256 VGPRs); 2 -> COLT / 2 waves of
 // 128 x 64 = 4 x 2 accumulators (128 accumulator registers; FOUR waves at COLT = 8, so two workgroups share a CU at two
 // waves per SIMD): each A fragment read from LDS then feeds two MFMAs - 32 instead of 64 KiB of fragment reads per slab, the
 // LDS side drops from ~576 to ~320 cycles per slab against 512 of matrix-pipe time - and the workgroup that is in its
 // epilogue leaves the matrix pipes to its neighbour.
-template <int COLT, int CPW>
+// BD_P = slabs of look-ahead (the loop is latency bound: period = load latency / look-ahead while that exceeds the 512
+// cycles of matrix-pipe time per slab), BD_RING = BD_P + 1 A slots in LDS / W register sets; the slab loop is unrolled by
+// the ring depth so that slots and register sets are compile-time constants.
+template <int COLT, int CPW, int BD_P>
 __device__ __forceinline__ void gemm_bf16p_bd_body(const Bf16pArgs& p, const int bid0, const int zs) {
+  constexpr int BD_RING = BD_P + 1;
   static_assert(COLT % CPW == 0, "column tiles must divide among the waves");
   constexpr int NW = COLT / CPW;                                  // waves of the workgroup
   constexpr int STAGEB = NW * 32 * EPI_LD * 4;                    // epilogue staging, one 32 x EPI_LD slab per wave
@@ -755,11 +764,9 @@ __device__ __forceinline__ void gemm_bf16p_bd_body(const Bf16pArgs& p, const int
   }
   const int rt0 = tm * PB_ROWT, ct0 = tn * COLT;
   const int mtiles = (p.M + 31) >> 5;
-  // phase skew experiment (DPOT_BF16P_BD_SKEW = units of ~3.4 us, DPOT_BF16P_BD_SKEWBIT = which workgroups wait): if the
-  // two workgroups of a CU run in lock step their epilogues coincide and the matrix pipes idle through both
-  if (p.super_c > 0 && ((bid0 >> p.super_r) & 1))
-    for (int i = 0; i < p.super_c; ++i) __builtin_amdgcn_s_sleep(127);
-
+  // (A deliberate phase skew between the two workgroups of a CU - every second workgroup sleeping 7-14 us before its first
+  // slab, three choices of "second" - was measured on the theory that their epilogues coincide: slower by about the sleep in
+  // every case, profiles/r04_bf16p_bd_skew_rejected.txt.  The epilogues do not overlap the neighbour's main loop either way.)
   // this wave's DMA piece of an A slab: piece b = wave (b < 8: row tile b >> 1, k-half b & 1); waves 8.. (none at COLT <= 8)
   // and, at COLT = 6, pieces 6 and 7 are taken by waves 0 and 1 as a second piece
   constexpr int NPA = (2 * PB_ROWT + NW - 1) / NW;                // A pieces per wave and slab (1 at 8 waves, 2 at 6)
@@ -835,25 +842,18 @@ __device__ __forceinline__ void gemm_bf16p_bd_body(const Bf16pArgs& p, const int
         for (int j = 0; j < CPW; ++j)
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][ks], wreg[s][j][ks], acc[i][j], 0, 0, 0);
   };
-  using I0 = std::integral_constant<int, 0>;
-  using I1 = std::integral_constant<int, 1>;
-  using I2 = std::integral_constant<int, 2>;
-  using I3 = std::integral_constant<int, 3>;
-  static_assert(BD_RING == 4 && BD_P == 3, "the slab loop is unrolled by the ring depth");
-  issue(0, I0{});
-  issue(1, I1{});
-  issue(2, I2{});
+  bd_sfor<0, BD_P>([&](auto S) __attribute__((always_inline)) { issue(decltype(S)::value, S); });
   int g = 0;
 #pragma unroll 1
-  for (; g + 4 <= nslab; g += 4) {
-    slab(g, I0{}, I3{});
-    slab(g + 1, I1{}, I0{});
-    slab(g + 2, I2{}, I1{});
-    slab(g + 3, I3{}, I2{});
-  }
-  if (g < nslab) slab(g, I0{}, I3{});
-  if (g + 1 < nslab) slab(g + 1, I1{}, I0{});
-  if (g + 2 < nslab) slab(g + 2, I2{}, I1{});
+  for (; g + BD_RING <= nslab; g += BD_RING)
+    bd_sfor<0, BD_RING>([&](auto S) __attribute__((always_inline)) {
+      constexpr int sv = decltype(S)::value;
+      slab(g + sv, S, std::integral_constant<int, (sv + BD_RING - 1) % BD_RING>{});
+    });
+  bd_sfor<0, BD_RING - 1>([&](auto S) __attribute__((always_inline)) {     // tail: g is a multiple of the ring depth
+    constexpr int sv = decltype(S)::value;
+    if (g + sv < nslab) slab(g + sv, S, std::integral_constant<int, (sv + BD_RING - 1) % BD_RING>{});
+  });
   asm volatile("" ::: "memory");
   __builtin_amdgcn_s_waitcnt(0x0070);                       // vmcnt(0) lgkmcnt(0): the trailing re-loads have landed too
   __builtin_amdgcn_s_barrier();                             // S: every wave has read the last slab; the ring becomes staging
@@ -897,10 +897,10 @@ __device__ __forceinline__ void gemm_bf16p_bd_body(const Bf16pArgs& p, const int
   }
 }
 
-template <int COLT, int CPW>
+template <int COLT, int CPW, int P>
 __global__ __launch_bounds__(64 * COLT / CPW, 2) void gemm_bf16p_bd_kernel(const Bf16pArgs p) {
   static_assert(CPW <= 2, "the epilogue's accumulator select covers 4 x 2 fragments");
-  gemm_bf16p_bd_body<COLT, CPW>(p, blockIdx.x, blockIdx.y);
+  gemm_bf16p_bd_body<COLT, CPW, P>(p, blockIdx.x, blockIdx.y);
 }
 
 // two independent problems in ONE launch (the fc1 and fc2 weight gradients of a block: 128 tiles each at DPOT-M - alone
@@ -915,10 +915,10 @@ __global__ __launch_bounds__(64 * (COLT + PB_NLOAD)) void gemm_bf16p_pair_kernel
   gemm_bf16p_body<COLT>(pp.a[which], (int)blockIdx.x - which * pp.n0, blockIdx.y);   // blockIdx.y: common split-K index
 }
 
-template <int COLT, int CPW>
+template <int COLT, int CPW, int P>
 __global__ __launch_bounds__(64 * COLT / CPW, 2) void gemm_bf16p_bd_pair_kernel(const Bf16pPair pp) {
   const int which = (int)blockIdx.x >= pp.n0 ? 1 : 0;
-  gemm_bf16p_bd_body<COLT, CPW>(pp.a[which], (int)blockIdx.x - which * pp.n0, blockIdx.y);
+  gemm_bf16p_bd_body<COLT, CPW, P>(pp.a[which], (int)blockIdx.x - which * pp.n0, blockIdx.y);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -1349,6 +1349,14 @@ static int bd_cpw(long long tiles) {
   return tiles >= 512 ? 2 : 1;
 }
 
+// slabs of look-ahead of the B-direct kernels (DPOT_BF16P_BD_P; instantiated: 3 / 5 / 7 at one column tile per wave, 3 / 4
+// at two - the W register ring is 8 resp. 16 VGPRs per slab)
+static int bd_lookahead(int cpw) {
+  static const int v = [] { const char* ev = getenv("DPOT_BF16P_BD_P"); return ev ? atoi(ev) : 0; }();
+  if (v > 0) return v;
+  return cpw == 2 ? 3 : 3;
+}
+
 extern "C" int dpot_gemm_bf16p_splitk(int M, int N, int K) {
   // weight-gradient shapes: few output tiles, long K.  Aim at >= 256 workgroups, keep >= 16 slabs (512 k) per split
   const long long tiles = (long long)((M + 127) / 128) * (N / 256);
@@ -1450,25 +1458,27 @@ extern "C" int dpot_gemm_bf16p(const void* Apacked, const void* Wpacked, const f
   static const int duo = [] { const char* ev = getenv("DPOT_BF16P_DUO"); return ev ? atoi(ev) : 1; }();
   const bool use_duo = planes == 1 && colt == PB_COLT && p.splits == 1 && p.super_r == 0 && (long long)p.tilesM * p.tilesN >= 512 &&
                        (duo == 1 || duo == 2 || (duo == 3 && packs));
-  // B-direct form (DPOT_BF16P_BD: 1 (default) = every plain-bf16 launch, 0 = off: the LDS-DMA kernels of rounds 2-3, 2 = only
-  // the launches the duo kernel does not take)
+  // B-direct form (DPOT_BF16P_BD: 1 (default) = by the shape rule below, 3 = every plain-bf16 launch, 0 = off: the LDS-DMA
+  // kernels of rounds 2-3, 2 = only the launches the duo kernel does not take)
   static const int bd = [] { const char* ev = getenv("DPOT_BF16P_BD"); return ev ? atoi(ev) : 1; }();
-  const bool use_bd = planes == 1 && p.super_r == 0 && (bd == 1 || (bd == 2 && !use_duo));
-  if (use_bd) {                                  // (super_r / super_c are free in this form: the skew experiment's knobs)
-    static const int skew = [] { const char* ev = getenv("DPOT_BF16P_BD_SKEW"); return ev ? atoi(ev) : 0; }();
-    static const int sbit = [] { const char* ev = getenv("DPOT_BF16P_BD_SKEWBIT"); return ev ? atoi(ev) : 8; }();
-    p.super_c = (long long)p.tilesM * p.tilesN >= 512 ? skew : 0;
-    p.super_r = sbit;
-  }
+  // shape rule (bd == 1): launches with several rounds of tiles or a long contraction; a single round of tiles with K < 2048
+  // (DPOT-S: 8192 x 1024 x 1024, 256 tiles, 32 slabs) keeps the LDS-DMA kernels, whose dedicated loader waves start the
+  // pipeline sooner - DPOT-S 5.73 -> 5.94 ms with B-direct everywhere, DPOT-M 14.97 -> 14.24, DPOT-L 102.9 -> 96.2
+  // (profiles/r04_bf16p_bd_step_ab_one_box.txt); bd == 3: every plain-bf16 launch
+  const bool bd_shape = (long long)p.tilesM * p.tilesN * p.splits >= 512 || p.slabs_per_split >= 64;
+  const bool use_bd = planes == 1 && p.super_r == 0 && ((bd == 1 && bd_shape) || bd == 3 || (bd == 2 && !use_duo));
   if (planes == 3)
     hipLaunchKernelGGL(gemm_bf16x6p_kernel, dim3((unsigned)(p.tilesM * p.tilesN), p.splits), dim3(512), 0,
                        as_stream(stream), p);
-  else if (use_bd && colt == 6)
-    hipLaunchKernelGGL((gemm_bf16p_bd_kernel<6, 1>), dim3(grid, p.splits), dim3(64 * 6), 0, as_stream(stream), p);
-  else if (use_bd && bd_cpw((long long)p.tilesM * p.tilesN * p.splits) == 2)
-    hipLaunchKernelGGL((gemm_bf16p_bd_kernel<PB_COLT, 2>), dim3(grid, p.splits), dim3(64 * 4), 0, as_stream(stream), p);
-  else if (use_bd)
-    hipLaunchKernelGGL((gemm_bf16p_bd_kernel<PB_COLT, 1>), dim3(grid, p.splits), dim3(64 * 8), 0, as_stream(stream), p);
+  else if (use_bd) {
+    const int cpw = colt == 6 ? 1 : bd_cpw((long long)p.tilesM * p.tilesN * p.splits);
+    const int la = bd_lookahead(cpw);
+#define BD_LAUNCH(CT, CW, LA) hipLaunchKernelGGL((gemm_bf16p_bd_kernel<CT, CW, LA>), dim3(grid, p.splits), dim3(64 * CT / CW), 0, as_stream(stream), p)
+    if (colt == 6) { if (la >= 7) BD_LAUNCH(6, 1, 7); else if (la >= 5) BD_LAUNCH(6, 1, 5); else BD_LAUNCH(6, 1, 3); }
+    else if (cpw == 2) { if (la >= 4) BD_LAUNCH(8, 2, 4); else BD_LAUNCH(8, 2, 3); }
+    else { if (la >= 7) BD_LAUNCH(8, 1, 7); else if (la >= 5) BD_LAUNCH(8, 1, 5); else BD_LAUNCH(8, 1, 3); }
+#undef BD_LAUNCH
+  }
   else if (use_duo)
     hipLaunchKernelGGL(gemm_bf16p_duo_kernel, dim3(grid), dim3(512), 0, as_stream(stream), p);
   else if (colt == 6)
@@ -1574,12 +1584,16 @@ extern "C" int dpot_gemm_bf16p_pair(const void* A0, const void* W0, float* C0, i
   pp.n0 = pp.a[0].tilesM * pp.a[0].tilesN;
   const unsigned grid = (unsigned)(pp.n0 + pp.a[1].tilesM * pp.a[1].tilesN);
   static const int bd = [] { const char* ev = getenv("DPOT_BF16P_BD"); return ev ? atoi(ev) : 1; }();
-  if (bd && colt == 6)
-    hipLaunchKernelGGL((gemm_bf16p_bd_pair_kernel<6, 1>), dim3(grid, splits), dim3(64 * 6), 0, as_stream(stream), pp);
-  else if (bd && bd_cpw((long long)grid * splits) == 2)
-    hipLaunchKernelGGL((gemm_bf16p_bd_pair_kernel<PB_COLT, 2>), dim3(grid, splits), dim3(64 * 4), 0, as_stream(stream), pp);
-  else if (bd)
-    hipLaunchKernelGGL((gemm_bf16p_bd_pair_kernel<PB_COLT, 1>), dim3(grid, splits), dim3(64 * 8), 0, as_stream(stream), pp);
+  const bool use_bd = bd == 3 || (bd && ((long long)grid * splits >= 512 || sps >= 128));
+  if (use_bd) {
+    const int cpw = colt == 6 ? 1 : bd_cpw((long long)grid * splits);
+    const int la = bd_lookahead(cpw);
+#define BD_LAUNCH(CT, CW, LA) hipLaunchKernelGGL((gemm_bf16p_bd_pair_kernel<CT, CW, LA>), dim3(grid, splits), dim3(64 * CT / CW), 0, as_stream(stream), pp)
+    if (colt == 6) { if (la >= 7) BD_LAUNCH(6, 1, 7); else if (la >= 5) BD_LAUNCH(6, 1, 5); else BD_LAUNCH(6, 1, 3); }
+    else if (cpw == 2) { if (la >= 4) BD_LAUNCH(8, 2, 4); else BD_LAUNCH(8, 2, 3); }
+    else { if (la >= 7) BD_LAUNCH(8, 1, 7); else if (la >= 5) BD_LAUNCH(8, 1, 5); else BD_LAUNCH(8, 1, 3); }
+#undef BD_LAUNCH
+  }
   else if (colt == 6)
     hipLaunchKernelGGL(gemm_bf16p_pair_kernel<6>, dim3(grid, splits), dim3(64 * (6 + PB_NLOAD)), 0, as_stream(stream), pp);
   else

@@ -237,29 +237,9 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
     const float denom = sqrtf(vv) / sb2 + eps;
     pv = pv - step * (mv / denom);
   };
-  // 16 bytes per lane and array (the flat buffers are 16-byte aligned, every tensor starts on a 4-float boundary): a wave
-  // moves 1 KiB per instruction, seven streams (4 reads + 3 writes) - round 3's one-float-per-lane form ran at 4.5 of
-  // the ~6.3 TB/s the HBM sustains
-  const bool vec = ((reinterpret_cast<uintptr_t>(p) | reinterpret_cast<uintptr_t>(g) | reinterpret_cast<uintptr_t>(m) |
-                     reinterpret_cast<uintptr_t>(v)) & 15u) == 0;
-  const long long n4 = vec ? n >> 2 : 0;
-  float4* p4 = reinterpret_cast<float4*>(p);
-  const float4* g4 = reinterpret_cast<const float4*>(g);
-  float4* m4 = reinterpret_cast<float4*>(m);
-  float4* v4 = reinterpret_cast<float4*>(v);
-  for (long long i = blockIdx.x * 256ll + threadIdx.x; i < n4; i += (long long)gridDim.x * 256) {
-    float4 pq = p4[i];
-    const float4 gq = g4[i];
-    float4 mq = m4[i], vq = v4[i];
-    upd(pq.x, gq.x, mq.x, vq.x);
-    upd(pq.y, gq.y, mq.y, vq.y);
-    upd(pq.z, gq.z, mq.z, vq.z);
-    upd(pq.w, gq.w, mq.w, vq.w);
-    m4[i] = mq;
-    v4[i] = vq;
-    p4[i] = pq;
-  }
-  for (long long i = 4 * n4 + blockIdx.x * 256ll + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+  // one float per lane and array.  (Round 4 tried 16 bytes per lane and stream - seven 1 KiB-per-wave streams: DPOT-M's
+  // 110 M parameters 689 -> 778 us, DPOT-Tiny unchanged at 34 us = 6.2 TB/s; profiles/r04_step_census_M_bf16_bd_first.txt)
+  for (long long i = blockIdx.x * 256ll + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
     float pv = p[i], mv = m[i], vv = v[i];
     upd(pv, g[i], mv, vv);
     m[i] = mv;
@@ -592,7 +572,7 @@ extern "C" int dpot_sumsq(const float* g, int64_t n, float* out, float* part, in
 extern "C" int dpot_adam_step(float* p, const float* g, float* m, float* v, int64_t n, const float* hyper,
                               const float* sumsq, float grad_scale, dpot_stream_t stream) {
   DPOT_REQUIRE(p && g && m && v && hyper && n > 0, "adam_step: bad argument");
-  hipLaunchKernelGGL(adam_kernel, dim3(grid_for((n + 3) / 4, 8192)), dim3(256), 0, as_stream(stream), p, g, m, v, (long long)n,
+  hipLaunchKernelGGL(adam_kernel, dim3(grid_for(n, 8192)), dim3(256), 0, as_stream(stream), p, g, m, v, (long long)n,
                      hyper, sumsq, grad_scale);
   return check_launch("adam_kernel");
 }
