@@ -197,7 +197,9 @@ def mixer_roofline(model, B: int):
     # gfx950 correction follow MI355X_MICROARCH.md section HBM: bytes = (2 * FETCH_SIZE + WRITE_SIZE) * 1024
     traffic = None
     try:
-        pmc = json.load(open(os.path.join(ROOT, "profiles", "r03_pmc_mixer.json")))
+        pdir = os.path.join(ROOT, "profiles")
+        pmc_file = "r04_pmc_mixer.json" if os.path.exists(os.path.join(pdir, "r04_pmc_mixer.json")) else "r03_pmc_mixer.json"
+        pmc = json.load(open(os.path.join(pdir, pmc_file)))
         traffic = (2.0 * pmc["FETCH_SIZE"]["mean"] + pmc["WRITE_SIZE"]["mean"]) * 1024.0
     except Exception:
         pass
@@ -214,7 +216,7 @@ def mixer_roofline(model, B: int):
                        "complex multiplication), i.e. its matrix pipes run at 0.75 x achieved") if three else None,
         "bound": "mfma", "achieved": round(achieved, 2), "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
         "frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": traffic,
-        "traffic_note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, profiles/r03_pmc_mixer.json), "
+        "traffic_note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, profiles/r04_pmc_mixer.json), "
                         "(2*FETCH+WRITE)*1024 B; the training form of the launch also stores the pre-activation (saved for "
                         "the backward): 2 spectrum-sized writes instead of the 1 that algorithmic_bytes counts (round 2 also "
                         "stored the activated spectrum: 3 writes, 80.7 MB)",
@@ -251,30 +253,38 @@ def bf16_mlp_roofline(model, B: int):
                                                     pack_rows=True, pack_trans=True, store=False), reps=20)
     fl = 2.0 * M * mh * E
     by = 2.0 * M * E + 2.0 * mh * E + 3 * 2.0 * M * mh            # packed A + packed W read once, three bf16 packs written
-    traffic, tnote = None, "no PMC profile for this shape (profiles/r03_pmc_bf16p_M.json holds DPOT-M, batch 32)"
+    traffic, tnote, util = None, "no PMC profile for this shape (profiles/r04_pmc_bf16p_M.json holds DPOT-M, batch 32)", None
     try:
-        pmc = json.load(open(os.path.join(ROOT, "profiles", "r03_pmc_bf16p_M.json")))["forms"]["fc1_fwd"]
+        pmc = json.load(open(os.path.join(ROOT, "profiles", "r04_pmc_bf16p_M.json")))["forms"]["fc1_fwd"]
         if (M, E, mh) == (8192, 1024, 4096):
             traffic = float(pmc["bytes_guide"])
-            tnote = ("rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes (profiles/r03_pmc_bf16p_M.json): (2*FETCH + "
-                     "WRITE)*1024 B; un-doubled %.0f MB. Reads: every XCD's L2 pulls the whole A pack once (8 x 16.8 MB, from "
-                     "the Infinity Cache) + its weight chunks; writes 234 MB for 201 MB of packs" % (pmc["bytes_raw"] / 1e6))
+            util = pmc.get("mfma_util")
+            tnote = ("rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes (profiles/r04_pmc_bf16p_M.json): (2*FETCH + "
+                     "WRITE)*1024 B; un-doubled %.0f MB; algorithmic = A pack + W pack read once + three bf16 packs written"
+                     % (pmc["bytes_raw"] / 1e6))
     except Exception:
         pass
     tiles = ((M + 127) // 128) * (mh // 256)
-    duo = tiles >= 512 and os.environ.get("DPOT_BF16P_DUO", "1") != "0"
-    kname = "dpot::gemm_bf16p_duo_kernel (two 8-wave workgroups per CU)" if duo else "dpot::gemm_bf16p_kernel (8 compute + 4 loader waves)"
+    bd = os.environ.get("DPOT_BF16P_BD", "1") != "0" and (tiles >= 512 or E >= 2048)
+    if bd:
+        kname = ("dpot::gemm_bf16p_bd_kernel<8,2,3> (B-direct: W fragments straight from global memory into registers, only "
+                 "the A panel through LDS; four 128 x 64 waves, two workgroups per CU)" if tiles >= 512 else
+                 "dpot::gemm_bf16p_bd_kernel<8,1,3> (B-direct, eight 128 x 32 waves)")
+    else:
+        duo = tiles >= 512 and os.environ.get("DPOT_BF16P_DUO", "1") != "0"
+        kname = ("dpot::gemm_bf16p_duo_kernel (two 8-wave workgroups per CU)" if duo else
+                 "dpot::gemm_bf16p_kernel (8 compute + 4 loader waves, LDS-DMA)")
     return {"kernel": kname + " - channel-MLP fc1 forward: bf16 operands pre-packed fragment-block-major, "
                       "v_mfma_f32_32x32x16_bf16, epilogue in the accumulator layout writes the activated hidden layer as row + "
                       "transposed bf16 packs and act' as a bf16 pack",
             "shape": [M, mh, E], "bound": "mfma", "achieved": round(fl / t / 1e12, 1), "peak": 2500.0, "unit": "TFLOP/s",
             "frac": round(fl / t / 1e12 / 2500.0, 4), "us_per_launch": round(t * 1e6, 2), "flops_per_launch": fl,
             "algorithmic_bytes_per_launch": by, "hbm_frac": round(by / t / 1e9 / HBM_PEAK_GBS, 4), "traffic": traffic,
-            "traffic_note": tnote,
+            "traffic_note": tnote, "mfma_util_pmc": util,
             "note": "2.5 PFLOP/s = dense bf16 MFMA peak (MI355X_MICROARCH.md); a register-only MFMA loop sustains 1.4-1.8 "
-                    "PFLOP/s on random operands on this part (profiles/r02_mfma_bf16_peak.txt).  At DPOT-M the main loop of this "
-                    "launch takes 65-72 us (operand path: ~845 cycles per 24 KiB slab and CU), the epilogue ~50 (201 MB of pack "
-                    "stores 31, GELU + derivative 14): DESIGN.md section 3, profiles/r03_bf16p_duo.txt"}
+                    "PFLOP/s on random operands on this part (profiles/r02_mfma_bf16_peak.txt).  This launch is the one with the "
+                    "fattest epilogue (GELU + derivative on 33.5 M values, 201 MB of packs at DPOT-M); the same product with a plain "
+                    "fp32 output runs at 0.9-1.1 PFLOP/s (profiles/r04_bf16p_train_bench.txt)"}
 
 
 def timeit_graph(fn, reps: int = 30):

@@ -897,19 +897,14 @@ __device__ __forceinline__ void gemm_bf16p_bd_body(const Bf16pArgs& p, const int
   }
 }
 
-// PERSISTENT over the tiles (grid.x = min(tiles, resident workgroup slots)): a workgroup that has issued the stores of its
-// epilogue goes straight on to the loads of its next tile.  A workgroup that ENDS instead keeps its slot until every store
-// has been acknowledged, and the next workgroup's main loop - whose operands come out of L2 / Infinity Cache and leave the
-// HBM write path idle - cannot start under the drain of 100 - 200 KB of packs per tile (the launches with packed outputs
-// write 134 - 201 MB at DPOT-M: +26 / +42 us over the same product with an fp32 output).
+// (A PERSISTENT form - grid.x = the resident workgroup slots, every workgroup looping over its tiles, on the theory that a
+// workgroup which ENDS holds its slot until its pack stores are acknowledged while a persistent one starts the next tile's
+// loads under that drain - was built and measured in round 4: no effect on any launch or step, DPOT-M 14.05 / 14.08 ms,
+// DPOT-L 95.5 / 95.6 ms, profiles/r04_bf16p_bd_persistent_rejected.txt; it cost 30 VGPRs and was removed.)
 template <int COLT, int CPW, int P>
 __global__ __launch_bounds__(64 * COLT / CPW, 2) void gemm_bf16p_bd_kernel(const Bf16pArgs p) {
   static_assert(CPW <= 2, "the epilogue's accumulator select covers 4 x 2 fragments");
-  const int ntiles = p.tilesM * p.tilesN;
-  for (int v = blockIdx.x; v < ntiles; v += gridDim.x) {
-    gemm_bf16p_bd_body<COLT, CPW, P>(p, v, blockIdx.y);
-    __syncthreads();                       // the staging reads of this tile's epilogue precede the next tile's first DMA
-  }
+  gemm_bf16p_bd_body<COLT, CPW, P>(p, blockIdx.x, blockIdx.y);
 }
 
 // two independent problems in ONE launch (the fc1 and fc2 weight gradients of a block: 128 tiles each at DPOT-M - alone
@@ -926,12 +921,8 @@ __global__ __launch_bounds__(64 * (COLT + PB_NLOAD)) void gemm_bf16p_pair_kernel
 
 template <int COLT, int CPW, int P>
 __global__ __launch_bounds__(64 * COLT / CPW, 2) void gemm_bf16p_bd_pair_kernel(const Bf16pPair pp) {
-  const int ntiles = pp.n0 + pp.a[1].tilesM * pp.a[1].tilesN;
-  for (int v = blockIdx.x; v < ntiles; v += gridDim.x) {
-    const int which = v >= pp.n0 ? 1 : 0;
-    gemm_bf16p_bd_body<COLT, CPW, P>(pp.a[which], v - which * pp.n0, blockIdx.y);
-    __syncthreads();
-  }
+  const int which = (int)blockIdx.x >= pp.n0 ? 1 : 0;
+  gemm_bf16p_bd_body<COLT, CPW, P>(pp.a[which], (int)blockIdx.x - which * pp.n0, blockIdx.y);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -1362,15 +1353,6 @@ static int bd_cpw(long long tiles) {
   return tiles >= 512 ? 2 : 1;
 }
 
-// grid.x of a B-direct launch: persistent workgroups, one per resident slot (256 CUs x 1 or 2 workgroups), when the tiles
-// need more than one round (DPOT_BF16P_BD_PERSIST=0: one workgroup per tile)
-static unsigned bd_grid(unsigned tiles, int splits, int cpw) {
-  static const int persist = [] { const char* ev = getenv("DPOT_BF16P_BD_PERSIST"); return ev ? atoi(ev) : 1; }();
-  const long long slots = 256ll * (cpw == 2 ? 2 : 1) / (splits > 1 ? splits : 1);
-  if (!persist || slots < 8 || tiles <= (unsigned)slots) return tiles;
-  return (unsigned)(slots / 8 * 8);          // a multiple of 8: a workgroup's tiles stay on its XCD's slice of the tile order
-}
-
 // slabs of look-ahead of the B-direct kernels: 3.  (4 / 5 / 7 were built and measured on the theory that the loop is bound
 // by load latency / look-ahead: no effect on any DPOT-S / -M / -L shape, profiles/r04_bf16p_bd_lookahead.txt.)
 static int bd_lookahead(int) { return 3; }
@@ -1491,7 +1473,6 @@ extern "C" int dpot_gemm_bf16p(const void* Apacked, const void* Wpacked, const f
   else if (use_bd) {
     const int cpw = colt == 6 ? 1 : bd_cpw((long long)p.tilesM * p.tilesN * p.splits);
     const int la = bd_lookahead(cpw);
-    grid = bd_grid(grid, p.splits, cpw);
 #define BD_LAUNCH(CT, CW, LA) hipLaunchKernelGGL((gemm_bf16p_bd_kernel<CT, CW, LA>), dim3(grid, p.splits), dim3(64 * CT / CW), 0, as_stream(stream), p)
     (void)la;
     if (colt == 6) BD_LAUNCH(6, 1, 3);
@@ -1608,8 +1589,7 @@ extern "C" int dpot_gemm_bf16p_pair(const void* A0, const void* W0, float* C0, i
   if (use_bd) {
     const int cpw = colt == 6 ? 1 : bd_cpw((long long)grid * splits);
     const int la = bd_lookahead(cpw);
-    const unsigned pgrid = bd_grid(grid, splits, cpw);
-#define BD_LAUNCH(CT, CW, LA) hipLaunchKernelGGL((gemm_bf16p_bd_pair_kernel<CT, CW, LA>), dim3(pgrid, splits), dim3(64 * CT / CW), 0, as_stream(stream), pp)
+#define BD_LAUNCH(CT, CW, LA) hipLaunchKernelGGL((gemm_bf16p_bd_pair_kernel<CT, CW, LA>), dim3(grid, splits), dim3(64 * CT / CW), 0, as_stream(stream), pp)
     (void)la;
     if (colt == 6) BD_LAUNCH(6, 1, 3);
     else if (cpw == 2) BD_LAUNCH(8, 2, 3);
