@@ -754,7 +754,18 @@ __device__ __forceinline__ void gemm_bf16p_bd_body(const Bf16pArgs& p, const int
   nslab = nslab < p.slabs_per_split ? nslab : p.slabs_per_split;
 
   int tm, tn;
-  {
+  if (p.super_r > 0) {
+    // L2-aware rasterisation (as in gemm_bf16p_body): the tiles an XCD runs at one time form super_r x super_c blocks of the
+    // tile grid, and an XCD walks the super-blocks of one super-row before the next
+    const int xcd = bid0 & 7, slot = bid0 >> 3;
+    const int sb = slot >> 5, in = slot & 31;
+    const int srows = p.tilesM / p.super_r, scols = p.tilesN / p.super_c;
+    const int gsb = sb * 8 + xcd;
+    if (gsb >= srows * scols) return;
+    const int srow = gsb % srows, scol = gsb / srows;
+    tm = srow * p.super_r + in % p.super_r;
+    tn = scol * p.super_c + in / p.super_r;
+  } else {
     const int ntiles = p.tilesM * p.tilesN;
     const int xcd = bid0 & 7, slot = bid0 >> 3;
     const int q = ntiles >> 3, r = ntiles & 7;
@@ -821,6 +832,10 @@ __device__ __forceinline__ void gemm_bf16p_bd_body(const Bf16pArgs& p, const int
   // s_waitcnt vmcnt(VMW) lgkmcnt(0) as the BUILTIN (the compiler's own wait-count pass sees it): simm16 = vmcnt[3:0] |
   // expcnt 7 << 4 | lgkmcnt 0 << 8 | vmcnt[5:4] << 14
   constexpr int WAITC = (VMW & 15) | 0x70 | ((VMW >> 4) << 14);
+  // (Two fragment-read schedules were built as variants in round 4 - all eight ds_read_b128 of a slab issued before its first
+  // MFMA, and the next slab's A fragments prefetched into a second register set under the current MFMAs (the structure of
+  // the LDS-DMA kernels): neither is faster on any DPOT-M / -L shape, the second spills at two column tiles per wave;
+  // profiles/r04_bf16p_bd_fragment_variants.txt.  The compiler's own just-in-time pairs stay.)
   auto slab = [&](int g, auto S, auto SN) __attribute__((always_inline)) {
     constexpr int s = decltype(S)::value;
     asm volatile("" ::: "memory");
@@ -1383,7 +1398,7 @@ static void bf16p_pick_super(int tilesM, int tilesN, int splits, int* sr, int* s
   // 1: the launches with >= 512 tiles (instead of the two-workgroup kernel); 2: only those with one round of 256..511 tiles
   // (the K = 4096 launches of DPOT-M: 64 x 4 tiles - every A row panel is otherwise pulled into four XCDs' L2s; measured:
   // 87.2 against 87.3 us back to back, DPOT-M step 14.64 against 14.68 ms - the L2 fill path is not what bounds them)
-  if (!enabled || splits > 1 || (enabled == 2 ? (nt < 256 || nt >= 512) : nt < 512)) return;
+  if (!enabled || splits > 1 || nt < 256 || (enabled == 2 && nt >= 512) || (enabled == 1 && nt < 512)) return;
   static const int cand[6][2] = {{8, 4}, {4, 8}, {16, 2}, {2, 16}, {32, 1}, {1, 32}};
   for (int i = 0; i < 6; ++i)
     if (tilesM % cand[i][0] == 0 && tilesN % cand[i][1] == 0) { *sr = cand[i][0]; *sc = cand[i][1]; return; }
@@ -1466,7 +1481,7 @@ extern "C" int dpot_gemm_bf16p(const void* Apacked, const void* Wpacked, const f
   // pipeline sooner - DPOT-S 5.73 -> 5.94 ms with B-direct everywhere, DPOT-M 14.97 -> 14.24, DPOT-L 102.9 -> 96.2
   // (profiles/r04_bf16p_bd_step_ab_one_box.txt); bd == 3: every plain-bf16 launch
   const bool bd_shape = (long long)p.tilesM * p.tilesN * p.splits >= 512 || p.slabs_per_split >= 64;
-  const bool use_bd = planes == 1 && p.super_r == 0 && ((bd == 1 && bd_shape) || bd == 3 || (bd == 2 && !use_duo));
+  const bool use_bd = planes == 1 && colt == (p.super_r ? PB_COLT : colt) && ((bd == 1 && bd_shape) || bd == 3 || (bd == 2 && !use_duo));
   if (planes == 3)
     hipLaunchKernelGGL(gemm_bf16x6p_kernel, dim3((unsigned)(p.tilesM * p.tilesN), p.splits), dim3(512), 0,
                        as_stream(stream), p);
