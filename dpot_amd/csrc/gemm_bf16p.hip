@@ -1391,8 +1391,11 @@ extern "C" int dpot_gemm_bf16p_splitk(int M, int N, int K) {
 // previous kernel - the 48 launches average 123.7 us with it against 121.1 us without
 // (profiles/r03_step_census_M_bf16_seq_raster{1,0}.txt): the column-major order it replaces streams each weight chunk
 // through one XCD's L2 exactly once, which matters more when nothing is cache-resident.
-static void bf16p_pick_super(int tilesM, int tilesN, int splits, int* sr, int* sc) {
-  static const int enabled = [] { const char* e = getenv("DPOT_BF16P_RASTER"); return e ? atoi(e) : 0; }();
+static void bf16p_pick_super(int tilesM, int tilesN, int splits, int* sr, int* sc, bool bdirect) {
+  // default: on (both ranges) for the B-direct kernels - round 4, inside the step: DPOT-M 14.36 -> 14.04 ms, DPOT-L 97.8 -> 95.3 ms
+  // (profiles/r04_bf16p_bd_raster.txt; the faster main loop feels the 2-4 fetches of every A panel) - off for the LDS-DMA ones
+  static const int env = [] { const char* e = getenv("DPOT_BF16P_RASTER"); return e ? atoi(e) : -1; }();
+  const int enabled = env >= 0 ? env : (bdirect ? 3 : 0);
   *sr = 0; *sc = 0;
   const long long nt = (long long)tilesM * tilesN;
   // 1: the launches with >= 512 tiles (instead of the two-workgroup kernel); 2: only those with one round of 256..511 tiles
@@ -1454,7 +1457,9 @@ extern "C" int dpot_gemm_bf16p(const void* Apacked, const void* Wpacked, const f
   p.cs_part = colsum_part;
   p.dact_out = reinterpret_cast<uint4*>(dact_out);
   p.dact_in = reinterpret_cast<const unsigned short*>(dact_in);
-  bf16p_pick_super(p.tilesM, p.tilesN, p.splits, &p.super_r, &p.super_c);
+  static const int bd = [] { const char* ev = getenv("DPOT_BF16P_BD"); return ev ? atoi(ev) : 1; }();
+  const bool bd_shape = (long long)p.tilesM * p.tilesN * p.splits >= 512 || p.slabs_per_split >= 64;
+  bf16p_pick_super(p.tilesM, p.tilesN, p.splits, &p.super_r, &p.super_c, planes == 1 && ((bd == 1 && bd_shape) || bd == 3));
   // 128 x 192 tiles where they fill the rounds of 256 CUs better (as for the pair launch below; a 192-wide tile costs ~0.83
   // of a 256-wide one): DPOT-L at batch 4 has 32 x 6 = 192 tiles of 128 x 256 in fc2 forward / fc1 data gradient - a
   // quarter of the chip idle - and 32 x 8 = 256 of 128 x 192
@@ -1475,12 +1480,10 @@ extern "C" int dpot_gemm_bf16p(const void* Apacked, const void* Wpacked, const f
                        (duo == 1 || duo == 2 || (duo == 3 && packs));
   // B-direct form (DPOT_BF16P_BD: 1 (default) = by the shape rule below, 3 = every plain-bf16 launch, 0 = off: the LDS-DMA
   // kernels of rounds 2-3, 2 = only the launches the duo kernel does not take)
-  static const int bd = [] { const char* ev = getenv("DPOT_BF16P_BD"); return ev ? atoi(ev) : 1; }();
   // shape rule (bd == 1): launches with several rounds of tiles or a long contraction; a single round of tiles with K < 2048
   // (DPOT-S: 8192 x 1024 x 1024, 256 tiles, 32 slabs) keeps the LDS-DMA kernels, whose dedicated loader waves start the
   // pipeline sooner - DPOT-S 5.73 -> 5.94 ms with B-direct everywhere, DPOT-M 14.97 -> 14.24, DPOT-L 102.9 -> 96.2
   // (profiles/r04_bf16p_bd_step_ab_one_box.txt); bd == 3: every plain-bf16 launch
-  const bool bd_shape = (long long)p.tilesM * p.tilesN * p.splits >= 512 || p.slabs_per_split >= 64;
   const bool use_bd = planes == 1 && colt == (p.super_r ? PB_COLT : colt) && ((bd == 1 && bd_shape) || bd == 3 || (bd == 2 && !use_duo));
   if (planes == 3)
     hipLaunchKernelGGL(gemm_bf16x6p_kernel, dim3((unsigned)(p.tilesM * p.tilesN), p.splits), dim3(512), 0,
