@@ -23,13 +23,14 @@ LARGE_SET = "test_large_batch16_vs_reference_golden"
 SWITCHES = {
     # bf16 channel-MLP kernels.  Default since round 4: the B-direct kernels (W fragments straight into registers).
     # BD=0: the LDS-DMA kernels of rounds 2-3 in their own default selection (two-workgroup kernel, 128 x 192 tiles, pairs)
-    "DPOT_BF16P_BD=0": (LARGE_SET + " or test_bf16_channel_mlp_mode_vs_oracle and MEDIUM-32", False),
+    "DPOT_BF16P_BD=0": (LARGE_SET, False),
     # ... and with the 12-wave kernel for every launch, 128 x 256 tiles only, un-paired weight gradients
     "DPOT_BF16P_BD=0 DPOT_BF16P_DUO=0 DPOT_BF16P_TILE192=0 DPOT_BF16P_PAIR=0":
-        (LARGE_SET + " or test_bf16_channel_mlp_mode_vs_oracle and MEDIUM-1", False),
-    # B-direct with eight 128 x 32 waves everywhere (no two-workgroup form), 128 x 256 tiles only, un-paired weight gradients
-    "DPOT_BF16P_BD_CPW=1 DPOT_BF16P_TILE192=0 DPOT_BF16P_PAIR=0":
-        (LARGE_SET + " or test_bf16_channel_mlp_mode_vs_oracle and (MEDIUM-32 or MEDIUM-1)", False),
+        ("test_bf16_channel_mlp_mode_vs_oracle and (MEDIUM-32 or MEDIUM-1)", False),
+    # B-direct with eight 128 x 32 waves everywhere (no two-workgroup form), column-major tile order, 128 x 256 tiles only,
+    # un-paired weight gradients
+    "DPOT_BF16P_BD_CPW=1 DPOT_BF16P_RASTER=0 DPOT_BF16P_TILE192=0 DPOT_BF16P_PAIR=0":
+        ("test_bf16_channel_mlp_mode_vs_oracle and (MEDIUM-32 or MEDIUM-1)", False),
     "DPOT_AFNO_3MULT=0": (SMALL_SET, True),               # four-product fused mixer
     "DPOT_AFNO_FUSED=0": (SMALL_SET, True),               # two generic GEMM launches per mixer
     # separate GroupNorm / DFT kernels, GroupNorm never applied on load, generic GEMM instead of the panel / weight-
