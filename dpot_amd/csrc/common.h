@@ -79,6 +79,9 @@ __device__ __forceinline__ void gelu_val_der(float x, float& val, float& der) {
   der = fmaf(x, phi, x >= 0.f ? 1.0f - e : e);
 }
 
+// (Round 4 also measured a two-elements-at-a-time form on the packed fp32 pipe - v_pk_fma_f32 for the polynomial and the FMAs
+// around it, bit-identical results - in the bf16 GEMM's packed-output epilogue, where no MFMA competes: no gain,
+// profiles/r04_bf16p_gelu_packed_rejected.txt.  That epilogue is not VALU-bound.)
 __device__ __forceinline__ float act_fwd(int act, float x) {
   switch (act) {
     case DPOT_ACT_GELU: return gelu_fwd(x);

@@ -766,12 +766,20 @@ __device__ __forceinline__ void gemm_bf16p_bd_body(const Bf16pArgs& p, const int
     tm = srow * p.super_r + in % p.super_r;
     tn = scol * p.super_c + in / p.super_r;
   } else {
+    // XCD-contiguous order: XCD x runs the tiles [x n / 8, (x + 1) n / 8) of the COLUMN-major (super_c == 0: an XCD holds few
+    // W chunks and many A panels) or ROW-major (super_c == 1: few A panels, many W chunks) enumeration - the host picks the
+    // one that makes the eight L2s fetch fewer operand bytes (bf16p_row_major)
     const int ntiles = p.tilesM * p.tilesN;
     const int xcd = bid0 & 7, slot = bid0 >> 3;
     const int q = ntiles >> 3, r = ntiles & 7;
     const int tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + slot;
-    tn = tile / p.tilesM;
-    tm = tile - tn * p.tilesM;
+    if (p.super_c == 1) {
+      tm = tile / p.tilesN;
+      tn = tile - tm * p.tilesN;
+    } else {
+      tn = tile / p.tilesM;
+      tm = tile - tn * p.tilesM;
+    }
   }
   const int rt0 = tm * PB_ROWT, ct0 = tn * COLT;
   const int mtiles = (p.M + 31) >> 5;
@@ -1356,6 +1364,25 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
                                                             long long sCs, int csL);
 }
 
+// 1 if the ROW-major XCD-contiguous tile order makes the eight L2s fetch fewer operand bytes than the column-major one:
+// XCD x holds a contiguous eighth of the enumeration, i.e. (column-major) ~tilesN / 8 W chunks x all their row panels, or
+// (row-major) ~tilesM / 8 A panels x all their column chunks; an operand piece is fetched once per XCD that touches it.
+// Round 4: the counters showed every bf16 launch moving 4.0-4.7 TB/s through the fabric, 2.1-2.9x its algorithmic bytes.
+static int bf16p_row_major(int tilesM, int tilesN, int rowt, int colt) {
+  static const int enabled = [] { const char* ev = getenv("DPOT_BF16P_ROWMAJOR"); return ev ? atoi(ev) : 1; }();
+  if (!enabled) return 0;
+  auto cost = [&](int outer, int inner, double outer_bytes, double inner_bytes) {
+    // enumeration with `outer` slowest: an XCD's n / 8 consecutive tiles span ceil-ish (n / 8) / inner + 1 outer values
+    const double n = (double)outer * inner, per = n / 8.0;
+    double outers = per / inner; if (outers < 1.0) outers = 1.0;
+    const double inners = per < inner ? per : inner;
+    return 8.0 * (outers * outer_bytes + inners * inner_bytes);
+  };
+  const double a = 32.0 * rowt, w = 32.0 * colt;              // bytes per k of an A panel / a W chunk (same K: drop it)
+  const double col = cost(tilesN, tilesM, w, a), row = cost(tilesM, tilesN, a, w);
+  return row < 0.95 * col ? 1 : 0;
+}
+
 // B-direct kernels: 32-column tiles per wave (DPOT_BF16P_BD_CPW: 1 = eight 128 x 32 waves, one workgroup per CU; 2 = four
 // 128 x 64 waves, two workgroups per CU)
 static int bd_cpw(long long tiles) {
@@ -1489,6 +1516,7 @@ extern "C" int dpot_gemm_bf16p(const void* Apacked, const void* Wpacked, const f
     hipLaunchKernelGGL(gemm_bf16x6p_kernel, dim3((unsigned)(p.tilesM * p.tilesN), p.splits), dim3(512), 0,
                        as_stream(stream), p);
   else if (use_bd) {
+    if (p.super_r == 0) p.super_c = bf16p_row_major(p.tilesM, p.tilesN, PB_ROWT, colt);
     const int cpw = colt == 6 ? 1 : bd_cpw((long long)p.tilesM * p.tilesN * p.splits);
     const int la = bd_lookahead(cpw);
 #define BD_LAUNCH(CT, CW, LA) hipLaunchKernelGGL((gemm_bf16p_bd_kernel<CT, CW, LA>), dim3(grid, p.splits), dim3(64 * CT / CW), 0, as_stream(stream), p)
@@ -1605,6 +1633,7 @@ extern "C" int dpot_gemm_bf16p_pair(const void* A0, const void* W0, float* C0, i
   static const int bd = [] { const char* ev = getenv("DPOT_BF16P_BD"); return ev ? atoi(ev) : 1; }();
   const bool use_bd = bd == 3 || (bd && ((long long)grid * splits >= 512 || sps >= 128));
   if (use_bd) {
+    for (int i = 0; i < 2; ++i) pp.a[i].super_c = bf16p_row_major(pp.a[i].tilesM, pp.a[i].tilesN, PB_ROWT, colt);
     const int cpw = colt == 6 ? 1 : bd_cpw((long long)grid * splits);
     const int la = bd_lookahead(cpw);
 #define BD_LAUNCH(CT, CW, LA) hipLaunchKernelGGL((gemm_bf16p_bd_pair_kernel<CT, CW, LA>), dim3(grid, splits), dim3(64 * CT / CW), 0, as_stream(stream), pp)
