@@ -428,13 +428,15 @@ __device__ __forceinline__ float tn_sum_splits(const float* __restrict__ w, long
   return v;
 }
 
-__global__ __launch_bounds__(256) void afno_wgrad2_reduce_kernel(const float* __restrict__ ws, int splits, int nb, int bs,
-                                                                 float* __restrict__ dw1, float* __restrict__ db1,
-                                                                 float* __restrict__ dw2, float* __restrict__ db2) {
+// (bid, nblk: this workgroup's index / the number of workgroups working on the reduction - the stand-alone kernel passes
+// blockIdx.x / gridDim.x, block_finalize_kernel a slice of its grid)
+__device__ __forceinline__ void afno_wgrad2_reduce_body(int bid, int nblk, const float* __restrict__ ws, int splits, int nb,
+                                                        int bs, float* __restrict__ dw1, float* __restrict__ db1,
+                                                        float* __restrict__ dw2, float* __restrict__ db2) {
   const int n2 = 2 * bs;
   const long long MN = (long long)n2 * n2, total = MN * 2 * nb;
   const long long nw = (long long)nb * bs * bs;
-  for (long long idx = blockIdx.x * 256ll + threadIdx.x; idx < 2 * nw; idx += (long long)gridDim.x * 256) {
+  for (long long idx = bid * 256ll + threadIdx.x; idx < 2 * nw; idx += (long long)nblk * 256) {
     const int layer = idx >= nw;
     const long long q = idx - layer * nw;
     const int o = (int)(q % bs), i = (int)((q / bs) % bs), k = (int)(q / ((long long)bs * bs));
@@ -449,13 +451,18 @@ __global__ __launch_bounds__(256) void afno_wgrad2_reduce_kernel(const float* __
   }
   const float* wc = ws + (long long)splits * total;
   const long long nc = (long long)2 * nb * n2;
-  for (long long idx = blockIdx.x * 256ll + threadIdx.x; idx < nc; idx += (long long)gridDim.x * 256) {
+  for (long long idx = bid * 256ll + threadIdx.x; idx < nc; idx += (long long)nblk * 256) {
     const float v = tn_sum_splits(wc + idx, nc, splits);
     const int layer = idx >= (long long)nb * n2;
     const long long q = idx - (long long)layer * nb * n2;
     const int c = (int)(q % bs), part = (int)((q / bs) & 1), k = (int)(q / n2);
     (layer ? db2 : db1)[((long long)part * nb + k) * bs + c] = v;
   }
+}
+__global__ __launch_bounds__(256) void afno_wgrad2_reduce_kernel(const float* __restrict__ ws, int splits, int nb, int bs,
+                                                                 float* __restrict__ dw1, float* __restrict__ db1,
+                                                                 float* __restrict__ dw2, float* __restrict__ db2) {
+  afno_wgrad2_reduce_body(blockIdx.x, gridDim.x, ws, splits, nb, bs, dw1, db1, dw2, db2);
 }
 }  // namespace dpot
 
@@ -482,7 +489,8 @@ extern "C" int64_t dpot_afno_wgrad2_ws_elems(int nb, int bs, int splitk) {
 extern "C" int dpot_afno_wgrad2(const float* S, const float* dO1pre, const float* O1, const float* dO2, int ld, int Mm,
                                 int nb, int bs, float* dw1, float* db1, float* dw2, float* db2, float* workspace,
                                 int splitk, dpot_stream_t stream) {
-  DPOT_REQUIRE(S && dO1pre && O1 && dO2 && dw1 && db1 && dw2 && db2 && workspace, "afno_wgrad2: null pointer");
+  DPOT_REQUIRE(S && dO1pre && O1 && dO2 && workspace, "afno_wgrad2: null pointer");
+  DPOT_REQUIRE((dw1 && db1 && dw2 && db2) || (!dw1 && !db1 && !dw2 && !db2), "afno_wgrad2: outputs must be all given or all NULL");
   const int N = 2 * bs;
   DPOT_REQUIRE(nb > 0 && bs > 0 && (N % TN_W == 0 || N == TW) && Mm > 0 && Mm % TN_TOK == 0 && ld >= nb * N && ld % 4 == 0,
                "afno_wgrad2: needs 2*bs %% 128 == 0 or 2*bs == 192, Mm %% 32 == 0");
@@ -509,7 +517,7 @@ extern "C" int dpot_afno_wgrad2(const float* S, const float* dO1pre, const float
                        p);
   }
   int rc = check_launch("gemm_tn_kernel");
-  if (rc) return rc;
+  if (rc || !dw1) return rc;            // dw1 == NULL: partials only, dpot_block_finalize reduces them
   long long blocks = (2ll * nb * bs * bs + 255) / 256;
   if (blocks > 4096) blocks = 4096;
   hipLaunchKernelGGL(afno_wgrad2_reduce_kernel, dim3((unsigned)blocks), dim3(256), 0, s, (const float*)workspace, splitk, nb,
@@ -525,15 +533,15 @@ extern "C" int dpot_afno_wgrad2(const float* S, const float* dO1pre, const float
 // Two same-shaped problems -> half the split factor of two separate launches (less partial traffic, longer token ranges).
 // ---------------------------------------------------------------------------------------------------------------------
 namespace dpot {
-__global__ __launch_bounds__(256) void mlp_wgrad2_reduce_kernel(const float* __restrict__ ws, int splits, int E, int mh,
-                                                                float* __restrict__ dW2, float* __restrict__ dW1,
-                                                                float* __restrict__ db2, float* __restrict__ db1) {
+__device__ __forceinline__ void mlp_wgrad2_reduce_body(int bid, int nblk, const float* __restrict__ ws, int splits, int E,
+                                                       int mh, float* __restrict__ dW2, float* __restrict__ dW1,
+                                                       float* __restrict__ db2, float* __restrict__ db1) {
   __shared__ float tile[32][33];
   const long long MN = (long long)E * mh, total = 2 * MN;
   const int L = E > mh ? E : mh;
   // 32 x 32 tiles of the [E, mh] outputs: problem 0 is copied, problem 1 goes out transposed (coalesced both ways)
   const int tn = mh / 32, tcount = (E / 32) * tn;
-  for (int tix = blockIdx.x; tix < 2 * tcount; tix += gridDim.x) {
+  for (int tix = bid; tix < 2 * tcount; tix += nblk) {
     const int prob = tix >= tcount, tt = tix - prob * tcount;
     const int r0 = (tt / tn) * 32, c0 = (tt % tn) * 32;
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
@@ -555,9 +563,71 @@ __global__ __launch_bounds__(256) void mlp_wgrad2_reduce_kernel(const float* __r
     }
   }
   const float* wc = ws + (long long)splits * total;
-  for (int idx = blockIdx.x * 256 + threadIdx.x; idx < E + mh; idx += gridDim.x * 256) {
+  for (int idx = bid * 256 + threadIdx.x; idx < E + mh; idx += nblk * 256) {
     const int prob = idx >= E, g = idx - prob * E;
     (prob ? db1 : db2)[g] = tn_sum_splits(wc + (long long)prob * L + g, 2ll * L, splits);
+  }
+}
+__global__ __launch_bounds__(256) void mlp_wgrad2_reduce_kernel(const float* __restrict__ ws, int splits, int E, int mh,
+                                                                float* __restrict__ dW2, float* __restrict__ dW1,
+                                                                float* __restrict__ db2, float* __restrict__ db1) {
+  mlp_wgrad2_reduce_body(blockIdx.x, gridDim.x, ws, splits, E, mh, dW2, dW1, db2, db1);
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// ONE finalising launch per DPOT block (round 4): the fixed-order reductions that end a block's backward - the split-K
+// partials of the two AFNO weight gradients (+ un-packing to the parameters' layout, bias gradients), those of the two
+// channel-MLP weight gradients (+ bias gradients), and the per-sample partials of both GroupNorms' parameter gradients -
+// were three launches of a few microseconds each (DPOT-Tiny: 8.1 + 6.5 + 5.3 us per block as eager kernel time, ~4 us each
+// inside the replayed graph).  The grid is cut into three slices; each slice runs the body of the stand-alone kernel
+// unchanged, so every sum keeps its order (bit-identical results).  A slice of zero workgroups is skipped.
+// ---------------------------------------------------------------------------------------------------------------------
+struct FinalizeArgs {
+  // slice A: AFNO weight gradients (dpot_afno_wgrad2's reduction)
+  const float* a_ws; int a_splits, a_nb, a_bs; float *a_dw1, *a_db1, *a_dw2, *a_db2; int nA;
+  // slice M: channel-MLP weight gradients (dpot_mlp_wgrad2's reduction)
+  const float* m_ws; int m_splits, m_E, m_mh; float *m_dW2, *m_dW1, *m_db2, *m_db1; int nM;
+  // slice G: GroupNorm parameter gradients (dpot_groupnorm_param_grads): g_jobs jobs x ceil(E / 64) workgroups
+  const float* g_part[2]; float* g_dgamma[2]; float* g_dbeta[2]; int g_jobs, g_B, g_E, nG;
+};
+// = norm.hip groupnorm_param_grad_kernel: block = 64 channels x 4 sample lanes, fixed order
+__device__ __forceinline__ void gn_param_grad_body(int bx, const float* __restrict__ part, float* __restrict__ dgamma,
+                                                   float* __restrict__ dbeta, int B, int E) {
+  __shared__ float red[2][4][64];
+  const int tc = threadIdx.x & 63, tr = threadIdx.x >> 6;
+  const int c = bx * 64 + tc;
+  float sg0 = 0.f, sg1 = 0.f, sb0 = 0.f, sb1 = 0.f;
+  if (c < E) {
+    int b = tr;
+    for (; b + 4 < B; b += 8) {
+      sg0 += part[((long long)0 * B + b) * E + c];
+      sg1 += part[((long long)0 * B + b + 4) * E + c];
+      sb0 += part[((long long)1 * B + b) * E + c];
+      sb1 += part[((long long)1 * B + b + 4) * E + c];
+    }
+    for (; b < B; b += 4) {
+      sg0 += part[((long long)0 * B + b) * E + c];
+      sb0 += part[((long long)1 * B + b) * E + c];
+    }
+  }
+  red[0][tr][tc] = sg0 + sg1;
+  red[1][tr][tc] = sb0 + sb1;
+  __syncthreads();
+  if (tr == 0 && c < E) {
+    dgamma[c] = (red[0][0][tc] + red[0][1][tc]) + (red[0][2][tc] + red[0][3][tc]);
+    dbeta[c] = (red[1][0][tc] + red[1][1][tc]) + (red[1][2][tc] + red[1][3][tc]);
+  }
+}
+__global__ __launch_bounds__(256) void block_finalize_kernel(const FinalizeArgs a) {
+  const int b = blockIdx.x;
+  if (b < a.nA) {
+    afno_wgrad2_reduce_body(b, a.nA, a.a_ws, a.a_splits, a.a_nb, a.a_bs, a.a_dw1, a.a_db1, a.a_dw2, a.a_db2);
+  } else if (b < a.nA + a.nM) {
+    mlp_wgrad2_reduce_body(b - a.nA, a.nM, a.m_ws, a.m_splits, a.m_E, a.m_mh, a.m_dW2, a.m_dW1, a.m_db2, a.m_db1);
+  } else {
+    const int g = b - a.nA - a.nM, per = (a.g_E + 63) / 64;
+    const int job = g / per;
+    gn_param_grad_body(g - job * per, a.g_part[job], a.g_dgamma[job], a.g_dbeta[job], a.g_B, a.g_E);
   }
 }
 }  // namespace dpot
@@ -584,7 +654,8 @@ extern "C" int64_t dpot_mlp_wgrad2_ws_elems(int E, int mh, int splitk) {
 extern "C" int dpot_mlp_wgrad2(const float* do2, const float* Hh, const float* xn2, const float* dHpre, int T, int E,
                                int mh, float* dW2, float* db2, float* dW1, float* db1, float* workspace, int splitk,
                                dpot_stream_t stream) {
-  DPOT_REQUIRE(do2 && Hh && xn2 && dHpre && dW2 && db2 && dW1 && db1 && workspace, "mlp_wgrad2: null pointer");
+  DPOT_REQUIRE(do2 && Hh && xn2 && dHpre && workspace, "mlp_wgrad2: null pointer");
+  DPOT_REQUIRE((dW2 && db2 && dW1 && db1) || (!dW2 && !db2 && !dW1 && !db1), "mlp_wgrad2: outputs must be all given or all NULL");
   DPOT_REQUIRE(T > 0 && E % TN_W == 0 && mh % TN_W == 0 && T % TN_TOK == 0, "mlp_wgrad2: needs E, mh %% 128 == 0, T %% 32 == 0");
   DPOT_REQUIRE(aligned16(do2) && aligned16(Hh) && aligned16(xn2) && aligned16(dHpre) && aligned16(workspace),
                "mlp_wgrad2: operands must be 16-byte aligned");
@@ -603,10 +674,42 @@ extern "C" int dpot_mlp_wgrad2(const float* do2, const float* Hh, const float* x
   hipStream_t s = as_stream(stream);
   hipLaunchKernelGGL(gemm_tn_kernel, dim3((unsigned)(p.tiles1 * p.tiles2), 1, (unsigned)(2 * splitk)), dim3(384), 0, s, p);
   int rc = check_launch("gemm_tn_kernel");
-  if (rc) return rc;
+  if (rc || !dW2) return rc;            // dW2 == NULL: partials only, dpot_block_finalize reduces them
   int blocks = 2 * (E / 32) * (mh / 32);
   if (blocks > 2048) blocks = 2048;
   hipLaunchKernelGGL(mlp_wgrad2_reduce_kernel, dim3(blocks), dim3(256), 0, s, (const float*)workspace, splitk, E, mh, dW2,
                      dW1, db2, db1);
   return check_launch("mlp_wgrad2_reduce_kernel");
+}
+
+extern "C" int dpot_block_finalize(const float* afno_ws, int afno_splitk, int nb, int bs, float* dw1, float* db1, float* dw2,
+                                   float* db2, const float* mlp_ws, int mlp_splitk, int E, int mh, float* dW2, float* dfb2,
+                                   float* dW1, float* dfb1, const float* const* gn_parts, float* const* gn_dgammas,
+                                   float* const* gn_dbetas, int gn_jobs, int B, int Egn, dpot_stream_t stream) {
+  FinalizeArgs a{};
+  if (afno_ws) {
+    DPOT_REQUIRE(afno_splitk >= 1 && nb > 0 && bs > 0 && dw1 && db1 && dw2 && db2, "block_finalize: bad AFNO slice");
+    a.a_ws = afno_ws; a.a_splits = afno_splitk; a.a_nb = nb; a.a_bs = bs; a.a_dw1 = dw1; a.a_db1 = db1; a.a_dw2 = dw2; a.a_db2 = db2;
+    long long blocks = (2ll * nb * bs * bs + 255) / 256;            // as dpot_afno_wgrad2
+    a.nA = (int)(blocks > 4096 ? 4096 : blocks);
+  }
+  if (mlp_ws) {
+    DPOT_REQUIRE(mlp_splitk >= 1 && E > 0 && mh > 0 && E % 32 == 0 && mh % 32 == 0 && dW2 && dfb2 && dW1 && dfb1,
+                 "block_finalize: bad channel-MLP slice");
+    a.m_ws = mlp_ws; a.m_splits = mlp_splitk; a.m_E = E; a.m_mh = mh; a.m_dW2 = dW2; a.m_dW1 = dW1; a.m_db2 = dfb2; a.m_db1 = dfb1;
+    int blocks = 2 * (E / 32) * (mh / 32);                          // as dpot_mlp_wgrad2
+    a.nM = blocks > 2048 ? 2048 : blocks;
+  }
+  if (gn_jobs > 0) {
+    DPOT_REQUIRE(gn_jobs <= 2 && gn_parts && gn_dgammas && gn_dbetas && B > 0 && Egn > 0, "block_finalize: bad GroupNorm slice");
+    for (int i = 0; i < gn_jobs; ++i) {
+      DPOT_REQUIRE(gn_parts[i] && gn_dgammas[i] && gn_dbetas[i], "block_finalize: null pointer in GroupNorm job %d", i);
+      a.g_part[i] = gn_parts[i]; a.g_dgamma[i] = gn_dgammas[i]; a.g_dbeta[i] = gn_dbetas[i];
+    }
+    a.g_jobs = gn_jobs; a.g_B = B; a.g_E = Egn; a.nG = gn_jobs * ((Egn + 63) / 64);
+  }
+  const int total = a.nA + a.nM + a.nG;
+  DPOT_REQUIRE(total > 0, "block_finalize: nothing to do");
+  hipLaunchKernelGGL(block_finalize_kernel, dim3((unsigned)total), dim3(256), 0, as_stream(stream), a);
+  return check_launch("block_finalize_kernel");
 }

@@ -328,9 +328,11 @@ def _mixer_fwd(xn1, packed, dims, afno_layout=None, norm=None):
     return y1, S, O1pre, O1
 
 
-def _mixer_core_bwd(dO2, S, O1pre, O1, wb1, wb2, dims, fused, afno_layout, sinks):
+def _mixer_core_bwd(dO2, S, O1pre, O1, wb1, wb2, dims, fused, afno_layout, sinks, pending=None):
     """backward of _mixer_core: dO2 [Mm, 2E] -> (dS, dw1, db1, dw2, db2); wb1 / wb2: the fragment-block-major W^T (fused
-    kernel) or the plain Wbig (generic GEMM); sinks = (s_w1, s_b1, s_w2, s_b2)"""
+    kernel) or the plain Wbig (generic GEMM); sinks = (s_w1, s_b1, s_w2, s_b2).  pending (a dict, BlockFn): the fused
+    weight-gradient launch leaves its split-K partials for the block's ONE finalising launch (pending["afno"] = the job)
+    and the four gradients are returned as plain tensors - the caller calls the sinks' done() after that launch"""
     B, tok, E, h, w, nb, bs, mx, my, mh, act = dims
     s_w1, s_b1, s_w2, s_b2 = sinks
     Mm = B * mx * my
@@ -361,8 +363,11 @@ def _mixer_core_bwd(dO2, S, O1pre, O1, wb1, wb2, dims, fused, afno_layout, sinks
     if sk2:
         dw1, db1 = ops._out(s_w1.out(), (2, nb, bs, bs), dev), ops._out(s_b1.out(), (2, nb, bs), dev)
         dw2, db2 = ops._out(s_w2.out(), (2, nb, bs, bs), dev), ops._out(s_b2.out(), (2, nb, bs), dev)
-        ops.afno_wgrad2(S, dO1pre, O1, dO2, nb, bs, dw1, db1, dw2, db2, sk2)
-        dw1, db1, dw2, db2 = s_w1.done(dw1), s_b1.done(db1), s_w2.done(dw2), s_b2.done(db2)
+        if pending is not None:
+            pending["afno"] = ops.afno_wgrad2(S, dO1pre, O1, dO2, nb, bs, dw1, db1, dw2, db2, sk2, defer=True)
+        else:
+            ops.afno_wgrad2(S, dO1pre, O1, dO2, nb, bs, dw1, db1, dw2, db2, sk2)
+            dw1, db1, dw2, db2 = s_w1.done(dw1), s_b1.done(db1), s_w2.done(dw2), s_b2.done(db2)
     else:
         dw1, db1 = ops._out(s_w1.out(), (2, nb, bs, bs), dev), ops._out(s_b1.out(), (2, nb, bs), dev)
         ops.gemm(S, dO1pre, dw1, 2 * bs, 2 * bs, Mm, colsum_out=db1, colsum_of=2, **wkw)
@@ -554,6 +559,9 @@ class BlockFn(torch.autograd.Function):
         dev = dout.device
         dout = dout.contiguous()
         do2 = dout.view(M, E)
+        # one finalising launch per block (csrc/gemm_tn.hip block_finalize_kernel): the fused weight-gradient launches leave
+        # their split-K partials, and those are reduced together with the GroupNorm parameter-gradient partials at the end
+        pending = {} if ops.block_finalize_enabled() else None
         # channel MLP
         mlp_pk = ctx.mlp_pk
         bf16p = mlp_pk is not None and mlp_pk.kind != "f32"
@@ -609,9 +617,12 @@ class BlockFn(torch.autograd.Function):
             if skm:
                 df2w, df2b = ops._out(s_f2w.out(), (E, mh), dev), ops._out(s_f2b.out(), (E,), dev)
                 df1w, df1b = ops._out(s_f1w.out(), (mh, E), dev), ops._out(s_f1b.out(), (mh,), dev)
-                ops.mlp_wgrad2(do2, Hh, xn2.view(M, E), dHpre, df2w, df2b, df1w, df1b, skm)
-                df2w, df2b = s_f2w.done(df2w.view(E, mh, 1, 1)), s_f2b.done(df2b)
-                df1w, df1b = s_f1w.done(df1w.view(mh, E, 1, 1)), s_f1b.done(df1b)
+                if pending is not None:      # partials only: reduced by the block's finalising launch below
+                    pending["mlp"] = ops.mlp_wgrad2(do2, Hh, xn2.view(M, E), dHpre, df2w, df2b, df1w, df1b, skm, defer=True)
+                else:
+                    ops.mlp_wgrad2(do2, Hh, xn2.view(M, E), dHpre, df2w, df2b, df1w, df1b, skm)
+                    df2w, df2b = s_f2w.done(df2w.view(E, mh, 1, 1)), s_f2b.done(df2b)
+                    df1w, df1b = s_f1w.done(df1w.view(mh, E, 1, 1)), s_f1b.done(df1b)
             else:
                 df1w, df1b = wgrad(dHpre, xn2.view(M, E), s_f1w, s_f1b, (mh, E, 1, 1))
             if bf16p:
@@ -627,7 +638,7 @@ class BlockFn(torch.autograd.Function):
             dy1, gn2_part, dO2 = ops.gn_bwd_rfft2(dxn2.view(B, tok, E), y1, mean2, rstd2, n2w, h, w, nb, mx, my,
                                                   col_weights=1)
             dS, dw1, db1, dw2, db2 = _mixer_core_bwd(dO2, S, O1pre, O1, wb1, wb2, ctx.dims, ctx.fused_mixer,
-                                                     ctx.afno_layout, (s_w1, s_b1, s_w2, s_b2))
+                                                     ctx.afno_layout, (s_w1, s_b1, s_w2, s_b2), pending)
             if E // 8 <= 64:
                 dx, gn1_part = ops.irfft2_gn_bwd(dS, dy1, x, mean1, rstd1, n1w, h, w, nb, mx, my, add=dout,
                                                  col_weights=0)
@@ -642,8 +653,16 @@ class BlockFn(torch.autograd.Function):
             dxn1, dw1, db1, dw2, db2 = _mixer_bwd(dy1, S, O1pre, O1, wb1, wb2, ctx.dims, ctx.fused_mixer,
                                                   ctx.afno_layout, (s_w1, s_b1, s_w2, s_b2))
             dx, gn1_part = ops.groupnorm_bwd(dxn1, x, mean1, rstd1, n1w, add=dout, defer=True)
-        (dn1w, dn1b), (dn2w, dn2b) = ops.groupnorm_param_grads([(gn1_part, s_n1w.out(), s_n1b.out()),
-                                                                (gn2_part, s_n2w.out(), s_n2b.out())])
+        gn_jobs = [(gn1_part, s_n1w.out(), s_n1b.out()), (gn2_part, s_n2w.out(), s_n2b.out())]
+        if pending:
+            (dn1w, dn1b), (dn2w, dn2b) = ops.block_finalize(pending.get("afno"), pending.get("mlp"), gn_jobs)
+            if "mlp" in pending:
+                df2w, df2b = s_f2w.done(df2w.view(E, mh, 1, 1)), s_f2b.done(df2b)
+                df1w, df1b = s_f1w.done(df1w.view(mh, E, 1, 1)), s_f1b.done(df1b)
+            if "afno" in pending:
+                dw1, db1, dw2, db2 = s_w1.done(dw1), s_b1.done(db1), s_w2.done(dw2), s_b2.done(db2)
+        else:
+            (dn1w, dn1b), (dn2w, dn2b) = ops.groupnorm_param_grads(gn_jobs)
         dn1w, dn1b = s_n1w.done(dn1w), s_n1b.done(dn1b)
         dn2w, dn2b = s_n2w.done(dn2w), s_n2b.done(dn2b)
         return (dx, dn1w, dn1b, dw1, db1, dw2, db2, dn2w, dn2b, df1w, df1b, df2w, df2b, None, None, None, None, None,

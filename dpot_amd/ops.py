@@ -544,14 +544,17 @@ def mlp_wgrad2_splitk(T: int, E: int, mh: int, precision: Optional[int] = None) 
 
 
 def mlp_wgrad2(do2: Tensor, Hh: Tensor, xn2: Tensor, dHpre: Tensor, dW2: Tensor, db2: Tensor, dW1: Tensor, db1: Tensor,
-               splitk: int) -> None:
+               splitk: int, defer: bool = False):
+    """both weight gradients of a channel MLP, one launch + one reduce.  defer=True: the launch writes its split-K partials
+    only and the job (for `block_finalize`, which reduces it together with the block's other partials) is returned"""
     lib = _lib.load()
     T, E = do2.shape
     mh = Hh.shape[1]
     ws = torch.empty(lib.dpot_mlp_wgrad2_ws_elems(E, mh, splitk), dtype=torch.float32, device=do2.device)
-    check(lib.dpot_mlp_wgrad2(do2.data_ptr(), Hh.data_ptr(), xn2.data_ptr(), dHpre.data_ptr(), T, E, mh, dW2.data_ptr(),
-                              db2.data_ptr(), dW1.data_ptr(), db1.data_ptr(), ws.data_ptr(), splitk, _stream()),
-          "mlp_wgrad2")
+    outs = (None,) * 4 if defer else (dW2.data_ptr(), db2.data_ptr(), dW1.data_ptr(), db1.data_ptr())
+    check(lib.dpot_mlp_wgrad2(do2.data_ptr(), Hh.data_ptr(), xn2.data_ptr(), dHpre.data_ptr(), T, E, mh, *outs,
+                              ws.data_ptr(), splitk, _stream()), "mlp_wgrad2")
+    return (ws, splitk, E, mh, dW2, db2, dW1, db1) if defer else None
 
 
 def afno_wgrad2_splitk(Mm: int, nb: int, bs: int) -> int:
@@ -560,14 +563,43 @@ def afno_wgrad2_splitk(Mm: int, nb: int, bs: int) -> int:
 
 
 def afno_wgrad2(S: Tensor, dO1pre: Tensor, O1: Tensor, dO2: Tensor, nb: int, bs: int, dw1: Tensor, db1: Tensor,
-                dw2: Tensor, db2: Tensor, splitk: int) -> None:
-    """dw1 / db1 (from S, dO1pre) and dw2 / db2 (from O1, dO2) of an AFNO block's complex MLP: one launch + one reduce"""
+                dw2: Tensor, db2: Tensor, splitk: int, defer: bool = False):
+    """dw1 / db1 (from S, dO1pre) and dw2 / db2 (from O1, dO2) of an AFNO block's complex MLP: one launch + one reduce.
+    defer=True: partials only; returns the job for `block_finalize`"""
     lib = _lib.load()
     Mm, ld = S.shape
     ws = torch.empty(lib.dpot_afno_wgrad2_ws_elems(nb, bs, splitk), dtype=torch.float32, device=S.device)
-    check(lib.dpot_afno_wgrad2(S.data_ptr(), dO1pre.data_ptr(), O1.data_ptr(), dO2.data_ptr(), ld, Mm, nb, bs,
-                               dw1.data_ptr(), db1.data_ptr(), dw2.data_ptr(), db2.data_ptr(), ws.data_ptr(), splitk,
-                               _stream()), "afno_wgrad2")
+    outs = (None,) * 4 if defer else (dw1.data_ptr(), db1.data_ptr(), dw2.data_ptr(), db2.data_ptr())
+    check(lib.dpot_afno_wgrad2(S.data_ptr(), dO1pre.data_ptr(), O1.data_ptr(), dO2.data_ptr(), ld, Mm, nb, bs, *outs,
+                               ws.data_ptr(), splitk, _stream()), "afno_wgrad2")
+    return (ws, splitk, nb, bs, dw1, db1, dw2, db2) if defer else None
+
+
+def block_finalize(afno_job, mlp_job, gn_jobs):
+    """ONE launch for the reductions that end a DPOT block's backward (csrc/gemm_tn.hip block_finalize_kernel): the deferred
+    split-K partials of `afno_wgrad2` and / or `mlp_wgrad2` (jobs as those return them, or None) and the GroupNorm
+    parameter-gradient partials gn_jobs = [(part [2,B,E], out_dgamma | None, out_dbeta | None)] (<= 2).  Returns the
+    GroupNorm outputs [(dgamma, dbeta)]; the weight-gradient outputs are the tensors handed to the deferred calls."""
+    null = None
+    a = afno_job if afno_job is not None else (None, 0, 0, 0, None, None, None, None)
+    m = mlp_job if mlp_job is not None else (None, 0, 0, 0, None, None, None, None)
+    n = len(gn_jobs)
+    outs, B, E = [], 0, 0
+    parts = dgs = dbs = null
+    if n:
+        _, B, E = gn_jobs[0][0].shape
+        outs = [(_out(og, (E,), p.device), _out(ob, (E,), p.device)) for p, og, ob in gn_jobs]
+        parts = (C.c_void_p * n)(*[p.data_ptr() for p, _, _ in gn_jobs])
+        dgs = (C.c_void_p * n)(*[g.data_ptr() for g, _ in outs])
+        dbs = (C.c_void_p * n)(*[b.data_ptr() for _, b in outs])
+    check(_lib.load().dpot_block_finalize(_p(a[0]), a[1], a[2], a[3], _p(a[4]), _p(a[5]), _p(a[6]), _p(a[7]),
+                                          _p(m[0]), m[1], m[2], m[3], _p(m[4]), _p(m[5]), _p(m[6]), _p(m[7]),
+                                          parts, dgs, dbs, n, B, E, _stream()), "block_finalize")
+    return outs
+
+
+def block_finalize_enabled() -> bool:
+    return os.environ.get("DPOT_BLOCK_FINALIZE", "1") != "0"
 
 
 def afno_mlp2_supported(nb: int, bs: int) -> bool:

@@ -161,6 +161,15 @@ int64_t dpot_afno_wgrad2_ws_elems(int nb, int bs, int splitk);
 int dpot_afno_wgrad2(const float* S, const float* dO1pre, const float* O1, const float* dO2, int ld, int Mm, int nb,
                      int bs, float* dw1, float* db1, float* dw2, float* db2, float* workspace, int splitk,
                      dpot_stream_t stream);
+/* dpot_afno_wgrad2 / dpot_mlp_wgrad2 with ALL FOUR outputs NULL write their split-K partials to the workspace only; ONE
+ * finalising launch per DPOT block then runs, in three slices of one grid, the fixed-order reductions that end the block's
+ * backward (models/dpot.py:165-180): the AFNO weight-gradient partials (afno_ws != NULL; outputs as dpot_afno_wgrad2), the
+ * channel-MLP ones (mlp_ws != NULL; as dpot_mlp_wgrad2) and the GroupNorm parameter gradients of gn_jobs <= 2 layers
+ * (as dpot_groupnorm_param_grads).  Same summation orders as the stand-alone reductions: bit-identical results. */
+int dpot_block_finalize(const float* afno_ws, int afno_splitk, int nb, int bs, float* dw1, float* db1, float* dw2,
+                        float* db2, const float* mlp_ws, int mlp_splitk, int E, int mh, float* dW2, float* dfb2, float* dW1,
+                        float* dfb1, const float* const* gn_parts, float* const* gn_dgammas, float* const* gn_dbetas,
+                        int gn_jobs, int B, int Egn, dpot_stream_t stream);
 /* the split-K factor the library would pick for this shape (>= 1) */
 int dpot_gemm_auto_splitk(int M, int N, int K, int batch);
 /* the same for a given dpot_gemm_desc.precision (the bf16x6 kernel prefers fewer, larger workgroups) */

@@ -216,6 +216,30 @@ def test_small_model_at_1024_resolution_vs_oracle():
         assert_close(p.grad, sd[k].grad, f"1024^2 d{k}")
 
 
+def test_block_finalize_launch_is_bit_identical(monkeypatch):
+    """round 4: the three reductions that end a block's backward (AFNO / channel-MLP split-K partials, GroupNorm parameter
+    gradients) run as ONE launch (csrc/gemm_tn.hip block_finalize_kernel, slices of one grid, same summation orders) - every
+    gradient must equal the three-launch form bit for bit (DPOT_BLOCK_FINALIZE=0)"""
+    from dpot_amd import DPOTNet
+    cfg = R.DPOTConfig(**R.TINY)
+    S = cfg.img_size
+    x = R.recipe_input((4, S, S, cfg.in_timesteps, cfg.in_channels), salt=71).cuda()
+    up = (R.recipe_input((4, S, S, cfg.out_timesteps, cfg.out_channels), salt=72) * 0.3).cuda()
+
+    def grads(flag):
+        monkeypatch.setenv("DPOT_BLOCK_FINALIZE", flag)
+        m = DPOTNet(**R.TINY)
+        m.load_state_dict(_recipe_sd("TINY", 4))
+        m.cuda()
+        xg = x.clone().requires_grad_(True)
+        y, _ = m(xg)
+        (y * up).sum().backward()
+        return [xg.grad] + [p.grad for k, p in m.named_parameters() if not k.startswith("cls_head.")]
+
+    for a, b in zip(grads("1"), grads("0")):
+        assert torch.equal(a, b)
+
+
 @pytest.fixture
 def bf16_mlp():
     from dpot_amd import ops
