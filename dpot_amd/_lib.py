@@ -48,6 +48,13 @@ class PackJob(C.Structure):
                 ("trans", C.c_int32)]
 
 
+class LayoutJob(C.Structure):
+    """mirror of struct dpot_layout_job"""
+    _fields_ = [("src", c_fp), ("add", c_fp), ("dst", c_fp), ("d0", C.c_int32), ("d1", C.c_int32), ("d2", C.c_int32),
+                ("v0", C.c_int32), ("v1", C.c_int32), ("v2", C.c_int32), ("s0", C.c_int64), ("s1", C.c_int64),
+                ("s2", C.c_int64)]
+
+
 class AfnoPackJob(C.Structure):
     """mirror of struct dpot_afno_pack_job"""
     _fields_ = [("w", c_fp), ("b", c_fp), ("wbig", c_fp), ("bbig", c_fp), ("fwd", c_fp), ("bwd", c_fp)]
@@ -126,6 +133,7 @@ SIGNATURES = {
     "dpot_window_slide_bwd": (c_i, [c_fp] * 3 + [c_i64] + [c_i] * 3 + [c_fp]),
     "dpot_resize_pad_window": (c_i, [c_fp, c_i, c_fp, c_fp] + [c_i] * 6 + [c_fp]),
     "dpot_panel_pack_weights": (c_i, [c_fp, c_i, c_i, c_fp]),
+    "dpot_layout_jobs": (c_i, [c_fp, c_i, c_i64, c_fp]),
     "dpot_bf16_packed_elems": (c_i64, [c_i, c_i, c_i]),
     "dpot_bf16_pack_rows": (c_i, [c_fp, c_i, c_i, c_i, c_i, c_i, c_fp, c_fp]),
     "dpot_bf16_pack_jobs": (c_i, [c_fp, c_i, c_i, c_i, c_fp]),

@@ -93,6 +93,26 @@ __global__ void copy2d_pad_kernel(const float* __restrict__ src, int sR, int sC,
   }
 }
 
+// Small weight-only LAYOUT jobs in ONE launch (round 4): dst[i0][i1][i2] (contiguous, d0 x d1 x d2) =
+//   (i0 < v0 && i1 < v1 && i2 < v2 ? src[i0 s0 + i1 s1 + i2 s2] : 0) + (add ? add[i2] : 0)
+// covers the zero-padded copies, small transposes, bias broadcasts and "+ bias" passes that DPOTNet derives from its
+// parameters every optimiser step (padded patch-conv weights, pos_embed^T + conv bias, de-embed bias per pixel, padded tail
+// weights: eight launches of 2-18 us - ~4 us each inside the replayed graph).  The table lives in device memory (a by-value
+// table indexed by blockIdx.y is copied to scratch by every thread); the destinations are persistent buffers.
+__global__ __launch_bounds__(256) void layout_jobs_kernel(const dpot_layout_job* __restrict__ jobs) {
+  const dpot_layout_job j = jobs[blockIdx.y];
+  const unsigned total = (unsigned)j.d0 * (unsigned)j.d1 * (unsigned)j.d2;
+  const unsigned d12 = (unsigned)j.d1 * (unsigned)j.d2;
+  for (unsigned idx = blockIdx.x * 256u + threadIdx.x; idx < total; idx += gridDim.x * 256u) {
+    const unsigned i0 = idx / d12, r = idx - i0 * d12;
+    const unsigned i1 = r / (unsigned)j.d2, i2 = r - i1 * (unsigned)j.d2;
+    float v = 0.f;
+    if ((int)i0 < j.v0 && (int)i1 < j.v1 && (int)i2 < j.v2) v = j.src[(long long)i0 * j.s0 + (long long)i1 * j.s1 + (long long)i2 * j.s2];
+    if (j.add) v += j.add[i2];
+    j.dst[idx] = v;
+  }
+}
+
 // dst[C,R] = src[R,C]^T per batch; 32x32 tiles through LDS (+1 padding: conflict-free)
 __global__ __launch_bounds__(256) void transpose2d_kernel(const float* __restrict__ src, float* __restrict__ dst, int R,
                                                           int C) {
@@ -338,6 +358,14 @@ extern "C" int dpot_copy2d_pad(const float* src, int sR, int sC, float* dst, int
   hipLaunchKernelGGL(copy2d_pad_kernel, dim3(grid_for((long long)dR * dC)), dim3(256), 0, as_stream(stream), src, sR,
                      sC, dst, dR, dC);
   return check_launch("copy2d_pad_kernel");
+}
+
+extern "C" int dpot_layout_jobs(const dpot_layout_job* jobs_dev, int njobs, int64_t max_elems, dpot_stream_t stream) {
+  DPOT_REQUIRE(jobs_dev && njobs > 0 && njobs <= 65535 && max_elems > 0 && max_elems < (1ll << 31), "layout_jobs: bad argument");
+  long long g = (max_elems + 255) / 256;
+  if (g > 256) g = 256;
+  hipLaunchKernelGGL(layout_jobs_kernel, dim3((unsigned)g, njobs), dim3(256), 0, as_stream(stream), jobs_dev);
+  return check_launch("layout_jobs_kernel");
 }
 
 extern "C" int dpot_transpose2d(const float* src, float* dst, int nbatch, int R, int C, dpot_stream_t stream) {

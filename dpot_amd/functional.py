@@ -105,20 +105,36 @@ def embed_grid_matrix(gx, gy, gt, X: int, Y: int, T: int, Cc: int, P: int):
     return ops.patchify(z, gx, gy, gt, P)[:, Cc * P * P:].contiguous()
 
 
-def embed_derived(pos, w0, b0, w2, b2, taw, tagamma, tt, T: int, grid=None):
+def embed_layout_jobs(pos, w0, b0, w2, b2):
+    """the layout pieces of embed_derived as ops.LayoutJobs entries, in the order (w0p, b0p, w2p, posb)"""
+    hid, E = w0.shape[0], w2.shape[0]
+    K0 = w0[0].numel()
+    hidp = _pad4(hid)
+    tok = pos.shape[2] * pos.shape[3]
+    return [(w0, None, (1, hidp, K0), (1, hid, K0), (0, K0, 1)),               # zero rows hid..hidp
+            (b0, None, (1, 1, hidp), (1, 1, hid), (0, 0, 1)),
+            (w2, None, (1, E, hidp), (1, E, hid), (0, hid, 1)),                # zero cols hid..hidp
+            (pos, b2, (1, tok, E), (1, tok, E), (0, 1, tok))]                  # pos^T [tok, E] + conv bias
+
+
+def embed_derived(pos, w0, b0, w2, b2, taw, tagamma, tt, T: int, grid=None, layouts=None):
     """weight-only products of the embed stage (they depend on no activation, so a T_ar-step rollout computes them
     once per optimiser step, see DPOTNet.weights_scope): padded conv weights, pos+bias, the cos-scaled aggregation
-    weights and the folded [1x1 conv -> TimeAggregator] matrices V / c described in EmbedFn.forward"""
+    weights and the folded [1x1 conv -> TimeAggregator] matrices V / c described in EmbedFn.forward.  layouts: the four
+    tensors of `embed_layout_jobs`, already refreshed (DPOTNet: one launch for all layout pieces of the model)"""
     hid, E = w0.shape[0], w2.shape[0]
     K0 = w0[0].numel()
     hidp = _pad4(hid)
     tok = pos.shape[2] * pos.shape[3]
     dev = pos.device
-    w0p = ops.copy2d_pad(w0, hid, K0, hidp, K0)                                # zero rows hid..hidp
-    b0p = ops.copy2d_pad(b0, 1, hid, 1, hidp).view(hidp)
-    w2p = ops.copy2d_pad(w2, E, hid, E, hidp)                                  # zero cols hid..hidp
-    posT = ops.transpose2d(pos, 1, E, tok).view(tok, E)                        # [tok, E]
-    posb = ops.bias_add(posT, b2)                                              # pos + conv bias
+    if layouts is not None:
+        w0p, b0p, w2p, posb = layouts[0].view(hidp, K0), layouts[1].view(hidp), layouts[2].view(E, hidp), layouts[3].view(tok, E)
+    else:
+        w0p = ops.copy2d_pad(w0, hid, K0, hidp, K0)                                # zero rows hid..hidp
+        b0p = ops.copy2d_pad(b0, 1, hid, 1, hidp).view(hidp)
+        w2p = ops.copy2d_pad(w2, E, hid, E, hidp)                                  # zero cols hid..hidp
+        posT = ops.transpose2d(pos, 1, E, tok).view(tok, E)                        # [tok, E]
+        posb = ops.bias_add(posT, b2)                                              # pos + conv bias
     ws = ops.timeagg_scale_w(taw, tagamma, tt) if tagamma is not None else taw
     V = torch.empty(T * hidp, E, dtype=torch.float32, device=dev)
     ops.gemm(w2p, ws, V, hidp, E, E, transA=True, lda=hidp, ldb=E, ldc=E, batch=T, strideA=0, strideB=E * E,
@@ -670,16 +686,32 @@ class BlockFn(torch.autograd.Function):
 
 
 # ======================================================================================================
-def head_derived(o0w, o0b, o4w, o4b, P: int, wt_out=None):
+def head_layout_jobs(o0b, o4w, o4b, P: int, old: int):
+    """the small layout pieces of head_derived as ops.LayoutJobs entries, in the order (bexp, [w4p, b4p])"""
+    co = o4w.shape[0]
+    PP = P * P
+    jobs = [(o0b, None, (1, PP, old), (1, PP, old), (0, 0, 1))]                # bias repeated per pixel of the patch
+    if old == 32 and 0 < co <= 32:
+        jobs += [(o4w, None, (1, 32, 32), (1, co, 32), (0, 32, 1)), (o4b, None, (1, 1, 32), (1, 1, co), (0, 0, 1))]
+    return jobs
+
+
+def head_derived(o0w, o0b, o4w, o4b, P: int, wt_out=None, layouts=None):
     """weight-only layouts of the de-embed stage: ConvTranspose2d(k=s=P) weight as the GEMM matrix whose columns are
     ordered (i, j, o) - the GEMM result IS the pixel-major [pixels, old] matrix -, its bias repeated per pixel, and
-    the zero-padded last 1x1 conv of the fused tail (None when the fused tail does not apply)"""
+    the zero-padded last 1x1 conv of the fused tail (None when the fused tail does not apply).  layouts: the tensors of
+    `head_layout_jobs`, already refreshed"""
     E, old = o0w.shape[0], o0w.shape[1]
     co = o4w.shape[0]
     PP = P * P
     wt = ops.transpose2d(o0w, E, old, PP, out=wt_out).view(E, PP * old)
-    bexp = ops.tile_vec(o0b, PP)
     w4p = b4p = None
+    if layouts is not None:
+        bexp = layouts[0].view(PP * old)
+        if len(layouts) > 1:
+            w4p, b4p = layouts[1].view(32, 32), layouts[2].view(32)
+        return wt, bexp, w4p, b4p
+    bexp = ops.tile_vec(o0b, PP)
     if old == 32 and 0 < co <= 32:
         w4p, b4p = ops.out_tail_pad(o4w, o4b, co)
     return wt, bexp, w4p, b4p

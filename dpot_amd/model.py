@@ -23,7 +23,8 @@ import torch.nn as nn
 from . import _lib, ops
 import contextlib
 
-from .functional import (AdaINFn, BlockFn, EmbedFn, HeadFn, embed_derived, embed_grid_matrix, head_derived,
+from .functional import (AdaINFn, BlockFn, EmbedFn, HeadFn, embed_derived, embed_grid_matrix, embed_layout_jobs,
+                         head_derived, head_layout_jobs,
                          mlp_pack_kind)
 
 ACTIVATIONS = ("gelu", "tanh", "sigmoid", "relu", "leaky_relu", "softplus", "ELU", "silu")
@@ -162,8 +163,21 @@ class DPOTNet(nn.Module):
             if grid is None or grid.device != self._gx.device:
                 grid = self._embed_grid = embed_grid_matrix(self._gx, self._gy, self._gt, self.img_size, self.img_size,
                                                             self.in_timesteps, self.in_channels, self.patch_size)
+        # every small layout piece of the model (padded conv weights, pos_embed^T + bias, de-embed bias per pixel, padded
+        # tail weights) in ONE launch from a device-resident job table with persistent outputs (ops.LayoutJobs)
+        lay_e = lay_h = None
+        if os.environ.get("DPOT_LAYOUT_JOBS", "1") != "0":
+            je = embed_layout_jobs(self.pos_embed, pe[0].weight, pe[0].bias, pe[2].weight, pe[2].bias)
+            jh = head_layout_jobs(ol[0].bias, ol[4].weight, ol[4].bias, self.patch_size, ol[0].weight.shape[1])
+            lj = getattr(self, "_layout_jobs", None)
+            key = tuple(j[0].data_ptr() for j in je + jh)
+            if lj is None or lj.key[:len(key)] != key:
+                lj = self._layout_jobs = ops.LayoutJobs(je + jh)
+            lay = lj.refresh()
+            lay_e, lay_h = lay[:len(je)], lay[len(je):]
         emb = embed_derived(self.pos_embed, pe[0].weight, pe[0].bias, pe[2].weight, pe[2].bias, ta.w,
-                            ta.gamma if self.time_agg == "exp_mlp" else None, self._tt, self.in_timesteps, grid=grid)
+                            ta.gamma if self.time_agg == "exp_mlp" else None, self._tt, self.in_timesteps, grid=grid,
+                            layouts=lay_e)
         # Wbig = [[Wr, Wi], [-Wi, Wr]] of every AFNO layer + its fragment-block-major forms, ONE launch for all layers
         pk = []
         if len(self.blocks):
@@ -176,7 +190,8 @@ class DPOTNet(nn.Module):
         wt_buf = getattr(self, "_wt_buf", None)
         if wt_buf is None or wt_buf.device != ol[0].weight.device or wt_buf.numel() != self.embed_dim * PP_old:
             wt_buf = self._wt_buf = torch.empty(self.embed_dim, PP_old, dtype=torch.float32, device=ol[0].weight.device)
-        head = head_derived(ol[0].weight, ol[0].bias, ol[4].weight, ol[4].bias, self.patch_size, wt_out=wt_buf)
+        head = head_derived(ol[0].weight, ol[0].bias, ol[4].weight, ol[4].bias, self.patch_size, wt_out=wt_buf,
+                            layouts=lay_h)
         mlp_pk, head_pk = self._panel_packs_refresh(wt_buf)
         d = (emb, pk, head + (head_pk,), mlp_pk)
         if self._scope_depth > 0:

@@ -202,6 +202,34 @@ class PanelPacks:
             check(lib.dpot_panel_pack_weights(self.table.data_ptr(), self.n, self.max_elems, _stream()), "pack_weights")
 
 
+class LayoutJobs:
+    """Small weight-only layout products (zero-padded copies, small transposes, bias broadcasts, "+ bias") refreshed by ONE
+    launch (dpot_layout_jobs) from a device-resident table.  jobs = [(src, add | None, (d0, d1, d2), (v0, v1, v2),
+    (s0, s1, s2))]: out[i0, i1, i2] = (inside v ? src.flat[i0 s0 + i1 s1 + i2 s2] : 0) + (add[i2] if add is not None).
+    self.out[i]: persistent [d0, d1, d2] tensors (the table stays valid while the sources do not move: self.key)."""
+
+    def __init__(self, jobs):
+        import numpy as np
+        dev = jobs[0][0].device
+        self.out = [torch.empty(d, dtype=torch.float32, device=dev) for _, _, d, _, _ in jobs]
+        self.key = tuple(j[0].data_ptr() for j in jobs) + tuple(j[1].data_ptr() for j in jobs if j[1] is not None)
+        host = np.zeros(len(jobs) * C.sizeof(_lib.LayoutJob), dtype=np.uint8)
+        tab = (_lib.LayoutJob * len(jobs)).from_buffer(host)
+        for i, ((src, add, d, v, st), dst) in enumerate(zip(jobs, self.out)):
+            t = tab[i]
+            t.src, t.add, t.dst = src.data_ptr(), (add.data_ptr() if add is not None else None), dst.data_ptr()
+            t.d0, t.d1, t.d2 = d
+            t.v0, t.v1, t.v2 = v
+            t.s0, t.s1, t.s2 = st
+        self.table = torch.from_numpy(host).to(dev)
+        self.n = len(jobs)
+        self.max_elems = max(d[0] * d[1] * d[2] for _, _, d, _, _ in jobs)
+
+    def refresh(self):
+        check(_lib.load().dpot_layout_jobs(self.table.data_ptr(), self.n, self.max_elems, _stream()), "layout_jobs")
+        return self.out
+
+
 def gemm_panel(A: Tensor, Wpacked: Tensor, N: int, *, bias: Optional[Tensor] = None, act: int = 0,
                mode: int = EPI_LINEAR, aux: Optional[Tensor] = None, res: Optional[Tensor] = None,
                save_pre: bool = False) -> Tuple[Tensor, Optional[Tensor]]:

@@ -170,6 +170,18 @@ int dpot_block_finalize(const float* afno_ws, int afno_splitk, int nb, int bs, f
                         float* db2, const float* mlp_ws, int mlp_splitk, int E, int mh, float* dW2, float* dfb2, float* dW1,
                         float* dfb1, const float* const* gn_parts, float* const* gn_dgammas, float* const* gn_dbetas,
                         int gn_jobs, int B, int Egn, dpot_stream_t stream);
+/* Small weight-only layout jobs (zero-padded copies, small transposes, bias broadcasts, "+ bias") in ONE launch from a DEVICE
+ * table: dst[i0][i1][i2] (contiguous d0 x d1 x d2) = (inside v0 x v1 x v2 ? src[i0 s0 + i1 s1 + i2 s2] : 0) + (add ? add[i2] : 0).
+ * The pieces DPOTNet derives from its parameters once per optimiser step (models/dpot.py:198-202 padded for the MFMA
+ * kernels, :378 pos_embed + bias, :315-321 de-embed bias / tail weights).  max_elems = the largest d0*d1*d2.  72 bytes. */
+typedef struct dpot_layout_job {
+  const float* src;
+  const float* add;     /* [d2] or NULL */
+  float* dst;
+  int32_t d0, d1, d2, v0, v1, v2;
+  int64_t s0, s1, s2;
+} dpot_layout_job;
+int dpot_layout_jobs(const dpot_layout_job* jobs_dev, int njobs, int64_t max_elems, dpot_stream_t stream);
 /* the split-K factor the library would pick for this shape (>= 1) */
 int dpot_gemm_auto_splitk(int M, int N, int K, int batch);
 /* the same for a given dpot_gemm_desc.precision (the bf16x6 kernel prefers fewer, larger workgroups) */

@@ -240,6 +240,32 @@ def test_block_finalize_launch_is_bit_identical(monkeypatch):
         assert torch.equal(a, b)
 
 
+def test_layout_jobs_launch_is_bit_identical(monkeypatch):
+    """round 4: the small weight-only layout pieces (padded conv weights, pos_embed^T + bias, de-embed bias per pixel, padded
+    tail weights) come from ONE launch over a device-resident job table (csrc/misc.hip layout_jobs_kernel) instead of eight
+    copy / transpose / bias launches: prediction, cls output and every gradient must not change by a bit
+    (DPOT_LAYOUT_JOBS=0), for DPOT-Tiny and for the mini config (3 channels, 16-wide tail, 4 time steps)"""
+    from dpot_amd import DPOTNet
+    for name, kw in (("TINY", R.TINY), ("MINI", R.MINI)):
+        cfg = R.DPOTConfig(**kw)
+        S = cfg.img_size
+        x = R.recipe_input((2, S, S, cfg.in_timesteps, cfg.in_channels), salt=71).cuda()
+        up = (R.recipe_input((2, S, S, cfg.out_timesteps, cfg.out_channels), salt=72) * 0.3).cuda()
+
+        def run(flag):
+            monkeypatch.setenv("DPOT_LAYOUT_JOBS", flag)
+            m = DPOTNet(**kw)
+            m.load_state_dict(R.recipe_state_dict(cfg, salt=4))
+            m.cuda()
+            xg = x.clone().requires_grad_(True)
+            y, c = m(xg)
+            ((y * up).sum() + c.sum()).backward()
+            return [y.detach(), c.detach(), xg.grad] + [p.grad for p in m.parameters()]
+
+        for a, b in zip(run("1"), run("0")):
+            assert torch.equal(a, b), name
+
+
 @pytest.fixture
 def bf16_mlp():
     from dpot_amd import ops
