@@ -44,6 +44,12 @@ CONFIGS = {
     "L": ("DPOT-Large", LARGE, 16, 1, "bf16", False, "configs[4] model, one rollout step"),
     "L20": ("DPOT-Large", LARGE, 4, 20, "bf16", True, "configs[4]"),
 }
+# how the fp32 GEMMs OUTSIDE the channel MLP form their products: the headline (T) is native fp32 MFMA everywhere; the
+# bf16-channel-MLP configs run `auto` - native fp32 MFMA below 3 GFLOP, the fp32-ACCURATE bf16x6 operand split above (de-embed
+# GEMMs, embed fold: same accuracy class as native fp32, DESIGN.md "GEMM precision modes"; parity at these sizes incl. the
+# DPOT-L batch-16 reference golden at rtol 1e-4 runs under it in tests/test_gpu_optout.py) - and report the all-native figure
+# beside it (`gemm_f32`)
+CONFIG_GEMM = {"T": "f32", "S": "auto", "M": "auto", "L": "auto", "L20": "auto"}
 FP32_MFMA_PEAK_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
 SUSTAINED_FP32_MFMA_TFLOPS = 132.8   # register-only MFMA loop, random operands (profiles/r02_mfma_f32_peak.txt)
 HBM_PEAK_GBS = 8000.0              # MI355X_MICROARCH.md: HBM3E spec
@@ -76,9 +82,10 @@ def parse():
                     help="train_temporal.py:205 noise injection (configs/pretrain_tiny.yaml:71 uses 0.0005)")
     ap.add_argument("--skip-cpu-baseline", action="store_true")
     ap.add_argument("--no-pipeline", action="store_true", help="skip the input-pipeline-inclusive timing")
-    ap.add_argument("--gemm-precision", default=os.environ.get("DPOT_GEMM_PRECISION", "f32"),
+    ap.add_argument("--gemm-precision", default=os.environ.get("DPOT_GEMM_PRECISION"),
                     choices=("f32", "bf16x6", "auto"),
-                    help="how the GEMMs form their fp32 products for the headline number (f32 = native fp32 MFMA)")
+                    help="how the fp32 GEMMs form their products (default: f32 = native fp32 MFMA for the headline config T, "
+                         "auto for S / M / L / L20 - see CONFIG_GEMM)")
     ap.add_argument("--no-alt", action="store_true", help="skip the extra timing with --gemm-precision auto")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     ap.add_argument("--no-other-configs", action="store_true",
@@ -459,6 +466,7 @@ def other_configs(args):
                         "activation_recomputation": d["config"]["activation_recomputation"],
                         "peak_mem_GB": d["config"]["peak_mem_GB"], "final_loss": d["config"]["final_loss"],
                         "model_flops_frac": d.get("model_flops_frac"),
+                        "gemm_precision": d["config"]["gemm_precision"], "gemm_f32": d.get("gemm_f32"),
                         "roofline": {k: rl.get(k) for k in ("kernel", "bound", "achieved", "peak", "unit", "frac", "traffic",
                                                             "us_per_launch", "flops_per_launch",
                                                             "algorithmic_bytes_per_launch", "traffic_note")},
@@ -500,6 +508,8 @@ def main():
         log(f"[bench] --gpus {args.gpus} but WORLD_SIZE={world}: running with the launcher's world size")
     cname, ckw, cB, T_ar, cmlp, recompute, cbase = CONFIGS[args.config]
     headline = args.config == "T"
+    if args.gemm_precision is None:
+        args.gemm_precision = CONFIG_GEMM[args.config]
     # DPOT_BENCH_DEBUG_GLOO=1: functional dry-run of the N>1 code path on a 1-GPU box (all ranks share cuda:0, gloo
     # collectives) - for testing only, never a performance number
     debug_gloo = os.environ.get("DPOT_BENCH_DEBUG_GLOO") == "1"
@@ -622,7 +632,10 @@ def main():
             "value": round(value, 2), "unit": "samples/s" if T_ar == 1 else "sample-steps/s", "n_gpus": world,
             "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(ms, 4), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f32" if mlp_prec in (None, "f32") else f"f32 (channel-MLP GEMM operands {mlp_prec})",
+            "vs_baseline": None,
+            "dtype": ("f32" if mlp_prec in (None, "f32") else f"f32 (channel-MLP GEMM operands {mlp_prec})")
+                     + ("" if args.gemm_precision == "f32" else
+                        f"; fp32 GEMMs >= 3 GFLOP as the fp32-accurate bf16x6 operand split (gemm_precision {args.gemm_precision})"),
             "data": "synthetic",
             "config": {"workload": f"{cname} (embed {ckw['embed_dim']}, depth {ckw['depth']}, n_blocks {ckw['n_blocks']}, "
                                    f"modes {ckw['modes']}, patch 8, mlp_ratio {ckw['mlp_ratio']}) on synthetic ns2d-shaped "
@@ -686,6 +699,26 @@ def main():
         except Exception as e:                                 # pragma: no cover
             log(f"[bench] roofline probe failed: {e}")
             out["roofline"] = None
+        if not headline and world == 1 and graphed is not None and args.gemm_precision == "auto" and not args.no_alt:
+            # the bf16-channel-MLP configs run `auto`; the same step with every fp32 GEMM on native fp32 MFMA, beside it
+            try:
+                ops.set_gemm_precision("f32")
+                g2 = GraphedTrainStep(model, opt, xx, yy, msk, noise_scale=args.noise_scale, warmup=1 if T_ar > 1 else 2)
+                for _ in range(args.warmup):
+                    g2.replay(lr_at(step_idx[0]))
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                for _ in range(args.steps):
+                    g2.replay(lr_at(step_idx[0]))
+                torch.cuda.synchronize()
+                e2 = time.perf_counter() - t1
+                out["gemm_f32"] = {"gemm_precision": "f32 (native fp32 MFMA for every GEMM outside the channel MLP)",
+                                   "value": round(B * T_ar * args.steps / e2, 2), "ms_per_step": round(e2 / args.steps * 1e3, 4)}
+                del g2
+            except Exception as e:                             # pragma: no cover
+                log(f"[bench] gemm_f32 timing failed: {e}")
+            finally:
+                ops.set_gemm_precision(args.gemm_precision)
         if headline and world == 1 and graphed is not None and args.gemm_precision == "f32" and not args.no_alt \
                 and not args.brief:
             # not the headline: the same step with the large GEMMs on the bf16x6 kernel (fp32 emulated by operand

@@ -31,6 +31,11 @@ SWITCHES = {
     # un-paired weight gradients
     "DPOT_BF16P_BD_CPW=1 DPOT_BF16P_RASTER=0 DPOT_BF16P_TILE192=0 DPOT_BF16P_PAIR=0":
         ("test_bf16_channel_mlp_mode_vs_oracle and (MEDIUM-32 or MEDIUM-1)", False),
+    # not an opt-OUT but the mode `bench.py --config S|M|L|L20` runs: fp32 GEMMs >= 3 GFLOP on the fp32-accurate bf16x6 operand
+    # split (`auto`).  The DPOT-L batch-16 reference golden (fp32 path at rtol 1e-4, then the bf16 channel-MLP mode) and the
+    # S / M gradient cases against the oracle must hold under it as they do with native fp32 MFMA
+    "DPOT_GEMM_PRECISION=auto": (LARGE_SET + " or test_full_model_gradients_vs_oracle and (TINY-32 or SMALL-1 or MEDIUM-1)"
+                                 " or test_bf16_channel_mlp_mode_vs_oracle and MEDIUM-1", False),
     "DPOT_AFNO_3MULT=0": (SMALL_SET, True),               # four-product fused mixer
     "DPOT_AFNO_FUSED=0": (SMALL_SET, True),               # two generic GEMM launches per mixer
     # separate GroupNorm / DFT kernels, GroupNorm never applied on load, generic GEMM instead of the panel / weight-
