@@ -253,11 +253,14 @@ __device__ __forceinline__ void epi_fragment_direct(const Bf16pArgs& p, int m0f,
     __builtin_amdgcn_sched_barrier(0);
   }
 #ifndef PB_ABL_NOSTORE
+#ifndef PB_ABL_NODACT
   if (want_d) {
     uint4* dp = p.dact_out + frag * 128 + lane;
     st_chunk(dp, dq[0], dq[1], dq[2], dq[3]);
     st_chunk(dp + 64, dq[4], dq[5], dq[6], dq[7]);
   }
+#endif
+#ifndef PB_ABL_NOTRANS
   if (p.out_trans) {
     // packed pairs w[k] = rows (2k, 2k+1 of this lane's 16).  Lane kh = 0 completes row octets 0 and 2, kh = 1 octets 1
     // and 3: swap the upper half-wave of X = w[a] with the lower half-wave of Y = w[a + 2], a in {0, 1, 4, 5} - then
@@ -277,6 +280,7 @@ __device__ __forceinline__ void epi_fragment_direct(const Bf16pArgs& p, int m0f,
     st_chunk(tp + 64, X[2], X[3], Y[2], Y[3]);
   }
 #endif
+#endif
   if (p.cs_part) {      // column sums of the fragment's 32 rows: 16 in the lane (fixed order), then the two half-waves
     cs += __shfl_xor(cs, 32);
     if (kh == 0) p.cs_part[(long long)(m0f >> 5) * p.N + n0f + li] = cs;
@@ -285,7 +289,7 @@ __device__ __forceinline__ void epi_fragment_direct(const Bf16pArgs& p, int m0f,
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-#ifndef PB_ABL_NOSTORE
+#if !defined(PB_ABL_NOSTORE) && !defined(PB_ABL_NOROWS)
     if (p.out_rows) {   // instruction s2 writes block s2 whole: lane l = chunk (row l & 31, column octet 2 s2 + (l >> 5))
 #pragma unroll
       for (int s2 = 0; s2 < 2; ++s2) {

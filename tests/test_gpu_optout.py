@@ -15,7 +15,7 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 SMALL_SET = ("test_full_model_gradients_vs_oracle and (TINY-32 or SMALL-1) or "
-             "test_bf16_channel_mlp_mode_vs_oracle and (MEDIUM-1 or TINY-32) or test_tiny_at_other_resolutions_vs_oracle")
+             "test_bf16_channel_mlp_mode_vs_oracle and MEDIUM-1 or test_tiny_at_other_resolutions_vs_oracle and 64-3")
 LARGE_SET = "test_large_batch16_vs_reference_golden"
 
 # switch group (set together in one child: they act on different kernels) -> (-k expression over test_gpu_sizes.py, also
