@@ -151,7 +151,7 @@ SIGNATURES = {
     "dpot_afno_wgrad2_ws_elems": (c_i64, [c_i] * 3),
     "dpot_afno_wgrad2": (c_i, [c_fp] * 4 + [c_i] * 4 + [c_fp] * 5 + [c_i, c_fp]),
     "dpot_block_finalize": (c_i, [c_fp, c_i, c_i, c_i] + [c_fp] * 4 + [c_fp, c_i, c_i, c_i] + [c_fp] * 4 + [c_fp] * 3
-                            + [c_i, c_i, c_i, c_fp]),
+                            + [c_i, c_i, c_i] + [c_fp] * 4 + [c_i, c_fp]),
     "dpot_bf16_pack_both_supported": (c_i, [c_i, c_i]),
     "dpot_bf16_pack_both": (c_i, [c_fp, c_i, c_i, c_i, c_fp, c_fp, c_fp, c_fp]),
     "dpot_bf16_pack_both_norm": (c_i, [c_fp, c_i, c_i, c_i, c_fp, c_fp, c_fp, c_fp, c_i, c_i, c_fp, c_fp, c_fp]),

@@ -589,7 +589,26 @@ struct FinalizeArgs {
   const float* m_ws; int m_splits, m_E, m_mh; float *m_dW2, *m_dW1, *m_db2, *m_db1; int nM;
   // slice G: GroupNorm parameter gradients (dpot_groupnorm_param_grads): g_jobs jobs x ceil(E / 64) workgroups
   const float* g_part[2]; float* g_dgamma[2]; float* g_dbeta[2]; int g_jobs, g_B, g_E, nG;
+  // slice C: column sums of up to two partial matrices [rows, N] (the bias gradients of the bf16 channel MLP, whose
+  // producers - the pack pass and the GEMM epilogue - leave per-row-tile partial sums): out[n] = sum_r part[r, n]
+  const float* c_part[2]; float* c_out[2]; int c_rows[2], c_N[2], c_blocks[2];
 };
+// four accumulators over r mod 4 (memory-level parallelism), combined in a fixed order
+__device__ __forceinline__ void colsum_rows_body(int bx, const float* __restrict__ part, float* __restrict__ out, int rows,
+                                                 int N) {
+  const int n = bx * 256 + threadIdx.x;
+  if (n >= N) return;
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  int r = 0;
+  for (; r + 3 < rows; r += 4) {
+    s0 += part[(long long)r * N + n];
+    s1 += part[(long long)(r + 1) * N + n];
+    s2 += part[(long long)(r + 2) * N + n];
+    s3 += part[(long long)(r + 3) * N + n];
+  }
+  for (; r < rows; ++r) s0 += part[(long long)r * N + n];
+  out[n] = (s0 + s1) + (s2 + s3);
+}
 // = norm.hip groupnorm_param_grad_kernel: block = 64 channels x 4 sample lanes, fixed order
 __device__ __forceinline__ void gn_param_grad_body(int bx, const float* __restrict__ part, float* __restrict__ dgamma,
                                                    float* __restrict__ dbeta, int B, int E) {
@@ -624,10 +643,15 @@ __global__ __launch_bounds__(256) void block_finalize_kernel(const FinalizeArgs 
     afno_wgrad2_reduce_body(b, a.nA, a.a_ws, a.a_splits, a.a_nb, a.a_bs, a.a_dw1, a.a_db1, a.a_dw2, a.a_db2);
   } else if (b < a.nA + a.nM) {
     mlp_wgrad2_reduce_body(b - a.nA, a.nM, a.m_ws, a.m_splits, a.m_E, a.m_mh, a.m_dW2, a.m_dW1, a.m_db2, a.m_db1);
-  } else {
+  } else if (b < a.nA + a.nM + a.nG) {
     const int g = b - a.nA - a.nM, per = (a.g_E + 63) / 64;
     const int job = g / per;
     gn_param_grad_body(g - job * per, a.g_part[job], a.g_dgamma[job], a.g_dbeta[job], a.g_B, a.g_E);
+  } else {
+    int c = b - a.nA - a.nM - a.nG;
+    const int job = c >= a.c_blocks[0] ? 1 : 0;
+    c -= job * a.c_blocks[0];
+    colsum_rows_body(c, a.c_part[job], a.c_out[job], a.c_rows[job], a.c_N[job]);
   }
 }
 }  // namespace dpot
@@ -685,8 +709,18 @@ extern "C" int dpot_mlp_wgrad2(const float* do2, const float* Hh, const float* x
 extern "C" int dpot_block_finalize(const float* afno_ws, int afno_splitk, int nb, int bs, float* dw1, float* db1, float* dw2,
                                    float* db2, const float* mlp_ws, int mlp_splitk, int E, int mh, float* dW2, float* dfb2,
                                    float* dW1, float* dfb1, const float* const* gn_parts, float* const* gn_dgammas,
-                                   float* const* gn_dbetas, int gn_jobs, int B, int Egn, dpot_stream_t stream) {
+                                   float* const* gn_dbetas, int gn_jobs, int B, int Egn, const float* const* cs_parts,
+                                   float* const* cs_outs, const int* cs_rows, const int* cs_cols, int cs_jobs,
+                                   dpot_stream_t stream) {
   FinalizeArgs a{};
+  if (cs_jobs > 0) {
+    DPOT_REQUIRE(cs_jobs <= 2 && cs_parts && cs_outs && cs_rows && cs_cols, "block_finalize: bad column-sum slice");
+    for (int i = 0; i < cs_jobs; ++i) {
+      DPOT_REQUIRE(cs_parts[i] && cs_outs[i] && cs_rows[i] > 0 && cs_cols[i] > 0, "block_finalize: bad column-sum job %d", i);
+      a.c_part[i] = cs_parts[i]; a.c_out[i] = cs_outs[i]; a.c_rows[i] = cs_rows[i]; a.c_N[i] = cs_cols[i];
+      a.c_blocks[i] = (cs_cols[i] + 255) / 256;
+    }
+  }
   if (afno_ws) {
     DPOT_REQUIRE(afno_splitk >= 1 && nb > 0 && bs > 0 && dw1 && db1 && dw2 && db2, "block_finalize: bad AFNO slice");
     a.a_ws = afno_ws; a.a_splits = afno_splitk; a.a_nb = nb; a.a_bs = bs; a.a_dw1 = dw1; a.a_db1 = db1; a.a_dw2 = dw2; a.a_db2 = db2;
@@ -708,7 +742,7 @@ extern "C" int dpot_block_finalize(const float* afno_ws, int afno_splitk, int nb
     }
     a.g_jobs = gn_jobs; a.g_B = B; a.g_E = Egn; a.nG = gn_jobs * ((Egn + 63) / 64);
   }
-  const int total = a.nA + a.nM + a.nG;
+  const int total = a.nA + a.nM + a.nG + a.c_blocks[0] + a.c_blocks[1];
   DPOT_REQUIRE(total > 0, "block_finalize: nothing to do");
   hipLaunchKernelGGL(block_finalize_kernel, dim3((unsigned)total), dim3(256), 0, as_stream(stream), a);
   return check_launch("block_finalize_kernel");

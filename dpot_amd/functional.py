@@ -598,7 +598,8 @@ class BlockFn(torch.autograd.Function):
         if bf16p and xn2.dtype == torch.bfloat16:
             # pack-both path (see _block_parts): xn2 / Hh ARE the transposed bf16 packs; each gradient is packed once, in
             # both forms, and its bias column sums come out of the same pass
-            dop, dopT, df2b = ops.bf16_pack_both(do2, want_colsum=True, colsum_out=s_f2b.out())
+            dcs = pending is not None          # bias column sums: partials now, summed by the block's finalising launch
+            dop, dopT, df2b = ops.bf16_pack_both(do2, want_colsum=True, colsum_out=s_f2b.out(), defer_colsum=dcs)
             # both weight gradients in ONE launch once dHpre's pack exists, when each alone would need split-K
             pair = ops.gemm_bf16p_pair_wanted(E, mh, mh, E, M)
             if not pair:
@@ -606,14 +607,18 @@ class BlockFn(torch.autograd.Function):
             # dHpre = (do2 W2) * act'(Hpre) leaves the GEMM as its two packs + bias column sums only
             _, _, dhp, dhpT, df1b = ops.gemm_bf16p_packed(dop, mlp_pk[3], M, mh, E, act=act, mode=EPI_DACT, dact=Hpre,
                                                           pack_rows=True, pack_trans=True, colsum=True,
-                                                          colsum_out=s_f1b.out(), store=False)
+                                                          colsum_out=s_f1b.out(), store=False, defer_colsum=dcs)
+            if dcs:
+                pending["cs"] = [df2b, df1b]
+                df2b, df1b = df2b[3], df1b[3]
             if pair:
                 df2w, df1w = ops.gemm_bf16p_pair(dopT, Hh, E, mh, dhpT, xn2, mh, E, M, out0=s_f2w.out(), out1=s_f1w.out())
             else:
                 df1w, _ = ops.gemm_bf16p(dhpT, xn2, mh, E, M, out=s_f1w.out())
             del dop, dopT
-            df2w, df2b = s_f2w.done(df2w.view(E, mh, 1, 1)), s_f2b.done(df2b)
-            df1w, df1b = s_f1w.done(df1w.view(mh, E, 1, 1)), s_f1b.done(df1b)
+            df2w, df1w = s_f2w.done(df2w.view(E, mh, 1, 1)), s_f1w.done(df1w.view(mh, E, 1, 1))
+            if not dcs:
+                df2b, df1b = s_f2b.done(df2b), s_f1b.done(df1b)
             dxn2, _ = ops.gemm_bf16p(dhp, mlp_pk[1], M, E, mh)
             del dhp, dhpT
         else:
@@ -671,7 +676,10 @@ class BlockFn(torch.autograd.Function):
             dx, gn1_part = ops.groupnorm_bwd(dxn1, x, mean1, rstd1, n1w, add=dout, defer=True)
         gn_jobs = [(gn1_part, s_n1w.out(), s_n1b.out()), (gn2_part, s_n2w.out(), s_n2b.out())]
         if pending:
-            (dn1w, dn1b), (dn2w, dn2b) = ops.block_finalize(pending.get("afno"), pending.get("mlp"), gn_jobs)
+            (dn1w, dn1b), (dn2w, dn2b) = ops.block_finalize(pending.get("afno"), pending.get("mlp"), gn_jobs,
+                                                            pending.get("cs", ()))
+            if "cs" in pending:
+                df2b, df1b = s_f2b.done(df2b), s_f1b.done(df1b)
             if "mlp" in pending:
                 df2w, df2b = s_f2w.done(df2w.view(E, mh, 1, 1)), s_f2b.done(df2b)
                 df1w, df1b = s_f1w.done(df1w.view(mh, E, 1, 1)), s_f1b.done(df1b)

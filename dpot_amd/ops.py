@@ -282,7 +282,7 @@ def bf16_pack_both_supported(rows: int, K: int) -> bool:
 
 
 def bf16_pack_both(x: Tensor, want_rows: bool = True, want_trans: bool = True, colsum_out: Optional[Tensor] = None,
-                   want_colsum: bool = False, norm=None):
+                   want_colsum: bool = False, norm=None, defer_colsum: bool = False):
     """one pass over x [M, K] fp32 -> (row-form pack | None, transposed pack | None, column sums | None): the two operand
     forms the bf16 channel MLP needs of an activation (data GEMM and weight gradient) and its bias gradient.
     norm = (mean [B,G], rstd [B,G], gamma [K], beta [K], rows_per_sample): the packs of GroupNorm(x) with those statistics
@@ -300,6 +300,8 @@ def bf16_pack_both(x: Tensor, want_rows: bool = True, want_trans: bool = True, c
         return pr, pt, None
     part = torch.empty(M // 64, K, dtype=torch.float32, device=x.device) if want_colsum else None
     check(lib.dpot_bf16_pack_both(x.data_ptr(), x.stride(0), M, K, _p(pr), _p(pt), _p(part), _stream()), "bf16_pack_both")
+    if want_colsum and defer_colsum:      # the column sums are left as partials: (part, rows, N, out) for `block_finalize`
+        return pr, pt, (part, M // 64, K, _out(colsum_out, (K,), x.device))
     cs = colsum(part, M // 64, K, out=colsum_out) if want_colsum else None
     return pr, pt, cs
 
@@ -339,7 +341,7 @@ def gemm_bf16p_packed(Ap: Tensor, Wp: Tensor, M: int, N: int, K: int, *, bias: O
                       save_pre: bool = False, out: Optional[Tensor] = None, splitk: Optional[int] = None,
                       planes: int = 1, pack_rows: bool = False, pack_trans: bool = False, colsum: bool = False,
                       colsum_out: Optional[Tensor] = None, store: bool = True, save_dact: bool = False,
-                      dact: Optional[Tensor] = None):
+                      dact: Optional[Tensor] = None, defer_colsum: bool = False):
     """gemm_bf16p whose epilogue can ALSO emit the packed forms of the output and its column sums
     (pack_rows / pack_trans / colsum: planes == 1, M % 32 == 0, no split-K); store=False skips the fp32 output.
     save_dact (EPI_ACT): instead of the fp32 pre-activation, the second return value is act'(pre) as a packed bf16
@@ -361,7 +363,10 @@ def gemm_bf16p_packed(Ap: Tensor, Wp: Tensor, M: int, N: int, K: int, *, bias: O
                               res.stride(0) if res is not None else 0, _p(pre), N, _p(C_), N, M, N, K,
                               act, mode, planes, splitk, _p(ws), _p(pr), _p(pt), _p(part), _p(dout), _p(dact),
                               _stream()), "gemm_bf16p")
-    cs = globals()["colsum"](part, M // 32, N, out=colsum_out) if colsum else None
+    if colsum and defer_colsum:           # (part, rows, N, out) for `block_finalize`
+        cs = (part, M // 32, N, _out(colsum_out, (N,), Ap.device))
+    else:
+        cs = globals()["colsum"](part, M // 32, N, out=colsum_out) if colsum else None
     return C_, (dout if save_dact else pre), pr, pt, cs
 
 
@@ -603,11 +608,12 @@ def afno_wgrad2(S: Tensor, dO1pre: Tensor, O1: Tensor, dO2: Tensor, nb: int, bs:
     return (ws, splitk, nb, bs, dw1, db1, dw2, db2) if defer else None
 
 
-def block_finalize(afno_job, mlp_job, gn_jobs):
+def block_finalize(afno_job, mlp_job, gn_jobs, cs_jobs=()):
     """ONE launch for the reductions that end a DPOT block's backward (csrc/gemm_tn.hip block_finalize_kernel): the deferred
     split-K partials of `afno_wgrad2` and / or `mlp_wgrad2` (jobs as those return them, or None) and the GroupNorm
-    parameter-gradient partials gn_jobs = [(part [2,B,E], out_dgamma | None, out_dbeta | None)] (<= 2).  Returns the
-    GroupNorm outputs [(dgamma, dbeta)]; the weight-gradient outputs are the tensors handed to the deferred calls."""
+    parameter-gradient partials gn_jobs = [(part [2,B,E], out_dgamma | None, out_dbeta | None)] (<= 2), and the deferred
+    column sums cs_jobs of `bf16_pack_both` / `gemm_bf16p_packed` (defer_colsum=True; <= 2).  Returns the GroupNorm outputs
+    [(dgamma, dbeta)]; the other outputs are the tensors handed to / returned by the deferred calls."""
     null = None
     a = afno_job if afno_job is not None else (None, 0, 0, 0, None, None, None, None)
     m = mlp_job if mlp_job is not None else (None, 0, 0, 0, None, None, None, None)
@@ -620,9 +626,17 @@ def block_finalize(afno_job, mlp_job, gn_jobs):
         parts = (C.c_void_p * n)(*[p.data_ptr() for p, _, _ in gn_jobs])
         dgs = (C.c_void_p * n)(*[g.data_ptr() for g, _ in outs])
         dbs = (C.c_void_p * n)(*[b.data_ptr() for _, b in outs])
+    nc = len(cs_jobs)                              # [(part [rows, N], rows, N, out [N])] (<= 2): deferred column sums
+    cparts = couts = crows = ccols = null
+    if nc:
+        cparts = (C.c_void_p * nc)(*[j[0].data_ptr() for j in cs_jobs])
+        couts = (C.c_void_p * nc)(*[j[3].data_ptr() for j in cs_jobs])
+        crows = (C.c_int * nc)(*[j[1] for j in cs_jobs])
+        ccols = (C.c_int * nc)(*[j[2] for j in cs_jobs])
     check(_lib.load().dpot_block_finalize(_p(a[0]), a[1], a[2], a[3], _p(a[4]), _p(a[5]), _p(a[6]), _p(a[7]),
                                           _p(m[0]), m[1], m[2], m[3], _p(m[4]), _p(m[5]), _p(m[6]), _p(m[7]),
-                                          parts, dgs, dbs, n, B, E, _stream()), "block_finalize")
+                                          parts, dgs, dbs, n, B, E, cparts, couts, crows, ccols, nc, _stream()),
+          "block_finalize")
     return outs
 
 

@@ -165,11 +165,14 @@ int dpot_afno_wgrad2(const float* S, const float* dO1pre, const float* O1, const
  * finalising launch per DPOT block then runs, in three slices of one grid, the fixed-order reductions that end the block's
  * backward (models/dpot.py:165-180): the AFNO weight-gradient partials (afno_ws != NULL; outputs as dpot_afno_wgrad2), the
  * channel-MLP ones (mlp_ws != NULL; as dpot_mlp_wgrad2) and the GroupNorm parameter gradients of gn_jobs <= 2 layers
- * (as dpot_groupnorm_param_grads).  Same summation orders as the stand-alone reductions: bit-identical results. */
+ * (as dpot_groupnorm_param_grads) - same summation orders as the stand-alone reductions: bit-identical results - and the column
+ * sums out[n] = sum_r part[r, n] of cs_jobs <= 2 partial matrices [cs_rows, cs_cols] (the bias gradients of the bf16 channel
+ * MLP, whose pack pass / GEMM epilogue leave per-row-tile partial sums; fixed order: four accumulators over r mod 4). */
 int dpot_block_finalize(const float* afno_ws, int afno_splitk, int nb, int bs, float* dw1, float* db1, float* dw2,
                         float* db2, const float* mlp_ws, int mlp_splitk, int E, int mh, float* dW2, float* dfb2, float* dW1,
                         float* dfb1, const float* const* gn_parts, float* const* gn_dgammas, float* const* gn_dbetas,
-                        int gn_jobs, int B, int Egn, dpot_stream_t stream);
+                        int gn_jobs, int B, int Egn, const float* const* cs_parts, float* const* cs_outs, const int* cs_rows,
+                        const int* cs_cols, int cs_jobs, dpot_stream_t stream);
 /* Small weight-only layout jobs (zero-padded copies, small transposes, bias broadcasts, "+ bias") in ONE launch from a DEVICE
  * table: dst[i0][i1][i2] (contiguous d0 x d1 x d2) = (inside v0 x v1 x v2 ? src[i0 s0 + i1 s1 + i2 s2] : 0) + (add ? add[i2] : 0).
  * The pieces DPOTNet derives from its parameters once per optimiser step (models/dpot.py:198-202 padded for the MFMA
