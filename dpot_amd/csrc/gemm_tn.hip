@@ -593,21 +593,35 @@ struct FinalizeArgs {
   // producers - the pack pass and the GEMM epilogue - leave per-row-tile partial sums): out[n] = sum_r part[r, n]
   const float* c_part[2]; float* c_out[2]; int c_rows[2], c_N[2], c_blocks[2];
 };
-// four accumulators over r mod 4 (memory-level parallelism), combined in a fixed order
+// a workgroup = 32 columns x 8 row lanes (128-byte row segments); a lane strides the rows by 8 with four accumulators
+// (four loads in flight), the eight lanes of a column are combined through LDS in a fixed order.  (One thread per column
+// over all rows - 16 workgroups of 256 dependent loads at DPOT-M - made the whole finalising launch slower than the
+// launches it replaced: DPOT-M 13.23 -> 13.38 ms, profiles/r04_block_finalize_colsum.txt.)
+constexpr int CS_COLS = 32, CS_LANES = 8;
 __device__ __forceinline__ void colsum_rows_body(int bx, const float* __restrict__ part, float* __restrict__ out, int rows,
                                                  int N) {
-  const int n = bx * 256 + threadIdx.x;
-  if (n >= N) return;
+  __shared__ float red[CS_LANES][CS_COLS];
+  const int tc = threadIdx.x % CS_COLS, tr = threadIdx.x / CS_COLS;
+  const int n = bx * CS_COLS + tc;
   float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-  int r = 0;
-  for (; r + 3 < rows; r += 4) {
-    s0 += part[(long long)r * N + n];
-    s1 += part[(long long)(r + 1) * N + n];
-    s2 += part[(long long)(r + 2) * N + n];
-    s3 += part[(long long)(r + 3) * N + n];
+  if (n < N) {
+    int r = tr;
+    for (; r + 3 * CS_LANES < rows; r += 4 * CS_LANES) {
+      s0 += part[(long long)r * N + n];
+      s1 += part[(long long)(r + CS_LANES) * N + n];
+      s2 += part[(long long)(r + 2 * CS_LANES) * N + n];
+      s3 += part[(long long)(r + 3 * CS_LANES) * N + n];
+    }
+    for (; r < rows; r += CS_LANES) s0 += part[(long long)r * N + n];
   }
-  for (; r < rows; ++r) s0 += part[(long long)r * N + n];
-  out[n] = (s0 + s1) + (s2 + s3);
+  red[tr][tc] = (s0 + s1) + (s2 + s3);
+  __syncthreads();
+  if (tr == 0 && n < N) {
+    float v = 0.f;
+#pragma unroll
+    for (int k = 0; k < CS_LANES; ++k) v += red[k][tc];
+    out[n] = v;
+  }
 }
 // = norm.hip groupnorm_param_grad_kernel: block = 64 channels x 4 sample lanes, fixed order
 __device__ __forceinline__ void gn_param_grad_body(int bx, const float* __restrict__ part, float* __restrict__ dgamma,
@@ -718,7 +732,7 @@ extern "C" int dpot_block_finalize(const float* afno_ws, int afno_splitk, int nb
     for (int i = 0; i < cs_jobs; ++i) {
       DPOT_REQUIRE(cs_parts[i] && cs_outs[i] && cs_rows[i] > 0 && cs_cols[i] > 0, "block_finalize: bad column-sum job %d", i);
       a.c_part[i] = cs_parts[i]; a.c_out[i] = cs_outs[i]; a.c_rows[i] = cs_rows[i]; a.c_N[i] = cs_cols[i];
-      a.c_blocks[i] = (cs_cols[i] + 255) / 256;
+      a.c_blocks[i] = (cs_cols[i] + CS_COLS - 1) / CS_COLS;
     }
   }
   if (afno_ws) {
