@@ -394,11 +394,11 @@ def _mixer_core_bwd(dO2, S, O1pre, O1, wb1, wb2, dims, fused, afno_layout, sinks
     return dS, dw1, db1, dw2, db2
 
 
-def _mixer_bwd(dy1, S, O1pre, O1, wb1, wb2, dims, fused, afno_layout, sinks):
-    """backward of _mixer_fwd: returns (dxn1 = adjoint-rfft2(dS) + dy1, dw1, db1, dw2, db2)"""
+def _mixer_bwd(dy1, S, O1pre, O1, wb1, wb2, dims, fused, afno_layout, sinks, pending=None):
+    """backward of _mixer_fwd: returns (dxn1 = adjoint-rfft2(dS) + dy1, dw1, db1, dw2, db2); pending: see _mixer_core_bwd"""
     B, tok, E, h, w, nb, bs, mx, my, mh, act = dims
     dO2 = ops.rfft2(dy1, h, w, nb, mx, my, 1)                              # adjoint of irfft2
-    dS, dw1, db1, dw2, db2 = _mixer_core_bwd(dO2, S, O1pre, O1, wb1, wb2, dims, fused, afno_layout, sinks)
+    dS, dw1, db1, dw2, db2 = _mixer_core_bwd(dO2, S, O1pre, O1, wb1, wb2, dims, fused, afno_layout, sinks, pending)
     dxn1 = ops.irfft2(dS, B, h, w, E, nb, mx, my, 0, res=dy1)              # adjoint of rfft2, + skip path
     return dxn1, dw1, db1, dw2, db2
 
@@ -672,7 +672,7 @@ class BlockFn(torch.autograd.Function):
             dy1, gn2_part = ops.groupnorm_bwd(dxn2.view(B, tok, E), y1, mean2, rstd2, n2w, defer=True)
             # AFNO mixer
             dxn1, dw1, db1, dw2, db2 = _mixer_bwd(dy1, S, O1pre, O1, wb1, wb2, ctx.dims, ctx.fused_mixer,
-                                                  ctx.afno_layout, (s_w1, s_b1, s_w2, s_b2))
+                                                  ctx.afno_layout, (s_w1, s_b1, s_w2, s_b2), pending)
             dx, gn1_part = ops.groupnorm_bwd(dxn1, x, mean1, rstd1, n1w, add=dout, defer=True)
         gn_jobs = [(gn1_part, s_n1w.out(), s_n1b.out()), (gn2_part, s_n2w.out(), s_n2b.out())]
         if pending:
