@@ -19,28 +19,26 @@ SMALL_SET = ("test_full_model_gradients_vs_oracle and (TINY-32 or SMALL-1) or "
 LARGE_SET = "test_large_batch16_vs_reference_golden"
 
 # switch group (set together in one child: they act on different kernels) -> (-k expression over test_gpu_sizes.py, also
-# run the golden-vector model tests of test_gpu_model.py?)
+# run the golden-vector model tests of test_gpu_model.py?).  Four children: the round-end GPU gate has to stay short.
 SWITCHES = {
     # bf16 channel-MLP kernels.  Default since round 4: the B-direct kernels (W fragments straight into registers).
     # BD=0: the LDS-DMA kernels of rounds 2-3 in their own default selection (two-workgroup kernel, 128 x 192 tiles, pairs)
     "DPOT_BF16P_BD=0": (LARGE_SET, False),
-    # ... and with the 12-wave kernel for every launch, 128 x 256 tiles only, un-paired weight gradients
-    "DPOT_BF16P_BD=0 DPOT_BF16P_DUO=0 DPOT_BF16P_TILE192=0 DPOT_BF16P_PAIR=0":
-        ("test_bf16_channel_mlp_mode_vs_oracle and (SMALL-32 or MEDIUM-1)", False),
-    # B-direct with eight 128 x 32 waves everywhere (no two-workgroup form), column-major tile order, 128 x 256 tiles only,
-    # un-paired weight gradients
-    "DPOT_BF16P_BD_CPW=1 DPOT_BF16P_RASTER=0 DPOT_BF16P_TILE192=0 DPOT_BF16P_PAIR=0":
-        ("test_bf16_channel_mlp_mode_vs_oracle and (MEDIUM-32 or MEDIUM-1)", False),
     # not an opt-OUT but the mode `bench.py --config S|M|L|L20` runs: fp32 GEMMs >= 3 GFLOP on the fp32-accurate bf16x6 operand
     # split (`auto`).  The DPOT-L batch-16 reference golden (fp32 path at rtol 1e-4, then the bf16 channel-MLP mode) and the
-    # S / M gradient cases against the oracle must hold under it as they do with native fp32 MFMA
-    "DPOT_GEMM_PRECISION=auto": (LARGE_SET + " or test_full_model_gradients_vs_oracle and (TINY-32 or SMALL-1 or MEDIUM-1)"
+    # Tiny / M gradient cases against the oracle must hold under it as they do with native fp32 MFMA
+    "DPOT_GEMM_PRECISION=auto": (LARGE_SET + " or test_full_model_gradients_vs_oracle and TINY-32"
                                  " or test_bf16_channel_mlp_mode_vs_oracle and MEDIUM-1", False),
-    "DPOT_AFNO_3MULT=0": (SMALL_SET, True),               # four-product fused mixer
-    "DPOT_AFNO_FUSED=0": (SMALL_SET, True),               # two generic GEMM launches per mixer
-    # separate GroupNorm / DFT kernels, GroupNorm never applied on load, generic GEMM instead of the panel / weight-
-    # gradient kernels, explicit patch matrix instead of the implicit-GEMM embedding
-    "DPOT_GN_DFT=0 DPOT_GN_ONLOAD=0 DPOT_PANEL_GEMM=0 DPOT_GEMM_TN=0 DPOT_EMBED_IMPLICIT=0": (SMALL_SET, True),
+    # every round-3/4 fallback at once: four-product fused mixer, separate GroupNorm / DFT kernels, GroupNorm never applied
+    # on load, generic GEMM instead of the panel / weight-gradient kernels, explicit patch matrix, three reduce launches per
+    # block, eight layout launches, B-direct with eight waves everywhere / column-major order / 256-wide tiles / un-paired
+    ("DPOT_AFNO_3MULT=0 DPOT_GN_DFT=0 DPOT_GN_ONLOAD=0 DPOT_PANEL_GEMM=0 DPOT_GEMM_TN=0 DPOT_EMBED_IMPLICIT=0 "
+     "DPOT_BLOCK_FINALIZE=0 DPOT_LAYOUT_JOBS=0 DPOT_BF16P_BD_CPW=1 DPOT_BF16P_RASTER=0 DPOT_BF16P_ROWMAJOR=0 "
+     "DPOT_BF16P_TILE192=0 DPOT_BF16P_PAIR=0"): (SMALL_SET, True),
+    # the mixer as two generic GEMM launches, and the LDS-DMA bf16 kernels with the 12-wave kernel for every launch, 128 x 256
+    # tiles only, un-paired weight gradients
+    "DPOT_AFNO_FUSED=0 DPOT_BF16P_BD=0 DPOT_BF16P_DUO=0 DPOT_BF16P_TILE192=0 DPOT_BF16P_PAIR=0":
+        (SMALL_SET + " or test_bf16_channel_mlp_mode_vs_oracle and SMALL-32", True),
 }
 
 
