@@ -338,6 +338,12 @@ def _mixer_fwd(xn1, packed, dims, afno_layout=None, norm=None):
     norm = (mean, rstd, gamma, beta): xn1 is the UN-normalised block input and both DFT kernels apply GroupNorm1 on their
     loads (the transform's input and the residual) - the normalised field is never written"""
     B, tok, E, h, w, nb, bs, mx, my, mh, act = dims
+    lay = afno_layout if afno_layout is not None else getattr(packed[0], "layout", 0)
+    if norm is None and packed[0][2] is not None and ops.afno_fused_supported(h, w, E, nb, mx, my, G=0, B=B, layout=lay):
+        # the whole mixer in ONE launch (csrc/afno_fused.hip, SURVEY 8 f4), spectrum and hidden layer on chip
+        S, O1pre, y1 = ops.afno_fused_fwd(xn1, None, None, packed[0][2], packed[0][1], packed[1][2], packed[1][1], None,
+                                          None, h, w, nb, mx, my, act)[:3]
+        return y1, S, O1pre, None
     S = ops.rfft2(xn1, h, w, nb, mx, my, 0, norm=norm)                     # [Mm, 2E]
     O2, O1pre, O1 = _mixer_core(S, packed, dims, afno_layout)
     y1 = ops.irfft2(O2, B, h, w, E, nb, mx, my, 1, res=xn1, res_norm=norm)  # + x_orig (the normalised input)
@@ -437,7 +443,7 @@ class AFNO2DFn(torch.autograd.Function):
 
 
 def _block_parts(x, n1w, n1b, n2w, n2b, f1w, f1b, packed, dims, mp, need_out, f2w=None, f2b=None, mlp_pk=None,
-                 afno_layout=None):
+                 afno_layout=None, save=True):
     """forward of one Block up to (and optionally including) the second channel-MLP GEMM; returns every intermediate
     the backward needs.  Called by BlockFn.forward, and again by BlockFn.backward when activations are recomputed."""
     B, tok, E, h, w, nb, bs, mx, my, mh, act = dims
@@ -452,7 +458,16 @@ def _block_parts(x, n1w, n1b, n2w, n2b, f1w, f1b, packed, dims, mp, need_out, f2
     # the statistics anyway (32x32 latent grid: statistics-only GroupNorm launches, no normalised tensor)
     onload = os.environ.get("DPOT_GN_ONLOAD", "1") != "0"
     pack_norm = both and onload and tok % 64 == 0 and (E // 8) % 4 == 0
-    if ops.gn_dft_supported(h, w, E):
+    lay = afno_layout if afno_layout is not None else getattr(packed[0], "layout", 0)
+    if packed[0][2] is not None and ops.afno_fused_supported(h, w, E, nb, mx, my, B=B, layout=lay):
+        # the whole AFNO layer - norm1, rfft2, both MLP layers, irfft2, + x_orig, norm2 - in ONE launch (csrc/afno_fused.hip,
+        # SURVEY 8 f4): spectrum and hidden layer stay on chip; save=False (nothing will run a backward on these
+        # intermediates: inference, or a forward whose Block recomputes): S / O1pre are not even written
+        S, O1pre, y1, xn2, mean1, rstd1, mean2, rstd2 = ops.afno_fused_fwd(
+            x, n1w, n1b, packed[0][2], packed[0][1], packed[1][2], packed[1][1], n2w, n2b, h, w, nb, mx, my, act, save=save,
+            want_y1=save or pack_norm, want_xn2=not pack_norm)
+        O1 = None
+    elif ops.gn_dft_supported(h, w, E):
         # GroupNorm fused with the neighbouring DFT (csrc/gn_dft.hip): norm1 + rfft2, and irfft2 + x_orig + norm2 -
         # two launches around the mixer instead of four, GroupNorm1(x) never written
         S, mean1, rstd1 = ops.gn_rfft2(x, n1w, n1b, h, w, nb, mx, my)
@@ -531,7 +546,9 @@ class BlockFn(torch.autograd.Function):
             packed = (ops.afno_pack3(w1, b1), ops.afno_pack3(w2, b2))
         dims = (B, tok, E, h, w, nb, bs, mx, my, mh, act)
         mp = ops.mlp_precision()                                               # channel-MLP GEMM precision override
-        out, parts = _block_parts(x, n1w, n1b, n2w, n2b, f1w, f1b, packed, dims, mp, True, f2w, f2b, mlp_pk)
+        # (no input needs a gradient - inference - or the Block recomputes: the intermediates are dropped right below)
+        keep = any(ctx.needs_input_grad) and not recompute
+        out, parts = _block_parts(x, n1w, n1b, n2w, n2b, f1w, f1b, packed, dims, mp, True, f2w, f2b, mlp_pk, save=keep)
         ctx.mlp_pk = mlp_pk if _mlp_panel_mode(mlp_pk, B * tok, E, mh, mp) else None
         ctx.fused_mixer = packed[0][2] is not None
         # weights the backward data path multiplies by: blocked W^T (fused kernel) or the plain Wbig (generic GEMM)

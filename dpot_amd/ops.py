@@ -788,6 +788,44 @@ def irfft2_gn(spec: Tensor, x: Tensor, mean1: Tensor, rstd1: Tensor, g1: Tensor,
     return y1, xn2, mean2, rstd2
 
 
+def afno_layer_mode() -> int:
+    """DPOT_AFNO_LAYER: 0 = never the one-launch AFNO layer (csrc/afno_fused.hip), 1 = wherever it is supported, unset /
+    'auto' = where it measured faster than the three-launch form (>= 256 (sample, block) workgroups: one per CU)"""
+    v = os.environ.get("DPOT_AFNO_LAYER", "auto")
+    return -1 if v == "auto" else int(v)
+
+
+def afno_fused_supported(h: int, w: int, E: int, nb: int, mx: int, my: int, G: int = 8, B: Optional[int] = None,
+                         layout: int = 1) -> bool:
+    """one-launch AFNO layer forward: 16x16 latent grid, 128 channels per block, all modes kept, three-product packs"""
+    mode = afno_layer_mode()
+    if mode == 0 or layout != 1 or not _lib.load().dpot_afno_fused_supported(h, w, E, G, nb, mx, my):
+        return False
+    return mode == 1 or (B is not None and B * nb >= 256)
+
+
+def afno_fused_fwd(x: Tensor, g1: Optional[Tensor], b1: Optional[Tensor], WaT: Tensor, ba: Tensor, WbT: Tensor, bb: Tensor,
+                   g2: Optional[Tensor], b2: Optional[Tensor], h: int, w: int, nb: int, mx: int, my: int, act: int,
+                   G: int = 8, eps: float = 1e-5, save: bool = True, want_y1: bool = True, want_xn2: bool = True):
+    """[GroupNorm1] -> rfft2 -> 2-layer complex MLP -> irfft2 + x_orig -> [GroupNorm2] in ONE launch (csrc/afno_fused.hip).
+    Returns (S, O1pre, y1, xn2, mean1, rstd1, mean2, rstd2) - the tensors gn_rfft2 / afno_mlp2 / irfft2_gn return, same
+    layouts; save=False (inference): S = O1pre = None; entries that do not apply are None"""
+    B, tok, E = x.shape
+    dev = x.device
+    Mm = B * mx * my
+    S = torch.empty(Mm, 2 * E, dtype=torch.float32, device=dev) if save else None
+    pre = torch.empty(Mm, 2 * E, dtype=torch.float32, device=dev) if save else None
+    want_xn2 = want_xn2 and g2 is not None
+    y1 = torch.empty_like(x) if (want_y1 or not want_xn2) else None
+    xn2 = torch.empty_like(x) if want_xn2 else None
+    st = [torch.empty(B, G, dtype=torch.float32, device=dev) if g is not None else None for g in (g1, g1, g2, g2)]
+    check(_lib.load().dpot_afno_fused_fwd(x.data_ptr(), _p(g1), _p(b1), WaT.data_ptr(), _p(ba), WbT.data_ptr(), _p(bb),
+                                          _p(g2), _p(b2), _p(S), _p(pre), _p(y1), _p(xn2), _p(st[0]), _p(st[1]),
+                                          _p(st[2]), _p(st[3]), B, h, w, E, G, nb, mx, my, act, eps, _stream()),
+          "afno_fused_fwd")
+    return S, pre, y1, xn2, st[0], st[1], st[2], st[3]
+
+
 def gn_bwd_rfft2(dy: Tensor, xin: Tensor, mean: Tensor, rstd: Tensor, gamma: Tensor, h: int, w: int, nb: int, mx: int,
                  my: int, G: int = 8, col_weights: int = 1):
     """(dx = GroupNorm backward of dy, part [2,B,E], spec = rfft2(dx; col_weights)) in one launch"""

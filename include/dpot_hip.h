@@ -281,6 +281,23 @@ int dpot_irfft2_gn_bwd(const float* spec, const float* res, const float* xin, co
                        int nb, int mx, int my, int col_weights, dpot_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * One AFNO layer's forward in ONE launch (csrc/afno_fused.hip; models/dpot.py:59-102, :165-175):
+ *   [GroupNorm1] -> rfft2_ortho -> block-diagonal complex 2-layer MLP -> irfft2_ortho -> + x_orig -> [GroupNorm2]
+ * = dpot_gn_rfft2 + dpot_afno_mlp2(layout 1, mode 0) + dpot_irfft2_gn without the spectrum / mixer output ever leaving
+ * the chip.  16 x 16 latent grid, E / nb == 128, every mode kept (mx = 16, my = 9), E / G in {64, 128}
+ * (dpot_afno_fused_supported; G = 0 asks about the norm-free form).  Wa / Wb: the layout-1 `fwd` packs and ba / bb the
+ * bbig rows of dpot_afno_pack_all.  Outputs, each in the layout of the three-launch path: S = the spectrum and pre = the
+ * layer-1 pre-activation [B*144, 2E] (saved for the backward; both may be NULL: inference), y1 = irfft2(..) + GN1(x),
+ * xn2 = GN2(y1) (either may be NULL), statistics [B, G].  gamma1 == NULL: no norm1 (x_orig = x: the reference's AFNO2D
+ * module alone); gamma2 == NULL: no norm2 (y1 only).
+ * ------------------------------------------------------------------------------------------------ */
+int dpot_afno_fused_supported(int h, int w, int E, int G, int nb, int mx, int my);
+int dpot_afno_fused_fwd(const float* x, const float* gamma1, const float* beta1, const float* Wa, const float* ba,
+                        const float* Wb, const float* bb, const float* gamma2, const float* beta2, float* S, float* pre,
+                        float* y1, float* xn2, float* mean1, float* rstd1, float* mean2, float* rstd2, int B, int h, int w,
+                        int E, int G, int nb, int mx, int my, int act, float eps, dpot_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
  * data movement / small ops
  * ------------------------------------------------------------------------------------------------ */
 /* x[B,X,Y,T,C] -> A[(b,px,py,t), (c,i,j)], c in [0,C+3): channels C..C+2 are the (x,y,t) unit grid

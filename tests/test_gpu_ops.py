@@ -1337,3 +1337,77 @@ def test_groupnorm_rfft2_fused_with_a_large_group_mean(ops):
         print(f"[gn_rfft2, mean/std = {ratio:g}] norm-wise error vs float64: fused {e_fused:.2e}, separate kernels {e_sep:.2e}")
         # the input's own representation error is eps * ratio (a float32 x cannot carry more): both paths sit there
         assert e_fused <= max(2.0 * e_sep, 3e-7 * ratio)
+
+
+@pytest.mark.parametrize("E,nb,B,norm,save,act", [(512, 4, 3, True, True, "gelu"), (1024, 8, 2, True, True, "gelu"),
+                                                  (512, 4, 2, False, True, "gelu"), (1024, 8, 3, True, False, "silu"),
+                                                  (512, 4, 1, True, False, "gelu")])
+def test_afno_layer_one_launch_vs_three_launches(ops, monkeypatch, E, nb, B, norm, save, act):
+    """csrc/afno_fused.hip (round 5): norm1 -> rfft2 -> both MLP layers -> irfft2 + x_orig -> norm2 in ONE launch
+    (register FFTs, spectrum / hidden layer as the MFMA operand in LDS) against (a) the three launches it replaces -
+    gn_rfft2, afno_mlp2 (three-product kernel), irfft2_gn, themselves pinned by the golden / oracle tests - on every tensor
+    both produce (S, layer-1 pre-activation, y1, xn2, both statistics) and (b) float64 torch.fft of the same layer
+    (models/dpot.py:59-102 + GroupNorm).  64 / 128 channels per group, the norm-free form (the reference's AFNO2D module
+    alone) and the inference form (S / pre not written)."""
+    monkeypatch.setenv("DPOT_AFNO_LAYER", "1")
+    h, G = 16, 8
+    mx, my, bs = 16, 9, E // nb
+    if not ops.afno_fused_supported(h, h, E, nb, mx, my, G=G if norm else 0):
+        pytest.skip("one-launch AFNO layer not available")
+    a = ops.ACT_IDS[act]
+    x = (rnd(B, h * h, E, seed=1) * 1.3 + 0.25).cuda()
+    g1, b1 = (1 + 0.3 * rnd(E, seed=2)).cuda(), (0.2 * rnd(E, seed=3)).cuda()
+    g2, b2 = (1 + 0.3 * rnd(E, seed=4)).cuda(), (0.2 * rnd(E, seed=5)).cuda()
+    w1, w2 = (rnd(2, nb, bs, bs, seed=6) * 0.09).cuda(), (rnd(2, nb, bs, bs, seed=7) * 0.09).cuda()
+    bb1, bb2 = (rnd(2, nb, bs, seed=8) * 0.1).cuda(), (rnd(2, nb, bs, seed=9) * 0.1).cuda()
+    packed = ops.AfnoPacks([(w1, bb1), (w2, bb2)]).refresh()
+    assert getattr(packed[0], "layout", 0) == 1
+    n = (g1, b1, g2, b2) if norm else (None, None, None, None)
+    S, pre, y1, xn2, m1, r1, m2, r2 = ops.afno_fused_fwd(x, n[0], n[1], packed[0][2], packed[0][1], packed[1][2],
+                                                         packed[1][1], n[2], n[3], h, h, nb, mx, my, a, save=save)
+    tol = dict(rtol=2e-5, atol_scale=2e-5)
+    # (a) the three launches
+    if norm:
+        S3, m1_3, r1_3 = ops.gn_rfft2(x, g1, b1, h, h, nb, mx, my)
+    else:
+        S3 = ops.rfft2(x, h, h, nb, mx, my, 0)
+    O2, pre3, _ = ops.afno_mlp2(S3, packed[0][2], packed[0][1], packed[1][2], packed[1][1], nb, bs, a, mode=0,
+                                want_pre=True, layout=1)
+    if norm:
+        y1_3, xn2_3, m2_3, r2_3 = ops.irfft2_gn(O2, x, m1_3, r1_3, g1, b1, g2, b2, h, h, nb, mx, my)
+    else:
+        y1_3 = ops.irfft2(O2, B, h, h, E, nb, mx, my, 1, res=x)
+    if save:
+        assert_close(S, S3, "spectrum", **tol)
+        assert_close(pre, pre3, "layer-1 pre-activation", **tol)
+    else:
+        assert S is None and pre is None
+    assert_close(y1, y1_3, "y1", **tol)
+    if norm:
+        assert_close(xn2, xn2_3, "xn2", **tol)
+        for t, t3, nm in ((m1, m1_3, "mean1"), (r1, r1_3, "rstd1"), (m2, m2_3, "mean2"), (r2, r2_3, "rstd2")):
+            assert_close(t, t3, nm, **tol)
+    else:
+        assert xn2 is None and m1 is None and m2 is None
+    # (b) float64 reference of the layer
+    xd = x.double().cpu()
+
+    def gn(t, g, b):
+        td = t.view(B, h * h, G, E // G)
+        mu, var = td.mean(dim=(1, 3), keepdim=True), td.var(dim=(1, 3), unbiased=False, keepdim=True)
+        return ((td - mu) / torch.sqrt(var + 1e-5)).view(B, h * h, E) * g.double().cpu() + b.double().cpu()
+
+    xn = gn(xd, g1, b1) if norm else xd
+    F = torch.fft.rfft2(xn.view(B, h, h, E), dim=(1, 2), norm="ortho").view(B, h, 9, nb, bs)
+    W1 = torch.complex(w1[0].double().cpu(), w1[1].double().cpu())
+    W2 = torch.complex(w2[0].double().cpu(), w2[1].double().cpu())
+    c1 = torch.complex(bb1[0].double().cpu(), bb1[1].double().cpu())
+    c2 = torch.complex(bb2[0].double().cpu(), bb2[1].double().cpu())
+    o1 = torch.einsum("bxykI,kIO->bxykO", F, W1) + c1
+    f = ACTS[act]
+    o1 = torch.complex(f(o1.real), f(o1.imag))
+    o2 = torch.einsum("bxykI,kIO->bxykO", o1, W2) + c2
+    yref = torch.fft.irfft2(o2.reshape(B, h, 9, E), s=(h, h), dim=(1, 2), norm="ortho").reshape(B, h * h, E) + xn
+    assert_close(y1, yref, "y1 vs float64")
+    if norm:
+        assert_close(xn2, gn(yref, g2, b2), "xn2 vs float64")
