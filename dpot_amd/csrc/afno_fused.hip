@@ -122,6 +122,14 @@ __global__ __launch_bounds__(64 * AF_NW) void afno_fused_fwd_kernel(const AfnoFu
   for (int k = 1; k < 4; ++k) sincospif((float)(q * k) * 0.125f, &ts[k], &tc[k]);
 
   auto bar = [&]() __attribute__((always_inline)) { __syncthreads(); };
+#ifdef AF_TIMING   /* kernel experiments only (scripts/afno_layer_phases.py): shader-clock stamps of waves 0 and 7 */
+  unsigned long long ts_[12];
+  int nts_ = 0;
+#define AF_STAMP() ts_[nts_++] = __builtin_amdgcn_s_memtime()
+#else
+#define AF_STAMP()
+#endif
+  AF_STAMP();
 
   // three sums over this wave's GroupNorm group -> (mean, rstd); `slot` = 0 (norm1) / 1 (norm2).  One barrier.
   auto group_stats = [&](double s_m, double s_mm, double s_q, int slot, float& mu_f, double& mu_d, float& rs)
@@ -162,6 +170,10 @@ __global__ __launch_bounds__(64 * AF_NW) void afno_fused_fwd_kernel(const AfnoFu
 #pragma unroll
       for (int y = 0; y < AF_W; ++y) v[n1][y] = xb[xlo + (n1 * 4 * AF_W + y) * E];
     const float piv = xb[c];                                     // the channel's first token (see gn_rfft2_kernel)
+#ifdef AF_TIMING
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+    AF_STAMP();                                                  // 1: x loaded
     double s_m = 0.0, s_mm = 0.0, s_q = 0.0;
 #pragma unroll
     for (int n1 = 0; n1 < 4; ++n1) {
@@ -220,6 +232,7 @@ __global__ __launch_bounds__(64 * AF_NW) void afno_fused_fwd_kernel(const AfnoFu
         Si[k1][ky] = fmaf(sgn_m, hi, lo);
       }
     }
+    AF_STAMP();                                                  // 2: rfft2 done
     // GroupNorm1 as a scale of the spectrum + a DC term: GN(x) = a (x - piv) + (beta + a (piv - mu))
     float a = 1.f, dcv = piv;
     if (p.g1) {
@@ -274,30 +287,48 @@ __global__ __launch_bounds__(64 * AF_NW) void afno_fused_fwd_kernel(const AfnoFu
         A[o + 8 * 256] = vi;
       }
   };
+  AF_STAMP();                                                    // 3: statistics known, spectrum scaled
   publish(p.S, false);
   bar();                                                         // spectrum complete
+  AF_STAMP();                                                    // 4: spectrum published
 
   // ================================ the two MLP layers ================================
   f32x4 P1[AF_WF], P2[AF_WF], P3[AF_WF];
+  // One layer = 8 K-slabs x 9 row tiles x 12 MFMAs, software-pipelined by hand (hipcc left alone issues every fragment
+  // read right in front of its first use and sinks the weight loads to the end of the previous slab: LDS and L2 latency
+  // exposed 72 + 8 times per layer): the fragments of tile t + 1 are read while the MFMAs of tile t issue, the Wr / Wi
+  // tiles of slab u + 2 are requested at the start of slab u (ring of three register sets); sched_barriers pin the order.
   auto layer = [&](const float* __restrict__ Wl) __attribute__((always_inline)) {
 #pragma unroll
     for (int i = 0; i < AF_WF; ++i) P1[i] = P2[i] = P3[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
     // slab u: Wr tile at ((u * 2 + 0) * 8 + wave) * 256, Wi tile at ((u * 2 + 1) * 8 + wave) * 256 floats
     const float* wl = Wl + (long long)kblk * (8 * 2 * 8 * 256) + wave * 256 + lane * 4;
-    f32x4 br = *reinterpret_cast<const f32x4*>(wl);
-    f32x4 bi = *reinterpret_cast<const f32x4*>(wl + 8 * 256);
+    f32x4 wr[3], wi[3];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      wr[u] = *reinterpret_cast<const f32x4*>(wl + u * (2 * 8 * 256));
+      wi[u] = *reinterpret_cast<const f32x4*>(wl + u * (2 * 8 * 256) + 8 * 256);
+    }
+    f32x4 ar = *reinterpret_cast<const f32x4*>(A + rofs);
+    f32x4 ai = *reinterpret_cast<const f32x4*>(A + rofs + 8 * 256);
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int u = 0; u < 8; ++u) {
-      f32x4 nbr = br, nbi = bi;
-      if (u + 1 < 8) {
-        nbr = *reinterpret_cast<const f32x4*>(wl + (u + 1) * (2 * 8 * 256));
-        nbi = *reinterpret_cast<const f32x4*>(wl + (u + 1) * (2 * 8 * 256) + 8 * 256);
+      if (u + 2 < 8) {
+        wr[(u + 2) % 3] = *reinterpret_cast<const f32x4*>(wl + (u + 2) * (2 * 8 * 256));
+        wi[(u + 2) % 3] = *reinterpret_cast<const f32x4*>(wl + (u + 2) * (2 * 8 * 256) + 8 * 256);
       }
+      const f32x4 br = wr[u % 3], bi = wi[u % 3];
       const f32x4 bs = br + bi;
 #pragma unroll
       for (int i = 0; i < AF_WF; ++i) {
-        const f32x4 ar = *reinterpret_cast<const f32x4*>(A + rofs + (i * 16 + u) * 256);
-        const f32x4 ai = *reinterpret_cast<const f32x4*>(A + rofs + (i * 16 + 8 + u) * 256);
+        const int un = i + 1 < AF_WF ? u : u + 1, in = i + 1 < AF_WF ? i + 1 : 0;    // the next tile
+        f32x4 arn = ar, ain = ai;
+        if (un < 8) {
+          arn = *reinterpret_cast<const f32x4*>(A + rofs + (in * 16 + un) * 256);
+          ain = *reinterpret_cast<const f32x4*>(A + rofs + (in * 16 + 8 + un) * 256);
+        }
+        __builtin_amdgcn_sched_barrier(0);
         const f32x4 as = ar + ai;
 #pragma unroll
         for (int s2 = 0; s2 < 4; ++s2) {
@@ -305,9 +336,10 @@ __global__ __launch_bounds__(64 * AF_NW) void afno_fused_fwd_kernel(const AfnoFu
           P2[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(ai[s2], bi[s2], P2[i], 0, 0, 0);
           P3[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(as[s2], bs[s2], P3[i], 0, 0, 0);
         }
+        __builtin_amdgcn_sched_barrier(0);
+        ar = arn;
+        ai = ain;
       }
-      br = nbr;
-      bi = nbi;
     }
   };
   // accumulators -> Sr / Si [k1 = e][ky = i] (+ bias): lane (n = lane & 15, q) holds rows 4 q + e of column n
@@ -325,11 +357,14 @@ __global__ __launch_bounds__(64 * AF_NW) void afno_fused_fwd_kernel(const AfnoFu
 
   layer(p.Wa);
   recombine(p.ba);
+  AF_STAMP();                                                    // 5: layer 1 done
   bar();                                                         // every wave is done reading the spectrum
   publish(p.pre, true);                                          // pre-activation saved, activated layer-1 output -> operand
   bar();
+  AF_STAMP();                                                    // 6: hidden layer published
   layer(p.Wb);
   recombine(p.bb);                                               // O2: this wave's 16 channels, modes as after phase A
+  AF_STAMP();                                                    // 7: layer 2 done
 
   // ================================ phase C: irfft2 + x_orig + GroupNorm2 ================================
   // column transform: DFT4 across the lanes (input n2 = brev2(q)), twiddle e^{+2 pi i n1 q / 16}, in-lane DFT4 over n1
@@ -409,6 +444,7 @@ __global__ __launch_bounds__(64 * AF_NW) void afno_fused_fwd_kernel(const AfnoFu
       s_q += (double)qq;
     }
   }
+  AF_STAMP();                                                    // 8: irfft2 + x_orig done
   float mu2 = 0.f, a2 = 1.f, c2 = 0.f;
   if (p.g2) {
     float rs2;
@@ -432,6 +468,16 @@ __global__ __launch_bounds__(64 * AF_NW) void afno_fused_fwd_kernel(const AfnoFu
       if (p.y1) p.y1[obase + o] = yv[k1][y];
       if (p.g2 && p.xn2) p.xn2[obase + o] = fmaf(yv[k1][y] - mu2, a2, c2);
     }
+#ifdef AF_TIMING
+  AF_STAMP();                                                    // 9: stores issued
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  AF_STAMP();                                                    // 10: stores drained
+  if ((wave == 0 || wave == 7) && lane == 0 && p.y1) {
+    unsigned long long* o = reinterpret_cast<unsigned long long*>(p.y1 + (long long)b * (AF_H * AF_W) * E + kblk * AF_BS) +
+                            (wave ? 12 : 0);
+    for (int i = 0; i < 11; ++i) o[i] = ts_[i];
+  }
+#endif
 }
 
 template <int CG>

@@ -790,9 +790,19 @@ def irfft2_gn(spec: Tensor, x: Tensor, mean1: Tensor, rstd1: Tensor, g1: Tensor,
 
 def afno_layer_mode() -> int:
     """DPOT_AFNO_LAYER: 0 = never the one-launch AFNO layer (csrc/afno_fused.hip), 1 = wherever it is supported, unset /
-    'auto' = where it measured faster than the three-launch form (>= 256 (sample, block) workgroups: one per CU)"""
+    'auto' = where it measured faster than the three-launch form (afno_layer_wins)"""
     v = os.environ.get("DPOT_AFNO_LAYER", "auto")
     return -1 if v == "auto" else int(v)
+
+
+def afno_layer_wins(B: int, nb: int) -> bool:
+    """one (sample, channel block) workgroup per CU and round: the one-launch layer costs ~100 us per round of 256
+    workgroups whatever their number, the three launches ~125 us per 256 (profiles/r05_f4_fused_vs_3launch.txt: 128
+    workgroups 84 vs 72 us - DPOT-Tiny at batch 32 stays on three launches -, 256: 98 vs 124, 512: 196 vs 240) - so it
+    is selected where the last round is at least 80 % full"""
+    n = B * nb
+    rounds = (n + 255) // 256
+    return n >= 0.8 * 256 * rounds
 
 
 def afno_fused_supported(h: int, w: int, E: int, nb: int, mx: int, my: int, G: int = 8, B: Optional[int] = None,
@@ -801,7 +811,7 @@ def afno_fused_supported(h: int, w: int, E: int, nb: int, mx: int, my: int, G: i
     mode = afno_layer_mode()
     if mode == 0 or layout != 1 or not _lib.load().dpot_afno_fused_supported(h, w, E, G, nb, mx, my):
         return False
-    return mode == 1 or (B is not None and B * nb >= 256)
+    return mode == 1 or (B is not None and afno_layer_wins(B, nb))
 
 
 def afno_fused_fwd(x: Tensor, g1: Optional[Tensor], b1: Optional[Tensor], WaT: Tensor, ba: Tensor, WbT: Tensor, bb: Tensor,

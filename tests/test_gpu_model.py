@@ -37,6 +37,21 @@ def _block_fn(m, x, h):
                          m.n_blocks, m.modes, m._act)
 
 
+def test_afno_mixer_golden_one_launch_layer(monkeypatch):
+    """the same reference golden (g1_afno_tiny: the DPOT-Tiny layer, E = 512, 4 blocks of 128) through the ONE-launch form
+    of the mixer's forward (csrc/afno_fused.hip, SURVEY 8 f4: rfft2 -> both MLP layers -> irfft2 + x in one kernel), which
+    `auto` only selects from 205 (sample, block) workgroups on; the backward consumes the S / pre-activation it saves"""
+    from dpot_amd import ops
+    monkeypatch.setenv("DPOT_AFNO_LAYER", "1")
+    if not (ops.afno_mlp2_supported(4, 128) and ops.afno_mlp3_supported(4, 128) and ops.afno_fused_supported(16, 16, 512, 4, 16, 9, G=0)):
+        pytest.skip("one-launch AFNO layer switched off (DPOT_AFNO_3MULT=0 / DPOT_AFNO_FUSED=0)")
+    calls = []
+    real = ops.afno_fused_fwd
+    monkeypatch.setattr(ops, "afno_fused_fwd", lambda *a, **k: (calls.append(1), real(*a, **k))[1])
+    test_afno_mixer_golden("g1_afno_tiny")
+    assert calls, "the one-launch kernel did not run"
+
+
 @pytest.mark.parametrize("name", ["g1_afno_trunc", "g1_afno_tiny"])
 def test_afno_mixer_golden(name):
     """AFNO2D alone (golden g1, written by the imported reference's AFNO2D module): the PRODUCT mixer -

@@ -37,7 +37,8 @@ SWITCHES = {
      "DPOT_BF16P_TILE192=0 DPOT_BF16P_PAIR=0"): (SMALL_SET, True),
     # the mixer as two generic GEMM launches, and the LDS-DMA bf16 kernels with the 12-wave kernel for every launch, 128 x 256
     # tiles only, un-paired weight gradients
-    "DPOT_AFNO_FUSED=0 DPOT_BF16P_BD=0 DPOT_BF16P_DUO=0 DPOT_BF16P_TILE192=0 DPOT_BF16P_PAIR=0":
+    # (DPOT_AFNO_LAYER=0: the three launches per AFNO layer forward at the batches where `auto` picks the one-launch kernel)
+    "DPOT_AFNO_FUSED=0 DPOT_AFNO_LAYER=0 DPOT_BF16P_BD=0 DPOT_BF16P_DUO=0 DPOT_BF16P_TILE192=0 DPOT_BF16P_PAIR=0":
         (SMALL_SET + " or test_bf16_channel_mlp_mode_vs_oracle and SMALL-32", True),
 }
 

@@ -86,6 +86,32 @@ def test_full_model_gradients_vs_oracle(name, B):
     print(f"[{name} B={B}] worst normalised gradient error {worst:.2e}")
 
 
+def test_full_model_gradients_with_one_launch_afno_layer(monkeypatch):
+    """DPOT-Tiny at batch 2 with the ONE-launch AFNO layer forward forced on (csrc/afno_fused.hip; `auto` selects it from
+    205 (sample, block) workgroups on, i.e. for DPOT-S / -M at batch 32 - the SMALL-32 / MEDIUM-32 cases above run it):
+    64 channels per GroupNorm group = two groups per workgroup; every gradient vs the oracle at rtol 1e-4, and the
+    no-grad forward (S / pre-activation not written) bit-identical to the training forward"""
+    from dpot_amd import ops
+    monkeypatch.setenv("DPOT_AFNO_LAYER", "1")
+    if not (ops.afno_mlp2_supported(4, 128) and ops.afno_mlp3_supported(4, 128) and ops.afno_fused_supported(16, 16, 512, 4, 16, 9)):
+        pytest.skip("one-launch AFNO layer switched off")
+    calls = []
+    real = ops.afno_fused_fwd
+    monkeypatch.setattr(ops, "afno_fused_fwd", lambda *a, **k: (calls.append(k.get("save", True)), real(*a, **k))[1])
+    oc = _oracle_case("TINY", 2)
+    m, xg, y, c = _hip_case("TINY", oc)
+    assert calls == [True] * 4, calls
+    assert_close(y, oc["y"], "pred")
+    assert_close(xg.grad, oc["dx"], "dx")
+    for k, p in m.named_parameters():
+        assert_close(p.grad, oc["grads"][k], f"d{k}")
+        assert _rel(p.grad.double().norm().item(), oc["grads"][k].double().norm().item()) <= RTOL, f"|d{k}|"
+    with torch.no_grad():
+        y0, c0 = m(oc["x"].cuda())
+    assert calls[4:] == [False] * 4, calls
+    assert torch.equal(y0, y.detach()) and torch.equal(c0, c.detach())
+
+
 # Tolerance of the OPT-IN reduced-precision channel MLP (`set_mlp_precision("bf16")`, BASELINE configs[2] "bf16
 # channel-MLP on MFMA" and the DPOT-M/L headline mode).  Both operands of fc1 / fc2 (forward, data gradient, weight
 # gradient) are rounded to bf16 (8-bit significand, unit round-off u = 2^-9 = 1.95e-3), as is the saved activation
