@@ -5,7 +5,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from dpot_amd import ops
 
-shapes = {"M": (8192, 1024, 4096), "L16": (16384, 1536, 6144), "L4": (4096, 1536, 6144)}
+shapes = {"S": (8192, 1024, 1024), "M": (8192, 1024, 4096), "L16": (16384, 1536, 6144), "L4": (4096, 1536, 6144)}
 M, E, mh = shapes[sys.argv[1]]
 form = sys.argv[2]
 x = torch.randn(M, E, device="cuda"); do = torch.randn(M, E, device="cuda")
