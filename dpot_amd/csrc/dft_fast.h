@@ -490,8 +490,9 @@ template <int CC>
 static int launch_rfft2_128(const float* x, float* spec, int B, int E, int nb, int mx, int my, int colw, float scale,
                             hipStream_t s) {
   const size_t lds = sizeof(float) * ((size_t)my * 128 * 2 * CC);
-  hipFuncSetAttribute(reinterpret_cast<const void*>(rfft2_128_kernel<CC>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                      160 * 1024);
+  const hipError_t ae = hipFuncSetAttribute(reinterpret_cast<const void*>(rfft2_128_kernel<CC>),
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  DPOT_REQUIRE(ae == hipSuccess, "rfft2_128: cannot raise the dynamic LDS limit to 160 KiB (%s)", hipGetErrorString(ae));
   hipLaunchKernelGGL((rfft2_128_kernel<CC>), dim3(E / CC, B), dim3(256), lds, s, x, spec, E, nb, mx, my, colw, scale);
   return check_launch("rfft2_128_kernel");
 }
@@ -499,8 +500,9 @@ template <int CC>
 static int launch_irfft2_128(const float* spec, const float* res, float* y, int B, int E, int nb, int mx, int my, int colw,
                              float scale, hipStream_t s) {
   const size_t lds = sizeof(float) * ((size_t)my * 128 * 2 * CC);
-  hipFuncSetAttribute(reinterpret_cast<const void*>(irfft2_128_kernel<CC>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                      160 * 1024);
+  const hipError_t ae = hipFuncSetAttribute(reinterpret_cast<const void*>(irfft2_128_kernel<CC>),
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  DPOT_REQUIRE(ae == hipSuccess, "irfft2_128: cannot raise the dynamic LDS limit to 160 KiB (%s)", hipGetErrorString(ae));
   hipLaunchKernelGGL((irfft2_128_kernel<CC>), dim3(E / CC, B), dim3(256), lds, s, spec, res, y, E, nb, mx, my, colw,
                      scale);
   return check_launch("irfft2_128_kernel");

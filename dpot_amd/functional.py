@@ -400,9 +400,48 @@ def _mixer_core_bwd(dO2, S, O1pre, O1, wb1, wb2, dims, fused, afno_layout, sinks
     return dS, dw1, db1, dw2, db2
 
 
+def _mixer_wgrads(S, dO1pre, O1, dO2, dims, sinks, pending=None):
+    """the four parameter gradients of the mixer's complex MLP from the operands the data path left (dw1 / db1 from S and
+    dO1pre, dw2 / db2 from O1 and dO2): one fused launch where dpot_afno_wgrad2 covers the shape (partials deferred to the
+    block's finalising launch with `pending`), else two generic split-K GEMMs - the second half of _mixer_core_bwd for
+    the one-launch backward (ops.afno_fused_bwd)"""
+    B, tok, E, h, w, nb, bs, mx, my, mh, act = dims
+    s_w1, s_b1, s_w2, s_b2 = sinks
+    Mm = B * mx * my
+    dev = dO2.device
+    dw1, db1 = ops._out(s_w1.out(), (2, nb, bs, bs), dev), ops._out(s_b1.out(), (2, nb, bs), dev)
+    dw2, db2 = ops._out(s_w2.out(), (2, nb, bs, bs), dev), ops._out(s_b2.out(), (2, nb, bs), dev)
+    sk2 = ops.afno_wgrad2_splitk(Mm, nb, bs) if S.stride(0) == 2 * E else 0
+    if sk2 and pending is not None:
+        pending["afno"] = ops.afno_wgrad2(S, dO1pre, O1, dO2, nb, bs, dw1, db1, dw2, db2, sk2, defer=True)
+        return dw1, db1, dw2, db2
+    if sk2:
+        ops.afno_wgrad2(S, dO1pre, O1, dO2, nb, bs, dw1, db1, dw2, db2, sk2)
+    else:
+        sk = max(2, ops.auto_splitk(2 * bs, 2 * bs, Mm, nb, tn=True))
+        wkw = dict(transA=True, lda=2 * E, ldb=2 * E, ldc=2 * bs, batch=nb, strideA=2 * bs, strideB=2 * bs,
+                   strideC=4 * bs * bs, splitk=sk, mode=ops.EPI_AFNO_WGRAD)
+        ops.gemm(O1, dO2, dw2, 2 * bs, 2 * bs, Mm, colsum_out=db2, colsum_of=2, **wkw)
+        ops.gemm(S, dO1pre, dw1, 2 * bs, 2 * bs, Mm, colsum_out=db1, colsum_of=2, **wkw)
+    return s_w1.done(dw1), s_b1.done(db1), s_w2.done(dw2), s_b2.done(db2)
+
+
+def _fused_layer_bwd_ok(ctx_fused_mixer, afno_layout, O1, dims, G):
+    """the one-launch AFNO layer backward (csrc/afno_fused.hip) applies where the one-launch forward does (same shapes, same
+    selection rule) and the forward left no activated layer-1 output (the backward launch re-derives it)"""
+    B, tok, E, h, w, nb, bs, mx, my, mh, act = dims
+    return (ctx_fused_mixer and O1 is None and ops.afno_fused_bwd_enabled()
+            and ops.afno_fused_supported(h, w, E, nb, mx, my, G=G, B=B, layout=afno_layout))
+
+
 def _mixer_bwd(dy1, S, O1pre, O1, wb1, wb2, dims, fused, afno_layout, sinks, pending=None):
     """backward of _mixer_fwd: returns (dxn1 = adjoint-rfft2(dS) + dy1, dw1, db1, dw2, db2); pending: see _mixer_core_bwd"""
     B, tok, E, h, w, nb, bs, mx, my, mh, act = dims
+    if _fused_layer_bwd_ok(fused, afno_layout, O1, dims, 0):
+        # the whole backward of the mixer in ONE launch, then the weight gradients from the operands it left
+        dxn1, dO2, O1, dO1pre, _, _ = ops.afno_fused_bwd(dy1, None, None, None, None, O1pre, wb2, wb1, None, None, None, None,
+                                                         None, h, w, nb, mx, my, act)
+        return (dxn1,) + tuple(_mixer_wgrads(S, dO1pre, O1, dO2, dims, sinks, pending))
     dO2 = ops.rfft2(dy1, h, w, nb, mx, my, 1)                              # adjoint of irfft2
     dS, dw1, db1, dw2, db2 = _mixer_core_bwd(dO2, S, O1pre, O1, wb1, wb2, dims, fused, afno_layout, sinks, pending)
     dxn1 = ops.irfft2(dS, B, h, w, E, nb, mx, my, 0, res=dy1)              # adjoint of rfft2, + skip path
@@ -536,7 +575,7 @@ class BlockFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, n1w, n1b, w1, b1, w2, b2, n2w, n2b, f1w, f1b, f2w, f2b, h: int, w: int, nb: int, modes: int,
-                act: int, packed=None, recompute: bool = False, mlp_pk=None):
+                act: int, packed=None, recompute: bool = False, mlp_pk=None, grad_enabled: bool = True):
         x = x.contiguous()
         B, tok, E = x.shape
         bs = E // nb
@@ -546,8 +585,10 @@ class BlockFn(torch.autograd.Function):
             packed = (ops.afno_pack3(w1, b1), ops.afno_pack3(w2, b2))
         dims = (B, tok, E, h, w, nb, bs, mx, my, mh, act)
         mp = ops.mlp_precision()                                               # channel-MLP GEMM precision override
-        # (no input needs a gradient - inference - or the Block recomputes: the intermediates are dropped right below)
-        keep = any(ctx.needs_input_grad) and not recompute
+        # (no input needs a gradient or the caller runs under no_grad - inference - or the Block recomputes: the
+        # intermediates are dropped right below.  grad_enabled comes from the CALLER: inside forward() autograd is always off,
+        # and needs_input_grad mirrors requires_grad of the inputs whatever the grad mode)
+        keep = grad_enabled and any(ctx.needs_input_grad) and not recompute
         out, parts = _block_parts(x, n1w, n1b, n2w, n2b, f1w, f1b, packed, dims, mp, True, f2w, f2b, mlp_pk, save=keep)
         ctx.mlp_pk = mlp_pk if _mlp_panel_mode(mlp_pk, B * tok, E, mh, mp) else None
         ctx.fused_mixer = packed[0][2] is not None
@@ -670,7 +711,14 @@ class BlockFn(torch.autograd.Function):
             else:
                 dxn2 = ops.linear_bwd_data(dHpre, f1w, precision=mp)               # [M, E]
         # parameter-gradient partials of norm2 are reduced together with norm1's at the end of the block (one launch)
-        if ops.gn_dft_supported(h, w, E):
+        if _fused_layer_bwd_ok(ctx.fused_mixer, ctx.afno_layout, O1, ctx.dims, 8):
+            # norm2 backward, adjoint irfft2, both MLP layers' data path, adjoint rfft2, skip, norm1 backward, outer skip in
+            # ONE launch (csrc/afno_fused.hip, round 5); dy1 / dS never exist in HBM; then the weight gradients
+            dx, dO2, O1, dO1pre, gn1_part, gn2_part = ops.afno_fused_bwd(
+                dxn2.view(B, tok, E), y1, mean2, rstd2, n2w, O1pre, wb2, wb1, x, mean1, rstd1, n1w, dout, h, w, nb, mx, my,
+                act)
+            dw1, db1, dw2, db2 = _mixer_wgrads(S, dO1pre, O1, dO2, ctx.dims, (s_w1, s_b1, s_w2, s_b2), pending)
+        elif ops.gn_dft_supported(h, w, E):
             # norm2 backward + rfft2 (adjoint of the forward irfft2), then irfft2 (adjoint) + skip + norm1 backward + outer
             # skip: two launches around the mixer's backward (csrc/gn_dft.hip)
             dy1, gn2_part, dO2 = ops.gn_bwd_rfft2(dxn2.view(B, tok, E), y1, mean2, rstd2, n2w, h, w, nb, mx, my,
@@ -707,7 +755,7 @@ class BlockFn(torch.autograd.Function):
         dn1w, dn1b = s_n1w.done(dn1w), s_n1b.done(dn1b)
         dn2w, dn2b = s_n2w.done(dn2w), s_n2b.done(dn2b)
         return (dx, dn1w, dn1b, dw1, db1, dw2, db2, dn2w, dn2b, df1w, df1b, df2w, df2b, None, None, None, None, None,
-                None, None, None)
+                None, None, None, None)
 
 
 # ======================================================================================================

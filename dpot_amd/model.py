@@ -170,8 +170,7 @@ class DPOTNet(nn.Module):
             je = embed_layout_jobs(self.pos_embed, pe[0].weight, pe[0].bias, pe[2].weight, pe[2].bias)
             jh = head_layout_jobs(ol[0].bias, ol[4].weight, ol[4].bias, self.patch_size, ol[0].weight.shape[1])
             lj = getattr(self, "_layout_jobs", None)
-            key = tuple(j[0].data_ptr() for j in je + jh)
-            if lj is None or lj.key[:len(key)] != key:
+            if lj is None or lj.key != ops.LayoutJobs.key_of(je + jh):
                 lj = self._layout_jobs = ops.LayoutJobs(je + jh)
             lay = lj.refresh()
             lay_e, lay_h = lay[:len(je)], lay[len(je):]
@@ -290,7 +289,8 @@ class DPOTNet(nn.Module):
             lat = BlockFn.apply(lat, blk.norm1.weight, blk.norm1.bias, f.w1, f.b1, f.w2, f.b2, blk.norm2.weight,
                                 blk.norm2.bias, blk.mlp[0].weight, blk.mlp[0].bias, blk.mlp[2].weight,
                                 blk.mlp[2].bias, h, h, self.n_blocks, self.modes, self._act,
-                                (pk[2 * i], pk[2 * i + 1]), recompute, mlp_pk[i] if mlp_pk is not None else None)
+                                (pk[2 * i], pk[2 * i + 1]), recompute, mlp_pk[i] if mlp_pk is not None else None,
+                                torch.is_grad_enabled())
         if hook is not None:
             lat = hook(len(self.blocks) + 1, lat)
         ol, ch = self.out_layer, self.cls_head

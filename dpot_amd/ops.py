@@ -212,7 +212,8 @@ class LayoutJobs:
         import numpy as np
         dev = jobs[0][0].device
         self.out = [torch.empty(d, dtype=torch.float32, device=dev) for _, _, d, _, _ in jobs]
-        self.key = tuple(j[0].data_ptr() for j in jobs) + tuple(j[1].data_ptr() for j in jobs if j[1] is not None)
+        self.key = LayoutJobs.key_of(jobs)
+        self.sources = [(j[0], j[1]) for j in jobs]        # the table holds raw pointers: keep the tensors alive
         host = np.zeros(len(jobs) * C.sizeof(_lib.LayoutJob), dtype=np.uint8)
         tab = (_lib.LayoutJob * len(jobs)).from_buffer(host)
         for i, ((src, add, d, v, st), dst) in enumerate(zip(jobs, self.out)):
@@ -224,6 +225,11 @@ class LayoutJobs:
         self.table = torch.from_numpy(host).to(dev)
         self.n = len(jobs)
         self.max_elems = max(d[0] * d[1] * d[2] for _, _, d, _, _ in jobs)
+
+    @staticmethod
+    def key_of(jobs):
+        """every raw pointer the device table would hold (src AND add of each job): the cache key of a LayoutJobs"""
+        return tuple(j[0].data_ptr() for j in jobs) + tuple(j[1].data_ptr() for j in jobs if j[1] is not None)
 
     def refresh(self):
         check(_lib.load().dpot_layout_jobs(self.table.data_ptr(), self.n, self.max_elems, _stream()), "layout_jobs")
@@ -834,6 +840,41 @@ def afno_fused_fwd(x: Tensor, g1: Optional[Tensor], b1: Optional[Tensor], WaT: T
                                           _p(st[2]), _p(st[3]), B, h, w, E, G, nb, mx, my, act, eps, _stream()),
           "afno_fused_fwd")
     return S, pre, y1, xn2, st[0], st[1], st[2], st[3]
+
+
+def afno_fused_bwd_enabled() -> bool:
+    """DPOT_AFNO_LAYER_BWD=1: the backward of a one-launch AFNO layer also runs as ONE launch (csrc/afno_fused.hip
+    afno_fused_bwd_kernel).  OFF by default - built, parity-green and REJECTED by measurement in round 5
+    (profiles/r05_f4_bwd_fused_vs_launches.txt, r05_f4_bwd_step_ab.txt, one box): 205 us against 179 us for the four launches
+    it replaces at 256 workgroups (DPOT-S / -M, batch 32), train step DPOT-S 5.27 -> 5.44 ms, DPOT-M 13.05 -> 13.41 ms.  It
+    moves 0.65x the bytes (dy1 / dS never exist in HBM) but a (sample, channel block) workgroup owns its CU alone (144 KiB of
+    LDS) and runs its phases one after the other: the loads of GroupNorm2's backward, the pre-activation reads between the
+    layers and the three operand streams of GroupNorm1's backward cannot hide behind another workgroup's MFMA phase, which
+    is exactly what the separate launches' 1024-thread streaming kernels do better."""
+    return os.environ.get("DPOT_AFNO_LAYER_BWD", "0") == "1"
+
+
+def afno_fused_bwd(dxn2: Tensor, y1: Optional[Tensor], mean2: Optional[Tensor], rstd2: Optional[Tensor],
+                   g2: Optional[Tensor], pre: Tensor, Wa_bwd2: Tensor, Wb_bwd1: Tensor, x: Optional[Tensor],
+                   mean1: Optional[Tensor], rstd1: Optional[Tensor], g1: Optional[Tensor], add: Optional[Tensor], h: int,
+                   w: int, nb: int, mx: int, my: int, act: int, G: int = 8):
+    """backward of afno_fused_fwd in ONE launch (csrc/afno_fused.hip): returns (dx, dO2, O1, dO1pre, part1, part2) - dx
+    [B, tok, E]; dO2 / O1 / dO1pre [B*mx*my, 2E] = the operands of the weight-gradient launch (afno_wgrad2 with the saved
+    spectrum S); part1 / part2 [2, B, E] the GroupNorm parameter-gradient partials (None without the norm)"""
+    B, tok, E = dxn2.shape
+    dev = dxn2.device
+    Mm = B * mx * my
+    dO2 = torch.empty(Mm, 2 * E, dtype=torch.float32, device=dev)
+    O1 = torch.empty_like(dO2)
+    dPre = torch.empty_like(dO2)
+    dx = torch.empty_like(dxn2)
+    part2 = torch.empty(2, B, E, dtype=torch.float32, device=dev) if g2 is not None else None
+    part1 = torch.empty(2, B, E, dtype=torch.float32, device=dev) if g1 is not None else None
+    check(_lib.load().dpot_afno_fused_bwd(dxn2.data_ptr(), _p(y1), _p(mean2), _p(rstd2), _p(g2), pre.data_ptr(),
+                                          Wa_bwd2.data_ptr(), Wb_bwd1.data_ptr(), _p(x), _p(mean1), _p(rstd1), _p(g1),
+                                          _p(add), dO2.data_ptr(), O1.data_ptr(), dPre.data_ptr(), dx.data_ptr(), _p(part2),
+                                          _p(part1), B, h, w, E, G, nb, mx, my, act, _stream()), "afno_fused_bwd")
+    return dx, dO2, O1, dPre, part1, part2
 
 
 def gn_bwd_rfft2(dy: Tensor, xin: Tensor, mean: Tensor, rstd: Tensor, gamma: Tensor, h: int, w: int, nb: int, mx: int,

@@ -296,6 +296,21 @@ int dpot_afno_fused_fwd(const float* x, const float* gamma1, const float* beta1,
                         const float* Wb, const float* bb, const float* gamma2, const float* beta2, float* S, float* pre,
                         float* y1, float* xn2, float* mean1, float* rstd1, float* mean2, float* rstd2, int B, int h, int w,
                         int E, int G, int nb, int mx, int my, int act, float eps, dpot_stream_t stream);
+/* The BACKWARD of the same layer in one launch (replaces dpot_gn_bwd_rfft2 + dpot_afno_mlp2(mode 1) + dpot_irfft2 +
+ * dpot_groupnorm_bwd; autograd of models/dpot.py:59-102, :165-175):
+ *   dy1 = GroupNorm2-backward(dxn2; y1, mean2, rstd2, gamma2),  dO2 = adjoint-irfft2(dy1),
+ *   dO1pre = (dO2 W2^H) * act'(pre),  O1 = act(pre),  dS = dO1pre W1^H,
+ *   dx = GroupNorm1-backward(adjoint-rfft2(dS) + dy1; x, mean1, rstd1, gamma1) + add.
+ * Wa_bwd2 / Wb_bwd1: the layout-1 `bwd` packs of layer 2 / layer 1 (dpot_afno_pack_all).  Outputs for the weight-gradient
+ * launch (dpot_afno_wgrad2): dO2, O1, dPre [B*144, 2E]; dx [B, 256, E]; part2 / part1 [2, B, E] = per-sample partials of
+ * the GroupNorm parameter gradients (sum d*xhat | sum d) as dpot_gn_bwd_rfft2 / dpot_irfft2_gn_bwd write them.
+ * gamma2 == NULL: dxn2 IS dy1 (no norm2); gamma1 == NULL: no norm1 (with both NULL: the backward of AFNO2D alone);
+ * add may be NULL. */
+int dpot_afno_fused_bwd(const float* dxn2, const float* y1, const float* mean2, const float* rstd2, const float* gamma2,
+                        const float* pre, const float* Wa_bwd2, const float* Wb_bwd1, const float* x, const float* mean1,
+                        const float* rstd1, const float* gamma1, const float* add, float* dO2, float* O1, float* dPre,
+                        float* dx, float* part2, float* part1, int B, int h, int w, int E, int G, int nb, int mx, int my,
+                        int act, dpot_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
  * data movement / small ops

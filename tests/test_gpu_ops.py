@@ -1411,3 +1411,92 @@ def test_afno_layer_one_launch_vs_three_launches(ops, monkeypatch, E, nb, B, nor
     assert_close(y1, yref, "y1 vs float64")
     if norm:
         assert_close(xn2, gn(yref, g2, b2), "xn2 vs float64")
+
+
+@pytest.mark.parametrize("E,nb,B,norm,act,add", [(512, 4, 3, True, "gelu", True), (1024, 8, 2, True, "gelu", True),
+                                                 (512, 4, 2, False, "gelu", False), (1024, 8, 3, True, "silu", False)])
+def test_afno_layer_backward_one_launch(ops, monkeypatch, E, nb, B, norm, act, add):
+    """csrc/afno_fused.hip afno_fused_bwd_kernel (round 5): norm2 backward -> adjoint irfft2 -> data path of both MLP layers
+    (act' from the saved pre-activation, O1 re-derived) -> adjoint rfft2 + skip -> norm1 backward + outer skip in ONE launch,
+    against (a) the launches it replaces (gn_bwd_rfft2 / groupnorm_bwd + rfft2, afno_mlp2 mode 1, irfft2 + groupnorm_bwd) on
+    every tensor both produce - dx, dO2, O1, dO1pre, the GroupNorm parameter-gradient partials - and (b) float64 autograd of
+    the layer as the reference computes it (models/dpot.py:59-102, :165-175): dx and, through the unchanged weight-gradient
+    launch on the operands the kernel left, dW1 / db1 / dW2 / db2.  64 / 128 channels per group and the norm-free form."""
+    monkeypatch.setenv("DPOT_AFNO_LAYER", "1")
+    h, G = 16, 8
+    mx, my, bs = 16, 9, E // nb
+    if not ops.afno_fused_supported(h, h, E, nb, mx, my, G=G if norm else 0):
+        pytest.skip("one-launch AFNO layer not available")
+    a = ops.ACT_IDS[act]
+    x = (rnd(B, h * h, E, seed=1) * 1.3 + 0.25).cuda()
+    g1, b1 = (1 + 0.3 * rnd(E, seed=2)).cuda(), (0.2 * rnd(E, seed=3)).cuda()
+    g2, b2 = (1 + 0.3 * rnd(E, seed=4)).cuda(), (0.2 * rnd(E, seed=5)).cuda()
+    w1, w2 = (rnd(2, nb, bs, bs, seed=6) * 0.09).cuda(), (rnd(2, nb, bs, bs, seed=7) * 0.09).cuda()
+    bb1, bb2 = (rnd(2, nb, bs, seed=8) * 0.1).cuda(), (rnd(2, nb, bs, seed=9) * 0.1).cuda()
+    dxn2 = rnd(B, h * h, E, seed=10).cuda()                       # upstream gradient (wrt xn2, or wrt y1 without the norm)
+    dout = rnd(B, h * h, E, seed=11).cuda() if add else None
+    packed = ops.AfnoPacks([(w1, bb1), (w2, bb2)]).refresh()
+    n = (g1, b1, g2, b2) if norm else (None, None, None, None)
+    S, pre, y1, xn2, m1, r1, m2, r2 = ops.afno_fused_fwd(x, n[0], n[1], packed[0][2], packed[0][1], packed[1][2],
+                                                         packed[1][1], n[2], n[3], h, h, nb, mx, my, a, save=True)
+    wb1, wb2 = packed[0][3], packed[1][3]
+    dx, dO2, O1, dPre, p1, p2 = ops.afno_fused_bwd(dxn2, y1 if norm else None, m2, r2, n[2], pre, wb2, wb1,
+                                                   x if norm else None, m1, r1, n[0], dout, h, h, nb, mx, my, a)
+    tol = dict(rtol=2e-5, atol_scale=2e-5)
+    # (a) the separate launches
+    if norm:
+        dy1, p2_3 = ops.groupnorm_bwd(dxn2, y1, m2, r2, g2, defer=True)
+    else:
+        dy1 = dxn2
+    dO2_3 = ops.rfft2(dy1, h, h, nb, mx, my, 1)
+    dS, O1_3, dPre_3 = ops.afno_mlp2(dO2_3, wb2, None, wb1, None, nb, bs, a, mode=1, aux=pre, want_mid=True, want_pre=True,
+                                     layout=1)
+    dxn1 = ops.irfft2(dS, B, h, h, E, nb, mx, my, 0, res=dy1)
+    if norm:
+        dx_3, p1_3 = ops.groupnorm_bwd(dxn1, x, m1, r1, g1, add=dout, defer=True)
+    else:
+        dx_3 = dxn1 + dout if add else dxn1
+    assert_close(dO2, dO2_3, "dO2", **tol)
+    assert_close(O1, O1_3, "O1", **tol)
+    assert_close(dPre, dPre_3, "dO1pre", **tol)
+    assert_close(dx, dx_3, "dx", **tol)
+    if norm:
+        assert_close(p1, p1_3, "norm1 parameter-gradient partials", rtol=1e-4, atol_scale=1e-4)
+        assert_close(p2, p2_3, "norm2 parameter-gradient partials", rtol=1e-4, atol_scale=1e-4)
+    else:
+        assert p1 is None and p2 is None
+    # (b) float64 autograd of the layer
+    xd = x.double().cpu().requires_grad_(True)
+    prm = [t.double().cpu().requires_grad_(True) for t in (g1, b1, g2, b2, w1, bb1, w2, bb2)]
+    G1, B1, G2, B2, W1p, C1p, W2p, C2p = prm
+
+    def gn(t, g, b):
+        td = t.view(B, h * h, G, E // G)
+        mu, var = td.mean(dim=(1, 3), keepdim=True), td.var(dim=(1, 3), unbiased=False, keepdim=True)
+        return ((td - mu) / torch.sqrt(var + 1e-5)).view(B, h * h, E) * g + b
+
+    xn = gn(xd, G1, B1) if norm else xd
+    F = torch.fft.rfft2(xn.view(B, h, h, E), dim=(1, 2), norm="ortho").view(B, h, 9, nb, bs)
+    o1 = torch.einsum("bxykI,kIO->bxykO", F, torch.complex(W1p[0], W1p[1])) + torch.complex(C1p[0], C1p[1])
+    f = ACTS[act]
+    o1 = torch.complex(f(o1.real), f(o1.imag))
+    o2 = torch.einsum("bxykI,kIO->bxykO", o1, torch.complex(W2p[0], W2p[1])) + torch.complex(C2p[0], C2p[1])
+    yref = torch.fft.irfft2(o2.reshape(B, h, 9, E), s=(h, h), dim=(1, 2), norm="ortho").reshape(B, h * h, E) + xn
+    out = gn(yref, G2, B2) if norm else yref
+    loss = (out * dxn2.double().cpu()).sum()
+    if add:
+        loss = loss + (xd * dout.double().cpu()).sum()
+    loss.backward()
+    assert_close(dx, xd.grad, "dx vs float64 autograd")
+    dw1, db1 = torch.empty(2, nb, bs, bs, device="cuda"), torch.empty(2, nb, bs, device="cuda")
+    dw2, db2 = torch.empty(2, nb, bs, bs, device="cuda"), torch.empty(2, nb, bs, device="cuda")
+    sk = ops.afno_wgrad2_splitk(B * mx * my, nb, bs)
+    if sk:
+        ops.afno_wgrad2(S, dPre, O1, dO2, nb, bs, dw1, db1, dw2, db2, sk)
+        for got, want, nm in ((dw1, W1p.grad, "dW1"), (db1, C1p.grad, "db1"), (dw2, W2p.grad, "dW2"), (db2, C2p.grad, "db2")):
+            assert_close(got, want, nm + " vs float64 autograd")
+    if norm:
+        assert_close(p1[0].sum(0), G1.grad, "dgamma1 vs float64 autograd")
+        assert_close(p1[1].sum(0), B1.grad, "dbeta1 vs float64 autograd")
+        assert_close(p2[0].sum(0), G2.grad, "dgamma2 vs float64 autograd")
+        assert_close(p2[1].sum(0), B2.grad, "dbeta2 vs float64 autograd")

@@ -89,13 +89,20 @@ def test_full_model_gradients_vs_oracle(name, B):
     print(f"[{name} B={B}] worst normalised gradient error {worst:.2e}")
 
 
-def test_full_model_gradients_with_one_launch_afno_layer(monkeypatch):
-    """DPOT-Tiny at batch 2 with the ONE-launch AFNO layer forward forced on (csrc/afno_fused.hip; `auto` selects it from
+@pytest.mark.parametrize("bwd", ["0", "1"])
+def test_full_model_gradients_with_one_launch_afno_layer(monkeypatch, bwd):
+    """(bwd = "1": with the one-launch BACKWARD of the layer as well - afno_fused_bwd_kernel, built and rejected by
+    measurement in round 5, kept behind DPOT_AFNO_LAYER_BWD=1 - so the opt-in path stays under the parity gate.)
+    DPOT-Tiny at batch 2 with the ONE-launch AFNO layer forward forced on (csrc/afno_fused.hip; `auto` selects it from
     205 (sample, block) workgroups on, i.e. for DPOT-S / -M at batch 32 - test_vs_reference_golden[SMALL-32 / MEDIUM-32] run it):
     64 channels per GroupNorm group = two groups per workgroup; every gradient vs the oracle at rtol 1e-4, and the
     no-grad forward (S / pre-activation not written) bit-identical to the training forward"""
     from dpot_amd import ops
     monkeypatch.setenv("DPOT_AFNO_LAYER", "1")
+    monkeypatch.setenv("DPOT_AFNO_LAYER_BWD", bwd)
+    bcalls = []
+    real_b = ops.afno_fused_bwd
+    monkeypatch.setattr(ops, "afno_fused_bwd", lambda *a, **k: (bcalls.append(1), real_b(*a, **k))[1])
     if not (ops.afno_mlp2_supported(4, 128) and ops.afno_mlp3_supported(4, 128) and ops.afno_fused_supported(16, 16, 512, 4, 16, 9)):
         pytest.skip("one-launch AFNO layer switched off")
     calls = []
@@ -104,6 +111,7 @@ def test_full_model_gradients_with_one_launch_afno_layer(monkeypatch):
     oc = _oracle_case("TINY", 2)
     m, xg, y, c = _hip_case("TINY", oc)
     assert calls == [True] * 4, calls
+    assert len(bcalls) == (4 if bwd == "1" else 0), bcalls
     assert_close(y, oc["y"], "pred")
     assert_close(xg.grad, oc["dx"], "dx")
     for k, p in m.named_parameters():
