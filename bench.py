@@ -540,18 +540,18 @@ def main():
     from dpot_amd.train import FlatParams, FusedAdam, GraphedTrainStep, SegmentedTrainStep, one_cycle_lr, train_step
     from dpot_amd.dp import dp_one_cycle_lr
     _lib.load()
-    ops.set_gemm_precision(args.gemm_precision)
 
     mlp_prec = args.mlp_precision if args.mlp_precision is not None else cmlp
 
     torch.manual_seed(0)                                       # identical random-init weights on every rank
     model = DPOTNet(**ckw).cuda()
-    model.mlp_precision = mlp_prec                             # per-model attribute (None: the process default = f32)
+    model.mlp_precision = mlp_prec                             # per-model attributes (None: the process default = f32)
+    model.gemm_precision = args.gemm_precision
     model.recompute_blocks = recompute
     fp = FlatParams(model)
     # DDP semantics for N>1: cls_head takes part (zero gradients -> weight decay only), grads averaged over ranks
     opt = FusedAdam(fp, lr=1e-3, betas=(0.9, 0.9), weight_decay=1e-6, max_norm=10000.0, update_tail=world > 1)
-    reducer = BucketedGradReducer(fp, n_buckets=4, overlap=True) if world > 1 else None
+    reducer = BucketedGradReducer(fp, overlap=True) if world > 1 else None     # bucket count by gradient bytes (dp.auto_n_buckets)
     if reducer is not None:
         reducer.broadcast_parameters(0)
     grad_scale = 1.0 / world
@@ -729,7 +729,7 @@ def main():
         if not headline and world == 1 and graphed is not None and args.gemm_precision == "auto" and not args.no_alt:
             # the bf16-channel-MLP configs run `auto`; the same step with every fp32 GEMM on native fp32 MFMA, beside it
             try:
-                ops.set_gemm_precision("f32")
+                model.gemm_precision = "f32"
                 g2 = GraphedTrainStep(model, opt, xx, yy, msk, noise_scale=args.noise_scale, warmup=1 if T_ar > 1 else 2)
                 for _ in range(args.warmup):
                     g2.replay(lr_at(step_idx[0]))
@@ -745,7 +745,7 @@ def main():
             except Exception as e:                             # pragma: no cover
                 log(f"[bench] gemm_f32 timing failed: {e}")
             finally:
-                ops.set_gemm_precision(args.gemm_precision)
+                model.gemm_precision = args.gemm_precision
         if args.config in ("M", "L") and world == 1 and graphed is not None and mlp_prec == "bf16" and not args.no_alt:
             # BASELINE configs[3] / [4] do not say bf16 (only configs[2] does): the SAME step with every GEMM on native fp32
             # MFMA - channel MLP included - i.e. the figure inside north_star's rtol 1e-4 (the parity gate of this mode:
@@ -757,10 +757,9 @@ def main():
                 model = opt = fp = None
                 gc.collect()
                 torch.cuda.empty_cache()
-                ops.set_gemm_precision("f32")
                 torch.manual_seed(0)
                 m32 = DPOTNet(**ckw).cuda()
-                m32.mlp_precision = None
+                m32.mlp_precision = m32.gemm_precision = "f32"
                 m32.recompute_blocks = recompute
                 o32 = FusedAdam(FlatParams(m32), lr=1e-3, betas=(0.9, 0.9), weight_decay=1e-6, max_norm=10000.0)
                 g32 = GraphedTrainStep(m32, o32, xx, yy, msk, noise_scale=args.noise_scale, warmup=2)
@@ -784,15 +783,13 @@ def main():
                 del g32, m32, o32
             except Exception as e:                             # pragma: no cover
                 log(f"[bench] all_f32 timing failed: {type(e).__name__}: {e}")
-            finally:
-                ops.set_gemm_precision(args.gemm_precision)
         if headline and world == 1 and graphed is not None and args.gemm_precision == "f32" and not args.no_alt \
                 and not args.brief:
             # not the headline: the same step with the large GEMMs on the bf16x6 kernel (fp32 emulated by operand
             # splitting on the bf16 matrix cores, same accuracy class - DESIGN.md "bf16x6"); a fresh graph is captured
             # because the kernel choice is baked in at capture time
             try:
-                ops.set_gemm_precision("auto")
+                model.gemm_precision = "auto"
                 g2 = GraphedTrainStep(model, opt, xx, yy, msk, noise_scale=args.noise_scale, warmup=2)
                 for _ in range(args.warmup):
                     g2.replay(lr_at(step_idx[0]))
@@ -809,7 +806,7 @@ def main():
             except Exception as e:                             # pragma: no cover
                 log(f"[bench] gemm_auto timing failed: {e}")
             finally:
-                ops.set_gemm_precision(args.gemm_precision)
+                model.gemm_precision = args.gemm_precision
         if world == 1 and T_ar == 1 and not args.brief:
             # forward-only (inference) rate of the same batch, SURVEY 8(d): no_grad forward, hipGraph replay
             try:

@@ -146,6 +146,13 @@ __global__ __launch_bounds__(64 * (NW + 2)) void gemm_panel_kernel(const PanelAr
 #pragma unroll
     for (int j = 0; j < NT; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
   auto mma = [&](const f32x4 (&af)[RT], const f32x4 (&bf)[NT]) __attribute__((always_inline)) {
+#ifdef PANEL_ABL_NOMFMA
+#pragma unroll
+    for (int i = 0; i < RT; ++i)
+#pragma unroll
+      for (int j = 0; j < NT; ++j) acc[i][j] += af[i] * bf[j][0];
+    return;
+#endif
 #pragma unroll
     for (int i = 0; i < RT; ++i)
 #pragma unroll
@@ -190,6 +197,17 @@ __global__ __launch_bounds__(64 * (NW + 2)) void gemm_panel_kernel(const PanelAr
     }
   }
   bar();                                               // S: every wave is done with the ring; all DMA has landed
+#ifdef PANEL_ABL_NOEPI   /* ablation builds (scripts/r05/panel_ablation.sh): results are garbage */
+  if (p.M > 0) {
+    float a = 0.f;
+#pragma unroll
+    for (int i = 0; i < RT; ++i)
+#pragma unroll
+      for (int j = 0; j < NT; ++j) a += acc[i][j][0] + acc[i][j][1] + acc[i][j][2] + acc[i][j][3];
+    if (a == 12345.678f) p.C[0] = a;
+    return;
+  }
+#endif
 
   // ---- epilogue: acc (+bias) -> [pre] -> act | * act'(aux) -> (+res) -> C
   float* const stage = stage_all + wave * (16 * WCOLS);
@@ -220,7 +238,9 @@ __global__ __launch_bounds__(64 * (NW + 2)) void gemm_panel_kernel(const PanelAr
       const int col = colw + 4 * c4;
       const bool ok = row < p.M;
       const long long rowc = ok ? row : p.M - 1;
-#ifndef PANEL_NO_NT_PRE   // saved for the backward only: non-temporal, it would only push live tensors out of L2 / Infinity Cache
+#ifdef PANEL_ABL_NOSTORE
+      if (p.pre && ok && v[0] == 12345.678f) p.pre[rowc * p.ldpre + col] = v[0];
+#elif !defined(PANEL_NO_NT_PRE)   // saved for the backward only: non-temporal, it would only push live tensors out of L2 / Infinity Cache
       if (p.pre && ok) {
         typedef float nt_f4 __attribute__((ext_vector_type(4)));
         const nt_f4 q = {v[0], v[1], v[2], v[3]};
@@ -242,7 +262,12 @@ __global__ __launch_bounds__(64 * (NW + 2)) void gemm_panel_kernel(const PanelAr
         const float4 r4 = *reinterpret_cast<const float4*>(p.res + rowc * p.ldres + col);
         v[0] += r4.x; v[1] += r4.y; v[2] += r4.z; v[3] += r4.w;
       }
-      if (ok) *reinterpret_cast<float4*>(p.C + rowc * p.ldc + col) = make_float4(v[0], v[1], v[2], v[3]);
+#ifdef PANEL_ABL_NOSTORE
+      if (ok && v[0] == 12345.678f)
+#else
+      if (ok)
+#endif
+        *reinterpret_cast<float4*>(p.C + rowc * p.ldc + col) = make_float4(v[0], v[1], v[2], v[3]);
     }
     __builtin_amdgcn_wave_barrier();
   };

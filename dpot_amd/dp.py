@@ -26,9 +26,20 @@ import torch.distributed as dist
 from .train import FlatParams
 
 
+def auto_n_buckets(grad_bytes: int) -> int:
+    """bucket count by gradient BYTES (round 5; a fixed 4 before): ~32 MB per bucket, at least 2 (one bucket would leave
+    nothing to overlap), at most 8 (every bucket boundary is a graph cut: ~40 us of host + launch gap per cut,
+    profiles/r05_dp_host_time.txt, and ring all-reduces over xGMI want large messages - 7 links x ~153 GB/s per GPU).
+    DPOT-Tiny (30 MB) -> 2, DPOT-S (123 MB) -> 4, DPOT-M (489 MB) / DPOT-L (2 GB) -> 8; SURVEY 8e: 2-4 for Tiny.
+    The reference leaves this to torch-DDP's 25 MB default (train_temporal_parallel.py:185 via accelerate)."""
+    return max(2, min(8, -(-int(grad_bytes) // (32 << 20))))
+
+
 class BucketedGradReducer:
-    def __init__(self, flat: FlatParams, process_group=None, n_buckets: int = 4, overlap: bool = True):
+    def __init__(self, flat: FlatParams, process_group=None, n_buckets: Optional[int] = None, overlap: bool = True):
         self.fp = flat
+        if n_buckets is None:
+            n_buckets = auto_n_buckets(flat.n_head * flat.grad.element_size())
         self.pg = process_group
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
         self.grad_scale = 1.0 / self.world
@@ -134,7 +145,7 @@ class BucketedGradReducer:
             self._launched[k] = True
             return
         if self.world == 1:
-            # dry run on one process (scripts/r04/dp_host_time.py): the stream choreography of a bucket all-reduce - side
+            # dry run on one process (scripts/dp_host_time.py): the stream choreography of a bucket all-reduce - side
             # stream waits for the compute stream, one device operation over the bucket on the side stream - without a
             # collective, to time the HOST side of the segmented step where no second GPU exists
             self._launched[k] = True

@@ -158,6 +158,7 @@ class EmbedFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, pos, w0, b0, w2, b2, taw, tagamma, gx, gy, gt, tt, P: int, act: int, derived=None):
+        ops.capture_precision(ctx)       # re-applied around backward (ops.with_ctx_precision)
         x = x.contiguous()
         B, X, Y, T, Cc = x.shape
         h, w = X // P, Y // P
@@ -195,6 +196,7 @@ class EmbedFn(torch.autograd.Function):
         return Yl.view(B, tok, E)
 
     @staticmethod
+    @ops.with_ctx_precision
     def backward(ctx, dY):
         _check_epoch(ctx, "EmbedFn")
         A0, Hpre, Hh, w0p, w2p, ws, V, wsum, posb, taw, tagamma, tt, grid = ctx.saved_tensors
@@ -455,6 +457,7 @@ class AFNO2DFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, w1, b1, w2, b2, h: int, w: int, nb: int, modes: int, act: int, packed=None):
+        ops.capture_precision(ctx)       # re-applied around backward (ops.with_ctx_precision)
         x = x.contiguous()
         B, tok, E = x.shape
         bs = E // nb
@@ -473,6 +476,7 @@ class AFNO2DFn(torch.autograd.Function):
         return y1
 
     @staticmethod
+    @ops.with_ctx_precision
     def backward(ctx, dy):
         _check_epoch(ctx, "AFNO2DFn")
         S, O1pre, O1, wb1, wb2 = ctx.saved_tensors
@@ -603,13 +607,15 @@ class BlockFn(torch.autograd.Function):
         ctx.dims = dims
         ctx.afno_layout = getattr(packed[0], "layout", 0) if ctx.fused_mixer else 0
         ctx.mlp_precision = mp
+        ctx.gemm_precision = ops._cur_gemm()
         ctx.sinks = _sinks(ctx, (n1w, n1b, w1, b1, w2, b2, n2w, n2b, f1w, f1b, f2w, f2b), 1)
         ctx.weights_epoch = _epoch_of(ctx.sinks)
         return out.view(B, tok, E)
 
     @staticmethod
     def backward(ctx, dout):
-        with ops.mlp_precision_scope(ctx.mlp_precision):      # the mode the forward ran in (a per-model attribute)
+        # the modes the forward ran in (per-model attributes), whatever thread autograd runs this on
+        with ops.precision_scope(getattr(ctx, "gemm_precision", None), ctx.mlp_precision):
             return BlockFn._backward(ctx, dout)
 
     @staticmethod
@@ -796,6 +802,7 @@ class HeadFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, o0w, o0b, o2w, o2b, o4w, o4b, c0w, c0b, c2w, c2b, c4w, c4b, h: int, w: int, P: int, act: int,
                 derived=None):
+        ops.capture_precision(ctx)       # re-applied around backward (ops.with_ctx_precision)
         ctx.set_materialize_grads(False)      # an unused output (cls_pred in train_temporal.py:226) costs nothing
         x = x.contiguous()
         B, tok, E = x.shape
@@ -851,6 +858,7 @@ class HeadFn(torch.autograd.Function):
         return pred, cls
 
     @staticmethod
+    @ops.with_ctx_precision
     def backward(ctx, dpred, dcls):
         _check_epoch(ctx, "HeadFn")
         x, wt, U, Upre, V, Vpre, o2w, o2b, o4w, cm, c1, c1pre, c2, c2pre, c0w, c2w, c4w = ctx.saved_tensors

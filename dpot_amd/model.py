@@ -124,6 +124,9 @@ class DPOTNet(nn.Module):
         # precision of the channel-MLP GEMMs of THIS model: None = the process default (ops.set_mlp_precision /
         # DPOT_MLP_PRECISION), or 'f32' | 'bf16x6' | 'auto' | 'bf16' (BASELINE configs[2]: "bf16 channel-MLP on MFMA")
         self.mlp_precision = None
+        # precision of every OTHER fp32 GEMM of this model: None = the process default (ops.set_gemm_precision /
+        # DPOT_GEMM_PRECISION), or 'f32' (native fp32 MFMA) | 'bf16x6' | 'auto' (the fp32-accurate operand split where faster)
+        self.gemm_precision = None
         self._scope_depth = 0
         self._scope_cache = None
         # optional callable(b, lat) -> lat, called with the latent ENTERING stage b (1..depth = block b-1,
@@ -143,7 +146,7 @@ class DPOTNet(nn.Module):
         if self._scope_depth == 1:
             self._scope_cache = None
             if dev.type == "cuda":
-                with ops.mlp_precision_scope(self.mlp_precision):
+                with ops.precision_scope(self.gemm_precision, self.mlp_precision):
                     self._derived_weights()
         try:
             yield self
@@ -250,7 +253,7 @@ class DPOTNet(nn.Module):
         return mlp_pk, head_pk
 
     def forward(self, x):
-        with ops.mlp_precision_scope(self.mlp_precision):
+        with ops.precision_scope(self.gemm_precision, self.mlp_precision):
             return self._forward(x)
 
     def _forward(self, x):

@@ -8,6 +8,8 @@ from __future__ import annotations
 
 import ctypes as C
 import contextlib
+import functools
+import threading
 import os
 from typing import Optional, Tuple
 
@@ -36,7 +38,7 @@ def set_gemm_precision(name: str) -> None:
 
 
 def gemm_precision() -> str:
-    return {v: k for k, v in _PRECISIONS.items()}[_gemm_precision]
+    return {v: k for k, v in _PRECISIONS.items()}[_cur_gemm()]
 
 
 # precision of the channel-MLP GEMMs only (Block.mlp, models/dpot.py:157-161); None = follow the global setting.
@@ -51,32 +53,94 @@ def set_mlp_precision(name: Optional[str]) -> None:
     _mlp_precision = None if name is None else _PRECISIONS[name]
 
 
+# per-THREAD overrides of the two process defaults above, set by the scopes below (round 5; ADVICE r4: the per-model
+# precision used to be a temporary write to the process-global, visible to a backward of another model running on autograd's
+# device thread at the same time).  A model applies its attributes around its own forward / weight derivation; every autograd
+# Function captures the effective values in its context and re-applies them around its backward, whatever thread runs it.
+_tls = threading.local()
+_UNSET = object()
+
+
+def _cur_gemm() -> int:
+    v = getattr(_tls, "gemm", None)
+    return _gemm_precision if v is None else v
+
+
+def _cur_mlp() -> Optional[int]:
+    v = getattr(_tls, "mlp", _UNSET)
+    return _mlp_precision if v is _UNSET else v
+
+
+def _code(prec) -> int:
+    return _PRECISIONS[prec] if isinstance(prec, str) else int(prec)
+
+
 @contextlib.contextmanager
 def mlp_precision_scope(prec):
     """the channel-MLP precision of ONE model while its kernels are being enqueued: `DPOTNet.mlp_precision` (a
     per-model attribute: 'f32' | 'bf16x6' | 'auto' | 'bf16' | None = the process default above) is applied around the
     model's forward, its weight derivation and - through the value captured in the autograd context - its backward, so two
-    models of one process can run different modes and nothing leaks to the next caller.  prec: a name, a precision code
-    or None (= leave the current setting)."""
-    global _mlp_precision
+    models of one process can run different modes and nothing leaks to the next caller or to another thread.  prec: a name,
+    a precision code or None (= leave the current setting)."""
     if prec is None:
         yield
         return
-    prev = _mlp_precision
-    _mlp_precision = _PRECISIONS[prec] if isinstance(prec, str) else int(prec)
+    prev = getattr(_tls, "mlp", _UNSET)
+    _tls.mlp = _code(prec)
     try:
         yield
     finally:
-        _mlp_precision = prev
+        if prev is _UNSET:
+            del _tls.mlp
+        else:
+            _tls.mlp = prev
+
+
+@contextlib.contextmanager
+def gemm_precision_scope(prec):
+    """the same for the GEMM precision of everything OUTSIDE the channel MLP (`DPOTNet.gemm_precision`: 'f32' | 'bf16x6' |
+    'auto' | None = the process default of set_gemm_precision / DPOT_GEMM_PRECISION)"""
+    if prec is None:
+        yield
+        return
+    prev = getattr(_tls, "gemm", None)
+    _tls.gemm = _code(prec)
+    try:
+        yield
+    finally:
+        _tls.gemm = prev
+
+
+@contextlib.contextmanager
+def precision_scope(gemm=None, mlp=None):
+    with gemm_precision_scope(gemm), mlp_precision_scope(mlp):
+        yield
+
+
+def with_ctx_precision(backward):
+    """decorator for torch.autograd.Function.backward: re-apply the precisions the forward captured in ctx.gemm_precision /
+    ctx.mlp_precision (see capture_precision) - autograd runs backward on its own thread, long after the model's scope"""
+    @functools.wraps(backward)
+    def wrapper(ctx, *grads):
+        with precision_scope(getattr(ctx, "gemm_precision", None), getattr(ctx, "mlp_precision", None)):
+            return backward(ctx, *grads)
+    return wrapper
+
+
+def capture_precision(ctx) -> None:
+    """store the precisions in effect on this thread in an autograd context (forward side of with_ctx_precision)"""
+    ctx.gemm_precision = _cur_gemm()
+    ctx.mlp_precision = _cur_mlp()
 
 
 def effective_mlp_precision() -> int:
-    """precision the channel-MLP GEMMs run in: the override if set, else the global GEMM precision"""
-    return _mlp_precision if _mlp_precision is not None else _gemm_precision
+    """precision the channel-MLP GEMMs run in: the override if set, else the GEMM precision in effect"""
+    m = _cur_mlp()
+    return m if m is not None else _cur_gemm()
 
 
 def mlp_precision() -> Optional[int]:
-    return _mlp_precision
+    return _cur_mlp()
 
 
 def _stream() -> int:
@@ -104,7 +168,7 @@ def auto_splitk(M: int, N: int, K: int, batch: int = 1, precision: Optional[int]
     """split-K factor for a GEMM; tn: a weight gradient (transA, not transB) - in native fp32 those run on the kernel
     of csrc/gemm_tn.hip, which wants one 128x128 workgroup per CU"""
     lib = _lib.load()
-    prec = _gemm_precision if precision is None else precision
+    prec = _cur_gemm() if precision is None else precision
     if tn and prec == GEMM_F32:
         s = lib.dpot_gemm_tn_splitk(M, N, K, batch)
         if s > 0:
@@ -137,7 +201,7 @@ def gemm(A: Tensor, B: Tensor, C_: Tensor, M: int, N: int, K: int, *, transA: bo
     d.accumulate = int(accumulate)
     d.tile = tile
     d.tag = tag
-    d.precision = _gemm_precision if precision is None else precision
+    d.precision = _cur_gemm() if precision is None else precision
     if splitk is None:
         # launches that cannot fill the chip (<= 128 output tiles: the embed fold's T small products, the cls head,
         # pos-embed terms) are latency bound - spread their K over more workgroups; big grids stay un-split
@@ -161,7 +225,7 @@ def gemm(A: Tensor, B: Tensor, C_: Tensor, M: int, N: int, K: int, *, transA: bo
 def panel_enabled() -> bool:
     """the panel kernel is an fp32 kernel: used while the global GEMM precision is 'f32' (the channel-MLP override of
     set_mlp_precision is checked where it applies, functional._mlp_panel_ok)"""
-    return os.environ.get("DPOT_PANEL_GEMM", "1") != "0" and _gemm_precision == GEMM_F32
+    return os.environ.get("DPOT_PANEL_GEMM", "1") != "0" and _cur_gemm() == GEMM_F32
 
 
 def gemm_panel_supported(M: int, N: int, K: int) -> bool:
@@ -389,7 +453,7 @@ def linear_fwd(x: Tensor, W: Tensor, bias: Optional[Tensor], act: int = 0, save_
     y = torch.empty(M, N, dtype=torch.float32, device=x.device)
     pre = torch.empty_like(y) if save_pre else None
     lib = _lib.load()
-    prec = _gemm_precision if precision is None else precision
+    prec = _cur_gemm() if precision is None else precision
     if (res is None and M <= 128 and prec != GEMM_BF16 and lib.dpot_small_linear_supported(M, N, K)
             and os.environ.get("DPOT_SMALL_LINEAR", "1") != "0"):
         # a handful of rows (the cls_head on the token mean): one pass over W, no split-K / reduce pair; exact fp32
@@ -578,7 +642,7 @@ def afno_block_weights(wbig: Tensor) -> Tuple[Tensor, Tensor]:
 
 def mlp_wgrad2_splitk(T: int, E: int, mh: int, precision: Optional[int] = None) -> int:
     """split factor of the fused fc1 + fc2 weight gradient (0: not covered / not worthwhile -> two separate GEMMs)"""
-    prec = _gemm_precision if precision is None else precision
+    prec = _cur_gemm() if precision is None else precision
     return _lib.load().dpot_mlp_wgrad2_splitk(T, E, mh) if prec == GEMM_F32 else 0
 
 
@@ -598,7 +662,7 @@ def mlp_wgrad2(do2: Tensor, Hh: Tensor, xn2: Tensor, dHpre: Tensor, dW2: Tensor,
 
 def afno_wgrad2_splitk(Mm: int, nb: int, bs: int) -> int:
     """split factor of the fused two-layer AFNO weight gradient (0: shape not covered -> two generic GEMM launches)"""
-    return _lib.load().dpot_afno_wgrad2_splitk(Mm, nb, bs) if _gemm_precision in (GEMM_F32, GEMM_AUTO) else 0
+    return _lib.load().dpot_afno_wgrad2_splitk(Mm, nb, bs) if _cur_gemm() in (GEMM_F32, GEMM_AUTO) else 0
 
 
 def afno_wgrad2(S: Tensor, dO1pre: Tensor, O1: Tensor, dO2: Tensor, nb: int, bs: int, dw1: Tensor, db1: Tensor,

@@ -4,7 +4,7 @@ device operation on the side stream, no collective - there is no second GPU here
 time spent inside replay() and the number of graph launches / bucket hand-offs per step; compare with GraphedTrainStep (one
 graph, no buckets).  The host time must stay well below the step time, or the GPU starves at N > 1."""
 import os, sys, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from dpot_amd import DPOTNet
 from dpot_amd.dp import BucketedGradReducer
@@ -25,7 +25,7 @@ def run(kind, n_buckets=4, steps=200):
         g = GraphedTrainStep(model, opt, xx, yy, msk, noise_scale=0.0005)
         nseg, nb = 1, 0
     else:
-        red = BucketedGradReducer(fp, n_buckets=n_buckets, overlap=True)
+        red = BucketedGradReducer(fp, n_buckets=n_buckets, overlap=True)       # n_buckets None: dp.auto_n_buckets (by bytes)
         red.dry_run = True
         g = SegmentedTrainStep(model, opt, red, xx, yy, msk, noise_scale=0.0005)
         nseg, nb = len(g.graphs) + 1, red.n_buckets
@@ -53,5 +53,6 @@ def run(kind, n_buckets=4, steps=200):
 
 
 run("single")
+run("segmented, auto buckets", None)
 for nb in (2, 4, 8):
     run(f"segmented, {nb} buckets", nb)

@@ -89,3 +89,12 @@ def test_two_rank_gloo_bucketed_allreduce(tmp_path):
     want = dict(zip([str(n) for n in fx["names"]], fx["grad_norms"]))
     for n, v in zip(got["names"], got["norms"]):
         assert abs(v - want[str(n)]) <= 1e-4 * want[str(n)] + 1e-7, n
+
+
+def test_bucket_count_follows_the_gradient_bytes():
+    """round 5: the default bucket count comes from the gradient BYTES (~32 MB per bucket, 2..8; a fixed 4 before) -
+    DPOT-Tiny 30 MB -> 2 (+ the grad-less cls_head tail bucket), DPOT-M 489 MB / DPOT-L 2 GB -> 8"""
+    from dpot_amd.dp import auto_n_buckets
+    assert auto_n_buckets(30 << 20) == 2 and auto_n_buckets(1 << 20) == 2
+    assert auto_n_buckets(123 << 20) == 4
+    assert auto_n_buckets(489 << 20) == 8 and auto_n_buckets(2 << 30) == 8

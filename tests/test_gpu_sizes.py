@@ -225,6 +225,45 @@ def test_mlp_precision_is_a_per_model_attribute():
     assert ops.mlp_precision() is None
 
 
+def test_gemm_precision_is_a_per_model_attribute():
+    """the GEMM precision of everything outside the channel MLP is an attribute of the MODEL too
+    (`DPOTNet.gemm_precision`, per-thread scopes in ops - ADVICE r4: no temporary write to a process global any more):
+    a bf16x6 model (fp32-accurate operand split on every GEMM) and a native-fp32 model run interleaved in one process, the
+    backward of each re-applies the forward's mode; the fp32 model is bit-identical to a plain run, the bf16x6 one agrees with
+    it at fp32 level but not bit for bit, the process default is untouched"""
+    from dpot_amd import DPOTNet, ops
+    assert ops.gemm_precision() == "f32" or ops.gemm_precision() == "auto"
+    default = ops.gemm_precision()
+    cfg = R.DPOTConfig(**R.TINY)
+    S = cfg.img_size
+    x = R.recipe_input((4, S, S, cfg.in_timesteps, cfg.in_channels), salt=71).cuda()
+    up = (R.recipe_input((4, S, S, cfg.out_timesteps, cfg.out_channels), salt=72) * 0.3).cuda()
+
+    def fresh(prec):
+        m = DPOTNet(**R.TINY)
+        m.load_state_dict(_recipe_sd("TINY", 4))
+        m.cuda()
+        m.gemm_precision = prec
+        return m
+
+    def run(m):
+        y, _ = m(x)
+        (y * up).sum().backward()
+        return y.detach().clone(), m.blocks[0].mlp[0].weight.grad.clone(), m.out_layer[0].weight.grad.clone()
+
+    y32, g32, h32 = run(fresh("f32"))
+    a, b = fresh("bf16x6"), fresh("f32")
+    ya, _ = a(x)
+    yb, _ = b(x)
+    (ya * up).sum().backward()                                   # backward of A after B's forward
+    (yb * up).sum().backward()
+    assert torch.equal(yb, y32) and torch.equal(b.blocks[0].mlp[0].weight.grad, g32)
+    assert torch.equal(b.out_layer[0].weight.grad, h32), "fp32 model disturbed by its neighbour"
+    assert not torch.equal(ya, y32), "the bf16x6 model ran the native kernels"
+    assert _nrel(ya, y32) <= 1e-5 and _nrel(a.out_layer[0].weight.grad, h32) <= 1e-5
+    assert ops.gemm_precision() == default
+
+
 def test_small_model_at_1024_resolution_vs_oracle():
     """the largest resolution utils/griddataset.py:35 lists (1024^2 -> a 128 x 128 latent grid at patch 8): a small DPOT
     (embed 64, depth 2) end to end against the CPU oracle - forward, dx, every parameter gradient; the mixer's DFTs run on
