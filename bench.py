@@ -257,34 +257,29 @@ def bf16_mlp_roofline(model, B: int):
     pk = ops.PanelPacks([(W1, mh, E, E, False)], bf16=True)
     pk.refresh()
     xp = ops.bf16_pack_rows(x)
+    # round 5: where the paired weight-gradient launch reads the hidden layer in ROW form (transposing LDS read), this launch
+    # no longer writes the transposed pack - as in the model (functional._mlp_rowform)
+    rowform = os.environ.get("DPOT_BF16P_ROWFORM", "0") == "1" and ops.gemm_bf16p_pair_rowform_ok(mh, E, mh, E, M)
     t = timeit_graph(lambda: ops.gemm_bf16p_packed(xp, pk.bufs[0], M, mh, E, bias=b1, act=1, mode=ops.EPI_ACT, save_dact=True,
-                                                    pack_rows=True, pack_trans=True, store=False), reps=20)
+                                                    pack_rows=True, pack_trans=not rowform, store=False), reps=20)
     fl = 2.0 * M * mh * E
-    by = 2.0 * M * E + 2.0 * mh * E + 3 * 2.0 * M * mh            # packed A + packed W read once, three bf16 packs written
-    traffic, tnote, util = None, "no PMC profile for this shape (profiles/r04_pmc_bf16p_M.json holds DPOT-M, batch 32)", None
+    npk = 2 if rowform else 3
+    by = 2.0 * M * E + 2.0 * mh * E + npk * 2.0 * M * mh          # packed A + packed W read once, the bf16 packs written
+    traffic, tnote, util = None, "no PMC profile for this shape (profiles/r05_pmc_bf16p_M.json holds DPOT-M, batch 32)", None
     try:
-        pmc = json.load(open(os.path.join(ROOT, "profiles", "r04_pmc_bf16p_M.json")))["forms"]["fc1_fwd"]
+        pmc = json.load(open(os.path.join(ROOT, "profiles", "r05_pmc_bf16p_M.json")))["forms"]["fc1_fwd"]
         if (M, E, mh) == (8192, 1024, 4096):
             traffic = float(pmc["bytes_guide"])
             util = pmc.get("mfma_util")
-            tnote = ("rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes (profiles/r04_pmc_bf16p_M.json): (2*FETCH + "
+            tnote = ("rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes (profiles/r05_pmc_bf16p_M.json): (2*FETCH + "
                      "WRITE)*1024 B; un-doubled %.0f MB; algorithmic = A pack + W pack read once + three bf16 packs written"
                      % (pmc["bytes_raw"] / 1e6))
     except Exception:
         pass
-    tiles = ((M + 127) // 128) * (mh // 256)
-    bd = os.environ.get("DPOT_BF16P_BD", "1") != "0" and (tiles >= 512 or E >= 2048)
-    if bd:
-        kname = ("dpot::gemm_bf16p_bd_kernel<8,2,3> (B-direct: W fragments straight from global memory into registers, only "
-                 "the A panel through LDS; four 128 x 64 waves, two workgroups per CU)" if tiles >= 512 else
-                 "dpot::gemm_bf16p_bd_kernel<8,1,3> (B-direct, eight 128 x 32 waves)")
-    else:
-        duo = tiles >= 512 and os.environ.get("DPOT_BF16P_DUO", "1") != "0"
-        kname = ("dpot::gemm_bf16p_duo_kernel (two 8-wave workgroups per CU)" if duo else
-                 "dpot::gemm_bf16p_kernel (8 compute + 4 loader waves, LDS-DMA)")
+    kname = ops.gemm_bf16p_kernel_name(M, mh, E, packed_outputs=True)       # the library's own selection
     return {"kernel": kname + " - channel-MLP fc1 forward: bf16 operands pre-packed fragment-block-major, "
-                      "v_mfma_f32_32x32x16_bf16, epilogue in the accumulator layout writes the activated hidden layer as row + "
-                      "transposed bf16 packs and act' as a bf16 pack",
+                      "v_mfma_f32_32x32x16_bf16, epilogue in the accumulator layout writes the activated hidden layer as a row-form "
+                      "bf16 pack" + ("" if rowform else " + a transposed one") + " and act' as a bf16 pack",
             "shape": [M, mh, E], "bound": "mfma", "achieved": round(fl / t / 1e12, 1), "peak": 2500.0, "unit": "TFLOP/s",
             "frac": round(fl / t / 1e12 / 2500.0, 4), "us_per_launch": round(t * 1e6, 2), "flops_per_launch": fl,
             "algorithmic_bytes_per_launch": by, "hbm_frac": round(by / t / 1e9 / HBM_PEAK_GBS, 4), "traffic": traffic,

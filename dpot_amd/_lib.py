@@ -145,7 +145,10 @@ SIGNATURES = {
     "dpot_gemm_bf16p_splitk": (c_i, [c_i, c_i, c_i]),
     "dpot_gemm_bf16p_pair_wanted": (c_i, [c_i] * 5),
     "dpot_gemm_bf16p_pair_splitk": (c_i, [c_i] * 5),
-    "dpot_gemm_bf16p_pair": (c_i, [c_fp, c_fp, c_fp, c_i, c_i, c_i, c_fp, c_fp, c_fp, c_i, c_i, c_i, c_i, c_i, c_fp, c_fp]),
+    "dpot_gemm_bf16p_pair_rowform_ok": (c_i, [c_i] * 5),
+    "dpot_gemm_bf16p_kernel_kind": (c_i, [c_i] * 6),
+    "dpot_gemm_bf16p_pair": (c_i, [c_fp, c_fp, c_fp, c_i, c_i, c_i, c_fp, c_fp, c_fp, c_i, c_i, c_i, c_i, c_i, c_fp, c_i, c_i,
+                                   c_fp]),
     "dpot_gemm_tn_splitk": (c_i, [c_i] * 4),
     "dpot_mlp_wgrad2_splitk": (c_i, [c_i] * 3),
     "dpot_mlp_wgrad2_ws_elems": (c_i64, [c_i] * 3),

@@ -266,7 +266,7 @@ extern "C" int dpot_rfft2(const float* x, float* spec, int B, int h, int w, int 
     return DPOT_EUNSUP;
   }
   const size_t lds = sizeof(float) * (tw + (size_t)CC * ((size_t)h * w + (size_t)h * my * 2));
-  hipFuncSetAttribute(reinterpret_cast<const void*>(rfft2_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(rfft2_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                       (int)lds);
   const float scale = (float)(1.0 / sqrt((double)h * (double)w));
   hipLaunchKernelGGL(rfft2_kernel, dim3(E / CC, B), dim3(256), lds, as_stream(stream), x, spec, h, w, E, nb, mx, my,
@@ -316,7 +316,7 @@ extern "C" int dpot_irfft2(const float* spec, const float* res, float* y, int B,
     return DPOT_EUNSUP;
   }
   const size_t lds = sizeof(float) * (tw + (size_t)CC * ((size_t)mx * my * 2 + (size_t)h * my * 2));
-  hipFuncSetAttribute(reinterpret_cast<const void*>(irfft2_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(irfft2_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                       (int)lds);
   const float scale = (float)(1.0 / sqrt((double)h * (double)w));
   hipLaunchKernelGGL(irfft2_kernel, dim3(E / CC, B), dim3(256), lds, as_stream(stream), spec, res, y, h, w, E, nb,

@@ -1,4 +1,5 @@
-// dft_fast.h - register-blocked rfft2 / irfft2 for the power-of-two latent grids: 16x16 (128^2 / patch 8) and 32x32
+// dft_fast.h - register-blocked rfft2 / irfft2 for the power-of-two latent grids (and, round 5, the 3 * 2^k ones: 24 / 48 / 96
+// = 192^2 / 384^2 / 768^2 fields at patch 8, one radix-3 stage in front of three 2^k-point transforms): 16x16 (128^2 / patch 8) and 32x32
 // (256^2 / patch 8) - what the DPOT configs use - plus 8x8, 64x64 and 128x128 (64^2, 512^2 and 1024^2 fields at patch 8:
 // the other resolutions utils/griddataset.py:35 lists; 128^2 / 256^2 at patch 16 / 4).  Same contract as the generic
 // kernels in dft.hip (which keep every other size, odd ones included):
@@ -72,6 +73,40 @@ template <> struct Twid<128> {
   }
 };
 
+// 3 * 2^k lines (round 5: 24 / 48 / 96-point latent grids = 192^2 / 384^2 / 768^2 fields at patch 8)
+template <> struct Twid<24> {
+  static __host__ __device__ constexpr float c(int i) {
+    constexpr float t[24] = {1.0f, 0.9659258127212524f, 0.8660253882408142f, 0.7071067690849304f, 0.5f, 0.258819043636322f, 0.0f, -0.258819043636322f, -0.5f, -0.7071067690849304f, -0.8660253882408142f, -0.9659258127212524f, -1.0f, -0.9659258127212524f, -0.8660253882408142f, -0.7071067690849304f, -0.5f, -0.258819043636322f, 0.0f, 0.258819043636322f, 0.5f, 0.7071067690849304f, 0.8660253882408142f, 0.9659258127212524f};
+    return t[i];
+  }
+  static __host__ __device__ constexpr float s(int i) {
+    constexpr float t[24] = {0.0f, 0.258819043636322f, 0.5f, 0.7071067690849304f, 0.8660253882408142f, 0.9659258127212524f, 1.0f, 0.9659258127212524f, 0.8660253882408142f, 0.7071067690849304f, 0.5f, 0.258819043636322f, 0.0f, -0.258819043636322f, -0.5f, -0.7071067690849304f, -0.8660253882408142f, -0.9659258127212524f, -1.0f, -0.9659258127212524f, -0.8660253882408142f, -0.7071067690849304f, -0.5f, -0.258819043636322f};
+    return t[i];
+  }
+};
+
+template <> struct Twid<48> {
+  static __host__ __device__ constexpr float c(int i) {
+    constexpr float t[48] = {1.0f, 0.9914448857307434f, 0.9659258127212524f, 0.9238795042037964f, 0.8660253882408142f, 0.7933533191680908f, 0.7071067690849304f, 0.6087614297866821f, 0.5f, 0.3826834261417389f, 0.258819043636322f, 0.13052618503570557f, 0.0f, -0.13052618503570557f, -0.258819043636322f, -0.3826834261417389f, -0.5f, -0.6087614297866821f, -0.7071067690849304f, -0.7933533191680908f, -0.8660253882408142f, -0.9238795042037964f, -0.9659258127212524f, -0.9914448857307434f, -1.0f, -0.9914448857307434f, -0.9659258127212524f, -0.9238795042037964f, -0.8660253882408142f, -0.7933533191680908f, -0.7071067690849304f, -0.6087614297866821f, -0.5f, -0.3826834261417389f, -0.258819043636322f, -0.13052618503570557f, 0.0f, 0.13052618503570557f, 0.258819043636322f, 0.3826834261417389f, 0.5f, 0.6087614297866821f, 0.7071067690849304f, 0.7933533191680908f, 0.8660253882408142f, 0.9238795042037964f, 0.9659258127212524f, 0.9914448857307434f};
+    return t[i];
+  }
+  static __host__ __device__ constexpr float s(int i) {
+    constexpr float t[48] = {0.0f, 0.13052618503570557f, 0.258819043636322f, 0.3826834261417389f, 0.5f, 0.6087614297866821f, 0.7071067690849304f, 0.7933533191680908f, 0.8660253882408142f, 0.9238795042037964f, 0.9659258127212524f, 0.9914448857307434f, 1.0f, 0.9914448857307434f, 0.9659258127212524f, 0.9238795042037964f, 0.8660253882408142f, 0.7933533191680908f, 0.7071067690849304f, 0.6087614297866821f, 0.5f, 0.3826834261417389f, 0.258819043636322f, 0.13052618503570557f, 0.0f, -0.13052618503570557f, -0.258819043636322f, -0.3826834261417389f, -0.5f, -0.6087614297866821f, -0.7071067690849304f, -0.7933533191680908f, -0.8660253882408142f, -0.9238795042037964f, -0.9659258127212524f, -0.9914448857307434f, -1.0f, -0.9914448857307434f, -0.9659258127212524f, -0.9238795042037964f, -0.8660253882408142f, -0.7933533191680908f, -0.7071067690849304f, -0.6087614297866821f, -0.5f, -0.3826834261417389f, -0.258819043636322f, -0.13052618503570557f};
+    return t[i];
+  }
+};
+
+template <> struct Twid<96> {
+  static __host__ __device__ constexpr float c(int i) {
+    constexpr float t[96] = {1.0f, 0.9978589415550232f, 0.9914448857307434f, 0.9807852506637573f, 0.9659258127212524f, 0.9469301104545593f, 0.9238795042037964f, 0.8968727588653564f, 0.8660253882408142f, 0.8314695954322815f, 0.7933533191680908f, 0.751839816570282f, 0.7071067690849304f, 0.659345805644989f, 0.6087614297866821f, 0.5555702447891235f, 0.5f, 0.44228869676589966f, 0.3826834261417389f, 0.3214394748210907f, 0.258819043636322f, 0.19509032368659973f, 0.13052618503570557f, 0.06540312618017197f, 0.0f, -0.06540312618017197f, -0.13052618503570557f, -0.19509032368659973f, -0.258819043636322f, -0.3214394748210907f, -0.3826834261417389f, -0.44228869676589966f, -0.5f, -0.5555702447891235f, -0.6087614297866821f, -0.659345805644989f, -0.7071067690849304f, -0.751839816570282f, -0.7933533191680908f, -0.8314695954322815f, -0.8660253882408142f, -0.8968727588653564f, -0.9238795042037964f, -0.9469301104545593f, -0.9659258127212524f, -0.9807852506637573f, -0.9914448857307434f, -0.9978589415550232f, -1.0f, -0.9978589415550232f, -0.9914448857307434f, -0.9807852506637573f, -0.9659258127212524f, -0.9469301104545593f, -0.9238795042037964f, -0.8968727588653564f, -0.8660253882408142f, -0.8314695954322815f, -0.7933533191680908f, -0.751839816570282f, -0.7071067690849304f, -0.659345805644989f, -0.6087614297866821f, -0.5555702447891235f, -0.5f, -0.44228869676589966f, -0.3826834261417389f, -0.3214394748210907f, -0.258819043636322f, -0.19509032368659973f, -0.13052618503570557f, -0.06540312618017197f, 0.0f, 0.06540312618017197f, 0.13052618503570557f, 0.19509032368659973f, 0.258819043636322f, 0.3214394748210907f, 0.3826834261417389f, 0.44228869676589966f, 0.5f, 0.5555702447891235f, 0.6087614297866821f, 0.659345805644989f, 0.7071067690849304f, 0.751839816570282f, 0.7933533191680908f, 0.8314695954322815f, 0.8660253882408142f, 0.8968727588653564f, 0.9238795042037964f, 0.9469301104545593f, 0.9659258127212524f, 0.9807852506637573f, 0.9914448857307434f, 0.9978589415550232f};
+    return t[i];
+  }
+  static __host__ __device__ constexpr float s(int i) {
+    constexpr float t[96] = {0.0f, 0.06540312618017197f, 0.13052618503570557f, 0.19509032368659973f, 0.258819043636322f, 0.3214394748210907f, 0.3826834261417389f, 0.44228869676589966f, 0.5f, 0.5555702447891235f, 0.6087614297866821f, 0.659345805644989f, 0.7071067690849304f, 0.751839816570282f, 0.7933533191680908f, 0.8314695954322815f, 0.8660253882408142f, 0.8968727588653564f, 0.9238795042037964f, 0.9469301104545593f, 0.9659258127212524f, 0.9807852506637573f, 0.9914448857307434f, 0.9978589415550232f, 1.0f, 0.9978589415550232f, 0.9914448857307434f, 0.9807852506637573f, 0.9659258127212524f, 0.9469301104545593f, 0.9238795042037964f, 0.8968727588653564f, 0.8660253882408142f, 0.8314695954322815f, 0.7933533191680908f, 0.751839816570282f, 0.7071067690849304f, 0.659345805644989f, 0.6087614297866821f, 0.5555702447891235f, 0.5f, 0.44228869676589966f, 0.3826834261417389f, 0.3214394748210907f, 0.258819043636322f, 0.19509032368659973f, 0.13052618503570557f, 0.06540312618017197f, 0.0f, -0.06540312618017197f, -0.13052618503570557f, -0.19509032368659973f, -0.258819043636322f, -0.3214394748210907f, -0.3826834261417389f, -0.44228869676589966f, -0.5f, -0.5555702447891235f, -0.6087614297866821f, -0.659345805644989f, -0.7071067690849304f, -0.751839816570282f, -0.7933533191680908f, -0.8314695954322815f, -0.8660253882408142f, -0.8968727588653564f, -0.9238795042037964f, -0.9469301104545593f, -0.9659258127212524f, -0.9807852506637573f, -0.9914448857307434f, -0.9978589415550232f, -1.0f, -0.9978589415550232f, -0.9914448857307434f, -0.9807852506637573f, -0.9659258127212524f, -0.9469301104545593f, -0.9238795042037964f, -0.8968727588653564f, -0.8660253882408142f, -0.8314695954322815f, -0.7933533191680908f, -0.751839816570282f, -0.7071067690849304f, -0.659345805644989f, -0.6087614297866821f, -0.5555702447891235f, -0.5f, -0.44228869676589966f, -0.3826834261417389f, -0.3214394748210907f, -0.258819043636322f, -0.19509032368659973f, -0.13052618503570557f, -0.06540312618017197f};
+    return t[i];
+  }
+};
+
 // ---------------------------------------------------------------------------------------------------------------------
 // N-point complex FFT in registers (N = 16 / 32), fully unrolled decimation-in-frequency with compile-time twiddles:
 // (N/2) log2 N butterflies instead of the N^2 complex MACs of the direct sum - the direct form made these kernels
@@ -132,9 +167,47 @@ __device__ __forceinline__ void fft_stage(float (&re)[N], float (&im)[N]) {
     fft_stage<N, SGN, LEN / 2>(re, im);
   }
 }
+// position of output X[k] in the array after fft_regs<N>: bit reversal for N = 2^k; for N = 3 * 2^k (one radix-3
+// decimation-in-frequency stage in front of three 2^k-point transforms) X[3 j + r] sits at r * (N / 3) + brev(j)
+template <int N>
+__host__ __device__ constexpr int fft_pos(int k) {
+  if constexpr (N % 3 == 0) return (k % 3) * (N / 3) + brev<N / 3>(k / 3);
+  else return brev<N>(k);
+}
 template <int N, int SGN>
 __device__ __forceinline__ void fft_regs(float (&re)[N], float (&im)[N]) {
-  fft_stage<N, SGN, N>(re, im);
+  if constexpr (N % 3 == 0) {
+    // radix-3 stage: y_r[n] = (a + w3^r b + w3^(2r) c) W^(r n), a / b / c = x[n], x[n + M], x[n + 2M], w3 = e^{SGN 2 pi i / 3}
+    constexpr int M = N / 3;
+    constexpr float S = (float)SGN, h = 0.86602540378443865f;      // sin(2 pi / 3)
+    fft_sfor<0, M>([&](auto Q) __attribute__((always_inline)) {
+      constexpr int n = decltype(Q)::value;
+      const float ar = re[n], ai = im[n], br = re[n + M], bi = im[n + M], cr = re[n + 2 * M], ci = im[n + 2 * M];
+      const float sr = br + cr, si = bi + ci, dr = br - cr, di = bi - ci;
+      re[n] = ar + sr;
+      im[n] = ai + si;
+      // a - (b + c) / 2  +-  S i h (b - c)
+      const float mr = fmaf(-0.5f, sr, ar), mi = fmaf(-0.5f, si, ai);
+      const float y1r = mr - S * h * di, y1i = mi + S * h * dr;
+      const float y2r = mr + S * h * di, y2i = mi - S * h * dr;
+      if constexpr (n == 0) {
+        re[n + M] = y1r;
+        im[n + M] = y1i;
+        re[n + 2 * M] = y2r;
+        im[n + 2 * M] = y2i;
+      } else {
+        constexpr float c1 = Twid<N>::c(n), s1 = S * Twid<N>::s(n);
+        constexpr float c2 = Twid<N>::c((2 * n) % N), s2 = S * Twid<N>::s((2 * n) % N);
+        re[n + M] = fmaf(y1r, c1, -y1i * s1);
+        im[n + M] = fmaf(y1r, s1, y1i * c1);
+        re[n + 2 * M] = fmaf(y2r, c2, -y2i * s2);
+        im[n + 2 * M] = fmaf(y2r, s2, y2i * c2);
+      }
+    });
+    fft_stage<N, SGN, M>(re, im);
+  } else {
+    fft_stage<N, SGN, N>(re, im);
+  }
 }
 
 __device__ __forceinline__ float colw_f(int colw, int ky, int w) {
@@ -190,8 +263,8 @@ __global__ __launch_bounds__(256) void rfft2_fast_kernel(const float* __restrict
     fft_regs<W, -1>(v, vi);
     fft_sfor<0, WF>([&](auto KY) __attribute__((always_inline)) {
       constexpr int ky = decltype(KY)::value;
-      Z[((ky * H + xr) * 2 + 0) * CC + c] = v[brev<W>(ky)];
-      Z[((ky * H + xr) * 2 + 1) * CC + c] = vi[brev<W>(ky)];
+      Z[((ky * H + xr) * 2 + 0) * CC + c] = v[fft_pos<W>(ky)];
+      Z[((ky * H + xr) * 2 + 1) * CC + c] = vi[fft_pos<W>(ky)];
     });
   }
   __syncthreads();
@@ -214,8 +287,8 @@ __global__ __launch_bounds__(256) void rfft2_fast_kernel(const float* __restrict
     fft_sfor<0, H>([&](auto KX) __attribute__((always_inline)) {
       constexpr int kx = decltype(KX)::value;
       if (kx < mx) {
-        out[kx * kxstride] = zr[brev<H>(kx)] * wgt;
-        out[kx * kxstride + bs] = zi[brev<H>(kx)] * wgt;
+        out[kx * kxstride] = zr[fft_pos<H>(kx)] * wgt;
+        out[kx * kxstride + bs] = zi[fft_pos<H>(kx)] * wgt;
       }
     });
   }
@@ -252,8 +325,8 @@ __global__ __launch_bounds__(256) void irfft2_fast_kernel(const float* __restric
     fft_regs<H, 1>(sr, si);
     fft_sfor<0, H>([&](auto XR) __attribute__((always_inline)) {
       constexpr int xr = decltype(XR)::value;
-      U[((xr * WF + ky) * 2 + 0) * CC + c] = sr[brev<H>(xr)] * wgt;
-      U[((xr * WF + ky) * 2 + 1) * CC + c] = si[brev<H>(xr)] * wgt;
+      U[((xr * WF + ky) * 2 + 0) * CC + c] = sr[fft_pos<H>(xr)] * wgt;
+      U[((xr * WF + ky) * 2 + 1) * CC + c] = si[fft_pos<H>(xr)] * wgt;
     });
   }
   __syncthreads();
@@ -289,7 +362,7 @@ __global__ __launch_bounds__(256) void irfft2_fast_kernel(const float* __restric
     }
     fft_sfor<0, W>([&](auto YY) __attribute__((always_inline)) {
       constexpr int yy = decltype(YY)::value;
-      float v = ur[brev<W>(yy)] * scale;
+      float v = ur[fft_pos<W>(yy)] * scale;
       if (res) v += q[yy];
       y[base + (long long)(xr * W + yy) * E + c] = v;
     });
@@ -469,7 +542,7 @@ template <int H, int W, int CC>
 static int launch_rfft2_fast(const float* x, float* spec, int B, int E, int nb, int mx, int my, int colw, float scale,
                              hipStream_t s, const DftNorm nrm) {
   constexpr size_t lds = sizeof(float) * ((size_t)(W / 2 + 1) * H * 2 * CC);
-  hipFuncSetAttribute(reinterpret_cast<const void*>(rfft2_fast_kernel<H, W, CC>),
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(rfft2_fast_kernel<H, W, CC>),
                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   hipLaunchKernelGGL((rfft2_fast_kernel<H, W, CC>), dim3(E / CC, B), dim3(256), lds, s, x, spec, E, nb, mx, my, colw,
                      scale, nrm);
@@ -479,7 +552,7 @@ template <int H, int W, int CC>
 static int launch_irfft2_fast(const float* spec, const float* res, float* y, int B, int E, int nb, int mx, int my,
                               int colw, float scale, hipStream_t s, const DftNorm nrm) {
   constexpr size_t lds = sizeof(float) * ((size_t)(W / 2 + 1) * H * 2 * CC);
-  hipFuncSetAttribute(reinterpret_cast<const void*>(irfft2_fast_kernel<H, W, CC>),
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(irfft2_fast_kernel<H, W, CC>),
                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   hipLaunchKernelGGL((irfft2_fast_kernel<H, W, CC>), dim3(E / CC, B), dim3(256), lds, s, spec, res, y, E, nb, mx, my,
                      colw, scale, nrm);
@@ -531,6 +604,15 @@ static inline int try_rfft2_fast(const float* x, float* spec, int B, int h, int 
     if (forced != 16 && forced != 32 && E % 12 == 0 && (E / nb) % 12 == 0 && (long long)B * (E / 12) >= 256) { *rc = launch_rfft2_fast<32, 32, 12>(x, spec, B, E, nb, mx, my, colw, scale, s, nrm); return 1; }
     if (forced != 16 && E % 32 == 0 && (long long)B * (E / 32) >= 128) { *rc = launch_rfft2_fast<32, 32, 32>(x, spec, B, E, nb, mx, my, colw, scale, s, nrm); return 1; }
     if (E % 16 == 0) { *rc = launch_rfft2_fast<32, 32, 16>(x, spec, B, E, nb, mx, my, colw, scale, s, nrm); return 1; }
+  } else if (h == 24 && w == 24) {
+    // round 5: 3 * 2^k lines (192^2 / 384^2 / 768^2 fields at patch 8) - a radix-3 stage in front of three 2^k-point register FFTs
+    if (E % 32 == 0) { *rc = launch_rfft2_fast<24, 24, 32>(x, spec, B, E, nb, mx, my, colw, scale, s, nrm); return 1; }
+    if (E % 8 == 0) { *rc = launch_rfft2_fast<24, 24, 8>(x, spec, B, E, nb, mx, my, colw, scale, s, nrm); return 1; }
+  } else if (h == 48 && w == 48) {
+    if (E % 16 == 0) { *rc = launch_rfft2_fast<48, 48, 16>(x, spec, B, E, nb, mx, my, colw, scale, s, nrm); return 1; }
+    if (E % 4 == 0) { *rc = launch_rfft2_fast<48, 48, 4>(x, spec, B, E, nb, mx, my, colw, scale, s, nrm); return 1; }
+  } else if (h == 96 && w == 96) {
+    if (E % 4 == 0) { *rc = launch_rfft2_fast<96, 96, 4>(x, spec, B, E, nb, mx, my, colw, scale, s, nrm); return 1; }
   } else if (h == 128 && w == 128 && !nrm.mean) {
     // 1024^2 fields at patch 8: two 64-point register FFTs per line; the kept ky rows in LDS ([my][128][2][CC])
     if (E % 4 == 0 && my <= 36) { *rc = launch_rfft2_128<4>(x, spec, B, E, nb, mx, my, colw, scale, s); return 1; }
@@ -556,6 +638,14 @@ static inline int try_irfft2_fast(const float* spec, const float* res, float* y,
     // 384 of 16-channel chunks (1.5 per CU: half the CUs run two in a row) - 20.4 against 29.8 us
     if (forced != 16 && E % 12 == 0 && (E / nb) % 12 == 0 && (long long)B * (E / 12) >= 256) { *rc = launch_irfft2_fast<32, 32, 12>(spec, res, y, B, E, nb, mx, my, colw, scale, s, nrm); return 1; }
     if (E % 16 == 0) { *rc = launch_irfft2_fast<32, 32, 16>(spec, res, y, B, E, nb, mx, my, colw, scale, s, nrm); return 1; }
+  } else if (h == 24 && w == 24) {
+    if (E % 32 == 0) { *rc = launch_irfft2_fast<24, 24, 32>(spec, res, y, B, E, nb, mx, my, colw, scale, s, nrm); return 1; }
+    if (E % 8 == 0) { *rc = launch_irfft2_fast<24, 24, 8>(spec, res, y, B, E, nb, mx, my, colw, scale, s, nrm); return 1; }
+  } else if (h == 48 && w == 48) {
+    if (E % 16 == 0) { *rc = launch_irfft2_fast<48, 48, 16>(spec, res, y, B, E, nb, mx, my, colw, scale, s, nrm); return 1; }
+    if (E % 4 == 0) { *rc = launch_irfft2_fast<48, 48, 4>(spec, res, y, B, E, nb, mx, my, colw, scale, s, nrm); return 1; }
+  } else if (h == 96 && w == 96) {
+    if (E % 4 == 0) { *rc = launch_irfft2_fast<96, 96, 4>(spec, res, y, B, E, nb, mx, my, colw, scale, s, nrm); return 1; }
   } else if (h == 128 && w == 128 && !nrm.mean) {
     if (E % 4 == 0 && my <= 36) { *rc = launch_irfft2_128<4>(spec, res, y, B, E, nb, mx, my, colw, scale, s); return 1; }
     if (E % 2 == 0) { *rc = launch_irfft2_128<2>(spec, res, y, B, E, nb, mx, my, colw, scale, s); return 1; }

@@ -44,6 +44,11 @@ struct Bf16pArgs {
   uint4* dact_out;
   const unsigned short* dact_in;
   int super_r, super_c;          // tile rasterisation: the 32 concurrent tiles of an XCD form super_r x super_c blocks
+  // round 5 (B-direct pair launch only): a_rowform - A is NOT the packed [M/32][K/16] operand but the ROW-form pack of the
+  // [K, M] activation ([K/32][M/16][64 chunks][8]: what the data GEMMs consume), read through ds_read_b64_tr_b16 - the
+  // weight gradients then need no transposed pack of the hidden layer / its gradient at all; transC - the fp32 result is
+  // stored transposed (e.C is [N, M], e.ldc its row length)
+  int a_rowform, transC;
   EpiArgs e;
 };
 
@@ -312,6 +317,30 @@ __device__ __forceinline__ void epi_fragment_direct(const Bf16pArgs& p, int m0f,
     }
     __builtin_amdgcn_wave_barrier();
   }
+}
+
+// plain store of one 32x32 fragment TRANSPOSED: element (m0f + m, n0f + n) goes to Ct[(n0f + n) * ldct + m0f + m] (round 5:
+// the weight gradient computed with its operands swapped - dW^T = H^T dY - lands in the parameter's own [out, in] layout).
+// The lane's four consecutive rows go into the staging slab as one 16-byte write, rows of the slab = columns of the fragment.
+__device__ __forceinline__ void epi_fragment_T(float* __restrict__ Ct, int ldct, int M, int N, int m0f, int n0f,
+                                               const f32x16& acc, float* stage, int lane) {
+  const int li = lane & 31, kh = lane >> 5;
+#pragma unroll
+  for (int g = 0; g < 4; ++g)
+    *reinterpret_cast<float4*>(&stage[li * EPI_LD + 8 * g + 4 * kh]) =
+        make_float4(acc[4 * g], acc[4 * g + 1], acc[4 * g + 2], acc[4 * g + 3]);
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  const int c4 = (lane & 7) * 4;
+#pragma unroll
+  for (int it = 0; it < 4; ++it) {
+    const int rn = it * 8 + (lane >> 3);
+    const int n = n0f + rn, m = m0f + c4;
+    if (n < N && m < M)      // M % 4 == 0 (host-checked): the four rows are all valid or all invalid
+      *reinterpret_cast<float4*>(Ct + (long long)n * ldct + m) = *reinterpret_cast<const float4*>(&stage[rn * EPI_LD + c4]);
+  }
+  __builtin_amdgcn_wave_barrier();
 }
 
 constexpr int PB_ROWT = 4;      // 32-row tiles per workgroup (128 rows)
@@ -741,7 +770,8 @@ __device__ __forceinline__ void bd_sfor(F&& f) {   // static for: f(integral_con
 // BD_P = slabs of look-ahead (the loop is latency bound: period = load latency / look-ahead while that exceeds the 512
 // cycles of matrix-pipe time per slab), BD_RING = BD_P + 1 A slots in LDS / W register sets; the slab loop is unrolled by
 // the ring depth so that slots and register sets are compile-time constants.
-template <int COLT, int CPW, int BD_P>
+typedef short bd_s16x4 __attribute__((ext_vector_type(4)));
+template <int COLT, int CPW, int BD_P, bool ATR = false>
 __device__ __forceinline__ void gemm_bf16p_bd_body(const Bf16pArgs& p, const int bid0, const int zs) {
   constexpr int BD_RING = BD_P + 1;
   static_assert(COLT % CPW == 0, "column tiles must divide among the waves");
@@ -803,9 +833,21 @@ __device__ __forceinline__ void gemm_bf16p_bd_body(const Bf16pArgs& p, const int
     const int bb = ahas[n] ? b : 0;
     int rt = rt0 + (bb >> 1);
     rt = rt < mtiles ? rt : mtiles - 1;
-    asrc[n] = p.A + ((long long)rt * ks16 + 2 * slab0 + (bb & 1)) * 512 + lane * 8;
+    if constexpr (ATR) {
+      // ROW-form source: the slab's 32 tokens x this row tile's 32 features are two 1 KiB blocks (feature halves fb) of
+      // chunks (token, 8 features).  LDS image of a row tile (2 KiB = 128 slots of 16 B) for the transposing read:
+      //   slot(t, fb, fh) = (t >> 2) * 16 + (fb * 2 + fh) * 4 + (t & 3)       fh = which 8 of the block's 16 features
+      // - the 16 chunks a 32-lane half of ds_read_b64_tr_b16 touches are 256 contiguous bytes (conflict free).  The DMA
+      // writes lane-linearly, so the permutation sits in the SOURCE address: instruction i = bb & 1 fills slots 64 i .. + 63,
+      // lane L <- token 16 i + 4 (L >> 4) + (L & 3), (fb, fh) = bits 3, 2 of L: four runs of 256 contiguous bytes
+      const int i = bb & 1, tk = 16 * i + 4 * (lane >> 4) + (lane & 3), fb = (lane >> 3) & 1, fh = (lane >> 2) & 1;
+      asrc[n] = p.A + ((long long)slab0 * (p.M >> 4) + 2 * rt + fb) * 512 + (fh * 32 + tk) * 8;
+    } else {
+      asrc[n] = p.A + ((long long)rt * ks16 + 2 * slab0 + (bb & 1)) * 512 + lane * 8;
+    }
     adst[n] = bb * 1024;
   }
+  const long long astride = ATR ? (long long)(p.M >> 4) * 512 : 1024;    // elements between consecutive slabs of A
   // this wave's W streams: column tiles ct0 + CPW wave + j, blocks 2 (slab0 + t) + ks
   const unsigned short* wsrc = p.W + ((long long)(ct0 + CPW * wave) * ks16 + 2 * slab0) * 512 + lane * 8;
   const long long wcol = (long long)ks16 * 512;                   // elements between neighbouring column tiles
@@ -831,7 +873,7 @@ __device__ __forceinline__ void gemm_bf16p_bd_body(const Bf16pArgs& p, const int
     constexpr int s = decltype(S)::value;
     t = t < last ? t : last;
 #pragma unroll
-    for (int n = 0; n < NPA; ++n) bglds16(asrc[n] + (long long)t * 1024, lds + s * BD_ASLAB + adst[n]);
+    for (int n = 0; n < NPA; ++n) bglds16(asrc[n] + (long long)t * astride, lds + s * BD_ASLAB + adst[n]);
 #pragma unroll
     for (int j = 0; j < CPW; ++j) {
       const bf16x8_t* wp = reinterpret_cast<const bf16x8_t*>(wsrc + j * wcol + (long long)t * 1024);
@@ -855,12 +897,32 @@ __device__ __forceinline__ void gemm_bf16p_bd_body(const Bf16pArgs& p, const int
     __builtin_amdgcn_s_barrier();                           // B_g: slab g complete in LDS; slab g - 1 consumed by every wave
     asm volatile("" ::: "memory");
     issue(g + BD_P, SN);                                    // into the slot / register set of slab g - 1
-    const unsigned char* base = lds + s * BD_ASLAB + lane * 16;
     bf16x8_t a[PB_ROWT][2];
+    if constexpr (ATR) {
+      // lane (f = lane & 31, kg = lane >> 5) wants tokens 16 ks + 8 kg .. + 7 of feature f: two transposing 64-bit reads
+      // (4 tokens each).  Inside a 16-lane group lane s SUPPLIES the address of (token T0 + (s >> 2), features 4 (s & 3) ..
+      // + 3) and RECEIVES feature s of the four tokens (scripts/ubench/tr_read_layout.hip checks image + addressing)
+      const int kg = lane >> 5, fb = (lane >> 4) & 1;
+      const unsigned char* base = lds + s * BD_ASLAB +
+                                  (((2 * kg) * 16 + (fb * 2 + ((lane & 3) >> 1)) * 4 + ((lane >> 2) & 3)) * 16 + (lane & 1) * 8);
 #pragma unroll
-    for (int ks = 0; ks < 2; ++ks)
+      for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
-      for (int i = 0; i < PB_ROWT; ++i) a[i][ks] = *reinterpret_cast<const bf16x8_t*>(base + (i * 2 + ks) * 1024);
+        for (int i = 0; i < PB_ROWT; ++i) {
+          typedef __attribute__((address_space(3))) bd_s16x4 lds_s16x4;
+          const bd_s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(base + i * 2048 + ks * 1024));
+          const bd_s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(base + i * 2048 + ks * 1024 + 256));
+          typedef short s16x8 __attribute__((ext_vector_type(8)));
+          const s16x8 both = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+          a[i][ks] = __builtin_bit_cast(bf16x8_t, both);
+        }
+    } else {
+      const unsigned char* base = lds + s * BD_ASLAB + lane * 16;
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+        for (int i = 0; i < PB_ROWT; ++i) a[i][ks] = *reinterpret_cast<const bf16x8_t*>(base + (i * 2 + ks) * 1024);
+    }
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
@@ -888,6 +950,24 @@ __device__ __forceinline__ void gemm_bf16p_bd_body(const Bf16pArgs& p, const int
 
   float* stage = reinterpret_cast<float*>(lds) + wave * (32 * EPI_LD);
   const int m0 = rt0 * 32, n0 = (ct0 + CPW * wave) * 32;
+  if (p.transC) {
+    // fp32 result (or split-K partial: the reduce then runs over [N, M]) stored transposed, fragment by fragment
+    float* ct = p.splits > 1 ? p.ws + (long long)zs * p.M * p.N : p.e.C;
+    const int ldct = p.splits > 1 ? p.M : p.e.ldc;
+#pragma unroll 1
+    for (int f = 0; f < PB_ROWT * CPW; ++f) {
+      const int fi = f / CPW, fj = f - fi * CPW;
+      f32x16 af;
+      if constexpr (CPW == 1) {
+        af = f == 0 ? acc[0][0] : f == 1 ? acc[1][0] : f == 2 ? acc[2][0] : acc[3][0];
+      } else {
+        af = f == 0 ? acc[0][0] : f == 1 ? acc[0][1] : f == 2 ? acc[1][0] : f == 3 ? acc[1][1] : f == 4 ? acc[2][0]
+           : f == 5 ? acc[2][1] : f == 6 ? acc[3][0] : acc[3][1];
+      }
+      epi_fragment_T(ct, ldct, p.M, p.N, m0 + 32 * fi, n0 + 32 * fj, af, stage, lane);
+    }
+    return;
+  }
   if (p.splits > 1) {
     float* ws = p.ws + (long long)zs * p.M * p.N;
     const int li = lane & 31, kh = lane >> 5;
@@ -946,10 +1026,10 @@ __global__ __launch_bounds__(64 * (COLT + PB_NLOAD)) void gemm_bf16p_pair_kernel
   gemm_bf16p_body<COLT>(pp.a[which], (int)blockIdx.x - which * pp.n0, blockIdx.y);   // blockIdx.y: common split-K index
 }
 
-template <int COLT, int CPW, int P>
+template <int COLT, int CPW, int P, bool ATR = false>
 __global__ __launch_bounds__(64 * COLT / CPW, 2) void gemm_bf16p_bd_pair_kernel(const Bf16pPair pp) {
   const int which = (int)blockIdx.x >= pp.n0 ? 1 : 0;
-  gemm_bf16p_bd_body<COLT, CPW, P>(pp.a[which], (int)blockIdx.x - which * pp.n0, blockIdx.y);
+  gemm_bf16p_bd_body<COLT, CPW, P, ATR>(pp.a[which], (int)blockIdx.x - which * pp.n0, blockIdx.y);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -1399,9 +1479,8 @@ static int bd_cpw(long long tiles) {
   return tiles >= 512 ? 2 : 1;
 }
 
-// slabs of look-ahead of the B-direct kernels: 3.  (4 / 5 / 7 were built and measured on the theory that the loop is bound
-// by load latency / look-ahead: no effect on any DPOT-S / -M / -L shape, profiles/r04_bf16p_bd_lookahead.txt.)
-static int bd_lookahead(int) { return 3; }
+// (slabs of look-ahead of the B-direct kernels: 3.  4 / 5 / 7 were built and measured on the theory that the loop is bound by
+// load latency / look-ahead: no effect on any DPOT-S / -M / -L shape, profiles/r04_bf16p_bd_lookahead.txt.)
 
 extern "C" int dpot_gemm_bf16p_splitk(int M, int N, int K) {
   // weight-gradient shapes: few output tiles, long K.  Aim at >= 256 workgroups, keep >= 16 slabs (512 k) per split
@@ -1436,6 +1515,66 @@ static void bf16p_pick_super(int tilesM, int tilesN, int splits, int* sr, int* s
   static const int cand[6][2] = {{8, 4}, {4, 8}, {16, 2}, {2, 16}, {32, 1}, {1, 32}};
   for (int i = 0; i < 6; ++i)
     if (tilesM % cand[i][0] == 0 && tilesN % cand[i][1] == 0) { *sr = cand[i][0]; *sc = cand[i][1]; return; }
+}
+
+// kernel selection of dpot_gemm_bf16p in ONE place (round 5): the launch and dpot_gemm_bf16p_kernel_kind (what
+// bench.py reports) read the same plan
+struct Bf16pPlan {
+  int tilesM, tilesN, splits, slabs_per_split, super_r, super_c, colt, cpw;
+  bool use_bd, use_duo;
+  unsigned grid;
+};
+static Bf16pPlan bf16p_plan(int M, int N, int K, int splitk, int planes, bool packs) {
+  Bf16pPlan pl;
+  pl.tilesM = (M + 32 * PB_ROWT - 1) / (32 * PB_ROWT);
+  pl.tilesN = N / (32 * PB_COLT);
+  const int nslab = planes == 3 ? K >> 4 : K >> 5;
+  pl.splits = splitk > 1 ? splitk : 1;
+  pl.slabs_per_split = (nslab + pl.splits - 1) / pl.splits;
+  pl.splits = (nslab + pl.slabs_per_split - 1) / pl.slabs_per_split;       // no empty split
+  // B-direct form (DPOT_BF16P_BD: 1 (default) = by the shape rule, 3 = every plain-bf16 launch, 0 = off: the LDS-DMA kernels of
+  // rounds 2-3, 2 = only the launches the duo kernel does not take - those then run in the XCD-contiguous order, not the
+  // super-block one).  Shape rule: launches with several rounds of tiles or a long contraction; a single round of tiles with
+  // K < 2048 (DPOT-S: 8192 x 1024 x 1024, 256 tiles, 32 slabs) keeps the LDS-DMA kernels, whose dedicated loader waves start
+  // the pipeline sooner - DPOT-S 5.73 -> 5.94 ms with B-direct everywhere, DPOT-M 14.97 -> 14.24, DPOT-L 102.9 -> 96.2
+  // (profiles/r04_bf16p_bd_step_ab_one_box.txt)
+  static const int bd = [] { const char* ev = getenv("DPOT_BF16P_BD"); return ev ? atoi(ev) : 1; }();
+  const bool bd_shape = (long long)pl.tilesM * pl.tilesN * pl.splits >= 512 || pl.slabs_per_split >= 64;
+  const bool bd_first = planes == 1 && ((bd == 1 && bd_shape) || bd == 3);
+  bf16p_pick_super(pl.tilesM, pl.tilesN, pl.splits, &pl.super_r, &pl.super_c, bd_first);
+  // 128 x 192 tiles where they fill the rounds of 256 CUs better (as for the pair launch below; a 192-wide tile costs ~0.83
+  // of a 256-wide one): DPOT-L at batch 4 has 32 x 6 = 192 tiles of 128 x 256 in fc2 forward / fc1 data gradient - a
+  // quarter of the chip idle - and 32 x 8 = 256 of 128 x 192
+  static const int allow192 = [] { const char* ev = getenv("DPOT_BF16P_TILE192"); return ev ? atoi(ev) : 1; }();
+  pl.colt = PB_COLT;
+  if (allow192 && planes == 1 && N % 192 == 0 && pl.super_r == 0) {
+    const long long t8 = (long long)pl.tilesM * pl.tilesN * pl.splits, t6 = (long long)pl.tilesM * (N / 192) * pl.splits;
+    if (t8 < 512 && 0.83 * (double)((t6 + 255) / 256) < 0.97 * (double)((t8 + 255) / 256)) pl.colt = 6;
+  }
+  if (pl.colt == 6) pl.tilesN = N / 192;
+  pl.grid = (unsigned)(pl.tilesM * pl.tilesN);
+  if (pl.super_r > 0) pl.grid = 256u * (unsigned)((pl.tilesM * pl.tilesN / 32 + 7) / 8);
+  // duo form (two workgroups per CU): every unsplit launch with >= 2 tiles per CU (DPOT_BF16P_DUO=0: never; 3: only the
+  // launches with packed outputs).  Measured inside the DPOT-L step at batch 16, where the fp32-output launches have 768
+  // tiles as well: 106.2 -> 104.0 ms with them on this kernel too (profiles/r03_bf16p_duo.txt)
+  static const int duo = [] { const char* ev = getenv("DPOT_BF16P_DUO"); return ev ? atoi(ev) : 1; }();
+  pl.use_duo = planes == 1 && pl.colt == PB_COLT && pl.splits == 1 && pl.super_r == 0 &&
+               (long long)pl.tilesM * pl.tilesN >= 512 && (duo == 1 || duo == 2 || (duo == 3 && packs));
+  pl.use_bd = bd_first || (planes == 1 && bd == 2 && !pl.use_duo);
+  if (pl.use_bd) pl.use_duo = false;
+  if (pl.use_bd && pl.super_r == 0) pl.super_c = bf16p_row_major(pl.tilesM, pl.tilesN, PB_ROWT, pl.colt);
+  pl.cpw = pl.colt == 6 ? 1 : bd_cpw((long long)pl.tilesM * pl.tilesN * pl.splits);
+  return pl;
+}
+// which kernel dpot_gemm_bf16p runs for a shape: 0 = LDS-DMA (8 compute + 4 loader waves), 1 = two-workgroup ("duo"),
+// 2 = B-direct with eight 128 x 32 waves, 3 = B-direct with four 128 x 64 waves (two workgroups per CU), 4 = bf16x6;
+// + 8: on 128 x 192 tiles
+extern "C" int dpot_gemm_bf16p_kernel_kind(int M, int N, int K, int splitk, int planes, int packed_outputs) {
+  if (!dpot_gemm_bf16p_supported(M, N, K)) return -1;
+  if (planes == 3) return 4;
+  const Bf16pPlan pl = bf16p_plan(M, N, K, splitk, planes, packed_outputs != 0);
+  const int kind = pl.use_bd ? (pl.cpw == 2 ? 3 : 2) : pl.use_duo ? 1 : 0;
+  return kind + (pl.colt == 6 ? 8 : 0);
 }
 
 extern "C" int dpot_gemm_bf16p(const void* Apacked, const void* Wpacked, const float* bias, const float* aux, int ldaux,
@@ -1477,54 +1616,26 @@ extern "C" int dpot_gemm_bf16p(const void* Apacked, const void* Wpacked, const f
   e.act = act; e.mode = epi_mode; e.accumulate = 0;
   e.M = M; e.N = N;
   const int nslab = planes == 3 ? K >> 4 : K >> 5;     // the bf16x6 kernel steps K in 16-k slabs
-  p.splits = splitk > 1 ? splitk : 1;
-  DPOT_REQUIRE(p.splits == 1 || workspace != nullptr, "gemm_bf16p: split-K needs a workspace of splitk*M*N floats");
-  DPOT_REQUIRE(p.splits <= nslab && p.splits <= 65535, "gemm_bf16p: too many splits");
-  p.slabs_per_split = (nslab + p.splits - 1) / p.splits;
-  p.splits = (nslab + p.slabs_per_split - 1) / p.slabs_per_split;       // no empty split
+  DPOT_REQUIRE(splitk <= 1 || workspace != nullptr, "gemm_bf16p: split-K needs a workspace of splitk*M*N floats");
+  DPOT_REQUIRE((splitk > 1 ? splitk : 1) <= nslab && splitk <= 65535, "gemm_bf16p: too many splits");
   p.ws = workspace;
   p.out_rows = reinterpret_cast<uint4*>(out_rows);
   p.out_trans = reinterpret_cast<uint4*>(out_trans);
   p.cs_part = colsum_part;
   p.dact_out = reinterpret_cast<uint4*>(dact_out);
   p.dact_in = reinterpret_cast<const unsigned short*>(dact_in);
-  static const int bd = [] { const char* ev = getenv("DPOT_BF16P_BD"); return ev ? atoi(ev) : 1; }();
-  const bool bd_shape = (long long)p.tilesM * p.tilesN * p.splits >= 512 || p.slabs_per_split >= 64;
-  bf16p_pick_super(p.tilesM, p.tilesN, p.splits, &p.super_r, &p.super_c, planes == 1 && ((bd == 1 && bd_shape) || bd == 3));
-  // 128 x 192 tiles where they fill the rounds of 256 CUs better (as for the pair launch below; a 192-wide tile costs ~0.83
-  // of a 256-wide one): DPOT-L at batch 4 has 32 x 6 = 192 tiles of 128 x 256 in fc2 forward / fc1 data gradient - a
-  // quarter of the chip idle - and 32 x 8 = 256 of 128 x 192
-  static const int allow192 = [] { const char* ev = getenv("DPOT_BF16P_TILE192"); return ev ? atoi(ev) : 1; }();
-  int colt = PB_COLT;
-  if (allow192 && planes == 1 && N % 192 == 0 && p.super_r == 0) {
-    const long long t8 = (long long)p.tilesM * p.tilesN * p.splits, t6 = (long long)p.tilesM * (N / 192) * p.splits;
-    if (t8 < 512 && 0.83 * (double)((t6 + 255) / 256) < 0.97 * (double)((t8 + 255) / 256)) colt = 6;
-  }
-  if (colt == 6) p.tilesN = N / 192;
-  unsigned grid = (unsigned)(p.tilesM * p.tilesN);
-  if (p.super_r > 0) grid = 256u * (unsigned)((p.tilesM * p.tilesN / 32 + 7) / 8);
-  // duo form (two workgroups per CU): every unsplit launch with >= 2 tiles per CU (DPOT_BF16P_DUO=0: never; 3: only the
-  // launches with packed outputs).  Measured inside the DPOT-L step at batch 16, where the fp32-output launches have 768
-  // tiles as well: 106.2 -> 104.0 ms with them on this kernel too (profiles/r03_bf16p_duo.txt)
-  static const int duo = [] { const char* ev = getenv("DPOT_BF16P_DUO"); return ev ? atoi(ev) : 1; }();
-  const bool use_duo = planes == 1 && colt == PB_COLT && p.splits == 1 && p.super_r == 0 && (long long)p.tilesM * p.tilesN >= 512 &&
-                       (duo == 1 || duo == 2 || (duo == 3 && packs));
-  // B-direct form (DPOT_BF16P_BD: 1 (default) = by the shape rule below, 3 = every plain-bf16 launch, 0 = off: the LDS-DMA
-  // kernels of rounds 2-3, 2 = only the launches the duo kernel does not take)
-  // shape rule (bd == 1): launches with several rounds of tiles or a long contraction; a single round of tiles with K < 2048
-  // (DPOT-S: 8192 x 1024 x 1024, 256 tiles, 32 slabs) keeps the LDS-DMA kernels, whose dedicated loader waves start the
-  // pipeline sooner - DPOT-S 5.73 -> 5.94 ms with B-direct everywhere, DPOT-M 14.97 -> 14.24, DPOT-L 102.9 -> 96.2
-  // (profiles/r04_bf16p_bd_step_ab_one_box.txt); bd == 3: every plain-bf16 launch
-  const bool use_bd = planes == 1 && colt == (p.super_r ? PB_COLT : colt) && ((bd == 1 && bd_shape) || bd == 3 || (bd == 2 && !use_duo));
+  p.a_rowform = 0; p.transC = 0;
+  const Bf16pPlan pl = bf16p_plan(M, N, K, splitk, planes, packs);
+  p.splits = pl.splits; p.slabs_per_split = pl.slabs_per_split; p.tilesN = pl.tilesN;
+  p.super_r = pl.super_r; p.super_c = pl.super_c;
+  const int colt = pl.colt, cpw = pl.cpw;
+  const bool use_bd = pl.use_bd, use_duo = pl.use_duo;
+  const unsigned grid = pl.grid;
   if (planes == 3)
     hipLaunchKernelGGL(gemm_bf16x6p_kernel, dim3((unsigned)(p.tilesM * p.tilesN), p.splits), dim3(512), 0,
                        as_stream(stream), p);
   else if (use_bd) {
-    if (p.super_r == 0) p.super_c = bf16p_row_major(p.tilesM, p.tilesN, PB_ROWT, colt);
-    const int cpw = colt == 6 ? 1 : bd_cpw((long long)p.tilesM * p.tilesN * p.splits);
-    const int la = bd_lookahead(cpw);
 #define BD_LAUNCH(CT, CW, LA) hipLaunchKernelGGL((gemm_bf16p_bd_kernel<CT, CW, LA>), dim3(grid, p.splits), dim3(64 * CT / CW), 0, as_stream(stream), p)
-    (void)la;
     if (colt == 6) BD_LAUNCH(6, 1, 3);
     else if (cpw == 2) BD_LAUNCH(8, 2, 3);
     else BD_LAUNCH(8, 1, 3);
@@ -1574,14 +1685,47 @@ extern "C" int dpot_gemm_bf16p_pair_wanted(int M0, int N0, int M1, int N1, int K
   return dpot_gemm_bf16p_pair_splitk(M0, N0, M1, N1, K) > 0 ? 1 : 0;
 }
 
+// the pair launch with ROW-form A operands (read through ds_read_b64_tr_b16) exists in the B-direct kernels without split-K
+static bool pair_use_bd(long long grid, int splits, int sps) {
+  static const int bd = [] { const char* ev = getenv("DPOT_BF16P_BD"); return ev ? atoi(ev) : 1; }();
+  return bd == 3 || (bd && (grid * splits >= 512 || sps >= 128));
+}
+static long long pair_grid(int M0, int N0, int M1, int N1, int splits, int* colt_out) {
+  static const int allow192 = [] { const char* ev = getenv("DPOT_BF16P_TILE192"); return ev ? atoi(ev) : 1; }();
+  const long long tm0 = (M0 + 127) / 128, tm1 = (M1 + 127) / 128;
+  int colt = PB_COLT;
+  if (allow192 && splits == 1 && N0 % 192 == 0 && N1 % 192 == 0) {
+    const long long t8 = tm0 * (N0 / 256) + tm1 * (N1 / 256), t6 = tm0 * (N0 / 192) + tm1 * (N1 / 192);
+    const double c8 = (double)((t8 + 255) / 256), c6 = 0.83 * (double)((t6 + 255) / 256);
+    if (c6 < 0.97 * c8) colt = 6;
+  }
+  if (colt_out) *colt_out = colt;
+  return tm0 * (N0 / (32 * colt)) + tm1 * (N1 / (32 * colt));
+}
+// 1: dpot_gemm_bf16p_pair(M0, N0, M1, N1, K) can take ROW-form A operands (a_rowform) and transposed outputs (transC) -
+// a caller that uses them can skip the transposed packs of the operands it hands over as A.  (A capability, not a
+// recommendation: measured in round 5 the launch is 1.8x slower with them - the permuted LDS-DMA source, four 256-byte runs
+// per wave instruction instead of one KiB, runs at a fraction of the linear rate - see ops / DESIGN.md.)
+extern "C" int dpot_gemm_bf16p_pair_rowform_ok(int M0, int N0, int M1, int N1, int K) {
+  if (dpot_gemm_bf16p_pair_splitk(M0, N0, M1, N1, K) != 1) return 0;
+  if (M0 % 32 || M1 % 32 || K % 32) return 0;
+  const long long grid = pair_grid(M0, N0, M1, N1, 1, nullptr);
+  return pair_use_bd(grid, 1, K >> 5) ? 1 : 0;
+}
+
 extern "C" int dpot_gemm_bf16p_pair(const void* A0, const void* W0, float* C0, int ldc0, int M0, int N0, const void* A1,
                                     const void* W1, float* C1, int ldc1, int M1, int N1, int K, int splitk,
-                                    float* workspace, dpot_stream_t stream) {
+                                    float* workspace, int a_rowform, int transC, dpot_stream_t stream) {
   DPOT_REQUIRE(A0 && W0 && C0 && A1 && W1 && C1, "gemm_bf16p_pair: null operand");
+  DPOT_REQUIRE((a_rowform & ~3) == 0 && (transC & ~3) == 0, "gemm_bf16p_pair: a_rowform / transC are 2-bit masks");
+  DPOT_REQUIRE(!(a_rowform | transC) || dpot_gemm_bf16p_pair_rowform_ok(M0, N0, M1, N1, K),
+               "gemm_bf16p_pair: row-form operands / transposed outputs need the un-split B-direct launch "
+               "(dpot_gemm_bf16p_pair_rowform_ok)");
   DPOT_REQUIRE(dpot_gemm_bf16p_supported(M0, N0, K) && dpot_gemm_bf16p_supported(M1, N1, K),
                "gemm_bf16p_pair: unsupported shape (N %% 256, K %% 32)");
-  DPOT_REQUIRE(ldc0 >= N0 && ldc1 >= N1 && ldc0 % 4 == 0 && ldc1 % 4 == 0 && aligned16(A0) && aligned16(W0) && aligned16(C0) &&
-                   aligned16(A1) && aligned16(W1) && aligned16(C1) && aligned16(workspace),
+  DPOT_REQUIRE(ldc0 >= ((transC & 1) ? M0 : N0) && ldc1 >= ((transC & 2) ? M1 : N1) && ldc0 % 4 == 0 && ldc1 % 4 == 0 &&
+                   aligned16(A0) && aligned16(W0) && aligned16(C0) && aligned16(A1) && aligned16(W1) && aligned16(C1) &&
+                   aligned16(workspace),
                "gemm_bf16p_pair: bad leading dimension / alignment");
   const int nslab = K >> 5;
   int splits = splitk > 1 ? splitk : 1;
@@ -1615,6 +1759,8 @@ extern "C" int dpot_gemm_bf16p_pair(const void* A0, const void* W0, float* C0, i
     p.ws = wss[i];
     p.out_rows = nullptr; p.out_trans = nullptr; p.cs_part = nullptr;
     p.dact_out = nullptr; p.dact_in = nullptr; p.super_r = 0; p.super_c = 0;
+    p.a_rowform = (a_rowform >> i) & 1;
+    p.transC = (transC >> i) & 1;
   }
   // 128 x 192 tiles when they need fewer workgroup-rounds' worth of time: DPOT-L's weight gradients are 1536 x 6144 and
   // 6144 x 1536 - 288 + 288 tiles of 128 x 256 = 2.25 rounds of 256 CUs, i.e. THREE rounds; 384 + 384 tiles of 128 x 192 are
@@ -1634,17 +1780,22 @@ extern "C" int dpot_gemm_bf16p_pair(const void* A0, const void* W0, float* C0, i
   }
   pp.n0 = pp.a[0].tilesM * pp.a[0].tilesN;
   const unsigned grid = (unsigned)(pp.n0 + pp.a[1].tilesM * pp.a[1].tilesN);
-  static const int bd = [] { const char* ev = getenv("DPOT_BF16P_BD"); return ev ? atoi(ev) : 1; }();
-  const bool use_bd = bd == 3 || (bd && ((long long)grid * splits >= 512 || sps >= 128));
+  const bool use_bd = pair_use_bd(grid, splits, sps);
+  DPOT_REQUIRE(!(a_rowform | transC) || (use_bd && splits == 1 && a_rowform == 3),
+               "gemm_bf16p_pair: row-form operands go with the un-split B-direct launch, for both problems");
   if (use_bd) {
     for (int i = 0; i < 2; ++i) pp.a[i].super_c = bf16p_row_major(pp.a[i].tilesM, pp.a[i].tilesN, PB_ROWT, colt);
     const int cpw = colt == 6 ? 1 : bd_cpw((long long)grid * splits);
-    const int la = bd_lookahead(cpw);
-#define BD_LAUNCH(CT, CW, LA) hipLaunchKernelGGL((gemm_bf16p_bd_pair_kernel<CT, CW, LA>), dim3(grid, splits), dim3(64 * CT / CW), 0, as_stream(stream), pp)
-    (void)la;
-    if (colt == 6) BD_LAUNCH(6, 1, 3);
-    else if (cpw == 2) BD_LAUNCH(8, 2, 3);
-    else BD_LAUNCH(8, 1, 3);
+#define BD_LAUNCH(CT, CW, LA, TR) hipLaunchKernelGGL((gemm_bf16p_bd_pair_kernel<CT, CW, LA, TR>), dim3(grid, splits), dim3(64 * CT / CW), 0, as_stream(stream), pp)
+    if (a_rowform) {
+      if (colt == 6) BD_LAUNCH(6, 1, 3, true);
+      else if (cpw == 2) BD_LAUNCH(8, 2, 3, true);
+      else BD_LAUNCH(8, 1, 3, true);
+    } else {
+      if (colt == 6) BD_LAUNCH(6, 1, 3, false);
+      else if (cpw == 2) BD_LAUNCH(8, 2, 3, false);
+      else BD_LAUNCH(8, 1, 3, false);
+    }
 #undef BD_LAUNCH
   }
   else if (colt == 6)

@@ -41,6 +41,13 @@ struct TnArgs {
   int tiles1, tiles2, splits, slabs_per_split;
   float* ws;             // [split][batch][N1][N2] (+ [split][batch][L] column-sum partials behind)
   int cs_of;             // 0: none, 1: column sums of A (length N1), 2: of B (length N2)
+  // round 5: the AFNO weight gradient dW = S^H dO as THREE real 128 x 128 products instead of the four blocks of the
+  // 256 x 256 real product (bs == 128): with A = [Ar | Ai], B = [Br | Bi] (columns)
+  //   P1 = Ar^T Br, P2 = Ai^T Bi, P3 = (Ar + Ai)^T (Bi - Br);   dWr = P1 + P2,  dWi = Ar^T Bi - Ai^T Br = P3 + P1 - P2
+  // (the reduce does the recombination).  grid.x = 3: tile 0 / 1 are the ordinary tiles (0,0) / (1,1), tile 2 streams all
+  // 256 columns of both operands in 16-token slabs (the same 32 KiB per slab) and forms the two sums on the fragments;
+  // partials [split][batch][3][128][128]
+  int gauss;
 };
 
 constexpr int TN_TOK = 32;                 // tokens per slab
@@ -72,13 +79,19 @@ __global__ __launch_bounds__(384) void gemm_tn_kernel(const TnArgs p) {
     const int q = ntiles >> 3, r = ntiles & 7;
     tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + slot;
   }
-  const int t1 = tile / p.tiles2, t2 = tile - t1 * p.tiles2;
+  int t1 = tile / p.tiles2, t2 = tile - t1 * p.tiles2;
+  const bool g3 = p.gauss && tile == 2;                 // the sum-product tile of the three-product form
+  if (p.gauss) t1 = t2 = (tile == 1 ? 1 : 0);
   const int zb = blockIdx.z / p.splits, zs = blockIdx.z - zb * p.splits;
   const int nslab_all = p.T / TN_TOK;
-  const int slab0 = zs * p.slabs_per_split;
+  int slab0 = zs * p.slabs_per_split;
   int nslab = nslab_all - slab0;
   nslab = nslab < p.slabs_per_split ? nslab : p.slabs_per_split;
   if (nslab < 0) nslab = 0;
+  if (g3) {                                             // 16-token slabs: twice as many over the same token range
+    slab0 *= 2;
+    nslab *= 2;
+  }
 
   auto bar = [&]() __attribute__((always_inline)) {
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -93,11 +106,16 @@ __global__ __launch_bounds__(384) void gemm_tn_kernel(const TnArgs p) {
     const int L = wave - 4;
     const bool second = zb >= p.batch1;
     const int zq = second ? zb - p.batch1 : zb;
-    const float* a0 = (second ? p.A2 : p.A) + zq * p.sA + (long long)(slab0 * TN_TOK + 16 * L + (lane >> 5)) * p.lda +
-                      t1 * TN_W + (lane & 31) * 4;
-    const float* b0 = (second ? p.B2 : p.B) + zq * p.sB + (long long)(slab0 * TN_TOK + 16 * L + (lane >> 5)) * p.ldb +
-                      t2 * TN_W + (lane & 31) * 4;
-    const long long sa2 = 2ll * p.lda, sb2 = 2ll * p.ldb, saS = (long long)TN_TOK * p.lda, sbS = (long long)TN_TOK * p.ldb;
+    // ordinary tile: an instruction moves two token rows of 128 columns; sum-product tile: ONE token row of all 256 columns
+    // (wave L: tokens 8L .. 8L+7 of a 16-token slab) - 8 + 8 instructions per slab and wave either way
+    const float* a0 = g3 ? (second ? p.A2 : p.A) + zq * p.sA + (long long)(slab0 * 16 + 8 * L) * p.lda + lane * 4
+                         : (second ? p.A2 : p.A) + zq * p.sA + (long long)(slab0 * TN_TOK + 16 * L + (lane >> 5)) * p.lda +
+                               t1 * TN_W + (lane & 31) * 4;
+    const float* b0 = g3 ? (second ? p.B2 : p.B) + zq * p.sB + (long long)(slab0 * 16 + 8 * L) * p.ldb + lane * 4
+                         : (second ? p.B2 : p.B) + zq * p.sB + (long long)(slab0 * TN_TOK + 16 * L + (lane >> 5)) * p.ldb +
+                               t2 * TN_W + (lane & 31) * 4;
+    const long long sa2 = (g3 ? 1ll : 2ll) * p.lda, sb2 = (g3 ? 1ll : 2ll) * p.ldb;
+    const long long saS = (long long)(g3 ? 16 : TN_TOK) * p.lda, sbS = (long long)(g3 ? 16 : TN_TOK) * p.ldb;
     auto issue = [&](int t, int ring) __attribute__((always_inline)) {
       float* dst = lds + ring * TN_SLABF + L * 8 * 256;
       const float* a = a0 + t * saS;
@@ -134,8 +152,8 @@ __global__ __launch_bounds__(384) void gemm_tn_kernel(const TnArgs p) {
     for (int eb = 0; eb < 4; ++eb) acc[ea][eb] = tn_f32x4{0.f, 0.f, 0.f, 0.f};
   tn_f32x4 cs = {0.f, 0.f, 0.f, 0.f};
   const int cs_sel = zb >= p.batch1 ? p.cs_of2 : p.cs_of;
-  const bool cs_a = cs_sel == 1 && t2 == 0 && wn == 0;
-  const bool cs_b = cs_sel == 2 && t1 == 0 && wm == 0;
+  const bool cs_a = cs_sel == 1 && (p.gauss ? !g3 : t2 == 0) && wn == 0;
+  const bool cs_b = cs_sel == 2 && (p.gauss ? !g3 : t1 == 0) && wm == 0;
 
   // this lane's fragment addresses inside a slab: A [tok = 4q + kq][wm*64 + 4*i16], B likewise with wn
   const int offA = kq * TN_W + wm * 64 + 4 * i16;
@@ -143,6 +161,41 @@ __global__ __launch_bounds__(384) void gemm_tn_kernel(const TnArgs p) {
   constexpr int NQ = TN_TOK / 4;                        // 4-token MFMA steps per slab
 
   bar();                                                // P
+  if (g3) {
+    // sum-product tile: slab image A [16 tok][256] | B [16 tok][256]; per 4-token step four fragment reads (Ar, Ai, Br, Bi),
+    // a = Ar + Ai, b = Bi - Br on the VALU, 16 MFMAs
+    const int oA = kq * 256 + wm * 64 + 4 * i16, oB = TN_TOK * TN_W + kq * 256 + wn * 64 + 4 * i16;
+    tn_f32x4 far = {0.f, 0.f, 0.f, 0.f}, fai = far, fbr = far, fbi = far;
+    if (nslab > 0) {
+      far = *reinterpret_cast<const tn_f32x4*>(lds + oA);
+      fai = *reinterpret_cast<const tn_f32x4*>(lds + oA + 128);
+      fbr = *reinterpret_cast<const tn_f32x4*>(lds + oB);
+      fbi = *reinterpret_cast<const tn_f32x4*>(lds + oB + 128);
+    }
+    int ring = 0;
+#pragma unroll 1
+    for (int g = 0; g < nslab; ++g) {
+      bar();                                            // B_g
+      const float* cur = lds + ring * TN_SLABF;
+      const int rn = ring == TN_RING - 1 ? 0 : ring + 1;
+      const float* nxt = g + 1 < nslab ? lds + rn * TN_SLABF : cur;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const tn_f32x4 a = far + fai, b = fbi - fbr;
+        const float* src = q + 1 < 4 ? cur + (q + 1) * 4 * 256 : nxt;
+        far = *reinterpret_cast<const tn_f32x4*>(src + oA);
+        fai = *reinterpret_cast<const tn_f32x4*>(src + oA + 128);
+        fbr = *reinterpret_cast<const tn_f32x4*>(src + oB);
+        fbi = *reinterpret_cast<const tn_f32x4*>(src + oB + 128);
+#pragma unroll
+        for (int ea = 0; ea < 4; ++ea)
+#pragma unroll
+          for (int eb = 0; eb < 4; ++eb)
+            acc[ea][eb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[ea], b[eb], acc[ea][eb], 0, 0, 0);
+      }
+      ring = rn;
+    }
+  } else {
   tn_f32x4 fa = {0.f, 0.f, 0.f, 0.f}, fb = fa;
   if (nslab > 0) {
     fa = *reinterpret_cast<const tn_f32x4*>(lds + offA);
@@ -173,16 +226,20 @@ __global__ __launch_bounds__(384) void gemm_tn_kernel(const TnArgs p) {
     }
     ring = rn;
   }
+  }
 
   // partial tile: element (n1 = 4*(4*kq + r) + ea, n2 = 4*i16 + eb) of the wave's 64 x 64 block
-  float* ws = p.ws + ((long long)zs * p.batch + zb) * p.N1 * p.N2;
-  const int n1b = t1 * TN_W + wm * 64, n2b = t2 * TN_W + wn * 64 + 4 * i16;
+  // (three-product form: [split][batch][3 tiles][128][128])
+  float* ws = p.gauss ? p.ws + (((long long)zs * p.batch + zb) * 3 + tile) * (TN_W * TN_W)
+                      : p.ws + ((long long)zs * p.batch + zb) * p.N1 * p.N2;
+  const int ldw = p.gauss ? TN_W : p.N2;
+  const int n1b = (p.gauss ? 0 : t1 * TN_W) + wm * 64, n2b = (p.gauss ? 0 : t2 * TN_W) + wn * 64 + 4 * i16;
 #pragma unroll
   for (int ea = 0; ea < 4; ++ea)
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int n1 = n1b + 4 * (4 * kq + r) + ea;
-      *reinterpret_cast<float4*>(ws + (long long)n1 * p.N2 + n2b) =
+      *reinterpret_cast<float4*>(ws + (long long)n1 * ldw + n2b) =
           make_float4(acc[ea][0][r], acc[ea][1][r], acc[ea][2][r], acc[ea][3][r]);
     }
   if (cs_a || cs_b) {
@@ -197,7 +254,8 @@ __global__ __launch_bounds__(384) void gemm_tn_kernel(const TnArgs p) {
     if (kq == 0) {
       const int L = p.csL ? p.csL : (cs_a ? p.N1 : p.N2);
       const int g0 = cs_a ? t1 * TN_W + wm * 64 : t2 * TN_W + wn * 64;
-      float* wc = p.ws + (long long)p.splits * p.batch * p.N1 * p.N2 + ((long long)zs * p.batch + zb) * L + g0 + 4 * i16;
+      const long long prod = p.gauss ? 3ll * TN_W * TN_W : (long long)p.N1 * p.N2;
+      float* wc = p.ws + (long long)p.splits * p.batch * prod + ((long long)zs * p.batch + zb) * L + g0 + 4 * i16;
       *reinterpret_cast<float4*>(wc) = make_float4(cs[0], cs[1], cs[2], cs[3]);
     }
   }
@@ -392,6 +450,7 @@ int dpot_gemm_tn_try(const dpot_gemm_desc* d, hipStream_t s) {
   if ((long long)p.slabs_per_split * (d->splitk - 1) >= nslab) return -1;      // an empty split would leave its partial unwritten
   p.ws = d->workspace;
   p.cs_of = d->colsum_of;
+  p.gauss = 0;
   hipLaunchKernelGGL(gemm_tn_kernel, dim3((unsigned)(p.tiles1 * p.tiles2), 1, (unsigned)(d->batch * d->splitk)), dim3(384),
                      0, s, p);
   return check_launch("gemm_tn_kernel");
@@ -432,20 +491,29 @@ __device__ __forceinline__ float tn_sum_splits(const float* __restrict__ w, long
 // blockIdx.x / gridDim.x, block_finalize_kernel a slice of its grid)
 __device__ __forceinline__ void afno_wgrad2_reduce_body(int bid, int nblk, const float* __restrict__ ws, int splits, int nb,
                                                         int bs, float* __restrict__ dw1, float* __restrict__ db1,
-                                                        float* __restrict__ dw2, float* __restrict__ db2) {
+                                                        float* __restrict__ dw2, float* __restrict__ db2, int gauss) {
   const int n2 = 2 * bs;
-  const long long MN = (long long)n2 * n2, total = MN * 2 * nb;
+  const long long MN = gauss ? 3ll * bs * bs : (long long)n2 * n2, total = MN * 2 * nb;
   const long long nw = (long long)nb * bs * bs;
   for (long long idx = bid * 256ll + threadIdx.x; idx < 2 * nw; idx += (long long)nblk * 256) {
     const int layer = idx >= nw;
     const long long q = idx - layer * nw;
     const int o = (int)(q % bs), i = (int)((q / bs) % bs), k = (int)(q / ((long long)bs * bs));
     const float* base = ws + (long long)(layer * nb + k) * MN;
+    float* dw = layer ? dw2 : dw1;
+    if (gauss) {     // P1 = Ar^T Br, P2 = Ai^T Bi, P3 = (Ar + Ai)^T (Bi - Br): dWr = P1 + P2, dWi = P3 + P1 - P2
+      const long long e = (long long)i * bs + o, t = (long long)bs * bs;
+      const float p1 = tn_sum_splits(base + e, total, splits);
+      const float p2 = tn_sum_splits(base + t + e, total, splits);
+      const float p3 = tn_sum_splits(base + 2 * t + e, total, splits);
+      dw[q] = p1 + p2;
+      dw[nw + q] = p3 + p1 - p2;
+      continue;
+    }
     const float rr = tn_sum_splits(base + (long long)i * n2 + o, total, splits);
     const float ii = tn_sum_splits(base + (long long)(bs + i) * n2 + bs + o, total, splits);
     const float ri = tn_sum_splits(base + (long long)i * n2 + bs + o, total, splits);
     const float ir = tn_sum_splits(base + (long long)(bs + i) * n2 + o, total, splits);
-    float* dw = layer ? dw2 : dw1;
     dw[q] = rr + ii;
     dw[nw + q] = ri - ir;
   }
@@ -461,8 +529,14 @@ __device__ __forceinline__ void afno_wgrad2_reduce_body(int bid, int nblk, const
 }
 __global__ __launch_bounds__(256) void afno_wgrad2_reduce_kernel(const float* __restrict__ ws, int splits, int nb, int bs,
                                                                  float* __restrict__ dw1, float* __restrict__ db1,
-                                                                 float* __restrict__ dw2, float* __restrict__ db2) {
-  afno_wgrad2_reduce_body(blockIdx.x, gridDim.x, ws, splits, nb, bs, dw1, db1, dw2, db2);
+                                                                 float* __restrict__ dw2, float* __restrict__ db2, int gauss) {
+  afno_wgrad2_reduce_body(blockIdx.x, gridDim.x, ws, splits, nb, bs, dw1, db1, dw2, db2, gauss);
+}
+
+// three-product form of the AFNO weight gradient (TnArgs::gauss): 128 channels per block; DPOT_AFNO_WGRAD_GAUSS=0: four products
+static int tn_gauss(int bs) {
+  static const int enabled = [] { const char* e = getenv("DPOT_AFNO_WGRAD_GAUSS"); return e ? atoi(e) : 1; }();
+  return enabled && bs == TN_W ? 1 : 0;
 }
 }  // namespace dpot
 
@@ -470,9 +544,11 @@ extern "C" int dpot_afno_wgrad2_splitk(int Mm, int nb, int bs) {
   static const int enabled = [] { const char* e = getenv("DPOT_AFNO_WGRAD2"); return e ? atoi(e) : 1; }();
   const int N = 2 * bs;
   if (!enabled || nb <= 0 || bs <= 0 || (N % TN_W && N != TW) || Mm <= 0 || Mm % TN_TOK) return 0;
-  const long long tiles = N == TW ? (long long)2 * nb : (long long)2 * nb * (N / TN_W) * (N / TN_W);
+  const long long tiles = N == TW ? (long long)2 * nb : tn_gauss(bs) ? 6ll * nb : (long long)2 * nb * (N / TN_W) * (N / TN_W);
   const int nslab = Mm / TN_TOK;
-  long long s = (256 + tiles / 2) / tiles;
+  // three-product form: 3 tiles per problem do not divide 256 - round DOWN (one round of workgroups: 24 tiles x 10 splits = 240
+  // at DPOT-Tiny; rounded to 11 the launch needs a second round: 75 against 59 us, profiles/r05_tn_bench_gauss.txt)
+  long long s = tn_gauss(bs) && N != TW ? 256 / tiles : (256 + tiles / 2) / tiles;
   const long long smax = nslab / 4;
   if (s > smax) s = smax;
   if (s < 1) s = 1;
@@ -483,7 +559,7 @@ extern "C" int dpot_afno_wgrad2_splitk(int Mm, int nb, int bs) {
 
 extern "C" int64_t dpot_afno_wgrad2_ws_elems(int nb, int bs, int splitk) {
   const int64_t N = 2 * bs;
-  return (int64_t)splitk * 2 * nb * (N * N + N);
+  return (int64_t)splitk * 2 * nb * ((tn_gauss(bs) ? 3 * (int64_t)bs * bs : N * N) + N);
 }
 
 extern "C" int dpot_afno_wgrad2(const float* S, const float* dO1pre, const float* O1, const float* dO2, int ld, int Mm,
@@ -508,20 +584,21 @@ extern "C" int dpot_afno_wgrad2(const float* S, const float* dO1pre, const float
   DPOT_REQUIRE((long long)p.slabs_per_split * (splitk - 1) < nslab, "afno_wgrad2: split factor leaves an empty split");
   p.ws = workspace;
   p.cs_of = 2;
+  p.gauss = tn_gauss(bs);
   hipStream_t s = as_stream(stream);
   if (N == TW) {
     p.tiles1 = p.tiles2 = 1;
     hipLaunchKernelGGL(gemm_tn192_kernel, dim3(1, 1, (unsigned)(2 * nb * splitk)), dim3(704), 0, s, p);
   } else {
-    hipLaunchKernelGGL(gemm_tn_kernel, dim3((unsigned)(p.tiles1 * p.tiles2), 1, (unsigned)(2 * nb * splitk)), dim3(384), 0, s,
-                       p);
+    hipLaunchKernelGGL(gemm_tn_kernel, dim3((unsigned)(p.gauss ? 3 : p.tiles1 * p.tiles2), 1, (unsigned)(2 * nb * splitk)),
+                       dim3(384), 0, s, p);
   }
   int rc = check_launch("gemm_tn_kernel");
   if (rc || !dw1) return rc;            // dw1 == NULL: partials only, dpot_block_finalize reduces them
   long long blocks = (2ll * nb * bs * bs + 255) / 256;
   if (blocks > 4096) blocks = 4096;
   hipLaunchKernelGGL(afno_wgrad2_reduce_kernel, dim3((unsigned)blocks), dim3(256), 0, s, (const float*)workspace, splitk, nb,
-                     bs, dw1, db1, dw2, db2);
+                     bs, dw1, db1, dw2, db2, p.gauss);
   return check_launch("afno_wgrad2_reduce_kernel");
 }
 
@@ -584,7 +661,7 @@ __global__ __launch_bounds__(256) void mlp_wgrad2_reduce_kernel(const float* __r
 // ---------------------------------------------------------------------------------------------------------------------
 struct FinalizeArgs {
   // slice A: AFNO weight gradients (dpot_afno_wgrad2's reduction)
-  const float* a_ws; int a_splits, a_nb, a_bs; float *a_dw1, *a_db1, *a_dw2, *a_db2; int nA;
+  const float* a_ws; int a_splits, a_nb, a_bs, a_gauss; float *a_dw1, *a_db1, *a_dw2, *a_db2; int nA;
   // slice M: channel-MLP weight gradients (dpot_mlp_wgrad2's reduction)
   const float* m_ws; int m_splits, m_E, m_mh; float *m_dW2, *m_dW1, *m_db2, *m_db1; int nM;
   // slice G: GroupNorm parameter gradients (dpot_groupnorm_param_grads): g_jobs jobs x ceil(E / 64) workgroups
@@ -654,7 +731,7 @@ __device__ __forceinline__ void gn_param_grad_body(int bx, const float* __restri
 __global__ __launch_bounds__(256) void block_finalize_kernel(const FinalizeArgs a) {
   const int b = blockIdx.x;
   if (b < a.nA) {
-    afno_wgrad2_reduce_body(b, a.nA, a.a_ws, a.a_splits, a.a_nb, a.a_bs, a.a_dw1, a.a_db1, a.a_dw2, a.a_db2);
+    afno_wgrad2_reduce_body(b, a.nA, a.a_ws, a.a_splits, a.a_nb, a.a_bs, a.a_dw1, a.a_db1, a.a_dw2, a.a_db2, a.a_gauss);
   } else if (b < a.nA + a.nM) {
     mlp_wgrad2_reduce_body(b - a.nA, a.nM, a.m_ws, a.m_splits, a.m_E, a.m_mh, a.m_dW2, a.m_dW1, a.m_db2, a.m_db1);
   } else if (b < a.nA + a.nM + a.nG) {
@@ -709,6 +786,7 @@ extern "C" int dpot_mlp_wgrad2(const float* do2, const float* Hh, const float* x
   DPOT_REQUIRE((long long)p.slabs_per_split * (splitk - 1) < nslab, "mlp_wgrad2: split factor leaves an empty split");
   p.ws = workspace;
   p.cs_of = 1; p.cs_of2 = 2; p.csL = E > mh ? E : mh;
+  p.gauss = 0;
   hipStream_t s = as_stream(stream);
   hipLaunchKernelGGL(gemm_tn_kernel, dim3((unsigned)(p.tiles1 * p.tiles2), 1, (unsigned)(2 * splitk)), dim3(384), 0, s, p);
   int rc = check_launch("gemm_tn_kernel");
@@ -737,7 +815,7 @@ extern "C" int dpot_block_finalize(const float* afno_ws, int afno_splitk, int nb
   }
   if (afno_ws) {
     DPOT_REQUIRE(afno_splitk >= 1 && nb > 0 && bs > 0 && dw1 && db1 && dw2 && db2, "block_finalize: bad AFNO slice");
-    a.a_ws = afno_ws; a.a_splits = afno_splitk; a.a_nb = nb; a.a_bs = bs; a.a_dw1 = dw1; a.a_db1 = db1; a.a_dw2 = dw2; a.a_db2 = db2;
+    a.a_ws = afno_ws; a.a_splits = afno_splitk; a.a_nb = nb; a.a_bs = bs; a.a_gauss = tn_gauss(bs); a.a_dw1 = dw1; a.a_db1 = db1; a.a_dw2 = dw2; a.a_db2 = db2;
     long long blocks = (2ll * nb * bs * bs + 255) / 256;            // as dpot_afno_wgrad2
     a.nA = (int)(blocks > 4096 ? 4096 : blocks);
   }

@@ -290,6 +290,20 @@ def mlp_pack_kind(E: int, mh: int, M: Optional[int] = None) -> Optional[str]:
     return None
 
 
+def _mlp_rowform(M: int, E: int, mh: int) -> bool:
+    """bf16 channel MLP, pack-both path: the two weight gradients of a block come from ONE launch that reads the hidden layer
+    and its gradient in ROW form through the transposing LDS read (dW2^T = H^T dY stored transposed, dW1 = dH^T X) - no
+    transposed packs of those two.  OPT-IN (DPOT_BF16P_ROWFORM=1): built, bit-identical to the transposed-pack launch and
+    REJECTED by measurement in round 5 (VERDICT r4 #2 asked for it): the two packed-output epilogues save 2.6 + 3.9 us of CU
+    time per block at DPOT-M (profiles/r05_pmc_bf16p_M_rowform{0,1}.json: SQ_BUSY_CU_CYCLES 44.5 -> 42.9 M and 39.2 -> 36.8 M;
+    the round-4 ablation had promised 10 + 8) while the paired weight-gradient launch goes from 50.1 to 90.1 M busy cycles -
+    same LDS cycles, same bank conflicts, same bytes fetched: the LDS-DMA image a conflict-free ds_read_b64_tr_b16 needs
+    forces a permuted SOURCE address (four 256-byte runs per wave instruction), and the DMA engine, already the bound of these
+    loops at ~29 B/clk/CU, delivers that at about half the linear rate.  Train step, one box: DPOT-M 12.43 -> 13.38 ms,
+    DPOT-L 89.8 -> 101.6 ms (profiles/r05_rowform_gauss_step_ab.txt)."""
+    return os.environ.get("DPOT_BF16P_ROWFORM", "0") == "1" and ops.gemm_bf16p_pair_rowform_ok(mh, E, mh, E, M)
+
+
 def _mlp_panel_mode(mlp_pk, M, E, mh, mp) -> int:
     """which pre-packed-weight kernel the channel MLP runs on: 0 = none (generic split GEMM), 1 = fp32 panel
     (csrc/gemm_panel.hip), 2 = bf16 panel (csrc/gemm_bf16p.hip; plain bf16 or the fp32-accurate bf16x6 split, by the
@@ -542,15 +556,20 @@ def _block_parts(x, n1w, n1b, n2w, n2b, f1w, f1b, packed, dims, mp, need_out, f2
         else:
             xp, xpT, _ = ops.bf16_pack_both(xn2.view(M, E))
         del xn2
-        # fc1: the epilogue emits the activated hidden layer directly in its two packed forms (no fp32 copy of it exists)
+        # fc1: the epilogue emits the activated hidden layer directly in its packed forms (no fp32 copy of it exists)
         # (Hpre here = act'(pre-activation) as a bf16 pack: all the backward needs of it, at half the bytes of the fp32
         # pre-activation and without a second activation evaluation)
+        # round 5: where the paired weight-gradient launch reads ROW-form operands through the transposing LDS read
+        # (ops.gemm_bf16p_pair_rowform_ok: DPOT-M / -L), the hidden layer is kept in its ROW form only - the transposed pack
+        # (67 MB per block at DPOT-M, written by this epilogue at the HBM rate with the matrix pipes idle) is gone
+        rowform = _mlp_rowform(M, E, mh)
         _, Hpre, hp, hpT, _ = ops.gemm_bf16p_packed(xp, mlp_pk[0], M, mh, E, bias=f1b, act=act, mode=EPI_ACT,
-                                                    save_dact=True, pack_rows=need_out, pack_trans=True, store=False)
+                                                    save_dact=True, pack_rows=need_out or rowform, pack_trans=not rowform,
+                                                    store=False)
         out = None
         if need_out:
             out, _ = ops.gemm_bf16p(hp, mlp_pk[2], M, E, mh, bias=f2b, res=x.view(M, E))
-        return out, (mean1, rstd1, S, O1pre, O1, y1, mean2, rstd2, xpT, Hpre, hpT)
+        return out, (mean1, rstd1, S, O1pre, O1, y1, mean2, rstd2, xpT, Hpre, hp if rowform else hpT)
     if panel == 2:   # bf16 matrix cores: weights pre-packed bf16 once per step, activations packed in one pass each
         Hh, Hpre = ops.gemm_bf16p(ops.bf16_pack_rows(xn2.view(M, E), planes=npl), mlp_pk[0], M, mh, E, bias=f1b, act=act,
                                   mode=EPI_ACT, save_pre=True, planes=npl)
@@ -666,16 +685,22 @@ class BlockFn(torch.autograd.Function):
             dop, dopT, df2b = ops.bf16_pack_both(do2, want_colsum=True, colsum_out=s_f2b.out(), defer_colsum=dcs)
             # both weight gradients in ONE launch once dHpre's pack exists, when each alone would need split-K
             pair = ops.gemm_bf16p_pair_wanted(E, mh, mh, E, M)
-            if not pair:
+            rowform = _mlp_rowform(M, E, mh)                # Hh is then the hidden layer's ROW-form pack (see _block_parts)
+            if not pair and not rowform:
                 df2w, _ = ops.gemm_bf16p(dopT, Hh, E, mh, M, out=s_f2w.out())
-            # dHpre = (do2 W2) * act'(Hpre) leaves the GEMM as its two packs + bias column sums only
+            # dHpre = (do2 W2) * act'(Hpre) leaves the GEMM as its packs + bias column sums only
             _, _, dhp, dhpT, df1b = ops.gemm_bf16p_packed(dop, mlp_pk[3], M, mh, E, act=act, mode=EPI_DACT, dact=Hpre,
-                                                          pack_rows=True, pack_trans=True, colsum=True,
+                                                          pack_rows=True, pack_trans=not rowform, colsum=True,
                                                           colsum_out=s_f1b.out(), store=False, defer_colsum=dcs)
             if dcs:
                 pending["cs"] = [df2b, df1b]
                 df2b, df1b = df2b[3], df1b[3]
-            if pair:
+            if rowform:
+                # dW2^T [mh, E] = H^T dY (stored transposed = dW2 [E, mh]) and dW1 [mh, E] = dH^T X: the A operands are the
+                # ROW-form packs of H and dH, read through the transposing LDS read (csrc/gemm_bf16p.hip, round 5)
+                df2w, df1w = ops.gemm_bf16p_pair(Hh, dopT, mh, E, dhp, xn2, mh, E, M, out0=s_f2w.out(), out1=s_f1w.out(),
+                                                 rowform=True, trans0=True)
+            elif pair:
                 df2w, df1w = ops.gemm_bf16p_pair(dopT, Hh, E, mh, dhpT, xn2, mh, E, M, out0=s_f2w.out(), out1=s_f1w.out())
             else:
                 df1w, _ = ops.gemm_bf16p(dhpT, xn2, mh, E, M, out=s_f1w.out())

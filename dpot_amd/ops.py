@@ -392,17 +392,43 @@ def gemm_bf16p_pair_wanted(M0: int, N0: int, M1: int, N1: int, K: int) -> bool:
     return bool(_lib.load().dpot_gemm_bf16p_pair_wanted(M0, N0, M1, N1, K))
 
 
+BF16P_KERNEL_KINDS = {0: "dpot::gemm_bf16p_kernel (8 compute + 4 loader waves, LDS-DMA)",
+                      1: "dpot::gemm_bf16p_duo_kernel (two 8-wave workgroups per CU)",
+                      2: "dpot::gemm_bf16p_bd_kernel<8,1,3> (B-direct: W fragments straight from global memory into registers, "
+                         "only the A panel through LDS; eight 128 x 32 waves)",
+                      3: "dpot::gemm_bf16p_bd_kernel<8,2,3> (B-direct: W fragments straight from global memory into registers, "
+                         "only the A panel through LDS; four 128 x 64 waves, two workgroups per CU)",
+                      4: "dpot::gemm_bf16x6p_kernel (fp32-accurate three-plane split)"}
+
+
+def gemm_bf16p_kernel_name(M: int, N: int, K: int, splitk: int = 1, planes: int = 1, packed_outputs: bool = False) -> str:
+    """the kernel dpot_gemm_bf16p runs for this shape, from the library's own selection (dpot_gemm_bf16p_kernel_kind)"""
+    k = _lib.load().dpot_gemm_bf16p_kernel_kind(M, N, K, splitk, planes, int(packed_outputs))
+    return BF16P_KERNEL_KINDS.get(k & 7, f"kind {k}") + (" on 128 x 192 tiles" if k >= 8 else "")
+
+
+def gemm_bf16p_pair_rowform_ok(M0: int, N0: int, M1: int, N1: int, K: int) -> bool:
+    """the pair launch for these shapes takes ROW-form A operands / transposed outputs (gemm_bf16p_pair(rowform=True))"""
+    return bool(_lib.load().dpot_gemm_bf16p_pair_rowform_ok(M0, N0, M1, N1, K))
+
+
 def gemm_bf16p_pair(A0: Tensor, W0: Tensor, M0: int, N0: int, A1: Tensor, W1: Tensor, M1: int, N1: int, K: int,
                     out0: Optional[Tensor] = None, out1: Optional[Tensor] = None,
-                    splitk: Optional[int] = None) -> Tuple[Tensor, Tensor]:
+                    splitk: Optional[int] = None, rowform: bool = False, trans0: bool = False,
+                    trans1: bool = False) -> Tuple[Tensor, Tensor]:
     """(A0 W0^T [M0,N0], A1 W1^T [M1,N1]) on the bf16 matrix cores in ONE launch (packed plain-bf16 operands, common K,
-    one common split-K factor - None: the library's choice): the two channel-MLP weight gradients of a block"""
+    one common split-K factor - None: the library's choice): the two channel-MLP weight gradients of a block.
+    rowform: A0 / A1 are the ROW-form packs of the [K, M_i] activations (as the data GEMMs consume them; read through the
+    transposing LDS read - no transposed pack needed); trans_i: result i is returned / written TRANSPOSED ([N_i, M_i])"""
     lib = _lib.load()
-    C0, C1 = _out(out0, (M0, N0), A0.device), _out(out1, (M1, N1), A1.device)
+    C0 = _out(out0, (N0, M0) if trans0 else (M0, N0), A0.device)
+    C1 = _out(out1, (N1, M1) if trans1 else (M1, N1), A1.device)
     sk = max(1, lib.dpot_gemm_bf16p_pair_splitk(M0, N0, M1, N1, K)) if splitk is None else splitk
     ws = torch.empty(sk * (M0 * N0 + M1 * N1), dtype=torch.float32, device=A0.device) if sk > 1 else None
-    check(lib.dpot_gemm_bf16p_pair(A0.data_ptr(), W0.data_ptr(), C0.data_ptr(), N0, M0, N0, A1.data_ptr(),
-                                   W1.data_ptr(), C1.data_ptr(), N1, M1, N1, K, sk, _p(ws), _stream()), "gemm_bf16p_pair")
+    check(lib.dpot_gemm_bf16p_pair(A0.data_ptr(), W0.data_ptr(), C0.data_ptr(), M0 if trans0 else N0, M0, N0, A1.data_ptr(),
+                                   W1.data_ptr(), C1.data_ptr(), M1 if trans1 else N1, M1, N1, K, sk, _p(ws),
+                                   3 if rowform else 0, (1 if trans0 else 0) | (2 if trans1 else 0), _stream()),
+          "gemm_bf16p_pair")
     return C0, C1
 
 

@@ -544,6 +544,10 @@ int dpot_bf16_pack_jobs(const dpot_pack_job* jobs_dev, int njobs, int max_elems,
 /* C[M,N] (fp32) = epilogue(A @ Wt^T), A = packed [M, K], Wt = packed [N, K] (same `planes`); epilogue as
  * dpot_gemm_panel.  Needs N % 256 == 0 and K % 32 == 0 (dpot_gemm_bf16p_supported). */
 int dpot_gemm_bf16p_supported(int M, int N, int K);
+/* which kernel dpot_gemm_bf16p selects for a shape (for reports: bench.py names the kernel it times): 0 = LDS-DMA kernel
+ * (8 compute + 4 loader waves), 1 = two-workgroup kernel, 2 = B-direct with eight 128 x 32 waves, 3 = B-direct with four
+ * 128 x 64 waves (two workgroups per CU), 4 = bf16x6; + 8 when it runs on 128 x 192 tiles; -1: unsupported shape */
+int dpot_gemm_bf16p_kernel_kind(int M, int N, int K, int splitk, int planes, int packed_outputs);
 int dpot_gemm_bf16p(const void* Apacked, const void* Wpacked, const float* bias, const float* aux, int ldaux,
                     const float* res, int ldres, float* pre, int ldpre, float* C, int ldc, int M, int N, int K, int act,
                     int epi_mode, int planes, int splitk, float* workspace, void* out_rows, void* out_trans,
@@ -555,9 +559,16 @@ int dpot_gemm_bf16p_pair_wanted(int M0, int N0, int M1, int N1, int K);
 /* common split-K factor of the pair launch: 0 = do not pair, 1 = no split, s > 1 = s splits (workspace of
  * s * (M0*N0 + M1*N1) floats; the partial sums are reduced in a fixed order by two further launches) */
 int dpot_gemm_bf16p_pair_splitk(int M0, int N0, int M1, int N1, int K);
+/* a_rowform / transC (2-bit masks, bit i = problem i; round 5): with bit i of a_rowform set, A_i is NOT the packed
+ * [M_i/32][K/16] operand but the ROW-form pack of the [K, M_i] activation ([K/32][M_i/16][64 chunks][8] - what
+ * dpot_bf16_pack_rows / the out_rows epilogue write and the data GEMMs consume), read through ds_read_b64_tr_b16: the weight
+ * gradients dW1 = dH^T X and dW2^T = H^T dY then need no TRANSPOSED pack of the hidden layer or of its gradient.  With bit
+ * i of transC set, C_i is stored transposed: C_i points at an [N_i, M_i] matrix of row length ldc_i.  Both need
+ * dpot_gemm_bf16p_pair_rowform_ok (the un-split B-direct launch; a_rowform then covers both problems). */
+int dpot_gemm_bf16p_pair_rowform_ok(int M0, int N0, int M1, int N1, int K);
 int dpot_gemm_bf16p_pair(const void* A0, const void* W0, float* C0, int ldc0, int M0, int N0, const void* A1,
                          const void* W1, float* C1, int ldc1, int M1, int N1, int K, int splitk, float* workspace,
-                         dpot_stream_t stream);
+                         int a_rowform, int transC, dpot_stream_t stream);
 /* out_rows / out_trans / colsum_part (all optional, planes == 1, splitk <= 1, M % 32 == 0): the epilogue also emits the
  * 1-plane packs of the FINAL output (row form [M, N]; transposed form = rows N, k M) and partial column sums
  * [M/32, N] - the next GEMMs of a chain then need no pack pass over this output; C may be NULL in that case.

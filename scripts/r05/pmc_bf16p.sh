@@ -18,7 +18,11 @@ import csv, glob, json, collections
 M, E, mh = {"S": (8192, 1024, 1024), "M": (8192, 1024, 4096), "L16": (16384, 1536, 6144), "L4": (4096, 1536, 6144)}["$SHAPE"]
 A, H = 2.0 * M * E, 2.0 * M * mh                         # bf16 bytes of a [tokens, E] / [tokens, hidden] pack
 Wb = 2.0 * E * mh
-alg = {"fc1_fwd": A + Wb + 3 * H, "fc2_fwd": H + Wb + 2 * 4.0 * M * E, "fc2_dgrad": A + Wb + H + 2 * H,
+import ctypes, os, sys
+sys.path.insert(0, os.getcwd())
+from dpot_amd import ops
+npk = 1 if os.environ.get("DPOT_BF16P_ROWFORM", "0") == "1" and ops.gemm_bf16p_pair_rowform_ok(mh, E, mh, E, M) else 2      # packs of the hidden layer / its gradient written
+alg = {"fc1_fwd": A + Wb + (npk + 1) * H, "fc2_fwd": H + Wb + 2 * 4.0 * M * E, "fc2_dgrad": A + Wb + H + npk * H,
        "fc1_dgrad": H + Wb + 4.0 * M * E, "pair": 2 * (A + H) + 2 * 4.0 * E * mh}
 forms = {}
 for form in alg:

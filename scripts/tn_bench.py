@@ -28,7 +28,7 @@ def afno(Mm, nb, bs, E, nsets):
     db1, db2 = torch.empty(2, nb, bs, device="cuda"), torch.empty(2, nb, bs, device="cuda")
     fl = 2.0 * 2 * nb * N * N * Mm
     auto = ops.afno_wgrad2_splitk(Mm, nb, bs)
-    for sk in (2, 4, 6, 8, 12, 16, 18, 24, 36):
+    for sk in (2, 4, 5, 6, 8, 10, 12, 16, 18, 24, 36):
         nslab = Mm // 32
         sps = (nslab + sk - 1) // sk
         if sps * (sk - 1) >= nslab: continue
@@ -53,5 +53,8 @@ def mlp(T, E, mh, nsets):
 print("DPOT-Tiny B=32 (kernel + reduce launch per call)")
 for nsets in (1, 5):
     afno(4608, 4, 128, 512, nsets)
+print("DPOT-S / -M B=32 AFNO weight gradients")
+afno(4608, 8, 128, 1024, 3)
+print("DPOT-Tiny channel MLP")
 for nsets in (1, 5):
     mlp(8192, 512, 512, nsets)

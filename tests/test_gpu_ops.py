@@ -147,7 +147,11 @@ def test_linear_bwd_weight_auto_splitk_large_k(ops):
                                               # per line - 4-channel chunks (<= 36 kept columns) and 2-channel chunks
                                               # (all 65 columns incl. the Nyquist one), truncated and full mode sets
                                               (1, 128, 128, 8, 1, 32), (2, 128, 128, 8, 2, 20), (1, 128, 128, 12, 2, 128),
-                                              (1, 128, 128, 6, 3, 64)])
+                                              (1, 128, 128, 6, 3, 64),
+                                              # round 5: 3 * 2^k grids (192^2 / 384^2 / 768^2 fields at patch 8) on register
+                                              # FFTs with a radix-3 front stage - full and truncated mode sets, both chunk widths
+                                              (2, 24, 24, 64, 4, 32), (2, 24, 24, 8, 2, 7), (1, 48, 48, 32, 2, 20),
+                                              (1, 48, 48, 12, 3, 48), (1, 96, 96, 8, 1, 64), (1, 96, 96, 4, 2, 30)])
 def test_rfft2_irfft2_vs_torch(ops, B, h, w, E, nb, modes):
     bs = E // nb
     mx, my = min(modes, h), min(modes, w // 2 + 1)
@@ -168,10 +172,12 @@ def test_rfft2_irfft2_vs_torch(ops, B, h, w, E, nb, modes):
     assert_close(y.view(B, h, w, E), yref, "irfft2")
 
 
-def test_dft_adjoints_match_autograd(ops):
-    """col_weights variants are the exact adjoints torch.autograd uses for irfft2 / rfft2"""
-    B, h, w, E, nb = 2, 16, 16, 32, 4
-    bs, mx, my = E // nb, 7, 6
+@pytest.mark.parametrize("h,mx,my", [(16, 7, 6), (24, 24, 13), (48, 9, 25)])
+def test_dft_adjoints_match_autograd(ops, h, mx, my):
+    """col_weights variants are the exact adjoints torch.autograd uses for irfft2 / rfft2 (16-point lines; round 5: the
+    3 * 2^k lines too, with every mode kept incl. the Nyquist column)"""
+    B, w, E, nb = 2, h, 32, 4
+    bs = E // nb
     x = rnd(B, h, w, E, seed=1).double().requires_grad_(True)
     G = torch.complex(rnd(B, mx, my, E, seed=2).double(), rnd(B, mx, my, E, seed=3).double())
     s = torch.fft.rfft2(x, dim=(1, 2), norm="ortho")[:, :mx, :my]
@@ -1123,6 +1129,32 @@ def test_bf16_panel_pair_launch_matches_single(ops):
     S0, _ = ops.gemm_bf16p(packs[0], packs[1], n0, k0, T, splitk=1)
     S1, _ = ops.gemm_bf16p(packs[2], packs[3], n1, k1, T, splitk=1)
     assert torch.equal(C0, S0) and torch.equal(C1, S1)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("T,E,mh", [(8192, 1024, 4096), (512, 1536, 6144), (2048, 1024, 4096)])
+def test_bf16_pair_launch_with_row_form_operands(ops, T, E, mh):
+    """round 5: the paired weight-gradient launch reading the hidden layer H [T, mh] and its gradient dH in ROW form through
+    ds_read_b64_tr_b16 (permuted LDS-DMA image, csrc/gemm_bf16p.hip ATR) - dW2^T = H^T dY stored transposed, dW1 = dH^T X -
+    against the launch on TRANSPOSED packs it replaces: same products, same k order -> bit-identical; and against float64
+    products of the bf16-rounded operands.  DPOT-M's shape (256 tiles, eight-wave workgroups), DPOT-L's (128 x 192 tiles,
+    768 of them) and a short contraction at DPOT-M's widths."""
+    if not ops.gemm_bf16p_pair_rowform_ok(mh, E, mh, E, T):
+        pytest.skip("row-form pair launch not available for this shape / switched off")
+    torch.manual_seed(T + E)
+    h, dh = torch.randn(T, mh, device="cuda"), torch.randn(T, mh, device="cuda")
+    x, dy = torch.randn(T, E, device="cuda"), torch.randn(T, E, device="cuda")
+    hp, dhp = ops.bf16_pack_rows(h), ops.bf16_pack_rows(dh)                    # ROW form (what the data GEMMs consume)
+    xT, dyT = ops.bf16_pack_rows(x, trans=True), ops.bf16_pack_rows(dy, trans=True)
+    dW2, dW1 = ops.gemm_bf16p_pair(hp, dyT, mh, E, dhp, xT, mh, E, T, rowform=True, trans0=True)
+    assert dW2.shape == (E, mh) and dW1.shape == (mh, E)
+    r = lambda t: t.bfloat16().double()
+    assert_close(dW2, r(dy).t() @ r(h), "dW2 = dY^T H (computed as H^T dY, stored transposed)")
+    assert_close(dW1, r(dh).t() @ r(x), "dW1 = dH^T X")
+    hT, dhT = ops.bf16_pack_rows(h, trans=True), ops.bf16_pack_rows(dh, trans=True)
+    O2, O1 = ops.gemm_bf16p_pair(dyT, hT, E, mh, dhT, xT, mh, E, T, splitk=1)  # the launch on transposed packs
+    assert torch.equal(dW1, O1), "row-form operand changed dW1"
+    assert_close(dW2, O2, "dW2 vs the transposed-pack launch", rtol=1e-6, atol_scale=1e-6)
 
 
 @pytest.mark.gpu

@@ -24,7 +24,13 @@ LARGE_SET = "test_vs_reference_golden and LARGE-16"
 SWITCHES = {
     # bf16 channel-MLP kernels.  Default since round 4: the B-direct kernels (W fragments straight into registers).
     # BD=0: the LDS-DMA kernels of rounds 2-3 in their own default selection (two-workgroup kernel, 128 x 192 tiles, pairs)
+    # (DPOT_BF16P_ROWFORM=1, an opt-IN riding along: it only acts on the B-direct pair launch, which BD=0 switches off - so it
+    # gets the DPOT-M case of its own below)
     "DPOT_BF16P_BD=0": (LARGE_SET, False),
+    # round 5 opt-ins that were built and rejected by measurement - kept under the gate: the one-launch AFNO layer BACKWARD and
+    # the weight gradients on ROW-form operands through the transposing LDS read (DPOT-M at batch 32: reference golden, fp32
+    # leg + bf16 leg; DPOT-S at batch 32 runs the one-launch layer forward + backward)
+    "DPOT_AFNO_LAYER_BWD=1 DPOT_BF16P_ROWFORM=1": ("test_vs_reference_golden and (MEDIUM-32 or SMALL-32)", False),
     # not an opt-OUT but the mode `bench.py --config S|M|L|L20` runs: fp32 GEMMs >= 3 GFLOP on the fp32-accurate bf16x6 operand
     # split (`auto`).  The DPOT-L batch-16 reference golden (fp32 path at rtol 1e-4, then the bf16 channel-MLP mode) and the
     # Tiny / M gradient cases against the oracle must hold under it as they do with native fp32 MFMA
@@ -45,8 +51,7 @@ SWITCHES = {
 }
 
 
-@pytest.mark.parametrize("switch", list(SWITCHES))
-def test_parity_subset_under_opt_out_switch(switch):
+def _child_cmd(switch):
     expr, with_model = SWITCHES[switch]
     env = dict(os.environ)
     for kv in switch.split():
@@ -56,9 +61,35 @@ def test_parity_subset_under_opt_out_switch(switch):
     if with_model:
         expr = f"({expr}) or (test_gpu_model and not baseline_configs_forward)"   # (31 s of CPU oracle per child for DPOT-L)
     cmd = [sys.executable, "-m", "pytest", "-x", "-q", "-m", "gpu", "-p", "no:cacheprovider"] + files + ["-k", expr]
-    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=1500)
-    tail = (r.stdout + r.stderr)[-3000:]
-    assert r.returncode == 0, f"{switch}: parity subset failed\n{tail}"
-    last = [ln for ln in r.stdout.splitlines() if " passed" in ln]
+    return cmd, env
+
+
+@pytest.fixture(scope="module")
+def children():
+    """all child pytest processes are started TOGETHER (round 5: the five of them took 230 s of the GPU gate one after the other;
+    most of a child's time is the CPU oracle and process start-up, the GPU work of all of them together is a few seconds) and
+    each parametrised test below waits for its own"""
+    procs = {}
+    for switch in SWITCHES:
+        cmd, env = _child_cmd(switch)
+        env["OMP_NUM_THREADS"] = str(max(4, (os.cpu_count() or 8) // len(SWITCHES)))
+        procs[switch] = subprocess.Popen(cmd, cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    yield procs
+    for p in procs.values():
+        if p.poll() is None:
+            p.kill()
+
+
+@pytest.mark.parametrize("switch", list(SWITCHES))
+def test_parity_subset_under_opt_out_switch(switch, children):
+    p = children[switch]
+    try:
+        out, _ = p.communicate(timeout=1500)
+    except subprocess.TimeoutExpired:
+        p.kill()
+        raise
+    tail = out[-3000:]
+    assert p.returncode == 0, f"{switch}: parity subset failed\n{tail}"
+    last = [ln for ln in out.splitlines() if " passed" in ln]
     assert last and " failed" not in last[-1], tail
     print(f"[{switch}] {last[-1].strip()}")

@@ -143,9 +143,10 @@ def _nrel(a, b):
     return ((a - b).norm() / (b.norm() + 1e-300)).item()
 
 
-@pytest.mark.parametrize("img,B,mlp", [(64, 3, None), (256, 2, None), (256, 2, "bf16")])
+@pytest.mark.parametrize("img,B,mlp", [(64, 3, None), (256, 2, None), (256, 2, "bf16"), (192, 2, None)])
 def test_tiny_at_other_resolutions_vs_oracle(img, B, mlp):
-    """the DPOT-Tiny architecture on the other latent grids of utils/griddataset.py:35 (64^2 -> 8x8 tokens, 256^2 -> 32x32):
+    """the DPOT-Tiny architecture on the other latent grids of utils/griddataset.py:35 (64^2 -> 8x8 tokens, 256^2 -> 32x32; round 5:
+    192^2 -> 24x24, a 3 * 2^k grid: radix-3 register FFTs):
     every gradient vs the CPU oracle.  8x8: the register FFTs for 8-point lines, 64 tokens per sample; 32x32 at 64 channels per
     group: chunked statistics-only GroupNorm with norm1 applied on the load of rfft2 / irfft2 - here in the fp32 mode too -
     and (bf16 channel MLP) norm2 inside the pack pass, at a second shape besides DPOT-L"""
