@@ -203,10 +203,11 @@ def mixer_roofline(model, B: int):
     # HBM traffic per launch from the L2 memory-side counters: collected in separate rocprofv3 --pmc passes
     # (scripts/gpu_pmc.sh -> profiles/r02_pmc_mixer.json; bench.py itself cannot run the profiler).  Units and the
     # gfx950 correction follow MI355X_MICROARCH.md section HBM: bytes = (2 * FETCH_SIZE + WRITE_SIZE) * 1024
-    traffic = None
+    traffic, pmc_file = None, "r05_pmc_mixer.json"
     try:
         pdir = os.path.join(ROOT, "profiles")
-        pmc_file = "r04_pmc_mixer.json" if os.path.exists(os.path.join(pdir, "r04_pmc_mixer.json")) else "r03_pmc_mixer.json"
+        pmc_file = next((f for f in ("r05_pmc_mixer.json", "r04_pmc_mixer.json", "r03_pmc_mixer.json")
+                         if os.path.exists(os.path.join(pdir, f))), "r03_pmc_mixer.json")
         pmc = json.load(open(os.path.join(pdir, pmc_file)))
         traffic = (2.0 * pmc["FETCH_SIZE"]["mean"] + pmc["WRITE_SIZE"]["mean"]) * 1024.0
     except Exception:
@@ -224,7 +225,7 @@ def mixer_roofline(model, B: int):
                        "complex multiplication), i.e. its matrix pipes run at 0.75 x achieved") if three else None,
         "bound": "mfma", "achieved": round(achieved, 2), "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
         "frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": traffic,
-        "traffic_note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, profiles/r04_pmc_mixer.json), "
+        "traffic_note": f"rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, profiles/{pmc_file}), "
                         "(2*FETCH+WRITE)*1024 B; the training form of the launch also stores the pre-activation (saved for "
                         "the backward): 2 spectrum-sized writes instead of the 1 that algorithmic_bytes counts (round 2 also "
                         "stored the activated spectrum: 3 writes, 80.7 MB)",

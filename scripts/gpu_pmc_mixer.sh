@@ -1,6 +1,6 @@
 #!/bin/bash
 # HBM traffic of the fused AFNO mixer kernel (DPOT-Tiny shape, training form) from the L2 memory-side counters:
-# separate --pmc passes with --kernel-trace only (MI355X_MICROARCH.md, HBM section) -> gpurun_out/pmc_mixer_r03.json
+# separate --pmc passes with --kernel-trace only (MI355X_MICROARCH.md, HBM section) -> gpurun_out/r05_pmc_mixer.json
 mkdir -p gpurun_out
 R=$PWD
 cd /tmp && export TMPDIR=/tmp
@@ -21,7 +21,7 @@ for c in ("FETCH_SIZE", "WRITE_SIZE"):
         res[c] = {"kernel": k, "launches": len(v), "mean": sum(v) / len(v), "min": min(v), "max": max(v)}
 res["note"] = ("rocprofv3 --pmc, one counter per pass; launches = the training form of the DPOT-Tiny mixer (M=4608, nb=4, bs=128) "
                "from scripts/afno_mlp_bench.py tiny-train; bytes = (2*FETCH_SIZE + WRITE_SIZE) * 1024 per MI355X_MICROARCH.md")
-json.dump(res, open("gpurun_out/pmc_mixer_r03.json", "w"), indent=1)
+json.dump(res, open("gpurun_out/r05_pmc_mixer.json", "w"), indent=1)
 print(json.dumps(res, indent=1))
 PY
 rm -rf gpurun_out/pmcm_FETCH_SIZE gpurun_out/pmcm_WRITE_SIZE

@@ -1,0 +1,15 @@
+#!/bin/bash
+# end-of-round records on HEAD: GPU suite, default bench line, rocprofv3 kernel stats of the same bench command, step
+# censuses (T / S / M / L), mixer counters, 2-process gloo dry run of the N > 1 path
+mkdir -p gpurun_out
+( time timeout 1500 python -m pytest tests/ -x -q -m gpu --durations=8 -p no:cacheprovider ) > gpurun_out/r05_final_gpu_tests.txt 2>&1
+tail -16 gpurun_out/r05_final_gpu_tests.txt
+( time timeout 600 python bench.py ) > gpurun_out/r05_final_bench.json 2> gpurun_out/r05_final_bench.err
+tail -c 600 gpurun_out/r05_final_bench.json; tail -4 gpurun_out/r05_final_bench.err
+bash scripts/gpu_prof.sh r05prof --no-other-configs --no-alt --no-pipeline > /dev/null 2>&1; mv gpurun_out/r05prof.stats.txt gpurun_out/r05_final_bench_kernel_stats.txt; rm -f gpurun_out/r05prof.seq.txt; head -14 gpurun_out/r05_final_bench_kernel_stats.txt
+bash scripts/gpu_census.sh > /dev/null 2>&1; mv gpurun_out/census.txt gpurun_out/r05_final_census_T.txt
+for c in S M; do bash scripts/gpu_census_M.sh $c bf16 > /dev/null 2>&1; mv gpurun_out/census$c.txt gpurun_out/r05_final_census_$c.txt; done
+CENSUS_BATCH=16 bash scripts/gpu_census_M.sh L bf16 > /dev/null 2>&1; mv gpurun_out/censusL.txt gpurun_out/r05_final_census_L.txt
+head -12 gpurun_out/r05_final_census_M.txt
+bash scripts/gpu_pmc_mixer.sh > gpurun_out/r05_pmc_mixer.log 2>&1; tail -12 gpurun_out/r05_pmc_mixer.log
+DPOT_BENCH_DEBUG_GLOO=1 timeout 600 python bench.py --gpus 2 --steps 5 --warmup 2 > gpurun_out/r05_final_gloo2_T.json 2> gpurun_out/r05_final_gloo2_T.err; tail -c 900 gpurun_out/r05_final_gloo2_T.json; tail -3 gpurun_out/r05_final_gloo2_T.err

@@ -318,6 +318,33 @@ def test_block_finalize_launch_is_bit_identical(monkeypatch):
         assert torch.equal(a, b)
 
 
+def test_block_finalize_colsum_slice_bf16_mode(monkeypatch):
+    """in the bf16 channel-MLP mode the finalising launch also reduces the bias column sums (df1b, df2b), in a
+    different order than the stand-alone colsum kernel - so DPOT_BLOCK_FINALIZE=1 / 0 agree to fp32 rounding there, not bit for
+    bit (the fp32 model above is bit-identical): every gradient within 1e-6 norm-wise, the two bias gradients included"""
+    from dpot_amd import DPOTNet
+    cfg = R.DPOTConfig(**R.SMALL)
+    S = cfg.img_size
+    x = R.recipe_input((4, S, S, cfg.in_timesteps, cfg.in_channels), salt=71).cuda()
+    up = (R.recipe_input((4, S, S, cfg.out_timesteps, cfg.out_channels), salt=72) * 0.3).cuda()
+
+    def grads(flag):
+        monkeypatch.setenv("DPOT_BLOCK_FINALIZE", flag)
+        m = DPOTNet(**R.SMALL)
+        m.load_state_dict(_recipe_sd("SMALL", 4))
+        m.cuda()
+        m.mlp_precision = "bf16"
+        xg = x.clone().requires_grad_(True)
+        y, _ = m(xg)
+        (y * up).sum().backward()
+        return {"dx": xg.grad, **{k: p.grad for k, p in m.named_parameters() if not k.startswith("cls_head.")}}
+
+    a, b = grads("1"), grads("0")
+    for k in a:
+        assert _nrel(a[k], b[k]) <= 1e-6, k
+    assert any(k.endswith("mlp.0.bias") for k in a)
+
+
 def test_layout_jobs_launch_is_bit_identical(monkeypatch):
     """round 4: the small weight-only layout pieces (padded conv weights, pos_embed^T + bias, de-embed bias per pixel, padded
     tail weights) come from ONE launch over a device-resident job table (csrc/misc.hip layout_jobs_kernel) instead of eight
