@@ -92,7 +92,7 @@ SIGNATURES = {
     "dpot_groupnorm_bwd": (c_i, [c_fp] * 11 + [c_i] * 4 + [c_fp]),
     "dpot_groupnorm_param_grads": (c_i, [C.c_void_p] * 3 + [c_i] * 3 + [c_fp]),
     "dpot_afno_fused_supported": (c_i, [c_i] * 7),
-    "dpot_afno_fused_fwd": (c_i, [c_fp] * 17 + [c_i] * 9 + [c_f, c_fp]),
+    "dpot_afno_fused_fwd": (c_i, [c_fp] * 19 + [c_i] * 9 + [c_f, c_fp]),
     "dpot_afno_fused_bwd": (c_i, [c_fp] * 19 + [c_i] * 9 + [c_fp]),
     "dpot_gn_dft_supported": (c_i, [c_i] * 4),
     "dpot_gn_rfft2": (c_i, [c_fp] * 6 + [c_i] * 8 + [c_f, c_fp]),

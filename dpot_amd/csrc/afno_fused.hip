@@ -54,6 +54,11 @@ struct AfnoFusedArgs {
   float* rstd1;
   float* mean2;         // [B, G] (with g2)
   float* rstd2;
+  // optional (with g2; round 5): GroupNorm2(y1) as the two bf16 operand packs of the channel MLP (csrc/gemm_bf16p.hip) -
+  // xp: row form [B*256 / 32][E / 16][64 chunks][8] (A operand of fc1), xpT: transposed form [E / 32][B*256 / 16][64][8]
+  // (operand of the fc1 weight gradient) - what dpot_bf16_pack_both_norm(y1, statistics) would write, bit for bit
+  uint4* xp;
+  uint4* xpT;
   int B, E, G, nb, act;
   float eps;
 };
@@ -76,6 +81,13 @@ __device__ __forceinline__ void xchg16(float v, float& lo, float& hi) {
   hi = __uint_as_float(r[1]);
 }
 
+__device__ __forceinline__ unsigned af_pack2(float lo, float hi) {   // v_cvt_pk_bf16_f32, round to nearest even
+  typedef float f32x2_t __attribute__((ext_vector_type(2)));
+  typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+  const f32x2_t v = {lo, hi};
+  return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2_t));
+}
+
 // 4-point DFT in place, SGN = -1 forward / +1 inverse: out[k] = sum_n in[n] e^{SGN 2 pi i n k / 4}
 template <int SGN>
 __device__ __forceinline__ void dft4(float (&r)[4], float (&i)[4]) {
@@ -93,7 +105,9 @@ __device__ __forceinline__ void dft4(float (&r)[4], float (&i)[4]) {
   i[3] = a1i - s * a3r;
 }
 
-template <int CG, int ACTK>
+// PK: also emit GroupNorm2's output as the channel MLP's bf16 operand packs (a separate instantiation: the extra live values cost
+// the plain form 4 spilled registers and ~2 us)
+template <int CG, int ACTK, bool PK>
 __global__ __launch_bounds__(64 * AF_NW) void afno_fused_fwd_kernel(const AfnoFusedArgs p) {
   __shared__ __attribute__((aligned(16))) float lds[AF_AREG + 128];
   float* const A = lds;                                          // operand region
@@ -468,6 +482,48 @@ __global__ __launch_bounds__(64 * AF_NW) void afno_fused_fwd_kernel(const AfnoFu
       if (p.y1) p.y1[obase + o] = yv[k1][y];
       if (p.g2 && p.xn2) p.xn2[obase + o] = fmaf(yv[k1][y] - mu2, a2, c2);
     }
+  if constexpr (PK) {
+  if (p.g2 && (p.xp || p.xpT)) {
+    // GroupNorm2(y1) straight into the bf16 operand packs of the channel MLP (the separate pack pass re-read y1: one launch
+    // and one field-sized read per block less).  Same expression as bf16_pack_both_kernel: fmaf(v - mean, rstd * gamma, beta).
+    const int Mtok = p.B * (AF_H * AF_W);
+    unsigned short* const Aw = reinterpret_cast<unsigned short*>(A) + wave * (AF_H * AF_W * 16);   // [token][16 channels] bf16
+    // (the operand region is free: the GroupNorm2 barrier above came after every wave's last fragment read)
+#pragma unroll
+    for (int k1 = 0; k1 < 4; ++k1) {
+      const int xr = 4 * k1 + q;
+      unsigned w[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j)
+        w[j] = af_pack2(fmaf(yv[k1][2 * j] - mu2, a2, c2), fmaf(yv[k1][2 * j + 1] - mu2, a2, c2));
+      if (p.xpT) {
+        // transposed form: chunk = (feature, 8 consecutive tokens) - the lane's 16 values of a row are two chunks
+        uint4* tp = p.xpT + ((long long)(ch >> 5) * (Mtok >> 4) + b * AF_H + xr) * 64 + (ch & 31);
+        tp[0] = make_uint4(w[0], w[1], w[2], w[3]);
+        tp[32] = make_uint4(w[4], w[5], w[6], w[7]);
+      }
+      if (p.xp) {
+#pragma unroll
+        for (int y = 0; y < AF_W; ++y)
+          Aw[(xr * AF_W + y) * 16 + c] = (unsigned short)((y & 1) ? (w[y >> 1] >> 16) : (w[y >> 1] & 0xffffu));
+      }
+    }
+    if (p.xp) {
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      // row form: chunk = (token, 8 consecutive features); this wave's 16 channels are feature block kblk * 8 + wave
+      const int fblk = kblk * (AF_BS / 16) + wave;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const int id = i * 64 + lane, t = id >> 1, h = id & 1;
+        const uint4 v = *reinterpret_cast<const uint4*>(Aw + t * 16 + h * 8);
+        const int T = b * (AF_H * AF_W) + t;
+        p.xp[((long long)(T >> 5) * (E >> 4) + fblk) * 64 + (T & 31) + 32 * h] = v;
+      }
+    }
+  }
+  }
 #ifdef AF_TIMING
   AF_STAMP();                                                    // 9: stores issued
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -915,10 +971,14 @@ static int launch_fused_bwd(const AfnoFusedBwdArgs& p, hipStream_t s) {
 template <int CG>
 static int launch_fused(const AfnoFusedArgs& p, hipStream_t s) {
   const dim3 grid((unsigned)(p.B * p.nb)), blk(64 * AF_NW);
-  if (p.act == DPOT_ACT_GELU)
-    hipLaunchKernelGGL((afno_fused_fwd_kernel<CG, DPOT_ACT_GELU>), grid, blk, 0, s, p);
-  else
-    hipLaunchKernelGGL((afno_fused_fwd_kernel<CG, -1>), grid, blk, 0, s, p);
+  const bool pk = p.xp || p.xpT;
+  if (p.act == DPOT_ACT_GELU) {
+    if (pk) hipLaunchKernelGGL((afno_fused_fwd_kernel<CG, DPOT_ACT_GELU, true>), grid, blk, 0, s, p);
+    else hipLaunchKernelGGL((afno_fused_fwd_kernel<CG, DPOT_ACT_GELU, false>), grid, blk, 0, s, p);
+  } else {
+    if (pk) hipLaunchKernelGGL((afno_fused_fwd_kernel<CG, -1, true>), grid, blk, 0, s, p);
+    else hipLaunchKernelGGL((afno_fused_fwd_kernel<CG, -1, false>), grid, blk, 0, s, p);
+  }
   return check_launch("afno_fused_fwd_kernel");
 }
 
@@ -937,12 +997,15 @@ extern "C" int dpot_afno_fused_supported(int h, int w, int E, int G, int nb, int
 extern "C" int dpot_afno_fused_fwd(const float* x, const float* gamma1, const float* beta1, const float* Wa,
                                    const float* ba, const float* Wb, const float* bb, const float* gamma2,
                                    const float* beta2, float* S, float* pre, float* y1, float* xn2, float* mean1,
-                                   float* rstd1, float* mean2, float* rstd2, int B, int h, int w, int E, int G, int nb,
-                                   int mx, int my, int act, float eps, dpot_stream_t stream) {
+                                   float* rstd1, float* mean2, float* rstd2, void* xn2_rows_bf16, void* xn2_trans_bf16,
+                                   int B, int h, int w, int E, int G, int nb, int mx, int my, int act, float eps,
+                                   dpot_stream_t stream) {
   const bool norm = gamma1 || gamma2;
   DPOT_REQUIRE(dpot_afno_fused_supported(h, w, E, norm ? G : 0, nb, mx, my),
                "afno_fused_fwd: needs a 16x16 latent grid, 128 channels per block, all modes kept, 64 or 128 channels per group");
-  DPOT_REQUIRE(x && Wa && Wb && (y1 || xn2) && B > 0, "afno_fused_fwd: bad argument");
+  DPOT_REQUIRE(x && Wa && Wb && (y1 || xn2 || xn2_rows_bf16) && B > 0, "afno_fused_fwd: bad argument");
+  DPOT_REQUIRE(!(xn2_rows_bf16 || xn2_trans_bf16) || (gamma2 && E % 32 == 0 && aligned16(xn2_rows_bf16) && aligned16(xn2_trans_bf16)),
+               "afno_fused_fwd: the bf16 packs are packs of GroupNorm2's output (gamma2), E %% 32 == 0, 16-byte aligned");
   DPOT_REQUIRE(!gamma1 || (beta1 && mean1 && rstd1), "afno_fused_fwd: norm1 needs beta1, mean1, rstd1");
   DPOT_REQUIRE(!gamma2 || (beta2 && mean2 && rstd2), "afno_fused_fwd: norm2 needs beta2, mean2, rstd2");
   DPOT_REQUIRE(gamma2 || y1, "afno_fused_fwd: without norm2 the output is y1");
@@ -951,6 +1014,7 @@ extern "C" int dpot_afno_fused_fwd(const float* x, const float* gamma1, const fl
   AfnoFusedArgs p;
   p.x = x; p.g1 = gamma1; p.b1 = beta1; p.Wa = Wa; p.ba = ba; p.Wb = Wb; p.bb = bb; p.g2 = gamma2; p.b2 = beta2;
   p.S = S; p.pre = pre; p.y1 = y1; p.xn2 = xn2; p.mean1 = mean1; p.rstd1 = rstd1; p.mean2 = mean2; p.rstd2 = rstd2;
+  p.xp = reinterpret_cast<uint4*>(xn2_rows_bf16); p.xpT = reinterpret_cast<uint4*>(xn2_trans_bf16);
   p.B = B; p.E = E; p.G = G; p.nb = nb; p.act = act; p.eps = eps;
   hipStream_t s = as_stream(stream);
   const int cg = norm ? E / G : 128;

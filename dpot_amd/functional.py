@@ -516,13 +516,20 @@ def _block_parts(x, n1w, n1b, n2w, n2b, f1w, f1b, packed, dims, mp, need_out, f2
     onload = os.environ.get("DPOT_GN_ONLOAD", "1") != "0"
     pack_norm = both and onload and tok % 64 == 0 and (E // 8) % 4 == 0
     lay = afno_layout if afno_layout is not None else getattr(packed[0], "layout", 0)
+    fused_xp = None
     if packed[0][2] is not None and ops.afno_fused_supported(h, w, E, nb, mx, my, B=B, layout=lay):
         # the whole AFNO layer - norm1, rfft2, both MLP layers, irfft2, + x_orig, norm2 - in ONE launch (csrc/afno_fused.hip,
         # SURVEY 8 f4): spectrum and hidden layer stay on chip; save=False (nothing will run a backward on these
         # intermediates: inference, or a forward whose Block recomputes): S / O1pre are not even written
-        S, O1pre, y1, xn2, mean1, rstd1, mean2, rstd2 = ops.afno_fused_fwd(
+        # (round 5: with the bf16 channel MLP the same launch also writes GroupNorm2(y1) as the two bf16 operand packs -
+        # DPOT_AFNO_LAYER_PACKS=0: the separate pack pass over y1 instead)
+        fused_packs = pack_norm and os.environ.get("DPOT_AFNO_LAYER_PACKS", "1") != "0"
+        res = ops.afno_fused_fwd(
             x, n1w, n1b, packed[0][2], packed[0][1], packed[1][2], packed[1][1], n2w, n2b, h, w, nb, mx, my, act, save=save,
-            want_y1=save or pack_norm, want_xn2=not pack_norm)
+            want_y1=save or (pack_norm and not fused_packs), want_xn2=not pack_norm, want_packs=fused_packs,
+            packs_trans=save)
+        S, O1pre, y1, xn2, mean1, rstd1, mean2, rstd2 = res[:8]
+        fused_xp = res[8:] if fused_packs else None
         O1 = None
     elif ops.gn_dft_supported(h, w, E):
         # GroupNorm fused with the neighbouring DFT (csrc/gn_dft.hip): norm1 + rfft2, and irfft2 + x_orig + norm2 -
@@ -551,7 +558,9 @@ def _block_parts(x, n1w, n1b, n2w, n2b, f1w, f1b, packed, dims, mp, need_out, f2
         # plain-bf16 channel MLP, one pack pass per activation: the pass that packs xn2 / Hh as the A operand of the
         # next GEMM also writes the TRANSPOSED pack the weight gradient will need - that (bf16, half the bytes) is what
         # the backward keeps; the fp32 xn2 / Hh are dropped right here
-        if pack_norm:
+        if fused_xp is not None:
+            xp, xpT = fused_xp                      # written by the one-launch AFNO layer itself
+        elif pack_norm:
             xp, xpT, _ = ops.bf16_pack_both(y1.view(M, E), norm=(mean2, rstd2, n2w, n2b, tok))
         else:
             xp, xpT, _ = ops.bf16_pack_both(xn2.view(M, E))

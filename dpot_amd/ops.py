@@ -912,23 +912,36 @@ def afno_fused_supported(h: int, w: int, E: int, nb: int, mx: int, my: int, G: i
 
 def afno_fused_fwd(x: Tensor, g1: Optional[Tensor], b1: Optional[Tensor], WaT: Tensor, ba: Tensor, WbT: Tensor, bb: Tensor,
                    g2: Optional[Tensor], b2: Optional[Tensor], h: int, w: int, nb: int, mx: int, my: int, act: int,
-                   G: int = 8, eps: float = 1e-5, save: bool = True, want_y1: bool = True, want_xn2: bool = True):
+                   G: int = 8, eps: float = 1e-5, save: bool = True, want_y1: bool = True, want_xn2: bool = True,
+                   want_packs: bool = False, packs_trans: bool = True):
     """[GroupNorm1] -> rfft2 -> 2-layer complex MLP -> irfft2 + x_orig -> [GroupNorm2] in ONE launch (csrc/afno_fused.hip).
     Returns (S, O1pre, y1, xn2, mean1, rstd1, mean2, rstd2) - the tensors gn_rfft2 / afno_mlp2 / irfft2_gn return, same
-    layouts; save=False (inference): S = O1pre = None; entries that do not apply are None"""
+    layouts; save=False (inference): S = O1pre = None; entries that do not apply are None.
+    want_packs (with g2): two more entries (xp, xpT) = GroupNorm2(y1) as the bf16 operand packs of the channel MLP (what
+    bf16_pack_both(y1, norm=...) returns), written by the same launch; packs_trans=False: xpT = None (inference: only the
+    weight gradient reads the transposed form)"""
     B, tok, E = x.shape
     dev = x.device
     Mm = B * mx * my
     S = torch.empty(Mm, 2 * E, dtype=torch.float32, device=dev) if save else None
     pre = torch.empty(Mm, 2 * E, dtype=torch.float32, device=dev) if save else None
     want_xn2 = want_xn2 and g2 is not None
-    y1 = torch.empty_like(x) if (want_y1 or not want_xn2) else None
+    want_packs = want_packs and g2 is not None
+    y1 = torch.empty_like(x) if (want_y1 or not (want_xn2 or want_packs)) else None
     xn2 = torch.empty_like(x) if want_xn2 else None
     st = [torch.empty(B, G, dtype=torch.float32, device=dev) if g is not None else None for g in (g1, g1, g2, g2)]
-    check(_lib.load().dpot_afno_fused_fwd(x.data_ptr(), _p(g1), _p(b1), WaT.data_ptr(), _p(ba), WbT.data_ptr(), _p(bb),
-                                          _p(g2), _p(b2), _p(S), _p(pre), _p(y1), _p(xn2), _p(st[0]), _p(st[1]),
-                                          _p(st[2]), _p(st[3]), B, h, w, E, G, nb, mx, my, act, eps, _stream()),
+    lib = _lib.load()
+    xp = xpT = None
+    if want_packs:
+        n = lib.dpot_bf16_packed_elems(B * tok, E, 1)
+        xp = torch.empty(n, dtype=torch.bfloat16, device=dev)
+        xpT = torch.empty(lib.dpot_bf16_packed_elems(E, B * tok, 1), dtype=torch.bfloat16, device=dev) if packs_trans else None
+    check(lib.dpot_afno_fused_fwd(x.data_ptr(), _p(g1), _p(b1), WaT.data_ptr(), _p(ba), WbT.data_ptr(), _p(bb),
+                                  _p(g2), _p(b2), _p(S), _p(pre), _p(y1), _p(xn2), _p(st[0]), _p(st[1]),
+                                  _p(st[2]), _p(st[3]), _p(xp), _p(xpT), B, h, w, E, G, nb, mx, my, act, eps, _stream()),
           "afno_fused_fwd")
+    if want_packs:
+        return S, pre, y1, xn2, st[0], st[1], st[2], st[3], xp, xpT
     return S, pre, y1, xn2, st[0], st[1], st[2], st[3]
 
 

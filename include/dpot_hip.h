@@ -289,13 +289,16 @@ int dpot_irfft2_gn_bwd(const float* spec, const float* res, const float* xin, co
  * bbig rows of dpot_afno_pack_all.  Outputs, each in the layout of the three-launch path: S = the spectrum and pre = the
  * layer-1 pre-activation [B*144, 2E] (saved for the backward; both may be NULL: inference), y1 = irfft2(..) + GN1(x),
  * xn2 = GN2(y1) (either may be NULL), statistics [B, G].  gamma1 == NULL: no norm1 (x_orig = x: the reference's AFNO2D
- * module alone); gamma2 == NULL: no norm2 (y1 only).
+ * module alone); gamma2 == NULL: no norm2 (y1 only).  xn2_rows_bf16 / xn2_trans_bf16 (optional, with gamma2): GroupNorm2(y1) as
+ * the two 1-plane bf16 operand packs of the channel MLP - exactly what dpot_bf16_pack_both_norm(y1, mean2, rstd2, ...) writes
+ * (dpot_bf16_packed_elems(B*256, E, 1) elements each), so that pack launch and its re-read of y1 disappear.
  * ------------------------------------------------------------------------------------------------ */
 int dpot_afno_fused_supported(int h, int w, int E, int G, int nb, int mx, int my);
 int dpot_afno_fused_fwd(const float* x, const float* gamma1, const float* beta1, const float* Wa, const float* ba,
                         const float* Wb, const float* bb, const float* gamma2, const float* beta2, float* S, float* pre,
-                        float* y1, float* xn2, float* mean1, float* rstd1, float* mean2, float* rstd2, int B, int h, int w,
-                        int E, int G, int nb, int mx, int my, int act, float eps, dpot_stream_t stream);
+                        float* y1, float* xn2, float* mean1, float* rstd1, float* mean2, float* rstd2, void* xn2_rows_bf16,
+                        void* xn2_trans_bf16, int B, int h, int w, int E, int G, int nb, int mx, int my, int act, float eps,
+                        dpot_stream_t stream);
 /* The BACKWARD of the same layer in one launch (replaces dpot_gn_bwd_rfft2 + dpot_afno_mlp2(mode 1) + dpot_irfft2 +
  * dpot_groupnorm_bwd; autograd of models/dpot.py:59-102, :165-175):
  *   dy1 = GroupNorm2-backward(dxn2; y1, mean2, rstd2, gamma2),  dO2 = adjoint-irfft2(dy1),

@@ -1443,6 +1443,15 @@ def test_afno_layer_one_launch_vs_three_launches(ops, monkeypatch, E, nb, B, nor
     assert_close(y1, yref, "y1 vs float64")
     if norm:
         assert_close(xn2, gn(yref, g2, b2), "xn2 vs float64")
+        # the same launch writing GroupNorm2(y1) as the channel MLP's two bf16 operand packs == the separate pack pass over y1
+        res = ops.afno_fused_fwd(x, g1, b1, packed[0][2], packed[0][1], packed[1][2], packed[1][1], g2, b2, h, h, nb, mx, my, a,
+                                 save=save, want_xn2=False, want_packs=True)
+        # (a separate instantiation of the kernel: same arithmetic, the compiler's FMA contraction may differ in the last bit)
+        assert_close(res[2], y1, "y1 of the pack-emitting instantiation", rtol=1e-6, atol_scale=1e-6)
+        assert res[3] is None
+        xp3, xpT3, _ = ops.bf16_pack_both(res[2].view(B * h * h, E), norm=(res[6], res[7], g2, b2, h * h))
+        assert torch.equal(res[8].view(torch.int16), xp3.view(torch.int16)), "row-form pack of GroupNorm2(y1)"
+        assert torch.equal(res[9].view(torch.int16), xpT3.view(torch.int16)), "transposed pack of GroupNorm2(y1)"
 
 
 @pytest.mark.parametrize("E,nb,B,norm,act,add", [(512, 4, 3, True, "gelu", True), (1024, 8, 2, True, "gelu", True),

@@ -2,6 +2,7 @@
 the CPU oracle, and the configs[4] workload - a 20-step auto-regressive DPOT-Large rollout train step - with and
 without activation recomputation.  (The toy-size golden tests live in test_gpu_model.py.)"""
 import functools
+import os
 from collections import OrderedDict
 
 import pytest
@@ -545,6 +546,9 @@ def test_vs_reference_golden(name, B):
             ops.set_mlp_precision(None)
         return y.detach(), c.detach(), xg.grad, OrderedDict((k, p.grad) for k, p in m.named_parameters())
 
+    if name in ("SMALL", "MEDIUM") and os.environ.get("DPOT_AFNO_LAYER", "auto") == "auto":
+        # these two cases are the parity gate of the one-launch AFNO layer forward in its `auto` selection (256 workgroups)
+        assert ops.afno_fused_supported(16, 16, cfg.embed_dim, cfg.n_blocks, 16, 9, B=B), "one-launch AFNO layer not selected"
     y, c, dx, grads = run(None)
     assert_sub(y, fx, "y", f"{name} B={B} pred")
     assert_close(c, fx["c"], f"{name} B={B} cls")
