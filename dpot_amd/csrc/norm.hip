@@ -287,13 +287,31 @@ __global__ __launch_bounds__(GN_THREADS) void groupnorm_fwd_cached_kernel(const 
   }
 }
 
-template <int ITEMS>
+// PK (round 5; 128 channels per group, T % 32 == 0): the kernel ALSO writes dx - the gradient that enters the previous block's
+// channel-MLP backward - as that backward's bf16 operands: the row-form pack (A operand of the fc2 data gradient), the
+// transposed pack (operand of the fc2 weight gradient) and its per-sample column sums (bias gradient), i.e. what
+// dpot_bf16_pack_both(dx, column sums) would produce from a second pass over dx.  An item of the thread grid = 32 tokens x 128
+// channels = one row tile of the pack: staged as bf16 in LDS, written out as eight whole 1 KiB blocks per form.
+struct GnBwdPacks {
+  uint4* rows;          // [B*T / 32][E / 16][64 chunks][8 bf16]
+  uint4* trans;         // [E / 32][B*T / 16][64 chunks][8 bf16]
+  float* colsum;        // [B, E]: sum over the sample's tokens
+};
+__device__ __forceinline__ unsigned gn_pack2(float lo, float hi) {     // v_cvt_pk_bf16_f32, round to nearest even
+  typedef float f32x2_t __attribute__((ext_vector_type(2)));
+  typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+  const f32x2_t v = {lo, hi};
+  return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2_t));
+}
+
+template <int ITEMS, bool PK>
 __global__ __launch_bounds__(GN_THREADS) void groupnorm_bwd_cached_kernel(
     const float* __restrict__ dy, const float* __restrict__ x, const float* __restrict__ mean,
     const float* __restrict__ rstd, const float* __restrict__ gamma, const float* __restrict__ add,
-    float* __restrict__ dx, float* __restrict__ part, int B, int T, int E, int G) {
+    float* __restrict__ dx, float* __restrict__ part, int B, int T, int E, int G, const GnBwdPacks pk) {
   __shared__ float red[2][GN_THREADS][4];
   __shared__ double shd[32];
+  __shared__ __attribute__((aligned(16))) unsigned short tile[PK ? 32 * 128 : 8];   // [32 tokens][128 channels] bf16
   const int g = blockIdx.x, b = blockIdx.y;
   const int cg = E / G, TJ = cg / 4, TT = GN_THREADS / TJ;
   const int tj = threadIdx.x % TJ, tt = threadIdx.x / TJ;
@@ -340,18 +358,56 @@ __global__ __launch_bounds__(GN_THREADS) void groupnorm_bwd_cached_kernel(
   const float m1 = (float)(s1 / n);
   const float m2 = (float)(s2 / n);
   const float4 ga = *reinterpret_cast<const float4*>(gamma + g * cg + tj * 4);
+  float cs[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
   for (int i = 0; i < ITEMS; ++i) {
     const int t = tt + i * TT;
+    float4 r = make_float4(0.f, 0.f, 0.f, 0.f);
     if (t < T) {
       const long long o = off + (long long)t * E;
-      float4 r = make_float4(rs * (ga.x * d[i].x - m1 - xh[i].x * m2), rs * (ga.y * d[i].y - m1 - xh[i].y * m2),
-                             rs * (ga.z * d[i].z - m1 - xh[i].z * m2), rs * (ga.w * d[i].w - m1 - xh[i].w * m2));
+      r = make_float4(rs * (ga.x * d[i].x - m1 - xh[i].x * m2), rs * (ga.y * d[i].y - m1 - xh[i].y * m2),
+                      rs * (ga.z * d[i].z - m1 - xh[i].z * m2), rs * (ga.w * d[i].w - m1 - xh[i].w * m2));
       if (add) {
         const float4 a = *reinterpret_cast<const float4*>(add + o);
         r.x += a.x; r.y += a.y; r.z += a.z; r.w += a.w;
       }
       *reinterpret_cast<float4*>(dx + o) = r;
+    }
+    if constexpr (PK) {
+      // host-checked: cg == 128 (TJ = TT = 32: item i = tokens 32 i .. 32 i + 31 of the sample = row tile b * T / 32 + i), T % 32 == 0
+      if (32 * i < T) {
+        cs[0] += r.x; cs[1] += r.y; cs[2] += r.z; cs[3] += r.w;
+        *reinterpret_cast<uint2*>(&tile[tt * 128 + 4 * tj]) = make_uint2(gn_pack2(r.x, r.y), gn_pack2(r.z, r.w));
+        __syncthreads();
+        const int tid = threadIdx.x;
+        if (tid < 512) {
+          // row form: block fb (16 features) of this row tile, chunk l = (token l & 31, features 8 (l >> 5) .. + 7)
+          const int fb = tid >> 6, l = tid & 63;
+          const uint4 v = *reinterpret_cast<const uint4*>(&tile[(l & 31) * 128 + 16 * fb + 8 * (l >> 5)]);
+          pk.rows[((long long)(b * (T >> 5) + i) * (E >> 4) + g * 8 + fb) * 64 + l] = v;
+        } else {
+          // transposed form: block (feature tile ft, token block tb), chunk l = (feature l & 31, tokens 8 (l >> 5) .. + 7)
+          const int c2 = tid - 512, bt = c2 >> 6, l = c2 & 63, ft = bt >> 1, tb = bt & 1;
+          const unsigned short* src = &tile[(16 * tb + 8 * (l >> 5)) * 128 + 32 * ft + (l & 31)];
+          unsigned w[4];
+#pragma unroll
+          for (int j = 0; j < 4; ++j) w[j] = (unsigned)src[(2 * j) * 128] | ((unsigned)src[(2 * j + 1) * 128] << 16);
+          pk.trans[((long long)(g * 4 + ft) * (((long long)B * T) >> 4) + b * (T >> 4) + 2 * i + tb) * 64 + l] =
+              make_uint4(w[0], w[1], w[2], w[3]);
+        }
+        __syncthreads();
+      }
+    }
+  }
+  if constexpr (PK) {
+    // column sums of dx over the sample's tokens: the token lanes of a channel quad through `red`, fixed order
+#pragma unroll
+    for (int k = 0; k < 4; ++k) red[0][threadIdx.x][k] = cs[k];
+    __syncthreads();
+    if (tt < 4) {
+      float sacc = 0.f;
+      for (int r = 0; r < TT; ++r) sacc += red[0][r * TJ + tj][tt];
+      pk.colsum[(long long)b * E + g * cg + tj * 4 + tt] = sacc;
     }
   }
 }
@@ -637,11 +693,11 @@ extern "C" int dpot_groupnorm_bwd(const float* dy, const float* x, const float* 
     hipLaunchKernelGGL(gn_chunk_bwd_apply_kernel, grid, dim3(GN_THREADS), 0, as_stream(stream), dy, x, mean, rstd, gamma, add,
                        dx, part, (const float*)workspace, B, T, E, G, ck);
   } else if (items == 4)
-    hipLaunchKernelGGL(groupnorm_bwd_cached_kernel<4>, dim3(G, B), dim3(GN_THREADS), 0, as_stream(stream), dy, x, mean,
-                       rstd, gamma, add, dx, part, B, T, E, G);
+    hipLaunchKernelGGL((groupnorm_bwd_cached_kernel<4, false>), dim3(G, B), dim3(GN_THREADS), 0, as_stream(stream), dy, x, mean,
+                       rstd, gamma, add, dx, part, B, T, E, G, GnBwdPacks{nullptr, nullptr, nullptr});
   else if (items == 8)
-    hipLaunchKernelGGL(groupnorm_bwd_cached_kernel<8>, dim3(G, B), dim3(GN_THREADS), 0, as_stream(stream), dy, x, mean,
-                       rstd, gamma, add, dx, part, B, T, E, G);
+    hipLaunchKernelGGL((groupnorm_bwd_cached_kernel<8, false>), dim3(G, B), dim3(GN_THREADS), 0, as_stream(stream), dy, x, mean,
+                       rstd, gamma, add, dx, part, B, T, E, G, GnBwdPacks{nullptr, nullptr, nullptr});
   else if (vec)
     hipLaunchKernelGGL(groupnorm_bwd_kernel<4>, dim3(G, B), dim3(GN_THREADS), 0, as_stream(stream), dy, x, mean, rstd,
                        gamma, add, dx, part, B, T, E, G);
@@ -654,6 +710,34 @@ extern "C" int dpot_groupnorm_bwd(const float* dy, const float* x, const float* 
   jobs.part[0] = part; jobs.dgamma[0] = dgamma; jobs.dbeta[0] = dbeta;
   hipLaunchKernelGGL(groupnorm_param_grad_kernel, dim3(cdiv(E, 64), 1), dim3(256), 0, as_stream(stream), jobs, B, E);
   return check_launch("groupnorm_param_grad_kernel");
+}
+
+// dpot_groupnorm_bwd (partials left for dpot_groupnorm_param_grads / dpot_block_finalize) that ALSO writes dx as the bf16 operand
+// packs + per-sample column sums of the previous block's channel-MLP backward (see groupnorm_bwd_cached_kernel<.., PK>)
+extern "C" int dpot_groupnorm_bwd_packs_supported(int T, int E, int G) {
+  if (T <= 0 || E <= 0 || G <= 0 || E % G || E / G != 128 || T % 32 || E % 32) return 0;
+  const int items = gn_cached_items(T, E, G);
+  return (items == 4 || items == 8) ? 1 : 0;
+}
+extern "C" int dpot_groupnorm_bwd_packs(const float* dy, const float* x, const float* mean, const float* rstd,
+                                        const float* gamma, const float* add, float* dx, float* part, void* dx_rows_bf16,
+                                        void* dx_trans_bf16, float* dx_colsum, int B, int T, int E, int G,
+                                        dpot_stream_t stream) {
+  DPOT_REQUIRE(dy && x && mean && rstd && gamma && dx && part && dx_rows_bf16 && dx_trans_bf16 && dx_colsum,
+               "groupnorm_bwd_packs: null pointer");
+  DPOT_REQUIRE(B > 0 && B <= 65535 && dpot_groupnorm_bwd_packs_supported(T, E, G),
+               "groupnorm_bwd_packs: needs 128 channels per group, T %% 32 == 0 and a slab the cached kernel holds");
+  DPOT_REQUIRE(aligned16(x) && aligned16(dy) && aligned16(dx) && aligned16(gamma) && aligned16(add) && aligned16(dx_rows_bf16) &&
+                   aligned16(dx_trans_bf16),
+               "groupnorm_bwd_packs: pointers must be 16-byte aligned");
+  const GnBwdPacks pk{reinterpret_cast<uint4*>(dx_rows_bf16), reinterpret_cast<uint4*>(dx_trans_bf16), dx_colsum};
+  if (gn_cached_items(T, E, G) == 4)
+    hipLaunchKernelGGL((groupnorm_bwd_cached_kernel<4, true>), dim3(G, B), dim3(GN_THREADS), 0, as_stream(stream), dy, x, mean,
+                       rstd, gamma, add, dx, part, B, T, E, G, pk);
+  else
+    hipLaunchKernelGGL((groupnorm_bwd_cached_kernel<8, true>), dim3(G, B), dim3(GN_THREADS), 0, as_stream(stream), dy, x, mean,
+                       rstd, gamma, add, dx, part, B, T, E, G, pk);
+  return check_launch("groupnorm_bwd_cached_kernel");
 }
 
 extern "C" int dpot_groupnorm_param_grads(const float* const* parts, float* const* dgammas, float* const* dbetas,

@@ -15,6 +15,7 @@ kernels, and the data-parallel reducer is notified the moment a parameter's grad
 from __future__ import annotations
 
 import os
+from collections import OrderedDict
 from typing import Optional
 
 import torch
@@ -598,6 +599,30 @@ def _block_parts(x, n1w, n1b, n2w, n2b, f1w, f1b, packed, dims, mp, need_out, f2
     return out, (mean1, rstd1, S, O1pre, O1, y1, mean2, rstd2, xn2, Hpre, Hh)
 
 
+# The gradient a Block's backward returns (dx) is the `dout` of the PREVIOUS Block's backward, whose bf16 channel MLP first packs
+# it (row form, transposed form, bias column sums: one more pass over it).  Round 5: the GroupNorm1-backward kernel that produces
+# dx writes those packs itself (ops.groupnorm_bwd_packs); they travel beside the autograd gradient in this side table, keyed by
+# the gradient's address.  An entry HOLDS dx, so its memory cannot be handed to another tensor while the entry lives (a stale
+# key can never alias a different gradient); the consumer pops its entry, at most two entries are kept.
+_GRAD_PACKS: "OrderedDict[int, tuple]" = OrderedDict()
+
+
+def _stash_grad_packs(dx: Tensor, dop: Tensor, dopT: Tensor, cs: Tensor) -> None:
+    _GRAD_PACKS[dx.data_ptr()] = (dx, dx._version, dop, dopT, cs)
+    while len(_GRAD_PACKS) > 2:
+        _GRAD_PACKS.popitem(last=False)
+
+
+def _take_grad_packs(do2: Tensor):
+    e = _GRAD_PACKS.pop(do2.data_ptr(), None)
+    if e is None:
+        return None
+    dx, ver, dop, dopT, cs = e
+    if dx.numel() != do2.numel() or dx._version != ver:       # another tensor / modified in place since: pack it afresh
+        return None
+    return dop, dopT, cs
+
+
 class BlockFn(torch.autograd.Function):
     """x[B,tok,E] -> x + MLP(GN2(GN1(x) + irfft2(Mix(rfft2(GN1(x))))))
 
@@ -607,7 +632,8 @@ class BlockFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, n1w, n1b, w1, b1, w2, b2, n2w, n2b, f1w, f1b, f2w, f2b, h: int, w: int, nb: int, modes: int,
-                act: int, packed=None, recompute: bool = False, mlp_pk=None, grad_enabled: bool = True):
+                act: int, packed=None, recompute: bool = False, mlp_pk=None, grad_enabled: bool = True,
+                emit_grad_packs: bool = False):
         x = x.contiguous()
         B, tok, E = x.shape
         bs = E // nb
@@ -632,6 +658,7 @@ class BlockFn(torch.autograd.Function):
         else:
             ctx.save_for_backward(x, *parts, wb1, wb2, n1w, n2w, f1w, f2w)
         ctx.recompute = recompute
+        ctx.emit_grad_packs = emit_grad_packs     # a Block precedes this one: its bf16 channel-MLP backward wants dx packed
         ctx.dims = dims
         ctx.afno_layout = getattr(packed[0], "layout", 0) if ctx.fused_mixer else 0
         ctx.mlp_precision = mp
@@ -691,7 +718,12 @@ class BlockFn(torch.autograd.Function):
             # pack-both path (see _block_parts): xn2 / Hh ARE the transposed bf16 packs; each gradient is packed once, in
             # both forms, and its bias column sums come out of the same pass
             dcs = pending is not None          # bias column sums: partials now, summed by the block's finalising launch
-            dop, dopT, df2b = ops.bf16_pack_both(do2, want_colsum=True, colsum_out=s_f2b.out(), defer_colsum=dcs)
+            taken = _take_grad_packs(do2)
+            if taken is not None:              # packed by the kernel that produced this gradient (the next Block's backward)
+                dop, dopT, cs_b = taken
+                df2b = (cs_b, B, E, ops._out(s_f2b.out(), (E,), dev)) if dcs else ops.colsum(cs_b, B, E, out=s_f2b.out())
+            else:
+                dop, dopT, df2b = ops.bf16_pack_both(do2, want_colsum=True, colsum_out=s_f2b.out(), defer_colsum=dcs)
             # both weight gradients in ONE launch once dHpre's pack exists, when each alone would need split-K
             pair = ops.gemm_bf16p_pair_wanted(E, mh, mh, E, M)
             rowform = _mlp_rowform(M, E, mh)                # Hh is then the hidden layer's ROW-form pack (see _block_parts)
@@ -772,7 +804,13 @@ class BlockFn(torch.autograd.Function):
                 # 128 channels per group (DPOT-S / -M): this pair reads four fields with 4-byte accesses and runs at 64.7 us
                 # against 20.0 + 24.6 us for the separate kernels (profiles/r03_step_census_M_bf16_v1.txt) - not fused
                 dxn1 = ops.irfft2(dS, B, h, w, E, nb, mx, my, 0, res=dy1)
-                dx, gn1_part = ops.groupnorm_bwd(dxn1, x, mean1, rstd1, n1w, add=dout, defer=True)
+                if (ctx.emit_grad_packs and bf16p and xn2.dtype == torch.bfloat16 and ops.groupnorm_bwd_packs_supported(tok, E)
+                        and os.environ.get("DPOT_GRAD_PACKS", "1") != "0"):
+                    # dx goes to the previous Block's bf16 channel-MLP backward: written here in its packed forms as well
+                    dx, gn1_part, gp_r, gp_t, gp_cs = ops.groupnorm_bwd_packs(dxn1, x, mean1, rstd1, n1w, add=dout)
+                    _stash_grad_packs(dx, gp_r, gp_t, gp_cs)
+                else:
+                    dx, gn1_part = ops.groupnorm_bwd(dxn1, x, mean1, rstd1, n1w, add=dout, defer=True)
         else:
             dy1, gn2_part = ops.groupnorm_bwd(dxn2.view(B, tok, E), y1, mean2, rstd2, n2w, defer=True)
             # AFNO mixer
@@ -795,7 +833,7 @@ class BlockFn(torch.autograd.Function):
         dn1w, dn1b = s_n1w.done(dn1w), s_n1b.done(dn1b)
         dn2w, dn2b = s_n2w.done(dn2w), s_n2b.done(dn2b)
         return (dx, dn1w, dn1b, dw1, db1, dw2, db2, dn2w, dn2b, df1w, df1b, df2w, df2b, None, None, None, None, None,
-                None, None, None, None)
+                None, None, None, None, None)
 
 
 # ======================================================================================================

@@ -293,7 +293,7 @@ class DPOTNet(nn.Module):
                                 blk.norm2.bias, blk.mlp[0].weight, blk.mlp[0].bias, blk.mlp[2].weight,
                                 blk.mlp[2].bias, h, h, self.n_blocks, self.modes, self._act,
                                 (pk[2 * i], pk[2 * i + 1]), recompute, mlp_pk[i] if mlp_pk is not None else None,
-                                torch.is_grad_enabled())
+                                torch.is_grad_enabled(), i > 0)
         if hook is not None:
             lat = hook(len(self.blocks) + 1, lat)
         ol, ch = self.out_layer, self.cls_head

@@ -249,6 +249,16 @@ int dpot_groupnorm_fwd(const float* x, const float* gamma, const float* beta, fl
 int dpot_groupnorm_bwd(const float* dy, const float* x, const float* mean, const float* rstd,
                        const float* gamma, const float* add, float* dx, float* dgamma, float* dbeta,
                        float* part /* [2,B,E] */, float* workspace, int B, int T, int E, int G, dpot_stream_t stream);
+/* round 5: the same backward (partials left in `part`) that ALSO writes dx - the gradient entering the previous block's
+ * channel-MLP backward - as that backward's bf16 operands: dx_rows_bf16 / dx_trans_bf16 = the two 1-plane packs
+ * dpot_bf16_pack_both(dx) would write (dpot_bf16_packed_elems(B*T, E, 1) elements each) and dx_colsum [B, E] = the column sums
+ * of dx per sample (bias gradient partials; reduce over B, e.g. as a column-sum job of dpot_block_finalize).  Needs
+ * dpot_groupnorm_bwd_packs_supported: 128 channels per group, T % 32 == 0, T <= 256 (DPOT-S / -M at 128^2). */
+int dpot_groupnorm_bwd_packs_supported(int T, int E, int G);
+int dpot_groupnorm_bwd_packs(const float* dy, const float* x, const float* mean, const float* rstd, const float* gamma,
+                             const float* add, float* dx, float* part /* [2,B,E] */, void* dx_rows_bf16,
+                             void* dx_trans_bf16, float* dx_colsum /* [B,E] */, int B, int T, int E, int G,
+                             dpot_stream_t stream);
 /* dgamma == dbeta == NULL above leaves the per-sample partials in `part`; this reduces up to 4 such partial sets
  * (HOST arrays of njobs pointers; e.g. the two GroupNorm layers of a block) in ONE launch. */
 int dpot_groupnorm_param_grads(const float* const* parts, float* const* dgammas, float* const* dbetas, int njobs,

@@ -346,6 +346,44 @@ def test_block_finalize_colsum_slice_bf16_mode(monkeypatch):
     assert any(k.endswith("mlp.0.bias") for k in a)
 
 
+def test_gradient_packs_between_blocks_are_bit_identical(monkeypatch):
+    """round 5: in the bf16 channel-MLP mode a Block's backward hands its input gradient to the previous Block ALSO as bf16 packs
+    + bias column sums, written by the GroupNorm backward kernel that produces it (functional._GRAD_PACKS side table) instead of
+    a separate pack pass: every gradient must equal the separate-pass form (DPOT_GRAD_PACKS=0) - bit for bit except the fc2 bias
+    gradients, whose column sums are formed per sample instead of per 64 tokens (fp32 rounding) - and the side table must not
+    keep more than two entries"""
+    from dpot_amd import DPOTNet, functional
+    cfg = R.DPOTConfig(**R.SMALL)
+    S = cfg.img_size
+    x = R.recipe_input((4, S, S, cfg.in_timesteps, cfg.in_channels), salt=71).cuda()
+    up = (R.recipe_input((4, S, S, cfg.out_timesteps, cfg.out_channels), salt=72) * 0.3).cuda()
+    taken = []
+    real = functional._take_grad_packs
+    monkeypatch.setattr(functional, "_take_grad_packs", lambda t: (lambda r: (taken.append(r is not None), r)[1])(real(t)))
+
+    def grads(flag):
+        monkeypatch.setenv("DPOT_GRAD_PACKS", flag)
+        taken.clear()
+        m = DPOTNet(**R.SMALL)
+        m.load_state_dict(_recipe_sd("SMALL", 4))
+        m.cuda()
+        m.mlp_precision = "bf16"
+        xg = x.clone().requires_grad_(True)
+        y, _ = m(xg)
+        (y * up).sum().backward()
+        return {"dx": xg.grad, **{k: p.grad for k, p in m.named_parameters() if not k.startswith("cls_head.")}}, list(taken)
+
+    a, ta = grads("1")
+    b, tb = grads("0")
+    assert sum(ta) == cfg.depth - 1 and sum(tb) == 0, (ta, tb)      # every Block but the last one found its packs
+    assert len(functional._GRAD_PACKS) <= 2
+    for k in a:
+        if k.endswith("mlp.2.bias"):
+            assert _nrel(a[k], b[k]) <= 1e-6, k
+        else:
+            assert torch.equal(a[k], b[k]), k
+
+
 def test_layout_jobs_launch_is_bit_identical(monkeypatch):
     """round 4: the small weight-only layout pieces (padded conv weights, pos_embed^T + bias, de-embed bias per pixel, padded
     tail weights) come from ONE launch over a device-resident job table (csrc/misc.hip layout_jobs_kernel) instead of eight
