@@ -91,7 +91,8 @@ SIGNATURES = {
     "dpot_groupnorm_fwd": (c_i, [c_fp] * 7 + [c_i] * 4 + [c_f, c_fp]),
     "dpot_groupnorm_bwd": (c_i, [c_fp] * 11 + [c_i] * 4 + [c_fp]),
     "dpot_groupnorm_bwd_packs_supported": (c_i, [c_i] * 3),
-    "dpot_groupnorm_bwd_packs": (c_i, [c_fp] * 11 + [c_i] * 4 + [c_fp]),
+    "dpot_groupnorm_bwd_packs_rows": (c_i, [c_i] * 4),
+    "dpot_groupnorm_bwd_packs": (c_i, [c_fp] * 12 + [c_i] * 4 + [c_fp]),
     "dpot_groupnorm_param_grads": (c_i, [C.c_void_p] * 3 + [c_i] * 3 + [c_fp]),
     "dpot_afno_fused_supported": (c_i, [c_i] * 7),
     "dpot_afno_fused_fwd": (c_i, [c_fp] * 19 + [c_i] * 9 + [c_f, c_fp]),

@@ -612,6 +612,98 @@ __global__ __launch_bounds__(GN_THREADS) void gn_chunk_bwd_apply_kernel(
   }
 }
 
+// pass B with the gradient packs (round 5, see groupnorm_bwd_cached_kernel<.., PK>): the same dx, written ALSO as the bf16 operand
+// packs + column-sum partials of the previous block's channel-MLP backward.  Few, large slabs (DPOT-L: 1024 tokens x 192 channels
+// per (sample, group), chunks of 256 tokens): the chunk is walked in sub-tiles of 32 tokens = one row tile of the pack, staged in
+// fp32 in LDS ([32][cg]) - the packs leave as whole 1 KiB blocks, the column sums are formed from the staged tile in a fixed order.
+// Host-checked: cg % 32 == 0, cg <= 256, TC % 32 == 0, T % 32 == 0.  colsum: [B * chunks, E] (one row per chunk).
+__global__ __launch_bounds__(GN_THREADS) void gn_chunk_bwd_apply_pk_kernel(
+    const float* __restrict__ dy, const float* __restrict__ x, const float* __restrict__ mean,
+    const float* __restrict__ rstd, const float* __restrict__ gamma, const float* __restrict__ add,
+    float* __restrict__ dx, float* __restrict__ part, const float* __restrict__ ws, int B, int T, int E, int G,
+    GnChunks c, const GnBwdPacks pk) {
+  __shared__ double shd[32];
+  __shared__ __attribute__((aligned(16))) float tile[32 * 256];
+  const int ch = blockIdx.x, g = blockIdx.y, b = blockIdx.z;
+  const int cg = E / G, q4 = cg >> 2;
+  const float mu = mean[b * G + g], rs = rstd[b * G + g];
+  double s1 = 0.0, s2 = 0.0;
+  if ((int)threadIdx.x < cg) {
+    const int col = g * cg + threadIdx.x;
+    float tdx = 0.f, td = 0.f;
+    for (int k = 0; k < c.chunks; ++k) {
+      const float* w = ws + ((long long)b * c.chunks + k) * 2 * E + col;
+      tdx += w[0];
+      td += w[E];
+    }
+    if (ch == 0) {
+      part[((long long)0 * B + b) * E + col] = tdx;
+      part[((long long)1 * B + b) * E + col] = td;
+    }
+    const float gm = gamma[col];
+    s1 = (double)(gm * td);
+    s2 = (double)(gm * tdx);
+  }
+  const double n = (double)T * cg;
+  block_sum2_d(s1, s2, shd);
+  const float m1 = (float)(s1 / n);
+  const float m2 = (float)(s2 / n);
+  const int t0 = ch * c.TC;
+  const int nt = T - t0 < c.TC ? T - t0 : c.TC;
+  const int tid = threadIdx.x;
+  const int nfb = cg >> 4, nft = cg >> 5;                  // 16-feature blocks / 32-feature tiles of the group
+  float csum = 0.f;
+  for (int st = 0; st * 32 < nt; ++st) {
+    const int ts = t0 + 32 * st;                           // first token of the sub-tile (a multiple of 32)
+    const long long off = ((long long)b * T + ts) * E + g * cg;
+    for (unsigned i = tid; i < 32u * (unsigned)q4; i += GN_THREADS) {
+      const unsigned t = i / (unsigned)q4, j = i - t * (unsigned)q4;
+      const long long o = off + (long long)t * E + 4 * j;
+      const float4 d = *reinterpret_cast<const float4*>(dy + o);
+      const float4 v = *reinterpret_cast<const float4*>(x + o);
+      const float4 ga = *reinterpret_cast<const float4*>(gamma + g * cg + 4 * j);
+      float4 r;
+      r.x = rs * (ga.x * d.x - m1 - (v.x - mu) * rs * m2);
+      r.y = rs * (ga.y * d.y - m1 - (v.y - mu) * rs * m2);
+      r.z = rs * (ga.z * d.z - m1 - (v.z - mu) * rs * m2);
+      r.w = rs * (ga.w * d.w - m1 - (v.w - mu) * rs * m2);
+      if (add) {
+        const float4 a4 = *reinterpret_cast<const float4*>(add + o);
+        r.x += a4.x; r.y += a4.y; r.z += a4.z; r.w += a4.w;
+      }
+      *reinterpret_cast<float4*>(dx + o) = r;
+      *reinterpret_cast<float4*>(&tile[t * cg + 4 * j]) = r;
+    }
+    __syncthreads();
+    const long long rt = ((long long)b * T + ts) >> 5;     // row tile of the pack
+    for (int cidx = tid; cidx < nfb * 64; cidx += GN_THREADS) {
+      // row form: block fb, chunk l = (token l & 31, features 8 (l >> 5) .. + 7)
+      const int fb = cidx >> 6, l = cidx & 63;
+      const float* sp = &tile[(l & 31) * cg + 16 * fb + 8 * (l >> 5)];
+      const float4 a0 = *reinterpret_cast<const float4*>(sp), a1 = *reinterpret_cast<const float4*>(sp + 4);
+      pk.rows[(rt * (E >> 4) + (g * cg >> 4) + fb) * 64 + l] =
+          make_uint4(gn_pack2(a0.x, a0.y), gn_pack2(a0.z, a0.w), gn_pack2(a1.x, a1.y), gn_pack2(a1.z, a1.w));
+    }
+    for (int cidx = tid; cidx < nft * 128; cidx += GN_THREADS) {
+      // transposed form: block (feature tile ft, token block tb), chunk l = (feature l & 31, tokens 8 (l >> 5) .. + 7)
+      const int bt = cidx >> 6, l = cidx & 63, ft = bt >> 1, tb = bt & 1;
+      const float* sp = &tile[(16 * tb + 8 * (l >> 5)) * cg + 32 * ft + (l & 31)];
+      unsigned w[4];
+#pragma unroll
+      for (int jj = 0; jj < 4; ++jj) w[jj] = gn_pack2(sp[(2 * jj) * cg], sp[(2 * jj + 1) * cg]);
+      pk.trans[((long long)((g * cg >> 5) + ft) * (((long long)B * T) >> 4) + (((long long)b * T + ts) >> 4) + tb) * 64 + l] =
+          make_uint4(w[0], w[1], w[2], w[3]);
+    }
+    if (tid < cg) {                                        // column sums of the sub-tile, tokens ascending
+      float a = 0.f;
+      for (int t = 0; t < 32; ++t) a += tile[t * cg + tid];
+      csum += a;
+    }
+    __syncthreads();
+  }
+  if (tid < cg) pk.colsum[((long long)b * c.chunks + ch) * E + g * cg + tid] = csum;
+}
+
 // chunking of a slab, or {0, 0} when the one-workgroup-per-slab kernels are the right ones
 static GnChunks gn_chunking(int B, int T, int E, int G) {
   static const int enabled = [] { const char* e = getenv("DPOT_GN_CHUNKED"); return e ? atoi(e) : 1; }();
@@ -714,6 +806,17 @@ extern "C" int dpot_groupnorm_bwd(const float* dy, const float* x, const float* 
 
 // dpot_groupnorm_bwd (partials left for dpot_groupnorm_param_grads / dpot_block_finalize) that ALSO writes dx as the bf16 operand
 // packs + per-sample column sums of the previous block's channel-MLP backward (see groupnorm_bwd_cached_kernel<.., PK>)
+// (returns the number of column-sum partial ROWS per sample the call writes: 1 for the one-workgroup-per-slab kernel, the number
+// of chunks for the chunked one; 0 = not supported)
+extern "C" int dpot_groupnorm_bwd_packs_rows(int B, int T, int E, int G) {
+  if (B <= 0 || T <= 0 || E <= 0 || G <= 0 || E % G || T % 32 || E % 32) return 0;
+  const int cg = E / G;
+  const int items = gn_cached_items(T, E, G);
+  if (cg == 128 && (items == 4 || items == 8)) return 1;
+  const GnChunks ck = gn_chunking(B, T, E, G);
+  if (ck.chunks && cg % 32 == 0 && cg <= 256 && ck.TC % 32 == 0) return ck.chunks;
+  return 0;
+}
 extern "C" int dpot_groupnorm_bwd_packs_supported(int T, int E, int G) {
   if (T <= 0 || E <= 0 || G <= 0 || E % G || E / G != 128 || T % 32 || E % 32) return 0;
   const int items = gn_cached_items(T, E, G);
@@ -721,23 +824,37 @@ extern "C" int dpot_groupnorm_bwd_packs_supported(int T, int E, int G) {
 }
 extern "C" int dpot_groupnorm_bwd_packs(const float* dy, const float* x, const float* mean, const float* rstd,
                                         const float* gamma, const float* add, float* dx, float* part, void* dx_rows_bf16,
-                                        void* dx_trans_bf16, float* dx_colsum, int B, int T, int E, int G,
+                                        void* dx_trans_bf16, float* dx_colsum, float* workspace, int B, int T, int E, int G,
                                         dpot_stream_t stream) {
   DPOT_REQUIRE(dy && x && mean && rstd && gamma && dx && part && dx_rows_bf16 && dx_trans_bf16 && dx_colsum,
                "groupnorm_bwd_packs: null pointer");
-  DPOT_REQUIRE(B > 0 && B <= 65535 && dpot_groupnorm_bwd_packs_supported(T, E, G),
-               "groupnorm_bwd_packs: needs 128 channels per group, T %% 32 == 0 and a slab the cached kernel holds");
+  const int rows = dpot_groupnorm_bwd_packs_rows(B, T, E, G);
+  DPOT_REQUIRE(B > 0 && B <= 65535 && rows > 0,
+               "groupnorm_bwd_packs: needs T %% 32 == 0 and either 128 channels per group in a slab the cached kernel holds or a "
+               "chunked slab with chunks of a multiple of 32 tokens (dpot_groupnorm_bwd_packs_rows)");
   DPOT_REQUIRE(aligned16(x) && aligned16(dy) && aligned16(dx) && aligned16(gamma) && aligned16(add) && aligned16(dx_rows_bf16) &&
                    aligned16(dx_trans_bf16),
                "groupnorm_bwd_packs: pointers must be 16-byte aligned");
   const GnBwdPacks pk{reinterpret_cast<uint4*>(dx_rows_bf16), reinterpret_cast<uint4*>(dx_trans_bf16), dx_colsum};
-  if (gn_cached_items(T, E, G) == 4)
-    hipLaunchKernelGGL((groupnorm_bwd_cached_kernel<4, true>), dim3(G, B), dim3(GN_THREADS), 0, as_stream(stream), dy, x, mean,
-                       rstd, gamma, add, dx, part, B, T, E, G, pk);
-  else
-    hipLaunchKernelGGL((groupnorm_bwd_cached_kernel<8, true>), dim3(G, B), dim3(GN_THREADS), 0, as_stream(stream), dy, x, mean,
-                       rstd, gamma, add, dx, part, B, T, E, G, pk);
-  return check_launch("groupnorm_bwd_cached_kernel");
+  if (dpot_groupnorm_bwd_packs_supported(T, E, G)) {
+    if (gn_cached_items(T, E, G) == 4)
+      hipLaunchKernelGGL((groupnorm_bwd_cached_kernel<4, true>), dim3(G, B), dim3(GN_THREADS), 0, as_stream(stream), dy, x, mean,
+                         rstd, gamma, add, dx, part, B, T, E, G, pk);
+    else
+      hipLaunchKernelGGL((groupnorm_bwd_cached_kernel<8, true>), dim3(G, B), dim3(GN_THREADS), 0, as_stream(stream), dy, x, mean,
+                         rstd, gamma, add, dx, part, B, T, E, G, pk);
+    return check_launch("groupnorm_bwd_cached_kernel");
+  }
+  DPOT_REQUIRE(workspace && aligned16(workspace), "groupnorm_bwd_packs: the chunked form needs the workspace of dpot_groupnorm_ws_elems");
+  const GnChunks ck = gn_chunking(B, T, E, G);
+  const dim3 grid(ck.chunks, G, B);
+  hipLaunchKernelGGL(gn_chunk_bwd_part_kernel, grid, dim3(GN_THREADS), 0, as_stream(stream), dy, x, mean, rstd, workspace, T, E,
+                     G, ck);
+  int rc0 = check_launch("gn_chunk_bwd_part_kernel");
+  if (rc0) return rc0;
+  hipLaunchKernelGGL(gn_chunk_bwd_apply_pk_kernel, grid, dim3(GN_THREADS), 0, as_stream(stream), dy, x, mean, rstd, gamma, add,
+                     dx, part, (const float*)workspace, B, T, E, G, ck, pk);
+  return check_launch("gn_chunk_bwd_apply_pk_kernel");
 }
 
 extern "C" int dpot_groupnorm_param_grads(const float* const* parts, float* const* dgammas, float* const* dbetas,

@@ -720,8 +720,9 @@ class BlockFn(torch.autograd.Function):
             dcs = pending is not None          # bias column sums: partials now, summed by the block's finalising launch
             taken = _take_grad_packs(do2)
             if taken is not None:              # packed by the kernel that produced this gradient (the next Block's backward)
-                dop, dopT, cs_b = taken
-                df2b = (cs_b, B, E, ops._out(s_f2b.out(), (E,), dev)) if dcs else ops.colsum(cs_b, B, E, out=s_f2b.out())
+                dop, dopT, cs_b = taken             # cs_b: [B * token ranges, E] partial column sums
+                df2b = ((cs_b, cs_b.shape[0], E, ops._out(s_f2b.out(), (E,), dev)) if dcs
+                        else ops.colsum(cs_b, cs_b.shape[0], E, out=s_f2b.out()))
             else:
                 dop, dopT, df2b = ops.bf16_pack_both(do2, want_colsum=True, colsum_out=s_f2b.out(), defer_colsum=dcs)
             # both weight gradients in ONE launch once dHpre's pack exists, when each alone would need split-K
@@ -804,7 +805,7 @@ class BlockFn(torch.autograd.Function):
                 # 128 channels per group (DPOT-S / -M): this pair reads four fields with 4-byte accesses and runs at 64.7 us
                 # against 20.0 + 24.6 us for the separate kernels (profiles/r03_step_census_M_bf16_v1.txt) - not fused
                 dxn1 = ops.irfft2(dS, B, h, w, E, nb, mx, my, 0, res=dy1)
-                if (ctx.emit_grad_packs and bf16p and xn2.dtype == torch.bfloat16 and ops.groupnorm_bwd_packs_supported(tok, E)
+                if (ctx.emit_grad_packs and bf16p and xn2.dtype == torch.bfloat16 and ops.groupnorm_bwd_packs_supported(tok, E, B=B)
                         and os.environ.get("DPOT_GRAD_PACKS", "1") != "0"):
                     # dx goes to the previous Block's bf16 channel-MLP backward: written here in its packed forms as well
                     dx, gn1_part, gp_r, gp_t, gp_cs = ops.groupnorm_bwd_packs(dxn1, x, mean1, rstd1, n1w, add=dout)
@@ -816,7 +817,15 @@ class BlockFn(torch.autograd.Function):
             # AFNO mixer
             dxn1, dw1, db1, dw2, db2 = _mixer_bwd(dy1, S, O1pre, O1, wb1, wb2, ctx.dims, ctx.fused_mixer,
                                                   ctx.afno_layout, (s_w1, s_b1, s_w2, s_b2), pending)
-            dx, gn1_part = ops.groupnorm_bwd(dxn1, x, mean1, rstd1, n1w, add=dout, defer=True)
+            if (ctx.emit_grad_packs and bf16p and xn2.dtype == torch.bfloat16 and ops.groupnorm_bwd_packs_supported(tok, E, B=B)
+                    and os.environ.get("DPOT_GRAD_PACKS", "1") == "2"):
+                # (DPOT-L: the CHUNKED GroupNorm backward can write the gradient's packs too - see the 128-channel branch above -
+                # but there the staging + two barriers per 32-token sub-tile cost what the saved pack pass did: DPOT-L 91.2 -> 90.9 ms,
+                # L20 2.185 -> 2.211 s, profiles/r05_grad_packs_step_ab_L.txt; opt-in, DPOT_GRAD_PACKS=2)
+                dx, gn1_part, gp_r, gp_t, gp_cs = ops.groupnorm_bwd_packs(dxn1, x, mean1, rstd1, n1w, add=dout)
+                _stash_grad_packs(dx, gp_r, gp_t, gp_cs)
+            else:
+                dx, gn1_part = ops.groupnorm_bwd(dxn1, x, mean1, rstd1, n1w, add=dout, defer=True)
         gn_jobs = [(gn1_part, s_n1w.out(), s_n1b.out()), (gn2_part, s_n2w.out(), s_n2b.out())]
         if pending:
             (dn1w, dn1b), (dn2w, dn2b) = ops.block_finalize(pending.get("afno"), pending.get("mlp"), gn_jobs,

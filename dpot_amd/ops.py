@@ -836,25 +836,32 @@ def groupnorm_bwd(dy: Tensor, x: Tensor, mean: Tensor, rstd: Tensor, gamma: Tens
     return (dx, part) if defer else (dx, dgamma, dbeta)
 
 
-def groupnorm_bwd_packs_supported(T: int, E: int, G: int = 8) -> bool:
-    return bool(_lib.load().dpot_groupnorm_bwd_packs_supported(T, E, G))
+def groupnorm_bwd_packs_rows(B: int, T: int, E: int, G: int = 8) -> int:
+    """column-sum partial rows per sample groupnorm_bwd_packs writes for this shape (0: not supported)"""
+    return int(_lib.load().dpot_groupnorm_bwd_packs_rows(B, T, E, G))
+
+
+def groupnorm_bwd_packs_supported(T: int, E: int, G: int = 8, B: int = 1) -> bool:
+    return groupnorm_bwd_packs_rows(B, T, E, G) > 0
 
 
 def groupnorm_bwd_packs(dy: Tensor, x: Tensor, mean: Tensor, rstd: Tensor, gamma: Tensor, G: int = 8,
                         add: Optional[Tensor] = None):
     """groupnorm_bwd(defer=True) that also writes dx as the bf16 operand packs of the previous block's channel-MLP backward:
-    returns (dx, part [2,B,E], dx row-form pack, dx transposed pack, column sums of dx per sample [B, E]) - the last three
-    are what bf16_pack_both(dx, want_colsum=True) would produce from a second pass over dx"""
+    returns (dx, part [2,B,E], dx row-form pack, dx transposed pack, column sums of dx [B * rows, E] over `rows` token ranges
+    per sample) - the last three are what bf16_pack_both(dx, want_colsum=True) would produce from a second pass over dx"""
     B, T, E = x.shape
     lib = _lib.load()
+    rows = lib.dpot_groupnorm_bwd_packs_rows(B, T, E, G)
     dx = torch.empty_like(x)
     part = torch.empty(2, B, E, dtype=torch.float32, device=x.device)
     pr = torch.empty(lib.dpot_bf16_packed_elems(B * T, E, 1), dtype=torch.bfloat16, device=x.device)
     pt = torch.empty(lib.dpot_bf16_packed_elems(E, B * T, 1), dtype=torch.bfloat16, device=x.device)
-    cs = torch.empty(B, E, dtype=torch.float32, device=x.device)
+    cs = torch.empty(B * max(rows, 1), E, dtype=torch.float32, device=x.device)
+    ws = _gn_workspace(B, T, E, G, x.device)
     check(lib.dpot_groupnorm_bwd_packs(dy.data_ptr(), x.data_ptr(), mean.data_ptr(), rstd.data_ptr(), gamma.data_ptr(),
                                        _p(add), dx.data_ptr(), part.data_ptr(), pr.data_ptr(), pt.data_ptr(), cs.data_ptr(),
-                                       B, T, E, G, _stream()), "groupnorm_bwd_packs")
+                                       _p(ws), B, T, E, G, _stream()), "groupnorm_bwd_packs")
     return dx, part, pr, pt, cs
 
 

@@ -251,14 +251,18 @@ int dpot_groupnorm_bwd(const float* dy, const float* x, const float* mean, const
                        float* part /* [2,B,E] */, float* workspace, int B, int T, int E, int G, dpot_stream_t stream);
 /* round 5: the same backward (partials left in `part`) that ALSO writes dx - the gradient entering the previous block's
  * channel-MLP backward - as that backward's bf16 operands: dx_rows_bf16 / dx_trans_bf16 = the two 1-plane packs
- * dpot_bf16_pack_both(dx) would write (dpot_bf16_packed_elems(B*T, E, 1) elements each) and dx_colsum [B, E] = the column sums
- * of dx per sample (bias gradient partials; reduce over B, e.g. as a column-sum job of dpot_block_finalize).  Needs
- * dpot_groupnorm_bwd_packs_supported: 128 channels per group, T % 32 == 0, T <= 256 (DPOT-S / -M at 128^2). */
-int dpot_groupnorm_bwd_packs_supported(int T, int E, int G);
+ * dpot_bf16_pack_both(dx) would write (dpot_bf16_packed_elems(B*T, E, 1) elements each) and dx_colsum [B * rows, E] = column
+ * sums of dx over `rows` token ranges per sample (bias gradient partials; reduce over the first dimension, e.g. as a
+ * column-sum job of dpot_block_finalize).  rows = dpot_groupnorm_bwd_packs_rows(B, T, E, G): 1 where one workgroup holds a
+ * (sample, group) slab (128 channels per group, T <= 256: DPOT-S / -M at 128^2), the number of token chunks where the slab is
+ * chunked (DPOT-L: 192 channels per group, 1024 tokens; needs `workspace` of dpot_groupnorm_ws_elems), 0 = not supported
+ * (T % 32 and E % 32 must be 0). */
+int dpot_groupnorm_bwd_packs_rows(int B, int T, int E, int G);
+int dpot_groupnorm_bwd_packs_supported(int T, int E, int G);   /* the one-workgroup-per-slab form alone */
 int dpot_groupnorm_bwd_packs(const float* dy, const float* x, const float* mean, const float* rstd, const float* gamma,
                              const float* add, float* dx, float* part /* [2,B,E] */, void* dx_rows_bf16,
-                             void* dx_trans_bf16, float* dx_colsum /* [B,E] */, int B, int T, int E, int G,
-                             dpot_stream_t stream);
+                             void* dx_trans_bf16, float* dx_colsum /* [B*rows,E] */, float* workspace, int B, int T, int E,
+                             int G, dpot_stream_t stream);
 /* dgamma == dbeta == NULL above leaves the per-sample partials in `part`; this reduces up to 4 such partial sets
  * (HOST arrays of njobs pointers; e.g. the two GroupNorm layers of a block) in ONE launch. */
 int dpot_groupnorm_param_grads(const float* const* parts, float* const* dgammas, float* const* dbetas, int njobs,

@@ -1544,25 +1544,29 @@ def test_afno_layer_backward_one_launch(ops, monkeypatch, E, nb, B, norm, act, a
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("B,T,E,add", [(3, 256, 1024, True), (2, 128, 1024, False), (1, 256, 2048, True)])
+@pytest.mark.parametrize("B,T,E,add", [(3, 256, 1024, True), (2, 128, 1024, False), (1, 256, 2048, True),
+                                       (4, 1024, 1536, True), (16, 1024, 1536, False), (2, 512, 768, True)])
 def test_groupnorm_bwd_writes_the_gradient_packs(ops, B, T, E, add):
     """round 5: the GroupNorm backward kernel that produces a Block's input gradient also writes it as the bf16 operands of the
-    previous Block's channel-MLP backward (csrc/norm.hip groupnorm_bwd_cached_kernel<.., PK>): dx and the parameter-gradient
-    partials bit-identical to the plain kernel, the packs and column sums equal to a separate bf16_pack_both pass over dx"""
+    previous Block's channel-MLP backward (csrc/norm.hip groupnorm_bwd_cached_kernel<.., PK>; DPOT-L's chunked slabs:
+    gn_chunk_bwd_apply_pk_kernel): dx and the parameter-gradient partials bit-identical to the plain kernels, the packs and
+    column sums equal to a separate bf16_pack_both pass over dx"""
     G = 8
-    if not ops.groupnorm_bwd_packs_supported(T, E, G):
+    rows = ops.groupnorm_bwd_packs_rows(B, T, E, G)
+    if rows == 0:
         pytest.skip("pack-emitting GroupNorm backward not available for this shape")
     torch.manual_seed(B + T + E)
     x = torch.randn(B, T, E, device="cuda") * 1.5 + 0.3
     dy = torch.randn(B, T, E, device="cuda")
     gw, gb = torch.randn(E, device="cuda"), torch.randn(E, device="cuda")
     res = torch.randn(B, T, E, device="cuda") if add else None
-    _, mean, rstd = ops.groupnorm_fwd(x, gw, gb, G, chunked=False)
+    _, mean, rstd = ops.groupnorm_fwd(x, gw, gb, G)
     dx0, part0 = ops.groupnorm_bwd(dy, x, mean, rstd, gw, G, add=res, defer=True)
     dx, part, pr, pt, cs = ops.groupnorm_bwd_packs(dy, x, mean, rstd, gw, G, add=res)
     assert torch.equal(dx, dx0) and torch.equal(part, part0)
+    assert cs.shape == (B * rows, E)
     pr0, pt0, cs0 = ops.bf16_pack_both(dx0.view(B * T, E), want_colsum=True)
     assert torch.equal(pr.view(torch.int16), pr0.view(torch.int16)), "row-form pack of dx"
     assert torch.equal(pt.view(torch.int16), pt0.view(torch.int16)), "transposed pack of dx"
     assert_close(cs.sum(0), cs0, "column sums of dx", rtol=1e-5, atol_scale=1e-5)
-    assert_close(cs, dx0.double().sum(1), "per-sample column sums of dx", rtol=1e-5, atol_scale=1e-5)
+    assert_close(cs.view(B, rows, E).sum(1), dx0.double().sum(1), "per-sample column sums of dx", rtol=1e-5, atol_scale=1e-5)
