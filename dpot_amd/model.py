@@ -286,14 +286,17 @@ class DPOTNet(nn.Module):
         recompute = self.recompute_blocks and torch.is_grad_enabled()
         hook = self._boundary_hook
         for i, blk in enumerate(self.blocks):
+            cut = False
             if hook is not None:
+                lat0 = lat
                 lat = hook(i + 1, lat)
-            f = blk.filter
+                cut = lat is not lat0          # the autograd graph is cut here (train.SegmentedTrainStep): this Block's input
+            f = blk.filter                     # gradient goes to a leaf, not to the previous Block - no gradient packs
             lat = BlockFn.apply(lat, blk.norm1.weight, blk.norm1.bias, f.w1, f.b1, f.w2, f.b2, blk.norm2.weight,
                                 blk.norm2.bias, blk.mlp[0].weight, blk.mlp[0].bias, blk.mlp[2].weight,
                                 blk.mlp[2].bias, h, h, self.n_blocks, self.modes, self._act,
                                 (pk[2 * i], pk[2 * i + 1]), recompute, mlp_pk[i] if mlp_pk is not None else None,
-                                torch.is_grad_enabled(), i > 0)
+                                torch.is_grad_enabled(), i > 0 and not cut)
         if hook is not None:
             lat = hook(len(self.blocks) + 1, lat)
         ol, ch = self.out_layer, self.cls_head

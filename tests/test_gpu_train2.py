@@ -198,6 +198,36 @@ def test_segmented_graph_step_equals_eager_step(T_ar):
     assert torch.equal(opt1.fp.flat, opt2.fp.flat)
 
 
+def test_segmented_graph_step_equals_eager_step_bf16_small(monkeypatch):
+    """the same at DPOT-Small with the bf16 channel MLP (batch 4): the graph cuts sit between Blocks whose backwards hand the
+    gradient on TOGETHER with its bf16 packs (functional._GRAD_PACKS, round 5) and run the one-launch AFNO layer forward with
+    its pack outputs; the Block behind a cut does not hand packs on (its gradient goes to a leaf): the chain must reproduce the
+    eager step - same loss, parameters to fp32 rounding"""
+    from dpot_amd.dp import BucketedGradReducer
+    from dpot_amd.train import SegmentedTrainStep, train_step
+    monkeypatch.setenv("DPOT_AFNO_LAYER", "1")               # (batch 4 is below the `auto` threshold of the one-launch layer)
+    m1, cfg = build(R.SMALL, salt=3)
+    m1.mlp_precision = "bf16"
+    xx, yy, msk = _batch(cfg, 4, T_ar=1)
+    opt1 = _opt(m1, update_tail=True)
+    for lr in (1e-3, 2e-3):
+        l_e, _ = train_step(m1, opt1, xx, yy, msk, lr=lr)
+    m2, _ = build(R.SMALL, salt=3)
+    m2.mlp_precision = "bf16"
+    opt2 = _opt(m2, update_tail=True)
+    red = BucketedGradReducer(opt2.fp, n_buckets=4, overlap=True)
+    seg = SegmentedTrainStep(m2, opt2, red, xx, yy, msk, warmup=1)
+    assert len(seg.graphs) >= 2
+    for lr in (1e-3, 2e-3):
+        l_s = seg.replay(lr)
+    assert l_s.item() == l_e.item()
+    # (not bit for bit here: the Block behind a cut packs its incoming gradient itself, and that pass forms the fc2 bias
+    # column sums per 64 tokens where the GroupNorm backward of the un-cut chain forms them per sample - fp32 rounding of
+    # six bias gradients; everything else is the same arithmetic)
+    d = (opt1.fp.flat - opt2.fp.flat).double().norm() / opt1.fp.flat.double().norm()
+    assert d.item() <= 1e-5, d.item()      # (Adam turns a last-bit difference of a near-zero gradient into +-lr on that element)
+
+
 def _free_port():
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
