@@ -197,7 +197,7 @@ __global__ __launch_bounds__(64 * (NW + 2)) void gemm_panel_kernel(const PanelAr
     }
   }
   bar();                                               // S: every wave is done with the ring; all DMA has landed
-#ifdef PANEL_ABL_NOEPI   /* ablation builds (scripts/r05/panel_ablation.sh): results are garbage */
+#ifdef PANEL_ABL_NOEPI   /* ablation builds (scripts/panel_ablation.sh): results are garbage */
   if (p.M > 0) {
     float a = 0.f;
 #pragma unroll

@@ -48,7 +48,7 @@ for form in alg:
         ent["mfma_util"] = round(ent["SQ_VALU_MFMA_BUSY_CYCLES"] / (4 * ent["SQ_BUSY_CU_CYCLES"]), 3)
     forms[form] = ent
 out = {"shape": {"name": "$SHAPE", "tokens": M, "E": E, "hidden": mh},
-       "note": "rocprofv3 --kernel-trace --pmc, one counter group per pass, scripts/r05/pmc_bf16p.sh; mean of 12 launches per "
+       "note": "rocprofv3 --kernel-trace --pmc, one counter group per pass, scripts/gpu_pmc_bf16p_r05.sh; mean of 12 launches per "
                "form (scripts/bf16p_one.py); bytes_guide = (2*FETCH_SIZE + WRITE_SIZE)*1024 (MI355X_MICROARCH.md: FETCH_SIZE "
                "reports half of a wide streaming read on gfx950); mfma_util = SQ_VALU_MFMA_BUSY_CYCLES / (4 SQ_BUSY_CU_CYCLES)",
        "forms": forms}
