@@ -27,6 +27,10 @@ SWITCHES = {
     # (DPOT_BF16P_ROWFORM=1, an opt-IN riding along: it only acts on the B-direct pair launch, which BD=0 switches off - so it
     # gets the DPOT-M case of its own below)
     "DPOT_BF16P_BD=0": (LARGE_SET, False),
+    # round 5 defaults switched OFF: four-product AFNO weight gradients, the separate pack passes of the bf16 channel MLP (no packs
+    # from the one-launch AFNO layer / the GroupNorm backward) - the forms these replaced stay under the gate
+    "DPOT_AFNO_WGRAD_GAUSS=0 DPOT_GRAD_PACKS=0 DPOT_AFNO_LAYER_PACKS=0":
+        ("test_vs_reference_golden and SMALL-32 or test_full_model_gradients_vs_oracle and TINY-32", False),
     # round 5 opt-ins that were built and rejected by measurement - kept under the gate: the one-launch AFNO layer BACKWARD and
     # the weight gradients on ROW-form operands through the transposing LDS read (DPOT-M at batch 32: reference golden, fp32
     # leg + bf16 leg; DPOT-S at batch 32 runs the one-launch layer forward + backward)
