@@ -409,21 +409,30 @@ __global__ __launch_bounds__(64 * (NW + 2)) void afno_mlp2_kernel(const AfnoMlpA
 // Packed weights (dpot_afno_pack_all, layout 1): [block][slab t][part][col tile c][4*l + e] =
 //      W_part[k = 16t + 4(l>>4) + e][n = 16c + (l&15)],   forward: (Wr, Wi);  backward: (Wr^T, -Wi^T).
 // =====================================================================================================================
-template <int RT, int BS, int ACTK>
-__global__ __launch_bounds__(64 * (BS / 16 + 2)) void afno_mlp3_kernel(const AfnoMlpArgs p) {
-  constexpr int NW = BS / 16;       // compute waves = 16-column tiles of one part (8 for bs = 128, 6 for bs = 96)
+// SPLIT (round 5; bs = 96, RT >= 2): six column tiles on EIGHT compute waves.  With one wave per column tile the six waves land
+// 2 + 2 + 1 + 1 on the four SIMDs (a workgroup's waves go to the SIMDs in the order 0, 2, 1, 3) and the matrix pipes top out at
+// 6 / 8; here waves 0-3 own all RT row tiles of column tiles 0-3, waves 4 / 5 the first ceil(RT / 2) row tiles of column tiles 4 / 5
+// and waves 6 / 7 their remaining row tiles - per SIMD RT + ceil(RT/2), RT + ceil(RT/2), RT + floor(RT/2), RT + floor(RT/2) row
+// tiles (8 : 8 : 7 : 7 at RT = 5 instead of 10 : 10 : 5 : 5).  Every wave still owns exactly ONE column tile: same code, its
+// row range [r0, r0 + NR) a compile-time size.  The loader waves become waves 8 and 9.
+template <int RT, int BS, int ACTK, bool SPLIT = false>
+__global__ __launch_bounds__(64 * ((SPLIT ? 8 : BS / 16) + 2)) void afno_mlp3_kernel(const AfnoMlpArgs p) {
+  constexpr int NW = BS / 16;       // 16-column tiles of one part (8 for bs = 128, 6 for bs = 96) = compute waves unless SPLIT
+  constexpr int NCW = SPLIT ? 8 : NW;   // compute waves
+  static_assert(!SPLIT || (NW == 6 && RT >= 2), "the split form is for six column tiles");
   constexpr int N = 2 * BS;
   constexpr int NSLAB = BS / 16;    // 16-k slabs per layer
   constexpr int NCT = 2 * NSLAB;    // 16-column tiles of Y1 (both parts)
   constexpr int WSL = 2 * NW * 256; // floats of a weight slab: [part][c][256]
   constexpr int XSL = 2 * RT * 256; // floats of an X slab: [part][row tile][16 rows][16 k]
   constexpr int WB = NW, XB = RT;   // DMA pieces per slab and loader wave
-  __shared__ __attribute__((aligned(16))) float lds[3 * WSL + 3 * XSL + RT * NCT * 256 + 256];
+  __shared__ __attribute__((aligned(16))) float lds[3 * WSL + 3 * XSL + RT * NCT * 256 + 256 + (SPLIT ? NCW * 512 : 0)];
   float* const Wr_ = lds;                   // ring [3][part][c][256]
   float* const Xb = lds + 3 * WSL;          // ring [3][part][RT][256]
   float* const Y1 = Xb + 3 * XSL;           // [RT][NCT][256]
   float* const sink = Y1 + RT * NCT * 256;  // 1 KiB nobody reads: target of the aux prefetch DMA
-  float* const stage_all = lds + ((NSLAB - 1) % 3) * WSL;      // epilogue staging: [NW][16][32] = one weight slab
+  // epilogue staging [compute waves][16][32]: one weight slab (NW waves); the split form's eight waves get a region of their own
+  float* const stage_all = SPLIT ? sink + 256 : lds + ((NSLAB - 1) % 3) * WSL;
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -446,9 +455,9 @@ __global__ __launch_bounds__(64 * (BS / 16 + 2)) void afno_mlp3_kernel(const Afn
     asm volatile("" ::: "memory");
   };
 
-  if (wave >= NW) {
+  if (wave >= NCW) {
     // ================================ loader waves ================================
-    const int L = wave - NW;
+    const int L = wave - NCW;
     const float* X = p.X + (long long)kblk * N;
     const float* Wa_l = p.Wa + (long long)kblk * (NSLAB * WSL) + lane * 4;
     const float* Wb_l = p.Wb + (long long)kblk * (NSLAB * WSL) + lane * 4;
@@ -506,44 +515,47 @@ __global__ __launch_bounds__(64 * (BS / 16 + 2)) void afno_mlp3_kernel(const Afn
   }
 
   // ================================ compute waves ================================
-  f32x4 P1[RT], P2[RT], P3[RT];
+  // NR row tiles [r0, r0 + NR) of column tile cw (NR == RT, r0 == 0, cw == wave unless SPLIT)
+  auto compute = [&](auto NRc, const int r0, const int cw) __attribute__((always_inline)) {
+  constexpr int NR = decltype(NRc)::value;
+  f32x4 P1[NR], P2[NR], P3[NR];
   auto zero_acc = [&]() __attribute__((always_inline)) {
 #pragma unroll
-    for (int i = 0; i < RT; ++i) P1[i] = P2[i] = P3[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int i = 0; i < NR; ++i) P1[i] = P2[i] = P3[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
   };
   // weight fragments of this wave's column tile: (b_r, b_i) of the slab in ring buffer `rb`
   auto read_w = [&](f32x4 (&b)[2], int rb) __attribute__((always_inline)) {
-    b[0] = *reinterpret_cast<const f32x4*>(Wr_ + rb * WSL + wave * 256 + lane * 4);
-    b[1] = *reinterpret_cast<const f32x4*>(Wr_ + rb * WSL + (NW + wave) * 256 + lane * 4);
+    b[0] = *reinterpret_cast<const f32x4*>(Wr_ + rb * WSL + cw * 256 + lane * 4);
+    b[1] = *reinterpret_cast<const f32x4*>(Wr_ + rb * WSL + (NW + cw) * 256 + lane * 4);
   };
   const int xfrag = fr * 16 + 4 * (fq ^ ((fr >> 2) & 3));
-  auto read_x = [&](f32x4 (&ar)[RT], f32x4 (&ai)[RT], int rb) __attribute__((always_inline)) {
+  auto read_x = [&](f32x4 (&ar)[NR], f32x4 (&ai)[NR], int rb) __attribute__((always_inline)) {
     const float* xs = Xb + rb * XSL + xfrag;
 #pragma unroll
-    for (int i = 0; i < RT; ++i) {
-      ar[i] = *reinterpret_cast<const f32x4*>(xs + i * 256);
-      ai[i] = *reinterpret_cast<const f32x4*>(xs + (RT + i) * 256);
+    for (int i = 0; i < NR; ++i) {
+      ar[i] = *reinterpret_cast<const f32x4*>(xs + (r0 + i) * 256);
+      ai[i] = *reinterpret_cast<const f32x4*>(xs + (RT + r0 + i) * 256);
     }
   };
-  auto read_y = [&](f32x4 (&ar)[RT], f32x4 (&ai)[RT], int u) __attribute__((always_inline)) {
+  auto read_y = [&](f32x4 (&ar)[NR], f32x4 (&ai)[NR], int u) __attribute__((always_inline)) {
 #pragma unroll
-    for (int i = 0; i < RT; ++i) {
-      ar[i] = *reinterpret_cast<const f32x4*>(Y1 + ((i * NCT + u) * 64 + fq * 16 + ((fr + u + 8 * (fq >> 1)) & 15)) * 4);
-      ai[i] = *reinterpret_cast<const f32x4*>(Y1 + ((i * NCT + u + NSLAB) * 64 + fq * 16 + ((fr + u + NSLAB + 8 * (fq >> 1)) & 15)) * 4);
+    for (int i = 0; i < NR; ++i) {
+      ar[i] = *reinterpret_cast<const f32x4*>(Y1 + (((r0 + i) * NCT + u) * 64 + fq * 16 + ((fr + u + 8 * (fq >> 1)) & 15)) * 4);
+      ai[i] = *reinterpret_cast<const f32x4*>(Y1 + (((r0 + i) * NCT + u + NSLAB) * 64 + fq * 16 + ((fr + u + NSLAB + 8 * (fq >> 1)) & 15)) * 4);
     }
   };
-  auto g12 = [&](const f32x4 (&ar)[RT], const f32x4 (&ai)[RT], const f32x4 (&b)[2]) __attribute__((always_inline)) {
+  auto g12 = [&](const f32x4 (&ar)[NR], const f32x4 (&ai)[NR], const f32x4 (&b)[2]) __attribute__((always_inline)) {
 #pragma unroll
-    for (int i = 0; i < RT; ++i)
+    for (int i = 0; i < NR; ++i)
 #pragma unroll
       for (int s2 = 0; s2 < 4; ++s2) {
         P1[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(ar[i][s2], b[0][s2], P1[i], 0, 0, 0);
         P2[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(ai[i][s2], b[1][s2], P2[i], 0, 0, 0);
       }
   };
-  auto g3 = [&](const f32x4 (&as)[RT], const f32x4& bs) __attribute__((always_inline)) {
+  auto g3 = [&](const f32x4 (&as)[NR], const f32x4& bs) __attribute__((always_inline)) {
 #pragma unroll
-    for (int i = 0; i < RT; ++i)
+    for (int i = 0; i < NR; ++i)
 #pragma unroll
       for (int s2 = 0; s2 < 4; ++s2) P3[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(as[i][s2], bs[s2], P3[i], 0, 0, 0);
   };
@@ -570,7 +582,7 @@ __global__ __launch_bounds__(64 * (BS / 16 + 2)) void afno_mlp3_kernel(const Afn
 #pragma unroll
     for (int it = 0; it < 2; ++it) {
       const int c4 = (it * 64 + ln) & 7;
-      bcol[it] = (c4 >> 2) * BS + 16 * wave + 4 * (c4 & 3);
+      bcol[it] = (c4 >> 2) * BS + 16 * cw + 4 * (c4 & 3);
       b4[it] = bias ? *reinterpret_cast<const float4*>(bias + kblk * N + bcol[it]) : make_float4(0.f, 0.f, 0.f, 0.f);
     }
     auto tile = [&](auto Ic) __attribute__((always_inline)) {
@@ -591,7 +603,7 @@ __global__ __launch_bounds__(64 * (BS / 16 + 2)) void afno_mlp3_kernel(const Afn
         const int r = g >> 3;
         const f32x4 t = *reinterpret_cast<const f32x4*>(stage + g * 4);
         float v[4] = {t[0] + b4[it].x, t[1] + b4[it].y, t[2] + b4[it].z, t[3] + b4[it].w};
-        const int row = row0 + 16 * i + r;
+        const int row = row0 + 16 * (r0 + i) + r;
         const int col = bcol[it];
         const bool ok = row < p.M;
         const int rowc = ok ? row : p.M - 1;
@@ -636,7 +648,7 @@ __global__ __launch_bounds__(64 * (BS / 16 + 2)) void afno_mlp3_kernel(const Afn
           }
           if (mid_b && ok) *reinterpret_cast<float4*>(mid_b + go) = make_float4(v[0], v[1], v[2], v[3]);
           const int s = col >> 4, kq = (col >> 2) & 3;
-          *reinterpret_cast<f32x4*>(Y1 + ((i * NCT + s) * 64 + kq * 16 + ((r + s + 8 * (kq >> 1)) & 15)) * 4) =
+          *reinterpret_cast<f32x4*>(Y1 + (((r0 + i) * NCT + s) * 64 + kq * 16 + ((r + s + 8 * (kq >> 1)) & 15)) * 4) =
               (f32x4){v[0], v[1], v[2], v[3]};
         } else {
           if (ok) *reinterpret_cast<float4*>(Y_b + go) = make_float4(v[0], v[1], v[2], v[3]);
@@ -645,20 +657,20 @@ __global__ __launch_bounds__(64 * (BS / 16 + 2)) void afno_mlp3_kernel(const Afn
       __builtin_amdgcn_wave_barrier();
     };
     tile(std::integral_constant<int, 0>{});
-    if constexpr (RT > 1) tile(std::integral_constant<int, 1>{});
-    if constexpr (RT > 2) tile(std::integral_constant<int, 2>{});
-    if constexpr (RT > 3) tile(std::integral_constant<int, 3>{});
-    if constexpr (RT > 4) tile(std::integral_constant<int, 4>{});
+    if constexpr (NR > 1) tile(std::integral_constant<int, 1>{});
+    if constexpr (NR > 2) tile(std::integral_constant<int, 2>{});
+    if constexpr (NR > 3) tile(std::integral_constant<int, 3>{});
+    if constexpr (NR > 4) tile(std::integral_constant<int, 4>{});
   };
 
   // one slab: G1, G2 on the current fragments, sums on the VALU, next slab's fragments into the freed registers, G3.
   // (B0 is dead once b_s is formed: ONE weight-fragment set.  At RT = 5 the kernel sits at the 168 VGPRs a 10-wave
   // workgroup leaves per wave and the allocator spills ~30 registers per lane AROUND the epilogues - not in the slab
   // loops; forming a_s in place of a_r to save 20 registers made the allocation worse, not better.)
-  f32x4 AR[RT], AI[RT], AS[RT], B0[2];
+  f32x4 AR[NR], AI[NR], AS[NR], B0[2];
   auto sums = [&](const f32x4 (&b)[2], f32x4& bs) __attribute__((always_inline)) {
 #pragma unroll
-    for (int i = 0; i < RT; ++i) AS[i] = AR[i] + AI[i];
+    for (int i = 0; i < NR; ++i) AS[i] = AR[i] + AI[i];
     bs = b[0] + b[1];
   };
 
@@ -668,14 +680,14 @@ __global__ __launch_bounds__(64 * (BS / 16 + 2)) void afno_mlp3_kernel(const Afn
   if (p.mode == 1) {
     // 16 rows x (64 B real + 64 B imaginary) per row tile = 2 instructions: lane -> (row, part, 16-byte chunk)
 #pragma unroll
-    for (int i = 0; i < RT; ++i)
+    for (int i = 0; i < NR; ++i)
 #pragma unroll
       for (int h2 = 0; h2 < 2; ++h2) {
         const int id = h2 * 64 + lane;
-        int row = row0 + 16 * i + (id >> 3);
+        int row = row0 + 16 * (r0 + i) + (id >> 3);
         row = row < p.M ? row : p.M - 1;
         const int part = (id >> 2) & 1, c = id & 3;
-        glds16(p.aux + (long long)row * p.ldo + (long long)kblk * N + part * BS + 16 * wave + 4 * c, sink);
+        glds16(p.aux + (long long)row * p.ldo + (long long)kblk * N + part * BS + 16 * cw + 4 * c, sink);
       }
   }
 
@@ -736,6 +748,15 @@ __global__ __launch_bounds__(64 * (BS / 16 + 2)) void afno_mlp3_kernel(const Afn
   }
   bar();                                               // S2
   epilogue(false, p.bb);
+  };
+  if constexpr (SPLIT) {
+    constexpr int RA = (RT + 1) / 2, RB = RT - RA;          // row tiles of column tiles 4 / 5 on waves 4 / 5 and on waves 6 / 7
+    if (wave < 4) compute(std::integral_constant<int, RT>{}, 0, wave);
+    else if (wave < 6) compute(std::integral_constant<int, RA>{}, 0, wave);
+    else compute(std::integral_constant<int, RB>{}, RA, wave - 2);
+  } else {
+    compute(std::integral_constant<int, RT>{}, 0, wave);
+  }
 }
 
 // Wbig [J][N][N] (row-major, as dpot_afno_pack writes it: W[k][n]) -> fragment-block-major copies
@@ -856,6 +877,20 @@ static int launch_rt(const AfnoMlpArgs& p, int rt, hipStream_t s) {
 template <int BS, int ACTK>
 static int launch3_rt(const AfnoMlpArgs& p, int rt, hipStream_t s) {
   const dim3 grid((unsigned)(p.nb * p.panels)), blk(64 * (BS / 16 + 2));
+  if constexpr (BS == 96) {
+    // six column tiles on eight compute waves (afno_mlp3_kernel<.., SPLIT>; DPOT_AFNO_SPLIT6=0: one wave per column tile)
+    static const int split6 = [] { const char* e = getenv("DPOT_AFNO_SPLIT6"); return e ? atoi(e) : 1; }();
+    if (split6 && rt >= 2) {
+      const dim3 blk8(64 * 10);
+      switch (rt) {
+        case 2: hipLaunchKernelGGL((afno_mlp3_kernel<2, BS, ACTK, true>), grid, blk8, 0, s, p); break;
+        case 3: hipLaunchKernelGGL((afno_mlp3_kernel<3, BS, ACTK, true>), grid, blk8, 0, s, p); break;
+        case 4: hipLaunchKernelGGL((afno_mlp3_kernel<4, BS, ACTK, true>), grid, blk8, 0, s, p); break;
+        default: hipLaunchKernelGGL((afno_mlp3_kernel<5, BS, ACTK, true>), grid, blk8, 0, s, p); break;
+      }
+      return check_launch("afno_mlp3_kernel");
+    }
+  }
   switch (rt) {
     case 1: hipLaunchKernelGGL((afno_mlp3_kernel<1, BS, ACTK>), grid, blk, 0, s, p); break;
     case 2: hipLaunchKernelGGL((afno_mlp3_kernel<2, BS, ACTK>), grid, blk, 0, s, p); break;

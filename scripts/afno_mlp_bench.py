@@ -18,7 +18,7 @@ def bench(nb, bs, M, reps=50):
     forms = {"fwd-train": lambda: ops.afno_mlp2(S, W1f, b1, W2f, b2, nb, bs, 1, mode=0, want_pre=True, want_mid=True),
              "fwd-infer": lambda: ops.afno_mlp2(S, W1f, b1, W2f, b2, nb, bs, 1, mode=0),
              "bwd-data": lambda: ops.afno_mlp2(S, W2b, None, W1b, None, nb, bs, 1, mode=1, aux=pre, want_mid=True)}
-    if bs == 128 and os.environ.get("DPOT_AFNO_3MULT", "1") != "0":
+    if ops.afno_mlp3_supported(nb, bs):
         # the three-product kernel on (Wr, Wi) fragment packs
         w1 = torch.randn(2, nb, bs, bs, device="cuda") * 0.05; w2 = torch.randn(2, nb, bs, bs, device="cuda") * 0.05
         c1 = torch.randn(2, nb, bs, device="cuda") * 0.1; c2 = torch.randn(2, nb, bs, device="cuda") * 0.1
@@ -72,5 +72,5 @@ if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "tiny-train":
         tiny_train()
     else:
-        for nb, bs, M in ((4, 128, 4608), (8, 128, 2304), (16, 96, 2176)):
+        for nb, bs, M in ((4, 128, 4608), (8, 128, 2304), (16, 96, 2176), (16, 96, 8704)):
             bench(nb, bs, M)
