@@ -23,5 +23,5 @@ int check_launch(const char* what) {
 
 }  // namespace dpot
 
-extern "C" int dpot_version(void) { return 200; /* 0.2.0: round 2 ABI (panel / bf16 / weight-gradient GEMMs, fused AFNO MLP, implicit embed) */ }
+extern "C" int dpot_version(void) { return 250; /* 0.2.5: round 5 ABI (one-launch AFNO layer fwd / bwd, row-form pair launch, gradient packs from the GroupNorm backward, kernel-kind query) */ }
 extern "C" const char* dpot_last_error(void) { return dpot::g_err; }
