@@ -504,8 +504,18 @@ def _self_launch(n: int) -> int:
     return subprocess.call(cmd, env=env)
 
 
+def _flush_c_stdio():
+    try:
+        import ctypes
+        ctypes.CDLL(None).fflush(None)
+    except Exception:                                          # pragma: no cover
+        pass
+    sys.stdout.flush()
+
+
 def main():
     args = parse()
+    final_line = ""
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         raise SystemExit(_self_launch(args.gpus))
     rank = int(os.environ.get("RANK", 0))
@@ -523,7 +533,16 @@ def main():
     if debug_gloo:
         local_rank = 0
     torch.cuda.set_device(local_rank)
-    if world > 1:
+    # DPOT_BENCH_FORCE_DP=1 (1-GPU box): take the N>1 code path with a ONE-rank RCCL communicator - the bucket all-reduces
+    # are real ncclAllReduce launches on the side stream between the graph segments (identity on one rank), so the stream
+    # choreography and RCCL's launch cost are measured on hardware where no second GPU exists
+    force_dp = world == 1 and os.environ.get("DPOT_BENCH_FORCE_DP") == "1"
+    dp_on = world > 1 or force_dp
+    if force_dp:
+        os.environ.setdefault("MASTER_PORT", "29517")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
+    if dp_on:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         if debug_gloo:
@@ -546,9 +565,10 @@ def main():
     model.recompute_blocks = recompute
     fp = FlatParams(model)
     # DDP semantics for N>1: cls_head takes part (zero gradients -> weight decay only), grads averaged over ranks
-    opt = FusedAdam(fp, lr=1e-3, betas=(0.9, 0.9), weight_decay=1e-6, max_norm=10000.0, update_tail=world > 1)
-    reducer = BucketedGradReducer(fp, overlap=True) if world > 1 else None     # bucket count by gradient bytes (dp.auto_n_buckets)
+    opt = FusedAdam(fp, lr=1e-3, betas=(0.9, 0.9), weight_decay=1e-6, max_norm=10000.0, update_tail=dp_on)
+    reducer = BucketedGradReducer(fp, overlap=True) if dp_on else None     # bucket count by gradient bytes (dp.auto_n_buckets)
     if reducer is not None:
+        reducer.single_rank_collective = force_dp
         reducer.broadcast_parameters(0)
     grad_scale = 1.0 / world
 
@@ -561,17 +581,17 @@ def main():
     total_steps = args.warmup + args.steps + 8
     # N>1: accelerate steps the scheduler `world` times per optimiser step over a schedule sized by the unsharded
     # loader (train_temporal_parallel.py:150,185) - dp.dp_one_cycle_lr reproduces that rule
-    lr_at = (lambda s: dp_one_cycle_lr(s, world, max(total_steps, 10) * world, 1e-3, pct_start=0.2)) if world > 1 \
+    lr_at = (lambda s: dp_one_cycle_lr(s, world, max(total_steps, 10) * world, 1e-3, pct_start=0.2)) if dp_on \
         else (lambda s: one_cycle_lr(s, max(total_steps, 10), 1e-3, pct_start=0.2))
 
     mode = "eager"
     graphed = None
-    if not args.no_graph and not (world > 1 and args.overlap):
+    if not args.no_graph and not (dp_on and args.overlap):
         try:
             # N>1: the graph holds fwd+bwd only; the all-reduce and the optimiser run after the replay
-            if world > 1 and args.no_overlap:
+            if dp_on and args.no_overlap:
                 graphed = _GraphedFwdBwd(model, opt, xx, yy, msk, args.noise_scale)
-            elif world > 1:
+            elif dp_on:
                 # default N>1 path: hipGraph segments cut at the gradient-bucket boundaries; bucket k is all-reduced
                 # on the side stream while the compute stream replays the backward of the earlier stages
                 graphed = SegmentedTrainStep(model, opt, reducer, xx, yy, msk, noise_scale=args.noise_scale,
@@ -592,7 +612,7 @@ def main():
         if graphed is None:
             return train_step(model, opt, xx, yy, msk, noise_scale=args.noise_scale, lr=lr, reducer=reducer,
                               grad_scale=grad_scale)[0]
-        if world > 1 and args.no_overlap:
+        if dp_on and args.no_overlap:
             graphed.replay()
             reducer.begin_step()
             reducer.finish()                                   # bucketed RCCL all-reduce (SUM) of the flat gradient
@@ -601,7 +621,7 @@ def main():
         return graphed.replay(lr)
 
     def fence():
-        if world > 1:
+        if dp_on:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -618,7 +638,7 @@ def main():
     elapsed = time.perf_counter() - t0
     rank_ms = [elapsed / args.steps * 1e3]
     rank_host_us = [host_s / args.steps * 1e6]
-    if world > 1:
+    if dp_on:
         # value uses the MAX over ranks; the per-rank spread (and the host cost of driving the segmented chain: 3-5 graph
         # launches + the collectives of a step from one thread) is reported beside it
         t = torch.tensor([elapsed, host_s], device="cuda", dtype=torch.float64)
@@ -658,11 +678,13 @@ def main():
                        "peak_mem_GB": round(torch.cuda.max_memory_allocated() / 2 ** 30, 2)},
         }
         out["config"]["host_us_per_step"] = round(max(rank_host_us), 1)
-        if world > 1:
+        if dp_on:
             out["config"]["collectives"] = {
                 "backend": dist.get_backend(), "world_size": dist.get_world_size(),
                 "library": ("gloo (DPOT_BENCH_DEBUG_GLOO=1: functional dry run, all ranks on cuda:0 - NOT a performance "
-                            "number)") if debug_gloo else f"RCCL {'.'.join(map(str, torch.cuda.nccl.version()))} over xGMI"}
+                            "number)") if debug_gloo else f"RCCL {'.'.join(map(str, torch.cuda.nccl.version()))} over xGMI"
+                           + (" (DPOT_BENCH_FORCE_DP=1: ONE-rank communicator on a 1-GPU box - real RCCL launches, no traffic)"
+                              if force_dp else "")}
             out["config"]["per_rank"] = {"ms_per_step_min": round(min(rank_ms), 4), "ms_per_step_max": round(max(rank_ms), 4),
                                          "host_us_per_step_min": round(min(rank_host_us), 1),
                                          "host_us_per_step_max": round(max(rank_host_us), 1),
@@ -674,7 +696,7 @@ def main():
                                    "one graph + all-reduce after backward" if args.no_overlap else
                                    f"segmented hipGraph chain ({len(graphed.graphs)} segments), bucket all-reduce on a "
                                    f"side stream overlapped with the remaining backward; {reducer.n_buckets} buckets")
-        if world == 1 and graphed is not None and args.sustain_seconds > 0 and not args.brief:
+        if not dp_on and graphed is not None and args.sustain_seconds > 0 and not args.brief:
             # the K-step figure above covers < 0.1 s of GPU time; a sustained run shows what the clocks settle at
             n_sus = max(args.steps, int(args.sustain_seconds / (elapsed / args.steps)))
             torch.cuda.synchronize()
@@ -722,7 +744,7 @@ def main():
         except Exception as e:                                 # pragma: no cover
             log(f"[bench] roofline probe failed: {e}")
             out["roofline"] = None
-        if not headline and world == 1 and graphed is not None and args.gemm_precision == "auto" and not args.no_alt:
+        if not headline and not dp_on and graphed is not None and args.gemm_precision == "auto" and not args.no_alt:
             # the bf16-channel-MLP configs run `auto`; the same step with every fp32 GEMM on native fp32 MFMA, beside it
             try:
                 model.gemm_precision = "f32"
@@ -742,7 +764,7 @@ def main():
                 log(f"[bench] gemm_f32 timing failed: {e}")
             finally:
                 model.gemm_precision = args.gemm_precision
-        if args.config in ("M", "L") and world == 1 and graphed is not None and mlp_prec == "bf16" and not args.no_alt:
+        if args.config in ("M", "L") and not dp_on and graphed is not None and mlp_prec == "bf16" and not args.no_alt:
             # BASELINE configs[3] / [4] do not say bf16 (only configs[2] does): the SAME step with every GEMM on native fp32
             # MFMA - channel MLP included - i.e. the figure inside north_star's rtol 1e-4 (the parity gate of this mode:
             # tests/test_gpu_sizes.py::test_vs_reference_golden, fp32 leg).  Fresh model / optimiser / graph: weight packs and
@@ -779,7 +801,7 @@ def main():
                 del g32, m32, o32
             except Exception as e:                             # pragma: no cover
                 log(f"[bench] all_f32 timing failed: {type(e).__name__}: {e}")
-        if headline and world == 1 and graphed is not None and args.gemm_precision == "f32" and not args.no_alt \
+        if headline and not dp_on and graphed is not None and args.gemm_precision == "f32" and not args.no_alt \
                 and not args.brief:
             # not the headline: the same step with the large GEMMs on the bf16x6 kernel (fp32 emulated by operand
             # splitting on the bf16 matrix cores, same accuracy class - DESIGN.md "bf16x6"); a fresh graph is captured
@@ -803,7 +825,7 @@ def main():
                 log(f"[bench] gemm_auto timing failed: {e}")
             finally:
                 model.gemm_precision = args.gemm_precision
-        if world == 1 and T_ar == 1 and not args.brief:
+        if not dp_on and T_ar == 1 and not args.brief:
             # forward-only (inference) rate of the same batch, SURVEY 8(d): no_grad forward, hipGraph replay
             try:
                 with torch.no_grad():
@@ -826,7 +848,7 @@ def main():
                                     "what": "DPOTNet forward only (no_grad), batch %d, hipGraph replay" % B}
             except Exception as e:                             # pragma: no cover
                 log(f"[bench] inference timing failed: {e}")
-        if headline and world == 1 and graphed is not None and not args.no_pipeline and not args.brief:
+        if headline and not dp_on and graphed is not None and not args.no_pipeline and not args.brief:
             # input-pipeline-inclusive rate (never `value`): raw 64x64 single-channel trajectories in host memory (the
             # ns2d_fno_1e-5 shape) -> pinned staging -> ONE H2D copy per batch on a copy stream -> device-side bilinear
             # resize to 128^2 + channel pad with ones + temporal window (csrc/data.hip) -> double-buffered batch slots;
@@ -863,19 +885,26 @@ def main():
                             "batching inclusive, single host thread"}
             except Exception as e:                             # pragma: no cover
                 log(f"[bench] pipeline-inclusive timing failed: {type(e).__name__}: {e}")
-        if headline and world == 1 and not args.skip_cpu_baseline and not args.brief:
+        if headline and not dp_on and not args.skip_cpu_baseline and not args.brief:
             out["cpu_baseline"] = cpu_baseline(args.cpu_seconds)
             out["speedup_vs_cpu_baseline"] = round(value / out["cpu_baseline"]["value"], 1)
-        if headline and world == 1 and not args.brief and not args.no_other_configs and args.batch is None:
+        if headline and not dp_on and not args.brief and not args.no_other_configs and args.batch is None:
             # BASELINE configs[2..4] through this same script, so that the driver's record carries them:
             # the model of this process is released first - DPOT-L at batch 16 wants the HBM to itself
             del graphed, model, opt, fp
             torch.cuda.empty_cache()
             out["other_configs"] = other_configs(args)
-        print(json.dumps(out), flush=True)
-    if world > 1:
+        final_line = json.dumps(out)
+    if dp_on:
         dist.barrier()
         dist.destroy_process_group()
+    # the JSON line is the LAST thing on stdout: RCCL prints its version banner through C stdio, which - stdout being a pipe -
+    # sits in the C library's buffer until it is flushed; flush it (every rank) before rank 0 prints
+    _flush_c_stdio()
+    if rank == 0:
+        if dp_on and world > 1:
+            time.sleep(0.5)                                    # the other ranks' flushes land first
+        print(final_line, flush=True)
 
 
 class _GraphedFwdBwd:

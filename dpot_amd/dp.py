@@ -84,6 +84,9 @@ class BucketedGradReducer:
         # call FlatParams.fire(i); (b) ordinary autograd accumulation (foreign graphs) -> post-accumulate hooks
         self._attached = True
         self.dry_run = False                 # world 1 only: go through the motions of the bucket all-reduces (see _launch)
+        # world 1 only: issue the REAL collectives on a one-rank process group (identity) - exercises RCCL's launch path and
+        # the stream hand-offs on a 1-GPU box (tests/test_gpu_train2.py, bench.py DPOT_BENCH_FORCE_DP=1)
+        self.single_rank_collective = False
         self.skip_zero_tail = True
         flat.callbacks.append(self._on_ready)
         for i, p in enumerate(flat.params):
@@ -116,7 +119,7 @@ class BucketedGradReducer:
     # -- set-up ------------------------------------------------------------------------------------------
     def broadcast_parameters(self, src: int = 0) -> None:
         """rank 0 -> all, one collective over the flat fp32 parameter buffer (DDP's initial broadcast)."""
-        if self.world > 1:
+        if self.world > 1 or (self.single_rank_collective and dist.is_initialized()):
             dist.broadcast(self.fp.flat, src=src, group=self.pg)
 
     # -- per step ----------------------------------------------------------------------------------------
@@ -141,10 +144,11 @@ class BucketedGradReducer:
         return hook
 
     def _launch(self, k: int) -> None:
-        if self._launched[k] or (self.world == 1 and not self.dry_run):
+        single = self.world == 1 and not (self.single_rank_collective and dist.is_initialized())
+        if self._launched[k] or (single and not self.dry_run):
             self._launched[k] = True
             return
-        if self.world == 1:
+        if single:
             # dry run on one process (scripts/dp_host_time.py): the stream choreography of a bucket all-reduce - side
             # stream waits for the compute stream, one device operation over the bucket on the side stream - without a
             # collective, to time the HOST side of the segmented step where no second GPU exists

@@ -337,6 +337,78 @@ def test_two_process_dp_segmented_rollout_vs_oracle(tmp_path):
         assert abs(got[k] - want) <= RTOL * want + 1e-7, k
 
 
+def _rccl_worker(rank, port, out_dir):
+    import torch.distributed as dist
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    from dpot_amd import DPOTNet
+    from dpot_amd.dp import BucketedGradReducer
+    from dpot_amd.train import FlatParams, FusedAdam, SegmentedTrainStep, rollout
+    cfg = R.DPOTConfig(**R.MINI)
+    sd = R.recipe_state_dict(cfg, salt=17)
+    B, T_ar = 4, 2
+    xs = R.recipe_input((B, cfg.img_size, cfg.img_size, cfg.in_timesteps, cfg.in_channels), salt=81).cuda()
+    ys = R.recipe_input((B, cfg.img_size, cfg.img_size, T_ar, cfg.out_channels), salt=82).cuda()
+    ms = torch.ones(B, cfg.img_size, cfg.img_size, 1, cfg.out_channels).cuda()
+    out = {}
+    for kind in ("plain", "eager", "segmented"):
+        model = DPOTNet(**R.MINI)
+        model.load_state_dict(sd)
+        model.cuda()
+        fp = FlatParams(model)
+        if kind == "plain":                                  # no reducer at all: the single-GPU gradient
+            fp.zero_grad()
+            loss, _ = rollout(model, xs, ys, ms)
+            loss.backward()
+            launched = 0
+        else:
+            red = BucketedGradReducer(fp, n_buckets=3, overlap=True)
+            red.single_rank_collective = True                # real ncclAllReduce launches on the side stream
+            red.broadcast_parameters(0)
+            if kind == "segmented":
+                opt = FusedAdam(fp, lr=0.0, betas=(0.9, 0.9), weight_decay=0.0, max_norm=1e4, update_tail=True)
+                seg = SegmentedTrainStep(model, opt, red, xs, ys, ms, warmup=1)
+                for _ in range(3):                           # replays queue behind each other without host syncs
+                    seg.replay(0.0)
+                launched = len(seg.graphs)
+            else:
+                fp.zero_grad()
+                red.begin_step()
+                loss, _ = rollout(model, xs, ys, ms)
+                loss.backward()
+                launched = sum(red._launched)
+                red.finish()
+        torch.cuda.synchronize()
+        out[kind] = fp.grad.cpu().numpy().copy()
+        out[kind + "_launched"] = launched
+    out["backend"] = np.array(dist.get_backend())
+    np.savez(os.path.join(out_dir, "rccl1.npz"), **out)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+def test_one_rank_rccl_collectives_leave_the_gradient_unchanged(tmp_path):
+    """the N > 1 code path with the REAL RCCL library on the one GPU of the test box: a one-rank nccl process group, the
+    bucket all-reduces issued as real collectives on the side stream (hook-driven during an eager backward, and between
+    the replays of the segmented hipGraph chain, three steps queued back to back).  SUM over one rank is the identity, so
+    the flat gradient must equal the plain single-GPU gradient BIT FOR BIT - a missing stream dependency between the
+    backward kernels, the collective and the consumer shows up as a difference"""
+    import torch.multiprocessing as mp
+    mp.spawn(_rccl_worker, args=(_free_port(), str(tmp_path)), nprocs=1, join=True)
+    got = np.load(os.path.join(str(tmp_path), "rccl1.npz"))
+    assert str(got["backend"]) == "nccl"
+    assert np.abs(got["plain"]).max() > 0
+    assert np.array_equal(got["eager"], got["plain"])
+    assert np.array_equal(got["segmented"], got["plain"])
+    assert int(got["eager_launched"]) >= 2 and int(got["segmented_launched"]) >= 2
+
+
 def test_backward_after_optimiser_step_raises():
     """the derived weight packs are persistent buffers; a backward that runs AFTER the optimiser changed the
     parameters would silently use overwritten packs - it must raise instead"""
