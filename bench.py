@@ -534,8 +534,9 @@ def main():
         local_rank = 0
     torch.cuda.set_device(local_rank)
     # DPOT_BENCH_FORCE_DP=1 (1-GPU box): take the N>1 code path with a ONE-rank RCCL communicator - the bucket all-reduces
-    # are real ncclAllReduce launches on the side stream between the graph segments (identity on one rank), so the stream
-    # choreography and RCCL's launch cost are measured on hardware where no second GPU exists
+    # are real calls into torch's ProcessGroupNCCL / RCCL on the side stream between the graph segments.  RCCL enqueues NO
+    # device work for a one-rank in-place all-reduce (rocprofv3 shows no kernel), so what is measured on hardware is the
+    # communicator set-up, the host path and the stream hand-offs of the chain - not a collective's run time
     force_dp = world == 1 and os.environ.get("DPOT_BENCH_FORCE_DP") == "1"
     dp_on = world > 1 or force_dp
     if force_dp:
@@ -591,6 +592,10 @@ def main():
             # N>1: the graph holds fwd+bwd only; the all-reduce and the optimiser run after the replay
             if dp_on and args.no_overlap:
                 graphed = _GraphedFwdBwd(model, opt, xx, yy, msk, args.noise_scale)
+            elif dp_on and os.environ.get("DPOT_DP_ONE_GRAPH") == "1":
+                # opt-in: the WHOLE data-parallel step, bucket all-reduces included, as one hipGraph
+                graphed = GraphedTrainStep(model, opt, xx, yy, msk, noise_scale=args.noise_scale,
+                                           warmup=1 if T_ar > 1 else 2, reducer=reducer, capture_collectives=True)
             elif dp_on:
                 # default N>1 path: hipGraph segments cut at the gradient-bucket boundaries; bucket k is all-reduced
                 # on the side stream while the compute stream replays the backward of the earlier stages
@@ -683,7 +688,7 @@ def main():
                 "backend": dist.get_backend(), "world_size": dist.get_world_size(),
                 "library": ("gloo (DPOT_BENCH_DEBUG_GLOO=1: functional dry run, all ranks on cuda:0 - NOT a performance "
                             "number)") if debug_gloo else f"RCCL {'.'.join(map(str, torch.cuda.nccl.version()))} over xGMI"
-                           + (" (DPOT_BENCH_FORCE_DP=1: ONE-rank communicator on a 1-GPU box - real RCCL launches, no traffic)"
+                           + (" (DPOT_BENCH_FORCE_DP=1: ONE-rank communicator on a 1-GPU box - real calls into RCCL, which enqueues no device work for one rank)"
                               if force_dp else "")}
             out["config"]["per_rank"] = {"ms_per_step_min": round(min(rank_ms), 4), "ms_per_step_max": round(max(rank_ms), 4),
                                          "host_us_per_step_min": round(min(rank_host_us), 1),
@@ -694,6 +699,8 @@ def main():
             out["config"]["buckets_MB"] = [round((hi - lo) * 4 / 1e6, 2) for lo, hi in reducer.ranges]
             out["config"]["dp"] = ("eager, hook-driven bucket all-reduce" if graphed is None else
                                    "one graph + all-reduce after backward" if args.no_overlap else
+                                   f"ONE hipGraph holding the step and its {reducer.n_buckets} bucket all-reduces (side stream "
+                                   f"forked inside the capture; DPOT_DP_ONE_GRAPH=1)" if isinstance(graphed, GraphedTrainStep) else
                                    f"segmented hipGraph chain ({len(graphed.graphs)} segments), bucket all-reduce on a "
                                    f"side stream overlapped with the remaining backward; {reducer.n_buckets} buckets")
         if not dp_on and graphed is not None and args.sustain_seconds > 0 and not args.brief:

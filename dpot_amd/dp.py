@@ -84,8 +84,9 @@ class BucketedGradReducer:
         # call FlatParams.fire(i); (b) ordinary autograd accumulation (foreign graphs) -> post-accumulate hooks
         self._attached = True
         self.dry_run = False                 # world 1 only: go through the motions of the bucket all-reduces (see _launch)
-        # world 1 only: issue the REAL collectives on a one-rank process group (identity) - exercises RCCL's launch path and
-        # the stream hand-offs on a 1-GPU box (tests/test_gpu_train2.py, bench.py DPOT_BENCH_FORCE_DP=1)
+        # world 1 only: issue the collectives for real on a one-rank process group (identity; RCCL enqueues no device work for
+        # one rank) - exercises the communicator, ProcessGroupNCCL's host path and the stream hand-offs on a 1-GPU box
+        # (tests/test_gpu_train2.py, bench.py DPOT_BENCH_FORCE_DP=1)
         self.single_rank_collective = False
         self.skip_zero_tail = True
         flat.callbacks.append(self._on_ready)

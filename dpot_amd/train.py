@@ -340,14 +340,20 @@ class GraphedTrainStep:
 
     def __init__(self, model: nn.Module, opt: FusedAdam, xx: Tensor, yy: Tensor, msk: Optional[Tensor],
                  T_bundle: int = 1, noise_scale: float = 0.0, warmup: int = 2, reducer=None,
-                 grad_scale: float = 1.0):
+                 grad_scale: float = 1.0, capture_collectives: bool = False):
         self.model, self.opt = model, opt
         self.xx, self.yy = xx.clone(), yy.clone()
         self.msk = msk.clone() if msk is not None else None
-        if reducer is not None and getattr(reducer, "world", 1) > 1:
-            raise ValueError("GraphedTrainStep captures the WHOLE step into one graph and cannot hold collectives: "
-                             "use SegmentedTrainStep for data-parallel training")
-        self.reducer, self.grad_scale = None, grad_scale
+        if reducer is not None and getattr(reducer, "world", 1) > 1 and not capture_collectives:
+            raise ValueError("GraphedTrainStep captures the WHOLE step into one graph; pass capture_collectives=True to "
+                             "capture the bucket all-reduces with it, or use SegmentedTrainStep (collectives between graphs)")
+        # capture_collectives (opt-in): the hook-driven bucket all-reduces are issued INSIDE the capture - the reducer's side
+        # stream forks from / joins the capturing stream, RCCL's kernels become nodes of the one graph; no cut in the
+        # autograd graph, no graph launches between the buckets
+        self.reducer = reducer if capture_collectives else None
+        if self.reducer is not None:
+            grad_scale = self.reducer.grad_scale
+        self.grad_scale = grad_scale
         self.T_bundle, self.noise_scale = T_bundle, noise_scale
         # eager warm-up on a side stream (allocator + lazy inits).  The warm-up iterations are NOT training steps:
         # parameters, Adam moments and the step counter are restored afterwards (a fine-tune of a pretrained
@@ -372,8 +378,12 @@ class GraphedTrainStep:
         if stage:
             opt.stage_hyper(opt.lr)
         opt.zero_grad()
+        if self.reducer is not None:
+            self.reducer.begin_step()
         loss, pred = rollout(self.model, self.xx, self.yy, self.msk, self.T_bundle, self.noise_scale)
         loss.backward()
+        if self.reducer is not None:
+            self.reducer.finish()
         opt.launch(self.grad_scale)
         return loss.detach(), pred.detach()
 
