@@ -406,6 +406,201 @@ __global__ __launch_bounds__(704) void gemm_tn192_kernel(const TnArgs p) {
   }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------
+// 96-channel three-product variant (round 5): the AFNO weight gradients of DPOT-Large in the Gauss form of TnArgs::gauss
+//     P1 = Ar^T Br,  P2 = Ai^T Bi,  P3 = (Ar + Ai)^T (Bi - Br)          (three 96 x 96 products instead of 192 x 192)
+// on TWELVE compute waves - product p on waves 4p .. 4p+3 in a 2 x 2 grid of 48 x 48 (3 x 3 accumulators) - + 2 loader
+// waves: 14 waves put 3 compute waves on every SIMD (the 192 x 192 kernel above has 3 / 2 / 2 / 2: its matrix pipes can
+// reach 75 % at best), and the launch executes 3/4 of the FLOPs.  Same slabs ([32 tok][192] per operand, ring of three),
+// same loaders, same split-K.  Fragments: tile e of a wave = 16 consecutive channels, one ds_read_b32 per tile and 4-token
+// step (consecutive lanes, consecutive floats); the P3 waves read both halves of both operands and form the sums on the
+// VALU.  Partials [split][problem][3][96][96] (+ column sums of dO from the P1 / P2 waves) - afno_wgrad2_reduce_body's
+// three-product branch recombines.
+// ---------------------------------------------------------------------------------------------------------------------
+constexpr int TG_BS = 96;
+constexpr int TGS = 208;                     // LDS row stride (floats): 192 + 16 - the four token groups of a ds_read_b32 (rows
+                                             // kq, kq+1, ..) start 16 banks apart; with 192 (= 0 mod 64 banks) they collide 4-way
+constexpr int TG_SLABF = 2 * TN_TOK * TGS;   // floats per slab: A [32][208] | B [32][208]  (3 slabs = 156 KiB)
+constexpr int TG_NI = 32;                    // DMA instructions per slab and loader wave: one token row each (48 lanes x 16 B)
+
+__global__ __launch_bounds__(896) void gemm_tn96g_kernel(const TnArgs p) {
+  __shared__ __attribute__((aligned(16))) float lds[TW_RING * TG_SLABF];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int zb = blockIdx.z / p.splits, zs = blockIdx.z - zb * p.splits;
+  const int nslab_all = p.T / TN_TOK;
+  const int slab0 = zs * p.slabs_per_split;
+  int nslab = nslab_all - slab0;
+  nslab = nslab < p.slabs_per_split ? nslab : p.slabs_per_split;
+  if (nslab < 0) nslab = 0;
+
+  auto bar = [&]() __attribute__((always_inline)) {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+  };
+
+  if (wave >= 12) {
+    // ---------------------------------- loader waves (as in gemm_tn192_kernel) ----------------------------------
+    const int L = wave - 12;
+    const bool second = zb >= p.batch1;
+    const int zq = second ? zb - p.batch1 : zb;
+    const float* abase = (second ? p.A2 : p.A) + zq * p.sA + (long long)slab0 * TN_TOK * p.lda;
+    const float* bbase = (second ? p.B2 : p.B) + zq * p.sB + (long long)slab0 * TN_TOK * p.ldb;
+    auto issue = [&](int t, int ring) __attribute__((always_inline)) {
+      float* dst = lds + ring * TG_SLABF;
+      const float* a = abase + (long long)t * TN_TOK * p.lda + 4 * lane;
+      const float* b = bbase + (long long)t * TN_TOK * p.ldb + 4 * lane;
+      if (lane < 48) {                                  // a token row = 192 floats = 48 lanes x 16 B, padded to TGS in LDS
+#pragma unroll
+        for (int j = 0; j < 16; ++j) tn_glds16(a + (long long)(L + 2 * j) * p.lda, dst + (L + 2 * j) * TGS);
+#pragma unroll
+        for (int j = 0; j < 16; ++j) tn_glds16(b + (long long)(L + 2 * j) * p.ldb, dst + (TN_TOK + L + 2 * j) * TGS);
+      }
+    };
+    if (nslab > 0) issue(0, 0);
+    if (nslab > 1) issue(1, 1);
+    if (nslab > 1) tn_wait_vm<TG_NI>(); else tn_wait_vm<0>();
+    bar();                                              // P
+    int ring = 2;
+#pragma unroll 1
+    for (int g = 0; g < nslab; ++g) {
+      tn_wait_vm<0>();
+      bar();                                            // B_g
+      if (g + 2 < nslab) issue(g + 2, ring);
+      ring = ring == TW_RING - 1 ? 0 : ring + 1;
+    }
+    return;
+  }
+
+  // ---------------------------------- compute waves ----------------------------------
+  const int prod = wave >> 2;                           // 0: Ar^T Br, 1: Ai^T Bi, 2: (Ar + Ai)^T (Bi - Br)
+  const int wm = (wave >> 1) & 1, wn = wave & 1;
+  const int i16 = lane & 15, kq = lane >> 4;
+  tn_f32x4 acc[3][3];
+#pragma unroll
+  for (int ea = 0; ea < 3; ++ea)
+#pragma unroll
+    for (int eb = 0; eb < 3; ++eb) acc[ea][eb] = tn_f32x4{0.f, 0.f, 0.f, 0.f};
+  float cs[3] = {0.f, 0.f, 0.f};
+  const int cs_sel = zb >= p.batch1 ? p.cs_of2 : p.cs_of;
+  const bool cs_a = cs_sel == 1 && prod < 2 && wn == 0;
+  const bool cs_b = cs_sel == 2 && prod < 2 && wm == 0;
+  const int half = prod == 1 ? TG_BS : 0;               // P2 reads the imaginary halves; P3 reads both (half = 0, + TG_BS)
+  const int offA = kq * TGS + half + wm * 48 + i16;
+  const int offB = TN_TOK * TGS + kq * TGS + half + wn * 48 + i16;
+  constexpr int NQ = TN_TOK / 4;
+
+  bar();                                                // P
+  if (prod < 2) {
+    float fa[3] = {0.f, 0.f, 0.f}, fb[3] = {0.f, 0.f, 0.f};
+    if (nslab > 0) {
+#pragma unroll
+      for (int e = 0; e < 3; ++e) {
+        fa[e] = lds[offA + 16 * e];
+        fb[e] = lds[offB + 16 * e];
+      }
+    }
+    int ring = 0;
+#pragma unroll 1
+    for (int g = 0; g < nslab; ++g) {
+      bar();                                            // B_g
+      const float* cur = lds + ring * TG_SLABF;
+      const int rn = ring == TW_RING - 1 ? 0 : ring + 1;
+      const float* nxt = g + 1 < nslab ? lds + rn * TG_SLABF : cur;
+#pragma unroll
+      for (int q = 0; q < NQ; ++q) {
+        float a[3], b[3];
+        const float* src = q + 1 < NQ ? cur + (q + 1) * 4 * TGS : nxt;
+#pragma unroll
+        for (int e = 0; e < 3; ++e) {
+          a[e] = fa[e];
+          b[e] = fb[e];
+          fa[e] = src[offA + 16 * e];
+          fb[e] = src[offB + 16 * e];
+        }
+        if (cs_a) { cs[0] += a[0]; cs[1] += a[1]; cs[2] += a[2]; }
+        if (cs_b) { cs[0] += b[0]; cs[1] += b[1]; cs[2] += b[2]; }
+#pragma unroll
+        for (int ea = 0; ea < 3; ++ea)
+#pragma unroll
+          for (int eb = 0; eb < 3; ++eb)
+            acc[ea][eb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[ea], b[eb], acc[ea][eb], 0, 0, 0);
+      }
+      ring = rn;
+    }
+  } else {
+    float far[3] = {0.f, 0.f, 0.f}, fai[3] = {0.f, 0.f, 0.f}, fbr[3] = {0.f, 0.f, 0.f}, fbi[3] = {0.f, 0.f, 0.f};
+    if (nslab > 0) {
+#pragma unroll
+      for (int e = 0; e < 3; ++e) {
+        far[e] = lds[offA + 16 * e];
+        fai[e] = lds[offA + TG_BS + 16 * e];
+        fbr[e] = lds[offB + 16 * e];
+        fbi[e] = lds[offB + TG_BS + 16 * e];
+      }
+    }
+    int ring = 0;
+#pragma unroll 1
+    for (int g = 0; g < nslab; ++g) {
+      bar();                                            // B_g
+      const float* cur = lds + ring * TG_SLABF;
+      const int rn = ring == TW_RING - 1 ? 0 : ring + 1;
+      const float* nxt = g + 1 < nslab ? lds + rn * TG_SLABF : cur;
+#pragma unroll
+      for (int q = 0; q < NQ; ++q) {
+        float a[3], b[3];
+        const float* src = q + 1 < NQ ? cur + (q + 1) * 4 * TGS : nxt;
+#pragma unroll
+        for (int e = 0; e < 3; ++e) {
+          a[e] = far[e] + fai[e];
+          b[e] = fbi[e] - fbr[e];
+          far[e] = src[offA + 16 * e];
+          fai[e] = src[offA + TG_BS + 16 * e];
+          fbr[e] = src[offB + 16 * e];
+          fbi[e] = src[offB + TG_BS + 16 * e];
+        }
+#pragma unroll
+        for (int ea = 0; ea < 3; ++ea)
+#pragma unroll
+          for (int eb = 0; eb < 3; ++eb)
+            acc[ea][eb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[ea], b[eb], acc[ea][eb], 0, 0, 0);
+      }
+      ring = rn;
+    }
+  }
+
+  // partial tile: element (row = wm*48 + 16*ea + 4*kq + r, col = wn*48 + 16*eb + i16) of product `prod`
+  float* ws = p.ws + (((long long)zs * p.batch + zb) * 3 + prod) * (TG_BS * TG_BS);
+#pragma unroll
+  for (int ea = 0; ea < 3; ++ea)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      float* row = ws + (long long)(wm * 48 + 16 * ea + 4 * kq + r) * TG_BS + wn * 48 + i16;
+#pragma unroll
+      for (int eb = 0; eb < 3; ++eb) row[16 * eb] = acc[ea][eb][r];
+    }
+  if (cs_a || cs_b) {
+    // lanes with equal i16 hold the sums over the tokens = kq (mod 4): fixed-order butterfly over kq
+#pragma unroll
+    for (int e = 0; e < 3; ++e) {
+      float v = cs[e];
+      v += __shfl_xor(v, 16);
+      v += __shfl_xor(v, 32);
+      cs[e] = v;
+    }
+    if (kq == 0) {
+      const int Lc = p.csL ? p.csL : (cs_a ? p.N1 : p.N2);
+      const int g0 = half + (cs_a ? wm : wn) * 48 + i16;
+      float* wc = p.ws + (long long)p.splits * p.batch * (3ll * TG_BS * TG_BS) + ((long long)zs * p.batch + zb) * Lc + g0;
+#pragma unroll
+      for (int e = 0; e < 3; ++e) wc[16 * e] = cs[e];
+    }
+  }
+}
+
 }  // namespace dpot
 
 using namespace dpot;
@@ -536,7 +731,9 @@ __global__ __launch_bounds__(256) void afno_wgrad2_reduce_kernel(const float* __
 // three-product form of the AFNO weight gradient (TnArgs::gauss): 128 channels per block; DPOT_AFNO_WGRAD_GAUSS=0: four products
 static int tn_gauss(int bs) {
   static const int enabled = [] { const char* e = getenv("DPOT_AFNO_WGRAD_GAUSS"); return e ? atoi(e) : 1; }();
-  return enabled && bs == TN_W ? 1 : 0;
+  // 96 channels per block (DPOT-Large): gemm_tn96g_kernel; DPOT_AFNO_WGRAD_GAUSS96=0: the 192 x 192 four-product kernel
+  static const int enabled96 = [] { const char* e = getenv("DPOT_AFNO_WGRAD_GAUSS96"); return e ? atoi(e) : 1; }();
+  return enabled && (bs == TN_W || (bs == TG_BS && enabled96)) ? 1 : 0;
 }
 }  // namespace dpot
 
@@ -588,7 +785,10 @@ extern "C" int dpot_afno_wgrad2(const float* S, const float* dO1pre, const float
   hipStream_t s = as_stream(stream);
   if (N == TW) {
     p.tiles1 = p.tiles2 = 1;
-    hipLaunchKernelGGL(gemm_tn192_kernel, dim3(1, 1, (unsigned)(2 * nb * splitk)), dim3(704), 0, s, p);
+    if (p.gauss)
+      hipLaunchKernelGGL(gemm_tn96g_kernel, dim3(1, 1, (unsigned)(2 * nb * splitk)), dim3(896), 0, s, p);
+    else
+      hipLaunchKernelGGL(gemm_tn192_kernel, dim3(1, 1, (unsigned)(2 * nb * splitk)), dim3(704), 0, s, p);
   } else {
     hipLaunchKernelGGL(gemm_tn_kernel, dim3((unsigned)(p.gauss ? 3 : p.tiles1 * p.tiles2), 1, (unsigned)(2 * nb * splitk)),
                        dim3(384), 0, s, p);

@@ -50,6 +50,11 @@ def mlp(T, E, mh, nsets):
         print(f"  mlp_wgrad2 T={T} E={E} mh={mh} sets={nsets} splitk={sk:2d}{'*' if sk == auto else ' '} {t*1e6:7.1f} us  {fl/t/1e12:6.1f} TF", flush=True)
 
 
+if len(sys.argv) > 1 and sys.argv[1] == "L":
+    # DPOT-Large at 256 x 256, batch 16: 32 x 17 kept modes per sample, 16 blocks of 96 channels (DPOT_AFNO_WGRAD_GAUSS96=0/1)
+    print(f"DPOT-L B=16 AFNO weight gradients, DPOT_AFNO_WGRAD_GAUSS96={os.environ.get('DPOT_AFNO_WGRAD_GAUSS96', '1')}")
+    afno(16 * 32 * 17, 16, 96, 1536, 3)
+    sys.exit(0)
 print("DPOT-Tiny B=32 (kernel + reduce launch per call)")
 for nsets in (1, 5):
     afno(4608, 4, 128, 512, nsets)

@@ -26,7 +26,9 @@ SWITCHES = {
     # BD=0: the LDS-DMA kernels of rounds 2-3 in their own default selection (two-workgroup kernel, 128 x 192 tiles, pairs)
     # (DPOT_BF16P_ROWFORM=1, an opt-IN riding along: it only acts on the B-direct pair launch, which BD=0 switches off - so it
     # gets the DPOT-M case of its own below)
-    "DPOT_BF16P_BD=0": (LARGE_SET, False),
+    # (DPOT_AFNO_WGRAD_GAUSS96=0 rides along: the 192 x 192 four-product AFNO weight-gradient kernel that gemm_tn96g_kernel
+    # replaced at 96 channels per block - only DPOT-L has that shape)
+    "DPOT_BF16P_BD=0 DPOT_AFNO_WGRAD_GAUSS96=0": (LARGE_SET, False),
     # round 5 defaults switched OFF: four-product AFNO weight gradients, the separate pack passes of the bf16 channel MLP (no packs
     # from the one-launch AFNO layer / the GroupNorm backward) - the forms these replaced stay under the gate
     "DPOT_AFNO_WGRAD_GAUSS=0 DPOT_GRAD_PACKS=0 DPOT_AFNO_LAYER_PACKS=0":
