@@ -601,6 +601,9 @@ static inline int try_rfft2_fast(const float* x, float* spec, int B, int h, int 
     // 32-channel chunks (full 128-byte lines per token, 139 KiB of LDS: one workgroup per CU) when that still gives
     // >= 128 workgroups: 18.0 against 22.7 us at DPOT-L B = 4 (the inverse is FASTER with 16: 29.8 against 42.5 us)
     // 12-channel chunks: 512 balanced workgroups at DPOT-L B = 4 (see the inverse below) - 15.7 us (32: 18.1, 16: 22.7)
+    // round 5, DPOT-L at batch 16: with >= 2 rounds of 32-channel workgroups the full lines win again (step 90.40 -> 90.22,
+    // 90.63 -> 90.11 ms, profiles/r05_dft_cc_L.txt; 16-channel chunks: +1.0 ms)
+    if (forced != 16 && forced != 12 && E % 32 == 0 && (long long)B * (E / 32) >= 512) { *rc = launch_rfft2_fast<32, 32, 32>(x, spec, B, E, nb, mx, my, colw, scale, s, nrm); return 1; }
     if (forced != 16 && forced != 32 && E % 12 == 0 && (E / nb) % 12 == 0 && (long long)B * (E / 12) >= 256) { *rc = launch_rfft2_fast<32, 32, 12>(x, spec, B, E, nb, mx, my, colw, scale, s, nrm); return 1; }
     if (forced != 16 && E % 32 == 0 && (long long)B * (E / 32) >= 128) { *rc = launch_rfft2_fast<32, 32, 32>(x, spec, B, E, nb, mx, my, colw, scale, s, nrm); return 1; }
     if (E % 16 == 0) { *rc = launch_rfft2_fast<32, 32, 16>(x, spec, B, E, nb, mx, my, colw, scale, s, nrm); return 1; }
@@ -636,6 +639,7 @@ static inline int try_irfft2_fast(const float* spec, const float* res, float* y,
   } else if (h == 32 && w == 32) {
     // 12-channel chunks when the blocks allow it: 512 workgroups = 2 per CU at DPOT-L B = 4 (E = 1536) instead of the
     // 384 of 16-channel chunks (1.5 per CU: half the CUs run two in a row) - 20.4 against 29.8 us
+    // (32-channel chunks for the inverse, one workgroup per CU: +4 ms on the DPOT-L step at batch 16, profiles/r05_dft_cc_L.txt)
     if (forced != 16 && E % 12 == 0 && (E / nb) % 12 == 0 && (long long)B * (E / 12) >= 256) { *rc = launch_irfft2_fast<32, 32, 12>(spec, res, y, B, E, nb, mx, my, colw, scale, s, nrm); return 1; }
     if (E % 16 == 0) { *rc = launch_irfft2_fast<32, 32, 16>(spec, res, y, B, E, nb, mx, my, colw, scale, s, nrm); return 1; }
   } else if (h == 24 && w == 24) {
