@@ -22,6 +22,7 @@
 //   * bias gradients (column sums of one operand over the tokens) come from the fragments the waves read anyway.
 #include "common.h"
 #include "gemm_epi.h"
+#include <string.h>
 
 namespace dpot {
 
@@ -48,6 +49,11 @@ struct TnArgs {
   // 256 columns of both operands in 16-token slabs (the same 32 KiB per slab) and forms the two sums on the fragments;
   // partials [split][batch][3][128][128]
   int gauss;
+  // three-product form on gemm_tn_kernel (128 channels per block): the sum-product tile is the slowest of the three (four fragment
+  // reads and the VALU sums per step, twice the barriers), so it gets SHORTER token ranges: it is cut into `splits` ranges, the
+  // tiles P1 / P2 into splits12 <= splits (the partial slots zs >= splits12 of those tiles are neither written nor read).
+  // splits12 = splits elsewhere
+  int splits12, slabs_per_split12;
 };
 
 constexpr int TN_TOK = 32;                 // tokens per slab
@@ -73,20 +79,32 @@ __global__ __launch_bounds__(384) void gemm_tn_kernel(const TnArgs p) {
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
 
   const int ntiles = p.tiles1 * p.tiles2;
-  int tile;
-  {
+  int tile, zb, zs;
+  if (p.gauss) {
+    // three-product form: a ONE-dimensional grid of exactly the workgroups that have work - per problem splits12 token ranges of
+    // P1, splits12 of P2, `splits` of the sum-product tile (the hardware deals consecutive workgroups to the 8 XCDs in turn: a grid
+    // with idle members leaves some XCD with more than its 32 workgroups and the launch with a second round)
+    const int W = 2 * p.splits12 + p.splits;
+    const int lin = blockIdx.x;
+    zb = lin / W;
+    const int r = lin - zb * W;
+    tile = r < p.splits12 ? 0 : r < 2 * p.splits12 ? 1 : 2;
+    zs = r - (tile == 2 ? 2 * p.splits12 : tile * p.splits12);
+  } else {
     const int bid = blockIdx.x, xcd = bid & 7, slot = bid >> 3;
     const int q = ntiles >> 3, r = ntiles & 7;
     tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + slot;
+    zb = blockIdx.z / p.splits;
+    zs = blockIdx.z - zb * p.splits;
   }
   int t1 = tile / p.tiles2, t2 = tile - t1 * p.tiles2;
   const bool g3 = p.gauss && tile == 2;                 // the sum-product tile of the three-product form
   if (p.gauss) t1 = t2 = (tile == 1 ? 1 : 0);
-  const int zb = blockIdx.z / p.splits, zs = blockIdx.z - zb * p.splits;
   const int nslab_all = p.T / TN_TOK;
-  int slab0 = zs * p.slabs_per_split;
+  const int sps = p.gauss && !g3 ? p.slabs_per_split12 : p.slabs_per_split;
+  int slab0 = zs * sps;
   int nslab = nslab_all - slab0;
-  nslab = nslab < p.slabs_per_split ? nslab : p.slabs_per_split;
+  nslab = nslab < sps ? nslab : sps;
   if (nslab < 0) nslab = 0;
   if (g3) {                                             // 16-token slabs: twice as many over the same token range
     slab0 *= 2;
@@ -645,7 +663,7 @@ int dpot_gemm_tn_try(const dpot_gemm_desc* d, hipStream_t s) {
   if ((long long)p.slabs_per_split * (d->splitk - 1) >= nslab) return -1;      // an empty split would leave its partial unwritten
   p.ws = d->workspace;
   p.cs_of = d->colsum_of;
-  p.gauss = 0;
+  p.gauss = 0; p.splits12 = p.splits; p.slabs_per_split12 = p.slabs_per_split;
   hipLaunchKernelGGL(gemm_tn_kernel, dim3((unsigned)(p.tiles1 * p.tiles2), 1, (unsigned)(d->batch * d->splitk)), dim3(384),
                      0, s, p);
   return check_launch("gemm_tn_kernel");
@@ -697,9 +715,10 @@ __device__ __forceinline__ void afno_wgrad2_reduce_body(int bid, int nblk, const
     const float* base = ws + (long long)(layer * nb + k) * MN;
     float* dw = layer ? dw2 : dw1;
     if (gauss) {     // P1 = Ar^T Br, P2 = Ai^T Bi, P3 = (Ar + Ai)^T (Bi - Br): dWr = P1 + P2, dWi = P3 + P1 - P2
+      // (gauss = the number of token ranges of P1 / P2 and of the column sums, TnArgs::splits12 - <= splits)
       const long long e = (long long)i * bs + o, t = (long long)bs * bs;
-      const float p1 = tn_sum_splits(base + e, total, splits);
-      const float p2 = tn_sum_splits(base + t + e, total, splits);
+      const float p1 = tn_sum_splits(base + e, total, gauss);
+      const float p2 = tn_sum_splits(base + t + e, total, gauss);
       const float p3 = tn_sum_splits(base + 2 * t + e, total, splits);
       dw[q] = p1 + p2;
       dw[nw + q] = p3 + p1 - p2;
@@ -715,7 +734,7 @@ __device__ __forceinline__ void afno_wgrad2_reduce_body(int bid, int nblk, const
   const float* wc = ws + (long long)splits * total;
   const long long nc = (long long)2 * nb * n2;
   for (long long idx = bid * 256ll + threadIdx.x; idx < nc; idx += (long long)nblk * 256) {
-    const float v = tn_sum_splits(wc + idx, nc, splits);
+    const float v = tn_sum_splits(wc + idx, nc, gauss ? gauss : splits);
     const int layer = idx >= (long long)nb * n2;
     const long long q = idx - (long long)layer * nb * n2;
     const int c = (int)(q % bs), part = (int)((q / bs) & 1), k = (int)(q / n2);
@@ -735,6 +754,16 @@ static int tn_gauss(int bs) {
   static const int enabled96 = [] { const char* e = getenv("DPOT_AFNO_WGRAD_GAUSS96"); return e ? atoi(e) : 1; }();
   return enabled && (bs == TN_W || (bs == TG_BS && enabled96)) ? 1 : 0;
 }
+// token ranges of the tiles P1 / P2 when the sum-product tile is cut into `splitk` (TnArgs::splits12): 5/6 of them at 128 channels
+// per block (DPOT_TN_GAUSS_SKEW="num/den" changes the ratio, "1/1" = equal ranges); the 96-channel kernel computes the three
+// products in one workgroup
+static int tn_gauss_s12(int bs, int splitk) {
+  static const int num = [] { const char* e = getenv("DPOT_TN_GAUSS_SKEW"); return e ? atoi(e) : 5; }();
+  static const int den = [] { const char* e = getenv("DPOT_TN_GAUSS_SKEW"); const char* q = e ? strchr(e, '/') : nullptr; return q ? atoi(q + 1) : 6; }();
+  if (bs != TN_W || num <= 0 || den <= 0 || num >= den) return splitk;
+  const int s = splitk * num / den;
+  return s < 1 ? 1 : s;
+}
 }  // namespace dpot
 
 extern "C" int dpot_afno_wgrad2_splitk(int Mm, int nb, int bs) {
@@ -747,6 +776,14 @@ extern "C" int dpot_afno_wgrad2_splitk(int Mm, int nb, int bs) {
   // at DPOT-Tiny; rounded to 11 the launch needs a second round: 75 against 59 us, profiles/r05_tn_bench_gauss.txt)
   long long s = tn_gauss(bs) && N != TW ? 256 / tiles : (256 + tiles / 2) / tiles;
   const long long smax = nslab / 4;
+  if (tn_gauss(bs) && N != TW) {
+    // skewed ranges: the largest split count whose 2 * s12 + s workgroups per problem still fit one round of 256
+    // (DPOT-Tiny: 8 problems x (10 + 10 + 12), DPOT-S / -M: 16 x (5 + 5 + 6))
+    long long best = 1;
+    for (long long c = 1; c <= smax && c <= 64; ++c)
+      if (2ll * nb * (2 * tn_gauss_s12(bs, (int)c) + c) <= 256) best = c;
+    s = best;
+  }
   if (s > smax) s = smax;
   if (s < 1) s = 1;
   // no empty split
@@ -782,6 +819,8 @@ extern "C" int dpot_afno_wgrad2(const float* S, const float* dO1pre, const float
   p.ws = workspace;
   p.cs_of = 2;
   p.gauss = tn_gauss(bs);
+  p.splits12 = p.gauss ? tn_gauss_s12(bs, splitk) : splitk;
+  p.slabs_per_split12 = (nslab + p.splits12 - 1) / p.splits12;
   hipStream_t s = as_stream(stream);
   if (N == TW) {
     p.tiles1 = p.tiles2 = 1;
@@ -790,15 +829,17 @@ extern "C" int dpot_afno_wgrad2(const float* S, const float* dO1pre, const float
     else
       hipLaunchKernelGGL(gemm_tn192_kernel, dim3(1, 1, (unsigned)(2 * nb * splitk)), dim3(704), 0, s, p);
   } else {
-    hipLaunchKernelGGL(gemm_tn_kernel, dim3((unsigned)(p.gauss ? 3 : p.tiles1 * p.tiles2), 1, (unsigned)(2 * nb * splitk)),
-                       dim3(384), 0, s, p);
+    if (p.gauss)
+      hipLaunchKernelGGL(gemm_tn_kernel, dim3((unsigned)(2 * nb * (2 * p.splits12 + splitk))), dim3(384), 0, s, p);
+    else
+      hipLaunchKernelGGL(gemm_tn_kernel, dim3((unsigned)(p.tiles1 * p.tiles2), 1, (unsigned)(2 * nb * splitk)), dim3(384), 0, s, p);
   }
   int rc = check_launch("gemm_tn_kernel");
   if (rc || !dw1) return rc;            // dw1 == NULL: partials only, dpot_block_finalize reduces them
   long long blocks = (2ll * nb * bs * bs + 255) / 256;
   if (blocks > 4096) blocks = 4096;
   hipLaunchKernelGGL(afno_wgrad2_reduce_kernel, dim3((unsigned)blocks), dim3(256), 0, s, (const float*)workspace, splitk, nb,
-                     bs, dw1, db1, dw2, db2, p.gauss);
+                     bs, dw1, db1, dw2, db2, p.gauss ? p.splits12 : 0);
   return check_launch("afno_wgrad2_reduce_kernel");
 }
 
@@ -986,7 +1027,7 @@ extern "C" int dpot_mlp_wgrad2(const float* do2, const float* Hh, const float* x
   DPOT_REQUIRE((long long)p.slabs_per_split * (splitk - 1) < nslab, "mlp_wgrad2: split factor leaves an empty split");
   p.ws = workspace;
   p.cs_of = 1; p.cs_of2 = 2; p.csL = E > mh ? E : mh;
-  p.gauss = 0;
+  p.gauss = 0; p.splits12 = p.splits; p.slabs_per_split12 = p.slabs_per_split;
   hipStream_t s = as_stream(stream);
   hipLaunchKernelGGL(gemm_tn_kernel, dim3((unsigned)(p.tiles1 * p.tiles2), 1, (unsigned)(2 * splitk)), dim3(384), 0, s, p);
   int rc = check_launch("gemm_tn_kernel");
@@ -1015,7 +1056,7 @@ extern "C" int dpot_block_finalize(const float* afno_ws, int afno_splitk, int nb
   }
   if (afno_ws) {
     DPOT_REQUIRE(afno_splitk >= 1 && nb > 0 && bs > 0 && dw1 && db1 && dw2 && db2, "block_finalize: bad AFNO slice");
-    a.a_ws = afno_ws; a.a_splits = afno_splitk; a.a_nb = nb; a.a_bs = bs; a.a_gauss = tn_gauss(bs); a.a_dw1 = dw1; a.a_db1 = db1; a.a_dw2 = dw2; a.a_db2 = db2;
+    a.a_ws = afno_ws; a.a_splits = afno_splitk; a.a_nb = nb; a.a_bs = bs; a.a_gauss = tn_gauss(bs) ? tn_gauss_s12(bs, afno_splitk) : 0; a.a_dw1 = dw1; a.a_db1 = db1; a.a_dw2 = dw2; a.a_db2 = db2;
     long long blocks = (2ll * nb * bs * bs + 255) / 256;            // as dpot_afno_wgrad2
     a.nA = (int)(blocks > 4096 ? 4096 : blocks);
   }
