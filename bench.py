@@ -49,6 +49,7 @@ CONFIGS = {
 # GEMMs, embed fold: same accuracy class as native fp32, DESIGN.md "GEMM precision modes"; parity at these sizes incl. the
 # DPOT-L batch-16 reference golden at rtol 1e-4 runs under it in tests/test_gpu_optout.py) - and report the all-native figure
 # beside it (`gemm_f32`)
+L20_KEEP_LAST = 8                  # AR steps of the L20 rollout that keep their activations: 112.4 GiB + 17.15 GiB each -> 249.6 of 288 GiB (profiles/r05_l20_keep_last.txt)
 CONFIG_GEMM = {"T": "f32", "S": "auto", "M": "auto", "L": "auto", "L20": "auto"}
 FP32_MFMA_PEAK_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
 BF16_MFMA_PEAK_TFLOPS = 2500.0     # MI355X_MICROARCH.md: dense bf16 MFMA
@@ -564,6 +565,10 @@ def main():
     model.mlp_precision = mlp_prec                             # per-model attributes (None: the process default = f32)
     model.gemm_precision = args.gemm_precision
     model.recompute_blocks = recompute
+    # selective recomputation: the last KEEP_LAST AR steps of the rollout keep their activations (their backward runs first and
+    # frees them before the first recomputation) - free HBM spent on time; DPOT_BENCH_KEEP_LAST overrides
+    keep_last = int(os.environ.get("DPOT_BENCH_KEEP_LAST", L20_KEEP_LAST if (recompute and T_ar > 1) else 0))
+    model.recompute_keep_last = keep_last
     fp = FlatParams(model)
     # DDP semantics for N>1: cls_head takes part (zero gradients -> weight decay only), grads averaged over ranks
     opt = FusedAdam(fp, lr=1e-3, betas=(0.9, 0.9), weight_decay=1e-6, max_norm=10000.0, update_tail=dp_on)
@@ -679,7 +684,8 @@ def main():
                        "per_gpu_batch": B, "global_batch": B * world, "parallelism": f"dp{world}",
                        "launch": mode, "noise_scale": args.noise_scale, "final_loss": round(final_loss, 5),
                        "gemm_precision": args.gemm_precision, "mlp_precision": mlp_prec or args.gemm_precision,
-                       "activation_recomputation": recompute,
+                       "activation_recomputation": (f"all but the last {keep_last} of {T_ar} AR steps" if recompute and keep_last
+                                                    else recompute),
                        "peak_mem_GB": round(torch.cuda.max_memory_allocated() / 2 ** 30, 2)},
         }
         out["config"]["host_us_per_step"] = round(max(rank_host_us), 1)

@@ -121,6 +121,12 @@ class DPOTNet(nn.Module):
         # activation recomputation inside every Block (functional.BlockFn): keep only block inputs between forward
         # and backward - for long auto-regressive rollouts at 256^2 (BASELINE configs[4])
         self.recompute_blocks = False
+        # selective recomputation in an auto-regressive rollout (train.rollout tells the model which AR step a call is): the LAST
+        # `recompute_keep_last` AR steps keep their activations like an ordinary forward - their backward runs first and frees them
+        # before the first recomputation, so the peak stays at the end of the forward - and skip the second forward pass
+        # (bit-identical either way; spends free HBM on time: DPOT-L, 20 steps, batch 16: 112 GB with 0 kept)
+        self.recompute_keep_last = 0
+        self._ar_pos = None                          # (index, count) of the current AR step, set by train.rollout
         # precision of the channel-MLP GEMMs of THIS model: None = the process default (ops.set_mlp_precision /
         # DPOT_MLP_PRECISION), or 'f32' | 'bf16x6' | 'auto' | 'bf16' (BASELINE configs[2]: "bf16 channel-MLP on MFMA")
         self.mlp_precision = None
@@ -284,6 +290,9 @@ class DPOTNet(nn.Module):
         if self.normalize:
             lat = AdaINFn.apply(lat, s_sigma, s_mu)                     # AdaIN (models/dpot.py:386-387)
         recompute = self.recompute_blocks and torch.is_grad_enabled()
+        if recompute and self.recompute_keep_last > 0 and self._ar_pos is not None \
+                and self._ar_pos[0] >= self._ar_pos[1] - self.recompute_keep_last:
+            recompute = False
         hook = self._boundary_hook
         for i, blk in enumerate(self.blocks):
             cut = False

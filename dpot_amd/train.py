@@ -253,7 +253,11 @@ def _rollout(model, xx, yy, msk, T_bundle, noise_scale, noise):
     preds = []
     T_ar = yy.shape[-2]
     xx = ops._req(xx.contiguous(), "xx")
+    n_steps = len(range(0, T_ar, T_bundle))
+    tell = hasattr(model, "_ar_pos")
     for k, t in enumerate(range(0, T_ar, T_bundle)):
+        if tell:
+            model._ar_pos = (k, n_steps)            # DPOTNet.recompute_keep_last: which AR steps keep their activations
         y = yy[..., t:t + T_bundle, :]
         if noise_scale != 0.0:
             if noise is None and not xx.requires_grad and xx.numel() % 4 == 0:
@@ -267,6 +271,8 @@ def _rollout(model, xx, yy, msk, T_bundle, noise_scale, noise):
         preds.append(im)
         if t + T_bundle < T_ar:
             xx = _SlideFn.apply(xx, im)
+    if tell:
+        model._ar_pos = None
     pred = preds[0] if len(preds) == 1 else torch.cat(preds, dim=-2)
     return loss, pred
 

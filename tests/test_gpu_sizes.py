@@ -500,12 +500,13 @@ def _oracle_rollout_ckpt(sd, xx, yy, msk, cfg):
     return loss, torch.cat(preds, dim=-2)
 
 
-def _gpu_rollout_grads(kw, salt, xx, yy, msk, recompute):
+def _gpu_rollout_grads(kw, salt, xx, yy, msk, recompute, keep_last=0):
     from dpot_amd.train import FlatParams, FusedAdam, rollout
     torch.cuda.empty_cache()
     torch.cuda.reset_peak_memory_stats()
     m, _ = build(kw, salt=salt)
     m.recompute_blocks = recompute
+    m.recompute_keep_last = keep_last
     fp = FlatParams(m)
     opt = FusedAdam(fp, lr=1e-3, betas=(0.9, 0.9), weight_decay=1e-6, max_norm=10000.0)
     opt.zero_grad()
@@ -546,6 +547,12 @@ def test_large_20_step_rollout_vs_reference_golden():
     assert res[True][0] == res[False][0]
     assert torch.equal(res[True][1], res[False][1]), "recomputation must not change a single bit"
     assert res[True][2] < 0.6 * res[False][2], "recomputation should cut the activation memory"
+    # selective recomputation (DPOTNet.recompute_keep_last: the last AR steps keep their activations - what `bench.py --config L20`
+    # runs): same bits, memory between the two
+    loss, gn, norms, pred, flat, peak = _gpu_rollout_grads(R.LARGE, 6, xx, yy, msk, True, keep_last=7)
+    print(f"[LARGE T_ar={T_ar} B={B}] recompute all but the last 7 AR steps: peak memory {peak:.2f} GiB")
+    assert loss == res[True][0] and torch.equal(flat, res[True][1])
+    assert res[True][2] < peak < res[False][2]
 
 
 @pytest.mark.parametrize("name,B", REF_GOLDEN_CASES)
