@@ -210,17 +210,21 @@ def test_segmented_graph_step_equals_eager_step_bf16_small(monkeypatch):
     m1.mlp_precision = "bf16"
     xx, yy, msk = _batch(cfg, 4, T_ar=1)
     opt1 = _opt(m1, update_tail=True)
+    eager = []
     for lr in (1e-3, 2e-3):
         l_e, _ = train_step(m1, opt1, xx, yy, msk, lr=lr)
+        eager.append(l_e.item())
     m2, _ = build(R.SMALL, salt=3)
     m2.mlp_precision = "bf16"
     opt2 = _opt(m2, update_tail=True)
     red = BucketedGradReducer(opt2.fp, n_buckets=4, overlap=True)
     seg = SegmentedTrainStep(m2, opt2, red, xx, yy, msk, warmup=1)
     assert len(seg.graphs) >= 2
-    for lr in (1e-3, 2e-3):
-        l_s = seg.replay(lr)
-    assert l_s.item() == l_e.item()
+    losses = [seg.replay(lr).item() for lr in (1e-3, 2e-3)]
+    # the SECOND step's loss is a function of the first step's parameters, which differ in the last bit of six bias gradients
+    # (below): equal to fp32 rounding, not bit for bit (2e-7 relative observed)
+    assert losses[0] == eager[0]                                       # same parameters, same forward: same bits
+    assert abs(losses[1] - eager[1]) <= 1e-6 * abs(eager[1]), (losses, eager)
     # (not bit for bit here: the Block behind a cut packs its incoming gradient itself, and that pass forms the fc2 bias
     # column sums per 64 tokens where the GroupNorm backward of the un-cut chain forms them per sample - fp32 rounding of
     # six bias gradients; everything else is the same arithmetic)
