@@ -267,17 +267,22 @@ def bf16_mlp_roofline(model, B: int):
     fl = 2.0 * M * mh * E
     npk = 2 if rowform else 3
     by = 2.0 * M * E + 2.0 * mh * E + npk * 2.0 * M * mh          # packed A + packed W read once, the bf16 packs written
-    traffic, tnote, util = None, "no PMC profile for this shape (profiles/r05_pmc_bf16p_M.json holds DPOT-M, batch 32)", None
-    try:
-        pmc = json.load(open(os.path.join(ROOT, "profiles", "r05_pmc_bf16p_M.json")))["forms"]["fc1_fwd"]
-        if (M, E, mh) == (8192, 1024, 4096):
+    traffic, tnote, util = None, "no PMC profile for this shape (profiles/r05_pmc_bf16p_{S,M,L16}.json)", None
+    for tag in ("M", "L16", "S"):                        # counter profiles by shape (scripts/gpu_pmc_bf16p_r05.sh SHAPE)
+        try:
+            doc = json.load(open(os.path.join(ROOT, "profiles", f"r05_pmc_bf16p_{tag}.json")))
+            sh = doc["shape"]
+            if (M, E, mh) != (sh["tokens"], sh["E"], sh["hidden"]):
+                continue
+            pmc = doc["forms"]["fc1_fwd"]
             traffic = float(pmc["bytes_guide"])
             util = pmc.get("mfma_util")
-            tnote = ("rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes (profiles/r05_pmc_bf16p_M.json): (2*FETCH + "
+            tnote = (f"rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes (profiles/r05_pmc_bf16p_{tag}.json): (2*FETCH + "
                      "WRITE)*1024 B; un-doubled %.0f MB; algorithmic = A pack + W pack read once + three bf16 packs written"
                      % (pmc["bytes_raw"] / 1e6))
-    except Exception:
-        pass
+            break
+        except Exception:
+            continue
     kname = ops.gemm_bf16p_kernel_name(M, mh, E, packed_outputs=True)       # the library's own selection
     return {"kernel": kname + " - channel-MLP fc1 forward: bf16 operands pre-packed fragment-block-major, "
                       "v_mfma_f32_32x32x16_bf16, epilogue in the accumulator layout writes the activated hidden layer as a row-form "
