@@ -49,7 +49,6 @@ CONFIGS = {
 # GEMMs, embed fold: same accuracy class as native fp32, DESIGN.md "GEMM precision modes"; parity at these sizes incl. the
 # DPOT-L batch-16 reference golden at rtol 1e-4 runs under it in tests/test_gpu_optout.py) - and report the all-native figure
 # beside it (`gemm_f32`)
-L20_KEEP_LAST = 8                  # AR steps of the L20 rollout that keep their activations: 112.4 GiB + 17.15 GiB each -> 249.6 of 288 GiB (profiles/r05_l20_keep_last.txt)
 CONFIG_GEMM = {"T": "f32", "S": "auto", "M": "auto", "L": "auto", "L20": "auto"}
 FP32_MFMA_PEAK_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
 BF16_MFMA_PEAK_TFLOPS = 2500.0     # MI355X_MICROARCH.md: dense bf16 MFMA
@@ -572,7 +571,15 @@ def main():
     model.recompute_blocks = recompute
     # selective recomputation: the last KEEP_LAST AR steps of the rollout keep their activations (their backward runs first and
     # frees them before the first recomputation) - free HBM spent on time; DPOT_BENCH_KEEP_LAST overrides
-    keep_last = int(os.environ.get("DPOT_BENCH_KEEP_LAST", L20_KEEP_LAST if (recompute and T_ar > 1) else 0))
+    keep_last = 0
+    if recompute and T_ar > 1:
+        # what fits: the rollout with every step recomputed peaks at ~7.0 GiB per sample, a kept step costs ~1.07 GiB per sample
+        # (measured at batch 16: 112.4 and 17.15 GiB); leave 30 GiB of the free memory alone (batch 16 on an empty 288 GiB card: 8)
+        Bq = args.batch if args.batch is not None else cB
+        free_gib = torch.cuda.mem_get_info()[0] / 2 ** 30
+        fit = int((free_gib - 30.0 - 7.03 * Bq) / (1.072 * Bq))
+        keep_last = max(0, min(fit, T_ar))
+    keep_last = int(os.environ.get("DPOT_BENCH_KEEP_LAST", keep_last))
     model.recompute_keep_last = keep_last
     fp = FlatParams(model)
     # DDP semantics for N>1: cls_head takes part (zero gradients -> weight decay only), grads averaged over ranks
