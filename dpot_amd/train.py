@@ -265,14 +265,16 @@ def _rollout(model, xx, yy, msk, T_bundle, noise_scale, noise):
                 xx = ops.noise_inject(xx, None, noise_scale)
             else:
                 xx = _NoiseFn.apply(xx, noise[k] if noise is not None else None, noise_scale)
-        im, _ = model(xx)
+        try:
+            im, _ = model(xx)
+        finally:
+            if tell:
+                model._ar_pos = None                # (never left behind: a later plain forward must not see a stale position)
         l = rel_l2_loss(im, y, msk)
         loss = l if loss is None else loss + l
         preds.append(im)
         if t + T_bundle < T_ar:
             xx = _SlideFn.apply(xx, im)
-    if tell:
-        model._ar_pos = None
     pred = preds[0] if len(preds) == 1 else torch.cat(preds, dim=-2)
     return loss, pred
 

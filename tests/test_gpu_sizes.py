@@ -501,9 +501,12 @@ def _oracle_rollout_ckpt(sd, xx, yy, msk, cfg):
 
 
 def _gpu_rollout_grads(kw, salt, xx, yy, msk, recompute, keep_last=0):
+    import gc
     from dpot_amd.train import FlatParams, FusedAdam, rollout
+    gc.collect()                                  # (reference cycles of earlier runs' autograd graphs can hold GiBs of activations)
     torch.cuda.empty_cache()
     torch.cuda.reset_peak_memory_stats()
+    base = torch.cuda.memory_allocated()          # whatever earlier tests of this process still hold is not this run's peak
     m, _ = build(kw, salt=salt)
     m.recompute_blocks = recompute
     m.recompute_keep_last = keep_last
@@ -513,7 +516,7 @@ def _gpu_rollout_grads(kw, salt, xx, yy, msk, recompute, keep_last=0):
     loss, pred = rollout(m, xx.cuda(), yy.cuda(), msk.cuda())
     loss.backward()
     torch.cuda.synchronize()
-    peak = torch.cuda.max_memory_allocated() / 2 ** 30
+    peak = (torch.cuda.max_memory_allocated() - base) / 2 ** 30
     norms = {k: p.grad.double().norm().item() for k, p in m.named_parameters()}
     return loss.item(), opt.grad_norm().item(), norms, pred.detach(), fp.grad.clone(), peak
 
