@@ -435,7 +435,11 @@ struct GnChunks {
   int TC, chunks;      // tokens per chunk, chunks per slab
 };
 
-// forward, pass A: per-chunk (mean, M2 = sum (x - mean)^2); two sweeps over the chunk (the second hits L2)
+// forward, pass A: per-chunk (mean, M2 = sum (x - mean)^2) in ONE sweep (round 5): sums of (x - p) and (x - p)^2 around a pivot p
+// close to the chunk mean (M2 = S2 - S1^2 / n then loses nothing measurable; large-mean and outlier cases in
+// tests/test_gpu_ops.py::test_groupnorm_chunked_*), block sums and the final arithmetic in double.  (Rounds 2-4 swept the chunk twice - mean, then
+// centred squares; at DPOT-L batch 16 the 32 chunks an XCD works on are 6.3 MB, more than its L2: the second sweep was not free -
+// 30 us per launch for a 100 MB tensor.)
 __global__ __launch_bounds__(GN_THREADS) void gn_chunk_stats_kernel(const float* __restrict__ x, float* __restrict__ ws,
                                                                     int T, int E, int G, GnChunks c) {
   __shared__ double shd[32];
@@ -445,26 +449,48 @@ __global__ __launch_bounds__(GN_THREADS) void gn_chunk_stats_kernel(const float*
   const int nt = T - t0 < c.TC ? T - t0 : c.TC;
   const unsigned nq = (unsigned)nt * (unsigned)q4;
   const float* xs = x + ((long long)b * T + t0) * E + g * cg;
-  float s = 0.f;
-  for (unsigned i = threadIdx.x; i < nq; i += GN_THREADS) {
+  // pivot: the mean of the chunk's first GN_THREADS float4s (one per thread) - within sigma / 32 of the chunk mean for ordinary
+  // data, and one outlier among them moves it by 1/1024 of its size only.  The first GN_PF float4s of every thread are loaded
+  // BEFORE the pivot's block reduction (they fly while it runs: the reduction's two barriers otherwise delay the first load of
+  // every workgroup by ~5 us, most of what the single sweep saves)
+  constexpr int GN_PF = 6;
+  float4 pre[GN_PF];
+#pragma unroll
+  for (int k = 0; k < GN_PF; ++k) {
+    const unsigned i = threadIdx.x + (unsigned)k * GN_THREADS;
+    const unsigned ic = i < nq ? i : 0u;
+    const unsigned t = ic / (unsigned)q4, j = ic - t * (unsigned)q4;
+    pre[k] = *reinterpret_cast<const float4*>(xs + (long long)t * E + 4 * j);
+  }
+  float p0;
+  {
+    const unsigned cnt = nq < (unsigned)GN_THREADS ? nq : (unsigned)GN_THREADS;
+    const double loc = threadIdx.x < nq ? (double)((pre[0].x + pre[0].y) + (pre[0].z + pre[0].w)) : 0.0;
+    p0 = (float)(block_sum_d(loc, shd) / (4.0 * cnt));
+  }
+  float s0 = 0.f, s1 = 0.f, q0 = 0.f, q1 = 0.f;
+  auto take = [&](const float4 v) __attribute__((always_inline)) {
+    const float d0 = v.x - p0, d1 = v.y - p0, d2 = v.z - p0, d3 = v.w - p0;
+    s0 += d0 + d1;
+    s1 += d2 + d3;
+    q0 = fmaf(d0, d0, q0); q0 = fmaf(d1, d1, q0);
+    q1 = fmaf(d2, d2, q1); q1 = fmaf(d3, d3, q1);
+  };
+#pragma unroll
+  for (int k = 0; k < GN_PF; ++k)
+    if (threadIdx.x + (unsigned)k * GN_THREADS < nq) take(pre[k]);
+  for (unsigned i = threadIdx.x + (unsigned)GN_PF * GN_THREADS; i < nq; i += GN_THREADS) {
     const unsigned t = i / (unsigned)q4, j = i - t * (unsigned)q4;
-    const float4 v = *reinterpret_cast<const float4*>(xs + (long long)t * E + 4 * j);
-    s += (v.x + v.y) + (v.z + v.w);
+    take(*reinterpret_cast<const float4*>(xs + (long long)t * E + 4 * j));
   }
   const double n = (double)nt * cg;
-  const float mu = (float)(block_sum_d((double)s, shd) / n);
-  float q = 0.f;
-  for (unsigned i = threadIdx.x; i < nq; i += GN_THREADS) {
-    const unsigned t = i / (unsigned)q4, j = i - t * (unsigned)q4;
-    const float4 v = *reinterpret_cast<const float4*>(xs + (long long)t * E + 4 * j);
-    const float d0 = v.x - mu, d1 = v.y - mu, d2 = v.z - mu, d3 = v.w - mu;
-    q = fmaf(d0, d0, q); q = fmaf(d1, d1, q); q = fmaf(d2, d2, q); q = fmaf(d3, d3, q);
-  }
-  const double m2 = block_sum_d((double)q, shd);
+  double S1 = (double)s0 + (double)s1, S2 = (double)q0 + (double)q1;
+  block_sum2_d(S1, S2, shd);
   if (threadIdx.x == 0) {
     float* w = ws + (((long long)b * G + g) * c.chunks + ch) * 2;
-    w[0] = mu;
-    w[1] = (float)m2;
+    double m2 = S2 - S1 * S1 / n;
+    w[0] = (float)((double)p0 + S1 / n);
+    w[1] = (float)(m2 > 0.0 ? m2 : 0.0);
   }
 }
 

@@ -1185,6 +1185,31 @@ def test_groupnorm_chunked_vs_fp64(ops, monkeypatch, B, T, E, G):
     assert_close(y, y0.double(), "chunked vs slab kernels")
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", ["large_mean", "outlier_first", "tiny_variance"])
+def test_groupnorm_chunked_statistics_hard_cases(ops, case):
+    """the one-sweep chunk statistics (sums around a pivot, csrc/norm.hip gn_chunk_stats_kernel) where a naive sum of squares
+    fails: mean >> sigma, an outlier as the very first element of a chunk (it enters the pivot), nearly constant data"""
+    B, T, E, G = 2, 2048, 768, 8
+    torch.manual_seed(5)
+    x = torch.randn(B, T, E, device="cuda")
+    if case == "large_mean":
+        x = x * 0.05 + 300.0
+    elif case == "outlier_first":
+        x[:, 0, 0] = 1.0e4
+        x[:, T // 2, 96] = -3.0e3
+    else:
+        x = x * 1e-4 + 2.0
+    gw = torch.ones(E, device="cuda"); gb = torch.zeros(E, device="cuda")
+    assert ops.groupnorm_ws_elems(B, T, E, G) > 0
+    y, mean, rstd = ops.groupnorm_fwd(x, gw, gb, G)
+    xd = x.double().view(B, T, G, E // G)
+    mu = xd.mean(dim=(1, 3)); var = xd.var(dim=(1, 3), unbiased=False)
+    assert_close(mean, mu, f"mean ({case})", rtol=1e-6, atol_scale=1e-6)
+    # rstd: eps = 1e-5 dominates the tiny-variance case
+    assert_close(rstd, 1 / torch.sqrt(var + 1e-5), f"rstd ({case})", rtol=2e-5, atol_scale=2e-5)
+
+
 @pytest.mark.parametrize("M", [8192, 8160])
 def test_gemm_bf16_panel_large_shape(ops, M):
     """the bf16 panel kernel on a many-tile shape (512 tiles: two rounds of workgroups; with DPOT_BF16P_RASTER=1 also the
