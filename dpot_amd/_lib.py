@@ -48,6 +48,17 @@ class PackJob(C.Structure):
                 ("trans", C.c_int32)]
 
 
+class AdamPackJob(C.Structure):
+    """mirror of struct dpot_adam_pack_job"""
+    _fields_ = [("off", C.c_int64), ("dst_rows", c_fp), ("dst_trans", c_fp), ("R", C.c_int32), ("K", C.c_int32),
+                ("tile0", C.c_int32), ("pad_", C.c_int32)]
+
+
+class AdamRange(C.Structure):
+    """mirror of struct dpot_adam_range"""
+    _fields_ = [("start", C.c_int64), ("len", C.c_int64)]
+
+
 class LayoutJob(C.Structure):
     """mirror of struct dpot_layout_job"""
     _fields_ = [("src", c_fp), ("add", c_fp), ("dst", c_fp), ("d0", C.c_int32), ("d1", C.c_int32), ("d2", C.c_int32),
@@ -143,6 +154,8 @@ SIGNATURES = {
     "dpot_bf16_packed_elems": (c_i64, [c_i, c_i, c_i]),
     "dpot_bf16_pack_rows": (c_i, [c_fp, c_i, c_i, c_i, c_i, c_i, c_fp, c_fp]),
     "dpot_bf16_pack_jobs": (c_i, [c_fp, c_i, c_i, c_i, c_fp]),
+    "dpot_adam_pack_supported": (c_i, [c_i, c_i]),
+    "dpot_adam_step_packs": (c_i, [c_fp] * 6 + [c_f, c_fp, c_fp, c_i, c_fp, c_i, c_i, c_fp]),
     "dpot_gemm_bf16p_supported": (c_i, [c_i, c_i, c_i]),
     "dpot_gemm_bf16p": (c_i, [c_fp, c_fp, c_fp, c_fp, c_i, c_fp, c_i, c_fp, c_i, c_fp, c_i] + [c_i] * 7 + [c_fp] * 7),
     "dpot_gemm_bf16p_splitk": (c_i, [c_i, c_i, c_i]),

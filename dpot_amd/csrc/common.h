@@ -174,4 +174,33 @@ __device__ __forceinline__ void block_sum2_d(double& a, double& b, double* sh) {
   b = rb;
 }
 
+// ---- Adam update shared by adam_kernel (loss_opt.hip) and adam_pack_kernel (gemm_bf16p.hip) ---------------------------
+// utils/optimizer.py:26-52: L2 weight decay folded into the gradient, bias-corrected step; the clip coefficient of
+// train_temporal.py:228 multiplies the gradient.  Every product / sum is written as the explicit fmaf / mul the compiler
+// would contract it to, so the two kernels produce bit-identical parameters whatever their surrounding code.
+struct AdamCoef {
+  float b1, b2, omb1, omb2, eps, wd, step, sb2, gs;
+};
+__device__ __forceinline__ AdamCoef adam_coef(const float* __restrict__ hyper, const float* __restrict__ sumsq,
+                                              float grad_scale) {
+  const float lr = hyper[0], b1 = hyper[1], b2 = hyper[2], eps = hyper[3], wd = hyper[4];
+  const float bc1 = hyper[5], bc2 = hyper[6], max_norm = hyper[7];
+  float gs = grad_scale;
+  if (sumsq) {
+    const float total_norm = sqrtf(sumsq[0]) * grad_scale;
+    float coef = max_norm / (total_norm + 1e-6f);
+    if (coef > 1.f) coef = 1.f;
+    gs *= coef;
+  }
+  return AdamCoef{b1, b2, 1.f - b1, 1.f - b2, eps, wd, lr / bc1, sqrtf(bc2), gs};
+}
+__device__ __forceinline__ void adam_update(const AdamCoef& c, float& pv, float gv, float& mv, float& vv) {
+  gv *= c.gs;
+  if (c.wd != 0.f) gv = fmaf(c.wd, pv, gv);
+  mv = fmaf(c.b1, mv, c.omb1 * gv);
+  vv = fmaf(c.b2, vv, (c.omb2 * gv) * gv);
+  const float denom = sqrtf(vv) / c.sb2 + c.eps;
+  pv = pv - c.step * (mv / denom);
+}
+
 }  // namespace dpot

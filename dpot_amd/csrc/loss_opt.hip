@@ -218,30 +218,12 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
                                                    float* __restrict__ m, float* __restrict__ v, long long n,
                                                    const float* __restrict__ hyper, const float* __restrict__ sumsq,
                                                    float grad_scale) {
-  const float lr = hyper[0], b1 = hyper[1], b2 = hyper[2], eps = hyper[3], wd = hyper[4];
-  const float bc1 = hyper[5], bc2 = hyper[6], max_norm = hyper[7];
-  float gs = grad_scale;
-  if (sumsq) {
-    const float total_norm = sqrtf(sumsq[0]) * grad_scale;
-    float coef = max_norm / (total_norm + 1e-6f);
-    if (coef > 1.f) coef = 1.f;
-    gs *= coef;
-  }
-  const float step = lr / bc1;
-  const float sb2 = sqrtf(bc2);
-  auto upd = [&](float& pv, float gv, float& mv, float& vv) __attribute__((always_inline)) {
-    gv *= gs;
-    if (wd != 0.f) gv = fmaf(wd, pv, gv);
-    mv = b1 * mv + (1.f - b1) * gv;
-    vv = b2 * vv + (1.f - b2) * gv * gv;
-    const float denom = sqrtf(vv) / sb2 + eps;
-    pv = pv - step * (mv / denom);
-  };
+  const AdamCoef c = adam_coef(hyper, sumsq, grad_scale);
   // one float per lane and array.  (Round 4 tried 16 bytes per lane and stream - seven 1 KiB-per-wave streams: DPOT-M's
   // 110 M parameters 689 -> 778 us, DPOT-Tiny unchanged at 34 us = 6.2 TB/s; profiles/r04_step_census_M_bf16_bd_first.txt)
   for (long long i = blockIdx.x * 256ll + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
     float pv = p[i], mv = m[i], vv = v[i];
-    upd(pv, g[i], mv, vv);
+    adam_update(c, pv, g[i], mv, vv);
     m[i] = mv;
     v[i] = vv;
     p[i] = pv;

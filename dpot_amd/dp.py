@@ -122,6 +122,7 @@ class BucketedGradReducer:
         """rank 0 -> all, one collective over the flat fp32 parameter buffer (DDP's initial broadcast)."""
         if self.world > 1 or (self.single_rank_collective and dist.is_initialized()):
             dist.broadcast(self.fp.flat, src=src, group=self.pg)
+            self.fp.epoch += 1           # parameters replaced: derived / packed weight copies (PanelPacks.fresh_for) are stale
 
     # -- per step ----------------------------------------------------------------------------------------
     def begin_step(self) -> None:

@@ -256,8 +256,25 @@ class PanelPacks:
         self.table = torch.from_numpy(host).to(dev)
         self.n = len(jobs)
         self.max_elems = max(rows * K for _, rows, K, _, _ in jobs)
+        self.jobs = list(jobs)                    # (the table holds raw pointers: this also keeps the sources alive)
+        # round 6: an optimiser that writes these packs itself (train.FusedAdam -> dpot_adam_step_packs) records here what the
+        # packs are fresh FOR - (its FlatParams, that buffer's epoch, the sources' tensor versions); refresh() is then a no-op
+        # until anything else moves the parameters (FlatParams.epoch bumps, load_state_dict / in-place writes bump _version)
+        self.fresh_for = None
 
-    def refresh(self) -> None:
+    def _fresh_key(self, fp):
+        return (id(fp), fp.epoch, tuple(j[0]._version for j in self.jobs[::2]))
+
+    def is_fresh(self) -> bool:
+        ff = self.fresh_for
+        return ff is not None and ff[1] == self._fresh_key(ff[0])
+
+    def mark_fresh(self, fp) -> None:
+        self.fresh_for = (fp, self._fresh_key(fp))
+
+    def refresh(self, force: bool = False) -> None:
+        if not force and self.is_fresh():
+            return
         lib = _lib.load()
         if self.bf16:
             check(lib.dpot_bf16_pack_jobs(self.table.data_ptr(), self.n, self.max_elems, self.planes, _stream()),
@@ -398,13 +415,15 @@ BF16P_KERNEL_KINDS = {0: "dpot::gemm_bf16p_kernel (8 compute + 4 loader waves, L
                          "only the A panel through LDS; eight 128 x 32 waves)",
                       3: "dpot::gemm_bf16p_bd_kernel<8,2,3> (B-direct: W fragments straight from global memory into registers, "
                          "only the A panel through LDS; four 128 x 64 waves, two workgroups per CU)",
-                      4: "dpot::gemm_bf16x6p_kernel (fp32-accurate three-plane split)"}
+                      4: "dpot::gemm_bf16x6p_kernel (fp32-accurate three-plane split)",
+                      5: "dpot::gemm_bf16bt_kernel (big tile: 256 rows, four waves of 128 x 128 accumulators, both operands "
+                         "through LDS-DMA)"}
 
 
 def gemm_bf16p_kernel_name(M: int, N: int, K: int, splitk: int = 1, planes: int = 1, packed_outputs: bool = False) -> str:
     """the kernel dpot_gemm_bf16p runs for this shape, from the library's own selection (dpot_gemm_bf16p_kernel_kind)"""
     k = _lib.load().dpot_gemm_bf16p_kernel_kind(M, N, K, splitk, planes, int(packed_outputs))
-    return BF16P_KERNEL_KINDS.get(k & 7, f"kind {k}") + (" on 128 x 192 tiles" if k >= 8 else "")
+    return BF16P_KERNEL_KINDS.get(k & 7, f"kind {k}") + (" on 192-column tiles" if k >= 8 else "")
 
 
 def gemm_bf16p_pair_rowform_ok(M0: int, N0: int, M1: int, N1: int, K: int) -> bool:
@@ -1270,6 +1289,72 @@ def adam_step(p: Tensor, g: Tensor, m: Tensor, v: Tensor, hyper: Tensor, sumsq_:
               grad_scale: float = 1.0) -> None:
     check(_lib.load().dpot_adam_step(p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), p.numel(),
                                      hyper.data_ptr(), _p(sumsq_), grad_scale, _stream()), "adam_step")
+
+
+class AdamPackPlan:
+    """Device tables of dpot_adam_step_packs for one (flat parameter buffer, PanelPacks of 1-plane bf16 weight packs): every
+    weight W [R, K] (row-major inside the flat buffer) that the pack set holds as the pair (W, R, K, K, False) / (W, K, R, K,
+    True) becomes a job whose 64 x 256 tiles run Adam AND write both packs; the rest of [0, n_active) becomes plain ranges of
+    <= 2^20 elements.  None (`AdamPackPlan.build` returns None) when any weight of the set does not qualify."""
+    MAX_RANGE = 1 << 20
+
+    @staticmethod
+    def build(flat: Tensor, n_active: int, pp: "PanelPacks"):
+        import numpy as np
+        lib = _lib.load()
+        if not pp.bf16 or pp.planes != 1 or pp.n % 2:
+            return None
+        base, jobs = flat.data_ptr(), []
+        for j in range(0, pp.n, 2):
+            (w, rows, K, ld, tr), (w2, rows2, K2, ld2, tr2) = pp.jobs[j], pp.jobs[j + 1]
+            off = (w.data_ptr() - base) // 4
+            if (w2.data_ptr() != w.data_ptr() or tr or not tr2 or ld != K or ld2 != K or rows2 != K or K2 != rows
+                    or (w.data_ptr() - base) % 16 or off < 0 or off + rows * K > n_active or not w.is_contiguous()
+                    or w.numel() != rows * K or not lib.dpot_adam_pack_supported(rows, K)):
+                return None
+            jobs.append((off, rows, K, pp.bufs[j], pp.bufs[j + 1]))
+        jobs.sort(key=lambda t: t[0])
+        self = AdamPackPlan()
+        self.pp = pp
+        dev = flat.device
+        ntiles, tile_job = 0, []
+        host = np.zeros(len(jobs) * C.sizeof(_lib.AdamPackJob), dtype=np.uint8)
+        tab = (_lib.AdamPackJob * len(jobs)).from_buffer(host)
+        ranges, pos = [], 0
+        for i, (off, R, K, drow, dtr) in enumerate(jobs):
+            if off < pos:
+                return None                                   # overlapping weights: not a layout this plan understands
+            t = tab[i]
+            t.off, t.dst_rows, t.dst_trans, t.R, t.K, t.tile0 = off, drow.data_ptr(), dtr.data_ptr(), R, K, ntiles
+            nt = (R // 64) * (K // 256)
+            tile_job += [i] * nt
+            ntiles += nt
+            ranges.append((pos, off - pos))
+            pos = off + R * K
+        ranges.append((pos, n_active - pos))
+        split = []
+        for st, ln in ranges:
+            while ln > 0:
+                c = min(ln, AdamPackPlan.MAX_RANGE)
+                split.append((st, c))
+                st, ln = st + c, ln - c
+        self.ntiles, self.nranges = ntiles, len(split)
+        self.max_range = max((c for _, c in split), default=0)
+        self.jobs_dev = torch.from_numpy(host).to(dev)
+        self.tile_job_dev = torch.tensor(tile_job, dtype=torch.int32, device=dev)
+        rh = np.array(split, dtype=np.int64).reshape(-1, 2) if split else np.zeros((0, 2), dtype=np.int64)
+        self.ranges_dev = torch.from_numpy(rh).to(dev)
+        self.key = (base, n_active, id(pp))
+        return self
+
+
+def adam_step_packs(plan: AdamPackPlan, p: Tensor, g: Tensor, m: Tensor, v: Tensor, hyper: Tensor, sumsq_: Optional[Tensor],
+                    grad_scale: float = 1.0) -> None:
+    """dpot_adam_step over the flat buffers whose channel-MLP weights ALSO leave as their two bf16 packs (plan.pp's buffers)"""
+    check(_lib.load().dpot_adam_step_packs(p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), hyper.data_ptr(), _p(sumsq_),
+                                           grad_scale, plan.jobs_dev.data_ptr(), plan.tile_job_dev.data_ptr(), plan.ntiles,
+                                           plan.ranges_dev.data_ptr() if plan.nranges else None, plan.nranges, plan.max_range,
+                                           _stream()), "adam_step_packs")
 
 
 def adam_stage(hyper: Tensor, step: Tensor, lr: float, beta1: float, beta2: float, eps: float, weight_decay: float,

@@ -12,6 +12,7 @@ from __future__ import annotations
 
 import contextlib
 import math
+import os
 from typing import Callable, Dict, Iterable, List, Optional, Sequence, Tuple
 
 import torch
@@ -44,6 +45,7 @@ class FlatParams:
         return (len(cls.EXEC_ORDER), 0)
 
     def __init__(self, model: nn.Module, tail_prefixes: Sequence[str] = ("cls_head.",)):
+        self.model = model
         named = [(n, p) for n, p in model.named_parameters() if p.requires_grad]
         head = [(n, p) for n, p in named if not any(n.startswith(t) for t in tail_prefixes)]
         head.sort(key=lambda np_: self._exec_rank(np_[0]))                     # stable: registration order within a module
@@ -144,9 +146,41 @@ class FusedAdam:
         use_clip = self.max_norm is not None
         if use_clip:
             ops.sumsq(g, self.sumsq, self._part)
-        ops.adam_step(self.fp.flat[:n], g, self.exp_avg[:n], self.exp_avg_sq[:n], self.hyper,
-                      self.sumsq if use_clip else None, grad_scale)
+        plan = self._pack_plan()
+        if plan is not None:
+            # round 6: the channel-MLP weights leave the optimiser ALSO as their two bf16 packs - the next forward's pack
+            # launch (a second read of every weight written here) disappears (PanelPacks.refresh sees them fresh)
+            ops.adam_step_packs(plan, self.fp.flat, self.fp.grad, self.exp_avg, self.exp_avg_sq, self.hyper,
+                                self.sumsq if use_clip else None, grad_scale)
+        else:
+            ops.adam_step(self.fp.flat[:n], g, self.exp_avg[:n], self.exp_avg_sq[:n], self.hyper,
+                          self.sumsq if use_clip else None, grad_scale)
         self.fp.epoch += 1            # parameters changed: a backward of an EARLIER forward must not run any more
+        if plan is not None:
+            plan.pp.mark_fresh(self.fp)
+
+    def mark_packs_fresh(self) -> None:
+        """after a graph replay whose captured Adam launch wrote the weight packs (the host-side record cannot see it)"""
+        plan = self._pack_plan()
+        if plan is not None:
+            plan.pp.mark_fresh(self.fp)
+
+    def _pack_plan(self):
+        """the dpot_adam_step_packs tables for the model's plain-bf16 channel-MLP weight packs (DPOTNet._panel_packs_bf16, made
+        by its first forward in that mode), or None: no such packs / a weight that does not tile / DPOT_ADAM_PACKS=0"""
+        if os.environ.get("DPOT_ADAM_PACKS", "1") == "0":
+            return None
+        pp = getattr(self.fp.model, "_panel_packs_bf16", None)
+        if pp is None:
+            self._plan = None
+            return None
+        key = (self.fp.flat.data_ptr(), self.n_active, id(pp))
+        plan = getattr(self, "_plan", None)
+        if plan is None or plan.key != key:
+            plan = self._plan = ops.AdamPackPlan.build(self.fp.flat, self.n_active, pp) or False
+            if plan:
+                plan.key = key
+        return plan or None
 
     def step(self, lr: Optional[float] = None, grad_scale: float = 1.0) -> None:
         self.stage_hyper(lr)
@@ -172,6 +206,11 @@ class FusedAdam:
         self.step_dev.copy_(sd)
         self.step_count, self.lr = sc, lr
         self.param_groups[0]["lr"] = lr
+        self.fp.epoch += 1                       # parameters changed behind the packs' back ...
+        plan = self._pack_plan()
+        if plan is not None:                     # ... so bring the optimiser-owned weight packs back in line right away: a graph
+            plan.pp.refresh(force=True)          # captured after this (GraphedTrainStep warm-up) relies on them being fresh
+            plan.pp.mark_fresh(self.fp)
 
     # -- checkpoint format of the reference: torch.optim state_dict (train_temporal.py:244,281) ------------
     def state_dict(self, model: nn.Module) -> dict:
@@ -405,6 +444,7 @@ class GraphedTrainStep:
         self.opt.stage_hyper(lr)
         self.graph.replay()
         self.opt.fp.epoch += 1        # the captured Adam + pack launches rewrote the parameters and their packed copies
+        self.opt.mark_packs_fresh()   # (the captured Adam wrote the weight packs too, if it owned them at capture time)
         return self.loss
 
 
@@ -528,4 +568,5 @@ class SegmentedTrainStep:
         red.finish()                          # compute stream joins the side stream
         self.opt_graph.replay()
         self.opt.fp.epoch += 1                # as FusedAdam.launch: an eager backward of an earlier forward must fail
+        self.opt.mark_packs_fresh()
         return self.loss

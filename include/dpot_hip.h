@@ -558,12 +558,34 @@ int dpot_bf16_pack_both_norm(const float* src, int ld, int rows, int K, const fl
                              void* dst_trans, dpot_stream_t stream);
 /* static weights: a DEVICE table of dpot_pack_job entries whose dst is the packed bf16 buffer, all weights in one launch */
 int dpot_bf16_pack_jobs(const dpot_pack_job* jobs_dev, int njobs, int max_elems, int planes, dpot_stream_t stream);
+/* Adam that ALSO emits the 1-plane bf16 packs of the channel-MLP weights (utils/optimizer.py:26-52 + the pack pass that
+ * would otherwise re-read every weight it has just written).  p / g / m / v / hyper / sumsq / grad_scale as for
+ * dpot_adam_step (include: the clip of train_temporal.py:228).  jobs_dev: DEVICE table, one entry per weight [R, K] stored
+ * row-major at element offset `off` of the flat buffers (R % 64 == 0, K % 256 == 0: dpot_adam_pack_supported); dst_rows =
+ * packed [R rows, K] (what dpot_bf16_pack_jobs writes for (src, R, K, K, trans = 0)), dst_trans = packed [K rows, R] (its
+ * (src, K, R, K, trans = 1) form); either may be NULL.  tile0 = index of the job's first 64 x 256 tile in the launch;
+ * tile_job_dev[ntiles] maps a tile to its job.  ranges_dev[nranges]: the remaining stretches of the flat buffers (each
+ * <= max_range_len elements; plain Adam).  Two launches, no allocation, capturable. */
+typedef struct dpot_adam_pack_job {
+  int64_t off;
+  void* dst_rows;
+  void* dst_trans;
+  int32_t R, K, tile0, pad_;
+} dpot_adam_pack_job;
+typedef struct dpot_adam_range {
+  int64_t start, len;
+} dpot_adam_range;
+int dpot_adam_pack_supported(int rows, int K);
+int dpot_adam_step_packs(float* p, const float* g, float* m, float* v, const float* hyper, const float* sumsq,
+                         float grad_scale, const dpot_adam_pack_job* jobs_dev, const int32_t* tile_job_dev, int ntiles,
+                         const dpot_adam_range* ranges_dev, int nranges, int max_range_len, dpot_stream_t stream);
 /* C[M,N] (fp32) = epilogue(A @ Wt^T), A = packed [M, K], Wt = packed [N, K] (same `planes`); epilogue as
  * dpot_gemm_panel.  Needs N % 256 == 0 and K % 32 == 0 (dpot_gemm_bf16p_supported). */
 int dpot_gemm_bf16p_supported(int M, int N, int K);
 /* which kernel dpot_gemm_bf16p selects for a shape (for reports: bench.py names the kernel it times): 0 = LDS-DMA kernel
  * (8 compute + 4 loader waves), 1 = two-workgroup kernel, 2 = B-direct with eight 128 x 32 waves, 3 = B-direct with four
- * 128 x 64 waves (two workgroups per CU), 4 = bf16x6; + 8 when it runs on 128 x 192 tiles; -1: unsupported shape */
+ * 128 x 64 waves (two workgroups per CU), 4 = bf16x6, 5 = big tile (256-row tiles, four waves of 128 x 128 accumulators,
+ * csrc/gemm_bf16bt.hip); + 8 when it runs on 192-column tiles; -1: unsupported shape */
 int dpot_gemm_bf16p_kernel_kind(int M, int N, int K, int splitk, int planes, int packed_outputs);
 int dpot_gemm_bf16p(const void* Apacked, const void* Wpacked, const float* bias, const float* aux, int ldaux,
                     const float* res, int ldres, float* pre, int ldpre, float* C, int ldc, int M, int N, int K, int act,

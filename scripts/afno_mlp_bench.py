@@ -68,9 +68,41 @@ def tiny_train(n=30):
     torch.cuda.synchronize()
 
 
+def tiny_bwd(n=30):
+    """the DPOT-Tiny (B=32) mixer DATA-GRADIENT launch (three-product kernel, mode 1), eagerly, n times"""
+    nb, bs, M = 4, 128, 4608
+    N = 2 * bs
+    S = torch.randn(M, nb * N, device="cuda")
+    pre = torch.randn(M, nb * N, device="cuda")
+    pk = ops.AfnoPacks([(torch.randn(2, nb, bs, bs, device="cuda") * 0.05, torch.randn(2, nb, bs, device="cuda") * 0.1),
+                        (torch.randn(2, nb, bs, bs, device="cuda") * 0.05, torch.randn(2, nb, bs, device="cuda") * 0.1)])
+    (_, _, _, k1), (_, _, _, k2) = pk.refresh()
+    for _ in range(n):
+        ops.afno_mlp2(S, k2, None, k1, None, nb, bs, 1, mode=1, aux=pre, want_mid=True, want_pre=True, layout=1)
+    torch.cuda.synchronize()
+
+
+def fused_fwd(n=30, E=1024, nb=8, B=32):
+    """the one-launch AFNO layer (csrc/afno_fused.hip), training form, DPOT-S / -M at batch 32 (256 workgroups)"""
+    os.environ["DPOT_AFNO_LAYER"] = "1"
+    h, mx, my, bs = 16, 16, 9, E // nb
+    x = torch.randn(B, h * h, E, device="cuda")
+    g1, b1 = torch.rand(E, device="cuda") + 0.5, torch.randn(E, device="cuda") * 0.1
+    pk = ops.AfnoPacks([(torch.randn(2, nb, bs, bs, device="cuda") * 0.05, torch.randn(2, nb, bs, device="cuda") * 0.1),
+                        (torch.randn(2, nb, bs, bs, device="cuda") * 0.05, torch.randn(2, nb, bs, device="cuda") * 0.1)])
+    p = pk.refresh()
+    for _ in range(n):
+        ops.afno_fused_fwd(x, g1, b1, p[0][2], p[0][1], p[1][2], p[1][1], g1, b1, h, h, nb, mx, my, 1, save=True, want_y1=True)
+    torch.cuda.synchronize()
+
+
 if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "tiny-train":
         tiny_train()
+    elif len(sys.argv) > 1 and sys.argv[1] == "tiny-bwd":
+        tiny_bwd()
+    elif len(sys.argv) > 1 and sys.argv[1] == "fused-fwd":
+        fused_fwd()
     else:
         for nb, bs, M in ((4, 128, 4608), (8, 128, 2304), (16, 96, 2176), (16, 96, 8704)):
             bench(nb, bs, M)

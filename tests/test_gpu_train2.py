@@ -471,3 +471,46 @@ def test_window_slide_rejects_mismatched_prediction():
         ops.window_slide(xx, torch.zeros(2, 8, 8, 1, 4, device="cuda"))      # out_channels != in_channels
     with pytest.raises(_lib.DpotHipError):
         ops.window_slide(xx, torch.zeros(2, 8, 4, 1, 3, device="cuda"))      # other spatial extent
+
+
+def test_adam_writes_the_weight_packs(monkeypatch):
+    """round 6: with the plain-bf16 channel MLP the fused Adam launch ALSO writes the two bf16 packs of every
+    channel-MLP weight (dpot_adam_step_packs: 64 x 256 tiles of the weight through LDS) and the next forward skips its pack
+    launch.  (a) parameters, moments and losses are BIT-identical to the separate Adam + pack launches (DPOT_ADAM_PACKS=0),
+    eagerly and under hipGraph replay; (b) the packs Adam wrote equal a forced refresh from the parameters; (c) anything else
+    that moves the parameters (load_state_dict, optimiser restore) makes the forward pack again."""
+    from dpot_amd.train import GraphedTrainStep, train_step
+    kw = dict(R.MINI, embed_dim=256, n_blocks=2, depth=2, mlp_ratio=2)
+    runs = {}
+    for packs in ("0", "1"):
+        monkeypatch.setenv("DPOT_ADAM_PACKS", packs)
+        m, cfg = build(kw, salt=7)
+        m.mlp_precision = "bf16"
+        xx, yy, msk = _batch(cfg, 4)
+        opt = _opt(m)
+        losses = [train_step(m, opt, xx, yy, msk, lr=lr)[0].item() for lr in (1e-3, 2e-3, 5e-4)]
+        pp = m._panel_packs_bf16
+        if packs == "1":
+            assert opt._pack_plan() is not None and opt._pack_plan().ntiles == 2 * 2 * (512 // 64) * (256 // 256)
+            assert pp.is_fresh()
+            mine = [b.clone() for b in pp.bufs]
+            pp.refresh(force=True)
+            assert all(torch.equal(a, b) for a, b in zip(mine, pp.bufs)), "packs written by Adam != packs of the parameters"
+            # (c) load_state_dict bumps the tensor versions: the packs are no longer trusted
+            m.load_state_dict(m.state_dict())
+            assert not pp.is_fresh()
+            snap = opt.snapshot()
+            opt.restore(snap)                      # re-packs eagerly and trusts them again (graph warm-up relies on it)
+            assert pp.is_fresh()
+        else:
+            assert opt._pack_plan() is None and not pp.is_fresh()
+        g = GraphedTrainStep(m, opt, xx, yy, msk, warmup=1)
+        losses += [g.replay(lr).item() for lr in (1e-3, 3e-3, 1e-3)]
+        if packs == "1":
+            mine = [b.clone() for b in pp.bufs]
+            pp.refresh(force=True)
+            assert all(torch.equal(a, b) for a, b in zip(mine, pp.bufs)), "packs after graph replays"
+        runs[packs] = (losses, opt.fp.flat.clone(), opt.exp_avg.clone(), opt.exp_avg_sq.clone())
+    assert runs["0"][0] == runs["1"][0], (runs["0"][0], runs["1"][0])
+    for a, b in zip(runs["0"][1:], runs["1"][1:]):
+        assert torch.equal(a, b)
