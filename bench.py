@@ -745,7 +745,8 @@ def main():
 
     from dpot_amd import DPOTNet, _lib, ops
     from dpot_amd.dp import BucketedGradReducer
-    from dpot_amd.train import FlatParams, FusedAdam, GraphedTrainStep, SegmentedTrainStep, one_cycle_lr, train_step
+    from dpot_amd.train import (FlatParams, FusedAdam, GraphedTrainStep, SegmentedTrainStep, make_dp_step, one_cycle_lr,
+                                train_step)
     from dpot_amd.dp import dp_one_cycle_lr
     _lib.load()
 
@@ -791,6 +792,7 @@ def main():
 
     mode = "eager"
     graphed = None
+    dp_info = None
     if not args.no_graph and not (dp_on and args.overlap):
         try:
             # N>1: the graph holds fwd+bwd only; the all-reduce and the optimiser run after the replay
@@ -801,10 +803,14 @@ def main():
                 graphed = GraphedTrainStep(model, opt, xx, yy, msk, noise_scale=args.noise_scale,
                                            warmup=1 if T_ar > 1 else 2, reducer=reducer, capture_collectives=True)
             elif dp_on:
-                # default N>1 path: hipGraph segments cut at the gradient-bucket boundaries; bucket k is all-reduced
-                # on the side stream while the compute stream replays the backward of the earlier stages
-                graphed = SegmentedTrainStep(model, opt, reducer, xx, yy, msk, noise_scale=args.noise_scale,
-                                             warmup=1 if T_ar > 1 else 2)
+                # default N>1 path (round 6): train.make_dp_step - the segmented hipGraph chain (cut at the gradient-bucket
+                # boundaries, bucket k all-reduced on the side stream while the compute stream replays the backward of the
+                # earlier stages) AND the one-graph step (collectives captured) are both built, one trial step is run in each
+                # from the same snapshot, and the one-graph step is kept only if its reduced gradient is bit-identical to the
+                # chain's and across the ranks.  DPOT_DP_ONE_GRAPH=0: the chain without the trial
+                graphed, dp_info = make_dp_step(model, opt, reducer, xx, yy, msk, noise_scale=args.noise_scale,
+                                                warmup=1 if T_ar > 1 else 2,
+                                                try_one_graph=os.environ.get("DPOT_DP_ONE_GRAPH", "auto") != "0")
             else:
                 graphed = GraphedTrainStep(model, opt, xx, yy, msk, noise_scale=args.noise_scale,
                                            warmup=1 if T_ar > 1 else 2)
@@ -902,10 +908,11 @@ def main():
                                                  "call (graph launches, stream waits, collective enqueues); it must stay "
                                                  "below ms_per_step or the GPU starves"}
             out["config"]["buckets_MB"] = [round((hi - lo) * 4 / 1e6, 2) for lo, hi in reducer.ranges]
+            out["config"]["dp_selection"] = dp_info
             out["config"]["dp"] = ("eager, hook-driven bucket all-reduce" if graphed is None else
                                    "one graph + all-reduce after backward" if args.no_overlap else
                                    f"ONE hipGraph holding the step and its {reducer.n_buckets} bucket all-reduces (side stream "
-                                   f"forked inside the capture; DPOT_DP_ONE_GRAPH=1)" if isinstance(graphed, GraphedTrainStep) else
+                                   f"forked inside the capture)" if isinstance(graphed, GraphedTrainStep) else
                                    f"segmented hipGraph chain ({len(graphed.graphs)} segments), bucket all-reduce on a "
                                    f"side stream overlapped with the remaining backward; {reducer.n_buckets} buckets")
         if not dp_on and graphed is not None and args.sustain_seconds > 0 and not args.brief:

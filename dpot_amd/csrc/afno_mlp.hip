@@ -415,6 +415,9 @@ __global__ __launch_bounds__(64 * (NW + 2)) void afno_mlp2_kernel(const AfnoMlpA
 // and waves 6 / 7 their remaining row tiles - per SIMD RT + ceil(RT/2), RT + ceil(RT/2), RT + floor(RT/2), RT + floor(RT/2) row
 // tiles (8 : 8 : 7 : 7 at RT = 5 instead of 10 : 10 : 5 : 5).  Every wave still owns exactly ONE column tile: same code, its
 // row range [r0, r0 + NR) a compile-time size.  The loader waves become waves 8 and 9.
+#ifndef AFNO_XSW
+#define AFNO_XSW 2      // XOR mask of the X-slab chunk swizzle (3 = the rounds 2-5 image, for A/B builds: scripts/variant.sh)
+#endif
 template <int RT, int BS, int ACTK, bool SPLIT = false>
 __global__ __launch_bounds__(64 * ((SPLIT ? 8 : BS / 16) + 2)) void afno_mlp3_kernel(const AfnoMlpArgs p) {
   constexpr int NW = BS / 16;       // 16-column tiles of one part (8 for bs = 128, 6 for bs = 96) = compute waves unless SPLIT
@@ -482,7 +485,7 @@ __global__ __launch_bounds__(64 * ((SPLIT ? 8 : BS / 16) + 2)) void afno_mlp3_ke
       const int r = lane >> 2;
       int row = row0 + 16 * i + r;
       row = row < p.M ? row : p.M - 1;                  // clamped: rows past M only feed outputs that are never stored
-      xoff[n] = (long long)row * p.ldx + part * BS + 4 * ((lane & 3) ^ ((r >> 2) & 2));
+      xoff[n] = (long long)row * p.ldx + part * BS + 4 * ((lane & 3) ^ ((r >> 2) & AFNO_XSW));
     }
     auto issue_x = [&](int t, float* dstbuf) __attribute__((always_inline)) {
 #pragma unroll
@@ -531,7 +534,7 @@ __global__ __launch_bounds__(64 * ((SPLIT ? 8 : BS / 16) + 2)) void afno_mlp3_ke
     b[0] = *reinterpret_cast<const f32x4*>(Wr_ + rb * WSL + cw * 256 + lane * 4);
     b[1] = *reinterpret_cast<const f32x4*>(Wr_ + rb * WSL + (NW + cw) * 256 + lane * 4);
   };
-  const int xfrag = fr * 16 + 4 * (fq ^ ((fr >> 2) & 2));
+  const int xfrag = fr * 16 + 4 * (fq ^ ((fr >> 2) & AFNO_XSW));
   auto read_x = [&](f32x4 (&ar)[NR], f32x4 (&ai)[NR], int rb) __attribute__((always_inline)) {
     const float* xs = Xb + rb * XSL + xfrag;
 #pragma unroll

@@ -1318,13 +1318,9 @@ static void bf16p_pick_super(int tilesM, int tilesN, int splits, int* sr, int* s
 // bench.py reports) read the same plan
 struct Bf16pPlan {
   int tilesM, tilesN, splits, slabs_per_split, super_r, super_c, colt, cpw;
-  bool use_bd, use_duo, use_bt;
+  bool use_bd, use_duo;
   unsigned grid;
 };
-// csrc/gemm_bf16bt.hip: 256 x 256 (256 x 192) tiles on four waves of 128 x 128 (128 x 96)
-namespace dpot {
-int bf16bt_launch(const Bf16pArgs& p, int colt, unsigned grid, hipStream_t stream);
-}
 static Bf16pPlan bf16p_plan(int M, int N, int K, int splitk, int planes, bool packs) {
   Bf16pPlan pl;
   pl.tilesM = (M + 32 * PB_ROWT - 1) / (32 * PB_ROWT);
@@ -1365,39 +1361,21 @@ static Bf16pPlan bf16p_plan(int M, int N, int K, int splitk, int planes, bool pa
   if (pl.use_bd) pl.use_duo = false;
   if (pl.use_bd && pl.super_r == 0) pl.super_c = bf16p_row_major(pl.tilesM, pl.tilesN, PB_ROWT, pl.colt);
   pl.cpw = pl.colt == 6 ? 1 : bd_cpw((long long)pl.tilesM * pl.tilesN * pl.splits);
-  // big-tile form (round 6, csrc/gemm_bf16bt.hip; DPOT_BF16P_BT=0: never): un-split plain-bf16 launches whose 256-row tile grid
-  // fills the 256 CUs in (nearly) whole rounds - 256-wide tiles first, 192-wide where those fill the rounds and 256 does not
-  // (DPOT-L: N = 1536 at 16384 tokens = 64 x 6 tiles of 256 x 256 = 1.5 rounds, 64 x 8 of 256 x 192 = 2)
-  static const int bt = [] { const char* ev = getenv("DPOT_BF16P_BT"); return ev ? atoi(ev) : 1; }();
-  pl.use_bt = false;
-  if (bt && planes == 1 && pl.splits == 1 && M % 256 == 0) {
-    auto fill = [](long long t) { return t < 256 ? 0.0 : (double)t / (256.0 * (double)((t + 255) / 256)); };
-    const long long t8 = N % 256 == 0 ? (long long)(M / 256) * (N / 256) : 0;
-    const long long t6 = N % 192 == 0 ? (long long)(M / 256) * (N / 192) : 0;
-    int colt = 0;
-    if (fill(t8) >= 0.9) colt = 8;
-    else if (fill(t6) >= 0.9) colt = 6;
-    if (colt) {
-      pl.use_bt = true; pl.use_bd = false; pl.use_duo = false;
-      pl.colt = colt;
-      pl.tilesM = M / 256;
-      pl.tilesN = N / (32 * colt);
-      bf16p_pick_super(pl.tilesM, pl.tilesN, 1, &pl.super_r, &pl.super_c, true);
-      if (pl.super_r == 0) pl.super_c = bf16p_row_major(pl.tilesM, pl.tilesN, 8, colt);
-      pl.grid = (unsigned)(pl.tilesM * pl.tilesN);
-      if (pl.super_r > 0) pl.grid = 256u * (unsigned)((pl.tilesM * pl.tilesN / 32 + 7) / 8);
-    }
-  }
+  // (Round 6 built a 256 x 256 / 256 x 192 "big tile" form - four waves of 128 x 128 accumulators on the unified 512-entry register
+  // file, both operands through LDS-DMA, the tile shape hipBLASLt picks for these products - bit-identical to these kernels and
+  // SLOWER on every DPOT-M / -L form: fp32-output launches +7..15 % (one wave per SIMD: nothing covers the barrier of every slab),
+  // packed-output launches +30..50 % (four waves per CU in the epilogue); DPOT-M 12.42 -> 14.21 ms, DPOT-L 88.0 -> 98.1 ms.
+  // profiles/r06_bt_step_ab.txt, r06_gemm_yardstick_bt.txt; the source is in the history: commit 'big-tile bf16 GEMM measured'.)
   return pl;
 }
 // which kernel dpot_gemm_bf16p runs for a shape: 0 = LDS-DMA (8 compute + 4 loader waves), 1 = two-workgroup ("duo"),
-// 2 = B-direct with eight 128 x 32 waves, 3 = B-direct with four 128 x 64 waves (two workgroups per CU), 4 = bf16x6,
-// 5 = big tile (256 rows, four waves of 128 x 128 / 128 x 96: csrc/gemm_bf16bt.hip); + 8: on 192-column tiles
+// 2 = B-direct with eight 128 x 32 waves, 3 = B-direct with four 128 x 64 waves (two workgroups per CU), 4 = bf16x6;
+// + 8: on 128 x 192 tiles
 extern "C" int dpot_gemm_bf16p_kernel_kind(int M, int N, int K, int splitk, int planes, int packed_outputs) {
   if (!dpot_gemm_bf16p_supported(M, N, K)) return -1;
   if (planes == 3) return 4;
   const Bf16pPlan pl = bf16p_plan(M, N, K, splitk, planes, packed_outputs != 0);
-  const int kind = pl.use_bt ? 5 : pl.use_bd ? (pl.cpw == 2 ? 3 : 2) : pl.use_duo ? 1 : 0;
+  const int kind = pl.use_bd ? (pl.cpw == 2 ? 3 : 2) : pl.use_duo ? 1 : 0;
   return kind + (pl.colt == 6 ? 8 : 0);
 }
 
@@ -1452,10 +1430,6 @@ extern "C" int dpot_gemm_bf16p(const void* Apacked, const void* Wpacked, const f
   const Bf16pPlan pl = bf16p_plan(M, N, K, splitk, planes, packs);
   p.splits = pl.splits; p.slabs_per_split = pl.slabs_per_split; p.tilesN = pl.tilesN;
   p.super_r = pl.super_r; p.super_c = pl.super_c;
-  if (pl.use_bt) {
-    p.tilesM = pl.tilesM;
-    return bf16bt_launch(p, pl.colt, pl.grid, as_stream(stream));
-  }
   const int colt = pl.colt, cpw = pl.cpw;
   const bool use_bd = pl.use_bd, use_duo = pl.use_duo;
   const unsigned grid = pl.grid;

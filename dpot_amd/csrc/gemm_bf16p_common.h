@@ -1,6 +1,6 @@
-// gemm_bf16p_common.h - what the bf16 GEMM translation units share (csrc/gemm_bf16p.hip: the 128-row-tile kernels and the host
-// side; csrc/gemm_bf16bt.hip: the 256 x 256 / four-wave kernel of round 6): the argument block, LDS-DMA / wait helpers and
-// the fragment epilogues (staged, in-accumulator-layout "direct", transposed store).
+// gemm_bf16p_common.h - the argument block, LDS-DMA / wait helpers and the fragment epilogues (staged, in-accumulator-layout
+// "direct", transposed store) of the bf16 GEMM kernels in csrc/gemm_bf16p.hip (split out in round 6 so that a second
+// translation unit - the measured-and-rejected 256 x 256 kernel - could share them).
 #pragma once
 #include <type_traits>
 

@@ -449,10 +449,13 @@ __global__ __launch_bounds__(GN_THREADS) void gn_chunk_stats_kernel(const float*
   const int nt = T - t0 < c.TC ? T - t0 : c.TC;
   const unsigned nq = (unsigned)nt * (unsigned)q4;
   const float* xs = x + ((long long)b * T + t0) * E + g * cg;
-  // pivot: the mean of the chunk's first GN_THREADS float4s (one per thread) - within sigma / 32 of the chunk mean for ordinary
-  // data, and one outlier among them moves it by 1/1024 of its size only.  The first GN_PF float4s of every thread are loaded
-  // BEFORE the pivot's block reduction (they fly while it runs: the reduction's two barriers otherwise delay the first load of
-  // every workgroup by ~5 us, most of what the single sweep saves)
+  // pivot: the mean of GN_THREADS float4s sampled with a STRIDE over the whole chunk (one per thread, index tid * nq / GN_THREADS)
+  // - within sigma / 32 of the chunk mean for ordinary data, one outlier among them moves it by 1/1024 of its size only, and a
+  // region that differs from the rest of the chunk (a constant / masked border at its start: round 5 sampled the FIRST
+  // GN_THREADS float4s only, ~21 tokens, and would have lost (offset / sigma)^2 x 1e-7 of M2 there - ADVICE r5) is sampled in
+  // proportion.  The sample and the first GN_PF float4s of every thread are loaded BEFORE the pivot's block reduction (they fly
+  // while it runs: the reduction's two barriers otherwise delay the first load of every workgroup by ~5 us, most of what the
+  // single sweep saves)
   constexpr int GN_PF = 6;
   float4 pre[GN_PF];
 #pragma unroll
@@ -465,7 +468,11 @@ __global__ __launch_bounds__(GN_THREADS) void gn_chunk_stats_kernel(const float*
   float p0;
   {
     const unsigned cnt = nq < (unsigned)GN_THREADS ? nq : (unsigned)GN_THREADS;
-    const double loc = threadIdx.x < nq ? (double)((pre[0].x + pre[0].y) + (pre[0].z + pre[0].w)) : 0.0;
+    const unsigned is = nq < (unsigned)GN_THREADS ? (threadIdx.x < nq ? threadIdx.x : 0u)
+                                                  : (unsigned)(((unsigned long long)threadIdx.x * nq) / GN_THREADS);
+    const unsigned ts = is / (unsigned)q4, js = is - ts * (unsigned)q4;
+    const float4 smp = *reinterpret_cast<const float4*>(xs + (long long)ts * E + 4 * js);
+    const double loc = threadIdx.x < cnt ? (double)((smp.x + smp.y) + (smp.z + smp.w)) : 0.0;
     p0 = (float)(block_sum_d(loc, shd) / (4.0 * cnt));
   }
   float s0 = 0.f, s1 = 0.f, q0 = 0.f, q1 = 0.f;

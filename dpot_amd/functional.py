@@ -613,6 +613,12 @@ def _stash_grad_packs(dx: Tensor, dop: Tensor, dopT: Tensor, cs: Tensor) -> None
         _GRAD_PACKS.popitem(last=False)
 
 
+def clear_grad_packs() -> None:
+    """drop the side table (the step classes call this after every backward: an entry nobody took - frozen prefix, a tensor
+    hook that replaced the gradient - would otherwise pin dx and both packs until two later stashes evict it)"""
+    _GRAD_PACKS.clear()
+
+
 def _take_grad_packs(do2: Tensor):
     e = _GRAD_PACKS.pop(do2.data_ptr(), None)
     if e is None:
@@ -661,7 +667,7 @@ class BlockFn(torch.autograd.Function):
         ctx.emit_grad_packs = emit_grad_packs     # a Block precedes this one: its bf16 channel-MLP backward wants dx packed
         ctx.dims = dims
         ctx.afno_layout = getattr(packed[0], "layout", 0) if ctx.fused_mixer else 0
-        ctx.mlp_precision = mp
+        ctx.mlp_precision = ops.effective_mlp_precision()    # a concrete code: the backward reproduces the forward's mode
         ctx.gemm_precision = ops._cur_gemm()
         ctx.sinks = _sinks(ctx, (n1w, n1b, w1, b1, w2, b2, n2w, n2b, f1w, f1b, f2w, f2b), 1)
         ctx.weights_epoch = _epoch_of(ctx.sinks)
@@ -805,7 +811,7 @@ class BlockFn(torch.autograd.Function):
                 # 128 channels per group (DPOT-S / -M): this pair reads four fields with 4-byte accesses and runs at 64.7 us
                 # against 20.0 + 24.6 us for the separate kernels (profiles/r03_step_census_M_bf16_v1.txt) - not fused
                 dxn1 = ops.irfft2(dS, B, h, w, E, nb, mx, my, 0, res=dy1)
-                if (ctx.emit_grad_packs and bf16p and xn2.dtype == torch.bfloat16 and ops.groupnorm_bwd_packs_supported(tok, E, B=B)
+                if (ctx.emit_grad_packs and ctx.needs_input_grad[0] and bf16p and xn2.dtype == torch.bfloat16 and ops.groupnorm_bwd_packs_supported(tok, E, B=B)
                         and os.environ.get("DPOT_GRAD_PACKS", "1") != "0"):
                     # dx goes to the previous Block's bf16 channel-MLP backward: written here in its packed forms as well
                     dx, gn1_part, gp_r, gp_t, gp_cs = ops.groupnorm_bwd_packs(dxn1, x, mean1, rstd1, n1w, add=dout)
@@ -817,7 +823,7 @@ class BlockFn(torch.autograd.Function):
             # AFNO mixer
             dxn1, dw1, db1, dw2, db2 = _mixer_bwd(dy1, S, O1pre, O1, wb1, wb2, ctx.dims, ctx.fused_mixer,
                                                   ctx.afno_layout, (s_w1, s_b1, s_w2, s_b2), pending)
-            if (ctx.emit_grad_packs and bf16p and xn2.dtype == torch.bfloat16 and ops.groupnorm_bwd_packs_supported(tok, E, B=B)
+            if (ctx.emit_grad_packs and ctx.needs_input_grad[0] and bf16p and xn2.dtype == torch.bfloat16 and ops.groupnorm_bwd_packs_supported(tok, E, B=B)
                     and os.environ.get("DPOT_GRAD_PACKS", "1") == "2"):
                 # (DPOT-L: the CHUNKED GroupNorm backward can write the gradient's packs too - see the 128-channel branch above -
                 # but there the staging + two barriers per 32-token sub-tile cost what the saved pack pass did: DPOT-L 91.2 -> 90.9 ms,

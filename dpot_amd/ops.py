@@ -130,7 +130,9 @@ def with_ctx_precision(backward):
 def capture_precision(ctx) -> None:
     """store the precisions in effect on this thread in an autograd context (forward side of with_ctx_precision)"""
     ctx.gemm_precision = _cur_gemm()
-    ctx.mlp_precision = _cur_mlp()
+    # the EFFECTIVE channel-MLP precision as a concrete code (ADVICE r5): an unset override (None = "follow the GEMM precision")
+    # would make the backward's scope a no-op and let it read whatever the autograd thread's default is by then
+    ctx.mlp_precision = effective_mlp_precision()
 
 
 def effective_mlp_precision() -> int:
@@ -415,15 +417,13 @@ BF16P_KERNEL_KINDS = {0: "dpot::gemm_bf16p_kernel (8 compute + 4 loader waves, L
                          "only the A panel through LDS; eight 128 x 32 waves)",
                       3: "dpot::gemm_bf16p_bd_kernel<8,2,3> (B-direct: W fragments straight from global memory into registers, "
                          "only the A panel through LDS; four 128 x 64 waves, two workgroups per CU)",
-                      4: "dpot::gemm_bf16x6p_kernel (fp32-accurate three-plane split)",
-                      5: "dpot::gemm_bf16bt_kernel (big tile: 256 rows, four waves of 128 x 128 accumulators, both operands "
-                         "through LDS-DMA)"}
+                      4: "dpot::gemm_bf16x6p_kernel (fp32-accurate three-plane split)"}
 
 
 def gemm_bf16p_kernel_name(M: int, N: int, K: int, splitk: int = 1, planes: int = 1, packed_outputs: bool = False) -> str:
     """the kernel dpot_gemm_bf16p runs for this shape, from the library's own selection (dpot_gemm_bf16p_kernel_kind)"""
     k = _lib.load().dpot_gemm_bf16p_kernel_kind(M, N, K, splitk, planes, int(packed_outputs))
-    return BF16P_KERNEL_KINDS.get(k & 7, f"kind {k}") + (" on 192-column tiles" if k >= 8 else "")
+    return BF16P_KERNEL_KINDS.get(k & 7, f"kind {k}") + (" on 128 x 192 tiles" if k >= 8 else "")
 
 
 def gemm_bf16p_pair_rowform_ok(M0: int, N0: int, M1: int, N1: int, K: int) -> bool:

@@ -19,7 +19,7 @@ import torch
 import torch.nn as nn
 
 from . import ops
-from .functional import rel_l2_loss
+from .functional import clear_grad_packs, rel_l2_loss
 
 Tensor = torch.Tensor
 
@@ -371,6 +371,7 @@ def train_step(model: nn.Module, opt: FusedAdam, xx: Tensor, yy: Tensor, msk: Op
         reducer.begin_step()
     loss, pred = rollout(model, xx, yy, msk, T_bundle, noise_scale)
     loss.backward()
+    clear_grad_packs()
     if reducer is not None:
         reducer.finish()
     opt.step(lr, grad_scale)
@@ -399,7 +400,13 @@ class GraphedTrainStep:
         # autograd graph, no graph launches between the buckets
         self.reducer = reducer if capture_collectives else None
         if self.reducer is not None:
+            if grad_scale != 1.0 and grad_scale != self.reducer.grad_scale:
+                raise ValueError(f"GraphedTrainStep(capture_collectives=True) scales the gradient by the reducer's 1 / world = "
+                                 f"{self.reducer.grad_scale}; a different grad_scale ({grad_scale}) was passed")
             grad_scale = self.reducer.grad_scale
+            # the capture bakes in WHICH buckets are all-reduced: always include the cls_head tail (a zero slice when the loss
+            # ignores it - the SUM of zeros - so the replayed graph stays right if the head starts to receive gradients later)
+            self.reducer.skip_zero_tail = False
         self.grad_scale = grad_scale
         self.T_bundle, self.noise_scale = T_bundle, noise_scale
         # eager warm-up on a side stream (allocator + lazy inits).  The warm-up iterations are NOT training steps:
@@ -429,6 +436,7 @@ class GraphedTrainStep:
             self.reducer.begin_step()
         loss, pred = rollout(self.model, self.xx, self.yy, self.msk, self.T_bundle, self.noise_scale)
         loss.backward()
+        clear_grad_packs()
         if self.reducer is not None:
             self.reducer.finish()
         opt.launch(self.grad_scale)
@@ -536,6 +544,7 @@ class SegmentedTrainStep:
                 self.model._boundary_hook = None
             assert len(cuts) == len(self.cut_at), f"expected {len(self.cut_at)} graph cuts, the forward made {len(cuts)}"
             loss.backward()
+            clear_grad_packs()
             self.loss, self.pred = loss.detach(), pred.detach()
 
         yield first
@@ -545,6 +554,7 @@ class SegmentedTrainStep:
             def seg(j=j):
                 out, leaf = cuts[j]
                 out.backward(leaf.grad)
+                clear_grad_packs()
                 leaf.grad = None
             yield seg
 
@@ -570,3 +580,81 @@ class SegmentedTrainStep:
         self.opt.fp.epoch += 1                # as FusedAdam.launch: an eager backward of an earlier forward must fail
         self.opt.mark_packs_fresh()
         return self.loss
+
+
+# ------------------------------------------------------------------------------------------------------
+def _grad_checksum(g: Tensor) -> Tensor:
+    """order-independent 64-bit checksum of the BIT patterns of a flat fp32 buffer (int64[2]: sum and sum of squares of the
+    words mod 2^64) - equal buffers give equal checksums; used across ranks (after an all-reduce every rank must hold the same
+    gradient bit for bit)"""
+    w = g.view(torch.int32).to(torch.int64)
+    return torch.stack([w.sum(), (w * w).sum()])
+
+
+def make_dp_step(model: nn.Module, opt: FusedAdam, reducer, xx: Tensor, yy: Tensor, msk: Optional[Tensor],
+                 noise_scale: float = 0.0, warmup: int = 2, T_bundle: int = 1, try_one_graph: bool = True):
+    """The N > 1 train step with the FAST mode chosen by verification (round 6): returns (step, info).
+
+    Reference mode = ``SegmentedTrainStep`` (graph segments, the bucket all-reduces issued between them: collectives never sit
+    inside a capture).  Fast mode = ``GraphedTrainStep(capture_collectives=True)``: the whole step, all-reduces included, as ONE
+    hipGraph (+0.7 % over the single-GPU graph at DPOT-Tiny against +4.2 %).  Whether the communication library's kernels
+    replay correctly as graph nodes across ranks cannot be known in advance, so both are captured, ONE step is run in each mode
+    from the same snapshot (parameters, Adam state, noise generator) and the reduced flat gradient is compared bit for bit
+    between the modes AND across the ranks (checksums through the process group); the one-graph step is kept only when every
+    rank agrees, otherwise the segmented chain runs and ``info`` says why.  Parameters, optimiser state and the noise
+    generator are left exactly as found.  Mirrors train_temporal_parallel.py:102,185,243-244 (accelerate's DDP step)."""
+    import torch.distributed as dist
+    seg = SegmentedTrainStep(model, opt, reducer, xx, yy, msk, noise_scale=noise_scale, warmup=warmup, T_bundle=T_bundle)
+    info = {"mode": "segmented", "why": "one-graph mode not tried"}
+    if not try_one_graph:
+        return seg, info
+    multi = dist.is_available() and dist.is_initialized()
+    one, err = None, None
+    tail_flag = reducer.skip_zero_tail
+    try:
+        one = GraphedTrainStep(model, opt, xx, yy, msk, T_bundle=T_bundle, noise_scale=noise_scale, warmup=1, reducer=reducer,
+                               capture_collectives=True)
+    except Exception as e:                                    # e.g. a backend whose collectives cannot be captured (gloo)
+        err = f"{type(e).__name__}: {e}"[:160]
+        torch.cuda.synchronize()
+    # every rank must take the same branch: agree on whether the capture worked everywhere
+    ok = torch.tensor([1 if one is not None else 0], device=xx.device, dtype=torch.int64)
+    if multi:
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN, group=reducer.pg)
+    if int(ok.item()) == 0:
+        reducer.skip_zero_tail = tail_flag
+        del one
+        info = {"mode": "segmented", "why": "one-graph capture failed" + (f" here ({err})" if err else " on another rank")}
+        return seg, info
+    snap = opt.snapshot()
+    rng = ops.rng_state(xx.device).clone()
+    grads = []
+    for step in (seg, one):
+        opt.restore(snap)
+        ops.rng_state(xx.device).copy_(rng)
+        reducer.skip_zero_tail = tail_flag if step is seg else False
+        step.replay(opt.lr)
+        torch.cuda.synchronize()
+        grads.append(opt.fp.grad[:opt.n_active].clone())
+    opt.restore(snap)
+    ops.rng_state(xx.device).copy_(rng)
+    same_modes = bool(torch.equal(grads[0], grads[1]))
+    cs = _grad_checksum(grads[1])
+    verdict = torch.tensor([1 if same_modes else 0], device=xx.device, dtype=torch.int64)
+    if multi:
+        lo, hi = cs.clone(), cs.clone()
+        dist.all_reduce(lo, op=dist.ReduceOp.MIN, group=reducer.pg)
+        dist.all_reduce(hi, op=dist.ReduceOp.MAX, group=reducer.pg)
+        same_ranks = bool(torch.equal(lo, hi))
+        dist.all_reduce(verdict, op=dist.ReduceOp.MIN, group=reducer.pg)
+    else:
+        same_ranks = True
+    if int(verdict.item()) == 1 and same_ranks:
+        del seg
+        return one, {"mode": "one-graph", "why": "reduced gradient of a trial step bit-identical to the segmented chain's and "
+                                                  "across the ranks"}
+    reducer.skip_zero_tail = tail_flag
+    del one
+    return seg, {"mode": "segmented", "why": "one-graph trial step " + ("differs from the segmented chain's gradient"
+                                                                         if int(verdict.item()) == 0 else
+                                                                         "gave different gradients on different ranks")}

@@ -584,8 +584,7 @@ int dpot_adam_step_packs(float* p, const float* g, float* m, float* v, const flo
 int dpot_gemm_bf16p_supported(int M, int N, int K);
 /* which kernel dpot_gemm_bf16p selects for a shape (for reports: bench.py names the kernel it times): 0 = LDS-DMA kernel
  * (8 compute + 4 loader waves), 1 = two-workgroup kernel, 2 = B-direct with eight 128 x 32 waves, 3 = B-direct with four
- * 128 x 64 waves (two workgroups per CU), 4 = bf16x6, 5 = big tile (256-row tiles, four waves of 128 x 128 accumulators,
- * csrc/gemm_bf16bt.hip); + 8 when it runs on 192-column tiles; -1: unsupported shape */
+ * 128 x 64 waves (two workgroups per CU), 4 = bf16x6; + 8 when it runs on 128 x 192 tiles; -1: unsupported shape */
 int dpot_gemm_bf16p_kernel_kind(int M, int N, int K, int splitk, int planes, int packed_outputs);
 int dpot_gemm_bf16p(const void* Apacked, const void* Wpacked, const float* bias, const float* aux, int ldaux,
                     const float* res, int ldres, float* pre, int ldpre, float* C, int ldc, int M, int N, int K, int act,

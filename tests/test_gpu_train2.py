@@ -429,6 +429,73 @@ def test_one_rank_rccl_collectives_leave_the_gradient_unchanged(tmp_path):
         print("one-graph capture of the collectives not available here:", str(got["onegraph_error"]))
 
 
+def _select_worker(rank, world, port, out_dir, backend):
+    import torch.distributed as dist
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    torch.cuda.set_device(0)
+    if backend == "nccl":
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    else:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    from dpot_amd import DPOTNet
+    from dpot_amd.dp import BucketedGradReducer
+    from dpot_amd.train import FlatParams, FusedAdam, GraphedTrainStep, SegmentedTrainStep, make_dp_step
+    cfg = R.DPOTConfig(**R.MINI)
+    model = DPOTNet(**R.MINI)
+    model.load_state_dict(R.recipe_state_dict(cfg, salt=17))
+    model.cuda()
+    fp = FlatParams(model)
+    red = BucketedGradReducer(fp, n_buckets=3, overlap=True)
+    red.single_rank_collective = backend == "nccl"
+    red.broadcast_parameters(0)
+    B = 4
+    xx = R.recipe_input((B, cfg.img_size, cfg.img_size, cfg.in_timesteps, cfg.in_channels), salt=81)
+    yy = R.recipe_input((B, cfg.img_size, cfg.img_size, 1, cfg.out_channels), salt=82)
+    sl = slice(2 * rank, 2 * rank + 2) if world > 1 else slice(0, B)
+    xs, ys = xx[sl].cuda(), yy[sl].cuda()
+    ms = torch.ones_like(ys)
+    opt = FusedAdam(fp, lr=1e-3, betas=(0.9, 0.9), weight_decay=1e-6, max_norm=1e4, update_tail=True)
+    before = (fp.flat.clone(), opt.exp_avg.clone(), int(opt.step_dev.item()))
+    step, info = make_dp_step(model, opt, red, xs, ys, ms, noise_scale=5e-4, warmup=1)
+    torch.cuda.synchronize()
+    # the selection leaves parameters / optimiser state as found
+    assert torch.equal(fp.flat, before[0]) and torch.equal(opt.exp_avg, before[1]) and int(opt.step_dev.item()) == before[2]
+    losses = [float(step.replay(1e-3).item()) for _ in range(3)]
+    torch.cuda.synchronize()
+    ref = fp.flat.clone()
+    dist.broadcast(ref, src=0)                               # (a device tensor: the nccl backend has no CPU path)
+    assert torch.equal(ref, fp.flat)                         # replicas stay identical
+    flat = fp.flat.cpu()
+    if rank == 0:
+        np.savez(os.path.join(out_dir, f"select_{backend}.npz"), mode=np.array(info["mode"]), why=np.array(info["why"]),
+                 kind=np.array(type(step).__name__), losses=np.array(losses), flat=flat.numpy())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+def test_dp_step_selection_one_rank_rccl_and_two_rank_gloo(tmp_path):
+    """round 6: train.make_dp_step builds the segmented chain AND the one-graph step, runs one trial step in
+    each from the same snapshot and keeps the one-graph step only if the reduced gradient is bit-identical between the modes
+    and across the ranks.  (a) one-rank RCCL communicator (the real library on the one GPU): the collectives capture, the
+    trial agrees -> one-graph SELECTED; (b) two ranks over gloo: a gloo collective cannot sit inside a stream capture -> the
+    capture fails on every rank, the selection FALLS BACK to the chain and says so; training continues either way and the
+    replicas stay bit-identical."""
+    import torch.multiprocessing as mp
+    mp.spawn(_select_worker, args=(1, _free_port(), str(tmp_path), "nccl"), nprocs=1, join=True)
+    a = np.load(os.path.join(str(tmp_path), "select_nccl.npz"))
+    assert str(a["mode"]) == "one-graph" and str(a["kind"]) == "GraphedTrainStep", (str(a["mode"]), str(a["why"]))
+    mp.spawn(_select_worker, args=(2, _free_port(), str(tmp_path), "gloo"), nprocs=2, join=True)
+    b = np.load(os.path.join(str(tmp_path), "select_gloo.npz"))
+    assert str(b["mode"]) == "segmented" and str(b["kind"]) == "SegmentedTrainStep"
+    assert "capture failed" in str(b["why"]), str(b["why"])
+    assert np.isfinite(a["losses"]).all() and np.isfinite(b["losses"]).all()
+
+
 def test_backward_after_optimiser_step_raises():
     """the derived weight packs are persistent buffers; a backward that runs AFTER the optimiser changed the
     parameters would silently use overwritten packs - it must raise instead"""
