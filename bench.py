@@ -265,13 +265,10 @@ def bf16_mlp_roofline(model, B: int):
     pk = ops.PanelPacks([(W1, mh, E, E, False)], bf16=True)
     pk.refresh()
     xp = ops.bf16_pack_rows(x)
-    # round 5: where the paired weight-gradient launch reads the hidden layer in ROW form (transposing LDS read), this launch
-    # no longer writes the transposed pack - as in the model (functional._mlp_rowform)
-    rowform = os.environ.get("DPOT_BF16P_ROWFORM", "0") == "1" and ops.gemm_bf16p_pair_rowform_ok(mh, E, mh, E, M)
     t = timeit_graph(lambda: ops.gemm_bf16p_packed(xp, pk.bufs[0], M, mh, E, bias=b1, act=1, mode=ops.EPI_ACT, save_dact=True,
-                                                    pack_rows=True, pack_trans=not rowform, store=False), reps=20)
+                                                    pack_rows=True, pack_trans=True, store=False), reps=20)
     fl = 2.0 * M * mh * E
-    npk = 2 if rowform else 3
+    npk = 3
     by = 2.0 * M * E + 2.0 * mh * E + npk * 2.0 * M * mh          # packed A + packed W read once, the bf16 packs written
     traffic, tnote, util = None, "no PMC profile for this shape (profiles/r05_pmc_bf16p_{S,M,L16}.json)", None
     for tag in ("M", "L16", "S"):                        # counter profiles by shape (scripts/gpu_pmc_bf16p_r05.sh SHAPE)
@@ -299,7 +296,7 @@ def bf16_mlp_roofline(model, B: int):
         log(f"[bench] hipBLASLt yardstick failed: {type(e).__name__}: {e}")
     return {"kernel": kname + " - channel-MLP fc1 forward: bf16 operands pre-packed fragment-block-major, "
                       "v_mfma_f32_32x32x16_bf16, epilogue in the accumulator layout writes the activated hidden layer as a row-form "
-                      "bf16 pack" + ("" if rowform else " + a transposed one") + " and act' as a bf16 pack",
+                      "bf16 pack + a transposed one and act' as a bf16 pack",
             "shape": [M, mh, E], "bound": "mfma", "achieved": round(fl / t / 1e12, 1), "peak": 2500.0, "unit": "TFLOP/s",
             "frac": round(fl / t / 1e12 / 2500.0, 4), "us_per_launch": round(t * 1e6, 2), "flops_per_launch": fl,
             "algorithmic_bytes_per_launch": by, "hbm_frac": round(by / t / 1e9 / HBM_PEAK_GBS, 4), "traffic": traffic,

@@ -9,5 +9,5 @@ The compute path is libdpot_hip.so (hand-written HIP kernels behind the C ABI in
 from .model import DPOTNet  # noqa: F401
 from . import _lib  # noqa: F401
 
-__version__ = "0.2.5"
+__version__ = "0.2.6"
 __all__ = ["DPOTNet"]

@@ -80,6 +80,7 @@ class SampleDesc(C.Structure):
 # name -> (restype, argtypes); every symbol include/dpot_hip.h declares
 SIGNATURES = {
     "dpot_version": (c_i, []),
+    "dpot_tune": (c_i, [C.c_char_p, c_i]),
     "dpot_last_error": (C.c_char_p, []),
     "dpot_gemm_f32": (c_i, [C.POINTER(GemmDesc), c_fp]),
     "dpot_gemm_workspace_bytes": (c_i64, [C.POINTER(GemmDesc)]),
@@ -107,7 +108,6 @@ SIGNATURES = {
     "dpot_groupnorm_param_grads": (c_i, [C.c_void_p] * 3 + [c_i] * 3 + [c_fp]),
     "dpot_afno_fused_supported": (c_i, [c_i] * 7),
     "dpot_afno_fused_fwd": (c_i, [c_fp] * 19 + [c_i] * 9 + [c_f, c_fp]),
-    "dpot_afno_fused_bwd": (c_i, [c_fp] * 19 + [c_i] * 9 + [c_fp]),
     "dpot_gn_dft_supported": (c_i, [c_i] * 4),
     "dpot_gn_rfft2": (c_i, [c_fp] * 6 + [c_i] * 8 + [c_f, c_fp]),
     "dpot_irfft2_gn": (c_i, [c_fp] * 12 + [c_i] * 9 + [c_f, c_fp]),
@@ -161,10 +161,8 @@ SIGNATURES = {
     "dpot_gemm_bf16p_splitk": (c_i, [c_i, c_i, c_i]),
     "dpot_gemm_bf16p_pair_wanted": (c_i, [c_i] * 5),
     "dpot_gemm_bf16p_pair_splitk": (c_i, [c_i] * 5),
-    "dpot_gemm_bf16p_pair_rowform_ok": (c_i, [c_i] * 5),
     "dpot_gemm_bf16p_kernel_kind": (c_i, [c_i] * 6),
-    "dpot_gemm_bf16p_pair": (c_i, [c_fp, c_fp, c_fp, c_i, c_i, c_i, c_fp, c_fp, c_fp, c_i, c_i, c_i, c_i, c_i, c_fp, c_i, c_i,
-                                   c_fp]),
+    "dpot_gemm_bf16p_pair": (c_i, [c_fp, c_fp, c_fp, c_i, c_i, c_i, c_fp, c_fp, c_fp, c_i, c_i, c_i, c_i, c_i, c_fp, c_fp]),
     "dpot_gemm_tn_splitk": (c_i, [c_i] * 4),
     "dpot_mlp_wgrad2_splitk": (c_i, [c_i] * 3),
     "dpot_mlp_wgrad2_ws_elems": (c_i64, [c_i] * 3),

@@ -536,437 +536,10 @@ __global__ __launch_bounds__(64 * AF_NW) void afno_fused_fwd_kernel(const AfnoFu
 #endif
 }
 
-// =====================================================================================================================
-// The BACKWARD of the same layer in one launch (round 5; the forward won at >= 205 workgroups, so the backward follows):
-//
-//   dxn2 -> GroupNorm2 backward -> dy1 -> rfft2 with the Hermitian column weights (adjoint of the forward irfft2) = dO2
-//        -> dO1 = dO2 W2^H, dO1pre = dO1 * act'(O1pre)  (O1 = act(O1pre) re-derived for the weight gradient)
-//        -> dS = dO1pre W1^H -> unweighted inverse transform (adjoint of the forward rfft2) + dy1 (the mixer's skip)
-//        -> GroupNorm1 backward + dout (the Block's outer skip) = dx
-//
-// replaces gn_bwd_rfft2 -> afno_mlp3 (mode 1) -> irfft2 (+ groupnorm_bwd | irfft2_gn_bwd).  Same workgroup = (sample,
-// channel block), same lane ownership as the forward: lane (c, q) of wave w owns channel 16 w + c and the token rows
-// q, q + 4, q + 8, q + 12 in BOTH transforms, so dy1 is re-derived in the last phase from the same two loads (dxn2, y1)
-// rather than kept in 64 registers across the MLP or written to HBM (the three-launch form writes and re-reads it).
-// Written for the weight-gradient launch (dpot_afno_wgrad2, unchanged): dO2, O1, dO1pre in the spectrum layout; the
-// GroupNorm parameter-gradient partials [2, B, E] (sum d xhat | sum d per sample and channel) as the gn_dft kernels
-// write them.  Wa / Wb are the layout-1 `bwd` packs (W^T, -Wi^T) of layer 2 and layer 1.
-struct AfnoFusedBwdArgs {
-  const float* dxn2;    // [B, 256, E] gradient wrt GroupNorm2's output (g2 == NULL: wrt y1 itself - the mixer alone)
-  const float* y1;      // [B, 256, E] GroupNorm2's input (with g2)
-  const float* mean2;   // [B, G]
-  const float* rstd2;
-  const float* g2;      // gamma2 or NULL
-  const float* pre;     // [B, 16, 9, nb, 2, 128] layer-1 pre-activation saved by the forward
-  const float* Wa;      // layer 2, `bwd` pack
-  const float* Wb;      // layer 1, `bwd` pack
-  const float* x;       // [B, 256, E] GroupNorm1's input (with g1)
-  const float* mean1;
-  const float* rstd1;
-  const float* g1;      // gamma1 or NULL
-  const float* add;     // [B, 256, E] or NULL: added to dx (outer skip)
-  float* dO2;           // spectrum layout
-  float* O1;
-  float* dPre;
-  float* dx;            // [B, 256, E]
-  float* part2;         // [2, B, E] (with g2)
-  float* part1;         // [2, B, E] (with g1)
-  int B, E, G, nb, act;
-};
-
-template <int CG, int ACTK>
-__global__ __launch_bounds__(64 * AF_NW) void afno_fused_bwd_kernel(const AfnoFusedBwdArgs p) {
-  __shared__ __attribute__((aligned(16))) float lds[AF_AREG + 128];
-  float* const A = lds;
-  double* const shd = reinterpret_cast<double*>(lds + AF_AREG);  // [2 norms][2 sums][8 waves] = 32 doubles
-
-  const int tid = threadIdx.x;
-  const int lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int c = lane & 15, q = lane >> 4;
-  const int hb = q >> 1, mb = q & 1;
-  const float sgn_h = hb ? -1.f : 1.f, sgn_m = mb ? -1.f : 1.f;
-  const bool rot = (hb & mb) != 0;
-  const int nb = p.nb, E = p.E;
-  const int kblk = (int)(blockIdx.x % (unsigned)nb), b = (int)(blockIdx.x / (unsigned)nb);
-  const int ch = kblk * AF_BS + 16 * wave + c;
-  const int grp = (kblk * AF_BS + 16 * wave) / CG;
-  constexpr int WPG = CG / 16;
-  const int gw0 = (wave / WPG) * WPG;
-  const float scale = 1.0f / 16.0f;
-
-  float tc[4], ts[4];
-  tc[0] = 1.f;
-  ts[0] = 0.f;
-#pragma unroll
-  for (int k = 1; k < 4; ++k) sincospif((float)(q * k) * 0.125f, &ts[k], &tc[k]);
-
-  auto bar = [&]() __attribute__((always_inline)) { __syncthreads(); };
-
-  // sum over the four lanes (q) of a channel; every one of them gets the same value
-  auto chan_sum = [&](float v) __attribute__((always_inline)) {
-    float lo, hi;
-    xchg32(v, lo, hi);
-    const float t = lo + hi;
-    xchg16(t, lo, hi);
-    return lo + hi;
-  };
-  // GroupNorm backward means of this wave's group from the per-channel sums (sb = sum d, sg = sum d xhat, already summed
-  // over the channel's four lanes): m1 = mean(gamma d), m2 = mean(gamma d xhat).  One barrier.
-  auto group_means = [&](float ga, float sb, float sg, int slot, float& m1, float& m2) __attribute__((always_inline)) {
-    double s1 = q == 0 ? (double)ga * (double)sb : 0.0;
-    double s2 = q == 0 ? (double)ga * (double)sg : 0.0;
-    s1 = wave_sum_d(s1);
-    s2 = wave_sum_d(s2);
-    double* sh = shd + slot * 16;
-    if (lane == 0) {
-      sh[wave] = s1;
-      sh[8 + wave] = s2;
-    }
-    bar();
-    double a = 0.0, bq = 0.0;
-#pragma unroll
-    for (int i = 0; i < WPG; ++i) {
-      a += sh[gw0 + i];
-      bq += sh[8 + gw0 + i];
-    }
-    constexpr double NE = (double)(AF_H * AF_W * CG);
-    m1 = (float)(a / NE);
-    m2 = (float)(bq / NE);
-  };
-
-  // ================================ phase A: GroupNorm2 backward + weighted rfft2 ================================
-  const long long fbase = (long long)b * (AF_H * AF_W) * E + kblk * AF_BS + 16 * wave;   // uniform
-  const int xlo = q * AF_W * E + c;
-  float Sr[4][AF_WF], Si[4][AF_WF];
-  float mu2 = 0.f, rs2 = 1.f, ga2 = 1.f, m1_2 = 0.f, m2_2 = 0.f;
-  {
-    const float* __restrict__ db = p.dxn2 + fbase;
-    float v[4][AF_W];
-#pragma unroll
-    for (int n1 = 0; n1 < 4; ++n1)
-#pragma unroll
-      for (int y = 0; y < AF_W; ++y) v[n1][y] = db[xlo + (n1 * 4 * AF_W + y) * E];
-    if (p.g2) {
-      const float* __restrict__ yb = p.y1 + fbase;
-      float xh[4][AF_W];
-      mu2 = p.mean2[b * p.G + grp];
-      rs2 = p.rstd2[b * p.G + grp];
-      ga2 = p.g2[ch];
-      float sd = 0.f, sx = 0.f;
-#pragma unroll
-      for (int n1 = 0; n1 < 4; ++n1)
-#pragma unroll
-        for (int y = 0; y < AF_W; ++y) {
-          xh[n1][y] = (yb[xlo + (n1 * 4 * AF_W + y) * E] - mu2) * rs2;
-          sd += v[n1][y];
-          sx = fmaf(v[n1][y], xh[n1][y], sx);
-        }
-      sd = chan_sum(sd);
-      sx = chan_sum(sx);
-      if (q == 0) {
-        p.part2[((long long)0 * p.B + b) * E + ch] = sx;
-        p.part2[((long long)1 * p.B + b) * E + ch] = sd;
-      }
-      group_means(ga2, sd, sx, 0, m1_2, m2_2);
-#pragma unroll
-      for (int n1 = 0; n1 < 4; ++n1)
-#pragma unroll
-        for (int y = 0; y < AF_W; ++y) v[n1][y] = rs2 * (ga2 * v[n1][y] - m1_2 - xh[n1][y] * m2_2);
-    }
-#pragma unroll
-    for (int n1 = 0; n1 < 4; ++n1) {
-      float vr[AF_W], vi[AF_W];
-#pragma unroll
-      for (int y = 0; y < AF_W; ++y) {
-        vr[y] = v[n1][y];
-        vi[y] = 0.f;
-      }
-      fft_regs<AF_W, -1>(vr, vi);
-      fft_sfor<0, AF_WF>([&](auto KY) __attribute__((always_inline)) {
-        constexpr int ky = decltype(KY)::value;
-        Sr[n1][ky] = vr[brev<AF_W>(ky)];
-        Si[n1][ky] = vi[brev<AF_W>(ky)];
-      });
-    }
-#pragma unroll
-    for (int ky = 0; ky < AF_WF; ++ky) {
-      float yr[4] = {Sr[0][ky], Sr[1][ky], Sr[2][ky], Sr[3][ky]};
-      float yi[4] = {Si[0][ky], Si[1][ky], Si[2][ky], Si[3][ky]};
-      dft4<-1>(yr, yi);
-      const float mul = scale * ((ky == 0 || ky == AF_W / 2) ? 1.f : 2.f);   // adjoint of the one-sided inverse
-#pragma unroll
-      for (int k1 = 0; k1 < 4; ++k1) {
-        float wr = yr[k1], wi = yi[k1];
-        if (k1 > 0) {
-          const float nr = fmaf(wr, tc[k1], wi * ts[k1]);
-          const float ni = fmaf(wi, tc[k1], -wr * ts[k1]);
-          wr = nr;
-          wi = ni;
-        }
-        float lo, hi;
-        xchg32(wr, lo, hi);
-        float tr = fmaf(sgn_h, hi, lo);
-        xchg32(wi, lo, hi);
-        float ti = fmaf(sgn_h, hi, lo);
-        const float rr = rot ? ti : tr, ri = rot ? -tr : ti;
-        xchg16(rr, lo, hi);
-        Sr[k1][ky] = fmaf(sgn_m, hi, lo) * mul;
-        xchg16(ri, lo, hi);
-        Si[k1][ky] = fmaf(sgn_m, hi, lo) * mul;
-      }
-    }
-  }
-
-  const int kq = c >> 2, ke = c & 3;
-  const int wofs = wave * 256 + kq * 64 + 16 * q + ke;
-  const int rofs = q * 64 + ((c ^ q) << 2);
-  const int ld2 = 2 * E;
-  const long long gbase = ((long long)b * (AF_H * AF_WF)) * ld2 + kblk * (2 * AF_BS) + 16 * wave;   // uniform
-  const int glo = (4 * (2 * mb + hb)) * AF_WF * ld2 + c;
-
-  // dO2 -> global + operand region
-#pragma unroll
-  for (int k1 = 0; k1 < 4; ++k1)
-#pragma unroll
-    for (int ky = 0; ky < AF_WF; ++ky) {
-      const int go = glo + (k1 * AF_WF + ky) * ld2;
-      p.dO2[gbase + go] = Sr[k1][ky];
-      p.dO2[gbase + go + AF_BS] = Si[k1][ky];
-      const int o = wofs + ((k1 ^ kq) << 2) + ky * AF_TILE;
-      A[o] = Sr[k1][ky];
-      A[o + 8 * 256] = Si[k1][ky];
-    }
-  bar();
-
-  f32x4 P1[AF_WF], P2[AF_WF], P3[AF_WF];
-  auto layer = [&](const float* __restrict__ Wl) __attribute__((always_inline)) {
-#pragma unroll
-    for (int i = 0; i < AF_WF; ++i) P1[i] = P2[i] = P3[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    const float* wl = Wl + (long long)kblk * (8 * 2 * 8 * 256) + wave * 256 + lane * 4;
-    f32x4 wr[3], wi[3];
-#pragma unroll
-    for (int u = 0; u < 2; ++u) {
-      wr[u] = *reinterpret_cast<const f32x4*>(wl + u * (2 * 8 * 256));
-      wi[u] = *reinterpret_cast<const f32x4*>(wl + u * (2 * 8 * 256) + 8 * 256);
-    }
-    f32x4 ar = *reinterpret_cast<const f32x4*>(A + rofs);
-    f32x4 ai = *reinterpret_cast<const f32x4*>(A + rofs + 8 * 256);
-    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-    for (int u = 0; u < 8; ++u) {
-      if (u + 2 < 8) {
-        wr[(u + 2) % 3] = *reinterpret_cast<const f32x4*>(wl + (u + 2) * (2 * 8 * 256));
-        wi[(u + 2) % 3] = *reinterpret_cast<const f32x4*>(wl + (u + 2) * (2 * 8 * 256) + 8 * 256);
-      }
-      const f32x4 br = wr[u % 3], bi = wi[u % 3];
-      const f32x4 bs = br + bi;
-#pragma unroll
-      for (int i = 0; i < AF_WF; ++i) {
-        const int un = i + 1 < AF_WF ? u : u + 1, in = i + 1 < AF_WF ? i + 1 : 0;
-        f32x4 arn = ar, ain = ai;
-        if (un < 8) {
-          arn = *reinterpret_cast<const f32x4*>(A + rofs + (in * 16 + un) * 256);
-          ain = *reinterpret_cast<const f32x4*>(A + rofs + (in * 16 + 8 + un) * 256);
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        const f32x4 as = ar + ai;
-#pragma unroll
-        for (int s2 = 0; s2 < 4; ++s2) {
-          P1[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(ar[s2], br[s2], P1[i], 0, 0, 0);
-          P2[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(ai[s2], bi[s2], P2[i], 0, 0, 0);
-          P3[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(as[s2], bs[s2], P3[i], 0, 0, 0);
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        ar = arn;
-        ai = ain;
-      }
-    }
-  };
-  auto recombine = [&]() __attribute__((always_inline)) {
-#pragma unroll
-    for (int i = 0; i < AF_WF; ++i)
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        Sr[e][i] = P1[i][e] - P2[i][e];
-        Si[e][i] = P3[i][e] - P1[i][e] - P2[i][e];
-      }
-  };
-
-  layer(p.Wa);
-  recombine();                                                   // dO1: this wave's 16 hidden channels (re | im)
-  bar();                                                         // every wave is done reading dO2
-  // dO1pre = dO1 * act'(O1pre) -> global + operand region; O1 = act(O1pre) -> global (operand of the weight gradient)
-  // (addresses off an OPAQUE copy of the lane offset, behind a scheduling barrier: otherwise the 72 pre-activation loads
-  // - independent of the layer - are hoisted above it and their registers spill)
-  int glo2 = glo;
-  asm volatile("" : "+v"(glo2));
-  __builtin_amdgcn_sched_barrier(0);
-  // the pre-activation of row group k1 + 1 is requested while group k1 is evaluated (two register sets, scheduling barriers
-  // at the group boundaries: left alone the scheduler hoists all 72 loads and the activation temporaries spill)
-  const float* __restrict__ pg = p.pre + gbase;
-  float pr[AF_WF], pi[AF_WF], prn[AF_WF], pin[AF_WF];
-#pragma unroll
-  for (int ky = 0; ky < AF_WF; ++ky) {
-    pr[ky] = pg[glo2 + ky * ld2];
-    pi[ky] = pg[glo2 + ky * ld2 + AF_BS];
-  }
-#pragma unroll
-  for (int k1 = 0; k1 < 4; ++k1) {
-    if (k1 < 3) {
-#pragma unroll
-      for (int ky = 0; ky < AF_WF; ++ky) {
-        prn[ky] = pg[glo2 + ((k1 + 1) * AF_WF + ky) * ld2];
-        pin[ky] = pg[glo2 + ((k1 + 1) * AF_WF + ky) * ld2 + AF_BS];
-      }
-    }
-    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-    for (int ky = 0; ky < AF_WF; ++ky) {
-      const int go = glo2 + (k1 * AF_WF + ky) * ld2;
-      float vr, dr, vi, di;
-      if (ACTK == DPOT_ACT_GELU) {
-        gelu_val_der(pr[ky], vr, dr);
-        gelu_val_der(pi[ky], vi, di);
-      } else {
-        vr = act_fwd(p.act, pr[ky]);
-        dr = act_bwd(p.act, pr[ky]);
-        vi = act_fwd(p.act, pi[ky]);
-        di = act_bwd(p.act, pi[ky]);
-      }
-      p.O1[gbase + go] = vr;
-      p.O1[gbase + go + AF_BS] = vi;
-      const float er = Sr[k1][ky] * dr, ei = Si[k1][ky] * di;
-      p.dPre[gbase + go] = er;
-      p.dPre[gbase + go + AF_BS] = ei;
-      const int o = wofs + ((k1 ^ kq) << 2) + ky * AF_TILE;
-      A[o] = er;
-      A[o + 8 * 256] = ei;
-    }
-    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-    for (int ky = 0; ky < AF_WF; ++ky) {
-      pr[ky] = prn[ky];
-      pi[ky] = pin[ky];
-    }
-  }
-  bar();
-  layer(p.Wb);
-  recombine();                                                   // dS
-
-  // ================================ phase C: unweighted inverse transform + dy1, GroupNorm1 backward + dout ===========
-#pragma unroll
-  for (int ky = 0; ky < AF_WF; ++ky) {
-    float yr[4], yi[4];
-#pragma unroll
-    for (int n1 = 0; n1 < 4; ++n1) {
-      float lo, hi;
-      xchg16(Sr[n1][ky], lo, hi);
-      const float tr = fmaf(sgn_m, hi, lo);
-      xchg16(Si[n1][ky], lo, hi);
-      const float ti = fmaf(sgn_m, hi, lo);
-      float er, orr, ei, oi;
-      xchg32(tr, er, orr);
-      xchg32(ti, ei, oi);
-      const float o2r = mb ? -oi : orr, o2i = mb ? orr : oi;
-      float wr = fmaf(sgn_h, o2r, er), wi = fmaf(sgn_h, o2i, ei);
-      if (n1 > 0) {
-        const float nr = fmaf(wr, tc[n1], -wi * ts[n1]);
-        const float ni = fmaf(wi, tc[n1], wr * ts[n1]);
-        wr = nr;
-        wi = ni;
-      }
-      yr[n1] = wr;
-      yi[n1] = wi;
-    }
-    dft4<1>(yr, yi);
-#pragma unroll
-    for (int k1 = 0; k1 < 4; ++k1) {
-      Sr[k1][ky] = yr[k1];
-      Si[k1][ky] = yi[k1];
-    }
-  }
-  int xlo2 = xlo;
-  asm volatile("" : "+v"(xlo2));
-  float mu1 = 0.f, rs1 = 1.f, ga1 = 1.f;
-  if (p.g1) {
-    mu1 = p.mean1[b * p.G + grp];
-    rs1 = p.rstd1[b * p.G + grp];
-    ga1 = p.g1[ch];
-  }
-  const float* __restrict__ db2 = p.dxn2 + fbase;
-  const float* __restrict__ yb2 = p.y1 + fbase;
-  const float* __restrict__ xb2 = p.x + fbase;
-  float dv[4][AF_W];                                             // (x-hat is re-derived from x in the apply loop: L2-hot)
-  float sd = 0.f, sx = 0.f;
-#pragma unroll
-  for (int k1 = 0; k1 < 4; ++k1) {
-    float ur[AF_W], ui[AF_W];
-#pragma unroll
-    for (int ky = 0; ky < AF_W; ++ky) {
-      ur[ky] = ky < AF_WF ? Sr[k1][ky] : 0.f;
-      ui[ky] = ky < AF_WF ? Si[k1][ky] : 0.f;
-    }
-    fft_regs<AF_W, 1>(ur, ui);
-    float dq[AF_W], yq[AF_W], xq[AF_W];
-#pragma unroll
-    for (int y = 0; y < AF_W; ++y) {
-      const int o = xlo2 + (k1 * 4 * AF_W + y) * E;
-      dq[y] = db2[o];
-      if (p.g2) yq[y] = yb2[o];
-      if (p.g1) xq[y] = xb2[o];
-    }
-    fft_sfor<0, AF_W>([&](auto YY) __attribute__((always_inline)) {
-      constexpr int yy = decltype(YY)::value;
-      float dy1 = dq[yy];
-      if (p.g2) dy1 = rs2 * (ga2 * dq[yy] - m1_2 - ((yq[yy] - mu2) * rs2) * m2_2);
-      const float d = fmaf(ur[brev<AF_W>(yy)], scale, dy1);
-      dv[k1][yy] = d;
-      if (p.g1) {
-        const float xh = (xq[yy] - mu1) * rs1;
-        sd += d;
-        sx = fmaf(d, xh, sx);
-      }
-    });
-    __builtin_amdgcn_sched_barrier(0);
-  }
-  float m1_1 = 0.f, m2_1 = 0.f;
-  if (p.g1) {
-    sd = chan_sum(sd);
-    sx = chan_sum(sx);
-    if (q == 0) {
-      p.part1[((long long)0 * p.B + b) * E + ch] = sx;
-      p.part1[((long long)1 * p.B + b) * E + ch] = sd;
-    }
-    group_means(ga1, sd, sx, 1, m1_1, m2_1);
-  }
-  int xlo3 = xlo2;
-  asm volatile("" : "+v"(xlo3));
-  const float* __restrict__ ab = p.add ? p.add + fbase : nullptr;
-  float* __restrict__ ob = p.dx + fbase;
-#pragma unroll
-  for (int k1 = 0; k1 < 4; ++k1) {                               // (one row group at a time: all 128 operand loads in flight
-#pragma unroll                                                   //  at once push the 64 held values out to scratch)
-    for (int y = 0; y < AF_W; ++y) {
-      const int o = xlo3 + (k1 * 4 * AF_W + y) * E;
-      float r = dv[k1][y];
-      if (p.g1) r = rs1 * (ga1 * r - m1_1 - ((xb2[o] - mu1) * rs1) * m2_1);
-      if (ab) r += ab[o];
-      ob[o] = r;
-    }
-    __builtin_amdgcn_sched_barrier(0);
-  }
-}
-
-template <int CG>
-static int launch_fused_bwd(const AfnoFusedBwdArgs& p, hipStream_t s) {
-  const dim3 grid((unsigned)(p.B * p.nb)), blk(64 * AF_NW);
-  if (p.act == DPOT_ACT_GELU)
-    hipLaunchKernelGGL((afno_fused_bwd_kernel<CG, DPOT_ACT_GELU>), grid, blk, 0, s, p);
-  else
-    hipLaunchKernelGGL((afno_fused_bwd_kernel<CG, -1>), grid, blk, 0, s, p);
-  return check_launch("afno_fused_bwd_kernel");
-}
+// (Round 5 also built the BACKWARD of the layer as one launch - GroupNorm2 backward -> weighted rfft2 -> both layers' data gradient ->
+// inverse + GroupNorm1 backward: parity-green and 15 % SLOWER than the four launches it replaced (205 vs 179 us at 256
+// workgroups, DPOT-S 5.27 -> 5.44 ms: a workgroup that owns its CU alone runs its load phases with nothing to hide them behind;
+// profiles/r05_f4_bwd_fused_vs_launches.txt, r05_f4_bwd_step_ab.txt).  Removed in round 6; the source is in the history.)
 
 template <int CG>
 static int launch_fused(const AfnoFusedArgs& p, hipStream_t s) {
@@ -1019,28 +592,4 @@ extern "C" int dpot_afno_fused_fwd(const float* x, const float* gamma1, const fl
   hipStream_t s = as_stream(stream);
   const int cg = norm ? E / G : 128;
   return cg == 64 ? launch_fused<64>(p, s) : launch_fused<128>(p, s);
-}
-
-extern "C" int dpot_afno_fused_bwd(const float* dxn2, const float* y1, const float* mean2, const float* rstd2,
-                                   const float* gamma2, const float* pre, const float* Wa_bwd2, const float* Wb_bwd1,
-                                   const float* x, const float* mean1, const float* rstd1, const float* gamma1,
-                                   const float* add, float* dO2, float* O1, float* dPre, float* dx, float* part2,
-                                   float* part1, int B, int h, int w, int E, int G, int nb, int mx, int my, int act,
-                                   dpot_stream_t stream) {
-  const bool norm = gamma1 || gamma2;
-  DPOT_REQUIRE(dpot_afno_fused_supported(h, w, E, norm ? G : 0, nb, mx, my),
-               "afno_fused_bwd: needs a 16x16 latent grid, 128 channels per block, all modes kept, 64 or 128 channels per group");
-  DPOT_REQUIRE(dxn2 && pre && Wa_bwd2 && Wb_bwd1 && dO2 && O1 && dPre && dx && B > 0, "afno_fused_bwd: bad argument");
-  DPOT_REQUIRE(!gamma2 || (y1 && mean2 && rstd2 && part2), "afno_fused_bwd: norm2 needs y1, mean2, rstd2, part2");
-  DPOT_REQUIRE(!gamma1 || (x && mean1 && rstd1 && part1), "afno_fused_bwd: norm1 needs x, mean1, rstd1, part1");
-  DPOT_REQUIRE(aligned16(Wa_bwd2) && aligned16(Wb_bwd1), "afno_fused_bwd: weight packs must be 16-byte aligned");
-  DPOT_REQUIRE((long long)B * nb <= 0x7fffffffLL && (long long)AF_H * AF_W * E < (1ll << 29), "afno_fused_bwd: too large");
-  AfnoFusedBwdArgs p;
-  p.dxn2 = dxn2; p.y1 = y1 ? y1 : dxn2; p.mean2 = mean2; p.rstd2 = rstd2; p.g2 = gamma2; p.pre = pre;
-  p.Wa = Wa_bwd2; p.Wb = Wb_bwd1; p.x = x ? x : dxn2; p.mean1 = mean1; p.rstd1 = rstd1; p.g1 = gamma1; p.add = add;
-  p.dO2 = dO2; p.O1 = O1; p.dPre = dPre; p.dx = dx; p.part2 = part2; p.part1 = part1;
-  p.B = B; p.E = E; p.G = G; p.nb = nb; p.act = act;
-  hipStream_t s = as_stream(stream);
-  const int cg = norm ? E / G : 128;
-  return cg == 64 ? launch_fused_bwd<64>(p, s) : launch_fused_bwd<128>(p, s);
 }

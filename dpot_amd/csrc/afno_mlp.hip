@@ -851,8 +851,6 @@ constexpr int AFNO_NUM_CU = 256;
 
 // rows per panel (multiple of 16, <= 80): fewest rounds of (panels * nb) workgroups over the CUs, one workgroup per CU
 static int pick_rt(int M, int nb) {
-  static const int forced = [] { const char* e = getenv("DPOT_AFNO_MLP_RT"); return e ? atoi(e) : 0; }();
-  if (forced >= 1 && forced <= 5) return forced;
   long long best_cost = -1;
   int best = 5;
   for (int rt = 5; rt >= 1; --rt) {
@@ -884,9 +882,8 @@ template <int BS, int ACTK>
 static int launch3_rt(const AfnoMlpArgs& p, int rt, hipStream_t s) {
   const dim3 grid((unsigned)(p.nb * p.panels)), blk(64 * (BS / 16 + 2));
   if constexpr (BS == 96) {
-    // six column tiles on eight compute waves (afno_mlp3_kernel<.., SPLIT>; DPOT_AFNO_SPLIT6=0: one wave per column tile)
-    static const int split6 = [] { const char* e = getenv("DPOT_AFNO_SPLIT6"); return e ? atoi(e) : 1; }();
-    if (split6 && rt >= 2) {
+    // six column tiles on eight compute waves (afno_mlp3_kernel<.., SPLIT>)
+    if (rt >= 2) {
       const dim3 blk8(64 * 10);
       switch (rt) {
         case 2: hipLaunchKernelGGL((afno_mlp3_kernel<2, BS, ACTK, true>), grid, blk8, 0, s, p); break;

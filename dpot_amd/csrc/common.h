@@ -4,6 +4,8 @@
 #include <stdint.h>
 #include <stdio.h>
 #include <stdarg.h>
+#include <stdlib.h>
+#include <string.h>
 
 #include "../../include/dpot_hip.h"
 
@@ -12,6 +14,9 @@ namespace dpot {
 // ---- error reporting -------------------------------------------------------------------------------
 void set_error(const char* fmt, ...);
 int check_launch(const char* what);
+// DPOT_TUNE="key=val,key=val": the ONE environment variable behind every fallback-path selector of the library (read once;
+// keys documented in DESIGN.md section 0 / dpot_amd/ops.py TUNE_KEYS).  Returns dflt when the key is absent.
+int tune(const char* key, int dflt);
 
 #define DPOT_REQUIRE(cond, ...)            \
   do {                                     \

@@ -585,7 +585,7 @@ static int launch_irfft2_128(const float* spec, const float* res, float* y, int 
 static inline int try_rfft2_fast(const float* x, float* spec, int B, int h, int w, int E, int nb, int mx, int my,
                                  int colw, float scale, hipStream_t s, int* rc,
                                  const DftNorm nrm = DftNorm{nullptr, nullptr, nullptr, nullptr, 0}) {
-  static const int forced = [] { const char* e = getenv("DPOT_DFT_CC"); return e ? atoi(e) : 0; }();
+  constexpr int forced = 0;      // (rounds 3-5: DPOT_DFT_CC forced a channel-chunk width for the sweeps in profiles/r05_dft_cc_L.txt)
   if (h == 16 && w == 16) {
     if (forced == 16 && E % 16 == 0) { *rc = launch_rfft2_fast<16, 16, 16>(x, spec, B, E, nb, mx, my, colw, scale, s, nrm); return 1; }
     // 64-channel slabs only when that still gives every CU >= 2 workgroups (latency hiding); else 32-channel slabs
@@ -626,7 +626,7 @@ static inline int try_rfft2_fast(const float* x, float* spec, int B, int h, int 
 static inline int try_irfft2_fast(const float* spec, const float* res, float* y, int B, int h, int w, int E, int nb,
                                   int mx, int my, int colw, float scale, hipStream_t s, int* rc,
                                   const DftNorm nrm = DftNorm{nullptr, nullptr, nullptr, nullptr, 0}) {
-  static const int forced = [] { const char* e = getenv("DPOT_DFT_CC"); return e ? atoi(e) : 0; }();
+  constexpr int forced = 0;      // (rounds 3-5: DPOT_DFT_CC forced a channel-chunk width for the sweeps in profiles/r05_dft_cc_L.txt)
   if (h == 16 && w == 16) {
     if (forced == 16 && E % 16 == 0) { *rc = launch_irfft2_fast<16, 16, 16>(spec, res, y, B, E, nb, mx, my, colw, scale, s, nrm); return 1; }
     if (forced != 32 && E % 64 == 0 && ((long long)B * (E / 64) >= 512 || forced == 64)) { *rc = launch_irfft2_fast<16, 16, 64>(spec, res, y, B, E, nb, mx, my, colw, scale, s, nrm); return 1; }

@@ -352,8 +352,8 @@ static int pick_tile(int M, int N, int batch, int forced) {
   // co-resident workgroups per CU hide each other's barriers, prologues and epilogues) is never slower than the
   // 128x128 tile for the native fp32 kernel, so auto picks it always; 128 stays available through desc.tile
   const long long t128 = (long long)cdiv(M, 128) * cdiv(N, 128) * batch;
-  static const int min128 = [] { const char* e = getenv("DPOT_TILE128_MIN_WG"); return e ? atoi(e) : (1 << 30); }();
-  return t128 >= min128 ? 128 : 64;
+  (void)t128;
+  return 64;
 }
 
 // bf16x6 path: the 128x128 tile owns 120 KB of LDS (one workgroup per CU) and halves both the operand-split work
@@ -376,8 +376,7 @@ extern "C" int dpot_gemm_auto_splitk(int M, int N, int K, int batch) {
   const int t = pick_tile(M, N, batch, 0);
   const long long tiles = (long long)cdiv(M, t) * cdiv(N, t) * batch;
   const int ktiles = cdiv(K, BK);
-  static const int per_cu = [] { const char* e = getenv("DPOT_SPLITK_WG_PER_CU"); return e ? atoi(e) : 2; }();
-  static const int min_slabs = [] { const char* e = getenv("DPOT_SPLITK_MIN_SLABS"); return e ? atoi(e) : 4; }();
+  constexpr int per_cu = 2, min_slabs = 4;
   if (tiles >= per_cu * NUM_CU || ktiles < 8) return 1;
   long long s = (per_cu * NUM_CU + tiles - 1) / tiles;   // aim at ~512 workgroups (2 per CU; measured in the DPOT
                                                          // step: 4 per CU costs more in workspace traffic + reduction than it gains)
@@ -392,10 +391,7 @@ extern "C" int dpot_gemm_auto_splitk(int M, int N, int K, int batch) {
 // (measured in the DPOT-Tiny step: 3 GFLOP and up: channel-MLP, embed and de-embed GEMMs), not on the 2.4 GFLOP batched AFNO mixer.
 static int resolve_precision(int precision, int M, int N, int K, int batch) {
   if (precision != DPOT_GEMM_AUTO) return precision;
-  static const double min_gflop = [] {
-    const char* e = getenv("DPOT_GEMM_AUTO_GFLOP");
-    return e ? atof(e) : 3.0;
-  }();
+  constexpr double min_gflop = 3.0;
   return 2.0 * M * N * K * batch >= min_gflop * 1e9 ? DPOT_GEMM_BF16X6 : DPOT_GEMM_F32;
 }
 
@@ -507,7 +503,7 @@ extern "C" int dpot_gemm_f32(const dpot_gemm_desc* d, dpot_stream_t stream) {
       if (vec) launch_gemm_split<64, true, 1, 4>(d, p, grid, s); else launch_gemm_split<64, false, 1, 4>(d, p, grid, s);
     }
   } else if (precision == DPOT_GEMM_BF16X6) {
-    static const int waves128 = [] { const char* e = getenv("DPOT_X_WAVES"); return e ? atoi(e) : 8; }();
+    constexpr int waves128 = 8;
     if (t == 128 && waves128 == 8) {
       if (vec) launch_gemm_split<128, true, 3, 8>(d, p, grid, s); else launch_gemm_split<128, false, 3, 8>(d, p, grid, s);
     } else if (t == 128) {

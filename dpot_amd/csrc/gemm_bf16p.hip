@@ -287,130 +287,8 @@ __global__ __launch_bounds__(64 * (COLT + PB_NLOAD)) void gemm_bf16p_kernel(cons
 // DPOT-M / -L shape (fc1 forward at DPOT-M 167.6 against 145.6 us, fc2 forward 134.6 against 92.3 us;
 // profiles/r03_bf16p_train_bench_tile256_rejected.txt) and was removed.)
 
-// ---------------------------------------------------------------------------------------------------------------------
-// "duo" form of the same GEMM for the launches with several rounds of tiles, built for the ones with a FAT epilogue (fc1
-// forward: GELU + its derivative + three bf16 packs = 201 MB at DPOT-M; fc2 data gradient).  In the 12-wave kernel above a CU holds ONE
-// workgroup (133 VGPRs x 12 waves), all 256 CUs run the same phase, and the epilogue (13.7 us per round of tiles at fc1
-// forward, 54 of 142 us) runs with the matrix pipes idle.  Here a workgroup is 8 SELF-LOADING waves with one fragment
-// register set (<= 128 VGPRs, 72 KiB of LDS): TWO workgroups share a CU, and the one in its epilogue leaves the matrix
-// pipes and the operand path to the other.  Same tile, wave grid, slab ring and epilogue code; the fragment reads of a
-// wave are no longer prefetched under its own MFMAs - the other three waves of the SIMD cover them.
-//   * per slab and wave: 3 of the 24 one-KiB DMA pieces; slab g + 2 is issued after barrier B_g (the slot of slab g - 1,
-//     which every wave has consumed: its MFMAs were issued before B_g), waited for (counted vmcnt) before B_(g+2);
-//   * nothing forces the two workgroups of a CU out of phase; a raised wave priority for the first 256 workgroups and a
-//     delayed start of the second 256 (0.3 - 0.7 of a main loop) were measured and change nothing
-//     (profiles/r03_bf16p_duo.txt): the gain is not an alternation of epilogue and main loop but 16 waves per CU in
-//     both - the main loop alone takes 65-72 us instead of 84-89 at fc1 forward of DPOT-M.
-// No split-K (the weight gradients have 3.4 MB epilogues and stay on the 12-wave kernel).
-__global__ __launch_bounds__(512, 4) void gemm_bf16p_duo_kernel(const Bf16pArgs p) {
-  __shared__ __attribute__((aligned(16))) unsigned char lds[3 * PB_SLABB];
-  const int tid = threadIdx.x;
-  const int lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int ks16 = p.K >> 4;
-  const int nslab = p.K >> 5;
-  const int bid0 = blockIdx.x;
-  int tm, tn;
-  {
-    const int ntiles = p.tilesM * p.tilesN;
-    const int xcd = bid0 & 7, slot = bid0 >> 3;
-    const int q = ntiles >> 3, r = ntiles & 7;
-    const int tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + slot;
-    tn = tile / p.tilesM;
-    tm = tile - tn * p.tilesM;
-  }
-  const int rt0 = tm * PB_ROWT, ct0 = tn * PB_COLT;
-  const int mtiles = (p.M + 31) >> 5;
-  // this wave's 3 pieces of a slab: piece b = wave + 8 n; b < 8: A (row tile b >> 1, k-half b & 1), else W
-  const unsigned short* src[3];
-  int dst[3];
-#pragma unroll
-  for (int n = 0; n < 3; ++n) {
-    const int b = wave + 8 * n;
-    if (b < 2 * PB_ROWT) {
-      int rt = rt0 + (b >> 1);
-      rt = rt < mtiles ? rt : mtiles - 1;
-      src[n] = p.A + ((long long)rt * ks16 + (b & 1)) * 512 + lane * 8;
-    } else {
-      const int c = b - 2 * PB_ROWT;
-      src[n] = p.W + ((long long)(ct0 + (c >> 1)) * ks16 + (c & 1)) * 512 + lane * 8;
-    }
-    dst[n] = b * 1024;
-  }
-  auto issue = [&](int t, int ring) __attribute__((always_inline)) {
-#pragma unroll
-    for (int n = 0; n < 3; ++n) bglds16(src[n] + (long long)t * 1024, lds + ring * PB_SLABB + dst[n]);
-  };
-
-  const int wm = wave >> 2, wn = wave & 3;
-  f32x16 acc[2][2];
-#pragma unroll
-  for (int i = 0; i < 2; ++i)
-#pragma unroll
-    for (int j = 0; j < 2; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-
-  issue(0, 0);
-  if (nslab > 1) issue(1, 1);
-  int ring = 0, ring2 = 2;                            // slots of slab g and of slab g + 2
-#pragma unroll 1
-  for (int g = 0; g < nslab; ++g) {
-    if (g + 1 < nslab) bwait_vm<3>(); else bwait_vm<0>();   // own pieces of slab g have landed (slab g + 1 may fly)
-    asm volatile("" ::: "memory");
-    __builtin_amdgcn_s_barrier();                     // B_g: slab g complete; slab g - 1 consumed by every wave
-    asm volatile("" ::: "memory");
-    if (g + 2 < nslab) issue(g + 2, ring2);
-    const unsigned char* base = lds + ring * PB_SLABB + lane * 16;
-    bf16x8_t a[2][2], b[2][2];
-#pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
-#pragma unroll
-      for (int i = 0; i < 2; ++i) a[i][ks] = *reinterpret_cast<const bf16x8_t*>(base + ((2 * wm + i) * 2 + ks) * 1024);
-#pragma unroll
-      for (int j = 0; j < 2; ++j)
-        b[j][ks] = *reinterpret_cast<const bf16x8_t*>(base + (2 * PB_ROWT + (2 * wn + j) * 2 + ks) * 1024);
-    }
-#pragma unroll
-    for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-      for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][ks], b[j][ks], acc[i][j], 0, 0, 0);
-    ring = ring == 2 ? 0 : ring + 1;
-    ring2 = ring2 == 2 ? 0 : ring2 + 1;
-  }
-  asm volatile("" ::: "memory");
-  __builtin_amdgcn_s_waitcnt(0xC07F);
-  __builtin_amdgcn_s_barrier();                       // S: every wave has read the last slab; the ring becomes staging
-  asm volatile("" ::: "memory");
-
-#ifdef PB_ABL_NOEPI
-  if (acc[0][0][0] == 12345.678f) reinterpret_cast<float*>(lds)[lane] = acc[1][1][3] + acc[0][1][2] + acc[1][0][1];
-  return;
-#endif
-  const int m0 = (rt0 + 2 * wm) * 32, n0 = (ct0 + 2 * wn) * 32;
-  if (p.out_rows || p.out_trans || p.cs_part || p.dact_out || p.dact_in) {
-    float* st1 = reinterpret_cast<float*>(lds) + wave * (32 * EPI_LD);
-    const bool direct = !p.e.pre && !p.e.res && !(p.e.mode == DPOT_EPI_DACT && !p.dact_in);
-#pragma unroll 1
-    for (int f = 0; f < 4; ++f) {
-      if (m0 + 32 * (f >> 1) >= p.M) break;
-      const f32x16 af = f == 0 ? acc[0][0] : f == 1 ? acc[0][1] : f == 2 ? acc[1][0] : acc[1][1];
-      if (direct) epi_fragment_direct(p, m0 + 32 * (f >> 1), n0 + 32 * (f & 1), af, st1, lane);
-      else epi_fragment_pack(p, m0 + 32 * (f >> 1), n0 + 32 * (f & 1), af, st1, lane);
-    }
-    return;
-  }
-  float* stage = reinterpret_cast<float*>(lds) + wave * (32 * EPI_LD);
-#pragma unroll 1
-  for (int f = 0; f < 4; ++f) {
-    const f32x16 af = f == 0 ? acc[0][0] : f == 1 ? acc[0][1] : f == 2 ? acc[1][0] : acc[1][1];
-    epi_fragment(p.e, 1, 0, m0 + 32 * (f >> 1), n0 + 32 * (f & 1), af, stage, lane);
-  }
-}
-
+// (Rounds 3-5 also carried a "duo" form of this kernel - two 8-wave workgroups per CU for launches with several rounds of tiles;
+// the B-direct kernels below took those launches in round 4 and it only ran behind an opt-out switch since: removed in round 6.)
 // ---------------------------------------------------------------------------------------------------------------------
 // "B-direct" form (round 4).  Round 3's ablations say the main loop of the kernels above is bound by the operand path:
 // ~845 CU cycles per 24 KiB slab whatever the clock, i.e. LDS-DMA (global_load ... lds) delivers ~29 B/clk/CU here - the
@@ -446,8 +324,7 @@ __device__ __forceinline__ void bd_sfor(F&& f) {   // static for: f(integral_con
 // BD_P = slabs of look-ahead (the loop is latency bound: period = load latency / look-ahead while that exceeds the 512
 // cycles of matrix-pipe time per slab), BD_RING = BD_P + 1 A slots in LDS / W register sets; the slab loop is unrolled by
 // the ring depth so that slots and register sets are compile-time constants.
-typedef short bd_s16x4 __attribute__((ext_vector_type(4)));
-template <int COLT, int CPW, int BD_P, bool ATR = false>
+template <int COLT, int CPW, int BD_P>
 __device__ __forceinline__ void gemm_bf16p_bd_body(const Bf16pArgs& p, const int bid0, const int zs) {
   constexpr int BD_RING = BD_P + 1;
   static_assert(COLT % CPW == 0, "column tiles must divide among the waves");
@@ -509,21 +386,10 @@ __device__ __forceinline__ void gemm_bf16p_bd_body(const Bf16pArgs& p, const int
     const int bb = ahas[n] ? b : 0;
     int rt = rt0 + (bb >> 1);
     rt = rt < mtiles ? rt : mtiles - 1;
-    if constexpr (ATR) {
-      // ROW-form source: the slab's 32 tokens x this row tile's 32 features are two 1 KiB blocks (feature halves fb) of
-      // chunks (token, 8 features).  LDS image of a row tile (2 KiB = 128 slots of 16 B) for the transposing read:
-      //   slot(t, fb, fh) = (t >> 2) * 16 + (fb * 2 + fh) * 4 + (t & 3)       fh = which 8 of the block's 16 features
-      // - the 16 chunks a 32-lane half of ds_read_b64_tr_b16 touches are 256 contiguous bytes (conflict free).  The DMA
-      // writes lane-linearly, so the permutation sits in the SOURCE address: instruction i = bb & 1 fills slots 64 i .. + 63,
-      // lane L <- token 16 i + 4 (L >> 4) + (L & 3), (fb, fh) = bits 3, 2 of L: four runs of 256 contiguous bytes
-      const int i = bb & 1, tk = 16 * i + 4 * (lane >> 4) + (lane & 3), fb = (lane >> 3) & 1, fh = (lane >> 2) & 1;
-      asrc[n] = p.A + ((long long)slab0 * (p.M >> 4) + 2 * rt + fb) * 512 + (fh * 32 + tk) * 8;
-    } else {
-      asrc[n] = p.A + ((long long)rt * ks16 + 2 * slab0 + (bb & 1)) * 512 + lane * 8;
-    }
+    asrc[n] = p.A + ((long long)rt * ks16 + 2 * slab0 + (bb & 1)) * 512 + lane * 8;
     adst[n] = bb * 1024;
   }
-  const long long astride = ATR ? (long long)(p.M >> 4) * 512 : 1024;    // elements between consecutive slabs of A
+  constexpr long long astride = 1024;                             // elements between consecutive slabs of A
   // this wave's W streams: column tiles ct0 + CPW wave + j, blocks 2 (slab0 + t) + ks
   const unsigned short* wsrc = p.W + ((long long)(ct0 + CPW * wave) * ks16 + 2 * slab0) * 512 + lane * 8;
   const long long wcol = (long long)ks16 * 512;                   // elements between neighbouring column tiles
@@ -574,31 +440,11 @@ __device__ __forceinline__ void gemm_bf16p_bd_body(const Bf16pArgs& p, const int
     asm volatile("" ::: "memory");
     issue(g + BD_P, SN);                                    // into the slot / register set of slab g - 1
     bf16x8_t a[PB_ROWT][2];
-    if constexpr (ATR) {
-      // lane (f = lane & 31, kg = lane >> 5) wants tokens 16 ks + 8 kg .. + 7 of feature f: two transposing 64-bit reads
-      // (4 tokens each).  Inside a 16-lane group lane s SUPPLIES the address of (token T0 + (s >> 2), features 4 (s & 3) ..
-      // + 3) and RECEIVES feature s of the four tokens (scripts/ubench/tr_read_layout.hip checks image + addressing)
-      const int kg = lane >> 5, fb = (lane >> 4) & 1;
-      const unsigned char* base = lds + s * BD_ASLAB +
-                                  (((2 * kg) * 16 + (fb * 2 + ((lane & 3) >> 1)) * 4 + ((lane >> 2) & 3)) * 16 + (lane & 1) * 8);
+    const unsigned char* base = lds + s * BD_ASLAB + lane * 16;
 #pragma unroll
-      for (int ks = 0; ks < 2; ++ks)
+    for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
-        for (int i = 0; i < PB_ROWT; ++i) {
-          typedef __attribute__((address_space(3))) bd_s16x4 lds_s16x4;
-          const bd_s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(base + i * 2048 + ks * 1024));
-          const bd_s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(base + i * 2048 + ks * 1024 + 256));
-          typedef short s16x8 __attribute__((ext_vector_type(8)));
-          const s16x8 both = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
-          a[i][ks] = __builtin_bit_cast(bf16x8_t, both);
-        }
-    } else {
-      const unsigned char* base = lds + s * BD_ASLAB + lane * 16;
-#pragma unroll
-      for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-        for (int i = 0; i < PB_ROWT; ++i) a[i][ks] = *reinterpret_cast<const bf16x8_t*>(base + (i * 2 + ks) * 1024);
-    }
+      for (int i = 0; i < PB_ROWT; ++i) a[i][ks] = *reinterpret_cast<const bf16x8_t*>(base + (i * 2 + ks) * 1024);
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
@@ -626,24 +472,6 @@ __device__ __forceinline__ void gemm_bf16p_bd_body(const Bf16pArgs& p, const int
 
   float* stage = reinterpret_cast<float*>(lds) + wave * (32 * EPI_LD);
   const int m0 = rt0 * 32, n0 = (ct0 + CPW * wave) * 32;
-  if (p.transC) {
-    // fp32 result (or split-K partial: the reduce then runs over [N, M]) stored transposed, fragment by fragment
-    float* ct = p.splits > 1 ? p.ws + (long long)zs * p.M * p.N : p.e.C;
-    const int ldct = p.splits > 1 ? p.M : p.e.ldc;
-#pragma unroll 1
-    for (int f = 0; f < PB_ROWT * CPW; ++f) {
-      const int fi = f / CPW, fj = f - fi * CPW;
-      f32x16 af;
-      if constexpr (CPW == 1) {
-        af = f == 0 ? acc[0][0] : f == 1 ? acc[1][0] : f == 2 ? acc[2][0] : acc[3][0];
-      } else {
-        af = f == 0 ? acc[0][0] : f == 1 ? acc[0][1] : f == 2 ? acc[1][0] : f == 3 ? acc[1][1] : f == 4 ? acc[2][0]
-           : f == 5 ? acc[2][1] : f == 6 ? acc[3][0] : acc[3][1];
-      }
-      epi_fragment_T(ct, ldct, p.M, p.N, m0 + 32 * fi, n0 + 32 * fj, af, stage, lane);
-    }
-    return;
-  }
   if (p.splits > 1) {
     float* ws = p.ws + (long long)zs * p.M * p.N;
     const int li = lane & 31, kh = lane >> 5;
@@ -702,10 +530,10 @@ __global__ __launch_bounds__(64 * (COLT + PB_NLOAD)) void gemm_bf16p_pair_kernel
   gemm_bf16p_body<COLT>(pp.a[which], (int)blockIdx.x - which * pp.n0, blockIdx.y);   // blockIdx.y: common split-K index
 }
 
-template <int COLT, int CPW, int P, bool ATR = false>
+template <int COLT, int CPW, int P>
 __global__ __launch_bounds__(64 * COLT / CPW, 2) void gemm_bf16p_bd_pair_kernel(const Bf16pPair pp) {
   const int which = (int)blockIdx.x >= pp.n0 ? 1 : 0;
-  gemm_bf16p_bd_body<COLT, CPW, P, ATR>(pp.a[which], (int)blockIdx.x - which * pp.n0, blockIdx.y);
+  gemm_bf16p_bd_body<COLT, CPW, P>(pp.a[which], (int)blockIdx.x - which * pp.n0, blockIdx.y);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -1250,7 +1078,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
 // (row-major) ~tilesM / 8 A panels x all their column chunks; an operand piece is fetched once per XCD that touches it.
 // Round 4: the counters showed every bf16 launch moving 4.0-4.7 TB/s through the fabric, 2.1-2.9x its algorithmic bytes.
 static int bf16p_row_major(int tilesM, int tilesN, int rowt, int colt) {
-  static const int enabled = [] { const char* ev = getenv("DPOT_BF16P_ROWMAJOR"); return ev ? atoi(ev) : 1; }();
+  static const int enabled = tune("bf16p_shape", 1);     // 0: none of the shape heuristics (tests: plain column-major order)
   if (!enabled) return 0;
   auto cost = [&](int outer, int inner, double outer_bytes, double inner_bytes) {
     // enumeration with `outer` slowest: an XCD's n / 8 consecutive tiles span ceil-ish (n / 8) / inner + 1 outer values
@@ -1264,16 +1092,14 @@ static int bf16p_row_major(int tilesM, int tilesN, int rowt, int colt) {
   return row < 0.95 * col ? 1 : 0;
 }
 
-// B-direct kernels: 32-column tiles per wave (DPOT_BF16P_BD_CPW: 1 = eight 128 x 32 waves, one workgroup per CU; 2 = four
-// 128 x 64 waves, two workgroups per CU)
+// B-direct kernels: 32-column tiles per wave - 1 = eight 128 x 32 waves, one workgroup per CU; 2 = four 128 x 64 waves, two
+// workgroups per CU once there are >= 2 tiles per CU (the second workgroup then exists); a single round of <= 256..511 tiles
+// keeps eight waves per workgroup (four would be ONE wave per SIMD).  Measured (profiles/r04_bf16p_bd_cpw.txt): DPOT-L at
+// batch 16, fc1 forward 408 -> 371 us, fc2 data gradient 378 -> 352; DPOT-M's 256-tile launches 74.8 -> 84.2 us the other way
+// round.  (DPOT_TUNE bf16p_shape=0: always eight waves)
 static int bd_cpw(long long tiles) {
-  // auto (0): two workgroups of four fat waves per CU once there are >= 2 tiles per CU (the second workgroup then exists);
-  // a single round of <= 256..511 tiles keeps eight waves per workgroup (four would be ONE wave per SIMD).  Measured
-  // (profiles/r04_bf16p_bd_cpw.txt): DPOT-L at batch 16, fc1 forward 408 -> 371 us, fc2 data gradient 378 -> 352; DPOT-M's
-  // 256-tile launches 74.8 -> 84.2 us the other way round
-  static const int v = [] { const char* ev = getenv("DPOT_BF16P_BD_CPW"); return ev ? atoi(ev) : 0; }();
-  if (v == 1 || v == 2) return v;
-  return tiles >= 512 ? 2 : 1;
+  static const int shape = tune("bf16p_shape", 1);
+  return shape && tiles >= 512 ? 2 : 1;
 }
 
 // (slabs of look-ahead of the B-direct kernels: 3.  4 / 5 / 7 were built and measured on the theory that the loop is bound by
@@ -1301,8 +1127,8 @@ extern "C" int dpot_gemm_bf16p_splitk(int M, int N, int K) {
 static void bf16p_pick_super(int tilesM, int tilesN, int splits, int* sr, int* sc, bool bdirect) {
   // default: on (both ranges) for the B-direct kernels - round 4, inside the step: DPOT-M 14.36 -> 14.04 ms, DPOT-L 97.8 -> 95.3 ms
   // (profiles/r04_bf16p_bd_raster.txt; the faster main loop feels the 2-4 fetches of every A panel) - off for the LDS-DMA ones
-  static const int env = [] { const char* e = getenv("DPOT_BF16P_RASTER"); return e ? atoi(e) : -1; }();
-  const int enabled = env >= 0 ? env : (bdirect ? 3 : 0);
+  static const int shape = tune("bf16p_shape", 1);
+  const int enabled = shape && bdirect ? 3 : 0;
   *sr = 0; *sc = 0;
   const long long nt = (long long)tilesM * tilesN;
   // 1: the launches with >= 512 tiles (instead of the two-workgroup kernel); 2: only those with one round of 256..511 tiles
@@ -1318,7 +1144,7 @@ static void bf16p_pick_super(int tilesM, int tilesN, int splits, int* sr, int* s
 // bench.py reports) read the same plan
 struct Bf16pPlan {
   int tilesM, tilesN, splits, slabs_per_split, super_r, super_c, colt, cpw;
-  bool use_bd, use_duo;
+  bool use_bd;
   unsigned grid;
 };
 static Bf16pPlan bf16p_plan(int M, int N, int K, int splitk, int planes, bool packs) {
@@ -1329,20 +1155,18 @@ static Bf16pPlan bf16p_plan(int M, int N, int K, int splitk, int planes, bool pa
   pl.splits = splitk > 1 ? splitk : 1;
   pl.slabs_per_split = (nslab + pl.splits - 1) / pl.splits;
   pl.splits = (nslab + pl.slabs_per_split - 1) / pl.slabs_per_split;       // no empty split
-  // B-direct form (DPOT_BF16P_BD: 1 (default) = by the shape rule, 3 = every plain-bf16 launch, 0 = off: the LDS-DMA kernels of
-  // rounds 2-3, 2 = only the launches the duo kernel does not take - those then run in the XCD-contiguous order, not the
-  // super-block one).  Shape rule: launches with several rounds of tiles or a long contraction; a single round of tiles with
-  // K < 2048 (DPOT-S: 8192 x 1024 x 1024, 256 tiles, 32 slabs) keeps the LDS-DMA kernels, whose dedicated loader waves start
-  // the pipeline sooner - DPOT-S 5.73 -> 5.94 ms with B-direct everywhere, DPOT-M 14.97 -> 14.24, DPOT-L 102.9 -> 96.2
-  // (profiles/r04_bf16p_bd_step_ab_one_box.txt)
-  static const int bd = [] { const char* ev = getenv("DPOT_BF16P_BD"); return ev ? atoi(ev) : 1; }();
+  // B-direct form (DPOT_TUNE bf16p_bd=0: off - the LDS-DMA kernels of rounds 2-3 everywhere).  Shape rule: launches with
+  // several rounds of tiles or a long contraction; a single round of tiles with K < 2048 (DPOT-S: 8192 x 1024 x 1024, 256
+  // tiles, 32 slabs) keeps the LDS-DMA kernel, whose dedicated loader waves start the pipeline sooner - DPOT-S 5.73 -> 5.94 ms
+  // with B-direct everywhere, DPOT-M 14.97 -> 14.24, DPOT-L 102.9 -> 96.2 (profiles/r04_bf16p_bd_step_ab_one_box.txt)
+  static const int bd = tune("bf16p_bd", 1);
   const bool bd_shape = (long long)pl.tilesM * pl.tilesN * pl.splits >= 512 || pl.slabs_per_split >= 64;
-  const bool bd_first = planes == 1 && ((bd == 1 && bd_shape) || bd == 3);
+  const bool bd_first = planes == 1 && bd && bd_shape;
   bf16p_pick_super(pl.tilesM, pl.tilesN, pl.splits, &pl.super_r, &pl.super_c, bd_first);
   // 128 x 192 tiles where they fill the rounds of 256 CUs better (as for the pair launch below; a 192-wide tile costs ~0.83
   // of a 256-wide one): DPOT-L at batch 4 has 32 x 6 = 192 tiles of 128 x 256 in fc2 forward / fc1 data gradient - a
   // quarter of the chip idle - and 32 x 8 = 256 of 128 x 192
-  static const int allow192 = [] { const char* ev = getenv("DPOT_BF16P_TILE192"); return ev ? atoi(ev) : 1; }();
+  static const int allow192 = tune("bf16p_shape", 1);
   pl.colt = PB_COLT;
   if (allow192 && planes == 1 && N % 192 == 0 && pl.super_r == 0) {
     const long long t8 = (long long)pl.tilesM * pl.tilesN * pl.splits, t6 = (long long)pl.tilesM * (N / 192) * pl.splits;
@@ -1351,14 +1175,7 @@ static Bf16pPlan bf16p_plan(int M, int N, int K, int splitk, int planes, bool pa
   if (pl.colt == 6) pl.tilesN = N / 192;
   pl.grid = (unsigned)(pl.tilesM * pl.tilesN);
   if (pl.super_r > 0) pl.grid = 256u * (unsigned)((pl.tilesM * pl.tilesN / 32 + 7) / 8);
-  // duo form (two workgroups per CU): every unsplit launch with >= 2 tiles per CU (DPOT_BF16P_DUO=0: never; 3: only the
-  // launches with packed outputs).  Measured inside the DPOT-L step at batch 16, where the fp32-output launches have 768
-  // tiles as well: 106.2 -> 104.0 ms with them on this kernel too (profiles/r03_bf16p_duo.txt)
-  static const int duo = [] { const char* ev = getenv("DPOT_BF16P_DUO"); return ev ? atoi(ev) : 1; }();
-  pl.use_duo = planes == 1 && pl.colt == PB_COLT && pl.splits == 1 && pl.super_r == 0 &&
-               (long long)pl.tilesM * pl.tilesN >= 512 && (duo == 1 || duo == 2 || (duo == 3 && packs));
-  pl.use_bd = bd_first || (planes == 1 && bd == 2 && !pl.use_duo);
-  if (pl.use_bd) pl.use_duo = false;
+  pl.use_bd = bd_first;
   if (pl.use_bd && pl.super_r == 0) pl.super_c = bf16p_row_major(pl.tilesM, pl.tilesN, PB_ROWT, pl.colt);
   pl.cpw = pl.colt == 6 ? 1 : bd_cpw((long long)pl.tilesM * pl.tilesN * pl.splits);
   // (Round 6 built a 256 x 256 / 256 x 192 "big tile" form - four waves of 128 x 128 accumulators on the unified 512-entry register
@@ -1368,14 +1185,14 @@ static Bf16pPlan bf16p_plan(int M, int N, int K, int splitk, int planes, bool pa
   // profiles/r06_bt_step_ab.txt, r06_gemm_yardstick_bt.txt; the source is in the history: commit 'big-tile bf16 GEMM measured'.)
   return pl;
 }
-// which kernel dpot_gemm_bf16p runs for a shape: 0 = LDS-DMA (8 compute + 4 loader waves), 1 = two-workgroup ("duo"),
+// which kernel dpot_gemm_bf16p runs for a shape: 0 = LDS-DMA (8 compute + 4 loader waves), (1: the "duo" kernel, removed),
 // 2 = B-direct with eight 128 x 32 waves, 3 = B-direct with four 128 x 64 waves (two workgroups per CU), 4 = bf16x6;
 // + 8: on 128 x 192 tiles
 extern "C" int dpot_gemm_bf16p_kernel_kind(int M, int N, int K, int splitk, int planes, int packed_outputs) {
   if (!dpot_gemm_bf16p_supported(M, N, K)) return -1;
   if (planes == 3) return 4;
   const Bf16pPlan pl = bf16p_plan(M, N, K, splitk, planes, packed_outputs != 0);
-  const int kind = pl.use_bd ? (pl.cpw == 2 ? 3 : 2) : pl.use_duo ? 1 : 0;
+  const int kind = pl.use_bd ? (pl.cpw == 2 ? 3 : 2) : 0;
   return kind + (pl.colt == 6 ? 8 : 0);
 }
 
@@ -1426,12 +1243,11 @@ extern "C" int dpot_gemm_bf16p(const void* Apacked, const void* Wpacked, const f
   p.cs_part = colsum_part;
   p.dact_out = reinterpret_cast<uint4*>(dact_out);
   p.dact_in = reinterpret_cast<const unsigned short*>(dact_in);
-  p.a_rowform = 0; p.transC = 0;
   const Bf16pPlan pl = bf16p_plan(M, N, K, splitk, planes, packs);
   p.splits = pl.splits; p.slabs_per_split = pl.slabs_per_split; p.tilesN = pl.tilesN;
   p.super_r = pl.super_r; p.super_c = pl.super_c;
   const int colt = pl.colt, cpw = pl.cpw;
-  const bool use_bd = pl.use_bd, use_duo = pl.use_duo;
+  const bool use_bd = pl.use_bd;
   const unsigned grid = pl.grid;
   if (planes == 3)
     hipLaunchKernelGGL(gemm_bf16x6p_kernel, dim3((unsigned)(p.tilesM * p.tilesN), p.splits), dim3(512), 0,
@@ -1443,8 +1259,6 @@ extern "C" int dpot_gemm_bf16p(const void* Apacked, const void* Wpacked, const f
     else BD_LAUNCH(8, 1, 3);
 #undef BD_LAUNCH
   }
-  else if (use_duo)
-    hipLaunchKernelGGL(gemm_bf16p_duo_kernel, dim3(grid), dim3(512), 0, as_stream(stream), p);
   else if (colt == 6)
     hipLaunchKernelGGL(gemm_bf16p_kernel<6>, dim3(grid, p.splits), dim3(64 * (6 + PB_NLOAD)), 0, as_stream(stream), p);
   else
@@ -1463,7 +1277,7 @@ extern "C" int dpot_gemm_bf16p(const void* Apacked, const void* Wpacked, const f
 // split-K factor of the pair launch (common to both problems): 0 = do not pair, 1 = pair without split, s > 1 = pair
 // with s splits (workspace: s * (M0*N0 + M1*N1) floats; two fixed-order reduce launches follow)
 extern "C" int dpot_gemm_bf16p_pair_splitk(int M0, int N0, int M1, int N1, int K) {
-  static const int enabled = [] { const char* e = getenv("DPOT_BF16P_PAIR"); return e ? atoi(e) : 1; }();
+  static const int enabled = tune("bf16p_shape", 1);
   if (!enabled || !dpot_gemm_bf16p_supported(M0, N0, K) || !dpot_gemm_bf16p_supported(M1, N1, K)) return 0;
   const long long t0 = (long long)((M0 + 127) / 128) * (N0 / 256), t1 = (long long)((M1 + 127) / 128) * (N1 / 256);
   if (t0 < 192 && t1 < 192) {
@@ -1487,45 +1301,19 @@ extern "C" int dpot_gemm_bf16p_pair_wanted(int M0, int N0, int M1, int N1, int K
   return dpot_gemm_bf16p_pair_splitk(M0, N0, M1, N1, K) > 0 ? 1 : 0;
 }
 
-// the pair launch with ROW-form A operands (read through ds_read_b64_tr_b16) exists in the B-direct kernels without split-K
+// B-direct pair launch: several rounds of tiles or a long contraction (as bf16p_plan)
 static bool pair_use_bd(long long grid, int splits, int sps) {
-  static const int bd = [] { const char* ev = getenv("DPOT_BF16P_BD"); return ev ? atoi(ev) : 1; }();
-  return bd == 3 || (bd && (grid * splits >= 512 || sps >= 128));
-}
-static long long pair_grid(int M0, int N0, int M1, int N1, int splits, int* colt_out) {
-  static const int allow192 = [] { const char* ev = getenv("DPOT_BF16P_TILE192"); return ev ? atoi(ev) : 1; }();
-  const long long tm0 = (M0 + 127) / 128, tm1 = (M1 + 127) / 128;
-  int colt = PB_COLT;
-  if (allow192 && splits == 1 && N0 % 192 == 0 && N1 % 192 == 0) {
-    const long long t8 = tm0 * (N0 / 256) + tm1 * (N1 / 256), t6 = tm0 * (N0 / 192) + tm1 * (N1 / 192);
-    const double c8 = (double)((t8 + 255) / 256), c6 = 0.83 * (double)((t6 + 255) / 256);
-    if (c6 < 0.97 * c8) colt = 6;
-  }
-  if (colt_out) *colt_out = colt;
-  return tm0 * (N0 / (32 * colt)) + tm1 * (N1 / (32 * colt));
-}
-// 1: dpot_gemm_bf16p_pair(M0, N0, M1, N1, K) can take ROW-form A operands (a_rowform) and transposed outputs (transC) -
-// a caller that uses them can skip the transposed packs of the operands it hands over as A.  (A capability, not a
-// recommendation: measured in round 5 the launch is 1.8x slower with them - the permuted LDS-DMA source, four 256-byte runs
-// per wave instruction instead of one KiB, runs at a fraction of the linear rate - see ops / DESIGN.md.)
-extern "C" int dpot_gemm_bf16p_pair_rowform_ok(int M0, int N0, int M1, int N1, int K) {
-  if (dpot_gemm_bf16p_pair_splitk(M0, N0, M1, N1, K) != 1) return 0;
-  if (M0 % 32 || M1 % 32 || K % 32) return 0;
-  const long long grid = pair_grid(M0, N0, M1, N1, 1, nullptr);
-  return pair_use_bd(grid, 1, K >> 5) ? 1 : 0;
+  static const int bd = tune("bf16p_bd", 1);
+  return bd && (grid * splits >= 512 || sps >= 128);
 }
 
 extern "C" int dpot_gemm_bf16p_pair(const void* A0, const void* W0, float* C0, int ldc0, int M0, int N0, const void* A1,
                                     const void* W1, float* C1, int ldc1, int M1, int N1, int K, int splitk,
-                                    float* workspace, int a_rowform, int transC, dpot_stream_t stream) {
+                                    float* workspace, dpot_stream_t stream) {
   DPOT_REQUIRE(A0 && W0 && C0 && A1 && W1 && C1, "gemm_bf16p_pair: null operand");
-  DPOT_REQUIRE((a_rowform & ~3) == 0 && (transC & ~3) == 0, "gemm_bf16p_pair: a_rowform / transC are 2-bit masks");
-  DPOT_REQUIRE(!(a_rowform | transC) || dpot_gemm_bf16p_pair_rowform_ok(M0, N0, M1, N1, K),
-               "gemm_bf16p_pair: row-form operands / transposed outputs need the un-split B-direct launch "
-               "(dpot_gemm_bf16p_pair_rowform_ok)");
   DPOT_REQUIRE(dpot_gemm_bf16p_supported(M0, N0, K) && dpot_gemm_bf16p_supported(M1, N1, K),
                "gemm_bf16p_pair: unsupported shape (N %% 256, K %% 32)");
-  DPOT_REQUIRE(ldc0 >= ((transC & 1) ? M0 : N0) && ldc1 >= ((transC & 2) ? M1 : N1) && ldc0 % 4 == 0 && ldc1 % 4 == 0 &&
+  DPOT_REQUIRE(ldc0 >= N0 && ldc1 >= N1 && ldc0 % 4 == 0 && ldc1 % 4 == 0 &&
                    aligned16(A0) && aligned16(W0) && aligned16(C0) && aligned16(A1) && aligned16(W1) && aligned16(C1) &&
                    aligned16(workspace),
                "gemm_bf16p_pair: bad leading dimension / alignment");
@@ -1561,14 +1349,12 @@ extern "C" int dpot_gemm_bf16p_pair(const void* A0, const void* W0, float* C0, i
     p.ws = wss[i];
     p.out_rows = nullptr; p.out_trans = nullptr; p.cs_part = nullptr;
     p.dact_out = nullptr; p.dact_in = nullptr; p.super_r = 0; p.super_c = 0;
-    p.a_rowform = (a_rowform >> i) & 1;
-    p.transC = (transC >> i) & 1;
   }
   // 128 x 192 tiles when they need fewer workgroup-rounds' worth of time: DPOT-L's weight gradients are 1536 x 6144 and
   // 6144 x 1536 - 288 + 288 tiles of 128 x 256 = 2.25 rounds of 256 CUs, i.e. THREE rounds; 384 + 384 tiles of 128 x 192 are
   // exactly three rounds of tiles three quarters the size (a 192-wide tile costs ~0.83 of a 256-wide one: 20 instead of
   // 24 KiB of operands per slab, and the loop is bound by those)
-  static const int allow192 = [] { const char* ev = getenv("DPOT_BF16P_TILE192"); return ev ? atoi(ev) : 1; }();
+  static const int allow192 = tune("bf16p_shape", 1);
   int colt = PB_COLT;
   if (allow192 && splits == 1 && N0 % 192 == 0 && N1 % 192 == 0) {
     const long long t8 = (long long)pp.a[0].tilesM * pp.a[0].tilesN + (long long)pp.a[1].tilesM * pp.a[1].tilesN;
@@ -1583,21 +1369,13 @@ extern "C" int dpot_gemm_bf16p_pair(const void* A0, const void* W0, float* C0, i
   pp.n0 = pp.a[0].tilesM * pp.a[0].tilesN;
   const unsigned grid = (unsigned)(pp.n0 + pp.a[1].tilesM * pp.a[1].tilesN);
   const bool use_bd = pair_use_bd(grid, splits, sps);
-  DPOT_REQUIRE(!(a_rowform | transC) || (use_bd && splits == 1 && a_rowform == 3),
-               "gemm_bf16p_pair: row-form operands go with the un-split B-direct launch, for both problems");
   if (use_bd) {
     for (int i = 0; i < 2; ++i) pp.a[i].super_c = bf16p_row_major(pp.a[i].tilesM, pp.a[i].tilesN, PB_ROWT, colt);
     const int cpw = colt == 6 ? 1 : bd_cpw((long long)grid * splits);
-#define BD_LAUNCH(CT, CW, LA, TR) hipLaunchKernelGGL((gemm_bf16p_bd_pair_kernel<CT, CW, LA, TR>), dim3(grid, splits), dim3(64 * CT / CW), 0, as_stream(stream), pp)
-    if (a_rowform) {
-      if (colt == 6) BD_LAUNCH(6, 1, 3, true);
-      else if (cpw == 2) BD_LAUNCH(8, 2, 3, true);
-      else BD_LAUNCH(8, 1, 3, true);
-    } else {
-      if (colt == 6) BD_LAUNCH(6, 1, 3, false);
-      else if (cpw == 2) BD_LAUNCH(8, 2, 3, false);
-      else BD_LAUNCH(8, 1, 3, false);
-    }
+#define BD_LAUNCH(CT, CW, LA) hipLaunchKernelGGL((gemm_bf16p_bd_pair_kernel<CT, CW, LA>), dim3(grid, splits), dim3(64 * CT / CW), 0, as_stream(stream), pp)
+    if (colt == 6) BD_LAUNCH(6, 1, 3);
+    else if (cpw == 2) BD_LAUNCH(8, 2, 3);
+    else BD_LAUNCH(8, 1, 3);
 #undef BD_LAUNCH
   }
   else if (colt == 6)

@@ -31,11 +31,6 @@ struct Bf16pArgs {
   uint4* dact_out;
   const unsigned short* dact_in;
   int super_r, super_c;          // tile rasterisation: the 32 concurrent tiles of an XCD form super_r x super_c blocks
-  // round 5 (B-direct pair launch only): a_rowform - A is NOT the packed [M/32][K/16] operand but the ROW-form pack of the
-  // [K, M] activation ([K/32][M/16][64 chunks][8]: what the data GEMMs consume), read through ds_read_b64_tr_b16 - the
-  // weight gradients then need no transposed pack of the hidden layer / its gradient at all; transC - the fp32 result is
-  // stored transposed (e.C is [N, M], e.ldc its row length)
-  int a_rowform, transC;
   EpiArgs e;
 };
 
@@ -304,30 +299,6 @@ __device__ __forceinline__ void epi_fragment_direct(const Bf16pArgs& p, int m0f,
     }
     __builtin_amdgcn_wave_barrier();
   }
-}
-
-// plain store of one 32x32 fragment TRANSPOSED: element (m0f + m, n0f + n) goes to Ct[(n0f + n) * ldct + m0f + m] (round 5:
-// the weight gradient computed with its operands swapped - dW^T = H^T dY - lands in the parameter's own [out, in] layout).
-// The lane's four consecutive rows go into the staging slab as one 16-byte write, rows of the slab = columns of the fragment.
-__device__ __forceinline__ void epi_fragment_T(float* __restrict__ Ct, int ldct, int M, int N, int m0f, int n0f,
-                                               const f32x16& acc, float* stage, int lane) {
-  const int li = lane & 31, kh = lane >> 5;
-#pragma unroll
-  for (int g = 0; g < 4; ++g)
-    *reinterpret_cast<float4*>(&stage[li * EPI_LD + 8 * g + 4 * kh]) =
-        make_float4(acc[4 * g], acc[4 * g + 1], acc[4 * g + 2], acc[4 * g + 3]);
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-  __builtin_amdgcn_wave_barrier();
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-  const int c4 = (lane & 7) * 4;
-#pragma unroll
-  for (int it = 0; it < 4; ++it) {
-    const int rn = it * 8 + (lane >> 3);
-    const int n = n0f + rn, m = m0f + c4;
-    if (n < N && m < M)      // M % 4 == 0 (host-checked): the four rows are all valid or all invalid
-      *reinterpret_cast<float4*>(Ct + (long long)n * ldct + m) = *reinterpret_cast<const float4*>(&stage[rn * EPI_LD + c4]);
-  }
-  __builtin_amdgcn_wave_barrier();
 }
 
 }  // namespace dpot

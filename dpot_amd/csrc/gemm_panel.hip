@@ -319,8 +319,6 @@ static int panel_chunk_cols(int N) {
 // every DPOT shape - M = 8192 then gives exactly one workgroup per CU and column chunk; shorter panels that would fit two
 // workgroups per CU (20 waves) are slower, taller ones re-balance worse.  Other heights only when they save a round.
 static int panel_pick_rt(int M, int nchunks, int nc) {
-  static const int forced = [] { const char* e = getenv("DPOT_PANEL_RT"); return e ? atoi(e) : 0; }();
-  if (forced >= 1 && forced <= 5) return forced;
   (void)nc;
   double best_cost = -1;
   int best = 4;

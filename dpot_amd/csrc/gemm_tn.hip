@@ -625,7 +625,7 @@ using namespace dpot;
 
 // split count the TN kernel wants for a shape (0: the shape is not eligible)
 extern "C" int dpot_gemm_tn_splitk(int M, int N, int K, int batch) {
-  static const int enabled = [] { const char* e = getenv("DPOT_GEMM_TN"); return e ? atoi(e) : 1; }();
+  static const int enabled = tune("panel", 1);
   // batched descriptors (the AFNO weight gradients: 4 x [256 x 256], 4608 tokens) stay on the generic kernel: measured
   // 37.4 us here against 36.2 us there
   if (!enabled || M <= 0 || N <= 0 || K <= 0 || batch != 1 || M % TN_W || N % TN_W || K % TN_TOK) return 0;
@@ -646,7 +646,7 @@ extern "C" int dpot_gemm_tn_splitk(int M, int N, int K, int batch) {
 // descriptor is not eligible (the generic kernel runs instead), else the launch status.  The partial sums land in
 // d->workspace in the layout the generic kernel uses, so the caller's reduce launch is unchanged.
 int dpot_gemm_tn_try(const dpot_gemm_desc* d, hipStream_t s) {
-  static const int enabled = [] { const char* e = getenv("DPOT_GEMM_TN"); return e ? atoi(e) : 1; }();
+  static const int enabled = tune("panel", 1);
   if (!enabled || !d->transA || d->transB || d->splitk <= 1 || !d->workspace || d->batch != 1) return -1;
   if (d->M % TN_W || d->N % TN_W || d->K % TN_TOK || d->lda % 4 || d->ldb % 4 || d->strideA % 4 || d->strideB % 4 ||
       !aligned16(d->A) || !aligned16(d->B) || !aligned16(d->workspace) || d->N % 4)
@@ -747,27 +747,24 @@ __global__ __launch_bounds__(256) void afno_wgrad2_reduce_kernel(const float* __
   afno_wgrad2_reduce_body(blockIdx.x, gridDim.x, ws, splits, nb, bs, dw1, db1, dw2, db2, gauss);
 }
 
-// three-product form of the AFNO weight gradient (TnArgs::gauss): 128 channels per block; DPOT_AFNO_WGRAD_GAUSS=0: four products
+// three-product form of the AFNO weight gradient (TnArgs::gauss): 128 channels per block, and 96 (DPOT-Large): gemm_tn96g_kernel;
+// DPOT_TUNE wgrad_gauss=0: four products (128: four tiles of gemm_tn_kernel; 96: the 192 x 192 kernel)
 static int tn_gauss(int bs) {
-  static const int enabled = [] { const char* e = getenv("DPOT_AFNO_WGRAD_GAUSS"); return e ? atoi(e) : 1; }();
-  // 96 channels per block (DPOT-Large): gemm_tn96g_kernel; DPOT_AFNO_WGRAD_GAUSS96=0: the 192 x 192 four-product kernel
-  static const int enabled96 = [] { const char* e = getenv("DPOT_AFNO_WGRAD_GAUSS96"); return e ? atoi(e) : 1; }();
-  return enabled && (bs == TN_W || (bs == TG_BS && enabled96)) ? 1 : 0;
+  static const int enabled = tune("wgrad_gauss", 1);
+  return enabled && (bs == TN_W || bs == TG_BS) ? 1 : 0;
 }
 // token ranges of the tiles P1 / P2 when the sum-product tile is cut into `splitk` (TnArgs::splits12): 5/6 of them at 128 channels
-// per block (DPOT_TN_GAUSS_SKEW="num/den" changes the ratio, "1/1" = equal ranges); the 96-channel kernel computes the three
-// products in one workgroup
+// per block (profiles/r05_tn_skew.txt); the 96-channel kernel computes the three products in one workgroup
 static int tn_gauss_s12(int bs, int splitk) {
-  static const int num = [] { const char* e = getenv("DPOT_TN_GAUSS_SKEW"); return e ? atoi(e) : 5; }();
-  static const int den = [] { const char* e = getenv("DPOT_TN_GAUSS_SKEW"); const char* q = e ? strchr(e, '/') : nullptr; return q ? atoi(q + 1) : 6; }();
-  if (bs != TN_W || num <= 0 || den <= 0 || num >= den) return splitk;
+  constexpr int num = 5, den = 6;
+  if (bs != TN_W) return splitk;
   const int s = splitk * num / den;
   return s < 1 ? 1 : s;
 }
 }  // namespace dpot
 
 extern "C" int dpot_afno_wgrad2_splitk(int Mm, int nb, int bs) {
-  static const int enabled = [] { const char* e = getenv("DPOT_AFNO_WGRAD2"); return e ? atoi(e) : 1; }();
+  static const int enabled = tune("panel", 1);
   const int N = 2 * bs;
   if (!enabled || nb <= 0 || bs <= 0 || (N % TN_W && N != TW) || Mm <= 0 || Mm % TN_TOK) return 0;
   const long long tiles = N == TW ? (long long)2 * nb : tn_gauss(bs) ? 6ll * nb : (long long)2 * nb * (N / TN_W) * (N / TN_W);
@@ -989,7 +986,7 @@ __global__ __launch_bounds__(256) void block_finalize_kernel(const FinalizeArgs 
 }  // namespace dpot
 
 extern "C" int dpot_mlp_wgrad2_splitk(int T, int E, int mh) {
-  static const int enabled = [] { const char* e = getenv("DPOT_MLP_WGRAD2"); return e ? atoi(e) : 1; }();
+  static const int enabled = tune("panel", 1);
   if (!enabled || T <= 0 || E <= 0 || mh <= 0 || E % TN_W || mh % TN_W || T % TN_TOK) return 0;
   const long long tiles = 2ll * (E / TN_W) * (mh / TN_W);
   if (tiles > 256) return 0;                           // big layers fill the chip per launch: nothing to merge for

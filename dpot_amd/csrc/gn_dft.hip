@@ -465,7 +465,7 @@ static void gd_attr(K kernel, size_t lds) {
 using namespace dpot;
 
 extern "C" int dpot_gn_dft_supported(int h, int w, int E, int G) {
-  static const int enabled = [] { const char* e = getenv("DPOT_GN_DFT"); return e ? atoi(e) : 1; }();
+  static const int enabled = tune("gn_fuse", 1);
   if (!enabled || h != GD_H || w != GD_W || G <= 0 || E <= 0 || E % G) return 0;
   const int cg = E / G;
   return cg == 64 || cg == 128 ? 1 : 0;

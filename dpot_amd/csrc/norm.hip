@@ -739,7 +739,7 @@ __global__ __launch_bounds__(GN_THREADS) void gn_chunk_bwd_apply_pk_kernel(
 
 // chunking of a slab, or {0, 0} when the one-workgroup-per-slab kernels are the right ones
 static GnChunks gn_chunking(int B, int T, int E, int G) {
-  static const int enabled = [] { const char* e = getenv("DPOT_GN_CHUNKED"); return e ? atoi(e) : 1; }();
+  constexpr int enabled = 1;
   GnChunks c{0, 0};
   const int cg = E / G;
   if (!enabled || cg % 4 || cg > GN_THREADS || gn_cached_items(T, E, G) != 0) return c;

@@ -275,34 +275,15 @@ def mlp_pack_kind(E: int, mh: int, M: Optional[int] = None) -> Optional[str]:
     eff = ops.effective_mlp_precision()
     Mq = 128 if M is None else M          # M = None: the model deriving its packs before it has seen a batch
     bf_ok = ops.gemm_bf16p_supported(Mq, mh, E) and ops.gemm_bf16p_supported(Mq, E, mh)
-    if os.environ.get("DPOT_BF16_PANEL", "1") != "0" and bf_ok:
-        if eff == ops.GEMM_BF16:
-            return "bf16"
-        # the three-plane panel kernel is OPT-IN (DPOT_X6_PANEL=1): measured on MI355X it reaches 154-190 TFLOP/s
-        # fp32-equivalent against 147-178 for the register-staged split kernel (gemm_split.h) - both sit at 70-80 % of what
-        # the power-limited bf16 matrix pipe sustains (~1.4-1.5 PF / 6, profiles/r02_mfma_bf16_peak.txt) - but needs a
-        # 10 B/element pack pass per activation operand that costs more than it gains (profiles/r02_bf16x6p_bench.txt)
-        if os.environ.get("DPOT_X6_PANEL", "0") == "1" and (
-                eff == ops.GEMM_BF16X6 or (eff == ops.GEMM_AUTO and (M is None or 2.0 * M * mh * E >= X6_MIN_FLOP))):
-            return "bf16x6"
+    if bf_ok and eff == ops.GEMM_BF16:
+        return "bf16"
+    # (The fp32-accurate modes do NOT take the three-plane panel kernel: it reaches 154-190 TFLOP/s fp32-equivalent against
+    # 147-178 for the register-staged split kernel (gemm_split.h) but needs a 10 B/element pack pass per activation operand that
+    # costs more than it gains - profiles/r02_bf16x6p_bench.txt; the opt-in of rounds 2-5 is gone, ops.gemm_bf16p(planes=3) stays.)
     if eff == ops.GEMM_F32 and ops.panel_enabled() and ops.gemm_panel_supported(Mq, mh, E) \
             and ops.gemm_panel_supported(Mq, E, mh):
         return "f32"
     return None
-
-
-def _mlp_rowform(M: int, E: int, mh: int) -> bool:
-    """bf16 channel MLP, pack-both path: the two weight gradients of a block come from ONE launch that reads the hidden layer
-    and its gradient in ROW form through the transposing LDS read (dW2^T = H^T dY stored transposed, dW1 = dH^T X) - no
-    transposed packs of those two.  OPT-IN (DPOT_BF16P_ROWFORM=1): built, bit-identical to the transposed-pack launch and
-    REJECTED by measurement in round 5 (VERDICT r4 #2 asked for it): the two packed-output epilogues save 2.6 + 3.9 us of CU
-    time per block at DPOT-M (profiles/r05_pmc_bf16p_M_rowform{0,1}.json: SQ_BUSY_CU_CYCLES 44.5 -> 42.9 M and 39.2 -> 36.8 M;
-    the round-4 ablation had promised 10 + 8) while the paired weight-gradient launch goes from 50.1 to 90.1 M busy cycles -
-    same LDS cycles, same bank conflicts, same bytes fetched: the LDS-DMA image a conflict-free ds_read_b64_tr_b16 needs
-    forces a permuted SOURCE address (four 256-byte runs per wave instruction), and the DMA engine, already the bound of these
-    loops at ~29 B/clk/CU, delivers that at about half the linear rate.  Train step, one box: DPOT-M 12.43 -> 13.38 ms,
-    DPOT-L 89.8 -> 101.6 ms (profiles/r05_rowform_gauss_step_ab.txt)."""
-    return os.environ.get("DPOT_BF16P_ROWFORM", "0") == "1" and ops.gemm_bf16p_pair_rowform_ok(mh, E, mh, E, M)
 
 
 def _mlp_panel_mode(mlp_pk, M, E, mh, mp) -> int:
@@ -417,48 +398,9 @@ def _mixer_core_bwd(dO2, S, O1pre, O1, wb1, wb2, dims, fused, afno_layout, sinks
     return dS, dw1, db1, dw2, db2
 
 
-def _mixer_wgrads(S, dO1pre, O1, dO2, dims, sinks, pending=None):
-    """the four parameter gradients of the mixer's complex MLP from the operands the data path left (dw1 / db1 from S and
-    dO1pre, dw2 / db2 from O1 and dO2): one fused launch where dpot_afno_wgrad2 covers the shape (partials deferred to the
-    block's finalising launch with `pending`), else two generic split-K GEMMs - the second half of _mixer_core_bwd for
-    the one-launch backward (ops.afno_fused_bwd)"""
-    B, tok, E, h, w, nb, bs, mx, my, mh, act = dims
-    s_w1, s_b1, s_w2, s_b2 = sinks
-    Mm = B * mx * my
-    dev = dO2.device
-    dw1, db1 = ops._out(s_w1.out(), (2, nb, bs, bs), dev), ops._out(s_b1.out(), (2, nb, bs), dev)
-    dw2, db2 = ops._out(s_w2.out(), (2, nb, bs, bs), dev), ops._out(s_b2.out(), (2, nb, bs), dev)
-    sk2 = ops.afno_wgrad2_splitk(Mm, nb, bs) if S.stride(0) == 2 * E else 0
-    if sk2 and pending is not None:
-        pending["afno"] = ops.afno_wgrad2(S, dO1pre, O1, dO2, nb, bs, dw1, db1, dw2, db2, sk2, defer=True)
-        return dw1, db1, dw2, db2
-    if sk2:
-        ops.afno_wgrad2(S, dO1pre, O1, dO2, nb, bs, dw1, db1, dw2, db2, sk2)
-    else:
-        sk = max(2, ops.auto_splitk(2 * bs, 2 * bs, Mm, nb, tn=True))
-        wkw = dict(transA=True, lda=2 * E, ldb=2 * E, ldc=2 * bs, batch=nb, strideA=2 * bs, strideB=2 * bs,
-                   strideC=4 * bs * bs, splitk=sk, mode=ops.EPI_AFNO_WGRAD)
-        ops.gemm(O1, dO2, dw2, 2 * bs, 2 * bs, Mm, colsum_out=db2, colsum_of=2, **wkw)
-        ops.gemm(S, dO1pre, dw1, 2 * bs, 2 * bs, Mm, colsum_out=db1, colsum_of=2, **wkw)
-    return s_w1.done(dw1), s_b1.done(db1), s_w2.done(dw2), s_b2.done(db2)
-
-
-def _fused_layer_bwd_ok(ctx_fused_mixer, afno_layout, O1, dims, G):
-    """the one-launch AFNO layer backward (csrc/afno_fused.hip) applies where the one-launch forward does (same shapes, same
-    selection rule) and the forward left no activated layer-1 output (the backward launch re-derives it)"""
-    B, tok, E, h, w, nb, bs, mx, my, mh, act = dims
-    return (ctx_fused_mixer and O1 is None and ops.afno_fused_bwd_enabled()
-            and ops.afno_fused_supported(h, w, E, nb, mx, my, G=G, B=B, layout=afno_layout))
-
-
 def _mixer_bwd(dy1, S, O1pre, O1, wb1, wb2, dims, fused, afno_layout, sinks, pending=None):
     """backward of _mixer_fwd: returns (dxn1 = adjoint-rfft2(dS) + dy1, dw1, db1, dw2, db2); pending: see _mixer_core_bwd"""
     B, tok, E, h, w, nb, bs, mx, my, mh, act = dims
-    if _fused_layer_bwd_ok(fused, afno_layout, O1, dims, 0):
-        # the whole backward of the mixer in ONE launch, then the weight gradients from the operands it left
-        dxn1, dO2, O1, dO1pre, _, _ = ops.afno_fused_bwd(dy1, None, None, None, None, O1pre, wb2, wb1, None, None, None, None,
-                                                         None, h, w, nb, mx, my, act)
-        return (dxn1,) + tuple(_mixer_wgrads(S, dO1pre, O1, dO2, dims, sinks, pending))
     dO2 = ops.rfft2(dy1, h, w, nb, mx, my, 1)                              # adjoint of irfft2
     dS, dw1, db1, dw2, db2 = _mixer_core_bwd(dO2, S, O1pre, O1, wb1, wb2, dims, fused, afno_layout, sinks, pending)
     dxn1 = ops.irfft2(dS, B, h, w, E, nb, mx, my, 0, res=dy1)              # adjoint of rfft2, + skip path
@@ -509,12 +451,12 @@ def _block_parts(x, n1w, n1b, n2w, n2b, f1w, f1b, packed, dims, mp, need_out, f2
     dev = x.device
     panel = _mlp_panel_mode(mlp_pk, M, E, mh, mp)
     npl = mlp_pk.planes if panel == 2 else 0
-    both = (panel == 2 and npl == 1 and os.environ.get("DPOT_PACK_BOTH", "1") != "0"
+    both = (panel == 2 and npl == 1 and ops.tune("pack_both") != 0
             and ops.bf16_pack_both_supported(M, E) and ops.bf16_pack_both_supported(M, mh))
-    # GroupNorm applied ON THE LOAD of its consumer (DPOT_GN_ONLOAD=0 disables): norm2 inside the pack pass of the bf16
+    # GroupNorm applied ON THE LOAD of its consumer (DPOT_TUNE gn_fuse=0 disables): norm2 inside the pack pass of the bf16
     # channel MLP (the fp32 GroupNorm2(y1) is never written); norm1 inside both DFT kernels where they are not fused with
     # the statistics anyway (32x32 latent grid: statistics-only GroupNorm launches, no normalised tensor)
-    onload = os.environ.get("DPOT_GN_ONLOAD", "1") != "0"
+    onload = ops.tune("gn_fuse") != 0
     pack_norm = both and onload and tok % 64 == 0 and (E // 8) % 4 == 0
     lay = afno_layout if afno_layout is not None else getattr(packed[0], "layout", 0)
     fused_xp = None
@@ -523,8 +465,8 @@ def _block_parts(x, n1w, n1b, n2w, n2b, f1w, f1b, packed, dims, mp, need_out, f2
         # SURVEY 8 f4): spectrum and hidden layer stay on chip; save=False (nothing will run a backward on these
         # intermediates: inference, or a forward whose Block recomputes): S / O1pre are not even written
         # (round 5: with the bf16 channel MLP the same launch also writes GroupNorm2(y1) as the two bf16 operand packs -
-        # DPOT_AFNO_LAYER_PACKS=0: the separate pack pass over y1 instead)
-        fused_packs = pack_norm and os.environ.get("DPOT_AFNO_LAYER_PACKS", "1") != "0"
+        # DPOT_TUNE packs=0: the separate pack pass over y1 instead)
+        fused_packs = pack_norm and ops.tune("packs") != 0
         res = ops.afno_fused_fwd(
             x, n1w, n1b, packed[0][2], packed[0][1], packed[1][2], packed[1][1], n2w, n2b, h, w, nb, mx, my, act, save=save,
             want_y1=save or (pack_norm and not fused_packs), want_xn2=not pack_norm, want_packs=fused_packs,
@@ -569,17 +511,12 @@ def _block_parts(x, n1w, n1b, n2w, n2b, f1w, f1b, packed, dims, mp, need_out, f2
         # fc1: the epilogue emits the activated hidden layer directly in its packed forms (no fp32 copy of it exists)
         # (Hpre here = act'(pre-activation) as a bf16 pack: all the backward needs of it, at half the bytes of the fp32
         # pre-activation and without a second activation evaluation)
-        # round 5: where the paired weight-gradient launch reads ROW-form operands through the transposing LDS read
-        # (ops.gemm_bf16p_pair_rowform_ok: DPOT-M / -L), the hidden layer is kept in its ROW form only - the transposed pack
-        # (67 MB per block at DPOT-M, written by this epilogue at the HBM rate with the matrix pipes idle) is gone
-        rowform = _mlp_rowform(M, E, mh)
         _, Hpre, hp, hpT, _ = ops.gemm_bf16p_packed(xp, mlp_pk[0], M, mh, E, bias=f1b, act=act, mode=EPI_ACT,
-                                                    save_dact=True, pack_rows=need_out or rowform, pack_trans=not rowform,
-                                                    store=False)
+                                                    save_dact=True, pack_rows=need_out, pack_trans=True, store=False)
         out = None
         if need_out:
             out, _ = ops.gemm_bf16p(hp, mlp_pk[2], M, E, mh, bias=f2b, res=x.view(M, E))
-        return out, (mean1, rstd1, S, O1pre, O1, y1, mean2, rstd2, xpT, Hpre, hp if rowform else hpT)
+        return out, (mean1, rstd1, S, O1pre, O1, y1, mean2, rstd2, xpT, Hpre, hpT)
     if panel == 2:   # bf16 matrix cores: weights pre-packed bf16 once per step, activations packed in one pass each
         Hh, Hpre = ops.gemm_bf16p(ops.bf16_pack_rows(xn2.view(M, E), planes=npl), mlp_pk[0], M, mh, E, bias=f1b, act=act,
                                   mode=EPI_ACT, save_pre=True, planes=npl)
@@ -733,22 +670,16 @@ class BlockFn(torch.autograd.Function):
                 dop, dopT, df2b = ops.bf16_pack_both(do2, want_colsum=True, colsum_out=s_f2b.out(), defer_colsum=dcs)
             # both weight gradients in ONE launch once dHpre's pack exists, when each alone would need split-K
             pair = ops.gemm_bf16p_pair_wanted(E, mh, mh, E, M)
-            rowform = _mlp_rowform(M, E, mh)                # Hh is then the hidden layer's ROW-form pack (see _block_parts)
-            if not pair and not rowform:
+            if not pair:
                 df2w, _ = ops.gemm_bf16p(dopT, Hh, E, mh, M, out=s_f2w.out())
             # dHpre = (do2 W2) * act'(Hpre) leaves the GEMM as its packs + bias column sums only
             _, _, dhp, dhpT, df1b = ops.gemm_bf16p_packed(dop, mlp_pk[3], M, mh, E, act=act, mode=EPI_DACT, dact=Hpre,
-                                                          pack_rows=True, pack_trans=not rowform, colsum=True,
+                                                          pack_rows=True, pack_trans=True, colsum=True,
                                                           colsum_out=s_f1b.out(), store=False, defer_colsum=dcs)
             if dcs:
                 pending["cs"] = [df2b, df1b]
                 df2b, df1b = df2b[3], df1b[3]
-            if rowform:
-                # dW2^T [mh, E] = H^T dY (stored transposed = dW2 [E, mh]) and dW1 [mh, E] = dH^T X: the A operands are the
-                # ROW-form packs of H and dH, read through the transposing LDS read (csrc/gemm_bf16p.hip, round 5)
-                df2w, df1w = ops.gemm_bf16p_pair(Hh, dopT, mh, E, dhp, xn2, mh, E, M, out0=s_f2w.out(), out1=s_f1w.out(),
-                                                 rowform=True, trans0=True)
-            elif pair:
+            if pair:
                 df2w, df1w = ops.gemm_bf16p_pair(dopT, Hh, E, mh, dhpT, xn2, mh, E, M, out0=s_f2w.out(), out1=s_f1w.out())
             else:
                 df1w, _ = ops.gemm_bf16p(dhpT, xn2, mh, E, M, out=s_f1w.out())
@@ -790,14 +721,7 @@ class BlockFn(torch.autograd.Function):
             else:
                 dxn2 = ops.linear_bwd_data(dHpre, f1w, precision=mp)               # [M, E]
         # parameter-gradient partials of norm2 are reduced together with norm1's at the end of the block (one launch)
-        if _fused_layer_bwd_ok(ctx.fused_mixer, ctx.afno_layout, O1, ctx.dims, 8):
-            # norm2 backward, adjoint irfft2, both MLP layers' data path, adjoint rfft2, skip, norm1 backward, outer skip in
-            # ONE launch (csrc/afno_fused.hip, round 5); dy1 / dS never exist in HBM; then the weight gradients
-            dx, dO2, O1, dO1pre, gn1_part, gn2_part = ops.afno_fused_bwd(
-                dxn2.view(B, tok, E), y1, mean2, rstd2, n2w, O1pre, wb2, wb1, x, mean1, rstd1, n1w, dout, h, w, nb, mx, my,
-                act)
-            dw1, db1, dw2, db2 = _mixer_wgrads(S, dO1pre, O1, dO2, ctx.dims, (s_w1, s_b1, s_w2, s_b2), pending)
-        elif ops.gn_dft_supported(h, w, E):
+        if ops.gn_dft_supported(h, w, E):
             # norm2 backward + rfft2 (adjoint of the forward irfft2), then irfft2 (adjoint) + skip + norm1 backward + outer
             # skip: two launches around the mixer's backward (csrc/gn_dft.hip)
             dy1, gn2_part, dO2 = ops.gn_bwd_rfft2(dxn2.view(B, tok, E), y1, mean2, rstd2, n2w, h, w, nb, mx, my,
@@ -812,7 +736,7 @@ class BlockFn(torch.autograd.Function):
                 # against 20.0 + 24.6 us for the separate kernels (profiles/r03_step_census_M_bf16_v1.txt) - not fused
                 dxn1 = ops.irfft2(dS, B, h, w, E, nb, mx, my, 0, res=dy1)
                 if (ctx.emit_grad_packs and ctx.needs_input_grad[0] and bf16p and xn2.dtype == torch.bfloat16 and ops.groupnorm_bwd_packs_supported(tok, E, B=B)
-                        and os.environ.get("DPOT_GRAD_PACKS", "1") != "0"):
+                        and ops.tune("packs") != 0):
                     # dx goes to the previous Block's bf16 channel-MLP backward: written here in its packed forms as well
                     dx, gn1_part, gp_r, gp_t, gp_cs = ops.groupnorm_bwd_packs(dxn1, x, mean1, rstd1, n1w, add=dout)
                     _stash_grad_packs(dx, gp_r, gp_t, gp_cs)
@@ -823,15 +747,10 @@ class BlockFn(torch.autograd.Function):
             # AFNO mixer
             dxn1, dw1, db1, dw2, db2 = _mixer_bwd(dy1, S, O1pre, O1, wb1, wb2, ctx.dims, ctx.fused_mixer,
                                                   ctx.afno_layout, (s_w1, s_b1, s_w2, s_b2), pending)
-            if (ctx.emit_grad_packs and ctx.needs_input_grad[0] and bf16p and xn2.dtype == torch.bfloat16 and ops.groupnorm_bwd_packs_supported(tok, E, B=B)
-                    and os.environ.get("DPOT_GRAD_PACKS", "1") == "2"):
-                # (DPOT-L: the CHUNKED GroupNorm backward can write the gradient's packs too - see the 128-channel branch above -
-                # but there the staging + two barriers per 32-token sub-tile cost what the saved pack pass did: DPOT-L 91.2 -> 90.9 ms,
-                # L20 2.185 -> 2.211 s, profiles/r05_grad_packs_step_ab_L.txt; opt-in, DPOT_GRAD_PACKS=2)
-                dx, gn1_part, gp_r, gp_t, gp_cs = ops.groupnorm_bwd_packs(dxn1, x, mean1, rstd1, n1w, add=dout)
-                _stash_grad_packs(dx, gp_r, gp_t, gp_cs)
-            else:
-                dx, gn1_part = ops.groupnorm_bwd(dxn1, x, mean1, rstd1, n1w, add=dout, defer=True)
+            # (DPOT-L: the CHUNKED GroupNorm backward could write the gradient's packs too - see the 128-channel branch above - but
+            # there the staging + two barriers per 32-token sub-tile cost what the saved pack pass did: DPOT-L 91.2 -> 90.9 ms,
+            # L20 2.185 -> 2.211 s, profiles/r05_grad_packs_step_ab_L.txt; the opt-in of round 5 is gone)
+            dx, gn1_part = ops.groupnorm_bwd(dxn1, x, mean1, rstd1, n1w, add=dout, defer=True)
         gn_jobs = [(gn1_part, s_n1w.out(), s_n1b.out()), (gn2_part, s_n2w.out(), s_n2b.out())]
         if pending:
             (dn1w, dn1b), (dn2w, dn2b) = ops.block_finalize(pending.get("afno"), pending.get("mlp"), gn_jobs,

@@ -175,7 +175,7 @@ class DPOTNet(nn.Module):
         # every small layout piece of the model (padded conv weights, pos_embed^T + bias, de-embed bias per pixel, padded
         # tail weights) in ONE launch from a device-resident job table with persistent outputs (ops.LayoutJobs)
         lay_e = lay_h = None
-        if os.environ.get("DPOT_LAYOUT_JOBS", "1") != "0":
+        if ops.tune("fused_small") != 0:
             je = embed_layout_jobs(self.pos_embed, pe[0].weight, pe[0].bias, pe[2].weight, pe[2].bias)
             jh = head_layout_jobs(ol[0].bias, ol[4].weight, ol[4].bias, self.patch_size, ol[0].weight.shape[1])
             lj = getattr(self, "_layout_jobs", None)

@@ -145,6 +145,49 @@ def mlp_precision() -> Optional[int]:
     return _cur_mlp()
 
 
+# ---- DPOT_TUNE: the ONE switchboard of the fallback-path selectors (round 6; rounds 1-5 grew 43 separate DPOT_* variables) ------
+# DPOT_TUNE="key=val,key=val" (integers).  Every key selects a PREVIOUS-GENERATION path that stays under the GPU test gate
+# (tests/test_gpu_optout.py runs parity subsets under them); the defaults are what measured fastest.  The C side reads the same
+# variable once per process (csrc/core.hip dpot::tune); this side reads it per call.  Besides DPOT_TUNE the package reads only
+# DPOT_HIP_LIB (library path), DPOT_GEMM_PRECISION and DPOT_MLP_PRECISION (process defaults of the precision modes).
+TUNE_KEYS = {
+    "mixer": (3, "AFNO mixer MLP: 3 = three-product fused kernel (afno_mlp3), 4 = four-product fused kernel (afno_mlp2), "
+                 "0 = two generic GEMM launches"),
+    "afno_layer": (-1, "one-launch AFNO layer forward (afno_fused_fwd): -1 = where it measured faster (>= 80 % full last "
+                       "round of (sample, block) workgroups), 0 = never, 1 = wherever supported"),
+    "gn_fuse": (1, "0 = GroupNorm as its own kernels: not fused with the mixer's DFTs, never applied on the load of its consumer"),
+    "panel": (1, "0 = generic GEMM kernels instead of the pre-packed-weight panel GEMM, the token-contraction weight-gradient "
+                 "kernels (gemm_tn) and their two-layer launches"),
+    "wgrad_gauss": (1, "0 = four-product AFNO weight gradients instead of the three-product forms"),
+    "bf16p_bd": (1, "0 = the LDS-DMA bf16 GEMM kernels of rounds 2-3 for every launch instead of the B-direct kernels"),
+    "bf16p_shape": (1, "0 = none of the bf16 GEMM shape heuristics: 128 x 256 tiles only, column-major tile order, eight waves, "
+                       "un-paired weight gradients"),
+    "packs": (1, "0 = bf16 packs by separate pack passes only: none from the one-launch AFNO layer, the GroupNorm backward or Adam"),
+    "pack_both": (1, "0 = bf16 channel MLP without the pack-both path (one pack pass per operand form, fp32 pre-activation saved)"),
+    "fused_small": (1, "0 = separate small launches: per-block reduce launches, eight layout launches, torch ops for the cls head"),
+    "embed_implicit": (1, "0 = explicit patch matrix + GEMM instead of the implicit-GEMM patch embedding"),
+}
+
+
+def _parse_tune():
+    out = {}
+    for kv in os.environ.get("DPOT_TUNE", "").split(","):
+        kv = kv.strip()
+        if not kv:
+            continue
+        k, _, v = kv.partition("=")
+        if k not in TUNE_KEYS:
+            raise ValueError(f"DPOT_TUNE: unknown key {k!r} (known: {', '.join(TUNE_KEYS)})")
+        out[k] = int(v)
+    return out
+
+
+def tune(key: str, default: Optional[int] = None) -> int:
+    """value of `key` in DPOT_TUNE, else its default (TUNE_KEYS)"""
+    d = TUNE_KEYS[key][0] if default is None else default
+    return _parse_tune().get(key, d)
+
+
 def _stream() -> int:
     return torch.cuda.current_stream().cuda_stream
 
@@ -227,7 +270,7 @@ def gemm(A: Tensor, B: Tensor, C_: Tensor, M: int, N: int, K: int, *, transA: bo
 def panel_enabled() -> bool:
     """the panel kernel is an fp32 kernel: used while the global GEMM precision is 'f32' (the channel-MLP override of
     set_mlp_precision is checked where it applies, functional._mlp_panel_ok)"""
-    return os.environ.get("DPOT_PANEL_GEMM", "1") != "0" and _cur_gemm() == GEMM_F32
+    return tune("panel") != 0 and _cur_gemm() == GEMM_F32
 
 
 def gemm_panel_supported(M: int, N: int, K: int) -> bool:
@@ -426,28 +469,18 @@ def gemm_bf16p_kernel_name(M: int, N: int, K: int, splitk: int = 1, planes: int 
     return BF16P_KERNEL_KINDS.get(k & 7, f"kind {k}") + (" on 128 x 192 tiles" if k >= 8 else "")
 
 
-def gemm_bf16p_pair_rowform_ok(M0: int, N0: int, M1: int, N1: int, K: int) -> bool:
-    """the pair launch for these shapes takes ROW-form A operands / transposed outputs (gemm_bf16p_pair(rowform=True))"""
-    return bool(_lib.load().dpot_gemm_bf16p_pair_rowform_ok(M0, N0, M1, N1, K))
-
-
 def gemm_bf16p_pair(A0: Tensor, W0: Tensor, M0: int, N0: int, A1: Tensor, W1: Tensor, M1: int, N1: int, K: int,
                     out0: Optional[Tensor] = None, out1: Optional[Tensor] = None,
-                    splitk: Optional[int] = None, rowform: bool = False, trans0: bool = False,
-                    trans1: bool = False) -> Tuple[Tensor, Tensor]:
+                    splitk: Optional[int] = None) -> Tuple[Tensor, Tensor]:
     """(A0 W0^T [M0,N0], A1 W1^T [M1,N1]) on the bf16 matrix cores in ONE launch (packed plain-bf16 operands, common K,
-    one common split-K factor - None: the library's choice): the two channel-MLP weight gradients of a block.
-    rowform: A0 / A1 are the ROW-form packs of the [K, M_i] activations (as the data GEMMs consume them; read through the
-    transposing LDS read - no transposed pack needed); trans_i: result i is returned / written TRANSPOSED ([N_i, M_i])"""
+    one common split-K factor - None: the library's choice): the two channel-MLP weight gradients of a block."""
     lib = _lib.load()
-    C0 = _out(out0, (N0, M0) if trans0 else (M0, N0), A0.device)
-    C1 = _out(out1, (N1, M1) if trans1 else (M1, N1), A1.device)
+    C0 = _out(out0, (M0, N0), A0.device)
+    C1 = _out(out1, (M1, N1), A1.device)
     sk = max(1, lib.dpot_gemm_bf16p_pair_splitk(M0, N0, M1, N1, K)) if splitk is None else splitk
     ws = torch.empty(sk * (M0 * N0 + M1 * N1), dtype=torch.float32, device=A0.device) if sk > 1 else None
-    check(lib.dpot_gemm_bf16p_pair(A0.data_ptr(), W0.data_ptr(), C0.data_ptr(), M0 if trans0 else N0, M0, N0, A1.data_ptr(),
-                                   W1.data_ptr(), C1.data_ptr(), M1 if trans1 else N1, M1, N1, K, sk, _p(ws),
-                                   3 if rowform else 0, (1 if trans0 else 0) | (2 if trans1 else 0), _stream()),
-          "gemm_bf16p_pair")
+    check(lib.dpot_gemm_bf16p_pair(A0.data_ptr(), W0.data_ptr(), C0.data_ptr(), N0, M0, N0, A1.data_ptr(), W1.data_ptr(),
+                                   C1.data_ptr(), N1, M1, N1, K, sk, _p(ws), _stream()), "gemm_bf16p_pair")
     return C0, C1
 
 
@@ -500,7 +533,7 @@ def linear_fwd(x: Tensor, W: Tensor, bias: Optional[Tensor], act: int = 0, save_
     lib = _lib.load()
     prec = _cur_gemm() if precision is None else precision
     if (res is None and M <= 128 and prec != GEMM_BF16 and lib.dpot_small_linear_supported(M, N, K)
-            and os.environ.get("DPOT_SMALL_LINEAR", "1") != "0"):
+            and tune("fused_small") != 0):
         # a handful of rows (the cls_head on the token mean): one pass over W, no split-K / reduce pair; exact fp32
         # (not under the opt-in bf16 operand rounding: that mode keeps its rounding at every batch size)
         check(lib.dpot_small_linear(x.data_ptr(), x.stride(0), W.data_ptr(), ldw or W.stride(0), _p(bias), y.data_ptr(),
@@ -756,16 +789,16 @@ def block_finalize(afno_job, mlp_job, gn_jobs, cs_jobs=()):
 
 
 def block_finalize_enabled() -> bool:
-    return os.environ.get("DPOT_BLOCK_FINALIZE", "1") != "0"
+    return tune("fused_small") != 0
 
 
 def afno_mlp2_supported(nb: int, bs: int) -> bool:
-    return bool(_lib.load().dpot_afno_mlp2_supported(nb, bs)) and os.environ.get("DPOT_AFNO_FUSED", "1") != "0"
+    return bool(_lib.load().dpot_afno_mlp2_supported(nb, bs)) and tune("mixer") != 0
 
 
 def afno_mlp3_supported(nb: int, bs: int) -> bool:
     """the three-product (Gauss / Karatsuba) form of the fused mixer kernel: bs == 128; DPOT_AFNO_3MULT=0 disables it"""
-    return bool(_lib.load().dpot_afno_mlp3_supported(nb, bs)) and os.environ.get("DPOT_AFNO_3MULT", "1") != "0"
+    return bool(_lib.load().dpot_afno_mlp3_supported(nb, bs)) and tune("mixer") == 3
 
 
 def afno_mlp2(X: Tensor, WaT: Tensor, ba: Optional[Tensor], WbT: Tensor, bb: Optional[Tensor], nb: int, bs: int,
@@ -933,10 +966,9 @@ def irfft2_gn(spec: Tensor, x: Tensor, mean1: Tensor, rstd1: Tensor, g1: Tensor,
 
 
 def afno_layer_mode() -> int:
-    """DPOT_AFNO_LAYER: 0 = never the one-launch AFNO layer (csrc/afno_fused.hip), 1 = wherever it is supported, unset /
-    'auto' = where it measured faster than the three-launch form (afno_layer_wins)"""
-    v = os.environ.get("DPOT_AFNO_LAYER", "auto")
-    return -1 if v == "auto" else int(v)
+    """DPOT_TUNE afno_layer: 0 = never the one-launch AFNO layer (csrc/afno_fused.hip), 1 = wherever it is supported, -1
+    (default) = where it measured faster than the three-launch form (afno_layer_wins)"""
+    return tune("afno_layer")
 
 
 def afno_layer_wins(B: int, nb: int) -> bool:
@@ -993,41 +1025,6 @@ def afno_fused_fwd(x: Tensor, g1: Optional[Tensor], b1: Optional[Tensor], WaT: T
     return S, pre, y1, xn2, st[0], st[1], st[2], st[3]
 
 
-def afno_fused_bwd_enabled() -> bool:
-    """DPOT_AFNO_LAYER_BWD=1: the backward of a one-launch AFNO layer also runs as ONE launch (csrc/afno_fused.hip
-    afno_fused_bwd_kernel).  OFF by default - built, parity-green and REJECTED by measurement in round 5
-    (profiles/r05_f4_bwd_fused_vs_launches.txt, r05_f4_bwd_step_ab.txt, one box): 205 us against 179 us for the four launches
-    it replaces at 256 workgroups (DPOT-S / -M, batch 32), train step DPOT-S 5.27 -> 5.44 ms, DPOT-M 13.05 -> 13.41 ms.  It
-    moves 0.65x the bytes (dy1 / dS never exist in HBM) but a (sample, channel block) workgroup owns its CU alone (144 KiB of
-    LDS) and runs its phases one after the other: the loads of GroupNorm2's backward, the pre-activation reads between the
-    layers and the three operand streams of GroupNorm1's backward cannot hide behind another workgroup's MFMA phase, which
-    is exactly what the separate launches' 1024-thread streaming kernels do better."""
-    return os.environ.get("DPOT_AFNO_LAYER_BWD", "0") == "1"
-
-
-def afno_fused_bwd(dxn2: Tensor, y1: Optional[Tensor], mean2: Optional[Tensor], rstd2: Optional[Tensor],
-                   g2: Optional[Tensor], pre: Tensor, Wa_bwd2: Tensor, Wb_bwd1: Tensor, x: Optional[Tensor],
-                   mean1: Optional[Tensor], rstd1: Optional[Tensor], g1: Optional[Tensor], add: Optional[Tensor], h: int,
-                   w: int, nb: int, mx: int, my: int, act: int, G: int = 8):
-    """backward of afno_fused_fwd in ONE launch (csrc/afno_fused.hip): returns (dx, dO2, O1, dO1pre, part1, part2) - dx
-    [B, tok, E]; dO2 / O1 / dO1pre [B*mx*my, 2E] = the operands of the weight-gradient launch (afno_wgrad2 with the saved
-    spectrum S); part1 / part2 [2, B, E] the GroupNorm parameter-gradient partials (None without the norm)"""
-    B, tok, E = dxn2.shape
-    dev = dxn2.device
-    Mm = B * mx * my
-    dO2 = torch.empty(Mm, 2 * E, dtype=torch.float32, device=dev)
-    O1 = torch.empty_like(dO2)
-    dPre = torch.empty_like(dO2)
-    dx = torch.empty_like(dxn2)
-    part2 = torch.empty(2, B, E, dtype=torch.float32, device=dev) if g2 is not None else None
-    part1 = torch.empty(2, B, E, dtype=torch.float32, device=dev) if g1 is not None else None
-    check(_lib.load().dpot_afno_fused_bwd(dxn2.data_ptr(), _p(y1), _p(mean2), _p(rstd2), _p(g2), pre.data_ptr(),
-                                          Wa_bwd2.data_ptr(), Wb_bwd1.data_ptr(), _p(x), _p(mean1), _p(rstd1), _p(g1),
-                                          _p(add), dO2.data_ptr(), O1.data_ptr(), dPre.data_ptr(), dx.data_ptr(), _p(part2),
-                                          _p(part1), B, h, w, E, G, nb, mx, my, act, _stream()), "afno_fused_bwd")
-    return dx, dO2, O1, dPre, part1, part2
-
-
 def gn_bwd_rfft2(dy: Tensor, xin: Tensor, mean: Tensor, rstd: Tensor, gamma: Tensor, h: int, w: int, nb: int, mx: int,
                  my: int, G: int = 8, col_weights: int = 1):
     """(dx = GroupNorm backward of dy, part [2,B,E], spec = rfft2(dx; col_weights)) in one launch"""
@@ -1067,7 +1064,7 @@ def patchify(x: Tensor, gx: Tensor, gy: Tensor, gt: Tensor, P: int) -> Tensor:
 
 def embed_supported(Cc: int, P: int, T: int, hid: int, w: int) -> bool:
     """shapes the implicit-GEMM patch embedding covers (csrc/embed.hip); DPOT_EMBED_IMPLICIT=0 disables it"""
-    return (os.environ.get("DPOT_EMBED_IMPLICIT", "1") != "0"
+    return (tune("embed_implicit") != 0
             and bool(_lib.load().dpot_embed_supported(Cc, P, T, hid, w)))
 
 

@@ -167,8 +167,8 @@ class FusedAdam:
 
     def _pack_plan(self):
         """the dpot_adam_step_packs tables for the model's plain-bf16 channel-MLP weight packs (DPOTNet._panel_packs_bf16, made
-        by its first forward in that mode), or None: no such packs / a weight that does not tile / DPOT_ADAM_PACKS=0"""
-        if os.environ.get("DPOT_ADAM_PACKS", "1") == "0":
+        by its first forward in that mode), or None: no such packs / a weight that does not tile / DPOT_TUNE packs=0"""
+        if ops.tune("packs") == 0:
             return None
         pp = getattr(self.fp.model, "_panel_packs_bf16", None)
         if pp is None:

@@ -64,6 +64,9 @@ enum {
 };
 
 int dpot_version(void);
+/* value of `key` in the environment variable DPOT_TUNE="key=val,key=val" (integers), or dflt: the one switchboard of the
+ * library's fallback-path selectors (keys: dpot_amd/ops.py TUNE_KEYS); read once per process */
+int dpot_tune(const char* key, int dflt);
 const char* dpot_last_error(void);
 
 /* ------------------------------------------------------------------------------------------------
@@ -313,21 +316,6 @@ int dpot_afno_fused_fwd(const float* x, const float* gamma1, const float* beta1,
                         float* y1, float* xn2, float* mean1, float* rstd1, float* mean2, float* rstd2, void* xn2_rows_bf16,
                         void* xn2_trans_bf16, int B, int h, int w, int E, int G, int nb, int mx, int my, int act, float eps,
                         dpot_stream_t stream);
-/* The BACKWARD of the same layer in one launch (replaces dpot_gn_bwd_rfft2 + dpot_afno_mlp2(mode 1) + dpot_irfft2 +
- * dpot_groupnorm_bwd; autograd of models/dpot.py:59-102, :165-175):
- *   dy1 = GroupNorm2-backward(dxn2; y1, mean2, rstd2, gamma2),  dO2 = adjoint-irfft2(dy1),
- *   dO1pre = (dO2 W2^H) * act'(pre),  O1 = act(pre),  dS = dO1pre W1^H,
- *   dx = GroupNorm1-backward(adjoint-rfft2(dS) + dy1; x, mean1, rstd1, gamma1) + add.
- * Wa_bwd2 / Wb_bwd1: the layout-1 `bwd` packs of layer 2 / layer 1 (dpot_afno_pack_all).  Outputs for the weight-gradient
- * launch (dpot_afno_wgrad2): dO2, O1, dPre [B*144, 2E]; dx [B, 256, E]; part2 / part1 [2, B, E] = per-sample partials of
- * the GroupNorm parameter gradients (sum d*xhat | sum d) as dpot_gn_bwd_rfft2 / dpot_irfft2_gn_bwd write them.
- * gamma2 == NULL: dxn2 IS dy1 (no norm2); gamma1 == NULL: no norm1 (with both NULL: the backward of AFNO2D alone);
- * add may be NULL. */
-int dpot_afno_fused_bwd(const float* dxn2, const float* y1, const float* mean2, const float* rstd2, const float* gamma2,
-                        const float* pre, const float* Wa_bwd2, const float* Wb_bwd1, const float* x, const float* mean1,
-                        const float* rstd1, const float* gamma1, const float* add, float* dO2, float* O1, float* dPre,
-                        float* dx, float* part2, float* part1, int B, int h, int w, int E, int G, int nb, int mx, int my,
-                        int act, dpot_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
  * data movement / small ops
@@ -597,16 +585,9 @@ int dpot_gemm_bf16p_pair_wanted(int M0, int N0, int M1, int N1, int K);
 /* common split-K factor of the pair launch: 0 = do not pair, 1 = no split, s > 1 = s splits (workspace of
  * s * (M0*N0 + M1*N1) floats; the partial sums are reduced in a fixed order by two further launches) */
 int dpot_gemm_bf16p_pair_splitk(int M0, int N0, int M1, int N1, int K);
-/* a_rowform / transC (2-bit masks, bit i = problem i; round 5): with bit i of a_rowform set, A_i is NOT the packed
- * [M_i/32][K/16] operand but the ROW-form pack of the [K, M_i] activation ([K/32][M_i/16][64 chunks][8] - what
- * dpot_bf16_pack_rows / the out_rows epilogue write and the data GEMMs consume), read through ds_read_b64_tr_b16: the weight
- * gradients dW1 = dH^T X and dW2^T = H^T dY then need no TRANSPOSED pack of the hidden layer or of its gradient.  With bit
- * i of transC set, C_i is stored transposed: C_i points at an [N_i, M_i] matrix of row length ldc_i.  Both need
- * dpot_gemm_bf16p_pair_rowform_ok (the un-split B-direct launch; a_rowform then covers both problems). */
-int dpot_gemm_bf16p_pair_rowform_ok(int M0, int N0, int M1, int N1, int K);
 int dpot_gemm_bf16p_pair(const void* A0, const void* W0, float* C0, int ldc0, int M0, int N0, const void* A1,
                          const void* W1, float* C1, int ldc1, int M1, int N1, int K, int splitk, float* workspace,
-                         int a_rowform, int transC, dpot_stream_t stream);
+                         dpot_stream_t stream);
 /* out_rows / out_trans / colsum_part (all optional, planes == 1, splitk <= 1, M % 32 == 0): the epilogue also emits the
  * 1-plane packs of the FINAL output (row form [M, N]; transposed form = rows N, k M) and partial column sums
  * [M/32, N] - the next GEMMs of a chain then need no pack pass over this output; C may be NULL in that case.

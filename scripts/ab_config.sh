@@ -1,7 +1,7 @@
 #!/bin/bash
 # A/B of a train step (hipGraph replay, `bench.py --brief`) under environment switches, pairs on ONE box:
 #   scripts/ab_config.sh OUTFILE CONFIG STEPS "ENV=a" "ENV=b" ["ENV=a" "ENV=b" ...]      (CONFIG: T | S | M | L | L20)
-# one line per run: "config M DPOT_GRAD_PACKS=0: 12.68 ms/step 2523.3 samples/s" - the form of every profiles/r05_*_step_ab.txt
+# one line per run: "config M DPOT_TUNE=packs=0: 12.68 ms/step 2523.3 samples/s" - the form of every profiles/r0*_step_ab.txt
 O=$1; CFG=$2; STEPS=$3; shift; shift; shift
 mkdir -p "$(dirname "$O")"
 for v in "$@"; do

@@ -7,7 +7,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from dpot_amd import ops
 
-os.environ["DPOT_AFNO_LAYER"] = "1"
+os.environ["DPOT_TUNE"] = "afno_layer=1"
 
 
 def timeit(fns, reps):

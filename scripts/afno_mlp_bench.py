@@ -1,5 +1,4 @@
-"""micro-benchmark of the fused AFNO MLP kernel (csrc/afno_mlp.hip): hipGraph of 50 launches, event timed.
-   DPOT_AFNO_MLP_RT=1..5 forces the panel height (16*RT rows)."""
+"""micro-benchmark of the fused AFNO MLP kernel (csrc/afno_mlp.hip): hipGraph of 50 launches, event timed."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -44,7 +43,7 @@ def bench(nb, bs, M, reps=50):
         e0.record(); g.replay(); e1.record(); e1.synchronize()
         t = e0.elapsed_time(e1) * 1e-3 / reps
         out.append(f"{name} {t*1e6:7.1f} us {flops/t/1e12:6.1f} TF")
-    print(f"RT={os.environ.get('DPOT_AFNO_MLP_RT','auto')} nb={nb} bs={bs} M={M}: " + " | ".join(out), flush=True)
+    print(f"nb={nb} bs={bs} M={M}: " + " | ".join(out), flush=True)
 
 def tiny_train(n=30):
     """the DPOT-Tiny (B=32) mixer launch in its training form, eagerly, n times (for rocprofv3 --pmc passes)"""
@@ -84,7 +83,7 @@ def tiny_bwd(n=30):
 
 def fused_fwd(n=30, E=1024, nb=8, B=32):
     """the one-launch AFNO layer (csrc/afno_fused.hip), training form, DPOT-S / -M at batch 32 (256 workgroups)"""
-    os.environ["DPOT_AFNO_LAYER"] = "1"
+    os.environ["DPOT_TUNE"] = "afno_layer=1"
     h, mx, my, bs = 16, 16, 9, E // nb
     x = torch.randn(B, h * h, E, device="cuda")
     g1, b1 = torch.rand(E, device="cuda") + 0.5, torch.randn(E, device="cuda") * 0.1

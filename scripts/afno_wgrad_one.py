@@ -2,7 +2,7 @@
 """launch ONE form of the AFNO weight-gradient kernels a few times (for rocprofv3 --pmc passes):
     T   - gemm_tn_kernel, three-product form, DPOT-Tiny B=32 (Mm 4608, 4 blocks of 128 channels)
     M   - the same at DPOT-S / -M (8 blocks of 128)
-    L   - gemm_tn96g_kernel, DPOT-L B=16 (Mm 8704, 16 blocks of 96);  DPOT_AFNO_WGRAD_GAUSS96=0: gemm_tn192_kernel
+    L   - gemm_tn96g_kernel, DPOT-L B=16 (Mm 8704, 16 blocks of 96);  DPOT_TUNE=wgrad_gauss=0: gemm_tn192_kernel
 operands rotate through 3 sets"""
 import os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))

@@ -15,24 +15,20 @@ pk = ops.PanelPacks([(W1, mh, E, E, False), (W1, E, mh, E, True), (W2, E, mh, mh
 pk.refresh()
 xp, xpT, _ = ops.bf16_pack_both(x)
 dop, dopT, _ = ops.bf16_pack_both(do)
-# round 5: where the paired weight-gradient launch takes ROW-form operands the two packed-output launches write no transposed pack
-rowform = os.environ.get("DPOT_BF16P_ROWFORM", "0") == "1" and ops.gemm_bf16p_pair_rowform_ok(mh, E, mh, E, M)
 _, D, hp, hpT, _ = ops.gemm_bf16p_packed(xp, pk.bufs[0], M, mh, E, bias=b1, act=1, mode=ops.EPI_ACT, save_dact=True,
-                                         pack_rows=True, pack_trans=not rowform, store=False)
+                                         pack_rows=True, pack_trans=True, store=False)
 _, _, dhp, dhpT, _ = ops.gemm_bf16p_packed(dop, pk.bufs[3], M, mh, E, act=1, mode=ops.EPI_DACT, dact=D, pack_rows=True,
-                                           pack_trans=not rowform, colsum=True, store=False)
+                                           pack_trans=True, colsum=True, store=False)
 o0, o1 = torch.empty(E, mh, device="cuda"), torch.empty(mh, E, device="cuda")
 fns = {
     "fc1_fwd": lambda: ops.gemm_bf16p_packed(xp, pk.bufs[0], M, mh, E, bias=b1, act=1, mode=ops.EPI_ACT, save_dact=True,
-                                             pack_rows=True, pack_trans=not rowform, store=False),
+                                             pack_rows=True, pack_trans=True, store=False),
     "fc2_fwd": lambda: ops.gemm_bf16p(hp, pk.bufs[2], M, E, mh, bias=b2, res=x),
     "fc2_dgrad": lambda: ops.gemm_bf16p_packed(dop, pk.bufs[3], M, mh, E, act=1, mode=ops.EPI_DACT, dact=D, pack_rows=True,
-                                               pack_trans=not rowform, colsum=True, store=False),
+                                               pack_trans=True, colsum=True, store=False),
     "fc1_dgrad": lambda: ops.gemm_bf16p(dhp, pk.bufs[1], M, E, mh),
-    "pair": (lambda: ops.gemm_bf16p_pair(hp, dopT, mh, E, dhp, xpT, mh, E, M, out0=o0, out1=o1, rowform=True, trans0=True))
-            if rowform else (lambda: ops.gemm_bf16p_pair(dopT, hpT, E, mh, dhpT, xpT, mh, E, M, out0=o0, out1=o1)),
+    "pair": lambda: ops.gemm_bf16p_pair(dopT, hpT, E, mh, dhpT, xpT, mh, E, M, out0=o0, out1=o1),
 }
-print("row-form weight gradients:", rowform, flush=True)
 torch.cuda.synchronize()
 print("MARK begin", flush=True)
 for _ in range(12):

@@ -1,6 +1,6 @@
 """micro-benchmark: the bf16 channel-MLP GEMMs in the forms the DPOT-M / -L train step launches them (packed outputs),
 per shape: fc1 fwd (act + packs + act' pack | old: fp32 pre-activation), fc2 fwd (+ residual), fc2 dgrad (act' product +
-packs + column sums), fc1 dgrad.  DPOT_BF16P_RASTER=0/1 selects the tile rasterisation (read once per process)."""
+packs + column sums), fc1 dgrad."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -22,7 +22,6 @@ def timeit(fn, reps=20):
 shapes = [("M B=32", 8192, 1024, 4096), ("L B=4", 4096, 1536, 6144), ("L B=16", 16384, 1536, 6144), ("S B=32", 8192, 1024, 1024)]
 if len(sys.argv) > 1:
     shapes = [s for s in shapes if s[0].split()[0] in sys.argv[1:]]
-print(f"DPOT_BF16P_RASTER={os.environ.get('DPOT_BF16P_RASTER', '1')}")
 for name, M, E, mh in shapes:
     x = torch.randn(M, E, device="cuda"); do = torch.randn(M, E, device="cuda")
     W1 = torch.randn(mh, E, device="cuda") * 0.03; W2 = torch.randn(E, mh, device="cuda") * 0.03

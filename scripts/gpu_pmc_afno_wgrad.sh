@@ -6,7 +6,7 @@ cd /tmp && export TMPDIR=/tmp
 for F in T M L L4; do
   for C in FETCH_SIZE WRITE_SIZE "SQ_BUSY_CU_CYCLES SQ_VALU_MFMA_BUSY_CYCLES" "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE"; do
     T=$(echo $C | tr ' ' '_')
-    if [ $F = L4 ]; then export DPOT_AFNO_WGRAD_GAUSS96=0; FF=L; else unset DPOT_AFNO_WGRAD_GAUSS96; FF=$F; fi
+    if [ $F = L4 ]; then export DPOT_TUNE=wgrad_gauss=0; FF=L; else unset DPOT_TUNE; FF=$F; fi
     timeout 240 rocprofv3 --kernel-trace --pmc $C --output-format csv -d $R/gpurun_out/pmcw_${F}-$T -o p -- python $R/scripts/afno_wgrad_one.py $FF > $R/gpurun_out/pmcw.log 2>&1
   done
 done

@@ -38,3 +38,20 @@ def assert_sub(t, fx, key, what="", rtol=RTOL):
     a = f.double().abs().sum().item()
     assert abs(a - float(fx[key + ".abssum"])) <= 10 * rtol * float(fx[key + ".abssum"]), what + ".abssum"
     assert abs(s - float(fx[key + ".sum"])) <= 10 * rtol * float(fx[key + ".abssum"]), what + ".sum"
+
+
+def set_tune(monkeypatch, **kv):
+    """DPOT_TUNE with the given keys set (merged over whatever the process - e.g. an opt-out child - already has); only the
+    PYTHON-side readers see a change made inside a running process (the C library reads DPOT_TUNE once): use it for the keys
+    dpot_amd/ops.py consults per call (mixer, afno_layer, packs, fused_small, embed_implicit)"""
+    import os
+    cur = dict(x.split("=") for x in os.environ.get("DPOT_TUNE", "").split(",") if x)
+    cur.update({k: str(v) for k, v in kv.items()})
+    monkeypatch.setenv("DPOT_TUNE", ",".join(f"{k}={v}" for k, v in cur.items()))
+
+
+def tune_value(key, default):
+    import os
+    cur = dict(x.split("=") for x in os.environ.get("DPOT_TUNE", "").split(",") if x)
+    return int(cur.get(key, default))
+

@@ -9,7 +9,7 @@ import os
 import pytest
 import torch
 
-from helpers import assert_close, assert_sub, load
+from helpers import assert_close, assert_sub, load, set_tune, tune_value
 from oracle import dpot_ref as R
 
 pytestmark = pytest.mark.gpu
@@ -42,9 +42,9 @@ def test_afno_mixer_golden_one_launch_layer(monkeypatch):
     of the mixer's forward (csrc/afno_fused.hip, SURVEY 8 f4: rfft2 -> both MLP layers -> irfft2 + x in one kernel), which
     `auto` only selects from 205 (sample, block) workgroups on; the backward consumes the S / pre-activation it saves"""
     from dpot_amd import ops
-    monkeypatch.setenv("DPOT_AFNO_LAYER", "1")
+    set_tune(monkeypatch, afno_layer=1)
     if not (ops.afno_mlp2_supported(4, 128) and ops.afno_mlp3_supported(4, 128) and ops.afno_fused_supported(16, 16, 512, 4, 16, 9, G=0)):
-        pytest.skip("one-launch AFNO layer switched off (DPOT_AFNO_3MULT=0 / DPOT_AFNO_FUSED=0)")
+        pytest.skip("one-launch AFNO layer switched off (DPOT_TUNE mixer != 3)")
     calls = []
     real = ops.afno_fused_fwd
     monkeypatch.setattr(ops, "afno_fused_fwd", lambda *a, **k: (calls.append(1), real(*a, **k))[1])
@@ -69,7 +69,7 @@ def test_afno_mixer_golden(name):
     x = R.recipe_input((B, h, h, E), salt=11)
     up = (R.recipe_input((B, h, h, E), salt=12) * 0.3)
     bs = E // nb
-    opted_out = os.environ.get("DPOT_AFNO_3MULT", "1") == "0" or os.environ.get("DPOT_AFNO_FUSED", "1") == "0"
+    opted_out = tune_value("mixer", 3) != 3 or tune_value("panel", 1) == 0
     if name == "g1_afno_tiny" and not opted_out:      # the DPOT-Tiny layer must run on the fused three-product kernel
         assert ops.afno_mlp2_supported(nb, bs) and ops.afno_mlp3_supported(nb, bs)
         assert ops.afno_wgrad2_splitk(B * min(modes, h) * min(modes, h // 2 + 1), nb, bs) > 0

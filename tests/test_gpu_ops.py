@@ -7,7 +7,7 @@ import numpy as np
 import pytest
 import torch
 
-from helpers import assert_close
+from helpers import assert_close, set_tune
 from oracle import dpot_ref as R
 
 pytestmark = pytest.mark.gpu
@@ -644,18 +644,16 @@ def test_gemm_bf16_panel_wgrad_splitk(ops, M, N, K, splitk):
     assert torch.equal(dw, dw2), "split-K reduction must be deterministic"
 
 
-def test_bf16_panel_model_step_matches_bf16_split_path(ops, monkeypatch):
+def test_bf16_panel_model_step_within_bf16_bound_of_fp32(ops, monkeypatch):
     """channel-MLP precision 'bf16' routes fc1 / fc2 forward, data and weight gradients through csrc/gemm_bf16p.hip when
-    the shapes allow it (E, mlp hidden multiples of 256).  Same arithmetic as the generic plain-bf16 GEMM (operands
-    rounded to bf16, fp32 accumulation) -> outputs and gradients agree to accumulation-order level, and sit within the
-    bf16 bound of the fp32 model."""
+    the shapes allow it (E, mlp hidden multiples of 256): operands rounded to bf16, fp32 accumulation -> outputs and
+    gradients sit within the bf16 bound of the fp32 model."""
     from dpot_amd import DPOTNet
     kw = dict(R.MINI, embed_dim=256, out_layer_dim=32, depth=2, mlp_ratio=1, n_blocks=4)
     cfg = R.DPOTConfig(**kw)
     x = R.recipe_input((2, cfg.img_size, cfg.img_size, cfg.in_timesteps, cfg.in_channels), salt=9).cuda()
 
-    def run(prec, panel):
-        monkeypatch.setenv("DPOT_BF16_PANEL", "1" if panel else "0")
+    def run(prec):
         m = DPOTNet(**kw).cuda()
         m.load_state_dict(R.recipe_state_dict(cfg, salt=4))
         ops.set_mlp_precision(prec)
@@ -667,15 +665,12 @@ def test_bf16_panel_model_step_matches_bf16_split_path(ops, monkeypatch):
             ops.set_mlp_precision(None)
         return y.detach(), {n: p.grad.clone() for n, p in m.named_parameters() if p.grad is not None}, used
 
-    y32, g32, _ = run(None, False)
-    yb, gb, used_b = run("bf16", False)
-    yp, gp, used_p = run("bf16", True)
-    assert used_p and not used_b
+    y32, g32, used_32 = run(None)
+    yp, gp, used_p = run("bf16")
+    assert used_p and not used_32
     rel = lambda a, b: ((a.double() - b.double()).norm() / b.double().norm().clamp_min(1e-30)).item()
-    assert rel(yp, yb) < 2e-4, rel(yp, yb)
     assert 1e-6 < rel(yp, y32) < 2e-2
     for n in g32:
-        assert rel(gp[n], gb[n]) < 3e-3, (n, rel(gp[n], gb[n]))
         assert rel(gp[n], g32[n]) < 5e-2, (n, rel(gp[n], g32[n]))
 
 
@@ -766,37 +761,6 @@ def test_gemm_bf16x6_panel_is_fp32_accurate(ops, M, N, K):
             assert_close(dw, dY.double().t() @ A[:Mt].double(), "wgrad (split-K)", rtol=2e-5, atol_scale=2e-6)
 
 
-def test_bf16x6_panel_model_step_matches_fp32(ops, monkeypatch):
-    """channel-MLP precision 'bf16x6' on the three-plane panel kernel: a model step (outputs + every gradient) agrees with
-    the native-fp32 step to fp32 round-off - it is the same arithmetic to ~2^-24 per product"""
-    from dpot_amd import DPOTNet
-    kw = dict(R.MINI, embed_dim=256, out_layer_dim=32, depth=2, mlp_ratio=1, n_blocks=4)
-    cfg = R.DPOTConfig(**kw)
-    x = R.recipe_input((2, cfg.img_size, cfg.img_size, cfg.in_timesteps, cfg.in_channels), salt=9).cuda()
-
-    monkeypatch.setenv("DPOT_X6_PANEL", "1")           # opt-in: the split kernel is the default bf16x6 path
-
-    def run(prec):
-        m = DPOTNet(**kw).cuda()
-        m.load_state_dict(R.recipe_state_dict(cfg, salt=4))
-        ops.set_mlp_precision(prec)
-        try:
-            y, _ = m(x)
-            (y ** 2).sum().backward()
-            used = getattr(m, "_panel_packs_bf16x6", None) is not None
-        finally:
-            ops.set_mlp_precision(None)
-        return y.detach(), {n: p.grad.clone() for n, p in m.named_parameters() if p.grad is not None}, used
-
-    y32, g32, u0 = run(None)
-    y6, g6, u1 = run("bf16x6")
-    assert u1 and not u0
-    rel = lambda a, b: ((a.double() - b.double()).norm() / b.double().norm().clamp_min(1e-30)).item()
-    assert rel(y6, y32) < 2e-6, rel(y6, y32)
-    for n in g32:
-        assert rel(g6[n], g32[n]) < 2e-5, (n, rel(g6[n], g32[n]))
-
-
 @pytest.mark.parametrize("M,N,K,batch,cs", [(512, 512, 8192, 1, 1), (256, 256, 4608, 1, 2), (128, 384, 2048, 1, 0),
                                             (512, 2048, 1024, 1, 0), (256, 128, 32 * 37, 1, 1)])
 def test_weight_gradient_kernel_vs_fp64(ops, M, N, K, batch, cs):
@@ -851,7 +815,7 @@ def test_bf16_mlp_pack_both_path_matches_separate_packs(ops, monkeypatch):
     x = R.recipe_input((2, cfg.img_size, cfg.img_size, cfg.in_timesteps, cfg.in_channels), salt=9).cuda()
 
     def run(both, recompute=False):
-        monkeypatch.setenv("DPOT_PACK_BOTH", "1" if both else "0")
+        set_tune(monkeypatch, pack_both=1 if both else 0)
         m = DPOTNet(**kw).cuda()
         m.load_state_dict(R.recipe_state_dict(cfg, salt=4))
         m.recompute_blocks = recompute
@@ -1066,11 +1030,15 @@ def test_small_linear_vs_fp64(ops, M, N, K, act):
     assert_close(pre, ref, "small_linear pre")
     assert_close(y, torch.nn.functional.gelu(ref) if act else ref, "small_linear act")
     # the GEMM path on the same operands (what larger batches use) agrees
-    os.environ["DPOT_SMALL_LINEAR"] = "0"
+    old = os.environ.get("DPOT_TUNE")
+    os.environ["DPOT_TUNE"] = (old + "," if old else "") + "fused_small=0"
     try:
         y2, _ = ops.linear_fwd(x, W, b, act=act, save_pre=True)
     finally:
-        del os.environ["DPOT_SMALL_LINEAR"]
+        if old is None:
+            del os.environ["DPOT_TUNE"]
+        else:
+            os.environ["DPOT_TUNE"] = old
     assert_close(y2, y.double(), "small_linear vs GEMM")
 
 
@@ -1132,36 +1100,10 @@ def test_bf16_panel_pair_launch_matches_single(ops):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("T,E,mh", [(8192, 1024, 4096), (512, 1536, 6144), (2048, 1024, 4096)])
-def test_bf16_pair_launch_with_row_form_operands(ops, T, E, mh):
-    """round 5: the paired weight-gradient launch reading the hidden layer H [T, mh] and its gradient dH in ROW form through
-    ds_read_b64_tr_b16 (permuted LDS-DMA image, csrc/gemm_bf16p.hip ATR) - dW2^T = H^T dY stored transposed, dW1 = dH^T X -
-    against the launch on TRANSPOSED packs it replaces: same products, same k order -> bit-identical; and against float64
-    products of the bf16-rounded operands.  DPOT-M's shape (256 tiles, eight-wave workgroups), DPOT-L's (128 x 192 tiles,
-    768 of them) and a short contraction at DPOT-M's widths."""
-    if not ops.gemm_bf16p_pair_rowform_ok(mh, E, mh, E, T):
-        pytest.skip("row-form pair launch not available for this shape / switched off")
-    torch.manual_seed(T + E)
-    h, dh = torch.randn(T, mh, device="cuda"), torch.randn(T, mh, device="cuda")
-    x, dy = torch.randn(T, E, device="cuda"), torch.randn(T, E, device="cuda")
-    hp, dhp = ops.bf16_pack_rows(h), ops.bf16_pack_rows(dh)                    # ROW form (what the data GEMMs consume)
-    xT, dyT = ops.bf16_pack_rows(x, trans=True), ops.bf16_pack_rows(dy, trans=True)
-    dW2, dW1 = ops.gemm_bf16p_pair(hp, dyT, mh, E, dhp, xT, mh, E, T, rowform=True, trans0=True)
-    assert dW2.shape == (E, mh) and dW1.shape == (mh, E)
-    r = lambda t: t.bfloat16().double()
-    assert_close(dW2, r(dy).t() @ r(h), "dW2 = dY^T H (computed as H^T dY, stored transposed)")
-    assert_close(dW1, r(dh).t() @ r(x), "dW1 = dH^T X")
-    hT, dhT = ops.bf16_pack_rows(h, trans=True), ops.bf16_pack_rows(dh, trans=True)
-    O2, O1 = ops.gemm_bf16p_pair(dyT, hT, E, mh, dhT, xT, mh, E, T, splitk=1)  # the launch on transposed packs
-    assert torch.equal(dW1, O1), "row-form operand changed dW1"
-    assert_close(dW2, O2, "dW2 vs the transposed-pack launch", rtol=1e-6, atol_scale=1e-6)
-
-
-@pytest.mark.gpu
 @pytest.mark.parametrize("B,T,E,G", [(4, 1024, 1536, 8), (2, 200, 96, 8), (1, 4096, 768, 8)])
 def test_groupnorm_chunked_vs_fp64(ops, monkeypatch, B, T, E, G):
     """few, large (sample, group) slabs: the chunked kernels (statistics merged through a workspace) against float64
-    and against the one-workgroup-per-slab kernels (DPOT_GN_CHUNKED is read once per process: compared via NULL workspace)"""
+    and against the one-workgroup-per-slab kernels (compared via NULL workspace)"""
     torch.manual_seed(B + T)
     x = torch.randn(B, T, E, device="cuda") * 1.7 + 0.8
     gw = torch.randn(E, device="cuda"); gb = torch.randn(E, device="cuda")
@@ -1217,7 +1159,7 @@ def test_groupnorm_chunked_statistics_hard_cases(ops, case):
 
 @pytest.mark.parametrize("M", [8192, 8160])
 def test_gemm_bf16_panel_large_shape(ops, M):
-    """the bf16 panel kernel on a many-tile shape (512 tiles: two rounds of workgroups; with DPOT_BF16P_RASTER=1 also the
+    """the bf16 panel kernel on a many-tile shape (512 tiles: two rounds of workgroups; also the
     L2-aware super-block tile order; launches with packed outputs run the two-workgroups-per-CU kernel from 512 tiles on -
     M = 8160 leaves its last row of tiles 96 rows tall).  bf16 x bf16 products are exact and the accumulation is fp32, so
     against an fp64 product of the bf16-ROUNDED operands the result must agree to fp32 accumulation accuracy - a
@@ -1332,7 +1274,7 @@ def test_groupnorm_dft_fused_kernels_vs_separate(ops, E, nb, modes):
     channels per group, full and truncated mode sets.  fp32 re-association only: rtol 2e-5 of the tensor scale."""
     B, h = 3, 16
     if not ops.gn_dft_supported(h, h, E):
-        pytest.skip("fused GroupNorm-DFT kernels switched off (DPOT_GN_DFT=0): the separate kernels run")
+        pytest.skip("fused GroupNorm-DFT kernels switched off (DPOT_TUNE gn_fuse=0): the separate kernels run")
     mx, my = min(modes, h), min(modes, h // 2 + 1)
     x = (rnd(B, h * h, E, seed=1) * 1.7 + 0.4).cuda()
     g1, b1 = (1 + 0.3 * rnd(E, seed=2)).cuda(), (0.2 * rnd(E, seed=3)).cuda()
@@ -1411,7 +1353,7 @@ def test_afno_layer_one_launch_vs_three_launches(ops, monkeypatch, E, nb, B, nor
     both produce (S, layer-1 pre-activation, y1, xn2, both statistics) and (b) float64 torch.fft of the same layer
     (models/dpot.py:59-102 + GroupNorm).  64 / 128 channels per group, the norm-free form (the reference's AFNO2D module
     alone) and the inference form (S / pre not written)."""
-    monkeypatch.setenv("DPOT_AFNO_LAYER", "1")
+    set_tune(monkeypatch, afno_layer=1)
     h, G = 16, 8
     mx, my, bs = 16, 9, E // nb
     if not ops.afno_fused_supported(h, h, E, nb, mx, my, G=G if norm else 0):
@@ -1482,95 +1424,6 @@ def test_afno_layer_one_launch_vs_three_launches(ops, monkeypatch, E, nb, B, nor
         xp3, xpT3, _ = ops.bf16_pack_both(res[2].view(B * h * h, E), norm=(res[6], res[7], g2, b2, h * h))
         assert torch.equal(res[8].view(torch.int16), xp3.view(torch.int16)), "row-form pack of GroupNorm2(y1)"
         assert torch.equal(res[9].view(torch.int16), xpT3.view(torch.int16)), "transposed pack of GroupNorm2(y1)"
-
-
-@pytest.mark.parametrize("E,nb,B,norm,act,add", [(512, 4, 3, True, "gelu", True), (1024, 8, 2, True, "gelu", True),
-                                                 (512, 4, 2, False, "gelu", False), (1024, 8, 3, True, "silu", False)])
-def test_afno_layer_backward_one_launch(ops, monkeypatch, E, nb, B, norm, act, add):
-    """csrc/afno_fused.hip afno_fused_bwd_kernel (round 5): norm2 backward -> adjoint irfft2 -> data path of both MLP layers
-    (act' from the saved pre-activation, O1 re-derived) -> adjoint rfft2 + skip -> norm1 backward + outer skip in ONE launch,
-    against (a) the launches it replaces (gn_bwd_rfft2 / groupnorm_bwd + rfft2, afno_mlp2 mode 1, irfft2 + groupnorm_bwd) on
-    every tensor both produce - dx, dO2, O1, dO1pre, the GroupNorm parameter-gradient partials - and (b) float64 autograd of
-    the layer as the reference computes it (models/dpot.py:59-102, :165-175): dx and, through the unchanged weight-gradient
-    launch on the operands the kernel left, dW1 / db1 / dW2 / db2.  64 / 128 channels per group and the norm-free form."""
-    monkeypatch.setenv("DPOT_AFNO_LAYER", "1")
-    h, G = 16, 8
-    mx, my, bs = 16, 9, E // nb
-    if not ops.afno_fused_supported(h, h, E, nb, mx, my, G=G if norm else 0):
-        pytest.skip("one-launch AFNO layer not available")
-    a = ops.ACT_IDS[act]
-    x = (rnd(B, h * h, E, seed=1) * 1.3 + 0.25).cuda()
-    g1, b1 = (1 + 0.3 * rnd(E, seed=2)).cuda(), (0.2 * rnd(E, seed=3)).cuda()
-    g2, b2 = (1 + 0.3 * rnd(E, seed=4)).cuda(), (0.2 * rnd(E, seed=5)).cuda()
-    w1, w2 = (rnd(2, nb, bs, bs, seed=6) * 0.09).cuda(), (rnd(2, nb, bs, bs, seed=7) * 0.09).cuda()
-    bb1, bb2 = (rnd(2, nb, bs, seed=8) * 0.1).cuda(), (rnd(2, nb, bs, seed=9) * 0.1).cuda()
-    dxn2 = rnd(B, h * h, E, seed=10).cuda()                       # upstream gradient (wrt xn2, or wrt y1 without the norm)
-    dout = rnd(B, h * h, E, seed=11).cuda() if add else None
-    packed = ops.AfnoPacks([(w1, bb1), (w2, bb2)]).refresh()
-    n = (g1, b1, g2, b2) if norm else (None, None, None, None)
-    S, pre, y1, xn2, m1, r1, m2, r2 = ops.afno_fused_fwd(x, n[0], n[1], packed[0][2], packed[0][1], packed[1][2],
-                                                         packed[1][1], n[2], n[3], h, h, nb, mx, my, a, save=True)
-    wb1, wb2 = packed[0][3], packed[1][3]
-    dx, dO2, O1, dPre, p1, p2 = ops.afno_fused_bwd(dxn2, y1 if norm else None, m2, r2, n[2], pre, wb2, wb1,
-                                                   x if norm else None, m1, r1, n[0], dout, h, h, nb, mx, my, a)
-    tol = dict(rtol=2e-5, atol_scale=2e-5)
-    # (a) the separate launches
-    if norm:
-        dy1, p2_3 = ops.groupnorm_bwd(dxn2, y1, m2, r2, g2, defer=True)
-    else:
-        dy1 = dxn2
-    dO2_3 = ops.rfft2(dy1, h, h, nb, mx, my, 1)
-    dS, O1_3, dPre_3 = ops.afno_mlp2(dO2_3, wb2, None, wb1, None, nb, bs, a, mode=1, aux=pre, want_mid=True, want_pre=True,
-                                     layout=1)
-    dxn1 = ops.irfft2(dS, B, h, h, E, nb, mx, my, 0, res=dy1)
-    if norm:
-        dx_3, p1_3 = ops.groupnorm_bwd(dxn1, x, m1, r1, g1, add=dout, defer=True)
-    else:
-        dx_3 = dxn1 + dout if add else dxn1
-    assert_close(dO2, dO2_3, "dO2", **tol)
-    assert_close(O1, O1_3, "O1", **tol)
-    assert_close(dPre, dPre_3, "dO1pre", **tol)
-    assert_close(dx, dx_3, "dx", **tol)
-    if norm:
-        assert_close(p1, p1_3, "norm1 parameter-gradient partials", rtol=1e-4, atol_scale=1e-4)
-        assert_close(p2, p2_3, "norm2 parameter-gradient partials", rtol=1e-4, atol_scale=1e-4)
-    else:
-        assert p1 is None and p2 is None
-    # (b) float64 autograd of the layer
-    xd = x.double().cpu().requires_grad_(True)
-    prm = [t.double().cpu().requires_grad_(True) for t in (g1, b1, g2, b2, w1, bb1, w2, bb2)]
-    G1, B1, G2, B2, W1p, C1p, W2p, C2p = prm
-
-    def gn(t, g, b):
-        td = t.view(B, h * h, G, E // G)
-        mu, var = td.mean(dim=(1, 3), keepdim=True), td.var(dim=(1, 3), unbiased=False, keepdim=True)
-        return ((td - mu) / torch.sqrt(var + 1e-5)).view(B, h * h, E) * g + b
-
-    xn = gn(xd, G1, B1) if norm else xd
-    F = torch.fft.rfft2(xn.view(B, h, h, E), dim=(1, 2), norm="ortho").view(B, h, 9, nb, bs)
-    o1 = torch.einsum("bxykI,kIO->bxykO", F, torch.complex(W1p[0], W1p[1])) + torch.complex(C1p[0], C1p[1])
-    f = ACTS[act]
-    o1 = torch.complex(f(o1.real), f(o1.imag))
-    o2 = torch.einsum("bxykI,kIO->bxykO", o1, torch.complex(W2p[0], W2p[1])) + torch.complex(C2p[0], C2p[1])
-    yref = torch.fft.irfft2(o2.reshape(B, h, 9, E), s=(h, h), dim=(1, 2), norm="ortho").reshape(B, h * h, E) + xn
-    out = gn(yref, G2, B2) if norm else yref
-    loss = (out * dxn2.double().cpu()).sum()
-    if add:
-        loss = loss + (xd * dout.double().cpu()).sum()
-    loss.backward()
-    assert_close(dx, xd.grad, "dx vs float64 autograd")
-    dw1, db1 = torch.empty(2, nb, bs, bs, device="cuda"), torch.empty(2, nb, bs, device="cuda")
-    dw2, db2 = torch.empty(2, nb, bs, bs, device="cuda"), torch.empty(2, nb, bs, device="cuda")
-    sk = ops.afno_wgrad2_splitk(B * mx * my, nb, bs)
-    if sk:
-        ops.afno_wgrad2(S, dPre, O1, dO2, nb, bs, dw1, db1, dw2, db2, sk)
-        for got, want, nm in ((dw1, W1p.grad, "dW1"), (db1, C1p.grad, "db1"), (dw2, W2p.grad, "dW2"), (db2, C2p.grad, "db2")):
-            assert_close(got, want, nm + " vs float64 autograd")
-    if norm:
-        assert_close(p1[0].sum(0), G1.grad, "dgamma1 vs float64 autograd")
-        assert_close(p1[1].sum(0), B1.grad, "dbeta1 vs float64 autograd")
-        assert_close(p2[0].sum(0), G2.grad, "dgamma2 vs float64 autograd")
-        assert_close(p2[1].sum(0), B2.grad, "dbeta2 vs float64 autograd")
 
 
 @pytest.mark.gpu

@@ -1,5 +1,5 @@
-"""The documented opt-out switches (DESIGN.md "Environment knobs") select the FALLBACK kernels of the product path.  They
-are read once per process (static initialisers in csrc/, module-level reads in dpot_amd/), so each switch gets its own
+"""The documented fallback selectors (DPOT_TUNE keys: dpot_amd/ops.py TUNE_KEYS) select the FALLBACK kernels
+of the product path.  The C library reads DPOT_TUNE once per process, so each group of keys gets its own
 child pytest process that re-runs a parity subset under it: the golden-vector model tests (test_gpu_model.py), the
 DPOT-Tiny / -Small / -Medium gradient cases against the oracle in fp32 and bf16 channel-MLP mode, and - for the switches
 that only act on DPOT-L's launch shapes - the DPOT-L batch-16 case against the reference's golden numbers; the `auto` GEMM
@@ -23,20 +23,14 @@ LARGE_SET = "test_vs_reference_golden and LARGE-16"
 # run the golden-vector model tests of test_gpu_model.py?).  Four children: the round-end GPU gate has to stay short.
 SWITCHES = {
     # bf16 channel-MLP kernels.  Default since round 4: the B-direct kernels (W fragments straight into registers).
-    # BD=0: the LDS-DMA kernels of rounds 2-3 in their own default selection (two-workgroup kernel, 128 x 192 tiles, pairs)
-    # (DPOT_BF16P_ROWFORM=1, an opt-IN riding along: it only acts on the B-direct pair launch, which BD=0 switches off - so it
-    # gets the DPOT-M case of its own below)
-    # (DPOT_AFNO_WGRAD_GAUSS96=0 rides along: the 192 x 192 four-product AFNO weight-gradient kernel that gemm_tn96g_kernel
-    # replaced at 96 channels per block - only DPOT-L has that shape)
-    "DPOT_BF16P_BD=0 DPOT_AFNO_WGRAD_GAUSS96=0": (LARGE_SET, False),
-    # round 5 defaults switched OFF: four-product AFNO weight gradients, the separate pack passes of the bf16 channel MLP (no packs
-    # from the one-launch AFNO layer / the GroupNorm backward) - the forms these replaced stay under the gate
-    "DPOT_AFNO_WGRAD_GAUSS=0 DPOT_GRAD_PACKS=0 DPOT_AFNO_LAYER_PACKS=0":
+    # bf16p_bd=0: the LDS-DMA kernels of rounds 2-3 for every launch, in their own default selection (128 x 192 tiles, pairs)
+    # (wgrad_gauss=0 rides along: four-product AFNO weight gradients - at DPOT-L's 96 channels per block that is the 192 x 192
+    # kernel that gemm_tn96g_kernel replaced)
+    "DPOT_TUNE=bf16p_bd=0,wgrad_gauss=0": (LARGE_SET, False),
+    # round 5 / 6 defaults switched OFF: four-product AFNO weight gradients, no bf16 packs from the one-launch AFNO layer / the
+    # GroupNorm backward / Adam (the separate pack passes these replaced stay under the gate)
+    "DPOT_TUNE=wgrad_gauss=0,packs=0":
         ("test_vs_reference_golden and SMALL-32 or test_full_model_gradients_vs_oracle and TINY-32", False),
-    # round 5 opt-ins that were built and rejected by measurement - kept under the gate: the one-launch AFNO layer BACKWARD and
-    # the weight gradients on ROW-form operands through the transposing LDS read (DPOT-M at batch 32: reference golden, fp32
-    # leg + bf16 leg; DPOT-S at batch 32 runs the one-launch layer forward + backward)
-    "DPOT_AFNO_LAYER_BWD=1 DPOT_BF16P_ROWFORM=1": ("test_vs_reference_golden and (MEDIUM-32 or SMALL-32)", False),
     # not an opt-OUT but the mode `bench.py --config S|M|L|L20` runs: fp32 GEMMs >= 3 GFLOP on the fp32-accurate bf16x6 operand
     # split (`auto`).  The DPOT-L batch-16 reference golden (fp32 path at rtol 1e-4, then the bf16 channel-MLP mode) and the
     # Tiny / M gradient cases against the oracle must hold under it as they do with native fp32 MFMA
@@ -45,14 +39,12 @@ SWITCHES = {
                                  " or test_bf16_channel_mlp_mode_vs_oracle and MEDIUM-1", False),
     # every round-3/4 fallback at once: four-product fused mixer, separate GroupNorm / DFT kernels, GroupNorm never applied
     # on load, generic GEMM instead of the panel / weight-gradient kernels, explicit patch matrix, three reduce launches per
-    # block, eight layout launches, B-direct with eight waves everywhere / column-major order / 256-wide tiles / un-paired
-    ("DPOT_AFNO_3MULT=0 DPOT_GN_DFT=0 DPOT_GN_ONLOAD=0 DPOT_PANEL_GEMM=0 DPOT_GEMM_TN=0 DPOT_EMBED_IMPLICIT=0 "
-     "DPOT_BLOCK_FINALIZE=0 DPOT_LAYOUT_JOBS=0 DPOT_BF16P_BD_CPW=1 DPOT_BF16P_RASTER=0 DPOT_BF16P_ROWMAJOR=0 "
-     "DPOT_BF16P_TILE192=0 DPOT_BF16P_PAIR=0"): (SMALL_SET, True),
-    # the mixer as two generic GEMM launches, and the LDS-DMA bf16 kernels with the 12-wave kernel for every launch, 128 x 256
-    # tiles only, un-paired weight gradients
-    # (DPOT_AFNO_LAYER=0: the three launches per AFNO layer forward at the batches where `auto` picks the one-launch kernel)
-    "DPOT_AFNO_FUSED=0 DPOT_AFNO_LAYER=0 DPOT_BF16P_BD=0 DPOT_BF16P_DUO=0 DPOT_BF16P_TILE192=0 DPOT_BF16P_PAIR=0":
+    # block, eight layout launches, B-direct with eight waves everywhere / column-major order / 256-wide tiles / un-paired,
+    # no pack-both path
+    "DPOT_TUNE=mixer=4,gn_fuse=0,panel=0,embed_implicit=0,fused_small=0,bf16p_shape=0,pack_both=0": (SMALL_SET, True),
+    # the mixer as two generic GEMM launches, the three launches per AFNO layer forward at the batches where `auto` picks the
+    # one-launch kernel, and the LDS-DMA bf16 kernels for every launch, 128 x 256 tiles only, un-paired weight gradients
+    "DPOT_TUNE=mixer=0,afno_layer=0,bf16p_bd=0,bf16p_shape=0":
         (SMALL_SET + " or test_vs_reference_golden and SMALL-32", True),
 }
 
@@ -61,7 +53,7 @@ def _child_cmd(switch):
     expr, with_model = SWITCHES[switch]
     env = dict(os.environ)
     for kv in switch.split():
-        k, v = kv.split("=")
+        k, _, v = kv.partition("=")
         env[k] = v
     files = ["tests/test_gpu_sizes.py"] + (["tests/test_gpu_model.py"] if with_model else [])
     if with_model:

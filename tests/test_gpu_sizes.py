@@ -8,7 +8,7 @@ from collections import OrderedDict
 import pytest
 import torch
 
-from helpers import RTOL, assert_close
+from helpers import RTOL, assert_close, set_tune, tune_value
 from oracle import dpot_ref as R
 
 pytestmark = pytest.mark.gpu
@@ -90,20 +90,13 @@ def test_full_model_gradients_vs_oracle(name, B):
     print(f"[{name} B={B}] worst normalised gradient error {worst:.2e}")
 
 
-@pytest.mark.parametrize("bwd", ["0", "1"])
-def test_full_model_gradients_with_one_launch_afno_layer(monkeypatch, bwd):
-    """(bwd = "1": with the one-launch BACKWARD of the layer as well - afno_fused_bwd_kernel, built and rejected by
-    measurement in round 5, kept behind DPOT_AFNO_LAYER_BWD=1 - so the opt-in path stays under the parity gate.)
-    DPOT-Tiny at batch 2 with the ONE-launch AFNO layer forward forced on (csrc/afno_fused.hip; `auto` selects it from
+def test_full_model_gradients_with_one_launch_afno_layer(monkeypatch):
+    """DPOT-Tiny at batch 2 with the ONE-launch AFNO layer forward forced on (csrc/afno_fused.hip; `auto` selects it from
     205 (sample, block) workgroups on, i.e. for DPOT-S / -M at batch 32 - test_vs_reference_golden[SMALL-32 / MEDIUM-32] run it):
     64 channels per GroupNorm group = two groups per workgroup; every gradient vs the oracle at rtol 1e-4, and the
     no-grad forward (S / pre-activation not written) bit-identical to the training forward"""
     from dpot_amd import ops
-    monkeypatch.setenv("DPOT_AFNO_LAYER", "1")
-    monkeypatch.setenv("DPOT_AFNO_LAYER_BWD", bwd)
-    bcalls = []
-    real_b = ops.afno_fused_bwd
-    monkeypatch.setattr(ops, "afno_fused_bwd", lambda *a, **k: (bcalls.append(1), real_b(*a, **k))[1])
+    set_tune(monkeypatch, afno_layer=1)
     if not (ops.afno_mlp2_supported(4, 128) and ops.afno_mlp3_supported(4, 128) and ops.afno_fused_supported(16, 16, 512, 4, 16, 9)):
         pytest.skip("one-launch AFNO layer switched off")
     calls = []
@@ -112,7 +105,6 @@ def test_full_model_gradients_with_one_launch_afno_layer(monkeypatch, bwd):
     oc = _oracle_case("TINY", 2)
     m, xg, y, c = _hip_case("TINY", oc)
     assert calls == [True] * 4, calls
-    assert len(bcalls) == (4 if bwd == "1" else 0), bcalls
     assert_close(y, oc["y"], "pred")
     assert_close(xg.grad, oc["dx"], "dx")
     for k, p in m.named_parameters():
@@ -298,7 +290,7 @@ def test_small_model_at_1024_resolution_vs_oracle():
 def test_block_finalize_launch_is_bit_identical(monkeypatch):
     """round 4: the three reductions that end a block's backward (AFNO / channel-MLP split-K partials, GroupNorm parameter
     gradients) run as ONE launch (csrc/gemm_tn.hip block_finalize_kernel, slices of one grid, same summation orders) - every
-    gradient must equal the three-launch form bit for bit (DPOT_BLOCK_FINALIZE=0)"""
+    gradient must equal the three-launch form bit for bit (DPOT_TUNE fused_small=0, which also un-merges the layout launches)"""
     from dpot_amd import DPOTNet
     cfg = R.DPOTConfig(**R.TINY)
     S = cfg.img_size
@@ -306,7 +298,7 @@ def test_block_finalize_launch_is_bit_identical(monkeypatch):
     up = (R.recipe_input((4, S, S, cfg.out_timesteps, cfg.out_channels), salt=72) * 0.3).cuda()
 
     def grads(flag):
-        monkeypatch.setenv("DPOT_BLOCK_FINALIZE", flag)
+        set_tune(monkeypatch, fused_small=flag)
         m = DPOTNet(**R.TINY)
         m.load_state_dict(_recipe_sd("TINY", 4))
         m.cuda()
@@ -321,7 +313,7 @@ def test_block_finalize_launch_is_bit_identical(monkeypatch):
 
 def test_block_finalize_colsum_slice_bf16_mode(monkeypatch):
     """in the bf16 channel-MLP mode the finalising launch also reduces the bias column sums (df1b, df2b), in a
-    different order than the stand-alone colsum kernel - so DPOT_BLOCK_FINALIZE=1 / 0 agree to fp32 rounding there, not bit for
+    different order than the stand-alone colsum kernel - so fused_small=1 / 0 agree to fp32 rounding there, not bit for
     bit (the fp32 model above is bit-identical): every gradient within 1e-6 norm-wise, the two bias gradients included"""
     from dpot_amd import DPOTNet
     cfg = R.DPOTConfig(**R.SMALL)
@@ -330,7 +322,7 @@ def test_block_finalize_colsum_slice_bf16_mode(monkeypatch):
     up = (R.recipe_input((4, S, S, cfg.out_timesteps, cfg.out_channels), salt=72) * 0.3).cuda()
 
     def grads(flag):
-        monkeypatch.setenv("DPOT_BLOCK_FINALIZE", flag)
+        set_tune(monkeypatch, fused_small=flag)
         m = DPOTNet(**R.SMALL)
         m.load_state_dict(_recipe_sd("SMALL", 4))
         m.cuda()
@@ -349,7 +341,7 @@ def test_block_finalize_colsum_slice_bf16_mode(monkeypatch):
 def test_gradient_packs_between_blocks_are_bit_identical(monkeypatch):
     """round 5: in the bf16 channel-MLP mode a Block's backward hands its input gradient to the previous Block ALSO as bf16 packs
     + bias column sums, written by the GroupNorm backward kernel that produces it (functional._GRAD_PACKS side table) instead of
-    a separate pack pass: every gradient must equal the separate-pass form (DPOT_GRAD_PACKS=0) - bit for bit except the fc2 bias
+    a separate pack pass: every gradient must equal the separate-pass form (DPOT_TUNE packs=0) - bit for bit except the fc2 bias
     gradients, whose column sums are formed per sample instead of per 64 tokens (fp32 rounding) - and the side table must not
     keep more than two entries"""
     from dpot_amd import DPOTNet, functional
@@ -362,7 +354,7 @@ def test_gradient_packs_between_blocks_are_bit_identical(monkeypatch):
     monkeypatch.setattr(functional, "_take_grad_packs", lambda t: (lambda r: (taken.append(r is not None), r)[1])(real(t)))
 
     def grads(flag):
-        monkeypatch.setenv("DPOT_GRAD_PACKS", flag)
+        set_tune(monkeypatch, packs=flag)
         taken.clear()
         m = DPOTNet(**R.SMALL)
         m.load_state_dict(_recipe_sd("SMALL", 4))
@@ -388,7 +380,7 @@ def test_layout_jobs_launch_is_bit_identical(monkeypatch):
     """round 4: the small weight-only layout pieces (padded conv weights, pos_embed^T + bias, de-embed bias per pixel, padded
     tail weights) come from ONE launch over a device-resident job table (csrc/misc.hip layout_jobs_kernel) instead of eight
     copy / transpose / bias launches: prediction, cls output and every gradient must not change by a bit
-    (DPOT_LAYOUT_JOBS=0), for DPOT-Tiny and for the mini config (3 channels, 16-wide tail, 4 time steps)"""
+    (DPOT_TUNE fused_small=0), for DPOT-Tiny and for the mini config (3 channels, 16-wide tail, 4 time steps)"""
     from dpot_amd import DPOTNet
     for name, kw in (("TINY", R.TINY), ("MINI", R.MINI)):
         cfg = R.DPOTConfig(**kw)
@@ -397,7 +389,7 @@ def test_layout_jobs_launch_is_bit_identical(monkeypatch):
         up = (R.recipe_input((2, S, S, cfg.out_timesteps, cfg.out_channels), salt=72) * 0.3).cuda()
 
         def run(flag):
-            monkeypatch.setenv("DPOT_LAYOUT_JOBS", flag)
+            set_tune(monkeypatch, fused_small=flag)
             m = DPOTNet(**kw)
             m.load_state_dict(R.recipe_state_dict(cfg, salt=4))
             m.cuda()
@@ -594,7 +586,7 @@ def test_vs_reference_golden(name, B):
             ops.set_mlp_precision(None)
         return y.detach(), c.detach(), xg.grad, OrderedDict((k, p.grad) for k, p in m.named_parameters())
 
-    if name in ("SMALL", "MEDIUM") and os.environ.get("DPOT_AFNO_LAYER", "auto") == "auto":
+    if name in ("SMALL", "MEDIUM") and tune_value("afno_layer", -1) == -1 and tune_value("mixer", 3) == 3:
         # these two cases are the parity gate of the one-launch AFNO layer forward in its `auto` selection (256 workgroups)
         assert ops.afno_fused_supported(16, 16, cfg.embed_dim, cfg.n_blocks, 16, 9, B=B), "one-launch AFNO layer not selected"
     y, c, dx, grads = run(None)

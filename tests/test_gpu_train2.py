@@ -10,7 +10,7 @@ import numpy as np
 import pytest
 import torch
 
-from helpers import RTOL, assert_close, load
+from helpers import RTOL, assert_close, load, set_tune
 from oracle import dpot_ref as R
 
 pytestmark = pytest.mark.gpu
@@ -205,7 +205,7 @@ def test_segmented_graph_step_equals_eager_step_bf16_small(monkeypatch):
     eager step - same loss, parameters to fp32 rounding"""
     from dpot_amd.dp import BucketedGradReducer
     from dpot_amd.train import SegmentedTrainStep, train_step
-    monkeypatch.setenv("DPOT_AFNO_LAYER", "1")               # (batch 4 is below the `auto` threshold of the one-launch layer)
+    set_tune(monkeypatch, afno_layer=1)                      # (batch 4 is below the `auto` threshold of the one-launch layer)
     m1, cfg = build(R.SMALL, salt=3)
     m1.mlp_precision = "bf16"
     xx, yy, msk = _batch(cfg, 4, T_ar=1)
@@ -543,14 +543,14 @@ def test_window_slide_rejects_mismatched_prediction():
 def test_adam_writes_the_weight_packs(monkeypatch):
     """round 6: with the plain-bf16 channel MLP the fused Adam launch ALSO writes the two bf16 packs of every
     channel-MLP weight (dpot_adam_step_packs: 64 x 256 tiles of the weight through LDS) and the next forward skips its pack
-    launch.  (a) parameters, moments and losses are BIT-identical to the separate Adam + pack launches (DPOT_ADAM_PACKS=0),
+    launch.  (a) parameters, moments and losses are BIT-identical to the separate Adam + pack launches (DPOT_TUNE packs=0),
     eagerly and under hipGraph replay; (b) the packs Adam wrote equal a forced refresh from the parameters; (c) anything else
     that moves the parameters (load_state_dict, optimiser restore) makes the forward pack again."""
     from dpot_amd.train import GraphedTrainStep, train_step
     kw = dict(R.MINI, embed_dim=256, n_blocks=2, depth=2, mlp_ratio=2)
     runs = {}
     for packs in ("0", "1"):
-        monkeypatch.setenv("DPOT_ADAM_PACKS", packs)
+        set_tune(monkeypatch, packs=packs)
         m, cfg = build(kw, salt=7)
         m.mlp_precision = "bf16"
         xx, yy, msk = _batch(cfg, 4)
