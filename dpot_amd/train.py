@@ -591,6 +591,28 @@ def _grad_checksum(g: Tensor) -> Tensor:
     return torch.stack([w.sum(), (w * w).sum()])
 
 
+def _end_stray_captures(streams) -> None:
+    """best effort after a FAILED stream capture: a stream that joined the capture (the reducer's side stream) can be left in
+    capture mode when the capture is torn down by an exception; end it through the HIP runtime and clear the sticky error"""
+    import ctypes
+    try:
+        hip = ctypes.CDLL("libamdhip64.so")
+    except OSError:
+        return
+    for st in streams:
+        if st is None:
+            continue
+        g = ctypes.c_void_p()
+        hip.hipStreamEndCapture(ctypes.c_void_p(st.cuda_stream), ctypes.byref(g))
+        if g.value:
+            hip.hipGraphDestroy(g)
+    hip.hipGetLastError()
+    try:
+        torch.cuda.synchronize()
+    except Exception:                                          # pragma: no cover
+        pass
+
+
 def make_dp_step(model: nn.Module, opt: FusedAdam, reducer, xx: Tensor, yy: Tensor, msk: Optional[Tensor],
                  noise_scale: float = 0.0, warmup: int = 2, T_bundle: int = 1, try_one_graph: bool = True):
     """The N > 1 train step with the FAST mode chosen by verification (round 6): returns (step, info).
@@ -609,14 +631,20 @@ def make_dp_step(model: nn.Module, opt: FusedAdam, reducer, xx: Tensor, yy: Tens
     if not try_one_graph:
         return seg, info
     multi = dist.is_available() and dist.is_initialized()
+    backend = dist.get_backend(reducer.pg) if multi else "none"
+    if multi and backend != "nccl":
+        # only RCCL's collectives are device work that a stream capture can record; a gloo collective synchronises the stream
+        # from the host - attempting the capture would leave the streams that joined it in a broken capture state
+        return seg, {"mode": "segmented", "why": f"one-graph capture failed: backend '{backend}' collectives cannot be recorded "
+                                                 f"in a hipGraph (RCCL only)"}
     one, err = None, None
     tail_flag = reducer.skip_zero_tail
     try:
         one = GraphedTrainStep(model, opt, xx, yy, msk, T_bundle=T_bundle, noise_scale=noise_scale, warmup=1, reducer=reducer,
                                capture_collectives=True)
-    except Exception as e:                                    # e.g. a backend whose collectives cannot be captured (gloo)
+    except Exception as e:                                    # an RCCL build / driver that cannot capture its collectives
         err = f"{type(e).__name__}: {e}"[:160]
-        torch.cuda.synchronize()
+        _end_stray_captures([torch.cuda.current_stream(), reducer.stream])
     # every rank must take the same branch: agree on whether the capture worked everywhere
     ok = torch.tensor([1 if one is not None else 0], device=xx.device, dtype=torch.int64)
     if multi:

@@ -482,8 +482,8 @@ def test_dp_step_selection_one_rank_rccl_and_two_rank_gloo(tmp_path):
     """round 6: train.make_dp_step builds the segmented chain AND the one-graph step, runs one trial step in
     each from the same snapshot and keeps the one-graph step only if the reduced gradient is bit-identical between the modes
     and across the ranks.  (a) one-rank RCCL communicator (the real library on the one GPU): the collectives capture, the
-    trial agrees -> one-graph SELECTED; (b) two ranks over gloo: a gloo collective cannot sit inside a stream capture -> the
-    capture fails on every rank, the selection FALLS BACK to the chain and says so; training continues either way and the
+    trial agrees -> one-graph SELECTED; (b) two ranks over gloo: a gloo collective cannot sit inside a stream capture (it
+    synchronises the stream from the host) -> the selection FALLS BACK to the chain and says so; training continues either way and the
     replicas stay bit-identical."""
     import torch.multiprocessing as mp
     mp.spawn(_select_worker, args=(1, _free_port(), str(tmp_path), "nccl"), nprocs=1, join=True)
