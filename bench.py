@@ -536,7 +536,7 @@ def cpu_baseline(seconds: float):
 
 # the fastest (per-GPU batch, kept AR steps) point of the DPOT-L 20-step rollout that fits 288 GiB, from the sweep on one box
 # (profiles/r06_l20_sweep.txt); the L20 entry itself stays at the LARGEST batch that fits, this one is reported beside it
-L20_FASTEST = {"batch": 8, "keep_last": 20}
+L20_FASTEST = {"batch": 10, "keep_last": 17}
 
 
 def _child(args, key, steps, warm, extra=(), env=None, timeout=300):
@@ -563,7 +563,7 @@ def other_configs(args):
             rl = d.get("roofline") or {}
             cfg = d["config"]
             ent = {"config": key, "baseline_config": cfg["baseline_config"], "value": d["value"], "unit": d["unit"],
-                   "ms_per_step": d["ms_per_step"], "steps": d["steps"], "warmup": d["warmup"], "dtype": d["dtype"][:40],
+                   "ms_per_step": d["ms_per_step"], "steps": d["steps"], "warmup": d["warmup"], "dtype": "f32, bf16 MLP operands",
                    "per_gpu_batch": cfg["per_gpu_batch"], "launch": cfg["launch"], "gemm_precision": cfg["gemm_precision"],
                    "recompute": cfg["activation_recomputation"], "peak_mem_GB": cfg["peak_mem_GB"],
                    "final_loss": cfg["final_loss"], "mixed_ceiling": (d.get("mixed_ceiling") or {}).get("value"),
@@ -634,9 +634,9 @@ def _compact_yardstick(rows):
     tab = [[r["form"].split(" ")[0], r["ours_us"], r["blaslt_bf16out_us"], r["blaslt_f32out_us"]] for r in rows]
     tot_o = sum(r["ours_us"] for r in rows)
     tot_y = sum(min(t for t in (r["blaslt_bf16out_us"], r["blaslt_f32out_us"]) if t is not None) for r in rows)
-    return {"cols": ["form", "ours_us", "hipblaslt_bf16out_us", "hipblaslt_f32out_us"], "rows": tab,
-            "ours_over_hipblaslt_best_total": round(tot_o / tot_y, 3),
-            "what": "torch.mm on bf16 tensors (hipBLASLt), same box / timing code; measurement only, never on the product path"}
+    # rows: [form, ours us, hipBLASLt bf16-out us, hipBLASLt fp32-out us] (torch.mm on bf16 tensors, same box / timing code;
+    # measurement only, never on the product path - DESIGN.md section 7)
+    return {"rows": tab, "ours_over_hipblaslt_best_total": round(tot_o / tot_y, 3)}
 
 
 def compact_line(out: dict) -> dict:
