@@ -218,3 +218,82 @@ def test_load_components_warns_for_absent_known_component():
         warnings.simplefilter("always")
         load_components_from_pretrained(m, R.recipe_state_dict(cfg, salt=1), ["blocks", "scale_feats"])
     assert any("scale_feats" in str(x.message) for x in w)
+
+
+def test_dpot_tune_switchboard(built_lib, monkeypatch):
+    """round 6: ONE environment variable (DPOT_TUNE="key=val,...") behind every fallback selector.  The Python side parses it per
+    call and rejects unknown keys; the C side (dpot_tune) parses the same string once per process - checked in a child process
+    because this one may already have cached it"""
+    import subprocess
+    import sys
+    from dpot_amd import ops
+    monkeypatch.delenv("DPOT_TUNE", raising=False)
+    assert all(ops.tune(k) == d for k, (d, _) in ops.TUNE_KEYS.items())
+    assert len(ops.TUNE_KEYS) <= 11
+    monkeypatch.setenv("DPOT_TUNE", "mixer=4, afno_layer=1,packs=0")
+    assert (ops.tune("mixer"), ops.tune("afno_layer"), ops.tune("packs"), ops.tune("panel")) == (4, 1, 0, 1)
+    monkeypatch.setenv("DPOT_TUNE", "no_such_key=1")
+    with pytest.raises(ValueError):
+        ops.tune("mixer")
+    code = ("from dpot_amd import _lib; l = _lib.load(); "
+            "print(l.dpot_tune(b'bf16p_bd', 1), l.dpot_tune(b'panel', 1), l.dpot_tune(b'wgrad_gauss', 1), l.dpot_tune(b'pan', 7))")
+    env = dict(os.environ, DPOT_TUNE="bf16p_bd=0,wgrad_gauss=0")
+    out = subprocess.run([sys.executable, "-c", code], cwd=ROOT, env=env, capture_output=True, text=True)
+    assert out.returncode == 0, out.stderr[-400:]
+    assert out.stdout.split() == ["0", "1", "0", "7"], out.stdout
+    # no other DPOT_* variable is read by the package or the library any more (bench.py has its own DPOT_BENCH_* / DPOT_DP_*)
+    allowed = {"DPOT_TUNE", "DPOT_HIP_LIB", "DPOT_GEMM_PRECISION", "DPOT_MLP_PRECISION"}
+    for dirpath, _, files in os.walk(os.path.join(ROOT, "dpot_amd")):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h")):
+                src = open(os.path.join(dirpath, f)).read()
+                for m in re.finditer(r"(?:getenv\(|environ(?:\.get)?[\[(])\s*\"(DPOT_[A-Z0-9_]+)\"", src):
+                    assert m.group(1) in allowed, (f, m.group(1))
+
+
+def test_adam_pack_plan_tables(built_lib):
+    """host side of dpot_adam_step_packs (ops.AdamPackPlan): the channel-MLP weights of a flat parameter buffer become 64 x 256
+    tile jobs, everything else plain ranges of <= 2^20 elements; jobs + ranges cover [0, n_active) exactly once"""
+    import ctypes
+    from dpot_amd import _lib, ops
+
+    class FakePacks:
+        bf16, planes = True, 1
+
+    E, mh = 256, 512
+    sizes = [1000, mh * E, 40, E * mh, (1 << 20) + 5000, mh * E, 12]       # small | W1 | small | W2 | long gap | W1' | tail
+    offs, off = [], 0
+    for n in sizes:
+        offs.append(off)
+        off += (n + 3) // 4 * 4
+    flat = torch.zeros(off)
+    view = lambda i, shape: flat[offs[i]:offs[i] + sizes[i]].view(shape)
+    w1, w2, w1b = view(1, (mh, E)), view(3, (E, mh)), view(5, (mh, E))
+    pp = FakePacks()
+    pp.jobs = [(w1, mh, E, E, False), (w1, E, mh, E, True), (w2, E, mh, mh, False), (w2, mh, E, mh, True),
+               (w1b, mh, E, E, False), (w1b, E, mh, E, True)]
+    pp.n = len(pp.jobs)
+    pp.bufs = [torch.zeros(r * k, dtype=torch.bfloat16) for _, r, k, _, _ in pp.jobs]
+    n_active = offs[6]                                       # the tail tensor is not updated
+    plan = ops.AdamPackPlan.build(flat, n_active, pp)
+    assert plan is not None and plan.ntiles == 2 * (mh // 64) * (E // 256) + (E // 64) * (mh // 256)
+    tab = (_lib.AdamPackJob * 3).from_buffer_copy(plan.jobs_dev.numpy().tobytes())
+    covered = torch.zeros(n_active, dtype=torch.int32)
+    tiles = 0
+    for j in tab:
+        assert j.tile0 == tiles and j.R % 64 == 0 and j.K % 256 == 0
+        tiles += (j.R // 64) * (j.K // 256)
+        covered[j.off:j.off + j.R * j.K] += 1
+    assert tiles == plan.ntiles == plan.tile_job_dev.numel()
+    assert plan.tile_job_dev.tolist() == sorted(plan.tile_job_dev.tolist())
+    rg = plan.ranges_dev.view(-1, 2).tolist()
+    assert len(rg) == plan.nranges and max(l for _, l in rg) == plan.max_range <= ops.AdamPackPlan.MAX_RANGE
+    for st, ln in rg:
+        covered[st:st + ln] += 1
+    assert int(covered.min()) == 1 and int(covered.max()) == 1           # every active element exactly once
+    # a weight that does not tile (K % 256 != 0) disables the plan
+    bad = torch.zeros(64 * 200).view(64, 200)
+    pp2 = FakePacks()
+    pp2.jobs = [(bad, 64, 200, 200, False), (bad, 200, 64, 200, True)]
+    pp2.n, pp2.bufs = 2, [torch.zeros(64 * 200, dtype=torch.bfloat16)] * 2
+    assert ops.AdamPackPlan.build(bad.view(-1), bad.numel(), pp2) is None
