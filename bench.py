@@ -536,7 +536,7 @@ def cpu_baseline(seconds: float):
 
 # the fastest (per-GPU batch, kept AR steps) point of the DPOT-L 20-step rollout that fits 288 GiB, from the sweep on one box
 # (profiles/r06_l20_sweep.txt); the L20 entry itself stays at the LARGEST batch that fits, this one is reported beside it
-L20_FASTEST = {"batch": 10, "keep_last": 17}
+L20_FASTEST = {"batch": 9, "keep_last": 20}
 
 
 def _child(args, key, steps, warm, extra=(), env=None, timeout=300):

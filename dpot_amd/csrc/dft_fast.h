@@ -233,6 +233,10 @@ struct DftNorm {
   const float* beta;
   int G;
 };
+// (Round 6 measured these kernels with 384 / 512 / 1024 threads per workgroup on the 32 x 32 grid of DPOT-L, on the theory that 4 waves
+// per CU - one 139 KiB workgroup - cannot keep enough loads in flight: rfft2 unchanged at 512 threads, 2.6x slower at 1024 (128
+// registers: 185 spills); irfft2 15-50 % slower with more threads or wider channel chunks.  profiles/r06_dft32_variants.txt.  They run
+// at 3.6 TB/s because the phases of the one resident workgroup - loads, row transforms, LDS, column transforms, stores - do not overlap.)
 template <int H, int W, int CC>
 __global__ __launch_bounds__(256) void rfft2_fast_kernel(const float* __restrict__ x, float* __restrict__ spec, int E,
                                                          int nb, int mx, int my, int colw, float scale,
