@@ -5,7 +5,9 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from dpot_amd import DPOTNet, ops
 from dpot_amd.train import FlatParams, FusedAdam, rollout
-from scripts.gpu_configs2 import CFGS
+import bench
+
+CFGS = {k: (v[1], v[2], 1) for k, v in bench.CONFIGS.items() if k in ("T", "S", "M", "L")}
 
 key, mlp = sys.argv[1], (sys.argv[2] if len(sys.argv) > 2 else None)
 kw, B, T_ar = CFGS[key]

@@ -13,5 +13,5 @@ bash scripts/gpu_census.sh > /dev/null 2>&1; mv gpurun_out/census.txt gpurun_out
 for c in S M; do bash scripts/gpu_census_M.sh $c bf16 > /dev/null 2>&1; mv gpurun_out/census$c.txt gpurun_out/${R}_final_census_$c.txt; done
 CENSUS_BATCH=16 bash scripts/gpu_census_M.sh L bf16 > /dev/null 2>&1; mv gpurun_out/censusL.txt gpurun_out/${R}_final_census_L.txt
 head -12 gpurun_out/${R}_final_census_M.txt
-DPOT_BENCH_DEBUG_GLOO=1 timeout 600 python bench.py --gpus 2 --steps 5 --warmup 2 > gpurun_out/${R}_final_gloo2_T.json 2> gpurun_out/${R}_final_gloo2_T.err; tail -c 900 gpurun_out/${R}_final_gloo2_T.json; grep -v "bench-full" gpurun_out/${R}_final_gloo2_T.err | tail -3
+DPOT_BENCH_DEBUG_GLOO=1 timeout 600 python bench.py --gpus 2 --steps 5 --warmup 2 2> gpurun_out/${R}_final_gloo2_T.err | grep "^{" | tail -1 > gpurun_out/${R}_final_gloo2_T.json; tail -c 900 gpurun_out/${R}_final_gloo2_T.json; grep -v "bench-full" gpurun_out/${R}_final_gloo2_T.err | tail -3
 rm -f gpurun_out/*.log

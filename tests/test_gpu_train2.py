@@ -581,3 +581,62 @@ def test_adam_writes_the_weight_packs(monkeypatch):
     assert runs["0"][0] == runs["1"][0], (runs["0"][0], runs["1"][0])
     for a, b in zip(runs["0"][1:], runs["1"][1:]):
         assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize("E,mh,depth", [(1024, 4096, 3), (1536, 6144, 2)])
+def test_adam_step_packs_at_model_sizes(E, mh, depth):
+    """dpot_adam_step_packs at the weight shapes of DPOT-M / DPOT-L (a flat buffer laid out like the model's: small tensors between
+    the channel-MLP weights, a > 2^20-element stretch, a tail the optimiser does not touch): parameters and both moments
+    bit-identical to dpot_adam_step over the same buffers, both packs of every weight bit-identical to dpot_bf16_pack_jobs of
+    the updated parameters; with and without the clip coefficient"""
+    from dpot_amd import ops
+    torch.manual_seed(E)
+    sizes = []
+    for _ in range(depth):
+        sizes += [2 * E, 4 * E * 96, mh * E, mh, E * mh, E]          # norms | AFNO-ish | W1 | b1 | W2 | b2
+    sizes = [(1 << 20) + 12345 * 4] + sizes + [4096]
+    offs, off = [], 0
+    for n in sizes:
+        offs.append(off)
+        off += (n + 3) // 4 * 4
+    n_active = offs[-1]
+    p0 = torch.randn(off, device="cuda") * 0.05
+    g = torch.randn(off, device="cuda") * 0.01
+    m0, v0 = torch.randn(off, device="cuda") * 0.01, torch.rand(off, device="cuda") * 1e-4
+    hyper = torch.zeros(8, device="cuda")
+    step = torch.zeros(1, dtype=torch.int64, device="cuda")
+    ops.adam_stage(hyper, step, 1e-3, 0.9, 0.9, 1e-8, 1e-6, 0.5, 3)
+    part, ss = torch.zeros(1024, device="cuda"), torch.zeros(1, device="cuda")
+    ops.sumsq(g[:n_active], ss, part)
+
+    def weights(p):
+        ws = []
+        for d in range(depth):
+            i = 1 + 6 * d
+            ws += [p[offs[i + 2]:offs[i + 2] + mh * E].view(mh, E), p[offs[i + 4]:offs[i + 4] + E * mh].view(E, mh)]
+        return ws
+
+    def jobs(p):
+        out = []
+        for w in weights(p):
+            R_, K = w.shape
+            out += [(w, R_, K, K, False), (w, K, R_, K, True)]
+        return out
+
+    for clip in (None, ss):
+        pa, ma, va = p0.clone(), m0.clone(), v0.clone()
+        ops.adam_step(pa[:n_active], g[:n_active], ma[:n_active], va[:n_active], hyper, clip, 0.5)
+        ref = ops.PanelPacks(jobs(pa), bf16=True)
+        ref.refresh()
+        pb, mb, vb = p0.clone(), m0.clone(), v0.clone()
+        pk = ops.PanelPacks(jobs(pb), bf16=True)
+        for b in pk.bufs:
+            b.zero_()
+        plan = ops.AdamPackPlan.build(pb, n_active, pk)
+        assert plan is not None and plan.ntiles == depth * 2 * (mh // 64) * (E // 256) and plan.max_range <= 1 << 20
+        ops.adam_step_packs(plan, pb, g, mb, vb, hyper, clip, 0.5)
+        torch.cuda.synchronize()
+        assert torch.equal(pa, pb) and torch.equal(ma, mb) and torch.equal(va, vb)
+        assert torch.equal(pb[n_active:], p0[n_active:])                      # the tail is not touched
+        for a, b in zip(ref.bufs, pk.bufs):
+            assert torch.equal(a.view(torch.int16), b.view(torch.int16))
