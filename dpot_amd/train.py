@@ -617,31 +617,37 @@ def make_dp_step(model: nn.Module, opt: FusedAdam, reducer, xx: Tensor, yy: Tens
                  noise_scale: float = 0.0, warmup: int = 2, T_bundle: int = 1, try_one_graph: bool = True):
     """The N > 1 train step with the FAST mode chosen by verification (round 6): returns (step, info).
 
-    Reference mode = ``SegmentedTrainStep`` (graph segments, the bucket all-reduces issued between them: collectives never sit
-    inside a capture).  Fast mode = ``GraphedTrainStep(capture_collectives=True)``: the whole step, all-reduces included, as ONE
-    hipGraph (+0.7 % over the single-GPU graph at DPOT-Tiny against +4.2 %).  Whether the communication library's kernels
-    replay correctly as graph nodes across ranks cannot be known in advance, so both are captured, ONE step is run in each mode
-    from the same snapshot (parameters, Adam state, noise generator) and the reduced flat gradient is compared bit for bit
-    between the modes AND across the ranks (checksums through the process group); the one-graph step is kept only when every
-    rank agrees, otherwise the segmented chain runs and ``info`` says why.  Parameters, optimiser state and the noise
-    generator are left exactly as found.  Mirrors train_temporal_parallel.py:102,185,243-244 (accelerate's DDP step)."""
+    Fast mode = ``GraphedTrainStep(capture_collectives=True)``: the whole step, bucket all-reduces included, as ONE hipGraph
+    (+0.4 % over the single-GPU graph at DPOT-Tiny against +4 % for the chain).  Fallback = ``SegmentedTrainStep`` (graph
+    segments, the all-reduces issued between them: collectives never sit inside a capture).  Whether the communication
+    library's kernels replay correctly as graph nodes across ranks cannot be known in advance, so the one-graph step is
+    captured and ONE trial step is run twice from the same snapshot (parameters, Adam state, noise generator): eagerly with the
+    hook-driven reducer (``train_step`` - the same kernels in the same order, collectives issued live) and as a replay of the
+    graph.  The reduced flat gradient must agree BIT FOR BIT between the two and across the ranks (checksums through the process
+    group); only then is the one-graph step returned, otherwise the segmented chain is built and ``info`` says why.  (The chain
+    itself is not the reference of the comparison: with the bf16 channel MLP its graph cuts change which kernel packs a
+    Block's incoming gradient, and six bias gradients differ in the last bit - tests/test_gpu_train2.py.)  Parameters,
+    optimiser state and the noise generator are left exactly as found.  Mirrors train_temporal_parallel.py:102,185,243-244."""
     import torch.distributed as dist
-    seg = SegmentedTrainStep(model, opt, reducer, xx, yy, msk, noise_scale=noise_scale, warmup=warmup, T_bundle=T_bundle)
-    info = {"mode": "segmented", "why": "one-graph mode not tried"}
+
+    def chain(why):
+        reducer.skip_zero_tail = tail_flag
+        seg = SegmentedTrainStep(model, opt, reducer, xx, yy, msk, noise_scale=noise_scale, warmup=warmup, T_bundle=T_bundle)
+        return seg, {"mode": "segmented", "why": why}
+
+    tail_flag = reducer.skip_zero_tail
     if not try_one_graph:
-        return seg, info
+        return chain("one-graph mode not tried")
     multi = dist.is_available() and dist.is_initialized()
     backend = dist.get_backend(reducer.pg) if multi else "none"
     if multi and backend != "nccl":
         # only RCCL's collectives are device work that a stream capture can record; a gloo collective synchronises the stream
         # from the host - attempting the capture would leave the streams that joined it in a broken capture state
-        return seg, {"mode": "segmented", "why": f"one-graph capture failed: backend '{backend}' collectives cannot be recorded "
-                                                 f"in a hipGraph (RCCL only)"}
+        return chain(f"one-graph capture failed: backend '{backend}' collectives cannot be recorded in a hipGraph (RCCL only)")
     one, err = None, None
-    tail_flag = reducer.skip_zero_tail
     try:
-        one = GraphedTrainStep(model, opt, xx, yy, msk, T_bundle=T_bundle, noise_scale=noise_scale, warmup=1, reducer=reducer,
-                               capture_collectives=True)
+        one = GraphedTrainStep(model, opt, xx, yy, msk, T_bundle=T_bundle, noise_scale=noise_scale, warmup=max(1, warmup),
+                               reducer=reducer, capture_collectives=True)
     except Exception as e:                                    # an RCCL build / driver that cannot capture its collectives
         err = f"{type(e).__name__}: {e}"[:160]
         _end_stray_captures([torch.cuda.current_stream(), reducer.stream])
@@ -650,18 +656,20 @@ def make_dp_step(model: nn.Module, opt: FusedAdam, reducer, xx: Tensor, yy: Tens
     if multi:
         dist.all_reduce(ok, op=dist.ReduceOp.MIN, group=reducer.pg)
     if int(ok.item()) == 0:
-        reducer.skip_zero_tail = tail_flag
         del one
-        info = {"mode": "segmented", "why": "one-graph capture failed" + (f" here ({err})" if err else " on another rank")}
-        return seg, info
+        return chain("one-graph capture failed" + (f" here ({err})" if err else " on another rank"))
     snap = opt.snapshot()
     rng = ops.rng_state(xx.device).clone()
     grads = []
-    for step in (seg, one):
+    for mode in ("eager", "graph"):
         opt.restore(snap)
         ops.rng_state(xx.device).copy_(rng)
-        reducer.skip_zero_tail = tail_flag if step is seg else False
-        step.replay(opt.lr)
+        reducer.skip_zero_tail = False                        # (as the capture: the cls_head tail is always reduced)
+        if mode == "eager":
+            train_step(model, opt, one.xx, one.yy, one.msk, T_bundle=T_bundle, noise_scale=noise_scale, lr=opt.lr,
+                       reducer=reducer, grad_scale=reducer.grad_scale)
+        else:
+            one.replay(opt.lr)
         torch.cuda.synchronize()
         grads.append(opt.fp.grad[:opt.n_active].clone())
     opt.restore(snap)
@@ -669,20 +677,16 @@ def make_dp_step(model: nn.Module, opt: FusedAdam, reducer, xx: Tensor, yy: Tens
     same_modes = bool(torch.equal(grads[0], grads[1]))
     cs = _grad_checksum(grads[1])
     verdict = torch.tensor([1 if same_modes else 0], device=xx.device, dtype=torch.int64)
+    same_ranks = True
     if multi:
         lo, hi = cs.clone(), cs.clone()
         dist.all_reduce(lo, op=dist.ReduceOp.MIN, group=reducer.pg)
         dist.all_reduce(hi, op=dist.ReduceOp.MAX, group=reducer.pg)
         same_ranks = bool(torch.equal(lo, hi))
         dist.all_reduce(verdict, op=dist.ReduceOp.MIN, group=reducer.pg)
-    else:
-        same_ranks = True
     if int(verdict.item()) == 1 and same_ranks:
-        del seg
-        return one, {"mode": "one-graph", "why": "reduced gradient of a trial step bit-identical to the segmented chain's and "
-                                                  "across the ranks"}
-    reducer.skip_zero_tail = tail_flag
+        return one, {"mode": "one-graph", "why": "reduced gradient of a trial step bit-identical to the eager hook-driven step's "
+                                                  "and across the ranks"}
     del one
-    return seg, {"mode": "segmented", "why": "one-graph trial step " + ("differs from the segmented chain's gradient"
-                                                                         if int(verdict.item()) == 0 else
-                                                                         "gave different gradients on different ranks")}
+    return chain("one-graph trial step " + ("differs from the eager step's gradient" if int(verdict.item()) == 0 else
+                                            "gave different gradients on different ranks"))

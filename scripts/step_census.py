@@ -1,5 +1,5 @@
 #!/usr/bin/env python
-"""census of one train step from a rocpd database: per-kernel launches / time between two adam_kernel dispatches"""
+"""census of one train step from a rocpd database: per-kernel launches / time between two optimiser steps"""
 import re
 import sqlite3
 import sys
@@ -12,7 +12,8 @@ kd = [t for t in tabs if t.startswith("rocpd_kernel_dispatch")][0]
 ks = [t for t in tabs if t.startswith("rocpd_info_kernel_symbol")][0]
 rows = cur.execute(f"select s.kernel_name, d.start, d.end, d.grid_size_x, d.grid_size_y, d.grid_size_z, d.workgroup_size_x "
                    f"from {kd} d join {ks} s on d.kernel_id = s.id order by d.start").fetchall()
-idx = [i for i, r in enumerate(rows) if "adam_kernel" in r[0]]
+# the LAST launch of an optimiser step: adam_kernel, or - Adam that writes the bf16 weight packs - adam_ranges_kernel
+idx = [i for i, r in enumerate(rows) if "adam_kernel" in r[0] or "adam_ranges_kernel" in r[0]]
 a, b = idx[-3], idx[-2]
 step = rows[a + 1:b + 1]
 c = collections.defaultdict(lambda: [0, 0.0])
