@@ -97,6 +97,10 @@ SIGNATURES = {
     "dpot_afno_mlp2_supported": (c_i, [c_i, c_i]),
     "dpot_afno_mlp2": (c_i, [c_fp] * 9 + [c_i] * 8 + [c_fp]),
     "dpot_afno_mlp3_supported": (c_i, [c_i, c_i]),
+    "dpot_afno_mlp6_supported": (c_i, [c_i, c_i]),
+    "dpot_afno_pack6_elems": (c_i64, [c_i, c_i]),
+    "dpot_afno_pack6": (c_i, [c_fp] * 3 + [c_i] * 3 + [c_fp]),
+    "dpot_afno_mlp6": (c_i, [c_fp] * 9 + [c_i] * 7 + [c_fp]),
     "dpot_afno_block_weights": (c_i, [c_fp] * 3 + [c_i, c_i, c_fp]),
     "dpot_afno_pack_all": (c_i, [c_fp, c_i, c_i, c_i, c_i, c_fp]),
     "dpot_groupnorm_ws_elems": (c_i64, [c_i] * 4),

@@ -12,7 +12,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libdpot_hip.so")
-SOURCES = ["core.hip", "gemm.hip", "gemm_panel.hip", "gemm_tn.hip", "gemm_bf16p.hip", "afno_mlp.hip", "afno_fused.hip", "dft.hip", "norm.hip", "gn_dft.hip", "misc.hip", "loss_opt.hip", "tail.hip", "data.hip", "embed.hip"]
+SOURCES = ["core.hip", "gemm.hip", "gemm_panel.hip", "gemm_tn.hip", "gemm_bf16p.hip", "afno_mlp.hip", "afno_mlp6.hip", "afno_fused.hip", "dft.hip", "norm.hip", "gn_dft.hip", "misc.hip", "loss_opt.hip", "tail.hip", "data.hip", "embed.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function",
          "-Wno-pass-failed"]
 

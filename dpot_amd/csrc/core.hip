@@ -41,6 +41,6 @@ int tune(const char* key, int dflt) {
 /* 0.2.6: round 6 ABI - dpot_adam_step_packs (Adam that writes the bf16 weight packs); dpot_gemm_bf16p_pair back to its 0.2.0
  * argument list (the row-form operand / transposed-output arguments of 0.2.5 are gone with the kernels they selected);
  * dpot_afno_fused_bwd removed; every fallback selector behind DPOT_TUNE */
-extern "C" int dpot_version(void) { return 260; }
+extern "C" int dpot_version(void) { return 261; }
 extern "C" int dpot_tune(const char* key, int dflt) { return dpot::tune(key, dflt); }
 extern "C" const char* dpot_last_error(void) { return dpot::g_err; }

@@ -302,6 +302,15 @@ def _mlp_panel_mode(mlp_pk, M, E, mh, mp) -> int:
     return 2 if ok else 0
 
 
+def _p6_of(packed, which: int):
+    """the bf16x6 mixer packs (csrc/afno_mlp6.hip) of a filter's two AfnoItems - which = 0: forward operands, 1: backward-data
+    operands - when the GEMM precision in effect asks for them ('auto' / 'bf16x6'), else None"""
+    a, b = getattr(packed[0], "p6", None), getattr(packed[1], "p6", None)
+    if a is None or b is None or a[which] is None or b[which] is None or not ops.afno_mlp6_wanted():
+        return None
+    return a[which], b[which]
+
+
 def _mixer_core(S, packed, dims, afno_layout=None):
     """the block-diagonal complex 2-layer MLP on the kept modes (models/dpot.py:72-94): spectrum S [Mm, 2E] ->
     (O2, O1pre, O1)"""
@@ -314,6 +323,9 @@ def _mixer_core(S, packed, dims, afno_layout=None):
         # except as the copy saved for the backward (csrc/afno_mlp.hip)
         # (layout 1: the (Wr, Wi) fragment packs of the three-product kernel; ops.AfnoItem carries the tag)
         lay = afno_layout if afno_layout is not None else getattr(packed[0], "layout", 0)
+        p6 = _p6_of(packed, 0)
+        if p6 is not None:       # fp32-accurate on the bf16 matrix cores (gemm_precision 'auto' / 'bf16x6'): same contract
+            wb1T, wb2T, lay = p6[0], p6[1], 2
         # only the pre-activation is saved: the activated layer-1 output (operand of the layer-2 weight gradient) is
         # re-derived by the backward launch from it (O1 = None here; one spectrum-sized store and 18.9 MB per block less)
         O2, O1pre, O1 = ops.afno_mlp2(S, wb1T, bb1, wb2T, bb2, nb, bs, act, mode=0, want_pre=True, want_mid=False,
@@ -426,6 +438,7 @@ class AFNO2DFn(torch.autograd.Function):
         ctx.fused = packed[0][2] is not None
         wb1, wb2 = (packed[0][3], packed[1][3]) if ctx.fused else (packed[0][0], packed[1][0])
         ctx.afno_layout = getattr(packed[0], "layout", 0) if ctx.fused else 0
+        ctx.p6b = _p6_of(packed, 1) if ctx.fused else None     # persistent buffers of the pack object (epoch-checked)
         ctx.save_for_backward(S, O1pre, O1, wb1, wb2)
         ctx.dims = dims
         ctx.sinks = _sinks(ctx, (w1, b1, w2, b2), 1)
@@ -437,8 +450,10 @@ class AFNO2DFn(torch.autograd.Function):
     def backward(ctx, dy):
         _check_epoch(ctx, "AFNO2DFn")
         S, O1pre, O1, wb1, wb2 = ctx.saved_tensors
-        dx, dw1, db1, dw2, db2 = _mixer_bwd(dy.contiguous(), S, O1pre, O1, wb1, wb2, ctx.dims, ctx.fused,
-                                            ctx.afno_layout, ctx.sinks)
+        lay = ctx.afno_layout
+        if ctx.p6b is not None:
+            (wb1, wb2), lay = ctx.p6b, 2
+        dx, dw1, db1, dw2, db2 = _mixer_bwd(dy.contiguous(), S, O1pre, O1, wb1, wb2, ctx.dims, ctx.fused, lay, ctx.sinks)
         return dx, dw1, db1, dw2, db2, None, None, None, None, None, None
 
 
@@ -604,6 +619,9 @@ class BlockFn(torch.autograd.Function):
         ctx.emit_grad_packs = emit_grad_packs     # a Block precedes this one: its bf16 channel-MLP backward wants dx packed
         ctx.dims = dims
         ctx.afno_layout = getattr(packed[0], "layout", 0) if ctx.fused_mixer else 0
+        # bf16x6 mixer packs (persistent buffers of the model's AfnoPacks, epoch-checked like every derived weight)
+        ctx.p6f = _p6_of(packed, 0) if ctx.fused_mixer else None
+        ctx.p6b = _p6_of(packed, 1) if ctx.fused_mixer else None
         ctx.mlp_precision = ops.effective_mlp_precision()    # a concrete code: the backward reproduces the forward's mode
         ctx.gemm_precision = ops._cur_gemm()
         ctx.sinks = _sinks(ctx, (n1w, n1b, w1, b1, w2, b2, n2w, n2b, f1w, f1b, f2w, f2b), 1)
@@ -623,16 +641,21 @@ class BlockFn(torch.autograd.Function):
         if ctx.recompute:
             x, wb1, bb1, wb2, bb2, n1w, n1b, n2w, n2b, f1w, f1b, f2w, *wts = ctx.saved_tensors
             wb1T, wb2T = wts if ctx.fused_mixer else (None, None)
+            p6f = ctx.p6f if ctx.p6f is not None else (None, None)
             with torch.no_grad():
                 _, parts = _block_parts(x, n1w, n1b, n2w, n2b, f1w, f1b,
-                                        ((wb1, bb1, wb1T, None), (wb2, bb2, wb2T, None)), ctx.dims, mp, False,
-                                        mlp_pk=ctx.mlp_pk, afno_layout=ctx.afno_layout)
+                                        (ops.AfnoItem((wb1, bb1, wb1T, None), ctx.afno_layout, (p6f[0], None)),
+                                         ops.AfnoItem((wb2, bb2, wb2T, None), ctx.afno_layout, (p6f[1], None))),
+                                        ctx.dims, mp, False, mlp_pk=ctx.mlp_pk, afno_layout=ctx.afno_layout)
             mean1, rstd1, S, O1pre, O1, y1, mean2, rstd2, xn2, Hpre, Hh = parts
         else:
             (x, mean1, rstd1, S, O1pre, O1, y1, mean2, rstd2, xn2, Hpre, Hh, wb1, wb2, n1w, n2w, f1w,
              f2w) = ctx.saved_tensors
         B, tok, E, h, w, nb, bs, mx, my, mh, act = ctx.dims
         s_n1w, s_n1b, s_w1, s_b1, s_w2, s_b2, s_n2w, s_n2b, s_f1w, s_f1b, s_f2w, s_f2b = ctx.sinks
+        afno_lay = ctx.afno_layout
+        if ctx.p6b is not None:      # the mixer's data gradient on the bf16 matrix cores (bf16x6), csrc/afno_mlp6.hip
+            (wb1, wb2), afno_lay = ctx.p6b, 2
         M, Mm = B * tok, B * mx * my
         dev = dout.device
         dout = dout.contiguous()
@@ -727,7 +750,7 @@ class BlockFn(torch.autograd.Function):
             dy1, gn2_part, dO2 = ops.gn_bwd_rfft2(dxn2.view(B, tok, E), y1, mean2, rstd2, n2w, h, w, nb, mx, my,
                                                   col_weights=1)
             dS, dw1, db1, dw2, db2 = _mixer_core_bwd(dO2, S, O1pre, O1, wb1, wb2, ctx.dims, ctx.fused_mixer,
-                                                     ctx.afno_layout, (s_w1, s_b1, s_w2, s_b2), pending)
+                                                     afno_lay, (s_w1, s_b1, s_w2, s_b2), pending)
             if E // 8 <= 64:
                 dx, gn1_part = ops.irfft2_gn_bwd(dS, dy1, x, mean1, rstd1, n1w, h, w, nb, mx, my, add=dout,
                                                  col_weights=0)
@@ -746,7 +769,7 @@ class BlockFn(torch.autograd.Function):
             dy1, gn2_part = ops.groupnorm_bwd(dxn2.view(B, tok, E), y1, mean2, rstd2, n2w, defer=True)
             # AFNO mixer
             dxn1, dw1, db1, dw2, db2 = _mixer_bwd(dy1, S, O1pre, O1, wb1, wb2, ctx.dims, ctx.fused_mixer,
-                                                  ctx.afno_layout, (s_w1, s_b1, s_w2, s_b2), pending)
+                                                  afno_lay, (s_w1, s_b1, s_w2, s_b2), pending)
             # (DPOT-L: the CHUNKED GroupNorm backward could write the gradient's packs too - see the 128-channel branch above - but
             # there the staging + two barriers per 32-token sub-tile cost what the saved pack pass did: DPOT-L 91.2 -> 90.9 ms,
             # L20 2.185 -> 2.211 s, profiles/r05_grad_packs_step_ab_L.txt; the opt-in of round 5 is gone)

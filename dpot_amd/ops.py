@@ -166,6 +166,8 @@ TUNE_KEYS = {
     "pack_both": (1, "0 = bf16 channel MLP without the pack-both path (one pack pass per operand form, fp32 pre-activation saved)"),
     "fused_small": (1, "0 = separate small launches: per-block reduce launches, eight layout launches, torch ops for the cls head"),
     "embed_implicit": (1, "0 = explicit patch matrix + GEMM instead of the implicit-GEMM patch embedding"),
+    "mixer6": (1, "bf16x6 mixer kernel afno_mlp6 under gemm_precision 'auto' / 'bf16x6': 1 = where it measured faster (96 channels "
+                  "per block: DPOT-L), 2 = wherever supported (also 128), 0 = never (the fp32 matrix-core kernels)"),
 }
 
 
@@ -667,9 +669,10 @@ class AfnoItem(tuple):
     """(Wbig, bbig, fwd pack | None, bwd pack | None) of one AFNO layer + the layout of the packs (0: fragment-block-major
     Wbig for afno_mlp2's four-product kernel, 1: (Wr, Wi) fragments for the three-product kernel)"""
 
-    def __new__(cls, items, layout: int = 0):
+    def __new__(cls, items, layout: int = 0, p6=None):
         self = super().__new__(cls, items)
         self.layout = layout
+        self.p6 = p6          # (fwd6, bwd6): the bf16x6 packs of csrc/afno_mlp6.hip (layout 2 of afno_mlp2), or None
         return self
 
 
@@ -700,12 +703,24 @@ class AfnoPacks:
             tab[i].fwd = fwd[i].data_ptr() if fused else None
             tab[i].bwd = bwd[i].data_ptr() if fused else None
         self.table = torch.from_numpy(host).to(dev)
-        self.items = [AfnoItem((wbig[i], bbig[i], fwd[i] if fused else None, bwd[i] if fused else None), self.layout)
+        # bf16x6 packs (csrc/afno_mlp6.hip): items alternate (first-layer weight, second-layer weight) - pairs of a filter
+        self.wbig = wbig
+        self.fwd6 = self.bwd6 = None
+        if fused and n % 2 == 0 and afno_mlp6_supported(nb, bs):
+            ne = int(_lib.load().dpot_afno_pack6_elems(nb, bs))
+            self.fwd6 = torch.empty(n, ne, dtype=torch.int16, device=dev)
+            self.bwd6 = torch.empty(n, ne, dtype=torch.int16, device=dev)
+        self.items = [AfnoItem((wbig[i], bbig[i], fwd[i] if fused else None, bwd[i] if fused else None), self.layout,
+                               (self.fwd6[i], self.bwd6[i]) if self.fwd6 is not None else None)
                       for i in range(n)]
 
     def refresh(self):
-        check(_lib.load().dpot_afno_pack_all(self.table.data_ptr(), self.n, self.nb, self.bs, self.layout, _stream()),
+        lib = _lib.load()
+        check(lib.dpot_afno_pack_all(self.table.data_ptr(), self.n, self.nb, self.bs, self.layout, _stream()),
               "afno_pack_all")
+        if self.fwd6 is not None and afno_mlp6_wanted():
+            check(lib.dpot_afno_pack6(self.wbig.data_ptr(), self.fwd6.data_ptr(), self.bwd6.data_ptr(), self.n, self.nb,
+                                      self.bs, _stream()), "afno_pack6")
         return self.items
 
 
@@ -801,6 +816,17 @@ def afno_mlp3_supported(nb: int, bs: int) -> bool:
     return bool(_lib.load().dpot_afno_mlp3_supported(nb, bs)) and tune("mixer") == 3
 
 
+def afno_mlp6_supported(nb: int, bs: int) -> bool:
+    """the bf16x6 (fp32-accurate, bf16 matrix cores) form of the fused mixer kernel, csrc/afno_mlp6.hip: bs in {96, 128}"""
+    return bool(_lib.load().dpot_afno_mlp6_supported(nb, bs)) and tune("mixer") != 0 and (tune("mixer6") == 2 or (tune("mixer6") == 1 and bs == 96))
+
+
+def afno_mlp6_wanted() -> bool:
+    """the mixer follows the GEMM precision in effect: 'auto' / 'bf16x6' -> the bf16x6 kernel (both are fp32-accurate, the
+    choice is speed); 'f32' -> the native fp32 matrix-core kernels"""
+    return _cur_gemm() in (GEMM_AUTO, GEMM_BF16X6)
+
+
 def afno_mlp2(X: Tensor, WaT: Tensor, ba: Optional[Tensor], WbT: Tensor, bb: Optional[Tensor], nb: int, bs: int,
               act: int, mode: int = 0, aux: Optional[Tensor] = None, want_pre: bool = False, want_mid: bool = False,
               layout: int = 0):
@@ -813,6 +839,10 @@ def afno_mlp2(X: Tensor, WaT: Tensor, ba: Optional[Tensor], WbT: Tensor, bb: Opt
     Y = torch.empty_like(X)
     pre = torch.empty_like(X) if want_pre else None
     mid = torch.empty_like(X) if want_mid else None
+    if layout == 2:      # WaT / WbT: the bf16x6 packs of AfnoPacks (item.p6), csrc/afno_mlp6.hip
+        check(_lib.load().dpot_afno_mlp6(X.data_ptr(), WaT.data_ptr(), _p(ba), WbT.data_ptr(), _p(bb), _p(aux), _p(pre),
+                                         _p(mid), Y.data_ptr(), M, nb, bs, ld, ld, act, mode, _stream()), "afno_mlp6")
+        return Y, pre, mid
     check(_lib.load().dpot_afno_mlp2(X.data_ptr(), WaT.data_ptr(), _p(ba), WbT.data_ptr(), _p(bb), _p(aux), _p(pre),
                                      _p(mid), Y.data_ptr(), M, nb, bs, ld, ld, act, mode, layout, _stream()),
           "afno_mlp2")

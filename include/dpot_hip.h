@@ -466,6 +466,22 @@ int dpot_afno_mlp3_supported(int nb, int bs);
 int dpot_afno_mlp2(const float* X, const float* Wa, const float* ba, const float* Wb, const float* bb,
                    const float* aux, float* pre, float* mid, float* Y, int M, int nb, int bs, int ldx, int ldo,
                    int act, int mode, int layout, dpot_stream_t stream);
+/* The same two-layer mixer MLP on the BF16 matrix cores at fp32 accuracy (csrc/afno_mlp6.hip, "bf16x6": every operand split
+ * into three bf16 planes, the six plane products of weight >= 2^-16 accumulated in fp32 on v_mfma_f32_32x32x16_bf16; results
+ * agree with dpot_afno_mlp2 to fp32 rounding - same tests, same tolerance).  Arguments, modes and outputs exactly as
+ * dpot_afno_mlp2; Wa6 / Wb6 are the packs dpot_afno_pack6 writes ([nb] matrices of dpot_afno_pack6_elems(1, bs) bf16 each):
+ * mode 0: (fwd6 of the first-layer weight, fwd6 of the second-layer weight); mode 1: (bwd6 of the SECOND-layer weight, bwd6 of
+ * the FIRST-layer weight).  bs in {96, 128} (dpot_afno_mlp6_supported).  This is what DPOTNet.gemm_precision 'auto' / 'bf16x6'
+ * selects for the mixer (models/dpot.py:72-94). */
+int dpot_afno_mlp6_supported(int nb, int bs);
+int64_t dpot_afno_pack6_elems(int nb, int bs);                    /* bf16 elements of one pack of nb matrices */
+/* wbig [nitems][nb][N][N] (W[k][n], what dpot_afno_pack_all leaves; items alternate first-layer weight, second-layer weight)
+ * -> fwd6 / bwd6 [nitems][nb][...] (either may be NULL): the forward operand (W) and the backward-data operand (W^T) of each
+ * matrix in the fragment order of the layer it is used in, three bf16 planes */
+int dpot_afno_pack6(const float* wbig, void* fwd6, void* bwd6, int nitems, int nb, int bs, dpot_stream_t stream);
+int dpot_afno_mlp6(const float* X, const void* Wa6, const float* ba, const void* Wb6, const float* bb, const float* aux,
+                   float* pre, float* mid, float* Y, int M, int nb, int bs, int ldx, int ldo, int act, int mode,
+                   dpot_stream_t stream);
 /* wbig [nmat][N][N] (row-major W[k][n]) -> [nmat][N/16][N/16][256] blocks of (16 n x 16 k), chunk l of a block =
  * (n = l&15, k = 4*(l>>4)..+3): fwd holds W (for X W), bwd holds W^T (for X W^T).  Either output may be NULL. */
 int dpot_afno_block_weights(const float* wbig, float* fwd, float* bwd, int nmat, int N, dpot_stream_t stream);

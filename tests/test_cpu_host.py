@@ -229,7 +229,7 @@ def test_dpot_tune_switchboard(built_lib, monkeypatch):
     from dpot_amd import ops
     monkeypatch.delenv("DPOT_TUNE", raising=False)
     assert all(ops.tune(k) == d for k, (d, _) in ops.TUNE_KEYS.items())
-    assert len(ops.TUNE_KEYS) <= 11
+    assert len(ops.TUNE_KEYS) <= 12
     monkeypatch.setenv("DPOT_TUNE", "mixer=4, afno_layer=1,packs=0")
     assert (ops.tune("mixer"), ops.tune("afno_layer"), ops.tune("packs"), ops.tune("panel")) == (4, 1, 0, 1)
     monkeypatch.setenv("DPOT_TUNE", "no_such_key=1")

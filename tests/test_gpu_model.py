@@ -52,6 +52,22 @@ def test_afno_mixer_golden_one_launch_layer(monkeypatch):
     assert calls, "the one-launch kernel did not run"
 
 
+def test_afno_mixer_golden_bf16x6_kernel(monkeypatch):
+    """round 6: the same reference golden (g1_afno_tiny, 128 channels per block) through the bf16x6 mixer kernel
+    (csrc/afno_mlp6.hip) that gemm_precision 'auto' selects at 96 channels per block and DPOT_TUNE mixer6=2 everywhere:
+    forward through the three-launch form, backward through its data-gradient form - same tolerance (fp32-accurate)"""
+    from dpot_amd import ops
+    set_tune(monkeypatch, mixer6=2, afno_layer=0)
+    if not ops.afno_mlp6_supported(4, 128):
+        pytest.skip("bf16x6 mixer switched off (DPOT_TUNE mixer = 0)")
+    calls = []
+    real = ops.afno_mlp2
+    monkeypatch.setattr(ops, "afno_mlp2", lambda *a, **k: (calls.append(k.get("layout")), real(*a, **k))[1])
+    with ops.precision_scope("auto", None):
+        test_afno_mixer_golden("g1_afno_tiny")
+    assert calls and all(l == 2 for l in calls), calls
+
+
 @pytest.mark.parametrize("name", ["g1_afno_trunc", "g1_afno_tiny"])
 def test_afno_mixer_golden(name):
     """AFNO2D alone (golden g1, written by the imported reference's AFNO2D module): the PRODUCT mixer -

@@ -952,6 +952,65 @@ def test_afno_mlp3_three_product_form(ops, nb, bs, M, act):
     assert_close(o1, f(pre_ref.float().double()), "act(aux) re-derived by the backward launch")     # == the forward's mid
 
 
+@pytest.mark.parametrize("nb,bs,M,act", [(4, 128, 4608, "gelu"), (2, 128, 333, "gelu"), (8, 128, 100, "relu"),
+                                         (1, 128, 16, "gelu"), (16, 96, 2176, "gelu"), (3, 96, 50, "gelu"),
+                                         (16, 96, 8704 - 37, "gelu"), (5, 96, 129, "tanh")])
+def test_afno_mlp6_bf16x6_form(ops, monkeypatch, nb, bs, M, act):
+    """round 6: the fused complex MLP on the BF16 matrix cores at fp32 accuracy (csrc/afno_mlp6.hip: every operand split into
+    three bf16 planes, six plane products, the hidden layer stays in registers in the transposed accumulator layout): forward
+    (pre, mid, Y) and backward data path against float64 complex arithmetic at the SAME tolerance as the fp32 kernels, and
+    against the three-product fp32 kernel; ragged row tiles; packs written by AfnoPacks under gemm_precision 'auto'"""
+    set_tune(monkeypatch, mixer6=2)
+    N = 2 * bs
+    assert ops.afno_mlp6_supported(nb, bs)
+    w1, w2 = rnd(2, nb, bs, bs, seed=2, scale=1.0 / math.sqrt(N)), rnd(2, nb, bs, bs, seed=3, scale=1.0 / math.sqrt(N))
+    b1, b2 = rnd(2, nb, bs, seed=4, scale=0.3), rnd(2, nb, bs, seed=5, scale=0.3)
+    X = rnd(M, nb * N, seed=1)
+    with ops.precision_scope("auto", None):
+        packs = ops.AfnoPacks([(w1.cuda(), b1.cuda()), (w2.cuda(), b2.cuda())])
+        it1, it2 = packs.refresh()
+    assert it1.p6 is not None and it2.p6 is not None
+    (wb1, bb1, f1, bw1), (wb2, bb2, f2, bw2) = it1, it2
+    f = ACTS[act]
+    Xc = torch.complex(X.double().view(M, nb, 2, bs)[:, :, 0], X.double().view(M, nb, 2, bs)[:, :, 1])   # [M, nb, bs]
+    W1c, W2c = torch.complex(w1[0].double(), w1[1].double()), torch.complex(w2[0].double(), w2[1].double())
+    B1c, B2c = torch.complex(b1[0].double(), b1[1].double()), torch.complex(b2[0].double(), b2[1].double())
+    pre_c = torch.einsum("mki,kio->mko", Xc, W1c) + B1c
+    planar = lambda z: torch.stack([z.real, z.imag], dim=2).reshape(M, -1)      # [M, nb, 2, bs] -> [M, nb*2*bs]
+    pre_ref = planar(pre_c)
+    mid_ref = f(pre_ref)
+    midc = torch.complex(mid_ref.view(M, nb, 2, bs)[:, :, 0], mid_ref.view(M, nb, 2, bs)[:, :, 1])
+    Y_ref = planar(torch.einsum("mki,kio->mko", midc, W2c) + B2c)
+    Y, pre, mid = ops.afno_mlp2(X.cuda(), it1.p6[0], bb1, it2.p6[0], bb2, nb, bs, ops.ACT_IDS[act], mode=0, want_pre=True,
+                                want_mid=True, layout=2)
+    assert_close(pre, pre_ref, "pre")
+    assert_close(mid, mid_ref, "mid")
+    assert_close(Y, Y_ref, "Y")
+    # inference form (nothing but Y stored) gives the same Y
+    Yi, _, _ = ops.afno_mlp2(X.cuda(), it1.p6[0], bb1, it2.p6[0], bb2, nb, bs, ops.ACT_IDS[act], mode=0, layout=2)
+    assert torch.equal(Yi, Y)
+    # against the fp32 three-product kernel on the same weights
+    Y3, _, _ = ops.afno_mlp2(X.cuda(), f1, bb1, f2, bb2, nb, bs, ops.ACT_IDS[act], mode=0, layout=1)
+    assert_close(Y, Y3.double(), "Y vs the fp32 kernel", rtol=2e-5, atol_scale=2e-5)
+    # no worse than the fp32 kernel against float64 (both ~3e-7 norm-wise)
+    e6 = (Y.double().cpu() - Y_ref).norm() / Y_ref.norm()
+    e3 = (Y3.double().cpu() - Y_ref).norm() / Y_ref.norm()
+    assert e6 <= 2.0 * e3 + 1e-7, (float(e6), float(e3))
+    # backward data path
+    dO2 = rnd(M, nb * N, seed=6)
+    pr = pre_ref.clone().requires_grad_(True)
+    (f(pr)).backward(torch.ones_like(pr))
+    dact = pr.grad
+    Wbig1, Wbig2 = wb1.cpu().double(), wb2.cpu().double()                       # [nb, N, N], W[k][n]
+    dmid_ref = torch.einsum("mko,kno->mkn", dO2.double().view(M, nb, N), Wbig2) * dact.view(M, nb, N)
+    dS_ref = torch.einsum("mko,kno->mkn", dmid_ref, Wbig1)
+    dS, o1, dmid = ops.afno_mlp2(dO2.cuda(), it2.p6[1], None, it1.p6[1], None, nb, bs, ops.ACT_IDS[act], mode=1,
+                                 aux=pre_ref.float().contiguous().cuda(), want_mid=True, want_pre=True, layout=2)
+    assert_close(dmid, dmid_ref.reshape(M, -1), "dO1pre")
+    assert_close(dS, dS_ref.reshape(M, -1), "dS")
+    assert_close(o1, f(pre_ref.float().double()), "act(aux) re-derived by the backward launch")     # == the forward's mid
+
+
 @pytest.mark.parametrize("nb,bs,Mm", [(4, 128, 4608), (2, 64, 32 * 13), (8, 128, 32 * 9),
                                       # round 3: bs = 96 (DPOT-Large, N = 192) on the 192 x 192-tile kernel
                                       (16, 96, 2176), (3, 96, 32 * 5), (16, 96, 32)])
