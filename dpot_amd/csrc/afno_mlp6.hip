@@ -75,6 +75,21 @@ __device__ __forceinline__ void split3(const float* v, bf16x8_t& a, bf16x8_t& b,
 
 // the six plane products of one 32 x 32 x 16 step, smallest terms first
 __device__ __forceinline__ void mma6(f32x16& acc, const bf16x8_t* w, const bf16x8_t* x) {
+#ifdef M6_SPLITACC
+  // (experiment: two independent accumulation chains per tile job)
+  f32x16 t;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) t[r] = 0.f;
+  t = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w[0], x[2], t, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w[0], x[0], acc, 0, 0, 0);
+  t = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w[2], x[0], t, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w[0], x[1], acc, 0, 0, 0);
+  t = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w[1], x[1], t, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w[1], x[0], acc, 0, 0, 0);
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] += t[r];
+  return;
+#endif
 #ifdef M6_ABL_NOMFMA
   acc[0] += __builtin_bit_cast(u32x4_t, w[0])[0] * 1e-30f + __builtin_bit_cast(u32x4_t, w[1])[0] * 1e-30f +
             __builtin_bit_cast(u32x4_t, w[2])[0] * 1e-30f + __builtin_bit_cast(u32x4_t, x[0])[0] * 1e-30f +
@@ -158,19 +173,63 @@ __device__ __forceinline__ void stage_store(float* stg, const float* v, float* r
 
 constexpr int M6_RING = 3;
 
+// one PAIR of values -> one dword of each of the three planes (the unit of split work that goes into an MFMA shadow)
+__device__ __forceinline__ void split_pair(float x0, float x1, unsigned& a, unsigned& b, unsigned& c) {
+  a = pack2(x0, x1);
+  x0 -= bf_lo(a);
+  x1 -= bf_hi(a);
+  b = pack2(x0, x1);
+  x0 -= bf_lo(b);
+  x1 -= bf_hi(b);
+  c = pack2(x0, x1);
+}
+struct Planes {           // 8 k-values of one lane as three bf16 planes, built one dword (pair) at a time
+  u32x4_t u[3];
+};
+__device__ __forceinline__ void planes_set(Planes& q, int k, float x0, float x1) {
+  unsigned a, b, c;
+  split_pair(x0, x1, a, b, c);
+  q.u[0][k] = a; q.u[1][k] = b; q.u[2][k] = c;
+}
+
+// the six plane products of tile job (fragments w, planes x) with the FILLER work of this job interleaved into the MFMA
+// shadows: one MFMA, then up to three VALU instructions (the split of the NEXT sub-slab's operand) and, once, the LDS-DMA
+// piece of a later ring step - left at the head of the step these serialise with the MFMAs (a wave issues in order)
+__device__ __forceinline__ void mma6p(f32x16& acc, const bf16x8_t* w, const Planes& xq) {
+  bf16x8_t x[3] = {__builtin_bit_cast(bf16x8_t, xq.u[0]), __builtin_bit_cast(bf16x8_t, xq.u[1]),
+                   __builtin_bit_cast(bf16x8_t, xq.u[2])};
+  mma6(acc, w, x);
+}
+__device__ __forceinline__ void interleave6() {
+  __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // MFMA
+  __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);   // the DMA piece (VMEM)
+  __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);   // VALU
+#pragma unroll
+  for (int k = 0; k < 5; ++k) {
+    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+    __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);
+  }
+}
+
 // NT = N / 32 channel tiles, PASSES = passes of the second layer (NT / PASSES output tiles each), ACTK = compile-time
 // activation (-1: run-time switch), WPE = waves per SIMD the register budget is cut for, MODE = 0 forward / 1 backward data
+//
+// Ring steps: 2 Q of them (Q = N / 16), each NT tile jobs = 6 NT MFMAs per wave behind one barrier, each fed by NT x 3 KiB of
+// fragments in a ring slot: first layer - step i = sub-slab i, all NT tiles; second layer - step Q + r = the PASSES
+// consecutive sub-slabs r PASSES .. of the job sequence s = pass Q + q, NT / PASSES tiles each.
 template <int NT, int PASSES, int ACTK, int WPE, int MODE>
 __global__ __launch_bounds__(256, WPE) void afno_mlp6_kernel(const AfnoMlp6Args p) {
   constexpr int N = 32 * NT;
   constexpr int Q = 2 * NT;                       // 16-k sub-slabs per layer
   constexpr int NS = NT;                          // 32-k super-slabs of the first layer
   constexpr int TP = NT / PASSES;                 // output tiles per pass of the second layer
-  constexpr int SLABB = NT * 3 * 1024;            // bytes of one sub-slab of fragments (all tiles)
-  constexpr int CH1 = NT * 3, CH2 = TP * 3;       // 1 KiB chunks per ring step: first / second layer
-  constexpr int PER1 = (CH1 + 3) / 4, PER2 = (CH2 + 3) / 4;   // DMA instructions per wave and step
-  constexpr int T = Q + PASSES * Q;               // ring steps
-  static_assert(NT % PASSES == 0, "passes must divide the tiles");
+  constexpr int SLABB = NT * 3 * 1024;            // bytes of one ring slot
+  constexpr int CH = NT * 3;                      // 1 KiB chunks per ring step
+  constexpr int PER = (CH + 3) / 4;               // DMA instructions per wave and step
+  constexpr int T = 2 * Q;                        // ring steps
+  constexpr int NJ2 = PASSES * Q;                 // sub-slab jobs of the second layer
+  static_assert(NT % PASSES == 0 && Q % PASSES == 0, "passes must divide the tiles and the sub-slabs");
+  static_assert(PER <= NT, "one DMA piece per tile job");
   __shared__ __attribute__((aligned(16))) unsigned char lds[M6_RING * SLABB];
 
   const int tid = threadIdx.x;
@@ -188,23 +247,28 @@ __global__ __launch_bounds__(256, WPE) void afno_mlp6_kernel(const AfnoMlp6Args 
   const unsigned char* wa = p.Wa + (long long)blk * Q * SLABB;
   const unsigned char* wb = p.Wb + (long long)blk * Q * SLABB;
 
-  // ring step i: its fragments (global source, chunk count)
-  auto dma = [&](const unsigned char* src, int slot, auto NCH) __attribute__((always_inline)) {
-    constexpr int nch = decltype(NCH)::value;
-    constexpr int per = (nch + 3) / 4;
-#pragma unroll
-    for (int n = 0; n < per; ++n) {
+  // DMA piece n (of PER) of ring step i into its slot: chunk c = wave + 4 n (a wave past the end re-copies its last chunk:
+  // uniform instruction count)
+  auto dma_piece = [&](auto II, auto NN) __attribute__((always_inline)) {
+    constexpr int i = decltype(II)::value, n = decltype(NN)::value;
+    if constexpr (i < T && n < PER) {
 #ifdef M6_ABL_DMA1
-      if (n > 0) break;                           // (ablation: one piece per wave and step; results are wrong)
+      if (n > 0) return;
 #endif
       int c = wave + 4 * n;
-      if (c >= nch) c -= 4;                       // uniform instruction count: a wave past the end re-copies its last chunk
-      bglds16(src + c * 1024 + lane * 16, lds + slot * SLABB + c * 1024);
+      if (c >= CH) c -= 4;
+      const unsigned char* src;
+      if constexpr (i < Q) {
+        src = wa + (long long)i * SLABB + c * 1024;
+      } else {
+        // chunk c of the step = job (c / (3 TP)) of the step, chunk (c % (3 TP)) of that job's TP tiles
+        const int jj = c / (3 * TP), within = c - jj * (3 * TP);
+        const int sj = (i - Q) * PASSES + jj;               // job s = pass Q + q
+        const int pass = sj / Q, q = sj - pass * Q;
+        src = wb + (long long)q * SLABB + (pass * TP * 3 + within) * 1024;
+      }
+      bglds16(src + lane * 16, lds + (i % M6_RING) * SLABB + c * 1024);
     }
-  };
-  auto src2 = [&](int i2) __attribute__((always_inline)) {   // second-layer step i2 = pass * Q + q
-    const int pass = i2 / Q, q = i2 - pass * Q;
-    return wb + (long long)q * SLABB + pass * (TP * 3 * 1024);
   };
 
   f32x16 acc1[NT];
@@ -214,60 +278,68 @@ __global__ __launch_bounds__(256, WPE) void afno_mlp6_kernel(const AfnoMlp6Args 
     for (int r = 0; r < 16; ++r) acc1[t][r] = 0.f;
 
   // ---- first layer: acc1^T = Wa^T X^T ------------------------------------------------------------------------------------
+  // X of super-slab S (16 k of this lane's row: k = 32 S + 16 g + 0 .. 15) sits in xbuf[S & 1], loaded two super-slabs ahead;
+  // its planes xq[S & 1][J] (J = the 8-k half = the sub-slab) are split during super-slab S - 1, pair by pair, in the shadows
+  // of that super-slab's MFMAs
   const float4* xp = reinterpret_cast<const float4*>(p.X + (long long)tokc * p.ldx + blk * N) + 4 * g;
-  float4 xn[4];                      // the super-slab fetched ahead (16 k of this lane's row)
-  bf16x8_t xb[2][3];                 // its two 8-k halves as bf16 planes: split right after the counted wait of step J = 0,
-#pragma unroll                       // so that the loaded registers are dead before the next prefetch is issued (no copies)
-  for (int k = 0; k < 4; ++k) xn[k] = xp[k];
-  dma(wa, 0, std::integral_constant<int, CH1>{});
-  dma(wa + SLABB, 1, std::integral_constant<int, CH1>{});
+  float4 xbuf[2][4];
+  Planes xq[2][2];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) xbuf[0][k] = xp[k];
+  if constexpr (NS > 1) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) xbuf[1][k] = xp[8 + k];
+  }
+  sfor6<0, PER>([&](auto NN) __attribute__((always_inline)) { dma_piece(std::integral_constant<int, 0>{}, NN); });
+  sfor6<0, PER>([&](auto NN) __attribute__((always_inline)) { dma_piece(std::integral_constant<int, 1>{}, NN); });
+  {
+    const float* x0 = reinterpret_cast<const float*>(xbuf[0]);
+#pragma unroll
+    for (int J = 0; J < 2; ++J)
+#pragma unroll
+      for (int k = 0; k < 4; ++k) planes_set(xq[0][J], k, x0[8 * J + 2 * k], x0[8 * J + 2 * k + 1]);
+  }
 
-  // one 16-k step of the first layer: ring step i = 2 S + J; XPF = X loads were issued in the previous step (J == 1)
-  auto step1 = [&](int i, int slot, auto JJ, auto LASTS) __attribute__((always_inline)) {
-    constexpr int J = decltype(JJ)::value;
-    constexpr bool LAST = decltype(LASTS)::value;
-    // arrived: the DMA of step i; still in flight: the DMA of step i + 1 (+ the X prefetch issued after it, J == 1)
-    constexpr int NEXT = LAST && J == 1 ? PER2 : PER1;
-    constexpr int VMW = NEXT + (J == 1 && !LAST ? 4 : 0);
+  sfor6<0, Q>([&](auto II) __attribute__((always_inline)) {
+    constexpr int i = decltype(II)::value;
+    constexpr int S = i >> 1, J = i & 1;
+    // arrived: the DMA of step i.  Issued after it: [step i - 1] the X loads of super-slab S' + 2 (J' == 0) and DMA(i + 1)
+    constexpr bool xprev = i >= 1 && ((i - 1) & 1) == 0 && ((i - 1) >> 1) + 2 < NS;
+    constexpr int VMW = PER + (xprev ? 4 : 0);
     asm volatile("" ::: "memory");
     __builtin_amdgcn_s_waitcnt((VMW & 15) | 0x70 | ((VMW >> 4) << 14));   // vmcnt(VMW) lgkmcnt(0)
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
-    int ns = slot + 2;
-    ns = ns >= M6_RING ? ns - M6_RING : ns;
-    if constexpr (J == 0) {
-      // (the X loads are older than the DMA the wait above left in flight: complete, no further wait; the empty asm keeps
-      // the split below the wait - hoisted above it the compiler guards it with vmcnt(0))
+    // (X of super-slab S + 1 - split by this step's fillers - is older than everything the wait left in flight: arrived;
+    // the fillers sit between scheduling barriers below the wait, so no use of it can move above)
+    if constexpr (J == 0 && S + 2 < NS) {
+      // X of super-slab S + 2 into the buffer of super-slab S (free: its planes were split during super-slab S - 1)
 #pragma unroll
-      for (int k = 0; k < 4; ++k) asm volatile("" : "+v"(xn[k].x), "+v"(xn[k].y), "+v"(xn[k].z), "+v"(xn[k].w));
-#pragma unroll
-      for (int hh = 0; hh < 2; ++hh) {
-        const float v[8] = {xn[2 * hh].x, xn[2 * hh].y, xn[2 * hh].z, xn[2 * hh].w,
-                            xn[2 * hh + 1].x, xn[2 * hh + 1].y, xn[2 * hh + 1].z, xn[2 * hh + 1].w};
-        split3(v, xb[hh][0], xb[hh][1], xb[hh][2]);
-      }
-      if constexpr (!LAST) {
-#pragma unroll
-        for (int k = 0; k < 4; ++k) xn[k] = xp[8 * ((i >> 1) + 1) + k];
-      }
+      for (int k = 0; k < 4; ++k) xbuf[S & 1][k] = xp[8 * (S + 2) + k];
     }
-    if constexpr (LAST) dma(src2(i + 2 - Q), ns, std::integral_constant<int, CH2>{});
-    else dma(wa + (long long)(i + 2) * SLABB, ns, std::integral_constant<int, CH1>{});
-    tiles<NT>(lds_base + slot * SLABB, acc1, xb[J]);
-  };
-  int slot = 0;
-#pragma unroll 1
-  for (int S = 0; S < NS - 1; ++S) {
-    step1(2 * S, slot, std::integral_constant<int, 0>{}, std::false_type{});
-    slot = slot + 1 == M6_RING ? 0 : slot + 1;
-    step1(2 * S + 1, slot, std::integral_constant<int, 1>{}, std::false_type{});
-    slot = slot + 1 == M6_RING ? 0 : slot + 1;
-  }
-  step1(2 * (NS - 1), slot, std::integral_constant<int, 0>{}, std::true_type{});
-  slot = slot + 1 == M6_RING ? 0 : slot + 1;
-  step1(2 * (NS - 1) + 1, slot, std::integral_constant<int, 1>{}, std::true_type{});
+    const float* xnext = reinterpret_cast<const float*>(xbuf[(S + 1) & 1]);
+    const unsigned addr = lds_base + (i % M6_RING) * SLABB;
+    bf16x8_t w[2][3];
+    lds_rd3<0>(w[0], addr);
+    sfor6<0, NT>([&](auto MM) __attribute__((always_inline)) {
+      constexpr int m = decltype(MM)::value;
+      if constexpr (m + 1 < NT) {
+        lds_rd3<(m + 1) * 3072>(w[(m + 1) & 1], addr);
+        lds_wait3<3>(w[m & 1]);
+      } else {
+        lds_wait3<0>(w[m & 1]);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      dma_piece(std::integral_constant<int, i + 2>{}, MM);
+      if constexpr (S + 1 < NS && m < 4)          // pair m of half J of the next super-slab
+        planes_set(xq[(S + 1) & 1][J], m, xnext[8 * J + 2 * m], xnext[8 * J + 2 * m + 1]);
+      mma6p(acc1[m], w[m & 1], xq[S & 1][J]);
+      interleave6();
+      __builtin_amdgcn_sched_barrier(0);
+    });
+  });
 
-  // the first two second-layer slabs are in flight; wait for them BEFORE the stores below join the queue (loads complete in
+  // the first two second-layer steps are in flight; wait for them BEFORE the stores below join the queue (loads complete in
   // order among themselves, not with respect to stores)
   asm volatile("" ::: "memory");
   __builtin_amdgcn_s_waitcnt(0x0070);
@@ -281,7 +353,7 @@ __global__ __launch_bounds__(256, WPE) void afno_mlp6_kernel(const AfnoMlp6Args 
 #else
   const bool st_ok = true;
 #endif
-  const bool w_pre = p.pre != nullptr && st_ok, w_mid = p.mid != nullptr && st_ok;   // (wave-uniform: st_ok is valid of row 0)
+  const bool w_pre = p.pre != nullptr && st_ok, w_mid = p.mid != nullptr && st_ok;
   // staged stores: this wave's slab in the ring slot nobody uses right now (the one the last first-layer step read - every
   // wave is past it after the barrier below); global base of the wave's tile rows
   const int row0 = blockIdx.x * 128 + wave * 32;
@@ -340,68 +412,92 @@ __global__ __launch_bounds__(256, WPE) void afno_mlp6_kernel(const AfnoMlp6Args 
     }
   }
 
-  // ---- second layer: acc2^T = Wb^T H^T, PASSES passes of TP output tiles ------------------------------------------------------
-  sfor6<0, PASSES>([&](auto PP) __attribute__((always_inline)) {
-    constexpr int pass = decltype(PP)::value;
-    f32x16 acc2[TP];
+  // ---- second layer: acc2^T = Wb^T H^T --------------------------------------------------------------------------------------
+  // sub-slab jobs s = pass Q + q (TP output tiles each); the planes of job s + 1 - registers 8 j .. 8 j + 7 of hidden tile t,
+  // q = 2 t + j - are split in the MFMA shadows of job s (two plane sets)
+  Planes hq[2];
 #pragma unroll
-    for (int m = 0; m < TP; ++m)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc2[m][r] = 0.f;
-    sfor6<0, Q>([&](auto QQ) __attribute__((always_inline)) {
-      constexpr int q = decltype(QQ)::value;
-      constexpr int i2 = pass * Q + q;            // second-layer step
-      constexpr int i = Q + i2;                   // ring step
-      constexpr int sl = i % M6_RING;
-      constexpr int t = q >> 1, j = q & 1;
-      asm volatile("" ::: "memory");
-      if constexpr (i2 >= 2) {                    // (steps 0 and 1: waited for above)
-        constexpr int VMW = i + 1 < T ? PER2 : 0;
-        __builtin_amdgcn_s_waitcnt((VMW & 15) | 0x70 | ((VMW >> 4) << 14));
-      }
-      __builtin_amdgcn_s_barrier();
-      asm volatile("" ::: "memory");
-      if constexpr (i + 2 < T) dma(src2(i2 + 2), (i + 2) % M6_RING, std::integral_constant<int, CH2>{});
-      float v[8];
-#pragma unroll
-      for (int k = 0; k < 8; ++k) v[k] = acc1[t][8 * j + k];
-      bf16x8_t hb[3];
-      split3(v, hb[0], hb[1], hb[2]);
-      tiles<TP>(lds_base + sl * SLABB, acc2, hb);
-    });
-    // output tiles pass * TP .. + TP - 1 (the bias of the next tile is fetched ahead); staged through the ring slot that the
-    // pass's last step read (no DMA targets it until the next step's barrier)
-    {
-      constexpr int last_i = Q + pass * Q + Q - 1;
-      float* stg2 = reinterpret_cast<float*>(lds + (last_i % M6_RING) * SLABB) + wave * (32 * M6_STG_LD);
-      asm volatile("" ::: "memory");
-      __builtin_amdgcn_s_waitcnt(0xc07f);                    // lgkmcnt(0): own fragment reads done
-      __builtin_amdgcn_s_barrier();                          // every wave is past the slot's last fragment read
-      asm volatile("" ::: "memory");
-      const float* bsrc = p.bb ? p.bb + blk * N + 4 * g + 32 * pass * TP : nullptr;
-      float4 bn[4];
-#pragma unroll
-      for (int G = 0; G < 4; ++G) bn[G] = bsrc ? *reinterpret_cast<const float4*>(bsrc + 8 * G) : make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll
-      for (int m = 0; m < TP; ++m) {
-        float4 bc[4];
-#pragma unroll
-        for (int G = 0; G < 4; ++G) bc[G] = bn[G];
-        if (m + 1 < TP) {
-#pragma unroll
-          for (int G = 0; G < 4; ++G)
-            bn[G] = bsrc ? *reinterpret_cast<const float4*>(bsrc + 32 * (m + 1) + 8 * G) : make_float4(0.f, 0.f, 0.f, 0.f);
-        }
-        float yv[16];
-#pragma unroll
-        for (int G = 0; G < 4; ++G) {
-          yv[4 * G] = acc2[m][4 * G] + bc[G].x; yv[4 * G + 1] = acc2[m][4 * G + 1] + bc[G].y;
-          yv[4 * G + 2] = acc2[m][4 * G + 2] + bc[G].z; yv[4 * G + 3] = acc2[m][4 * G + 3] + bc[G].w;
-        }
-        if (st_ok || yv[0] == 1.2345e-30f)
-          stage_store(stg2, yv, p.Y + obase + 32 * (pass * TP + m), p.ldo, rows_ok, lane);
-      }
+  for (int k = 0; k < 4; ++k) planes_set(hq[0], k, acc1[0][2 * k], acc1[0][2 * k + 1]);
+  f32x16 acc2[TP];
+  sfor6<0, Q>([&](auto RR) __attribute__((always_inline)) {
+    constexpr int r = decltype(RR)::value;       // ring step Q + r
+    constexpr int i = Q + r;
+    asm volatile("" ::: "memory");
+    if constexpr (r >= 2) {                       // (steps 0 and 1: waited for above)
+      constexpr int VMW = i + 1 < T ? PER : 0;
+      __builtin_amdgcn_s_waitcnt((VMW & 15) | 0x70 | ((VMW >> 4) << 14));
     }
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    sfor6<0, PASSES>([&](auto JJ) __attribute__((always_inline)) {
+      constexpr int jj = decltype(JJ)::value;
+      constexpr int sj = r * PASSES + jj;         // job
+      constexpr int pass = sj / Q, q = sj % Q;
+      if constexpr (q == 0) {
+#pragma unroll
+        for (int m = 0; m < TP; ++m)
+#pragma unroll
+          for (int e = 0; e < 16; ++e) acc2[m][e] = 0.f;
+      }
+      constexpr int sn = sj + 1;                  // the job whose planes are split here
+      constexpr int tn = (sn % Q) >> 1, jn = (sn % Q) & 1;
+      const unsigned addr = lds_base + (i % M6_RING) * SLABB + jj * (TP * 3072);
+      bf16x8_t w[2][3];
+      lds_rd3<0>(w[0], addr);
+      sfor6<0, TP>([&](auto MM) __attribute__((always_inline)) {
+        constexpr int m = decltype(MM)::value;
+        if constexpr (m + 1 < TP) {
+          lds_rd3<(m + 1) * 3072>(w[(m + 1) & 1], addr);
+          lds_wait3<3>(w[m & 1]);
+        } else {
+          lds_wait3<0>(w[m & 1]);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        dma_piece(std::integral_constant<int, i + 2>{}, std::integral_constant<int, jj * TP + m>{});
+        if constexpr (sn < NJ2) {
+          // the four pairs of the next job's planes over this job's TP tile slots
+          constexpr int k0 = m * 4 / TP, k1 = (m + 1) * 4 / TP;
+#pragma unroll
+          for (int k = k0; k < k1; ++k)
+            planes_set(hq[sn & 1], k, acc1[tn][8 * jn + 2 * k], acc1[tn][8 * jn + 2 * k + 1]);
+        }
+        mma6p(acc2[m], w[m & 1], hq[sj & 1]);
+        interleave6();
+        __builtin_amdgcn_sched_barrier(0);
+      });
+      if constexpr (q == Q - 1) {
+        // output tiles pass * TP .. + TP - 1 (the bias of the next tile is fetched ahead); staged through the ring slot that
+        // this step read (no DMA targets it until the next step's barrier)
+        float* stg2 = reinterpret_cast<float*>(lds + (i % M6_RING) * SLABB) + wave * (32 * M6_STG_LD);
+        asm volatile("" ::: "memory");
+        __builtin_amdgcn_s_waitcnt(0xc07f);                  // lgkmcnt(0): own fragment reads done
+        __builtin_amdgcn_s_barrier();                        // every wave is past the slot's last fragment read
+        asm volatile("" ::: "memory");
+        const float* bsrc = p.bb ? p.bb + blk * N + 4 * g + 32 * pass * TP : nullptr;
+        float4 bn[4];
+#pragma unroll
+        for (int G = 0; G < 4; ++G) bn[G] = bsrc ? *reinterpret_cast<const float4*>(bsrc + 8 * G) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int m = 0; m < TP; ++m) {
+          float4 bc[4];
+#pragma unroll
+          for (int G = 0; G < 4; ++G) bc[G] = bn[G];
+          if (m + 1 < TP) {
+#pragma unroll
+            for (int G = 0; G < 4; ++G)
+              bn[G] = bsrc ? *reinterpret_cast<const float4*>(bsrc + 32 * (m + 1) + 8 * G) : make_float4(0.f, 0.f, 0.f, 0.f);
+          }
+          float yv[16];
+#pragma unroll
+          for (int G = 0; G < 4; ++G) {
+            yv[4 * G] = acc2[m][4 * G] + bc[G].x; yv[4 * G + 1] = acc2[m][4 * G + 1] + bc[G].y;
+            yv[4 * G + 2] = acc2[m][4 * G + 2] + bc[G].z; yv[4 * G + 3] = acc2[m][4 * G + 3] + bc[G].w;
+          }
+          if (st_ok || yv[0] == 1.2345e-30f)
+            stage_store(stg2, yv, p.Y + obase + 32 * (pass * TP + m), p.ldo, rows_ok, lane);
+        }
+      }
+    });
   });
 }
 
