@@ -15,6 +15,9 @@ LIB = os.path.join(LIBDIR, "libdpot_hip.so")
 SOURCES = ["core.hip", "gemm.hip", "gemm_panel.hip", "gemm_tn.hip", "gemm_bf16p.hip", "afno_mlp.hip", "afno_mlp6.hip", "afno_fused.hip", "dft.hip", "norm.hip", "gn_dft.hip", "misc.hip", "loss_opt.hip", "tail.hip", "data.hip", "embed.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function",
          "-Wno-pass-failed"]
+# per-source extras.  afno_mlp6: the operand split runs beside MFMAs, where the v_pk_add_f32 the SLP vectoriser forms out of
+# neighbouring subtractions are slower than the scalar instructions (MI355X_MICROARCH.md; measured -3 % on the launch)
+EXTRA_FLAGS = {"afno_mlp6.hip": ["-fno-slp-vectorize"]}
 
 
 def _hipcc() -> str:
@@ -41,7 +44,7 @@ def build(force: bool = False, verbose: bool = True) -> str:
         o = os.path.join(LIBDIR, src.replace(".hip", ".o"))
         objs.append(o)
         if force or _stale(o, [s] + hdrs):
-            jobs.append([hipcc] + FLAGS + ["-c", s, "-o", o])
+            jobs.append([hipcc] + FLAGS + EXTRA_FLAGS.get(src, []) + ["-c", s, "-o", o])
 
     def run(cmd):
         if verbose:
