@@ -379,6 +379,22 @@ def train_step(model: nn.Module, opt: FusedAdam, xx: Tensor, yy: Tensor, msk: Op
 
 
 # ------------------------------------------------------------------------------------------------------
+def _retire_collective_watchdog_work(seconds: float = 0.4) -> None:
+    """Before a capture that will contain collectives: let the process group's watchdog thread retire the work items of the
+    LIVE collectives issued so far (the eager warm-up).  torch's nccl backend keeps every eager collective on a list that its
+    watchdog polls (hipEventQuery on the collective's end event, every ~100 ms) until the event has completed; the capture then
+    pulls the backend's internal communication stream into capture mode, and HIP refuses a query of an event on a capturing
+    stream (hipErrorCapturedEvent) - the watchdog thread throws and the PROCESS aborts.  Seen once in ~10 runs of the one-rank
+    RCCL test (round 6).  With the device idle the watchdog needs one of its periods to drop the finished items; there is no
+    API to ask it, so: synchronise, then sleep a few periods.  (Inside the capture torch does not enqueue work items at all.)"""
+    import time
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()):
+        return
+    torch.cuda.synchronize()
+    time.sleep(seconds)
+
+
 class GraphedTrainStep:
     """Captures forward + loss + backward + clip + Adam of a fixed-shape batch into one hipGraph.
 
@@ -420,6 +436,8 @@ class GraphedTrainStep:
                 self._body(stage=True)
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
+        if self.reducer is not None:
+            _retire_collective_watchdog_work()
         opt.restore(snap)
         self.graph = torch.cuda.CUDAGraph()
         opt.zero_grad()

@@ -10,8 +10,8 @@ wc -c gpurun_out/${R}_final_bench.json; tail -c 1500 gpurun_out/${R}_final_bench
 grep -v "bench-full" gpurun_out/${R}_final_bench.err > gpurun_out/${R}_final_bench.err.txt; rm -f gpurun_out/${R}_final_bench.err
 bash scripts/gpu_prof.sh ${R}prof --no-other-configs --no-alt --no-pipeline > /dev/null 2>&1; mv gpurun_out/${R}prof.stats.txt gpurun_out/${R}_final_bench_kernel_stats.txt; rm -f gpurun_out/${R}prof.seq.txt gpurun_out/${R}prof.log; head -14 gpurun_out/${R}_final_bench_kernel_stats.txt
 bash scripts/gpu_census.sh > /dev/null 2>&1; mv gpurun_out/census.txt gpurun_out/${R}_final_census_T.txt
-for c in S M; do bash scripts/gpu_census_M.sh $c bf16 > /dev/null 2>&1; mv gpurun_out/census$c.txt gpurun_out/${R}_final_census_$c.txt; done
-CENSUS_BATCH=16 bash scripts/gpu_census_M.sh L bf16 > /dev/null 2>&1; mv gpurun_out/censusL.txt gpurun_out/${R}_final_census_L.txt
+for c in S M; do CENSUS_GEMM=auto bash scripts/gpu_census_M.sh $c bf16 > /dev/null 2>&1; mv gpurun_out/census$c.txt gpurun_out/${R}_final_census_$c.txt; done
+CENSUS_GEMM=auto CENSUS_BATCH=16 bash scripts/gpu_census_M.sh L bf16 > /dev/null 2>&1; mv gpurun_out/censusL.txt gpurun_out/${R}_final_census_L.txt
 head -12 gpurun_out/${R}_final_census_M.txt
 DPOT_BENCH_DEBUG_GLOO=1 timeout 600 python bench.py --gpus 2 --steps 5 --warmup 2 2> gpurun_out/${R}_final_gloo2_T.err | grep "^{" | tail -1 > gpurun_out/${R}_final_gloo2_T.json; tail -c 900 gpurun_out/${R}_final_gloo2_T.json; grep -v "bench-full" gpurun_out/${R}_final_gloo2_T.err | tail -3
 rm -f gpurun_out/*.log
