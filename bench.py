@@ -159,7 +159,24 @@ def mixer_roofline(model, B: int):
         b2 = torch.randn(nb, N, device="cuda") * 0.1
 
         three = fused and ops.afno_mlp3_supported(nb, bs)
-        if three:
+        # round 6: under gemm_precision 'auto' / 'bf16x6' the model runs the mixer MLP as bf16x6 on the bf16 matrix cores where
+        # that measured faster (csrc/afno_mlp6.hip, 96 channels per block: DPOT-L) - time what the model runs
+        six = False
+        if fused and getattr(model, "gemm_precision", None) in ("auto", "bf16x6"):
+            with ops.precision_scope(model.gemm_precision, None):
+                six = ops.afno_mlp6_supported(nb, bs) and ops.afno_mlp6_wanted()
+                if six:
+                    wc1 = torch.randn(2, nb, bs, bs, device="cuda") * 0.05
+                    wc2 = torch.randn(2, nb, bs, bs, device="cuda") * 0.05
+                    bc1 = torch.randn(2, nb, bs, device="cuda") * 0.1
+                    bc2 = torch.randn(2, nb, bs, device="cuda") * 0.1
+                    it1, it2 = ops.AfnoPacks([(wc1, bc1), (wc2, bc2)]).refresh()
+                    six = it1.p6 is not None
+                    if six:
+                        b1, W1f, b2, W2f, three = it1[1], it1.p6[0], it2[1], it2.p6[0], False
+        if six:
+            pass
+        elif three:
             # the three-product kernel takes the (Wr, Wi) fragment packs that the model's AfnoPacks writes
             wc1 = torch.randn(2, nb, bs, bs, device="cuda") * 0.05
             wc2 = torch.randn(2, nb, bs, bs, device="cuda") * 0.05
@@ -175,7 +192,7 @@ def mixer_roofline(model, B: int):
             if fused:
                 # training form (round 3): only the pre-activation is saved; the backward launch re-derives act(pre)
                 return ops.afno_mlp2(S, W1f, b1, W2f, b2, nb, bs, 1, mode=0, want_pre=train, want_mid=False,
-                                     layout=1 if three else 0)
+                                     layout=2 if six else 1 if three else 0)
             O1, O1pre, O2 = torch.empty_like(S), torch.empty_like(S), torch.empty_like(S)
             kw = dict(lda=2 * E, ldb=N, ldc=2 * E, batch=nb, strideA=N, strideB=N * N, strideC=N, strideBias=N, tag=1)
             ops.gemm(S, W1, O1, Mm, N, N, bias=b1, act=1, mode=ops.EPI_ACT, preact=O1pre, ldpre=2 * E, stridePre=N, **kw)
@@ -219,6 +236,26 @@ def mixer_roofline(model, B: int):
         mfma_util = (pmc.get("tiny-train") or {}).get("mfma_util")
     except Exception:
         pass
+    if six:
+        return {
+            "kernel": ("dpot::afno_mlp6_kernel<NT,PASSES> (AFNO mixer under gemm_precision auto: BOTH layers of the block-diagonal "
+                       "complex MLP in one launch as bf16x6 - three bf16 planes per operand, six plane products on "
+                       "v_mfma_f32_32x32x16_bf16, fp32-accurate; hidden layer kept in registers)"),
+            "executed_flops_per_launch": flops * 6.0,
+            "flops_note": "flops_per_launch / achieved / frac count the ALGORITHMIC fp32 work (SURVEY 8d); the kernel executes six "
+                          "bf16 plane products per fp32 product: its roof is 2500 / 6 = 416.7 TFLOP/s of fp32-accurate work; `peak` "
+                          "stays the fp32-MFMA 157.3 TFLOP/s the fp32 kernels are priced against, `frac_of_bf16x6_roof` prices "
+                          "against its own",
+            "bound": "mfma", "achieved": round(achieved, 2), "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+            "frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4), "frac_of_bf16x6_roof": round(achieved / (2500.0 / 6.0), 4),
+            "traffic": None, "mfma_util_pmc": 0.511 if (nb, bs, Mm) == (16, 96, 8704) else None,
+            "traffic_note": "profiles/r06_pmc_mlp6.json (DPOT-L batch 16: 388 MB against 328 MB algorithmic)",
+            "us_per_launch": round(t * 1e6, 2), "flops_per_launch": flops, "algorithmic_bytes_per_launch": bytes_alg,
+            "hbm_frac": round(bytes_alg / t / 1e9 / HBM_PEAK_GBS, 4),
+            "inference_form": {"us_per_launch": round(t_inf * 1e6, 2), "achieved": round(flops / t_inf / 1e12, 2),
+                               "frac": round(flops / t_inf / 1e12 / FP32_MFMA_PEAK_TFLOPS, 4)},
+            "other_kernels": other_rooflines(model, B, timeit_graph),
+        }
     return {
         "kernel": ("dpot::afno_mlp3_kernel<RT> (AFNO mixer: BOTH layers of the block-diagonal complex MLP in one launch, "
                    "each complex product as THREE real ones - P1 = Sr Wr, P2 = Si Wi, P3 = (Sr+Si)(Wr+Wi) - on "
