@@ -50,7 +50,7 @@ struct AfnoMlp6Args {
 // x = a + b + c, three bf16 planes (round to nearest even each; the remainders are exact in fp32)
 __device__ __forceinline__ void split3(const float* v, bf16x8_t& a, bf16x8_t& b, bf16x8_t& c) {
   u32x4_t ua, ub, uc;
-#ifdef M6_ABL_NOSPLIT
+#ifdef M6_ABL_NOSPLIT   // (ablation builds, scripts/variant.sh afno_mlp6 NAME -DM6_ABL_...: NOSPLIT, DMA1, NOSTORE - results are wrong)
   for (int k = 0; k < 4; ++k) { ua[k] = __float_as_uint(v[k]); ub[k] = __float_as_uint(v[k + 4]); uc[k] = ua[k] ^ ub[k]; }
   a = __builtin_bit_cast(bf16x8_t, ua); b = __builtin_bit_cast(bf16x8_t, ub); c = __builtin_bit_cast(bf16x8_t, uc);
   return;
@@ -75,27 +75,6 @@ __device__ __forceinline__ void split3(const float* v, bf16x8_t& a, bf16x8_t& b,
 
 // the six plane products of one 32 x 32 x 16 step, smallest terms first
 __device__ __forceinline__ void mma6(f32x16& acc, const bf16x8_t* w, const bf16x8_t* x) {
-#ifdef M6_SPLITACC
-  // (experiment: two independent accumulation chains per tile job)
-  f32x16 t;
-#pragma unroll
-  for (int r = 0; r < 16; ++r) t[r] = 0.f;
-  t = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w[0], x[2], t, 0, 0, 0);
-  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w[0], x[0], acc, 0, 0, 0);
-  t = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w[2], x[0], t, 0, 0, 0);
-  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w[0], x[1], acc, 0, 0, 0);
-  t = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w[1], x[1], t, 0, 0, 0);
-  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w[1], x[0], acc, 0, 0, 0);
-#pragma unroll
-  for (int r = 0; r < 16; ++r) acc[r] += t[r];
-  return;
-#endif
-#ifdef M6_ABL_NOMFMA
-  acc[0] += __builtin_bit_cast(u32x4_t, w[0])[0] * 1e-30f + __builtin_bit_cast(u32x4_t, w[1])[0] * 1e-30f +
-            __builtin_bit_cast(u32x4_t, w[2])[0] * 1e-30f + __builtin_bit_cast(u32x4_t, x[0])[0] * 1e-30f +
-            __builtin_bit_cast(u32x4_t, x[1])[0] * 1e-30f + __builtin_bit_cast(u32x4_t, x[2])[0] * 1e-30f;
-  return;
-#endif
   acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w[0], x[2], acc, 0, 0, 0);
   acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w[2], x[0], acc, 0, 0, 0);
   acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w[1], x[1], acc, 0, 0, 0);
@@ -493,7 +472,7 @@ __global__ __launch_bounds__(256, WPE) void afno_mlp6_kernel(const AfnoMlp6Args 
             yv[4 * G] = acc2[m][4 * G] + bc[G].x; yv[4 * G + 1] = acc2[m][4 * G + 1] + bc[G].y;
             yv[4 * G + 2] = acc2[m][4 * G + 2] + bc[G].z; yv[4 * G + 3] = acc2[m][4 * G + 3] + bc[G].w;
           }
-          if (st_ok || yv[0] == 1.2345e-30f)
+          if (st_ok)
             stage_store(stg2, yv, p.Y + obase + 32 * (pass * TP + m), p.ldo, rows_ok, lane);
         }
       }
