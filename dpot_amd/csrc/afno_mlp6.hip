@@ -24,8 +24,10 @@
 //   * the weight fragments of a 16-k sub-slab (N / 32 tiles x 3 planes x 1 KiB) travel global -> LDS by LDS-DMA into a ring
 //     of three slots shared by the four waves of a workgroup (128 rows); one barrier per sub-slab; fragment reads are
 //     lane-linear ds_read_b128 (conflict-free).  Per sub-slab and wave: N / 32 x 3 fragment reads feed N / 32 x 6 MFMAs.
-//   * N = 256 (DPOT-Ti / -S / -M): the second layer runs in two passes of four output tiles (accumulators: 128 hidden + 64)
-//     so that two workgroups share a CU (<= 256 VGPRs); N = 192 (DPOT-L): one pass (96 + 96).
+//   * N = 192 (DPOT-L): accumulators 96 (hidden) + 96, 226-232 VGPRs, two workgroups per CU.  N = 256 (DPOT-Ti / -S / -M, opt-in
+//     DPOT_TUNE mixer6=2): 128 + 128 accumulators, one workgroup per CU at one wave per SIMD (186 VGPRs + 128 AGPRs; the two-pass
+//     form that fits 256 registers spills 70 of them and is no faster) - no gain over the fp32 kernels there: 144 / 288
+//     workgroups of 128 rows on 256 CUs.
 #include <type_traits>
 
 #include "common.h"
@@ -569,6 +571,6 @@ extern "C" int dpot_afno_mlp6(const float* X, const void* Wa6, const float* ba, 
   p.ba = ba; p.bb = bb; p.aux = aux; p.pre = pre; p.mid = mid; p.Y = Y;
   p.ldx = ldx; p.ldo = ldo; p.M = M; p.nb = nb; p.act = act; p.mode = mode;
   hipStream_t s = as_stream(stream);
-  if (bs == 128) return launch6<8, 2, 2>(p, s);
+  if (bs == 128) return launch6<8, 1, 1>(p, s);
   return launch6<6, 1, 2>(p, s);
 }
