@@ -837,6 +837,46 @@ def test_bf16_mlp_pack_both_path_matches_separate_packs(ops, monkeypatch):
         assert err <= 8e-3, (n, err)
 
 
+@pytest.mark.parametrize("bs", [96, 128])
+def test_bf16x6_mixer_in_the_model_with_recomputation(ops, monkeypatch, bs):
+    """round 6: a 32 x 32-grid model (the DPOT-L form of the Block: chunked GroupNorm statistics, rfft2 / irfft2 with GroupNorm
+    on load) with 96 / 128 channels per block under gemm_precision 'auto' runs its mixer MLP on the bf16x6 kernel
+    (csrc/afno_mlp6.hip) forward AND backward: (a) prediction and every gradient agree with the native-fp32 run to fp32
+    rounding; (b) activation recomputation (what `bench.py --config L20` runs: the packs travel through the autograd context)
+    reproduces the stored-activation run BIT FOR BIT; (c) the kernel really ran"""
+    from dpot_amd import DPOTNet
+    set_tune(monkeypatch, mixer6=2)
+    kw = dict(R.MINI, img_size=256, patch_size=8, embed_dim=2 * bs, out_layer_dim=32, depth=2, mlp_ratio=1, n_blocks=2, modes=32)
+    cfg = R.DPOTConfig(**kw)
+    x = R.recipe_input((2, cfg.img_size, cfg.img_size, cfg.in_timesteps, cfg.in_channels), salt=9).cuda()
+    calls = []
+    real = ops.afno_mlp2
+    monkeypatch.setattr(ops, "afno_mlp2", lambda *a, **k: (calls.append(k.get("layout")), real(*a, **k))[1])
+
+    def run(prec, recompute=False):
+        m = DPOTNet(**kw).cuda()
+        m.load_state_dict(R.recipe_state_dict(cfg, salt=4))
+        m.gemm_precision = prec
+        m.recompute_blocks = recompute
+        del calls[:]
+        y, _ = m(x)
+        (y ** 2).sum().backward()
+        return y.detach(), {n: p.grad.clone() for n, p in m.named_parameters() if p.grad is not None}, list(calls)
+
+    y0, g0, c0 = run("f32")
+    y1, g1, c1 = run("auto")
+    y2, g2, c2 = run("auto", True)
+    assert c0 and all(l != 2 for l in c0)
+    assert c1 and all(l == 2 for l in c1), c1                            # forward and backward-data launches of both Blocks
+    assert len(c2) > len(c1) and all(l == 2 for l in c2)                 # + the recomputed forwards
+    assert_close(y1, y0.cpu(), "pred auto vs f32")
+    for n in g0:
+        assert_close(g1[n], g0[n].cpu(), f"grad {n} auto vs f32")
+    assert torch.equal(y1, y2)
+    for n in g1:
+        assert torch.equal(g1[n], g2[n]), n                              # recomputation: same kernels, same bits
+
+
 def _unpack_rows(pk, M, N):
     """row-form pack [M/32][N/16][64 chunks][8 bf16] (chunk l = row l & 31, columns 8 * (l >> 5) .. + 7) -> [M, N] fp32"""
     t = pk.view(M // 32, N // 16, 2, 32, 8).float()                       # [rt, kb, half, row, 8]
