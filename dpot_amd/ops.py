@@ -705,20 +705,23 @@ class AfnoPacks:
         self.table = torch.from_numpy(host).to(dev)
         # bf16x6 packs (csrc/afno_mlp6.hip): items alternate (first-layer weight, second-layer weight) - pairs of a filter
         self.wbig = wbig
-        self.fwd6 = self.bwd6 = None
-        if fused and n % 2 == 0 and afno_mlp6_supported(nb, bs):
-            ne = int(_lib.load().dpot_afno_pack6_elems(nb, bs))
-            self.fwd6 = torch.empty(n, ne, dtype=torch.int16, device=dev)
-            self.bwd6 = torch.empty(n, ne, dtype=torch.int16, device=dev)
-        self.items = [AfnoItem((wbig[i], bbig[i], fwd[i] if fused else None, bwd[i] if fused else None), self.layout,
-                               (self.fwd6[i], self.bwd6[i]) if self.fwd6 is not None else None)
-                      for i in range(n)]
+        self.fwd6 = self.bwd6 = None               # allocated by the first refresh that wants them (3 bytes per weight element
+        self._p6_ok = fused and n % 2 == 0 and afno_mlp6_supported(nb, bs)   # each: nothing for a model that stays in 'f32')
+        self._fused = fused
+        self._base = [(wbig[i], bbig[i], fwd[i] if fused else None, bwd[i] if fused else None) for i in range(n)]
+        self.items = [AfnoItem(t, self.layout, None) for t in self._base]
 
     def refresh(self):
         lib = _lib.load()
         check(lib.dpot_afno_pack_all(self.table.data_ptr(), self.n, self.nb, self.bs, self.layout, _stream()),
               "afno_pack_all")
-        if self.fwd6 is not None and afno_mlp6_wanted():
+        if self._p6_ok and afno_mlp6_wanted():
+            if self.fwd6 is None:
+                ne = int(lib.dpot_afno_pack6_elems(self.nb, self.bs))
+                dev = self.wbig.device
+                self.fwd6 = torch.empty(self.n, ne, dtype=torch.int16, device=dev)
+                self.bwd6 = torch.empty(self.n, ne, dtype=torch.int16, device=dev)
+                self.items = [AfnoItem(t, self.layout, (self.fwd6[i], self.bwd6[i])) for i, t in enumerate(self._base)]
             check(lib.dpot_afno_pack6(self.wbig.data_ptr(), self.fwd6.data_ptr(), self.bwd6.data_ptr(), self.n, self.nb,
                                       self.bs, _stream()), "afno_pack6")
         return self.items
